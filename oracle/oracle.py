@@ -1,0 +1,192 @@
+"""ctypes/numpy front end of oracle/liboracle.so (the C restatement in sf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Each wrapper names the reference function it restates (file:line under /root/reference).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref/ when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "sf_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    elif os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(_HERE, "_ref", "libxxhash_ref.so")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return so
+
+
+class EMStats(C.Structure):
+    _fields_ = [("iters", C.c_uint32), ("converged", C.c_uint32), ("max_rel_diff", C.c_double),
+                ("alpha_sum", C.c_double), ("n_active", C.c_uint64)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.sfo_xxh64.restype = C.c_uint64
+        L.sfo_xxh64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.sfo_digamma.restype = C.c_double
+        L.sfo_digamma.argtypes = [C.c_double]
+        L.sfo_eq_create.restype = C.c_void_p
+        L.sfo_eq_destroy.argtypes = [C.c_void_p]
+        L.sfo_eq_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.sfo_eq_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sfo_eq_export.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.sfo_xxh64_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.sfo_cf_gaussian.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.sfo_fld_gaussian_counts.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p]
+        L.sfo_cf_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.sfo_efflen_smoothed.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.sfo_em_optimize.restype = C.c_int
+        L.sfo_em_optimize.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_int, C.c_double, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sfo_tpm.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.sfo_bootstrap.restype = C.c_int
+        L.sfo_bootstrap.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_double, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.sfo_gibbs.restype = C.c_int
+        L.sfo_gibbs.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def xxh64(data: bytes, seed=0) -> int:
+    """XXH64 (src/xxhash.c:346-455)."""
+    buf = C.create_string_buffer(data, len(data))
+    return int(lib().sfo_xxh64(C.cast(buf, C.c_void_p), len(data), seed))
+
+
+def xxh64_lists(ids, off):
+    """TranscriptGroup hash of each packed label (src/TranscriptGroup.cpp:9-12)."""
+    ids = _c(ids, np.uint32); off = _c(off, np.uint64)
+    out = np.empty(len(off) - 1, np.uint64)
+    lib().sfo_xxh64_lists(_p(ids), _p(off), len(off) - 1, _p(out))
+    return out
+
+
+def digamma(x):
+    return float(lib().sfo_digamma(float(x)))
+
+
+class EqBuilder:
+    """EquivalenceClassBuilder restated (include/EquivalenceClassBuilder.hpp:62-112)."""
+
+    def __init__(self):
+        self._h = lib().sfo_eq_create()
+
+    def add_batch(self, ids, off):
+        ids = _c(ids, np.uint32); off = _c(off, np.uint64)
+        if len(ids) == 0:
+            ids = np.zeros(1, np.uint32)
+        lib().sfo_eq_add(self._h, _p(ids), _p(off), len(off) - 1)
+
+    def finish(self):
+        n = C.c_uint64(); nnz = C.c_uint64(); tot = C.c_uint64()
+        lib().sfo_eq_finish(self._h, C.byref(n), C.byref(nnz), C.byref(tot))
+        self.n_classes, self.nnz, self.total_reads = n.value, nnz.value, tot.value
+        rowptr = np.zeros(n.value + 1, np.uint64); ids = np.zeros(max(nnz.value, 1), np.uint32)
+        counts = np.zeros(max(n.value, 1), np.uint64); hashes = np.zeros(max(n.value, 1), np.uint64)
+        lib().sfo_eq_export(self._h, _p(rowptr), _p(ids), _p(counts), _p(hashes))
+        return rowptr, ids[:nnz.value], counts[:n.value], hashes[:n.value]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sfo_eq_destroy(self._h); self._h = None
+
+
+def cf_gaussian(max_frag_len=1000, mean=200, sd=80):
+    """getNormalFragLengthDist (src/SailfishQuantify.cpp:648-673)."""
+    cf = np.zeros(max_frag_len); lib().sfo_cf_gaussian(max_frag_len, mean, sd, _p(cf)); return cf
+
+
+def fld_gaussian_counts(max_frag_len=1000, mean=200, sd=80, num_samples=10000):
+    """getNormalFragLengthCounts (src/SailfishQuantify.cpp:675-704)."""
+    d = np.zeros(max_frag_len, np.int32)
+    lib().sfo_fld_gaussian_counts(max_frag_len, mean, sd, num_samples, _p(d)); return d
+
+
+def cf_counts(fl_counts):
+    """correctionFactorsFromCounts (src/SailfishQuantify.cpp:769-807)."""
+    fl = _c(fl_counts, np.uint32); cf = np.zeros(len(fl))
+    lib().sfo_cf_counts(_p(fl), len(fl), _p(cf)); return cf
+
+
+def efflen_smoothed(ref_len, cf):
+    """computeSmoothedEffectiveLengths (src/SailfishQuantify.cpp:809-838)."""
+    rl = _c(ref_len, np.uint32); cf = _c(cf, np.float64); eff = np.zeros(len(rl))
+    lib().sfo_efflen_smoothed(_p(rl), len(rl), _p(cf), len(cf), _p(eff)); return eff
+
+
+def em_optimize(eff_len, rowptr, ids, counts, num_mapped, use_vbem=False, tol=0.01,
+                min_iter=50, max_iter=10000, check_mode=0):
+    """CollapsedEMOptimizer::optimize (src/CollapsedEMOptimizer.cpp:711-893).
+    Returns (rc, alpha, mass, stats-dict)."""
+    eff = _c(eff_len, np.float64); rp = _c(rowptr, np.uint64); ii = _c(ids, np.uint32); cc = _c(counts, np.uint64)
+    if len(ii) == 0:
+        ii = np.zeros(1, np.uint32)
+    if len(cc) == 0:
+        cc = np.zeros(1, np.uint64)
+    M = len(eff); alpha = np.zeros(max(M, 1)); mass = np.zeros(max(M, 1)); st = EMStats()
+    rc = lib().sfo_em_optimize(M, _p(eff), len(rp) - 1, _p(rp), _p(ii), _p(cc), int(num_mapped), int(use_vbem),
+                               float(tol), int(min_iter), int(max_iter), int(check_mode),
+                               _p(alpha), _p(mass), C.byref(st))
+    stats = dict(iters=st.iters, converged=bool(st.converged), max_rel_diff=st.max_rel_diff,
+                 alpha_sum=st.alpha_sum, n_active=st.n_active)
+    return rc, alpha[:M], mass[:M], stats
+
+
+def tpm(est_count, length, num_mapped):
+    """TPM column of quant.sf (src/GZipWriter.cpp:216-245)."""
+    a = _c(est_count, np.float64); l = _c(length, np.float64); out = np.zeros(len(a))
+    lib().sfo_tpm(len(a), _p(a), _p(l), float(num_mapped), _p(out)); return out
+
+
+def bootstrap(eff_len, rowptr, ids, counts, B, use_vbem=False, tol=0.01, max_iter=10000, seed=1):
+    """gatherBootstraps/doBootstrap (src/CollapsedEMOptimizer.cpp:438-525, 557-709). -> (B, M)"""
+    eff = _c(eff_len, np.float64); rp = _c(rowptr, np.uint64); ii = _c(ids, np.uint32); cc = _c(counts, np.uint64)
+    out = np.zeros((B, len(eff))); iters = np.zeros(B, np.uint32)
+    rc = lib().sfo_bootstrap(len(eff), _p(eff), len(rp) - 1, _p(rp), _p(ii), _p(cc), int(use_vbem), float(tol),
+                             int(max_iter), int(B), int(seed), _p(out), _p(iters))
+    return rc, out, iters
+
+
+def gibbs(eff_len, mass, rowptr, ids, counts, num_mapped, S, seed=1):
+    """CollapsedGibbsSampler::sample, one chain (src/CollapsedGibbsSampler.cpp:198-291). -> (S, M) int32"""
+    eff = _c(eff_len, np.float64); ms = _c(mass, np.float64)
+    rp = _c(rowptr, np.uint64); ii = _c(ids, np.uint32); cc = _c(counts, np.uint64)
+    out = np.zeros((S, len(eff)), np.int32)
+    rc = lib().sfo_gibbs(len(eff), _p(eff), _p(ms), len(rp) - 1, _p(rp), _p(ii), _p(cc), int(num_mapped), int(S),
+                         int(seed), _p(out))
+    return rc, out
+
+
+# --- the compiled reference (oracle/_ref), when present -------------------------------------
+def ref_xxhash():
+    """ctypes handle on the reference's own xxhash.c (oracle/_ref/libxxhash_ref.so) or None."""
+    so = os.path.join(_HERE, "_ref", "libxxhash_ref.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.XXH64.restype = C.c_uint64
+    L.XXH64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    return L
