@@ -1,0 +1,178 @@
+/*
+ * sfgpu.h -- C ABI of the MI355X-native Sailfish quantification core (libsfgpu.so).
+ *
+ * This is the drop-in boundary behind Sailfish's C++ host code: every entry point replaces one
+ * seam of the reference (file:line under the reference tree given next to each declaration;
+ * INTEGRATION.md shows the adaptor a maintainer would compile into `sailfish quant`).
+ *
+ * Conventions
+ *   - plain C: opaque handles, plain pointers and sizes, int error codes, no exceptions.
+ *   - pointers named d_* are DEVICE pointers (HBM of the current HIP device), h_* are HOST
+ *     pointers.  All buffers are caller-owned; handles own only their internal scratch.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the HIP default stream).  Work is
+ *     enqueued on that stream; functions documented as "synchronous" wait for it.
+ *   - errors: 0 = ok, otherwise an SFGPU_ERR_* code; sfgpu_last_error() gives the text
+ *     (thread-local).  Nothing here ever falls back to a CPU implementation: without a usable
+ *     gfx950 device every compute entry point returns SFGPU_ERR_HIP.
+ */
+#ifndef SFGPU_H
+#define SFGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFGPU_VERSION 100 /* 0.1.0 */
+#define SFGPU_API __attribute__((visibility("default")))
+
+enum {
+    SFGPU_OK = 0,
+    SFGPU_ERR_INVALID = 1,   /* bad argument */
+    SFGPU_ERR_HIP = 2,       /* HIP runtime / device failure */
+    SFGPU_ERR_NO_ACTIVE = 3, /* "no transcripts expressed" -- optimize() returns false,
+                                src/CollapsedEMOptimizer.cpp:794-798 */
+    SFGPU_ERR_ALPHA_SUM = 4, /* "total alpha weight was too small" -- :877-881 */
+    SFGPU_ERR_RANGE = 5,     /* a size exceeds what the device layout holds (see each call) */
+    SFGPU_ERR_STATE = 6      /* call order violated (e.g. export before finish) */
+};
+
+typedef void* sfgpu_stream;          /* hipStream_t */
+typedef struct sfgpu_eq sfgpu_eq;    /* EquivalenceClassBuilder on the device */
+typedef struct sfgpu_em sfgpu_em;    /* CollapsedEMOptimizer state on the device */
+
+SFGPU_API int sfgpu_version(void);
+SFGPU_API const char* sfgpu_last_error(void);
+/* Forwarded to sopt.jointLog by the adaptor (level: 0 info, 1 warn, 2 error).  NULL = silent. */
+SFGPU_API void sfgpu_set_logger(void (*log)(int level, const char* msg));
+/* Device name / CU count / HBM bytes of the current device (any pointer may be NULL). */
+SFGPU_API int sfgpu_device_info(char* name, int name_len, int* n_cu, uint64_t* hbm_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1. TranscriptGroup hash: XXH64(label bytes, 4*n, seed 0)
+ *     replaces: TranscriptGroup::TranscriptGroup(std::vector<uint32_t>)  src/TranscriptGroup.cpp:9-12
+ *               XXH64                                                    src/xxhash.c:346-455, 458-484
+ * Packed batch: label r = d_ids[d_offsets[r] .. d_offsets[r+1]).  Asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------- */
+SFGPU_API int sfgpu_xxh64_labels(const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads,
+                       uint64_t* d_hashes, sfgpu_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2-a5. EquivalenceClassBuilder   include/EquivalenceClassBuilder.hpp:53-119
+ * ------------------------------------------------------------------------------------------- */
+/* ctor: reserves room for `expected_classes` (the reference reserves 1e6, :57). 0 = default. */
+SFGPU_API int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stream);
+SFGPU_API int sfgpu_eq_destroy(sfgpu_eq* eq);
+/* start() :62 -- also clears any previous contents so a builder can be reused. */
+SFGPU_API int sfgpu_eq_start(sfgpu_eq* eq);
+/* addGroup() :90-108, batched: one call carries the hit lists of many reads (the reference's
+ * unit is the <=1000-read parser job, src/SailfishQuantify.cpp:73,399-416,608-625).
+ * label r = ids[offsets[r] .. offsets[r+1]); the ORDERED list is the key (equality ==
+ * vector equality, src/TranscriptGroup.cpp:53-55); empty lists are skipped like the call
+ * site's `if (txpIDs.size() > 0)` guard.  Thread-safe (calls are serialised per builder).
+ * offsets are uint32: one batch holds < 2^32 ids and < 2^31 reads (else SFGPU_ERR_RANGE).
+ * _host copies the batch to the device first; _device reads device-resident batches.
+ * Both return after the batch has been folded in (the caller may reuse its buffers). */
+SFGPU_API int sfgpu_eq_add_batch_host(sfgpu_eq* eq, const uint32_t* h_ids, const uint32_t* h_offsets, uint32_t n_reads);
+SFGPU_API int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads);
+/* finish() :64-80: snapshot into the canonical class order (first id, XXH64, length, label --
+ * the reference's order is hash-table order and run dependent).  Reports what the reference
+ * logs: #classes and sum(count); nnz = sum of label lengths. Synchronous. */
+SFGPU_API int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* total_reads);
+/* eqVec() :110-112 as CSR: rowptr[C+1], ids[nnz], counts[C] (uint64 like TGValue::count),
+ * hashes[C] (TranscriptGroup::hash; may be NULL).  nnz must be < 2^32 (SFGPU_ERR_RANGE).
+ * _device is asynchronous on the builder's stream; _host is synchronous. */
+SFGPU_API int sfgpu_eq_export_device(sfgpu_eq* eq, uint32_t* d_rowptr, uint32_t* d_ids, uint64_t* d_counts, uint64_t* d_hashes);
+SFGPU_API int sfgpu_eq_export_host(sfgpu_eq* eq, uint32_t* h_rowptr, uint32_t* h_ids, uint64_t* h_counts, uint64_t* h_hashes);
+
+/* ---------------------------------------------------------------------------------------------
+ * a14. fragment-length distribution -> effective lengths   src/SailfishQuantify.cpp
+ * The 1000-entry correction tables are serial prefix sums and are built on the host in the
+ * reference's evaluation order; the O(M) transform runs on the device.
+ * ------------------------------------------------------------------------------------------- */
+/* getNormalFragLengthDist :648-673 (mean/sd are integers in SailfishOpts.hpp:34-35) */
+SFGPU_API int sfgpu_cf_gaussian(uint32_t max_frag_len, uint64_t mean, uint64_t sd, double* h_cf);
+/* correctionFactorsFromCounts :769-807 */
+SFGPU_API int sfgpu_cf_counts(const uint32_t* h_fl_counts, uint32_t max_frag_len, double* h_cf);
+/* computeSmoothedEffectiveLengths :809-838 ; setEffectiveLengthsDirect :706-715 when h_cf == NULL */
+SFGPU_API int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h_cf, uint32_t max_frag_len,
+                          double* d_eff_len, sfgpu_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6-a12. CollapsedEMOptimizer   src/CollapsedEMOptimizer.cpp:711-893
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t M;               /* transcripts() .size() */
+    const double* d_len;      /* per transcript: RefLength if noEffectiveLengthCorrection else
+                                 EffectiveLength (:736-737); clamped to >= 1 internally (:738) */
+    uint64_t C;               /* eqVec().size() */
+    const uint32_t* d_rowptr; /* C+1 */
+    const uint32_t* d_ids;    /* rowptr[C] */
+    const uint64_t* d_counts; /* C; every count must be < 2^32 (SFGPU_ERR_RANGE) */
+    uint64_t num_mapped;      /* ReadExperiment::numMappedFragments() (:792) */
+} sfgpu_problem;
+
+typedef struct {
+    int use_vbem;             /* sopt.useVBOpt (:784) */
+    double tol;               /* relDiffTolerance: 0.01 at the call site, src/SailfishQuantify.cpp:1343 */
+    uint32_t min_iter;        /* 50 in optimize() (:716); 0 in doBootstrap (:486) */
+    uint32_t max_iter;        /* 10000 at the call site */
+    int check_mode;           /* 0: gate on alphasPrime > 1e-2 (:852); 1: on alphas > 1e-2 (:499) */
+    uint32_t iters_per_launch;/* iterations enqueued between host polls of the device-side stop
+                                 latch (the stop iteration is exact regardless). 0 = default (32) */
+} sfgpu_em_opts;
+
+typedef struct {
+    uint32_t iters;           /* itNum when the loop stopped */
+    uint32_t converged;
+    double max_rel_diff;      /* as logged at :871-872 */
+    double alpha_sum;         /* after truncateCountVector (:875) */
+    uint64_t n_active;        /* activeTranscriptIDs.size() (:774-782) */
+    double loop_ms;           /* device time of the iteration loop (HIP events on `stream`) */
+} sfgpu_em_stats;
+
+SFGPU_API int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stream);
+SFGPU_API int sfgpu_em_destroy(sfgpu_em* em);
+/* optimize() :711-893 without the bias branch: writes estCount (alpha after truncation) to
+ * d_alpha_out[M] and, if non-NULL, mass = alpha/alphaSum to d_mass_out[M].  Synchronous.
+ * Returns SFGPU_ERR_NO_ACTIVE / SFGPU_ERR_ALPHA_SUM where the reference returns false. */
+SFGPU_API int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
+                      sfgpu_em_stats* stats);
+
+/* The same loop in pieces, for callers that own the iteration (multi-GPU: classes sharded over
+ * ranks, alphaOut all-reduced between sweep and update).  All asynchronous on the stream.
+ *   begin : zero alphaOut, then alphaOut[t] = 1 for every transcript in a local class (:774-782)
+ *           -> caller may SUM-all-reduce alphaOut across ranks
+ *   init  : n_active = #(alphaOut > 0); alpha = active ? numMapped/n_active : 0 (:800-803); it = 0
+ *   sweep : alphaOut += E-step contributions of the local classes (EMUpdate_ :224-281 /
+ *           VBEMUpdate_ :322-367); no-op once the stop latch is set
+ *           -> caller may SUM-all-reduce alphaOut across ranks
+ *   update: [VBEM: alphaOut += prior] convergence test + alpha <- alphaOut, alphaOut <- 0
+ *           (:849-861), ++it, evaluates the loop condition of :820 into the stop latch
+ *   poll  : synchronous; reads the latch and counters
+ *   finish: truncate (:875), alphaSum, write outputs; synchronous */
+SFGPU_API int sfgpu_em_begin(sfgpu_em* em, const sfgpu_em_opts* opts);
+SFGPU_API int sfgpu_em_init(sfgpu_em* em);
+SFGPU_API int sfgpu_em_sweep(sfgpu_em* em);
+SFGPU_API int sfgpu_em_update(sfgpu_em* em);
+SFGPU_API int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats);
+SFGPU_API int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats);
+/* device pointer of alphaOut (M doubles) for the caller's collective */
+SFGPU_API double* sfgpu_em_alpha_out(sfgpu_em* em);
+/* Launch the E-step sweep kernel `n` times back to back (state untouched afterwards) and
+ * return its average duration from HIP events on the stream: the live roofline measurement. */
+SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n, double* avg_ms);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13. quant.sf columns   src/GZipWriter.cpp:216-245
+ *   TPM_t = ((estCount_t/numMapped)/len_t) / sum_u((estCount_u/numMapped)/len_u) * 1e6
+ * d_len as in sfgpu_problem.  Asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------- */
+SFGPU_API int sfgpu_tpm(const double* d_est_count, const double* d_len, uint64_t M, double num_mapped,
+              double* d_tpm, sfgpu_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFGPU_H */

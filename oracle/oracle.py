@@ -110,8 +110,11 @@ class EqBuilder:
         return rowptr, ids[:nnz.value], counts[:n.value], hashes[:n.value]
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().sfo_eq_destroy(self._h); self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().sfo_eq_destroy(self._h); self._h = None
+        except Exception:
+            pass
 
 
 def cf_gaussian(max_frag_len=1000, mean=200, sd=80):

@@ -1,0 +1,127 @@
+"""ctypes binding of libsfgpu.so (the C ABI declared in include/sfgpu.h).
+
+The HIP library is the product path: there is no CPU fallback.  If the shared object is
+missing, or a compute entry point fails, this module raises -- loudly.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsfgpu.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NO_ACTIVE, ERR_ALPHA_SUM, ERR_RANGE, ERR_STATE = range(7)
+
+
+class SfgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsfgpu error {code}: {msg}")
+        self.code = code
+
+
+class Problem(C.Structure):
+    _fields_ = [("M", C.c_uint64), ("d_len", C.c_void_p), ("C", C.c_uint64), ("d_rowptr", C.c_void_p),
+                ("d_ids", C.c_void_p), ("d_counts", C.c_void_p), ("num_mapped", C.c_uint64)]
+
+
+class EmOpts(C.Structure):
+    _fields_ = [("use_vbem", C.c_int), ("tol", C.c_double), ("min_iter", C.c_uint32), ("max_iter", C.c_uint32),
+                ("check_mode", C.c_int), ("iters_per_launch", C.c_uint32)]
+
+
+class EmStats(C.Structure):
+    _fields_ = [("iters", C.c_uint32), ("converged", C.c_uint32), ("max_rel_diff", C.c_double),
+                ("alpha_sum", C.c_double), ("n_active", C.c_uint64), ("loop_ms", C.c_double)]
+
+    def as_dict(self):
+        return dict(iters=self.iters, converged=bool(self.converged), max_rel_diff=self.max_rel_diff,
+                    alpha_sum=self.alpha_sum, n_active=self.n_active, loop_ms=self.loop_ms)
+
+
+_LOG_CB = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
+_lib = None
+_log_keepalive = None
+
+_P = C.c_void_p
+_SIGS = {
+    "sfgpu_version": (C.c_int, []),
+    "sfgpu_last_error": (C.c_char_p, []),
+    "sfgpu_set_logger": (None, [_LOG_CB]),
+    "sfgpu_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "sfgpu_xxh64_labels": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
+    "sfgpu_eq_create": (C.c_int, [C.POINTER(_P), C.c_uint64, _P]),
+    "sfgpu_eq_destroy": (C.c_int, [_P]),
+    "sfgpu_eq_start": (C.c_int, [_P]),
+    "sfgpu_eq_add_batch_host": (C.c_int, [_P, _P, _P, C.c_uint32]),
+    "sfgpu_eq_add_batch_device": (C.c_int, [_P, _P, _P, C.c_uint32]),
+    "sfgpu_eq_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sfgpu_eq_export_device": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sfgpu_eq_export_host": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sfgpu_cf_gaussian": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, _P]),
+    "sfgpu_cf_counts": (C.c_int, [_P, C.c_uint32, _P]),
+    "sfgpu_efflen_smoothed": (C.c_int, [_P, C.c_uint64, _P, C.c_uint32, _P, _P]),
+    "sfgpu_em_create": (C.c_int, [C.POINTER(_P), C.POINTER(Problem), _P]),
+    "sfgpu_em_destroy": (C.c_int, [_P]),
+    "sfgpu_em_optimize": (C.c_int, [_P, C.POINTER(EmOpts), _P, _P, C.POINTER(EmStats)]),
+    "sfgpu_em_begin": (C.c_int, [_P, C.POINTER(EmOpts)]),
+    "sfgpu_em_init": (C.c_int, [_P]),
+    "sfgpu_em_sweep": (C.c_int, [_P]),
+    "sfgpu_em_update": (C.c_int, [_P]),
+    "sfgpu_em_poll": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(EmStats)]),
+    "sfgpu_em_finish": (C.c_int, [_P, _P, _P, C.POINTER(EmStats)]),
+    "sfgpu_em_alpha_out": (_P, [_P]),
+    "sfgpu_em_time_sweep": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.POINTER(C.c_double)]),
+    "sfgpu_tpm": (C.c_int, [_P, _P, C.c_uint64, C.c_double, _P, _P]),
+}
+
+
+def exported_symbols():
+    """Names include/sfgpu.h declares (kept in lock-step with _SIGS by tests/test_abi.py)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libsfgpu.so (built in-tree by __graft_entry__.build()). Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise SfgpuError(rc, lib().sfgpu_last_error().decode("utf-8", "replace"))
+
+
+def set_logger(fn):
+    """fn(level:int, msg:str) or None -- forwarded from the library (the jointLog hook)."""
+    global _log_keepalive
+    if fn is None:
+        _log_keepalive = _LOG_CB(0)
+    else:
+        _log_keepalive = _LOG_CB(lambda lvl, msg: fn(lvl, msg.decode("utf-8", "replace")))
+    lib().sfgpu_set_logger(_log_keepalive)
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device (0 = null stream)."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous tensor / numpy array."""
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)

@@ -1,0 +1,595 @@
+// em.hip -- CollapsedEMOptimizer on the device (rows a6-a12 of SURVEY.md section 8).
+//
+// Replaces  src/CollapsedEMOptimizer.cpp:711-893 (optimize), :224-281 (EMUpdate_),
+//           :288-369 (VBEMUpdate_), :36-44 (truncateCountVector), :849-861 (convergence).
+//
+// Design (the reference is TBB parallel_for over an AoS vector of heap vectors with a CAS
+// loop per contribution):
+//   * classes are a flat CSR (rowptr u32, ids u32, counts u32) that stays resident in HBM;
+//   * the per-class aux weights of the reference are NOT materialised: w_i is proportional to
+//     1/effLen_i and its per-class normaliser cancels in v_i/denom (:762-768, :256-270), so the
+//     sweep gathers x_t = alpha_t/effLen_t (EM) or expTheta_t/effLen_t (VBEM) -- one M-vector
+//     rebuilt each iteration -- and streams only labels and counts: 4 B per nonzero instead of
+//     12 (algorithmic bytes B_iter' = 4L + 8C + 48M);
+//   * an iteration is [sweep over classes] -> [per-transcript update: convergence test, swap,
+//     next x]; the loop condition of :820 is evaluated ON THE DEVICE from a small state block,
+//     every kernel turns into a no-op once it holds, so the host can enqueue iterations in
+//     hipGraph chunks and still stop at exactly the reference's iteration;
+//   * all reductions that feed decisions (n_active, sum alpha, alphaSum) are two-stage and
+//     order-deterministic; the only nondeterministic order is the f64 atomic accumulation into
+//     alphaOut, as in the reference's CAS loop (:70-79).
+#include "common.h"
+
+#include <cfloat>
+#include <vector>
+
+namespace sfgpu {
+
+constexpr int kEmBlock = 256;
+constexpr int kMaxPartials = 1024;          // blocks of the per-transcript kernels
+constexpr uint32_t kDoneMark = 0xFFFFFFFFu;
+constexpr double kTiny = 4.9406564584124654e-324;   // numeric_limits<double>::denorm_min() (:33-34)
+constexpr double kPriorAlpha = 0.01;        // :786
+constexpr double kMinAlpha = 1e-8;          // :810
+constexpr double kCheckCutoff = 1e-2;       // :811
+
+struct EmState {
+    uint32_t it_a;                 // iterations completed; written by update, read by sweep
+    uint32_t it_b;                 // iteration in flight (or kDoneMark); written by sweep, read by update
+    uint32_t notconv[2];           // per iteration parity: some gated transcript moved by > tol
+    uint32_t gated[2];             // per iteration parity: some transcript passed the gate
+    unsigned long long maxrel[2];  // bit pattern of the largest relative change
+    unsigned long long n_active;
+    double alpha_sum;
+};
+
+// loop condition of :820, negated:  stop  <=>  it >= minIter && (it >= maxIter || converged)
+__device__ __forceinline__ bool em_stop(uint32_t it, const EmState* s, uint32_t min_iter, uint32_t max_iter) {
+    if (it < min_iter) return false;
+    if (it >= max_iter) return true;
+    return it > 0 && s->notconv[(it - 1) & 1] == 0;
+}
+
+// psi(x), x > 0: recurrence up to x >= 10 then the asymptotic series through B_14
+// (boost::math::digamma at :303, :314 in the reference; |err| ~ 1e-15).
+__device__ __forceinline__ double digamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    double inv = 1.0 / x, inv2 = inv * inv;
+    double s = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 * (1.0 / 240.0
+             - inv2 * (1.0 / 132.0 - inv2 * (691.0 / 32760.0 - inv2 * (1.0 / 12.0)))))));
+    return r + log(x) - 0.5 * inv - s;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+// deterministic block sum; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* lds /* kEmBlock/kWave */) {
+    v = wave_sum(v);
+    int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) lds[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < kEmBlock / kWave; ++i) t += lds[i];
+    __syncthreads();
+    return t;
+}
+
+// sum of the nb per-block partials, same order in every block -> identical everywhere
+__device__ __forceinline__ double sum_partials(const double* partials, int nb, double* lds) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kEmBlock) v += partials[i];
+    double t = block_sum(v, lds);
+    __shared__ double bc;
+    if (threadIdx.x == 0) bc = t;
+    __syncthreads();
+    return bc;
+}
+
+__global__ void k_clamp_len(uint64_t M, const double* __restrict__ len, double* __restrict__ lenc) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) { double l = len[t]; lenc[t] = (l <= 1.0) ? 1.0 : l; }   // :738
+}
+
+__global__ void k_narrow_counts(uint64_t C, const uint64_t* __restrict__ c64, uint32_t* __restrict__ c32,
+                                unsigned int* overflow) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    uint64_t v = c64[c];
+    if (v >> 32) atomicOr(overflow, 1u);
+    c32[c] = (uint32_t)v;
+}
+
+// :774-782  every transcript that appears in a class is active
+__global__ void k_mark_active(uint64_t L, const uint32_t* __restrict__ ids, double* alpha_out) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < L) alpha_out[ids[j]] = 1.0;
+}
+
+__global__ void k_count_active(uint64_t M, const double* __restrict__ flags, double* partials) {
+    __shared__ double lds[kEmBlock / kWave];
+    double v = 0.0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock)
+        v += (flags[t] > 0.0) ? 1.0 : 0.0;
+    double s = block_sum(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// :800-803 alpha_t = active ? (1/n_active) * numMapped : 0 ; also x for iteration 0 (EM) or
+// the partial sums of alpha (VBEM)
+template <bool VB>
+__global__ void k_init_alpha(uint64_t M, double* alpha, double* alpha_out, double* x, const double* __restrict__ lenc,
+                             double total_frags, const double* act_partials, double* sum_partials_out, int nb,
+                             EmState* st) {
+    __shared__ double lds[kEmBlock / kWave];
+    double n_act = sum_partials(act_partials, nb, lds);
+    double scale = 1.0 / n_act;
+    double local = 0.0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
+        double a = (alpha_out[t] > 0.0) ? scale * total_frags : 0.0;
+        alpha[t] = a; alpha_out[t] = 0.0;
+        if (VB) local += a; else x[t] = a / lenc[t];
+    }
+    if (VB) { double s = block_sum(local, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->it_a = 0; st->it_b = 0; st->notconv[0] = st->notconv[1] = 0; st->gated[0] = st->gated[1] = 0;
+        st->maxrel[0] = st->maxrel[1] = 0; st->n_active = (unsigned long long)n_act; st->alpha_sum = 0.0;
+    }
+}
+
+// VBEMUpdate_ prologue (:300-320): expTheta_t = alpha_t > denorm_min ? exp(psi(alpha_t) - psi(sum alpha)) : 0,
+// folded with the 1/effLen factor of the aux weight.
+__global__ void k_vb_prepare(uint64_t M, const double* __restrict__ alpha, double* __restrict__ x,
+                             const double* __restrict__ lenc, const double* sum_partials_in, int nb,
+                             const EmState* st, int force) {
+    if (!force && st->it_b == kDoneMark) return;
+    __shared__ double lds[kEmBlock / kWave];
+    double asum = sum_partials(sum_partials_in, nb, lds);
+    double log_norm = digamma_pos(asum);
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
+        double a = alpha[t];
+        x[t] = (a > kTiny) ? exp(digamma_pos(a) - log_norm) / lenc[t] : 0.0;
+    }
+}
+
+// E-step sweep, one lane per class (EMUpdate_ :236-277 / VBEMUpdate_ :325-366).
+template <bool VB>
+__global__ void __launch_bounds__(kEmBlock)
+k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+             const uint32_t* __restrict__ counts, const double* __restrict__ x, double* alpha_out,
+             EmState* st, uint32_t min_iter, uint32_t max_iter) {
+    uint32_t it = st->it_a;
+    bool stop = em_stop(it, st, min_iter, max_iter);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->it_b = stop ? kDoneMark : it;
+        if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; st->maxrel[it & 1] = 0; }
+    }
+    if (stop) return;
+    uint64_t c = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
+    if (c >= C) return;
+    uint32_t b = rowptr[c], e = rowptr[c + 1];
+    double cnt = (double)counts[c];
+    if (e - b == 1) { atomicAdd(&alpha_out[ids[b]], cnt); return; }     // :275 / :364
+    if (e == b) return;
+    double denom = 0.0;
+    for (uint32_t j = b; j < e; ++j) {
+        double v = x[ids[j]];
+        if (VB) { if (v > 0.0) denom += v; } else denom += v;
+    }
+    if (!(denom > kTiny)) return;                                       // :260 / :349
+    double inv = cnt / denom;                                           // :264
+    for (uint32_t j = b; j < e; ++j) {
+        uint32_t t = ids[j];
+        double v = x[t];
+        if (VB ? (v > 0.0) : (v == v)) atomicAdd(&alpha_out[t], v * inv);
+    }
+}
+
+// per-transcript update (:849-861): gate, relative change, alpha <- alphaOut, alphaOut <- 0, ++it
+template <bool VB>
+__global__ void __launch_bounds__(kEmBlock)
+k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* __restrict__ lenc,
+         double tol, int check_mode, double* sum_partials_out, EmState* st) {
+    uint32_t it = st->it_b;
+    if (it == kDoneMark) return;
+    __shared__ double lds[kEmBlock / kWave];
+    double local_sum = 0.0, local_max = -1.0;
+    unsigned notconv = 0, gated = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
+        double a = alpha[t];
+        double ap = alpha_out[t];
+        if (VB) ap += kPriorAlpha;                     // alphaOut starts at the prior (:318)
+        double gate = check_mode ? a : ap;             // :852 vs :499
+        if (gate > kCheckCutoff) {
+            double rel = fabs(a - ap) / ap;
+            gated = 1;
+            if (rel > local_max) local_max = rel;
+            if (rel > tol) notconv = 1;
+        }
+        alpha[t] = ap; alpha_out[t] = 0.0;
+        if (VB) local_sum += ap; else x[t] = ap / lenc[t];
+    }
+    // wave-level combine, one set of atomics per wave
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
+        notconv |= __shfl_down(notconv, o, kWave); gated |= __shfl_down(gated, o, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (notconv) atomicOr(&st->notconv[it & 1], 1u);
+        if (gated) { atomicOr(&st->gated[it & 1], 1u);
+                     if (local_max >= 0.0) atomicMax(&st->maxrel[it & 1], (unsigned long long)__double_as_longlong(local_max)); }
+    }
+    if (VB) { double s = block_sum(local_sum, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->it_a = it + 1;
+}
+
+// truncateCountVector (:36-44) + alphaSum
+__global__ void k_truncate(uint64_t M, const double* __restrict__ alpha, double cutoff, double* out, double* partials) {
+    __shared__ double lds[kEmBlock / kWave];
+    double v = 0.0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
+        double a = alpha[t];
+        if (a <= cutoff) a = 0.0;
+        out[t] = a; v += a;
+    }
+    double s = block_sum(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// :885-891 mass = alpha / alphaSum
+__global__ void k_mass(uint64_t M, const double* __restrict__ est, double* mass, const double* partials, int nb,
+                       EmState* st) {
+    __shared__ double lds[kEmBlock / kWave];
+    double asum = sum_partials(partials, nb, lds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha_sum = asum;
+    if (!mass) return;
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock)
+        mass[t] = est[t] / asum;
+}
+
+static inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kEmBlock - 1) / kEmBlock); }
+
+}  // namespace sfgpu
+
+using namespace sfgpu;
+
+struct sfgpu_em {
+    hipStream_t user_stream = nullptr;
+    hipStream_t stream = nullptr;          // own stream: graph capture is illegal on the null stream
+    hipStream_t cur = nullptr;             // where work goes: `stream` inside optimize(), the caller's stream for the piecewise API
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_join = nullptr;
+    sfgpu_problem prob{};
+    uint64_t L = 0;
+    int nb = 1;                            // blocks of the per-transcript kernels
+    double *alpha = nullptr, *alpha_out = nullptr, *x = nullptr, *lenc = nullptr;
+    double *partials = nullptr, *sum_partials = nullptr, *scratch = nullptr;
+    uint32_t* counts32 = nullptr;
+    EmState* d_state = nullptr;
+    EmState* h_state = nullptr;            // pinned
+    sfgpu_em_opts opts{};
+    bool begun = false;
+    hipGraphExec_t graph = nullptr;
+    sfgpu_em_opts graph_opts{};
+    uint32_t graph_iters = 0;
+};
+
+static void em_free(sfgpu_em* em) {
+    if (!em) return;
+    if (em->stream) (void)hipStreamSynchronize(em->stream);
+    if (em->graph) (void)hipGraphExecDestroy(em->graph);
+    void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
+                    em->counts32, em->d_state};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (em->h_state) (void)hipHostFree(em->h_state);
+    if (em->ev_a) (void)hipEventDestroy(em->ev_a);
+    if (em->ev_b) (void)hipEventDestroy(em->ev_b);
+    if (em->ev_join) (void)hipEventDestroy(em->ev_join);
+    if (em->stream) (void)hipStreamDestroy(em->stream);
+    delete em;
+}
+
+static int em_fill_opts(sfgpu_em* em, const sfgpu_em_opts* o) {
+    SF_REQUIRE(o, SFGPU_ERR_INVALID, "null sfgpu_em_opts");
+    SF_REQUIRE(o->tol >= 0.0, SFGPU_ERR_INVALID, "tol must be >= 0");
+    em->opts = *o;
+    if (em->opts.iters_per_launch == 0) em->opts.iters_per_launch = 32;
+    return SFGPU_OK;
+}
+
+// enqueue one full iteration on the handle's stream
+static int em_enqueue_sweep(sfgpu_em* em) {
+    const sfgpu_problem& p = em->prob;
+    if (p.C == 0) return SFGPU_OK;
+    dim3 g(blocks_for(p.C)), b(kEmBlock);
+    if (em->opts.use_vbem)
+        hipLaunchKernelGGL(k_sweep_lane<true>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
+                           em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
+    else
+        hipLaunchKernelGGL(k_sweep_lane<false>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
+                           em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
+
+static int em_enqueue_update(sfgpu_em* em) {
+    const sfgpu_problem& p = em->prob;
+    dim3 g(em->nb), b(kEmBlock);
+    if (em->opts.use_vbem) {
+        hipLaunchKernelGGL(k_update<true>, g, b, 0, em->cur, p.M, em->alpha, em->alpha_out, em->x, em->lenc,
+                           em->opts.tol, em->opts.check_mode, em->sum_partials, em->d_state);
+        SF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb,
+                           em->d_state, 0);
+    } else {
+        hipLaunchKernelGGL(k_update<false>, g, b, 0, em->cur, p.M, em->alpha, em->alpha_out, em->x, em->lenc,
+                           em->opts.tol, em->opts.check_mode, em->sum_partials, em->d_state);
+    }
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
+
+// order the handle's stream after everything already enqueued on the caller's stream
+static int em_join_user(sfgpu_em* em) {
+    SF_HIP(hipEventRecord(em->ev_join, em->user_stream));
+    SF_HIP(hipStreamWaitEvent(em->stream, em->ev_join, 0));
+    return SFGPU_OK;
+}
+
+static void em_stats_from_state(sfgpu_em* em, sfgpu_em_stats* s) {
+    if (!s) return;
+    const EmState* h = em->h_state;
+    uint32_t it = h->it_a;
+    s->iters = it;
+    s->n_active = h->n_active;
+    s->alpha_sum = h->alpha_sum;
+    if (it == 0) { s->converged = 0; s->max_rel_diff = -DBL_MAX; return; }
+    uint32_t par = (it - 1) & 1;
+    s->converged = h->notconv[par] == 0;
+    long long bits = (long long)h->maxrel[par];
+    double m; memcpy(&m, &bits, 8);
+    s->max_rel_diff = h->gated[par] ? m : -DBL_MAX;   // the reference starts from -DBL_MAX (:850)
+}
+
+extern "C" {
+
+int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stream) {
+    SF_REQUIRE(out && prob, SFGPU_ERR_INVALID, "sfgpu_em_create: null pointer");
+    SF_REQUIRE(prob->M > 0 && prob->d_len, SFGPU_ERR_INVALID, "sfgpu_em_create: need M > 0 and d_len");
+    SF_REQUIRE(prob->C == 0 || (prob->d_rowptr && prob->d_ids && prob->d_counts), SFGPU_ERR_INVALID,
+               "sfgpu_em_create: null CSR pointer");
+    sfgpu_em* em = new sfgpu_em();
+    em->prob = *prob;
+    em->user_stream = as_stream(stream);
+    const uint64_t M = prob->M, C = prob->C;
+    int nb = (int)((M + kEmBlock - 1) / kEmBlock);
+    em->nb = nb < 1 ? 1 : (nb > kMaxPartials ? kMaxPartials : nb);
+#define EM_TRY(expr)                                                                                 \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) {                                              \
+        set_error("%s failed: %s", #expr, hipGetErrorString(_e)); em_free(em); return SFGPU_ERR_HIP; } } while (0)
+    EM_TRY(hipStreamCreateWithFlags(&em->stream, hipStreamNonBlocking));
+    em->cur = em->stream;
+    EM_TRY(hipEventCreate(&em->ev_a)); EM_TRY(hipEventCreate(&em->ev_b));
+    EM_TRY(hipEventCreateWithFlags(&em->ev_join, hipEventDisableTiming));
+    EM_TRY(hipMalloc(&em->alpha, M * 8)); EM_TRY(hipMalloc(&em->alpha_out, M * 8));
+    EM_TRY(hipMalloc(&em->x, M * 8)); EM_TRY(hipMalloc(&em->lenc, M * 8)); EM_TRY(hipMalloc(&em->scratch, M * 8));
+    EM_TRY(hipMalloc(&em->partials, kMaxPartials * 8)); EM_TRY(hipMalloc(&em->sum_partials, kMaxPartials * 8));
+    EM_TRY(hipMalloc(&em->counts32, (C ? C : 1) * 4));
+    EM_TRY(hipMalloc(&em->d_state, sizeof(EmState)));
+    EM_TRY(hipHostMalloc(&em->h_state, sizeof(EmState), hipHostMallocDefault));
+    EM_TRY(hipMemsetAsync(em->d_state, 0, sizeof(EmState), em->cur));
+    int rc = em_join_user(em);
+    if (rc) { em_free(em); return rc; }
+    hipLaunchKernelGGL(k_clamp_len, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, prob->d_len, em->lenc);
+    uint32_t rp_end = 0;
+    if (C) {
+        unsigned int* ovf = reinterpret_cast<unsigned int*>(em->partials);
+        EM_TRY(hipMemsetAsync(ovf, 0, 4, em->cur));
+        hipLaunchKernelGGL(k_narrow_counts, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_counts,
+                           em->counts32, ovf);
+        unsigned int h_ovf = 0;
+        EM_TRY(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(&rp_end, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipStreamSynchronize(em->cur));
+        if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
+    } else {
+        EM_TRY(hipStreamSynchronize(em->cur));
+    }
+#undef EM_TRY
+    em->L = rp_end;
+    *out = em;
+    return SFGPU_OK;
+}
+
+int sfgpu_em_destroy(sfgpu_em* em) { em_free(em); return SFGPU_OK; }
+
+double* sfgpu_em_alpha_out(sfgpu_em* em) { return em ? em->alpha_out : nullptr; }
+
+static int em_begin_on(sfgpu_em* em, const sfgpu_em_opts* opts, hipStream_t work) {
+    SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_begin: null handle");
+    int rc = em_fill_opts(em, opts);
+    if (rc) return rc;
+    em->cur = work;
+    SF_HIP(hipMemsetAsync(em->alpha_out, 0, em->prob.M * 8, em->cur));
+    if (em->L) {
+        hipLaunchKernelGGL(k_mark_active, dim3(blocks_for(em->L)), dim3(kEmBlock), 0, em->cur, em->L, em->prob.d_ids,
+                           em->alpha_out);
+        SF_CHECK_LAUNCH();
+    }
+    em->begun = true;
+    return SFGPU_OK;
+}
+
+int sfgpu_em_begin(sfgpu_em* em, const sfgpu_em_opts* opts) {
+    SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_begin: null handle");
+    (void)hipStreamSynchronize(em->stream);    // nothing of a previous optimize() may be in flight
+    return em_begin_on(em, opts, em->user_stream);
+}
+
+static int sfgpu_em_init_impl(sfgpu_em* em) {
+    SF_REQUIRE(em && em->begun, SFGPU_ERR_STATE, "sfgpu_em_init: call begin first");
+    const sfgpu_problem& p = em->prob;
+    dim3 g(em->nb), b(kEmBlock);
+    hipLaunchKernelGGL(k_count_active, g, b, 0, em->cur, p.M, em->alpha_out, em->partials);
+    SF_CHECK_LAUNCH();
+    double total = (double)p.num_mapped;   // :792
+    if (em->opts.use_vbem) {
+        hipLaunchKernelGGL(k_init_alpha<true>, g, b, 0, em->cur, p.M, em->alpha, em->alpha_out, em->x, em->lenc, total,
+                           em->partials, em->sum_partials, em->nb, em->d_state);
+        SF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb,
+                           em->d_state, 1);
+    } else {
+        hipLaunchKernelGGL(k_init_alpha<false>, g, b, 0, em->cur, p.M, em->alpha, em->alpha_out, em->x, em->lenc, total,
+                           em->partials, em->sum_partials, em->nb, em->d_state);
+    }
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
+
+int sfgpu_em_init(sfgpu_em* em) { return sfgpu_em_init_impl(em); }
+
+int sfgpu_em_sweep(sfgpu_em* em) {
+    SF_REQUIRE(em && em->begun, SFGPU_ERR_STATE, "sfgpu_em_sweep: call begin/init first");
+    return em_enqueue_sweep(em);
+}
+
+int sfgpu_em_update(sfgpu_em* em) {
+    SF_REQUIRE(em && em->begun, SFGPU_ERR_STATE, "sfgpu_em_update: call begin/init first");
+    return em_enqueue_update(em);
+}
+
+int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
+    SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_poll: null handle");
+    SF_HIP(hipMemcpyAsync(em->h_state, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
+    SF_HIP(hipStreamSynchronize(em->cur));
+    const EmState* h = em->h_state;
+    uint32_t it = h->it_a;
+    bool stop = false;
+    if (it >= em->opts.min_iter) stop = (it >= em->opts.max_iter) || (it > 0 && h->notconv[(it - 1) & 1] == 0);
+    if (done) *done = stop ? 1 : 0;
+    em_stats_from_state(em, stats);
+    return SFGPU_OK;
+}
+
+int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats) {
+    SF_REQUIRE(em && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_finish: null pointer");
+    const sfgpu_problem& p = em->prob;
+    double cutoff = em->opts.use_vbem ? (kPriorAlpha + kMinAlpha) : kMinAlpha;   // :812
+    dim3 g(em->nb), b(kEmBlock);
+    hipLaunchKernelGGL(k_truncate, g, b, 0, em->cur, p.M, em->alpha, cutoff, d_alpha_out, em->partials);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_mass, g, b, 0, em->cur, p.M, d_alpha_out, d_mass_out, em->partials, em->nb, em->d_state);
+    SF_CHECK_LAUNCH();
+    SF_HIP(hipMemcpyAsync(em->h_state, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
+    SF_HIP(hipStreamSynchronize(em->cur));
+    em_stats_from_state(em, stats);
+    if (em->h_state->alpha_sum < kTiny) {                                       // :877-881
+        set_error("Total alpha weight was too small! Make sure you ran sailfish correctly.");
+        return SFGPU_ERR_ALPHA_SUM;
+    }
+    return SFGPU_OK;
+}
+
+static bool same_opts(const sfgpu_em_opts& a, const sfgpu_em_opts& b) {
+    return a.use_vbem == b.use_vbem && a.tol == b.tol && a.min_iter == b.min_iter && a.max_iter == b.max_iter &&
+           a.check_mode == b.check_mode && a.iters_per_launch == b.iters_per_launch;
+}
+
+// capture `n` iterations into an executable graph (kernel arguments are baked, the iteration
+// index and the stop latch live in device memory)
+static int em_build_graph(sfgpu_em* em, uint32_t n) {
+    if (em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == n) return SFGPU_OK;
+    if (em->graph) { (void)hipGraphExecDestroy(em->graph); em->graph = nullptr; }
+    hipGraph_t g = nullptr;
+    SF_HIP(hipStreamBeginCapture(em->cur, hipStreamCaptureModeThreadLocal));
+    int rc = SFGPU_OK;
+    for (uint32_t i = 0; i < n && rc == SFGPU_OK; ++i) {
+        rc = em_enqueue_sweep(em);
+        if (rc == SFGPU_OK) rc = em_enqueue_update(em);
+    }
+    hipError_t e = hipStreamEndCapture(em->cur, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    SF_HIP(e);
+    hipError_t ei = hipGraphInstantiate(&em->graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    SF_HIP(ei);
+    em->graph_opts = em->opts; em->graph_iters = n;
+    return SFGPU_OK;
+}
+
+int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
+                      sfgpu_em_stats* stats) {
+    SF_REQUIRE(em && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_optimize: null pointer");
+    int rc;
+    if ((rc = em_join_user(em))) return rc;
+    if ((rc = em_begin_on(em, opts, em->stream))) return rc;
+    if ((rc = sfgpu_em_init_impl(em))) return rc;
+    int done = 0;
+    sfgpu_em_stats st{};
+    if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+    if (st.n_active == 0) {                                                      // :794-798
+        set_error("It seems that no transcripts are expressed; something is likely wrong!");
+        if (stats) *stats = st;
+        return SFGPU_ERR_NO_ACTIVE;
+    }
+    log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
+    const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
+    const uint32_t chunk = em->opts.iters_per_launch;
+    if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
+    SF_HIP(hipEventRecord(em->ev_a, em->cur));
+    while (!done) {
+        if (use_graph) {
+            SF_HIP(hipGraphLaunch(em->graph, em->cur));
+        } else {
+            for (uint32_t i = 0; i < chunk; ++i) {
+                if ((rc = em_enqueue_sweep(em))) return rc;
+                if ((rc = em_enqueue_update(em))) return rc;
+            }
+        }
+        if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+    }
+    SF_HIP(hipEventRecord(em->ev_b, em->cur));
+    rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, em->ev_a, em->ev_b);
+    st.loop_ms = ms;
+    log_msg(0, "iteration = %u | max rel diff. = %g", st.iters, st.max_rel_diff);   // :871-872
+    if (stats) *stats = st;
+    return rc;
+}
+
+int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n, double* avg_ms) {
+    SF_REQUIRE(em && avg_ms && n > 0, SFGPU_ERR_INVALID, "sfgpu_em_time_sweep: bad argument");
+    int rc;
+    if (!em->begun) {
+        if ((rc = sfgpu_em_begin(em, opts))) return rc;
+        if ((rc = sfgpu_em_init(em))) return rc;
+    } else if ((rc = em_fill_opts(em, opts))) return rc;
+    // keep alphaOut and the state block intact: time on copies
+    EmState saved;
+    SF_HIP(hipMemcpyAsync(em->scratch, em->alpha_out, em->prob.M * 8, hipMemcpyDeviceToDevice, em->cur));
+    SF_HIP(hipMemcpyAsync(&saved, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
+    SF_HIP(hipStreamSynchronize(em->cur));
+    EmState run = saved; run.it_a = 0;
+    uint32_t keep_min = em->opts.min_iter, keep_max = em->opts.max_iter;
+    em->opts.min_iter = 1; em->opts.max_iter = 2;   // it_a = 0 never satisfies the stop test
+    SF_HIP(hipMemcpyAsync(em->d_state, &run, sizeof(EmState), hipMemcpyHostToDevice, em->cur));
+    for (int w = 0; w < 3; ++w) if ((rc = em_enqueue_sweep(em))) return rc;
+    SF_HIP(hipEventRecord(em->ev_a, em->cur));
+    for (uint32_t i = 0; i < n; ++i) if ((rc = em_enqueue_sweep(em))) return rc;
+    SF_HIP(hipEventRecord(em->ev_b, em->cur));
+    SF_HIP(hipStreamSynchronize(em->cur));
+    float ms = 0.f;
+    SF_HIP(hipEventElapsedTime(&ms, em->ev_a, em->ev_b));
+    *avg_ms = (double)ms / n;
+    em->opts.min_iter = keep_min; em->opts.max_iter = keep_max;
+    SF_HIP(hipMemcpyAsync(em->d_state, &saved, sizeof(EmState), hipMemcpyHostToDevice, em->cur));
+    SF_HIP(hipMemcpyAsync(em->alpha_out, em->scratch, em->prob.M * 8, hipMemcpyDeviceToDevice, em->cur));
+    SF_HIP(hipStreamSynchronize(em->cur));
+    return SFGPU_OK;
+}
+
+}  // extern "C"

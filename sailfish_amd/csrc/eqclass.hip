@@ -1,0 +1,500 @@
+// eqclass.hip -- EquivalenceClassBuilder on the device (rows a1-a5 of SURVEY.md section 8).
+//
+// Replaces  include/EquivalenceClassBuilder.hpp:53-119  (addGroup -> libcuckoo upsert,
+//           include/cuckoohash_map.hh:667-698), include/TranscriptGroup.hpp and
+//           src/TranscriptGroup.cpp (key = ordered id list, hash = XXH64, == is vector ==).
+//
+// Design (not the reference's: that is a lock-striped CPU cuckoo table fed one read at a time):
+//   * reads arrive as packed batches (ids[], offsets[]) resident in HBM; one lane per read
+//     hashes its label with XXH64 and probes an open-addressing table with linear probing;
+//   * a slot is one 16-byte pair {word, count}: word = tag(32) | rep(32).  tag = XXH64 >> 32
+//     filters probes; class identity is ALWAYS decided by a full label compare against the
+//     slot's representative label, exactly like operator== (src/TranscriptGroup.cpp:53-55),
+//     so XXH64 collisions are resolved the way the reference resolves them;
+//   * claiming a slot is a single 64-bit CAS that publishes tag and representative together,
+//     so no lane ever waits on another lane (no spin, no fence): rep is either a read index of
+//     the running batch (label still in the batch buffers, written before the launch) or
+//     0x80000000|class-id (label in the arena, written by an earlier launch);
+//   * after each sub-batch a commit kernel copies the labels of the newly created classes to
+//     the arena and re-points their slots, so batch buffers can be reused by the caller;
+//   * the table is sized from the number of classes actually seen (load <= 1/2), keeping the
+//     randomly probed working set cache-resident; inserts that would exceed the budget are
+//     deferred, the table is doubled, and the deferred reads are replayed;
+//   * finish() orders classes canonically (first id, XXH64, length, label) with a radix sort.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "primitives.h"
+#include "xxh64_device.h"
+
+namespace sfgpu {
+
+constexpr uint64_t kEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kArenaBit = 0x80000000u;
+constexpr uint64_t kSlack = 1ull << 20;      // >= lanes in flight that can pass the budget guard together
+constexpr uint64_t kMinHeadroom = 1ull << 16;
+constexpr int kBlock = 256;
+
+// ctr[0] = classes created by this launch, ctr[1] = deferred reads, ctr[2] = arena cursor (ids)
+enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_N = 4 };
+
+__global__ void k_table_init(uint64_t* table, uint64_t cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < cap; i += stride) { table[2 * i] = kEmpty; table[2 * i + 1] = 0; }
+}
+
+__device__ __forceinline__ bool labels_equal(const uint32_t* a, const uint32_t* b, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+// a1: standalone label hash (sfgpu_xxh64_labels)
+__global__ void k_hash_labels(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t n,
+                              uint64_t* __restrict__ out) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t b = off[r], len = off[r + 1] - b;
+    const uint32_t* lab = ids + b;
+    out[r] = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
+}
+
+// addGroup for a range of reads (list == nullptr: reads [first, first+n); else list[0..n)).
+__global__ void __launch_bounds__(kBlock)
+k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t first, uint32_t n,
+         const uint32_t* __restrict__ list, uint64_t* table, uint64_t mask,
+         const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ cls_len,
+         const uint32_t* __restrict__ arena, unsigned long long* ctr, uint32_t* newlist,
+         unsigned long long limit_new, uint32_t* deferred) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = list ? list[i] : first + i;
+    uint32_t b = off[r], len = off[r + 1] - b;
+    if (len == 0) return;  // call-site guard: empty hit lists never reach addGroup
+    const uint32_t* lab = ids + b;
+    uint64_t h = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
+    uint64_t tag = h >> 32;
+    uint64_t s = h & mask;
+    for (;;) {
+        uint64_t w = __hip_atomic_load(&table[2 * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == kEmpty) {
+            if (__hip_atomic_load(&ctr[CTR_NEW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit_new) {
+                unsigned long long d = atomicAdd(&ctr[CTR_DEFER], 1ull);
+                deferred[d] = r;
+                return;
+            }
+            uint64_t mine = (tag << 32) | (uint64_t)r;
+            unsigned long long old = atomicCAS((unsigned long long*)&table[2 * s], (unsigned long long)kEmpty,
+                                               (unsigned long long)mine);
+            if (old == kEmpty) {
+                unsigned long long idx = atomicAdd(&ctr[CTR_NEW], 1ull);
+                newlist[idx] = (uint32_t)s;
+                atomicAdd((unsigned long long*)&table[2 * s + 1], 1ull);
+                return;
+            }
+            w = old;
+        }
+        if ((w >> 32) == tag) {
+            uint32_t rep = (uint32_t)w;
+            const uint32_t* p; uint32_t l;
+            if (rep & kArenaBit) { uint32_t c = rep & ~kArenaBit; p = arena + cls_off[c]; l = cls_len[c]; }
+            else { uint32_t rb = off[rep]; p = ids + rb; l = off[rep + 1] - rb; }
+            if (l == len && labels_equal(p, lab, len)) {
+                atomicAdd((unsigned long long*)&table[2 * s + 1], 1ull);
+                return;
+            }
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+// move the labels of the classes created by the last k_insert into the arena
+__global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off,
+                         uint64_t* table, const uint32_t* __restrict__ newlist, uint64_t n_new, uint64_t base_cid,
+                         uint64_t* cls_hash, uint64_t* cls_off, uint32_t* cls_len, uint32_t* cls_slot,
+                         uint32_t* arena, unsigned long long* ctr) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_new) return;
+    uint32_t s = newlist[i];
+    uint64_t w = table[2 * (uint64_t)s];
+    uint32_t r = (uint32_t)w;
+    uint32_t b = off[r], len = off[r + 1] - b;
+    const uint32_t* lab = ids + b;
+    unsigned long long dst = atomicAdd(&ctr[CTR_ARENA], (unsigned long long)len);
+    for (uint32_t k = 0; k < len; ++k) arena[dst + k] = lab[k];
+    uint64_t cid = base_cid + i;
+    cls_hash[cid] = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
+    cls_off[cid] = dst; cls_len[cid] = len; cls_slot[cid] = s;
+    table[2 * (uint64_t)s] = (w & 0xFFFFFFFF00000000ull) | (uint64_t)(kArenaBit | (uint32_t)cid);
+}
+
+// re-insert every class into a larger table, carrying its count
+__global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table, uint64_t mask, uint64_t n_cls,
+                         const uint64_t* __restrict__ cls_hash, uint32_t* cls_slot) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cls) return;
+    uint64_t h = cls_hash[c];
+    uint64_t mine = ((h >> 32) << 32) | (uint64_t)(kArenaBit | (uint32_t)c);
+    uint64_t cnt = old_table[2 * (uint64_t)cls_slot[c] + 1];
+    uint64_t s = h & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS((unsigned long long*)&table[2 * s], (unsigned long long)kEmpty,
+                                           (unsigned long long)mine);
+        if (old == kEmpty) break;
+        s = (s + 1) & mask;
+    }
+    table[2 * s + 1] = cnt;
+    cls_slot[c] = (uint32_t)s;
+}
+
+// ---- finish(): canonical order ---------------------------------------------------------------
+__global__ void k_sort_keys(uint64_t n, const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
+                            const uint32_t* __restrict__ arena, uint64_t* keys, uint32_t* vals) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    keys[c] = ((uint64_t)arena[cls_off[c]] << 32) | (cls_hash[c] >> 32);
+    vals[c] = (uint32_t)c;
+}
+
+__device__ bool class_less(uint32_t a, uint32_t b, const uint64_t* cls_hash, const uint64_t* cls_off,
+                           const uint32_t* cls_len, const uint32_t* arena) {
+    if (cls_hash[a] != cls_hash[b]) return cls_hash[a] < cls_hash[b];
+    if (cls_len[a] != cls_len[b]) return cls_len[a] < cls_len[b];
+    const uint32_t* p = arena + cls_off[a]; const uint32_t* q = arena + cls_off[b];
+    for (uint32_t i = 0; i < cls_len[a]; ++i)
+        if (p[i] != q[i]) return p[i] < q[i];
+    return false;
+}
+
+// runs of equal (first id, hash>>32) keys are ordered by (hash, len, label); such runs are rare
+// and short, so the thread at the head of a run insertion-sorts it.
+__global__ void k_tie_fix(uint64_t n, const uint64_t* __restrict__ keys, uint32_t* order,
+                          const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
+                          const uint32_t* __restrict__ cls_len, const uint32_t* __restrict__ arena) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i > 0 && keys[i - 1] == keys[i]) return;        // not a run head
+    uint64_t e = i + 1;
+    while (e < n && keys[e] == keys[i]) ++e;
+    for (uint64_t a = i + 1; a < e; ++a) {
+        uint32_t v = order[a]; uint64_t b = a;
+        while (b > i && class_less(v, order[b - 1], cls_hash, cls_off, cls_len, arena)) { order[b] = order[b - 1]; --b; }
+        order[b] = v;
+    }
+}
+
+__global__ void k_sorted_lens(uint64_t n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cls_len,
+                              uint32_t* lens) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lens[i] = cls_len[order[i]];
+    else if (i == n) lens[i] = 0;
+}
+
+__global__ void k_sum_counts(uint64_t n, const uint64_t* __restrict__ table, const uint32_t* __restrict__ cls_slot,
+                             unsigned long long* total) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = (c < n) ? table[2 * (uint64_t)cls_slot[c] + 1] : 0ull;
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(total, v);
+}
+
+__global__ void k_export(uint64_t n, const uint32_t* __restrict__ order, const uint64_t* __restrict__ rowptr64,
+                         const uint64_t* __restrict__ table, const uint32_t* __restrict__ cls_slot,
+                         const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
+                         const uint32_t* __restrict__ cls_len, const uint32_t* __restrict__ arena,
+                         uint32_t* rowptr, uint32_t* ids, uint64_t* counts, uint64_t* hashes) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    rowptr[i] = (uint32_t)rowptr64[i];
+    if (i == n) return;
+    uint32_t c = order[i];
+    const uint32_t* p = arena + cls_off[c];
+    uint32_t* q = ids + rowptr64[i];
+    uint32_t len = cls_len[c];
+    for (uint32_t k = 0; k < len; ++k) q[k] = p[k];
+    counts[i] = table[2 * (uint64_t)cls_slot[c] + 1];
+    if (hashes) hashes[i] = cls_hash[c];
+}
+
+static inline unsigned grid_for(uint64_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace sfgpu
+
+using namespace sfgpu;
+
+struct sfgpu_eq {
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    bool finished = false;
+    uint64_t expected = 0;
+    uint64_t cap = 0;                     // slots (power of two)
+    DevBuf<uint64_t> table;               // 2*cap
+    uint64_t n_classes = 0;
+    DevBuf<uint64_t> cls_hash, cls_off;
+    DevBuf<uint32_t> cls_len, cls_slot;
+    DevBuf<uint32_t> arena; uint64_t arena_used = 0;
+    DevBuf<uint32_t> newlist, deferred_a, deferred_b;
+    unsigned long long* d_ctr = nullptr;
+    unsigned long long* h_ctr = nullptr;  // pinned
+    DevBuf<uint32_t> stage_ids, stage_off;
+    // finish() products
+    DevBuf<uint32_t> order; DevBuf<uint64_t> rowptr64;
+    uint64_t nnz = 0, total_reads = 0;
+    uint32_t sub_batch = 1u << 22;
+};
+
+static int eq_alloc_table(sfgpu_eq* eq, uint64_t cap) {
+    eq->table.p = nullptr; eq->table.cap = 0;
+    int rc = eq->table.reserve(2 * cap, eq->stream, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, cap);
+    SF_CHECK_LAUNCH();
+    eq->cap = cap;
+    return SFGPU_OK;
+}
+
+static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
+    SF_REQUIRE(new_cap <= (1ull << 31), SFGPU_ERR_RANGE, "equivalence-class table would exceed 2^31 slots");
+    uint64_t* old = eq->table.p;
+    int rc = eq_alloc_table(eq, new_cap);
+    if (rc) return rc;
+    if (eq->n_classes) {
+        hipLaunchKernelGGL(k_rehash, dim3(grid_for(eq->n_classes)), dim3(kBlock), 0, eq->stream, old, eq->table.p,
+                           new_cap - 1, eq->n_classes, eq->cls_hash.p, eq->cls_slot.p);
+        SF_CHECK_LAUNCH();
+    }
+    SF_HIP(hipStreamSynchronize(eq->stream));
+    if (old) SF_HIP(hipFree(old));
+    log_msg(0, "eq: table grown to %llu slots (%llu classes)", (unsigned long long)new_cap,
+            (unsigned long long)eq->n_classes);
+    return SFGPU_OK;
+}
+
+static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+
+static int eq_reset(sfgpu_eq* eq) {
+    eq->finished = false; eq->n_classes = 0; eq->arena_used = 0; eq->nnz = 0; eq->total_reads = 0;
+    uint64_t want = pow2_at_least(2 * (eq->expected ? eq->expected : 1000000ull) + 2 * kSlack);
+    if (eq->table.p && eq->cap == want) {
+        hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
+        SF_CHECK_LAUNCH();
+    } else {
+        if (eq->table.p) { SF_HIP(hipStreamSynchronize(eq->stream)); SF_HIP(hipFree(eq->table.p)); }
+        int rc = eq_alloc_table(eq, want);
+        if (rc) return rc;
+    }
+    SF_HIP(hipMemsetAsync(eq->d_ctr, 0, CTR_N * sizeof(unsigned long long), eq->stream));
+    return SFGPU_OK;
+}
+
+extern "C" {
+
+int sfgpu_xxh64_labels(const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads, uint64_t* d_hashes,
+                       sfgpu_stream stream) {
+    SF_REQUIRE(d_offsets && d_hashes, SFGPU_ERR_INVALID, "sfgpu_xxh64_labels: null pointer");
+    if (n_reads == 0) return SFGPU_OK;
+    hipLaunchKernelGGL(k_hash_labels, dim3(grid_for(n_reads)), dim3(kBlock), 0, as_stream(stream), d_ids, d_offsets,
+                       n_reads, d_hashes);
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
+
+int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stream) {
+    SF_REQUIRE(out, SFGPU_ERR_INVALID, "sfgpu_eq_create: null out");
+    sfgpu_eq* eq = new sfgpu_eq();
+    eq->stream = as_stream(stream);
+    eq->expected = expected_classes;
+    if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) eq->sub_batch = (uint32_t)v; }
+    hipError_t e1 = hipMalloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
+    hipError_t e2 = hipHostMalloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        set_error("sfgpu_eq_create: allocation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        delete eq; return SFGPU_ERR_HIP;
+    }
+    int rc = eq_reset(eq);
+    if (rc) { sfgpu_eq_destroy(eq); return rc; }
+    *out = eq;
+    return SFGPU_OK;
+}
+
+int sfgpu_eq_destroy(sfgpu_eq* eq) {
+    if (!eq) return SFGPU_OK;
+    (void)hipStreamSynchronize(eq->stream);
+    if (eq->d_ctr) (void)hipFree(eq->d_ctr);
+    if (eq->h_ctr) (void)hipHostFree(eq->h_ctr);
+    delete eq;
+    return SFGPU_OK;
+}
+
+int sfgpu_eq_start(sfgpu_eq* eq) {
+    SF_REQUIRE(eq, SFGPU_ERR_INVALID, "sfgpu_eq_start: null handle");
+    std::lock_guard<std::mutex> lk(eq->mu);
+    return eq_reset(eq);
+}
+
+// caller holds eq->mu
+static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads) {
+    SF_REQUIRE(n_reads < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: a batch holds < 2^31 reads");
+    SF_REQUIRE(!eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_add_batch: builder already finished (call start)");
+    if (n_reads == 0) return SFGPU_OK;
+    hipStream_t st = eq->stream;
+    uint32_t ends[2];
+    SF_HIP(hipMemcpyAsync(&ends[0], d_offsets, 4, hipMemcpyDeviceToHost, st));
+    SF_HIP(hipMemcpyAsync(&ends[1], d_offsets + n_reads, 4, hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    SF_REQUIRE(ends[1] >= ends[0], SFGPU_ERR_INVALID, "sfgpu_eq_add_batch: offsets not ascending");
+    uint64_t batch_ids = (uint64_t)ends[1] - ends[0];
+    int rc;
+    if ((rc = eq->arena.reserve(eq->arena_used + batch_ids + 1, st, true, eq->arena_used))) return rc;
+
+    for (uint32_t first = 0; first < n_reads; first += eq->sub_batch) {
+        uint32_t cnt = (n_reads - first < eq->sub_batch) ? (n_reads - first) : eq->sub_batch;
+        const uint32_t* list = nullptr;
+        uint32_t todo = cnt;
+        bool flip = false;
+        while (todo) {
+            // new-class budget of this launch: keep load <= 1/2 with room for the guard's slack
+            int64_t free_budget = (int64_t)(eq->cap / 2) - (int64_t)eq->n_classes - (int64_t)kSlack;
+            uint64_t need = todo < kMinHeadroom ? todo : kMinHeadroom;
+            if (free_budget < (int64_t)need) { if ((rc = eq_grow(eq, eq->cap * 2))) return rc; continue; }
+            uint64_t limit_new = (uint64_t)free_budget < todo ? (uint64_t)free_budget : todo;
+            if ((rc = eq->newlist.reserve(limit_new + kSlack, st, false))) return rc;
+            DevBuf<uint32_t>& dout = flip ? eq->deferred_b : eq->deferred_a;
+            if ((rc = dout.reserve(todo, st, false))) return rc;
+            uint64_t cls_need = eq->n_classes + limit_new + kSlack;
+            SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
+            if ((rc = eq->cls_hash.reserve(cls_need, st, true, eq->n_classes))) return rc;
+            if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
+            if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
+            if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
+            SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_insert, dim3(grid_for(todo)), dim3(kBlock), 0, st, d_ids, d_offsets, first, todo, list,
+                               eq->table.p, eq->cap - 1, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->d_ctr,
+                               eq->newlist.p, (unsigned long long)limit_new, dout.p);
+            SF_CHECK_LAUNCH();
+            SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            SF_HIP(hipStreamSynchronize(st));
+            uint64_t n_new = eq->h_ctr[CTR_NEW], n_def = eq->h_ctr[CTR_DEFER];
+            if (n_new) {
+                hipLaunchKernelGGL(k_commit, dim3(grid_for(n_new)), dim3(kBlock), 0, st, d_ids, d_offsets, eq->table.p,
+                                   eq->newlist.p, n_new, eq->n_classes, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p,
+                                   eq->cls_slot.p, eq->arena.p, eq->d_ctr);
+                SF_CHECK_LAUNCH();
+                eq->n_classes += n_new;
+            }
+            if (n_def) {
+                if ((rc = eq_grow(eq, eq->cap * 2))) return rc;   // synchronises: commit has finished
+                list = dout.p; todo = (uint32_t)n_def; flip = !flip;
+            } else {
+                todo = 0;
+            }
+        }
+    }
+    // the caller may reuse its buffers on return: wait for the last commit
+    SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    eq->arena_used = eq->h_ctr[CTR_ARENA];
+    return SFGPU_OK;
+}
+
+int sfgpu_eq_add_batch_host(sfgpu_eq* eq, const uint32_t* h_ids, const uint32_t* h_offsets, uint32_t n_reads) {
+    SF_REQUIRE(eq && h_offsets, SFGPU_ERR_INVALID, "sfgpu_eq_add_batch_host: null pointer");
+    if (n_reads == 0) return SFGPU_OK;
+    SF_REQUIRE(h_offsets[n_reads] >= h_offsets[0], SFGPU_ERR_INVALID, "sfgpu_eq_add_batch_host: offsets not ascending");
+    uint64_t n_ids = h_offsets[n_reads];
+    std::lock_guard<std::mutex> lk(eq->mu);   // mapping threads call this concurrently
+    int rc;
+    if ((rc = eq->stage_ids.reserve(n_ids + 1, eq->stream, false))) return rc;
+    if ((rc = eq->stage_off.reserve((uint64_t)n_reads + 1, eq->stream, false))) return rc;
+    if (n_ids) SF_HIP(hipMemcpyAsync(eq->stage_ids.p, h_ids, n_ids * 4, hipMemcpyHostToDevice, eq->stream));
+    SF_HIP(hipMemcpyAsync(eq->stage_off.p, h_offsets, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, eq->stream));
+    return eq_add_locked(eq, eq->stage_ids.p, eq->stage_off.p, n_reads);
+}
+
+int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads) {
+    SF_REQUIRE(eq && d_offsets, SFGPU_ERR_INVALID, "sfgpu_eq_add_batch: null pointer");
+    std::lock_guard<std::mutex> lk(eq->mu);
+    return eq_add_locked(eq, d_ids, d_offsets, n_reads);
+}
+
+int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* total_reads) {
+    SF_REQUIRE(eq, SFGPU_ERR_INVALID, "sfgpu_eq_finish: null handle");
+    std::lock_guard<std::mutex> lk(eq->mu);
+    hipStream_t st = eq->stream;
+    uint64_t n = eq->n_classes;
+    int rc;
+    if ((rc = eq->order.reserve(n + 1, st, false))) return rc;
+    if ((rc = eq->rowptr64.reserve(n + 2, st, false))) return rc;
+    eq->nnz = eq->arena_used; eq->total_reads = 0;
+    if (n) {
+        DevBuf<uint64_t> keys_in, keys_out; DevBuf<uint32_t> vals_in, lens;
+        if ((rc = keys_in.reserve(n, st, false)) || (rc = keys_out.reserve(n, st, false)) ||
+            (rc = vals_in.reserve(n, st, false)) || (rc = lens.reserve(n + 1, st, false))) return rc;
+        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
+                           eq->arena.p, keys_in.p, vals_in.p);
+        SF_CHECK_LAUNCH();
+        if ((rc = sort_pairs_u64_u32(keys_in.p, keys_out.p, vals_in.p, eq->order.p, n, st))) return rc;
+        hipLaunchKernelGGL(k_tie_fix, dim3(grid_for(n)), dim3(kBlock), 0, st, n, keys_out.p, eq->order.p, eq->cls_hash.p,
+                           eq->cls_off.p, eq->cls_len.p, eq->arena.p);
+        SF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_sorted_lens, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, n, eq->order.p, eq->cls_len.p, lens.p);
+        SF_CHECK_LAUNCH();
+        if ((rc = exclusive_scan_u32(lens.p, eq->rowptr64.p, n, st))) return rc;
+        SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(n)), dim3(kBlock), 0, st, n, eq->table.p, eq->cls_slot.p,
+                           eq->d_ctr + 3);
+        SF_CHECK_LAUNCH();
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        eq->total_reads = eq->h_ctr[3];
+    }
+    eq->finished = true;
+    if (n_classes) *n_classes = n;
+    if (nnz) *nnz = eq->nnz;
+    if (total_reads) *total_reads = eq->total_reads;
+    // the two lines the reference logs in finish() (EquivalenceClassBuilder.hpp:75-78)
+    log_msg(0, "Computed %llu rich equivalence classes for further processing", (unsigned long long)n);
+    log_msg(0, "Counted %llu total reads in the equivalence classes ", (unsigned long long)eq->total_reads);
+    return SFGPU_OK;
+}
+
+int sfgpu_eq_export_device(sfgpu_eq* eq, uint32_t* d_rowptr, uint32_t* d_ids, uint64_t* d_counts, uint64_t* d_hashes) {
+    SF_REQUIRE(eq && d_rowptr, SFGPU_ERR_INVALID, "sfgpu_eq_export: null pointer");
+    std::lock_guard<std::mutex> lk(eq->mu);
+    SF_REQUIRE(eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_export: call finish() first");
+    SF_REQUIRE(eq->nnz < (1ull << 32), SFGPU_ERR_RANGE, "sfgpu_eq_export: nnz does not fit uint32 rowptr");
+    uint64_t n = eq->n_classes;
+    if (n == 0) { SF_HIP(hipMemsetAsync(d_rowptr, 0, 4, eq->stream)); return SFGPU_OK; }
+    SF_REQUIRE(d_ids && d_counts, SFGPU_ERR_INVALID, "sfgpu_eq_export: null pointer");
+    hipLaunchKernelGGL(k_export, dim3(grid_for(n + 1)), dim3(kBlock), 0, eq->stream, n, eq->order.p, eq->rowptr64.p,
+                       eq->table.p, eq->cls_slot.p, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->arena.p,
+                       d_rowptr, d_ids, d_counts, d_hashes);
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
+
+int sfgpu_eq_export_host(sfgpu_eq* eq, uint32_t* h_rowptr, uint32_t* h_ids, uint64_t* h_counts, uint64_t* h_hashes) {
+    SF_REQUIRE(eq && h_rowptr, SFGPU_ERR_INVALID, "sfgpu_eq_export_host: null pointer");
+    uint64_t n, nnz;
+    { std::lock_guard<std::mutex> lk(eq->mu); n = eq->n_classes; nnz = eq->nnz;
+      SF_REQUIRE(eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_export_host: call finish() first"); }
+    DevBuf<uint32_t> rp, ids; DevBuf<uint64_t> cnt, hs;
+    hipStream_t st = eq->stream;
+    int rc;
+    if ((rc = rp.reserve(n + 1, st, false)) || (rc = ids.reserve(nnz + 1, st, false)) ||
+        (rc = cnt.reserve(n + 1, st, false)) || (rc = hs.reserve(n + 1, st, false))) return rc;
+    if ((rc = sfgpu_eq_export_device(eq, rp.p, ids.p, cnt.p, h_hashes ? hs.p : nullptr))) return rc;
+    SF_HIP(hipMemcpyAsync(h_rowptr, rp.p, (n + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (n) {
+        if (nnz) SF_HIP(hipMemcpyAsync(h_ids, ids.p, nnz * 4, hipMemcpyDeviceToHost, st));
+        SF_HIP(hipMemcpyAsync(h_counts, cnt.p, n * 8, hipMemcpyDeviceToHost, st));
+        if (h_hashes) SF_HIP(hipMemcpyAsync(h_hashes, hs.p, n * 8, hipMemcpyDeviceToHost, st));
+    }
+    SF_HIP(hipStreamSynchronize(st));
+    return SFGPU_OK;
+}
+
+}  // extern "C"

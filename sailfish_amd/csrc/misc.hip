@@ -1,0 +1,141 @@
+// misc.hip -- effective lengths (row a14) and the quant.sf columns (row a13).
+//
+// Replaces  src/SailfishQuantify.cpp:648-673 (getNormalFragLengthDist), :769-807
+//           (correctionFactorsFromCounts), :809-838 (computeSmoothedEffectiveLengths),
+//           :706-715 (setEffectiveLengthsDirect) and src/GZipWriter.cpp:216-245 (TPM).
+// The <=1000-entry correction tables are serial prefix sums: they are built on the host in the
+// reference's evaluation order (bit-identical), the O(M) transforms run on the device.
+#include "common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace sfgpu {
+
+constexpr int kMiscBlock = 256;
+constexpr int kMiscMaxBlocks = 1024;
+
+__global__ void k_efflen(uint64_t M, const uint32_t* __restrict__ ref_len, const double* __restrict__ cf,
+                         uint32_t max_len, double* __restrict__ eff) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    uint32_t L = ref_len[t];
+    if (!cf) { eff[t] = (double)L; return; }                       // setEffectiveLengthsDirect
+    double c = (L >= max_len) ? cf[max_len - 1] : cf[L];            // :823-825
+    double e = (double)L - c + 1.0;                                 // :827-828
+    if (e < 1.0) e = (double)L;                                     // :829-831
+    eff[t] = e;
+}
+
+__device__ __forceinline__ double blk_sum(double v, double* lds) {
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < kMiscBlock / kWave; ++i) t += lds[i];
+    __syncthreads();
+    return t;
+}
+
+// tfracDenom = sum_t (estCount_t / numMapped) / len_t   (GZipWriter.cpp:228-234), two-stage
+__global__ void k_tpm_partial(uint64_t M, const double* __restrict__ est, const double* __restrict__ len,
+                              double num_mapped, double* partials) {
+    __shared__ double lds[kMiscBlock / kWave];
+    double v = 0.0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kMiscBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kMiscBlock)
+        v += (est[t] / num_mapped) / len[t];
+    double s = blk_sum(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void k_tpm(uint64_t M, const double* __restrict__ est, const double* __restrict__ len, double num_mapped,
+                      const double* partials, int nb, double* __restrict__ tpm) {
+    __shared__ double lds[kMiscBlock / kWave];
+    __shared__ double denom_s;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kMiscBlock) v += partials[i];
+    double d = blk_sum(v, lds);
+    if (threadIdx.x == 0) denom_s = d;
+    __syncthreads();
+    double denom = denom_s;
+    for (uint64_t t = (uint64_t)blockIdx.x * kMiscBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kMiscBlock) {
+        double npm = est[t] / num_mapped;                           // :241
+        double tfrac = (npm / len[t]) / denom;                      // :242
+        tpm[t] = tfrac * 1000000.0;                                 // :243
+    }
+}
+
+}  // namespace sfgpu
+
+using namespace sfgpu;
+
+extern "C" {
+
+int sfgpu_cf_gaussian(uint32_t max_frag_len, uint64_t mean, uint64_t sd, double* h_cf) {
+    SF_REQUIRE(h_cf && max_frag_len > 0, SFGPU_ERR_INVALID, "sfgpu_cf_gaussian: bad argument");
+    double cum_mass = 0.0, cum_dens = 0.0;
+    for (uint32_t i = 0; i < max_frag_len; ++i) {
+        double inv_std = 1.0 / (double)sd;                          // :657-661 kernel lambda
+        double x = inv_std * ((double)i - (double)mean);
+        double d = std::exp(-0.5 * x * x) * inv_std;
+        cum_mass += (double)i * d;                                  // :666
+        cum_dens += d;
+        h_cf[i] = (cum_dens > 0) ? cum_mass / cum_dens : 0.0;       // :668-670
+    }
+    return SFGPU_OK;
+}
+
+int sfgpu_cf_counts(const uint32_t* h_fl_counts, uint32_t max_frag_len, double* h_cf) {
+    SF_REQUIRE(h_fl_counts && h_cf && max_frag_len > 0, SFGPU_ERR_INVALID, "sfgpu_cf_counts: bad argument");
+    double vals_prev = 0.0;
+    uint32_t mult_prev = h_fl_counts[0];                            // :779-784
+    h_cf[0] = 0.0;
+    for (uint32_t i = 1; i < max_frag_len; ++i) {                   // :791-803
+        uint32_t v = h_fl_counts[i];
+        double vals_i = (double)((uint64_t)v * (uint64_t)i) + vals_prev;
+        uint32_t mult_i = v + mult_prev;
+        h_cf[i] = (mult_i > 0) ? vals_i / (double)mult_i : 0.0;
+        vals_prev = vals_i; mult_prev = mult_i;
+    }
+    return SFGPU_OK;
+}
+
+int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h_cf, uint32_t max_frag_len,
+                          double* d_eff_len, sfgpu_stream stream) {
+    SF_REQUIRE(d_ref_len && d_eff_len, SFGPU_ERR_INVALID, "sfgpu_efflen_smoothed: null pointer");
+    if (M == 0) return SFGPU_OK;
+    hipStream_t st = as_stream(stream);
+    double* d_cf = nullptr;
+    if (h_cf) {
+        SF_REQUIRE(max_frag_len > 0, SFGPU_ERR_INVALID, "sfgpu_efflen_smoothed: max_frag_len == 0");
+        SF_HIP(hipMalloc(&d_cf, (size_t)max_frag_len * 8));
+        hipError_t e = hipMemcpyAsync(d_cf, h_cf, (size_t)max_frag_len * 8, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { (void)hipFree(d_cf); SF_HIP(e); }
+    }
+    hipLaunchKernelGGL(k_efflen, dim3((unsigned)((M + kMiscBlock - 1) / kMiscBlock)), dim3(kMiscBlock), 0, st, M,
+                       d_ref_len, d_cf, max_frag_len, d_eff_len);
+    hipError_t le = hipGetLastError();
+    if (d_cf) { (void)hipStreamSynchronize(st); (void)hipFree(d_cf); }
+    SF_HIP(le);
+    return SFGPU_OK;
+}
+
+int sfgpu_tpm(const double* d_est_count, const double* d_len, uint64_t M, double num_mapped, double* d_tpm,
+              sfgpu_stream stream) {
+    SF_REQUIRE(d_est_count && d_len && d_tpm, SFGPU_ERR_INVALID, "sfgpu_tpm: null pointer");
+    if (M == 0) return SFGPU_OK;
+    hipStream_t st = as_stream(stream);
+    int nb = (int)((M + kMiscBlock - 1) / kMiscBlock);
+    if (nb > kMiscMaxBlocks) nb = kMiscMaxBlocks;
+    double* partials = nullptr;
+    SF_HIP(hipMalloc(&partials, (size_t)kMiscMaxBlocks * 8));
+    hipLaunchKernelGGL(k_tpm_partial, dim3(nb), dim3(kMiscBlock), 0, st, M, d_est_count, d_len, num_mapped, partials);
+    hipLaunchKernelGGL(k_tpm, dim3(nb), dim3(kMiscBlock), 0, st, M, d_est_count, d_len, num_mapped, partials, nb, d_tpm);
+    hipError_t le = hipGetLastError();
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(partials);
+    SF_HIP(le);
+    return SFGPU_OK;
+}
+
+}  // extern "C"

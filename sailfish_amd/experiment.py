@@ -1,0 +1,94 @@
+"""In-memory model the hot path reads and writes -- the host-side mirror of
+include/ReadExperiment.hpp:65-99,236-257, include/Transcript.hpp:14-16,49-81,204-206 and
+include/SailfishOpts.hpp:9-41, laid out for the device: the reference's AoS
+`std::vector<Transcript>` becomes one SoA block resident in HBM."""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class SailfishOpts:
+    """Fields (and defaults) of include/SailfishOpts.hpp that the hot path consults;
+    defaults as set by the CLI table src/SailfishQuantify.cpp:1079-1153."""
+    numThreads: int = 1
+    useVBOpt: bool = False
+    noEffectiveLengthCorrection: bool = False
+    useUnsmoothedFLD: bool = False
+    maxFragLen: int = 1000
+    numFragSamples: int = 10000
+    fragLenDistPriorMean: int = 200
+    fragLenDistPriorSD: int = 80
+    maxReadOccs: int = 200
+    numBootstraps: int = 0
+    numGibbsSamples: int = 0
+    biasCorrect: bool = False
+    gcBiasCorrect: bool = False
+    dumpEq: bool = False
+    auxDir: str = "aux"
+    jointLog: Optional[object] = None   # callable(level:int, msg:str)
+
+
+class Transcripts:
+    """SoA view of std::vector<Transcript>: RefName / RefLength / EffectiveLength host-visible,
+    EffectiveLength, estCount and mass device-resident (float64)."""
+
+    def __init__(self, names: List[str], ref_len, device="cuda"):
+        ref_len = np.ascontiguousarray(ref_len, dtype=np.uint32)
+        assert len(names) == len(ref_len)
+        self.RefName = list(names)
+        self.device = torch.device(device)
+        # stored as raw uint32 bits in an int32 tensor (torch has no uint32 arithmetic)
+        self.RefLength = torch.from_numpy(ref_len.view(np.int32).copy()).to(self.device)
+        M = len(ref_len)
+        # Transcript ctor: EffectiveLength(-1.0) (Transcript.hpp:16); set by the FLD stage
+        self.EffectiveLength = torch.full((M,), -1.0, dtype=torch.float64, device=self.device)
+        self.estCount = torch.zeros(M, dtype=torch.float64, device=self.device)
+        self.mass = torch.zeros(M, dtype=torch.float64, device=self.device)
+        self.active = None
+
+    def __len__(self):
+        return len(self.RefName)
+
+    def ref_length_f64(self):
+        return (self.RefLength.to(torch.int64) & 0xFFFFFFFF).to(torch.float64)
+
+
+class ReadExperiment:
+    """Owner of the transcripts, the equivalence-class builder and the fragment counters
+    (include/ReadExperiment.hpp:65-99, 236-257)."""
+
+    def __init__(self, transcripts: Transcripts, sopt: Optional[SailfishOpts] = None):
+        from .eqclass import EquivalenceClassBuilder
+        self._transcripts = transcripts
+        self._eq = EquivalenceClassBuilder(logger=(sopt.jointLog if sopt else None), device=transcripts.device)
+        self._num_mapped = 0
+        self._num_observed = 0
+        self._fld = None
+
+    def transcripts(self) -> Transcripts:
+        return self._transcripts
+
+    def equivalenceClassBuilder(self):
+        return self._eq
+
+    def numMappedFragments(self) -> int:
+        return self._num_mapped
+
+    def setNumMappedFragments(self, n: int):
+        """numMappedFragmentsAtomic() = n (ReadExperiment.hpp:73)."""
+        self._num_mapped = int(n)
+
+    def numObservedFragments(self) -> int:
+        return self._num_observed
+
+    def setNumObservedFragments(self, n: int):
+        self._num_observed = int(n)
+
+    def fragLengthDist(self):
+        return self._fld
+
+    def setFragLengthDist(self, fld):
+        self._fld = np.asarray(fld, dtype=np.int32)

@@ -1,0 +1,124 @@
+"""CollapsedEMOptimizer -- host mirror of include/CollapsedEMOptimizer.hpp:25-35 /
+src/CollapsedEMOptimizer.cpp:711-893 over the C ABI (sfgpu_em_*)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .experiment import ReadExperiment, SailfishOpts
+
+
+class EMProblem:
+    """Device-resident problem handle (sfgpu_em): CSR of classes + per-transcript lengths."""
+
+    def __init__(self, length_f64, rowptr, ids, counts, num_mapped):
+        self._L = _lib.lib()
+        self.M = int(length_f64.numel())
+        self.C = int(rowptr.numel()) - 1
+        self.device = length_f64.device
+        # keep the tensors alive: the library reads them in place (caller-owned buffers)
+        self._keep = (length_f64.contiguous(), rowptr.contiguous(), ids.contiguous(), counts.contiguous())
+        prob = _lib.Problem(self.M, _lib.ptr(self._keep[0]).value, self.C, _lib.ptr(self._keep[1]).value,
+                            (_lib.ptr(self._keep[2]).value if self._keep[2].numel() else None),
+                            (_lib.ptr(self._keep[3]).value if self._keep[3].numel() else None), int(num_mapped))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(self._L.sfgpu_em_create(C.byref(h), C.byref(prob), _lib.current_stream_ptr()))
+        self._h = h
+        self.alpha = torch.zeros(self.M, dtype=torch.float64, device=self.device)
+        self.mass = torch.zeros(self.M, dtype=torch.float64, device=self.device)
+
+    @staticmethod
+    def opts(use_vbem=False, tol=0.01, min_iter=50, max_iter=10000, check_mode=0, iters_per_launch=0):
+        return _lib.EmOpts(int(use_vbem), float(tol), int(min_iter), int(max_iter), int(check_mode), int(iters_per_launch))
+
+    def optimize(self, **kw):
+        """Run the whole loop on the device; returns (rc, stats dict).  alpha/mass hold estCount/mass."""
+        o = self.opts(**kw)
+        st = _lib.EmStats()
+        rc = self._L.sfgpu_em_optimize(self._h, C.byref(o), _lib.ptr(self.alpha), _lib.ptr(self.mass), C.byref(st))
+        return rc, st.as_dict()
+
+    # piecewise API (multi-GPU driver, tests)
+    def begin(self, **kw):
+        self._o = self.opts(**kw)
+        _lib.check(self._L.sfgpu_em_begin(self._h, C.byref(self._o)))
+
+    def init(self):
+        _lib.check(self._L.sfgpu_em_init(self._h))
+
+    def sweep(self):
+        _lib.check(self._L.sfgpu_em_sweep(self._h))
+
+    def update(self):
+        _lib.check(self._L.sfgpu_em_update(self._h))
+
+    def poll(self):
+        done = C.c_int(); st = _lib.EmStats()
+        _lib.check(self._L.sfgpu_em_poll(self._h, C.byref(done), C.byref(st)))
+        return bool(done.value), st.as_dict()
+
+    def finish(self):
+        st = _lib.EmStats()
+        rc = self._L.sfgpu_em_finish(self._h, _lib.ptr(self.alpha), _lib.ptr(self.mass), C.byref(st))
+        return rc, st.as_dict()
+
+    def alpha_out_view(self):
+        """alphaOut (M float64) as a torch tensor aliasing the library's buffer, for collectives."""
+        p = self._L.sfgpu_em_alpha_out(self._h)
+        return _tensor_from_ptr(p, self.M, self.device)
+
+    def time_sweep(self, n=100, **kw):
+        o = self.opts(**kw); ms = C.c_double()
+        _lib.check(self._L.sfgpu_em_time_sweep(self._h, C.byref(o), int(n), C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.sfgpu_em_destroy(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _tensor_from_ptr(p, n, device):
+    """Zero-copy float64 tensor over device memory owned by the library."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(p), False), "version": 2}
+    return torch.as_tensor(h, device=device)
+
+
+class CollapsedEMOptimizer:
+    """optimize(readExp, sopt, relDiffTolerance, maxIter) exactly as the reference's driver calls
+    it (src/SailfishQuantify.cpp:1341-1343: tolerance 0.01, maxIter 10000)."""
+
+    def __init__(self):
+        self.last_stats = None
+        self._problem = None
+
+    def optimize(self, readExp: ReadExperiment, sopt: SailfishOpts, relDiffTolerance: float = 0.01,
+                 maxIter: int = 1000) -> bool:
+        if sopt.biasCorrect or sopt.gcBiasCorrect:
+            raise NotImplementedError("bias-aware effective lengths are outside the hot path (SURVEY.md 8f.3)")
+        if sopt.jointLog is not None:
+            _lib.set_logger(sopt.jointLog)
+        txps = readExp.transcripts()
+        vec = readExp.equivalenceClassBuilder().eqVec()
+        # :736-737  effLens(i) = noEffectiveLengthCorrection ? RefLength : EffectiveLength
+        length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
+        prob = EMProblem(length, vec.rowptr, vec.ids, vec.counts, readExp.numMappedFragments())
+        self._problem = prob
+        rc, st = prob.optimize(use_vbem=sopt.useVBOpt, tol=relDiffTolerance, min_iter=50, max_iter=maxIter)
+        self.last_stats = st
+        if rc in (_lib.ERR_NO_ACTIVE, _lib.ERR_ALPHA_SUM):
+            return False            # the reference logs and returns false (:794-798, :877-881)
+        _lib.check(rc)
+        txps.estCount.copy_(prob.alpha)    # setEstCount / setMass (:889-890)
+        txps.mass.copy_(prob.mass)
+        return True

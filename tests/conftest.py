@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Everything compiled (libsfgpu.so for gfx950, the C oracle, oracle/_ref when possible)."""
+    import __graft_entry__ as g
+    so = os.path.join(ROOT, "sailfish_amd", "csrc", "libsfgpu.so")
+    if not os.path.exists(so) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; the HIP path has no CPU fallback")
+    return torch.device("cuda:0")
