@@ -1,0 +1,79 @@
+"""CPU tests of the boundary: the shared library builds for gfx950, loads, and exports exactly the
+symbols include/sfgpu.h declares; no compute is possible without a GPU and it says so."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "sfgpu.h")).read()
+    return sorted(set(re.findall(r"SFGPU_API [a-z_ *]+?\b(sfgpu_[a-z0-9_]+)\(", txt)))
+
+
+def test_header_symbols_exported(built):
+    so = os.path.join(ROOT, "sailfish_amd", "csrc", "libsfgpu.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = sorted(set(re.findall(r" T (sfgpu_[a-z0-9_]+)", out)))
+    decl = _declared()
+    assert len(decl) >= 28
+    assert exported == decl
+
+
+def test_python_binding_matches_header(built):
+    from sailfish_amd import _lib
+    assert _lib.exported_symbols() == _declared()
+    L = _lib.lib()
+    assert L.sfgpu_version() == 100
+
+
+def test_header_is_plain_c(built, tmp_path):
+    """the boundary is a C ABI: the header must compile as C with no HIP/torch in sight"""
+    src = tmp_path / "t.c"
+    src.write_text('#include "sfgpu.h"\nint main(void){ sfgpu_problem p; sfgpu_em_opts o; (void)p; (void)o; return SFGPU_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "t.o")])
+
+
+def test_library_links_only_hip_runtime(built):
+    so = os.path.join(ROOT, "sailfish_amd", "csrc", "libsfgpu.so")
+    out = subprocess.check_output(["readelf", "-d", so], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any(n.startswith("libamdhip64") for n in needed)
+    assert not any("torch" in n or "c10" in n or "oracle" in n for n in needed)
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sailfish_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    rc = L.sfgpu_eq_create(C.byref(h), 0, None)
+    assert rc == _lib.ERR_HIP and b"device" in L.sfgpu_last_error().lower()
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under sailfish_amd/ may reference it"""
+    pkg = os.path.join(ROOT, "sailfish_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert "oracle" not in txt.lower(), os.path.join(dp, fn)
+
+
+def test_cf_tables_host_side(built):
+    """the correction tables are host-side serial prefix sums: callable without a GPU, bit-equal to the oracle"""
+    import numpy as np
+    from oracle import oracle as O
+    from sailfish_amd import SailfishOpts, efflen
+    np.testing.assert_array_equal(efflen.normal_cf(SailfishOpts()), O.cf_gaussian())
+    np.testing.assert_array_equal(efflen.normal_counts(SailfishOpts()), O.fld_gaussian_counts())
+    fl = O.fld_gaussian_counts().astype(np.uint32)
+    np.testing.assert_array_equal(efflen.counts_cf(fl), O.cf_counts(fl))

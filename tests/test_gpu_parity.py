@@ -1,0 +1,306 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the golden fixtures, and -- at BASELINE.json's full size -- through
+size-independent properties.  Bar: bit-exact for hashes / class labels / counts; TPM and NumReads
+within 1e-4 relative (north_star), and in practice ~1e-12."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 1e-4          # north_star: TPM / NumReads within 1e-4 relative
+TIGHT = 1e-9            # what we actually hold ourselves to on these sizes
+
+
+def _pack(reads):
+    off = np.zeros(len(reads) + 1, np.uint32)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    ids = np.concatenate([np.asarray(r, np.uint32) for r in reads]) if off[-1] else np.zeros(0, np.uint32)
+    return ids.astype(np.uint32), off
+
+
+def _oracle_classes(batches):
+    b = O.EqBuilder()
+    for ids, off in batches:
+        b.add_batch(ids, off.astype(np.uint64))
+    rp, ii, cc, hh = b.finish()
+    return b, rp.astype(np.uint32), ii, cc, hh
+
+
+def _gpu_classes(sf, gpu, batches, device_batches=True, **kw):
+    import torch
+    eq = sf.EquivalenceClassBuilder(device=gpu, **kw)
+    eq.start()
+    for ids, off in batches:
+        if device_batches:
+            eq.add_batch(torch.from_numpy(ids.view(np.int32)).to(gpu), torch.from_numpy(off.view(np.int32)).to(gpu))
+        else:
+            eq.add_batch(ids, off)
+    eq.finish()
+    return eq
+
+
+def _assert_same_classes(eq, ob, orp, oids, ocnt, ohash):
+    rp, ii, cc, hh = eq.eqVec().to_numpy()
+    assert (eq.n_classes, eq.nnz, eq.total_reads) == (ob.n_classes, ob.nnz, ob.total_reads)
+    np.testing.assert_array_equal(rp, orp); np.testing.assert_array_equal(ii, oids)
+    np.testing.assert_array_equal(cc, ocnt); np.testing.assert_array_equal(hh, ohash)
+
+
+@pytest.fixture(scope="module")
+def sf(gpu):
+    import sailfish_amd
+    return sailfish_amd
+
+
+# ---------------------------------------------------------------------------------------- a1
+def test_xxh64_kernel_golden_and_random(sf, gpu):
+    g = json.load(open(os.path.join(GOLD, "xxh64_vectors.json")))["vectors"]
+    reads = [np.array(v["ids"], np.uint32) for v in g]
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 70)) + [127, 128, 129, 199, 200, 201, 1000]:
+        reads.append(rng.integers(0, 2 ** 32, n, dtype=np.uint32))
+    ids, off = _pack(reads)
+    got = sf.xxh64_labels(ids, off, device=gpu).cpu().numpy().view(np.uint64)
+    for i, v in enumerate(g):
+        assert "%016x" % int(got[i]) == v["xxh64"]
+    np.testing.assert_array_equal(got, O.xxh64_lists(ids, off.astype(np.uint64)))
+
+
+# ------------------------------------------------------------------------------------- a2-a5
+def test_builder_kat_and_edge_cases(sf, gpu):
+    rng = np.random.default_rng(9)
+    reads = [[1, 2, 3]] * 3 + [[5]] * 2 + [[2, 9]]                       # SURVEY 8c builder KAT
+    reads += [[], [], [7], [1, 2], [2, 1], [1, 1, 2], [1, 2, 1]] * 2     # empties, permutations, repeated ids
+    reads += [list(range(200)), list(range(200)), list(range(199, -1, -1))]   # maxReadOccs-long labels
+    for _ in range(20000):
+        n = int(rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 16, 33]))
+        reads.append(rng.integers(1000, 1040, n).tolist())
+    batch = _pack(reads)
+    ob, *oc = _oracle_classes([batch])
+    for dev in (True, False):
+        eq = _gpu_classes(sf, gpu, [batch], device_batches=dev)
+        _assert_same_classes(eq, ob, *oc)
+    rp, ii, cc, _ = eq.eqVec().to_numpy()
+    got = {tuple(ii[rp[c]:rp[c + 1]]): int(cc[c]) for c in range(eq.n_classes)}
+    assert got[(1, 2, 3)] == 3 and got[(5,)] == 2 and got[(2, 9)] == 1
+    assert got[(1, 2)] == 2 and got[(2, 1)] == 2 and got[(1, 1, 2)] == 2 and got[tuple(range(200))] == 2
+
+
+def test_builder_empty_and_reuse(sf, gpu):
+    eq = sf.EquivalenceClassBuilder(device=gpu)
+    eq.start(); eq.finish()
+    assert eq.n_classes == 0 and eq.total_reads == 0 and eq.eqVec().size() == 0
+    eq.start()
+    eq.add_batch(np.zeros(0, np.uint32), np.zeros(4, np.uint32))        # three empty reads
+    eq.addGroup([3, 4]); eq.addGroup([3, 4]); eq.addGroup([9])
+    eq.finish()
+    rp, ii, cc, _ = eq.eqVec().to_numpy()
+    assert eq.n_classes == 2 and eq.total_reads == 3 and sorted(cc.tolist()) == [1, 2]
+    eq.start()                                                           # reuse clears
+    eq.addGroup([1]); eq.finish()
+    assert eq.n_classes == 1 and eq.total_reads == 1
+
+
+def test_builder_batching_and_order_independence(sf, gpu):
+    """same multiset of reads in one batch, many batches, shuffled: identical canonical export"""
+    from sailfish_amd import synth
+    _, ids, off = synth.workload(5000, 20000, 300_000)
+    ids = ids.numpy().view(np.uint32); off = off.numpy().view(np.uint32)
+    ob, *oc = _oracle_classes([(ids, off)])
+    eq = _gpu_classes(sf, gpu, [(ids, off)]); _assert_same_classes(eq, ob, *oc)
+    cuts = [0, 1, 1000, 1001, 150_000, 299_999, 300_000]
+    parts = [(ids[off[a]:off[b]].copy(), (off[a:b + 1] - off[a]).astype(np.uint32)) for a, b in zip(cuts[:-1], cuts[1:])]
+    eq = _gpu_classes(sf, gpu, parts); _assert_same_classes(eq, ob, *oc)
+    eq = _gpu_classes(sf, gpu, parts[::-1], device_batches=False); _assert_same_classes(eq, ob, *oc)
+
+
+def test_builder_growth_and_deferral(sf, gpu, monkeypatch):
+    """more distinct classes than the initial table budget: deferred reads are replayed after growth"""
+    monkeypatch.setenv("SFGPU_EQ_SUBBATCH", "65536")
+    rng = np.random.default_rng(2)
+    n = 3_500_000                                   # > 2^21 - slack distinct labels
+    a = rng.permutation(n).astype(np.uint32)
+    ids = np.stack([a, a[::-1] % 7], 1).reshape(-1).astype(np.uint32)   # all-distinct 2-id labels
+    off = (np.arange(n + 1, dtype=np.uint64) * 2).astype(np.uint32)
+    dup = 200_000
+    ids = np.concatenate([ids, ids[:2 * dup]]); off = np.concatenate([off, off[-1] + off[1:dup + 1]])
+    eq = _gpu_classes(sf, gpu, [(ids, off)], expected_classes=1000)
+    rp, ii, cc, hh = eq.eqVec().to_numpy()
+    assert eq.n_classes == n and eq.total_reads == n + dup and int(cc.sum()) == n + dup
+    lab = ii.reshape(-1, 2)
+    assert np.array_equal(np.sort(lab[:, 0]), np.arange(n, dtype=np.uint32))
+    two = lab[cc == 2][:, 0]
+    assert len(two) == dup and set(two.tolist()) == set(a[:dup].tolist())
+    np.testing.assert_array_equal(hh, O.xxh64_lists(ii, rp.astype(np.uint64)))
+    first = lab[:, 0].astype(np.uint64)
+    assert np.all(np.diff(first) >= 0)              # canonical order: first id ascending (then hash)
+
+
+# ------------------------------------------------------------------------------------ a6-a13
+@pytest.fixture(scope="module")
+def midsize(sf, gpu):
+    """M=5000 transcripts, 20000-label pool, 400k reads: classes via the oracle, shared by the EM tests"""
+    from sailfish_amd import synth
+    ref_len, ids, off = synth.workload(5000, 20000, 400_000)
+    ref_len = ref_len.numpy().view(np.uint32)
+    ob, rp, ii, cc, hh = _oracle_classes([(ids.numpy().view(np.uint32), off.numpy().view(np.uint32))])
+    eff = O.efflen_smoothed(ref_len, O.cf_gaussian())
+    return dict(ref_len=ref_len, eff=eff, rowptr=rp, ids=ii, counts=cc, R=400_000)
+
+
+def _gpu_em(sf, gpu, length, rp, ii, cc, num_mapped):
+    import torch
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(gpu)
+    return sf.EMProblem(torch.from_numpy(np.ascontiguousarray(length, dtype=np.float64)).to(gpu),
+                        t(rp.astype(np.uint32), np.int32), t(ii.astype(np.uint32), np.int32),
+                        t(cc.astype(np.uint64), np.int64), num_mapped)
+
+
+def _rel(a, b):
+    nz = b > 0
+    assert np.array_equal(a > 0, nz), "support differs"
+    return float(np.max(np.abs(a[nz] - b[nz]) / b[nz])) if nz.any() else 0.0
+
+
+@pytest.mark.parametrize("vb", [False, True])
+@pytest.mark.parametrize("n_iter", [1, 2, 50, 200])
+def test_em_fixed_iterations(sf, gpu, midsize, vb, n_iter):
+    """tol = 0 never converges: exactly max(n_iter, min_iter) iterations on both sides"""
+    m = midsize
+    rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"], use_vbem=vb, tol=0.0,
+                                    min_iter=0, max_iter=n_iter)
+    p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    grc, st = p.optimize(use_vbem=vb, tol=0.0, min_iter=0, max_iter=n_iter, iters_per_launch=7)
+    assert rc == 0 and grc == 0 and st["iters"] == ost["iters"] == n_iter
+    assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+    assert _rel(p.mass.cpu().numpy(), om) < TIGHT
+    assert abs(st["max_rel_diff"] - ost["max_rel_diff"]) <= 1e-9 * abs(ost["max_rel_diff"])
+    assert abs(st["alpha_sum"] - ost["alpha_sum"]) <= 1e-9 * ost["alpha_sum"]
+
+
+@pytest.mark.parametrize("vb", [False, True])
+def test_em_to_convergence_matches_stop_iteration(sf, gpu, midsize, vb):
+    m = midsize
+    rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"], use_vbem=vb)
+    p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    for chunk in (0, 1, 13):                         # the stop iteration must not depend on the polling chunk
+        grc, st = p.optimize(use_vbem=vb, iters_per_launch=chunk)
+        assert grc == 0 and st["iters"] == ost["iters"] and st["converged"] == ost["converged"]
+        assert st["n_active"] == ost["n_active"]
+        a = p.alpha.cpu().numpy()
+        assert _rel(a, oa) < REL_TOL and _rel(a, oa) < TIGHT
+    # quant.sf columns
+    import torch
+    from sailfish_amd import _lib
+    tp = torch.zeros_like(p.alpha)
+    _lib.check(_lib.lib().sfgpu_tpm(_lib.ptr(p.alpha), _lib.ptr(torch.from_numpy(m["eff"]).to(gpu)), len(oa), float(m["R"]),
+                                    _lib.ptr(tp), None))
+    torch.cuda.synchronize()
+    ot = O.tpm(oa, m["eff"], m["R"])
+    assert _rel(tp.cpu().numpy(), ot) < TIGHT and abs(float(tp.sum()) - 1e6) < 1e-3
+
+
+def test_em_survey_kat(sf, gpu):
+    """the only reference-binary EM outputs we hold"""
+    k = json.load(open(os.path.join(GOLD, "survey_kat.json")))
+    for key in ("em_toy5", "em_toy7"):
+        t = k[key]
+        eff = np.array(t["ref_len"], float) - t["eff_len_minus"]
+        rp = np.zeros(len(t["classes"]) + 1, np.uint32); rp[1:] = np.cumsum([len(c) for c in t["classes"]])
+        ii = np.array([x for c in t["classes"] for x in c], np.uint32); cc = np.array(t["counts"], np.uint64)
+        p = _gpu_em(sf, gpu, eff, rp, ii, cc, t["num_mapped"])
+        rc, st = p.optimize()
+        assert rc == 0
+        if key == "em_toy5":
+            assert st["iters"] == t["stop_iter"]
+            np.testing.assert_allclose(p.alpha.cpu().numpy(), t["em_est_count"], rtol=1e-12)
+            np.testing.assert_allclose(p.mass.cpu().numpy(), t["em_mass"], rtol=1e-12)
+            rc, st = p.optimize(use_vbem=True)
+            np.testing.assert_allclose(p.alpha.cpu().numpy(), t["vbem_est_count"], rtol=1e-11)
+        else:
+            np.testing.assert_allclose(p.alpha.cpu().numpy(), t["em_est_count_6dp"], atol=6e-7)
+
+
+def test_em_error_paths_and_degenerate_inputs(sf, gpu):
+    from sailfish_amd import _lib
+    eff = np.array([10.0, 20.0, 0.5])
+    p = _gpu_em(sf, gpu, eff, np.array([0], np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint64), 0)
+    rc, st = p.optimize()
+    assert rc == _lib.ERR_NO_ACTIVE                 # optimize() returns false: "no transcripts expressed"
+    p = _gpu_em(sf, gpu, eff, np.array([0, 1], np.uint32), np.array([1], np.uint32), np.array([0], np.uint64), 0)
+    rc, st = p.optimize()
+    assert rc == _lib.ERR_ALPHA_SUM                 # "total alpha weight was too small"
+    # singleton classes only + an effective length below 1 (clamped to 1, :738)
+    rp = np.array([0, 1, 2, 4], np.uint32); ii = np.array([0, 2, 1, 2], np.uint32); cc = np.array([5, 7, 11], np.uint64)
+    p = _gpu_em(sf, gpu, eff, rp, ii, cc, 23)
+    rc, st = p.optimize()
+    orc, oa, om, ost = O.em_optimize(eff, rp.astype(np.uint64), ii, cc, 23)
+    assert rc == 0 and orc == 0 and st["iters"] == ost["iters"]
+    assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+    with pytest.raises(_lib.SfgpuError):            # counts must fit 32 bits on the device
+        _gpu_em(sf, gpu, eff, rp, ii, np.array([5, 2 ** 32, 11], np.uint64), 23)
+
+
+def test_em_piecewise_equals_optimize(sf, gpu, midsize):
+    """the sweep/update pieces driven from the host (the multi-GPU control flow) stop at the same
+    iteration with the same numbers as the on-device loop"""
+    m = midsize
+    p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    rc, st_ref = p.optimize(use_vbem=True)
+    want = p.alpha.clone()
+    p.begin(use_vbem=True, tol=0.01, min_iter=50, max_iter=10000)
+    ao = p.alpha_out_view()
+    assert ao.numel() == len(m["eff"]) and float(ao.sum()) == st_ref["n_active"]
+    p.init()
+    done = False
+    while not done:
+        for _ in range(10):
+            p.sweep(); p.update()
+        done, st = p.poll()
+    rc, st = p.finish()
+    assert rc == 0 and st["iters"] == st_ref["iters"]
+    assert _rel(p.alpha.cpu().numpy(), want.cpu().numpy()) < 1e-12
+
+
+def test_efflen_and_end_to_end_driver(sf, gpu, midsize, tmp_path):
+    """the reference's call sequence (mainQuantify): start / addGroup / finish / FLD / optimize / quant.sf"""
+    from sailfish_amd import synth
+    m = midsize
+    _, ids, off = synth.workload(5000, 20000, 400_000)
+    names = [f"tx{i}" for i in range(len(m["ref_len"]))]
+    for noeff in (False, True):
+        sopt = sf.SailfishOpts(noEffectiveLengthCorrection=noeff)
+        exp = sf.ReadExperiment(sf.Transcripts(names, m["ref_len"], device=gpu), sopt)
+        eq = exp.equivalenceClassBuilder()
+        eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); assert eq.finish()
+        exp.setNumMappedFragments(eq.total_reads)
+        sf.efflen.set_effective_lengths(exp, sopt)
+        want_len = m["ref_len"].astype(np.float64) if noeff else m["eff"]
+        np.testing.assert_array_equal(exp.transcripts().EffectiveLength.cpu().numpy(), want_len)   # bit exact
+        assert sf.CollapsedEMOptimizer().optimize(exp, sopt, 0.01, 10000)
+        rc, oa, om, ost = O.em_optimize(want_len, m["rowptr"], m["ids"], m["counts"], m["R"])
+        assert _rel(exp.transcripts().estCount.cpu().numpy(), oa) < TIGHT
+        out = tmp_path / ("q1" if noeff else "q0")
+        sf.writer.write_abundances(str(out), exp, sopt)
+        sf.writer.write_equiv_counts(str(out), exp, sopt)
+        rows = open(out / "quant.sf").read().splitlines()
+        assert rows[0] == "Name\tLength\tEffectiveLength\tTPM\tNumReads" and len(rows) == len(names) + 1
+        ot = O.tpm(oa, want_len, m["R"])
+        for i in (0, 17, 4999):
+            f = rows[i + 1].split("\t")
+            assert f[0] == names[i] and int(f[1]) == m["ref_len"][i]
+            assert f[3] == "%g" % ot[i] or abs(float(f[3]) - ot[i]) <= 1e-5 * max(ot[i], 1e-300)
+            assert f[4] == "%g" % oa[i] or abs(float(f[4]) - oa[i]) <= 1e-5 * max(oa[i], 1e-300)
+        eqf = open(out / "aux" / "eq_classes.txt").read().splitlines()
+        assert int(eqf[0]) == len(names) and int(eqf[1]) == eq.n_classes and len(eqf) == 2 + len(names) + eq.n_classes
+    # empirical FLD branch (>= numFragSamples unique pairs)
+    sopt = sf.SailfishOpts()
+    exp = sf.ReadExperiment(sf.Transcripts(names, m["ref_len"], device=gpu), sopt)
+    fl = O.fld_gaussian_counts(1000, 250, 60, 20000).astype(np.uint32)
+    sf.efflen.set_effective_lengths(exp, sopt, fl_counts=fl, remaining_fl_ops=0)
+    np.testing.assert_array_equal(exp.transcripts().EffectiveLength.cpu().numpy(), O.efflen_smoothed(m["ref_len"], O.cf_counts(fl)))

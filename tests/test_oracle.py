@@ -1,0 +1,157 @@
+"""CPU tests: the oracle against every golden / known-answer vector we hold for the hot path."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _csr(classes):
+    rowptr = np.zeros(len(classes) + 1, np.uint64)
+    rowptr[1:] = np.cumsum([len(c) for c in classes])
+    ids = np.array([t for c in classes for t in c], np.uint32)
+    return rowptr, ids
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return json.load(open(os.path.join(GOLD, "survey_kat.json")))
+
+
+def test_xxh64_golden_vectors(built):
+    """fixture generated from the reference's own xxhash.c (tests/golden/make_xxh64_golden.py)"""
+    g = json.load(open(os.path.join(GOLD, "xxh64_vectors.json")))
+    assert len(g["vectors"]) >= 40
+    for v in g["vectors"]:
+        assert "%016x" % O.xxh64(np.array(v["ids"], np.uint32).tobytes()) == v["xxh64"], v["ids"]
+
+
+def test_xxh64_survey_kat(built):
+    for ids, want in [([], "ef46db3751d8e999"), ([5], "c3d48b2f79d2b939"), ([2, 9], "b6e5dcf465f8e9bc"),
+                      ([1, 2, 3], "b5148cb100a911fc"), (list(range(9)), "05df6b7adb49d27f")]:
+        assert "%016x" % O.xxh64(np.array(ids, np.uint32).tobytes()) == want
+
+
+def test_xxh64_vs_compiled_reference_and_pypi(built):
+    """oracle == oracle/_ref (reference xxhash.c, when built) == python-xxhash, all byte lengths 0..300"""
+    import xxhash
+    R = O.ref_xxhash()
+    rng = np.random.default_rng(1)
+    for n in range(0, 301):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        h = O.xxh64(b)
+        assert h == xxhash.xxh64(b, seed=0).intdigest()
+        if R is not None:
+            buf = C.create_string_buffer(b, len(b))
+            assert h == R.XXH64(C.cast(buf, C.c_void_p), len(b), 0)
+    assert O.xxh64(b"abc", seed=7) == xxhash.xxh64(b"abc", seed=7).intdigest()
+
+
+def test_builder_survey_kat(built, kat):
+    k = kat["builder"]
+    b = O.EqBuilder()
+    for r in k["reads"]:
+        b.add_batch(np.array(r, np.uint32), np.array([0, len(r)], np.uint64))
+    rowptr, ids, counts, hashes = b.finish()
+    assert b.n_classes == k["n_classes"] and b.total_reads == k["total"]
+    got = {",".join(map(str, ids[rowptr[c]:rowptr[c + 1]])): int(counts[c]) for c in range(b.n_classes)}
+    assert got == k["counts_by_label"]
+
+
+def test_builder_semantics_vs_dict(built):
+    """ordered lists are the key: permutations and duplicate ids are distinct classes; empties skipped"""
+    rng = np.random.default_rng(3)
+    reads = []
+    for _ in range(5000):
+        n = int(rng.choice([0, 1, 1, 2, 3, 7, 8, 9, 40, 200]))
+        reads.append(rng.integers(0, 30, n).astype(np.uint32))
+    reads += [np.array([1, 2], np.uint32), np.array([2, 1], np.uint32), np.array([1, 1, 2], np.uint32)] * 3
+    off = np.zeros(len(reads) + 1, np.uint64); off[1:] = np.cumsum([len(r) for r in reads])
+    b = O.EqBuilder(); b.add_batch(np.concatenate(reads), off)
+    rowptr, ids, counts, hashes = b.finish()
+    want = {}
+    for r in reads:
+        if len(r):
+            want[tuple(r.tolist())] = want.get(tuple(r.tolist()), 0) + 1
+    got = {tuple(ids[rowptr[c]:rowptr[c + 1]].tolist()): int(counts[c]) for c in range(b.n_classes)}
+    assert got == want and b.total_reads == sum(want.values())
+    # canonical order: (first id, hash, len, label)
+    keys = [(int(ids[rowptr[c]]), int(hashes[c]), int(rowptr[c + 1] - rowptr[c])) for c in range(b.n_classes)]
+    assert keys == sorted(keys)
+    for c in range(b.n_classes):
+        assert int(hashes[c]) == O.xxh64(ids[rowptr[c]:rowptr[c + 1]].tobytes())
+
+
+def test_em_survey_kat_toy5(built, kat):
+    k = kat["em_toy5"]
+    eff = np.array(k["ref_len"], float) - k["eff_len_minus"]
+    rowptr, ids = _csr(k["classes"]); cnt = np.array(k["counts"], np.uint64)
+    rc, a, m, st = O.em_optimize(eff, rowptr, ids, cnt, k["num_mapped"], tol=k["tol"], max_iter=k["max_iter"])
+    assert rc == 0 and st["iters"] == k["stop_iter"]
+    np.testing.assert_allclose(a, k["em_est_count"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(m, k["em_mass"], rtol=1e-14, atol=0)
+    rc, a, m, st = O.em_optimize(eff, rowptr, ids, cnt, k["num_mapped"], use_vbem=True, tol=k["tol"], max_iter=k["max_iter"])
+    assert rc == 0
+    # VBEM ran through a stand-in digamma in the survey build too; agreement is to ~1e-13
+    np.testing.assert_allclose(a, k["vbem_est_count"], rtol=1e-12, atol=0)
+
+
+def test_em_survey_kat_toy7_and_sampling(built, kat):
+    k = kat["em_toy7"]
+    eff = np.array(k["ref_len"], float) - k["eff_len_minus"]
+    rowptr, ids = _csr(k["classes"]); cnt = np.array(k["counts"], np.uint64)
+    rc, a, m, st = O.em_optimize(eff, rowptr, ids, cnt, k["num_mapped"])
+    assert rc == 0
+    np.testing.assert_allclose(a, k["em_est_count_6dp"], atol=6e-7)
+    # sampling paths are random_device seeded in the reference: distributional agreement only
+    rc, bs, _ = O.bootstrap(eff, rowptr, ids, cnt, 400, seed=11)
+    assert rc == 0 and np.all(np.abs(bs.mean(0) - np.array(k["bootstrap_mean_200"])) < 4 * bs.std(0) / np.sqrt(200) + 0.5)
+    rc, gs = O.gibbs(eff, m, rowptr, ids, cnt, k["num_mapped"], 2000, seed=5)
+    assert rc == 0 and np.all(gs.sum(1) == k["num_mapped"])
+    assert np.all(np.abs(gs.mean(0) - np.array(k["gibbs_mean_200"])) < 12.0)
+
+
+def test_em_error_paths(built):
+    eff = np.array([10.0, 20.0])
+    rc, *_ = O.em_optimize(eff, np.array([0], np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint64), 0)
+    assert rc == 1          # "no transcripts expressed"
+    rc, a, m, st = O.em_optimize(eff, np.array([0, 1], np.uint64), np.array([1], np.uint32), np.array([0], np.uint64), 0)
+    assert rc == 2          # alpha sum too small
+
+
+def test_digamma_vs_scipy(built):
+    from scipy.special import digamma
+    xs = np.concatenate([np.logspace(-8, 8, 400), [0.01, 1.0, 1.4616321449683623, 2.0, 10.0, 485.0]])
+    got = np.array([O.digamma(x) for x in xs])
+    want = digamma(xs)
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 5e-15
+
+
+def test_efflen_tables(built):
+    cf = O.cf_gaussian(1000, 200, 80)
+    assert cf[0] == 0.0 and np.all(np.diff(cf) >= 0) and abs(cf[999] - 202.0) < 3.0
+    i = np.arange(1000.0); d = np.exp(-0.5 * ((i - 200) / 80.0) ** 2) / 80.0
+    np.testing.assert_allclose(cf[1:], (np.cumsum(i * d) / np.cumsum(d))[1:], rtol=1e-12)
+    fld = O.fld_gaussian_counts()
+    assert abs(int(fld.sum()) - 10000) <= 40 and fld[200] == fld.max()
+    cfc = O.cf_counts(fld.astype(np.uint32))
+    assert abs(cfc[999] - cf[999]) < 0.5
+    ref_len = np.array([1, 50, 199, 200, 201, 999, 1000, 1001, 100000], np.uint32)
+    eff = O.efflen_smoothed(ref_len, cf)
+    for L, e in zip(ref_len, eff):
+        c = cf[min(int(L), 999)]
+        want = float(L) - c + 1.0
+        assert e == (want if want >= 1.0 else float(L))
+
+
+def test_tpm_columns(built):
+    rng = np.random.default_rng(0)
+    a = rng.random(100) * 50; a[::7] = 0; ln = rng.integers(200, 5000, 100).astype(float)
+    t = O.tpm(a, ln, a.sum())
+    assert abs(t.sum() - 1e6) < 1e-6 and np.all(t[::7] == 0)
+    np.testing.assert_allclose(t, (a / ln) / (a / ln).sum() * 1e6, rtol=1e-12)
