@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- whole-job throughput of the Sailfish quantification hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: packed quasi-mapping hit lists -> equivalence classes (start / addGroup / finish / eqVec)
+-> effective lengths -> EM (or VBEM) to convergence -> TPM / NumReads.  Read parsing and the
+quasi-mapper are third-party code outside the path and outside every timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|small]
+
+N = 1 : configs[1] of BASELINE.json ("cfg2": 50M single-end reads, 80k-transcript index, EM to
+        convergence), the configuration the metric is quoted on.
+N > 1 : launched by torch.distributed.run, one rank per GPU.  Weak scaling: every rank quantifies
+        its own R-read shard of ONE experiment; class tables are merged with one all-gather and the
+        EM runs on the merged classes (see sailfish_amd/distributed.py for the exchange).
+
+Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline ...).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (M transcripts, P label pool, R reads per GPU, VBEM?, paired-end?)
+    "small": (5_000, 20_000, 2_000_000, False, False),
+    "cfg2": (80_000, 1_000_000, 50_000_000, False, False),
+    "cfg3": (200_000, 4_000_000, 400_000_000, True, True),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md): 8 TB/s HBM3E
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--em-mode", default="auto", choices=["auto", "replicated", "sharded"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(ref_len_np, ids_t, off_t, target_s, use_vbem):
+    """The oracle (C restatement of the reference, 1 thread) timed on a bounded sample of the
+    same workload: class build on the first reads of the batch, then EM on the classes of that
+    sample for a bounded number of iterations; combined into the metric's unit (reads/s) by
+    scaling the EM leg to the iteration count the full problem needs."""
+    from oracle import oracle as O
+    n_build = 2_000_000
+    n_build = min(n_build, off_t.numel() - 1)
+    off = (off_t[: n_build + 1].long() & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
+    ids = ids_t[: int(off[-1])].cpu().numpy().view(np.uint32)
+    b = O.EqBuilder()
+    t0 = time.perf_counter()
+    b.add_batch(ids, off)
+    rp, ii, cc, hh = b.finish()
+    t_build = time.perf_counter() - t0
+    build_rate = n_build / t_build
+    eff = O.efflen_smoothed(ref_len_np, O.cf_gaussian())
+    # time a fixed number of iterations, sized to the remaining budget
+    t0 = time.perf_counter()
+    O.em_optimize(eff, rp, ii, cc, n_build, use_vbem=use_vbem, tol=0.0, min_iter=0, max_iter=3)
+    per_iter = (time.perf_counter() - t0) / 3
+    n_it = int(max(5, min(400, (target_s - t_build) / max(per_iter, 1e-6))))
+    t0 = time.perf_counter()
+    O.em_optimize(eff, rp, ii, cc, n_build, use_vbem=use_vbem, tol=0.0, min_iter=0, max_iter=n_it)
+    per_iter = (time.perf_counter() - t0) / n_it
+    return dict(build_reads_per_s=build_rate, em_ms_per_iter=per_iter * 1e3, sample_reads=n_build,
+                sample_classes=int(b.n_classes), sample_nnz=int(b.nnz), sample_em_iters=n_it)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import sailfish_amd as sf
+    from sailfish_amd import synth
+    from sailfish_amd import distributed as sfd
+
+    M, P, R, use_vbem, paired = WORKLOADS[a.workload]
+    # ---- synthetic inputs, generated on the device and left resident in HBM (untimed) ----------
+    ref_len = synth.transcript_lengths(M, device=dev)
+    poff, pids = synth.label_pool(M, P, device=dev)
+    ids, off = synth.reads_from_pool(poff, pids, R, seed=7 + 1000 * rank, device=dev)   # this rank's shard
+    del poff, pids
+    ref_len_np = ref_len.cpu().numpy().view(np.uint32)
+    n_hits = ids.numel()
+    names = [f"T{i}" for i in range(M)]
+    sopt = sf.SailfishOpts(useVBOpt=use_vbem)
+    # paired-end configs exercise the empirical FLD branch (>= numFragSamples unique pairs)
+    fl_counts = None
+    if paired:
+        i = np.arange(1000.0)
+        fl_counts = np.floor(np.exp(-0.5 * ((i - 200.0) / 80.0) ** 2) * 4000 + 0.5).astype(np.uint32)
+    exp = sf.ReadExperiment(sf.Transcripts(names, ref_len_np, device=dev), sopt)
+    quant = sfd.DistributedQuant(exp, sopt, group=(dist.group.WORLD if dist else None), em_mode=a.em_mode)
+    torch.cuda.synchronize()
+
+    def step():
+        return quant.run(ids, off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        info = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        info = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_reads = R * world * a.steps
+    value = total_reads / dt
+    st = info["em_stats"]
+    C, L = info["n_classes"], info["nnz"]
+
+    # ---- roofline of the dominant kernel, measured live with HIP events ------------------------
+    # EM sweep: algorithmic bytes per launch, aux-weight-free variant:
+    #   B_iter' = 4L + 8C + 48M   (+16M for VBEM's expTheta vector)
+    b_iter = 4 * L + 8 * C + 48 * M + (16 * M if use_vbem else 0)
+    sweep_ms = quant.time_sweep(200)
+    em_loop_ms_per_iter = st["loop_ms"] / max(st["iters"], 1)
+    # class build: B_read = 4*h + 4 (offset) + 16 (one slot probe) bytes per read
+    b_read = 4.0 * n_hits / R + 20.0
+    build_ms = info["t_build_ms"]
+    em_ms = info["t_em_ms"]
+    roof_em = dict(bound="hbm", kernel="k_sweep", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                   unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                   bytes_per_launch=b_iter, avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
+    roof_build = dict(bound="hbm", kernel="k_insert", achieved=b_read * R / (info["t_insert_ms"] * 1e-3) / 1e9,
+                      peak=HBM_PEAK_GBS, unit="GB/s",
+                      frac=b_read * R / (info["t_insert_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                      bytes_per_launch=b_read * R, avg_launch_ms=info["t_insert_ms"], launches_per_step=1)
+    dominant = roof_em if sweep_ms * st["iters"] >= info["t_insert_ms"] else roof_build
+
+    out = {
+        "metric": "reads quantified/sec (hit lists -> eq-classes -> EM to convergence -> TPM)",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{a.workload}: {R} reads/GPU x {world} GPU, {M}-transcript index, label pool {P}, "
+                               f"{'VBEM' if use_vbem else 'EM'} to convergence (tol 0.01, minIter 50)",
+                   "reads_per_gpu": R, "transcripts": M, "hits": n_hits, "classes": C, "nnz": L,
+                   "em_mode": info["em_mode"]},
+        "em_iters": st["iters"], "em_iters_per_s": st["iters"] / (em_ms * 1e-3),
+        "em_us_per_iter_loop": em_loop_ms_per_iter * 1e3,
+        "phase_ms": {"class_build": build_ms, "insert_kernel": info["t_insert_ms"], "merge": info.get("t_merge_ms", 0.0),
+                     "efflen": info["t_efflen_ms"], "em": em_ms, "tpm": info["t_tpm_ms"]},
+        "class_build_reads_per_s": R / (build_ms * 1e-3),
+        "roofline": dominant, "roofline_em_sweep": roof_em, "roofline_class_build": roof_build,
+    }
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cb = cpu_baseline(ref_len_np, ids, off, a.cpu_seconds, use_vbem)
+        # CPU seconds for the full step = build at the sampled rate + EM iterations at the sampled
+        # per-iteration cost scaled by nnz (the sweep is linear in nnz)
+        cpu_step_s = R / cb["build_reads_per_s"] + st["iters"] * cb["em_ms_per_iter"] * 1e-3 * (L / max(cb["sample_nnz"], 1))
+        out["cpu_baseline"] = {
+            "value": R / cpu_step_s, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C restatement, 1 thread): class build timed on the first {cb['sample_reads']} reads "
+                      f"({cb['build_reads_per_s']:.3g} reads/s), EM timed for {cb['sample_em_iters']} iterations on that "
+                      f"sample's {cb['sample_classes']} classes ({cb['em_ms_per_iter']:.3g} ms/iter), scaled to the full "
+                      f"step ({R} reads, {st['iters']} iterations, nnz ratio {L / max(cb['sample_nnz'], 1):.2f})",
+            "class_build_reads_per_s": cb["build_reads_per_s"], "em_ms_per_iter_sample": cb["em_ms_per_iter"],
+            "host_cores_available": os.cpu_count(),
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,21 @@ SFGPU_API int sfgpu_eq_start(sfgpu_eq* eq);
  * Both return after the batch has been folded in (the caller may reuse its buffers). */
 SFGPU_API int sfgpu_eq_add_batch_host(sfgpu_eq* eq, const uint32_t* h_ids, const uint32_t* h_offsets, uint32_t n_reads);
 SFGPU_API int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads);
+/* insertGroup(TranscriptGroup, count) :82-88, batched and with upsert semantics: group g is added
+ * with multiplicity d_counts[g] (equal labels accumulate).  Used to merge class tables built on
+ * different GPUs; same limits and synchronisation as sfgpu_eq_add_batch_device. */
+SFGPU_API int sfgpu_eq_add_weighted_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets,
+                                 const uint64_t* d_counts, uint32_t n_groups);
+/* Builder counters since the last start(): device time of the insert kernel (HIP events on the
+ * builder's stream), launches, table growths, deferred-and-replayed reads, current table slots. */
+typedef struct {
+    double insert_ms;
+    uint64_t insert_launches;
+    uint64_t table_grows;
+    uint64_t deferred_reads;
+    uint64_t table_slots;
+} sfgpu_eq_stats;
+SFGPU_API int sfgpu_eq_get_stats(sfgpu_eq* eq, sfgpu_eq_stats* out);
 /* finish() :64-80: snapshot into the canonical class order (first id, XXH64, length, label --
  * the reference's order is hash-table order and run dependent).  Reports what the reference
  * logs: #classes and sum(count); nnz = sum of label lengths. Synchronous. */

@@ -39,6 +39,11 @@ class EmStats(C.Structure):
                     alpha_sum=self.alpha_sum, n_active=self.n_active, loop_ms=self.loop_ms)
 
 
+class EqStats(C.Structure):
+    _fields_ = [("insert_ms", C.c_double), ("insert_launches", C.c_uint64), ("table_grows", C.c_uint64),
+                ("deferred_reads", C.c_uint64), ("table_slots", C.c_uint64)]
+
+
 _LOG_CB = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
 _lib = None
 _log_keepalive = None
@@ -55,6 +60,8 @@ _SIGS = {
     "sfgpu_eq_start": (C.c_int, [_P]),
     "sfgpu_eq_add_batch_host": (C.c_int, [_P, _P, _P, C.c_uint32]),
     "sfgpu_eq_add_batch_device": (C.c_int, [_P, _P, _P, C.c_uint32]),
+    "sfgpu_eq_add_weighted_device": (C.c_int, [_P, _P, _P, _P, C.c_uint32]),
+    "sfgpu_eq_get_stats": (C.c_int, [_P, C.POINTER(EqStats)]),
     "sfgpu_eq_finish": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sfgpu_eq_export_device": (C.c_int, [_P, _P, _P, _P, _P]),
     "sfgpu_eq_export_host": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -67,10 +67,11 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
          const uint32_t* __restrict__ list, uint64_t* table, uint64_t mask,
          const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ cls_len,
          const uint32_t* __restrict__ arena, unsigned long long* ctr, uint32_t* newlist,
-         unsigned long long limit_new, uint32_t* deferred) {
+         unsigned long long limit_new, uint32_t* deferred, const uint64_t* __restrict__ weights) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t r = list ? list[i] : first + i;
+    const unsigned long long inc = weights ? (unsigned long long)weights[r] : 1ull;
     uint32_t b = off[r], len = off[r + 1] - b;
     if (len == 0) return;  // call-site guard: empty hit lists never reach addGroup
     const uint32_t* lab = ids + b;
@@ -91,7 +92,7 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
             if (old == kEmpty) {
                 unsigned long long idx = atomicAdd(&ctr[CTR_NEW], 1ull);
                 newlist[idx] = (uint32_t)s;
-                atomicAdd((unsigned long long*)&table[2 * s + 1], 1ull);
+                atomicAdd((unsigned long long*)&table[2 * s + 1], inc);
                 return;
             }
             w = old;
@@ -102,7 +103,7 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
             if (rep & kArenaBit) { uint32_t c = rep & ~kArenaBit; p = arena + cls_off[c]; l = cls_len[c]; }
             else { uint32_t rb = off[rep]; p = ids + rb; l = off[rep + 1] - rb; }
             if (l == len && labels_equal(p, lab, len)) {
-                atomicAdd((unsigned long long*)&table[2 * s + 1], 1ull);
+                atomicAdd((unsigned long long*)&table[2 * s + 1], inc);
                 return;
             }
         }
@@ -243,6 +244,8 @@ struct sfgpu_eq {
     DevBuf<uint32_t> order; DevBuf<uint64_t> rowptr64;
     uint64_t nnz = 0, total_reads = 0;
     uint32_t sub_batch = 1u << 22;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    sfgpu_eq_stats stats{};
 };
 
 static int eq_alloc_table(sfgpu_eq* eq, uint64_t cap) {
@@ -267,6 +270,7 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
     }
     SF_HIP(hipStreamSynchronize(eq->stream));
     if (old) SF_HIP(hipFree(old));
+    eq->stats.table_grows++;
     log_msg(0, "eq: table grown to %llu slots (%llu classes)", (unsigned long long)new_cap,
             (unsigned long long)eq->n_classes);
     return SFGPU_OK;
@@ -275,6 +279,7 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
 static int eq_reset(sfgpu_eq* eq) {
+    eq->stats = sfgpu_eq_stats{};
     eq->finished = false; eq->n_classes = 0; eq->arena_used = 0; eq->nnz = 0; eq->total_reads = 0;
     uint64_t want = pow2_at_least(2 * (eq->expected ? eq->expected : 1000000ull) + 2 * kSlack);
     if (eq->table.p && eq->cap == want) {
@@ -309,6 +314,8 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) eq->sub_batch = (uint32_t)v; }
     hipError_t e1 = hipMalloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
     hipError_t e2 = hipHostMalloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
+    if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev1);
     if (e1 != hipSuccess || e2 != hipSuccess) {
         set_error("sfgpu_eq_create: allocation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         delete eq; return SFGPU_ERR_HIP;
@@ -324,6 +331,8 @@ int sfgpu_eq_destroy(sfgpu_eq* eq) {
     (void)hipStreamSynchronize(eq->stream);
     if (eq->d_ctr) (void)hipFree(eq->d_ctr);
     if (eq->h_ctr) (void)hipHostFree(eq->h_ctr);
+    if (eq->ev0) (void)hipEventDestroy(eq->ev0);
+    if (eq->ev1) (void)hipEventDestroy(eq->ev1);
     delete eq;
     return SFGPU_OK;
 }
@@ -335,7 +344,8 @@ int sfgpu_eq_start(sfgpu_eq* eq) {
 }
 
 // caller holds eq->mu
-static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads) {
+static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads,
+                         const uint64_t* d_weights = nullptr) {
     SF_REQUIRE(n_reads < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: a batch holds < 2^31 reads");
     SF_REQUIRE(!eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_add_batch: builder already finished (call start)");
     if (n_reads == 0) return SFGPU_OK;
@@ -370,12 +380,16 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
             if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
             SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));
+            SF_HIP(hipEventRecord(eq->ev0, st));
             hipLaunchKernelGGL(k_insert, dim3(grid_for(todo)), dim3(kBlock), 0, st, d_ids, d_offsets, first, todo, list,
                                eq->table.p, eq->cap - 1, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->d_ctr,
-                               eq->newlist.p, (unsigned long long)limit_new, dout.p);
+                               eq->newlist.p, (unsigned long long)limit_new, dout.p, d_weights);
             SF_CHECK_LAUNCH();
+            SF_HIP(hipEventRecord(eq->ev1, st));
             SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             SF_HIP(hipStreamSynchronize(st));
+            { float ms = 0.f; if (hipEventElapsedTime(&ms, eq->ev0, eq->ev1) == hipSuccess) eq->stats.insert_ms += ms; }
+            eq->stats.insert_launches++;
             uint64_t n_new = eq->h_ctr[CTR_NEW], n_def = eq->h_ctr[CTR_DEFER];
             if (n_new) {
                 hipLaunchKernelGGL(k_commit, dim3(grid_for(n_new)), dim3(kBlock), 0, st, d_ids, d_offsets, eq->table.p,
@@ -385,6 +399,7 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
                 eq->n_classes += n_new;
             }
             if (n_def) {
+                eq->stats.deferred_reads += n_def;
                 if ((rc = eq_grow(eq, eq->cap * 2))) return rc;   // synchronises: commit has finished
                 list = dout.p; todo = (uint32_t)n_def; flip = !flip;
             } else {
@@ -418,6 +433,21 @@ int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_
     SF_REQUIRE(eq && d_offsets, SFGPU_ERR_INVALID, "sfgpu_eq_add_batch: null pointer");
     std::lock_guard<std::mutex> lk(eq->mu);
     return eq_add_locked(eq, d_ids, d_offsets, n_reads);
+}
+
+int sfgpu_eq_add_weighted_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets,
+                                 const uint64_t* d_counts, uint32_t n_groups) {
+    SF_REQUIRE(eq && d_offsets && d_counts, SFGPU_ERR_INVALID, "sfgpu_eq_add_weighted: null pointer");
+    std::lock_guard<std::mutex> lk(eq->mu);
+    return eq_add_locked(eq, d_ids, d_offsets, n_groups, d_counts);
+}
+
+int sfgpu_eq_get_stats(sfgpu_eq* eq, sfgpu_eq_stats* out) {
+    SF_REQUIRE(eq && out, SFGPU_ERR_INVALID, "sfgpu_eq_get_stats: null pointer");
+    std::lock_guard<std::mutex> lk(eq->mu);
+    *out = eq->stats;
+    out->table_slots = eq->cap;
+    return SFGPU_OK;
 }
 
 int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* total_reads) {

@@ -1,0 +1,194 @@
+"""Multi-GPU driver of the quantification hot path: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm).
+
+Data flow for N ranks:
+  1. reads are sharded over ranks; every rank builds the class table of ITS reads with the HIP
+     builder -- no communication (reads are independent);
+  2. ONE exchange: the local tables (label lengths, labels, counts: a few tens of MB) are
+     all-gathered and every rank folds all of them into one table with the weighted upsert
+     (sfgpu_eq_add_weighted_device).  Equal labels from different ranks add their counts, so every
+     rank ends with the same canonical class list as a single-GPU run over all reads (integer
+     work: bit-exact);
+  3. EM over the merged classes, in one of two modes:
+       "sharded"   : classes are cut into N contiguous, nnz-balanced slices; each iteration is
+                     local sweep -> SUM all-reduce of alphaOut (M doubles, RCCL) -> update.  This is
+                     the north-star layout; the all-reduce is latency bound (M = 200k -> 1.6 MB).
+       "replicated": every rank runs the whole EM on the merged classes with the on-device loop --
+                     no per-iteration collective.
+     "auto" picks "sharded" only when a local sweep is expected to outlast an all-reduce
+     (nnz/N >= kShardNnz); at BASELINE's sizes (nnz <= ~2e7, sweep ~10 us) the per-iteration
+     all-reduce (tens of us over xGMI) costs more than it saves.
+
+The compute engine is injected so that the control flow is covered on CPU (gloo, world_size 2) by
+tests that supply their own CPU checker engine; the product engine is HipEngine (libsfgpu only)."""
+import time
+
+import numpy as np
+import torch
+
+from . import efflen as _efflen
+from . import writer as _writer
+from .eqclass import EquivalenceClassBuilder
+from .experiment import ReadExperiment, SailfishOpts
+from .optimizer import EMProblem
+
+kShardNnz = 1 << 27
+
+
+class HipEngine:
+    """Everything that touches data goes through libsfgpu (no CPU fallback)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def new_builder(self, expected=0):
+        return EquivalenceClassBuilder(expected_classes=expected, device=self.device)
+
+    def em_problem(self, length, rowptr, ids, counts, num_mapped):
+        return EMProblem(length, rowptr, ids, counts, num_mapped)
+
+    def set_effective_lengths(self, exp, sopt, fl_counts, remaining_fl_ops):
+        return _efflen.set_effective_lengths(exp, sopt, fl_counts=fl_counts, remaining_fl_ops=remaining_fl_ops)
+
+    def tpm(self, exp, sopt):
+        return _writer.tpm(exp, sopt)[0]
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+def _all_gather_var(t, group, world):
+    """all-gather of 1-D tensors of different lengths (sizes first, then padded payloads)."""
+    import torch.distributed as dist
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return [o[:s] for o, s in zip(outs, sizes)]
+
+
+def nnz_balanced_slices(rowptr_cpu, world):
+    """cut [0, C) into `world` contiguous class ranges of ~equal nnz"""
+    C = len(rowptr_cpu) - 1
+    L = int(rowptr_cpu[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(rowptr_cpu, L * r // world, side="left")))
+    cuts.append(C)
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
+
+
+class DistributedQuant:
+    def __init__(self, exp: ReadExperiment, sopt: SailfishOpts, group=None, em_mode="auto", engine=None,
+                 tol=0.01, max_iter=10000, poll_every=16):
+        self.exp, self.sopt, self.group = exp, sopt, group
+        self.world = 1
+        self.rank = 0
+        if group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group); self.rank = dist.get_rank(group)
+        self.engine = engine or HipEngine(exp.transcripts().device)
+        self.em_mode = em_mode
+        self.tol, self.max_iter, self.poll_every = tol, max_iter, poll_every
+        self.local = self.engine.new_builder()
+        self.merged = self.engine.new_builder() if self.world > 1 else None
+        self.problem = None
+
+    # ---- one pass of the hot path ------------------------------------------------------------
+    def run(self, ids, off, fl_counts=None, remaining_fl_ops=1):
+        eng, exp, sopt = self.engine, self.exp, self.sopt
+        info = {}
+        eng.sync(); t0 = time.perf_counter()
+        b = self.local
+        b.start(); b.add_batch(ids, off); b.finish()
+        vec = b.eqVec()
+        eng.sync(); t1 = time.perf_counter()
+        info["t_insert_ms"] = b.stats()["insert_ms"]
+        info["t_build_ms"] = (t1 - t0) * 1e3
+        if self.world > 1:
+            vec = self._merge(vec)
+            eng.sync(); t2 = time.perf_counter()
+            info["t_merge_ms"] = (t2 - t1) * 1e3
+            t1 = t2
+        exp.setNumMappedFragments(vec.total_reads)        # every read with a non-empty hit list is mapped
+        eng.set_effective_lengths(exp, sopt, fl_counts, remaining_fl_ops)
+        eng.sync(); t2 = time.perf_counter()
+        ok, st, mode = self._em(vec)
+        eng.sync(); t3 = time.perf_counter()
+        tpm = eng.tpm(exp, sopt)
+        eng.sync(); t4 = time.perf_counter()
+        info.update(ok=ok, em_stats=st, em_mode=mode, n_classes=vec.size(), nnz=vec.nnz, tpm=tpm,
+                    t_efflen_ms=(t2 - t1) * 1e3, t_em_ms=(t3 - t2) * 1e3, t_tpm_ms=(t4 - t3) * 1e3)
+        return info
+
+    # ---- class-table exchange ----------------------------------------------------------------
+    def _merge(self, vec):
+        w = self.world
+        rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
+        lens = (rp[1:] - rp[:-1]).to(torch.int32)
+        g_lens = _all_gather_var(lens, self.group, w)
+        g_ids = _all_gather_var(vec.ids, self.group, w)
+        g_cnt = _all_gather_var(vec.counts, self.group, w)
+        m = self.merged
+        m.start()
+        for ln, ii, cc in zip(g_lens, g_ids, g_cnt):     # same order on every rank -> same table
+            off = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=ln.device)
+            torch.cumsum(ln.to(torch.int64), 0, out=off[1:])
+            off32 = torch.where(off >= 2 ** 31, off - 2 ** 32, off).to(torch.int32)
+            m.insertGroups(ii, off32, cc)
+        m.finish()
+        return m.eqVec()
+
+    # ---- EM ------------------------------------------------------------------------------------
+    def _pick_mode(self, nnz):
+        if self.world == 1:
+            return "single"
+        if self.em_mode != "auto":
+            return self.em_mode
+        return "sharded" if nnz // self.world >= kShardNnz else "replicated"
+
+    def _em(self, vec):
+        exp, sopt = self.exp, self.sopt
+        txps = exp.transcripts()
+        length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
+        mode = self._pick_mode(vec.nnz)
+        kw = dict(use_vbem=sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)
+        if mode in ("single", "replicated"):
+            p = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
+            rc, st = p.optimize(**kw)
+        else:
+            import torch.distributed as dist
+            rp_cpu = (vec.rowptr.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+            cuts = nnz_balanced_slices(rp_cpu, self.world)
+            c0, c1 = cuts[self.rank], cuts[self.rank + 1]
+            j0, j1 = int(rp_cpu[c0]), int(rp_cpu[c1])
+            rp_loc = ((vec.rowptr[c0:c1 + 1].to(torch.int64) & 0xFFFFFFFF) - j0).to(torch.int32)
+            p = self.engine.em_problem(length, rp_loc, vec.ids[j0:j1], vec.counts[c0:c1], exp.numMappedFragments())
+            p.begin(**kw)
+            ao = p.alpha_out_view()
+            dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)     # union of the active sets
+            p.init()
+            done = False
+            while not done:
+                for _ in range(self.poll_every):
+                    p.sweep()
+                    dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)
+                    p.update()
+                done, _ = p.poll()
+            rc, st = p.finish()
+        self.problem = p
+        ok = rc == 0
+        if ok:
+            txps.estCount.copy_(p.alpha); txps.mass.copy_(p.mass)
+        return ok, st, mode
+
+    def time_sweep(self, n=200):
+        p = self.problem
+        return p.time_sweep(n, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)

@@ -93,6 +93,24 @@ class EquivalenceClassBuilder:
                 ids_h = np.zeros(1, np.uint32)
             _lib.check(self._L.sfgpu_eq_add_batch_host(self._h, _lib.ptr(ids_h), _lib.ptr(off_h), n))
 
+    def insertGroups(self, ids, offsets, counts):
+        """insertGroup(TranscriptGroup, count) (:82-88) for many groups, with upsert semantics:
+        group g = ids[offsets[g]:offsets[g+1]] is added with multiplicity counts[g].  Device tensors."""
+        self._flush()
+        n = int(offsets.shape[0]) - 1
+        if n <= 0:
+            return
+        ids_t = _as_dev_u32(ids, self.device); off_t = _as_dev_u32(offsets, self.device)
+        cnt_t = counts.to(torch.int64).contiguous().to(self.device)
+        torch.cuda.current_stream().synchronize()
+        _lib.check(self._L.sfgpu_eq_add_weighted_device(self._h, _lib.ptr(ids_t), _lib.ptr(off_t), _lib.ptr(cnt_t), n))
+
+    def stats(self):
+        st = _lib.EqStats()
+        _lib.check(self._L.sfgpu_eq_get_stats(self._h, C.byref(st)))
+        return dict(insert_ms=st.insert_ms, insert_launches=st.insert_launches, table_grows=st.table_grows,
+                    deferred_reads=st.deferred_reads, table_slots=st.table_slots)
+
     def finish(self):
         """finish() (:64-80): returns True; n_classes / total_reads are what the reference logs."""
         self._flush()
