@@ -19,6 +19,7 @@
 //     order-deterministic; the only nondeterministic order is the f64 atomic accumulation into
 //     alphaOut, as in the reference's CAS loop (:70-79).
 #include "common.h"
+#include "primitives.h"
 
 #include <cfloat>
 #include <vector>
@@ -38,7 +39,6 @@ struct EmState {
     uint32_t it_b;                 // iteration in flight (or kDoneMark); written by sweep, read by update
     uint32_t notconv[2];           // per iteration parity: some gated transcript moved by > tol
     uint32_t gated[2];             // per iteration parity: some transcript passed the gate
-    unsigned long long maxrel[2];  // bit pattern of the largest relative change
     unsigned long long n_active;
     double alpha_sum;
 };
@@ -136,7 +136,7 @@ __global__ void k_init_alpha(uint64_t M, double* alpha, double* alpha_out, doubl
     if (VB) { double s = block_sum(local, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->it_a = 0; st->it_b = 0; st->notconv[0] = st->notconv[1] = 0; st->gated[0] = st->gated[1] = 0;
-        st->maxrel[0] = st->maxrel[1] = 0; st->n_active = (unsigned long long)n_act; st->alpha_sum = 0.0;
+        st->n_active = (unsigned long long)n_act; st->alpha_sum = 0.0;
     }
 }
 
@@ -165,7 +165,7 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
     bool stop = em_stop(it, st, min_iter, max_iter);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->it_b = stop ? kDoneMark : it;
-        if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; st->maxrel[it & 1] = 0; }
+        if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
     }
     if (stop) return;
     uint64_t c = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
@@ -188,42 +188,239 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
     }
 }
 
-// per-transcript update (:849-861): gate, relative change, alpha <- alphaOut, alphaOut <- 0, ++it
+// ---- tiled E-step sweep ------------------------------------------------------------------------
+// Classes are stored in the canonical order (first id ascending), so a run of consecutive classes
+// touches a narrow band of transcripts.  A tile is the run of classes whose first nonzero falls
+// into one kTileNnz-sized bucket of the CSR (nnz-balanced; boundaries found once per problem).
+// Per tile, one 256-thread block:
+//   A  nonzero-parallel: coalesced load of the tile's ids, gather x from an LDS-staged window of x
+//      (global gather for members outside the window) -> vals[] in LDS; window offsets stay in VGPRs
+//   B  class-parallel  : denom = sum vals, vals *= count/denom            (EMUpdate_ :251-271)
+//   C  nonzero-parallel: LDS window accumulators += vals   (ds_add_f64; global atomics outside)
+//   D  flush the touched window entries with one global f64 atomic each
+// so HBM sees each label word once per iteration and global atomics drop by the in-tile reuse factor.
+// Any input is handled (labels that span far-apart transcripts or exceed the LDS budget fall back to
+// direct global accesses); locality only buys speed.
+constexpr int kTileNnz = 2048;               // CSR bucket that defines a tile
+constexpr int kTileCap = 3072;               // nonzeros a tile may stage in LDS (bucket + longest label)
+constexpr int kNnzPerThread = kTileCap / kEmBlock;
+constexpr int kWin = 1024;                   // LDS window (transcripts)
+
+// tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*kTileNnz, (i+1)*kTileNnz)
+__global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, uint32_t* tile_c0) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_tiles) return;
+    uint64_t target = (uint64_t)i * kTileNnz;
+    uint64_t lo = 0, hi = C;                         // first class with rowptr[c] >= target
+    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (rowptr[mid] >= target) hi = mid; else lo = mid + 1; }
+    tile_c0[i] = (uint32_t)lo;
+}
+
+// window of tile i: [lo, lo + span) with lo = smallest member and span <= kWin
+__global__ void __launch_bounds__(kEmBlock)
+k_tile_window(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
+              uint32_t* tile_lo, uint32_t* tile_span) {
+    __shared__ uint32_t rmin[kEmBlock / kWave], rmax[kEmBlock / kWave];
+    uint32_t b = rowptr[tile_c0[blockIdx.x]], e = rowptr[tile_c0[blockIdx.x + 1]];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (uint32_t j = b + threadIdx.x; j < e; j += kEmBlock) { uint32_t v = ids[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        uint32_t v = __shfl_down(mn, o, kWave); mn = v < mn ? v : mn;
+        uint32_t w = __shfl_down(mx, o, kWave); mx = w > mx ? w : mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { rmin[threadIdx.x / kWave] = mn; rmax[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kEmBlock / kWave; ++i) { mn = rmin[i] < mn ? rmin[i] : mn; mx = rmax[i] > mx ? rmax[i] : mx; }
+        if (e == b) { tile_lo[blockIdx.x] = 0; tile_span[blockIdx.x] = 0; }
+        else {
+            uint32_t span = mx - mn + 1;
+            tile_lo[blockIdx.x] = mn;
+            tile_span[blockIdx.x] = span < (uint32_t)kWin ? span : (uint32_t)kWin;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) tile_span[gridDim.x] = 0;   // scan sentinel
+}
+
+// one (transcript, slot) pair per window entry; sorted by transcript this is the cover list that the
+// per-transcript update walks to fold the tiles' partial sums in a fixed order
+__global__ void __launch_bounds__(kEmBlock)
+k_cover_pairs(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span,
+              const uint64_t* __restrict__ tile_off, uint64_t* keys, uint32_t* vals) {
+    uint32_t lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
+    uint64_t off = tile_off[blockIdx.x];
+    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) { keys[off + d] = (uint64_t)lo + d; vals[off + d] = (uint32_t)(off + d); }
+}
+
+__global__ void k_cover_ptr(uint64_t M, uint64_t P, const uint64_t* __restrict__ sorted_keys, uint32_t* cov_ptr) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > M) return;
+    uint64_t lo = 0, hi = P;
+    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] >= t) hi = mid; else lo = mid + 1; }
+    cov_ptr[t] = (uint32_t)lo;
+}
+
 template <bool VB>
 __global__ void __launch_bounds__(kEmBlock)
+k_sweep_tile(uint64_t M, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ tile_c0,
+             const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span,
+             const uint64_t* __restrict__ tile_off, const double* __restrict__ x, double* alpha_out,
+             double* __restrict__ partial, EmState* st, uint32_t min_iter, uint32_t max_iter, int ablate) {
+    uint32_t it = st->it_a;
+    bool stop = em_stop(it, st, min_iter, max_iter);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->it_b = stop ? kDoneMark : it;
+        if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
+    }
+    if (stop) return;
+    __shared__ double xs[kWin];
+    __shared__ double acc[kWin];
+    __shared__ double vals[kTileCap];
+    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
+    if (c0 == c1) return;
+    if (ablate & 16) return;
+    const uint32_t lo = tile_lo[blockIdx.x];
+    const uint32_t span = tile_span[blockIdx.x];          // members at lo + [0, span) live in the LDS window
+    const uint32_t j0 = rowptr[c0], j1 = rowptr[c1];
+    const uint32_t n = j1 - j0;
+    for (uint32_t i = threadIdx.x; i < span; i += kEmBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
+    (void)M;
+    if (n <= (uint32_t)kTileCap) {
+        // ---- A: ids -> window offsets (VGPRs); x gather -> vals[]
+        uint32_t tid_[kNnzPerThread];
+#pragma unroll
+        for (int k = 0; k < kNnzPerThread; ++k) {
+            uint32_t j = threadIdx.x + k * kEmBlock;
+            tid_[k] = (j < n) ? ids[j0 + j] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kNnzPerThread; ++k) {
+            uint32_t j = threadIdx.x + k * kEmBlock;
+            if (j < n && !(ablate & 4)) {
+                uint32_t d = tid_[k] - lo;
+                double v = (d < span) ? xs[d] : x[tid_[k]];
+                if (VB) { if (!(v > 0.0)) v = 0.0; }                   // expTheta == 0 terms are skipped (:344, :356)
+                vals[j] = v;
+            }
+        }
+        __syncthreads();
+        // ---- B: per class, denom and scale
+        if (!(ablate & 1))
+        for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+            uint32_t b = rowptr[c] - j0, e = rowptr[c + 1] - j0;
+            double cnt = (double)counts[c];
+            if (e - b == 1) { vals[b] = cnt; continue; }               // :275 / :364 the full count
+            double denom = 0.0;
+            for (uint32_t j = b; j < e; ++j) denom += vals[j];
+            double inv = (denom > kTiny) ? cnt / denom : 0.0;          // :260-264 ; skipped class adds nothing
+            for (uint32_t j = b; j < e; ++j) {
+                double v = vals[j];
+                vals[j] = (denom > kTiny && v == v) ? v * inv : 0.0;   // NaN terms are skipped (:269)
+            }
+        }
+        __syncthreads();
+        // ---- C: scatter-add
+        if (!(ablate & 2))
+#pragma unroll
+        for (int k = 0; k < kNnzPerThread; ++k) {
+            uint32_t j = threadIdx.x + k * kEmBlock;
+            if (j < n) {
+                double v = vals[j];
+                if (v != 0.0) {
+                    uint32_t d = tid_[k] - lo;
+                    if (d < span) atomicAdd(&acc[d], v); else atomicAdd(&alpha_out[tid_[k]], v);
+                }
+            }
+        }
+    } else {
+        // ---- oversize tile (a label longer than the LDS budget): direct path
+        __syncthreads();
+        for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+            uint32_t b = rowptr[c], e = rowptr[c + 1];
+            double cnt = (double)counts[c];
+            if (e - b == 1) { atomicAdd(&alpha_out[ids[b]], cnt); continue; }
+            double denom = 0.0;
+            for (uint32_t j = b; j < e; ++j) { double v = x[ids[j]]; if (VB) { if (v > 0.0) denom += v; } else denom += v; }
+            if (!(denom > kTiny)) continue;
+            double inv = cnt / denom;
+            for (uint32_t j = b; j < e; ++j) {
+                uint32_t t = ids[j]; double v = x[t];
+                if (VB ? (v > 0.0) : (v == v)) atomicAdd(&alpha_out[t], v * inv);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- D: publish the window (plain coalesced stores; folded per transcript by the update)
+    const uint64_t off = tile_off[blockIdx.x];
+    if (!(ablate & 8))
+    for (uint32_t i = threadIdx.x; i < span; i += kEmBlock) partial[off + i] = acc[i];
+}
+
+// alphaOut[t] += sum of the tiles' window entries for t, in cover-list order (deterministic)
+__device__ __forceinline__ double fold_partials(uint64_t t, const uint32_t* __restrict__ cov_ptr,
+                                                const uint32_t* __restrict__ cov_pos, const double* __restrict__ partial) {
+    double s = 0.0;
+    for (uint32_t k = cov_ptr[t], e = cov_ptr[t + 1]; k < e; ++k) s += partial[cov_pos[k]];
+    return s;
+}
+
+// piecewise API: make alphaOut complete before the caller's all-reduce
+__global__ void k_fold(uint64_t M, double* alpha_out, const uint32_t* __restrict__ cov_ptr,
+                       const uint32_t* __restrict__ cov_pos, const double* __restrict__ partial, const EmState* st) {
+    if (st->it_b == kDoneMark) return;
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) alpha_out[t] += fold_partials(t, cov_ptr, cov_pos, partial);
+}
+
+// per-transcript update (:849-861): gate, relative change, alpha <- alphaOut, alphaOut <- 0, ++it.
+// No atomics: the convergence flags are idempotent plain stores (every writer stores 1) and the
+// per-block maximum goes to blkmax[parity][block], reduced by the host when it polls.
+template <bool VB, bool FOLD>
+__global__ void __launch_bounds__(kEmBlock)
 k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* __restrict__ lenc,
-         double tol, int check_mode, double* sum_partials_out, EmState* st) {
+         double tol, int check_mode, double* sum_partials_out, double* blkmax, EmState* st,
+         const uint32_t* __restrict__ cov_ptr, const uint32_t* __restrict__ cov_pos,
+         const double* __restrict__ partial) {
     uint32_t it = st->it_b;
     if (it == kDoneMark) return;
     __shared__ double lds[kEmBlock / kWave];
+    __shared__ double lmax[kEmBlock / kWave];
     double local_sum = 0.0, local_max = -1.0;
-    unsigned notconv = 0, gated = 0;
+    unsigned notconv = 0;
     for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
         double a = alpha[t];
         double ap = alpha_out[t];
+        if (FOLD) ap += fold_partials(t, cov_ptr, cov_pos, partial);
         if (VB) ap += kPriorAlpha;                     // alphaOut starts at the prior (:318)
         double gate = check_mode ? a : ap;             // :852 vs :499
         if (gate > kCheckCutoff) {
             double rel = fabs(a - ap) / ap;
-            gated = 1;
-            if (rel > local_max) local_max = rel;
+            if (rel > local_max) local_max = rel;      // NaN never wins, as in the reference (:854)
             if (rel > tol) notconv = 1;
+            if (local_max < 0.0) local_max = 0.0;      // gated at least once
         }
         alpha[t] = ap; alpha_out[t] = 0.0;
         if (VB) local_sum += ap; else x[t] = ap / lenc[t];
     }
-    // wave-level combine, one set of atomics per wave
     for (int o = kWave / 2; o > 0; o >>= 1) {
         double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
-        notconv |= __shfl_down(notconv, o, kWave); gated |= __shfl_down(gated, o, kWave);
+        notconv |= __shfl_down(notconv, o, kWave);
     }
+    const int w = threadIdx.x / kWave;
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        if (notconv) atomicOr(&st->notconv[it & 1], 1u);
-        if (gated) { atomicOr(&st->gated[it & 1], 1u);
-                     if (local_max >= 0.0) atomicMax(&st->maxrel[it & 1], (unsigned long long)__double_as_longlong(local_max)); }
+        if (notconv) st->notconv[it & 1] = 1;
+        lmax[w] = local_max;
     }
     if (VB) { double s = block_sum(local_sum, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->it_a = it + 1;
+    else __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = lmax[0];
+        for (int i = 1; i < kEmBlock / kWave; ++i) if (lmax[i] > m) m = lmax[i];
+        blkmax[(it & 1) * kMaxPartials + blockIdx.x] = m;          // -1 = nothing gated in this block
+        if (blockIdx.x == 0) st->it_a = it + 1;
+    }
 }
 
 // truncateCountVector (:36-44) + alphaSum
@@ -267,6 +464,13 @@ struct sfgpu_em {
     double *alpha = nullptr, *alpha_out = nullptr, *x = nullptr, *lenc = nullptr;
     double *partials = nullptr, *sum_partials = nullptr, *scratch = nullptr;
     uint32_t* counts32 = nullptr;
+    uint32_t* tile_lo = nullptr; uint32_t* tile_c0 = nullptr; uint32_t* tile_span = nullptr; uint32_t n_tiles = 0;
+    uint64_t* tile_off = nullptr; uint64_t P = 0;          // window slots over all tiles
+    double* partial = nullptr;                              // [P] per-tile window sums of one sweep
+    uint32_t* cov_ptr = nullptr; uint32_t* cov_pos = nullptr;   // transcript -> its window slots
+    double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
+    int ablate = 0;                                         // timing experiments only (SFGPU_EM_ABLATE)
+    int sweep_variant = 1;                                  // 0 = lane-per-class/global atomics, 1 = LDS tiles
     EmState* d_state = nullptr;
     EmState* h_state = nullptr;            // pinned
     sfgpu_em_opts opts{};
@@ -281,9 +485,11 @@ static void em_free(sfgpu_em* em) {
     if (em->stream) (void)hipStreamSynchronize(em->stream);
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
-                    em->counts32, em->d_state};
+                    em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
+                    em->cov_ptr, em->cov_pos, em->blkmax};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (em->h_state) (void)hipHostFree(em->h_state);
+    if (em->h_blkmax) (void)hipHostFree(em->h_blkmax);
     if (em->ev_a) (void)hipEventDestroy(em->ev_a);
     if (em->ev_b) (void)hipEventDestroy(em->ev_b);
     if (em->ev_join) (void)hipEventDestroy(em->ev_join);
@@ -303,30 +509,55 @@ static int em_fill_opts(sfgpu_em* em, const sfgpu_em_opts* o) {
 static int em_enqueue_sweep(sfgpu_em* em) {
     const sfgpu_problem& p = em->prob;
     if (p.C == 0) return SFGPU_OK;
-    dim3 g(blocks_for(p.C)), b(kEmBlock);
-    if (em->opts.use_vbem)
-        hipLaunchKernelGGL(k_sweep_lane<true>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
-                           em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
-    else
-        hipLaunchKernelGGL(k_sweep_lane<false>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
-                           em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
+    dim3 b(kEmBlock);
+    const bool vb = em->opts.use_vbem != 0;
+    if (em->sweep_variant == 0) {
+        dim3 g(blocks_for(p.C));
+        if (vb) hipLaunchKernelGGL(k_sweep_lane<true>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
+                                   em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
+        else hipLaunchKernelGGL(k_sweep_lane<false>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
+                                em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
+    } else {
+        dim3 g(em->n_tiles);
+        if (vb) hipLaunchKernelGGL(k_sweep_tile<true>, g, b, 0, em->cur, p.M, p.d_rowptr, p.d_ids, em->counts32, em->tile_c0,
+                                   em->tile_lo, em->tile_span, em->tile_off, em->x, em->alpha_out, em->partial, em->d_state,
+                                   em->opts.min_iter, em->opts.max_iter, em->ablate);
+        else hipLaunchKernelGGL(k_sweep_tile<false>, g, b, 0, em->cur, p.M, p.d_rowptr, p.d_ids, em->counts32, em->tile_c0,
+                                em->tile_lo, em->tile_span, em->tile_off, em->x, em->alpha_out, em->partial, em->d_state,
+                                em->opts.min_iter, em->opts.max_iter, em->ablate);
+    }
     SF_CHECK_LAUNCH();
     return SFGPU_OK;
 }
 
-static int em_enqueue_update(sfgpu_em* em) {
+// `fold`: the sweep's per-tile window sums still have to be folded into alphaOut (true inside
+// optimize(); false in the piecewise API, where sfgpu_em_sweep folds before the caller's all-reduce)
+static int em_enqueue_update(sfgpu_em* em, bool fold) {
     const sfgpu_problem& p = em->prob;
     dim3 g(em->nb), b(kEmBlock);
+    fold = fold && em->sweep_variant != 0 && p.C != 0;
+#define UPD_ARGS p.M, em->alpha, em->alpha_out, em->x, em->lenc, em->opts.tol, em->opts.check_mode, em->sum_partials, \
+                 em->blkmax, em->d_state, em->cov_ptr, em->cov_pos, em->partial
     if (em->opts.use_vbem) {
-        hipLaunchKernelGGL(k_update<true>, g, b, 0, em->cur, p.M, em->alpha, em->alpha_out, em->x, em->lenc,
-                           em->opts.tol, em->opts.check_mode, em->sum_partials, em->d_state);
+        if (fold) hipLaunchKernelGGL((k_update<true, true>), g, b, 0, em->cur, UPD_ARGS);
+        else hipLaunchKernelGGL((k_update<true, false>), g, b, 0, em->cur, UPD_ARGS);
         SF_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb,
                            em->d_state, 0);
     } else {
-        hipLaunchKernelGGL(k_update<false>, g, b, 0, em->cur, p.M, em->alpha, em->alpha_out, em->x, em->lenc,
-                           em->opts.tol, em->opts.check_mode, em->sum_partials, em->d_state);
+        if (fold) hipLaunchKernelGGL((k_update<false, true>), g, b, 0, em->cur, UPD_ARGS);
+        else hipLaunchKernelGGL((k_update<false, false>), g, b, 0, em->cur, UPD_ARGS);
     }
+#undef UPD_ARGS
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
+
+static int em_enqueue_fold(sfgpu_em* em) {
+    const sfgpu_problem& p = em->prob;
+    if (em->sweep_variant == 0 || p.C == 0) return SFGPU_OK;
+    hipLaunchKernelGGL(k_fold, dim3(blocks_for(p.M)), dim3(kEmBlock), 0, em->cur, p.M, em->alpha_out, em->cov_ptr,
+                       em->cov_pos, em->partial, em->d_state);
     SF_CHECK_LAUNCH();
     return SFGPU_OK;
 }
@@ -348,9 +579,9 @@ static void em_stats_from_state(sfgpu_em* em, sfgpu_em_stats* s) {
     if (it == 0) { s->converged = 0; s->max_rel_diff = -DBL_MAX; return; }
     uint32_t par = (it - 1) & 1;
     s->converged = h->notconv[par] == 0;
-    long long bits = (long long)h->maxrel[par];
-    double m; memcpy(&m, &bits, 8);
-    s->max_rel_diff = h->gated[par] ? m : -DBL_MAX;   // the reference starts from -DBL_MAX (:850)
+    double m = -1.0;
+    for (int i = 0; i < em->nb; ++i) { double v = em->h_blkmax[par * kMaxPartials + i]; if (v > m) m = v; }
+    s->max_rel_diff = (m >= 0.0) ? m : -DBL_MAX;      // the reference starts from -DBL_MAX (:850)
 }
 
 extern "C" {
@@ -378,6 +609,11 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     EM_TRY(hipMalloc(&em->partials, kMaxPartials * 8)); EM_TRY(hipMalloc(&em->sum_partials, kMaxPartials * 8));
     EM_TRY(hipMalloc(&em->counts32, (C ? C : 1) * 4));
     EM_TRY(hipMalloc(&em->d_state, sizeof(EmState)));
+    EM_TRY(hipMalloc(&em->blkmax, 2 * kMaxPartials * 8));
+    EM_TRY(hipHostMalloc(&em->h_blkmax, 2 * kMaxPartials * 8, hipHostMallocDefault));
+    EM_TRY(hipMalloc(&em->tile_lo, 4));   // sized once nnz is known (below)
+    if (const char* v = getenv("SFGPU_EM_SWEEP")) em->sweep_variant = atoi(v);
+    if (const char* v = getenv("SFGPU_EM_ABLATE")) em->ablate = atoi(v);
     EM_TRY(hipHostMalloc(&em->h_state, sizeof(EmState), hipHostMallocDefault));
     EM_TRY(hipMemsetAsync(em->d_state, 0, sizeof(EmState), em->cur));
     int rc = em_join_user(em);
@@ -397,8 +633,50 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     } else {
         EM_TRY(hipStreamSynchronize(em->cur));
     }
-#undef EM_TRY
     em->L = rp_end;
+    if (C) {   // nnz-balanced tile plan of the sweep + the cover lists of the fold
+        em->n_tiles = (uint32_t)(((uint64_t)rp_end + kTileNnz - 1) / kTileNnz);
+        if (em->n_tiles == 0) em->n_tiles = 1;
+        const uint32_t nt = em->n_tiles;
+        (void)hipFree(em->tile_lo); em->tile_lo = nullptr;
+        EM_TRY(hipMalloc(&em->tile_lo, (size_t)nt * 4));
+        EM_TRY(hipMalloc(&em->tile_span, ((size_t)nt + 1) * 4));
+        EM_TRY(hipMalloc(&em->tile_c0, ((size_t)nt + 1) * 4));
+        EM_TRY(hipMalloc(&em->tile_off, ((size_t)nt + 1) * 8));
+        EM_TRY(hipMalloc(&em->cov_ptr, ((size_t)M + 1) * 4));
+        hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt,
+                           prob->d_rowptr, em->tile_c0);
+        hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
+                           em->tile_lo, em->tile_span);
+        EM_TRY(hipGetLastError());
+        if (exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur)) { em_free(em); return SFGPU_ERR_HIP; }
+        uint64_t P = 0;
+        EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipStreamSynchronize(em->cur));
+        if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
+        em->P = P;
+        EM_TRY(hipMalloc(&em->partial, (P ? P : 1) * 8));
+        EM_TRY(hipMalloc(&em->cov_pos, (P ? P : 1) * 4));
+        EM_TRY(hipMemsetAsync(em->partial, 0, (P ? P : 1) * 8, em->cur));
+        if (P) {
+            uint64_t *k_in = nullptr, *k_out = nullptr; uint32_t* v_in = nullptr;
+            EM_TRY(hipMalloc(&k_in, P * 8)); EM_TRY(hipMalloc(&k_out, P * 8)); EM_TRY(hipMalloc(&v_in, P * 4));
+            hipLaunchKernelGGL(k_cover_pairs, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off,
+                               k_in, v_in);
+            int bits = 1; while (bits < 32 && (1ull << bits) <= M) ++bits;
+            int src = sort_pairs_u64_u32(k_in, k_out, v_in, em->cov_pos, P, em->cur, bits);
+            if (!src) {
+                hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, em->cov_ptr);
+                (void)hipStreamSynchronize(em->cur);
+            }
+            (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in);
+            if (src) { em_free(em); return src; }
+        } else {
+            EM_TRY(hipMemsetAsync(em->cov_ptr, 0, ((size_t)M + 1) * 4, em->cur));
+        }
+        EM_TRY(hipGetLastError());
+    }
+#undef EM_TRY
     *out = em;
     return SFGPU_OK;
 }
@@ -453,17 +731,19 @@ int sfgpu_em_init(sfgpu_em* em) { return sfgpu_em_init_impl(em); }
 
 int sfgpu_em_sweep(sfgpu_em* em) {
     SF_REQUIRE(em && em->begun, SFGPU_ERR_STATE, "sfgpu_em_sweep: call begin/init first");
-    return em_enqueue_sweep(em);
+    int rc = em_enqueue_sweep(em);
+    return rc ? rc : em_enqueue_fold(em);
 }
 
 int sfgpu_em_update(sfgpu_em* em) {
     SF_REQUIRE(em && em->begun, SFGPU_ERR_STATE, "sfgpu_em_update: call begin/init first");
-    return em_enqueue_update(em);
+    return em_enqueue_update(em, false);
 }
 
 int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
     SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_poll: null handle");
     SF_HIP(hipMemcpyAsync(em->h_state, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
+    SF_HIP(hipMemcpyAsync(em->h_blkmax, em->blkmax, 2 * kMaxPartials * 8, hipMemcpyDeviceToHost, em->cur));
     SF_HIP(hipStreamSynchronize(em->cur));
     const EmState* h = em->h_state;
     uint32_t it = h->it_a;
@@ -484,6 +764,7 @@ int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu
     hipLaunchKernelGGL(k_mass, g, b, 0, em->cur, p.M, d_alpha_out, d_mass_out, em->partials, em->nb, em->d_state);
     SF_CHECK_LAUNCH();
     SF_HIP(hipMemcpyAsync(em->h_state, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
+    SF_HIP(hipMemcpyAsync(em->h_blkmax, em->blkmax, 2 * kMaxPartials * 8, hipMemcpyDeviceToHost, em->cur));
     SF_HIP(hipStreamSynchronize(em->cur));
     em_stats_from_state(em, stats);
     if (em->h_state->alpha_sum < kTiny) {                                       // :877-881
@@ -508,7 +789,7 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
     int rc = SFGPU_OK;
     for (uint32_t i = 0; i < n && rc == SFGPU_OK; ++i) {
         rc = em_enqueue_sweep(em);
-        if (rc == SFGPU_OK) rc = em_enqueue_update(em);
+        if (rc == SFGPU_OK) rc = em_enqueue_update(em, true);
     }
     hipError_t e = hipStreamEndCapture(em->cur, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -546,7 +827,7 @@ int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_o
         } else {
             for (uint32_t i = 0; i < chunk; ++i) {
                 if ((rc = em_enqueue_sweep(em))) return rc;
-                if ((rc = em_enqueue_update(em))) return rc;
+                if ((rc = em_enqueue_update(em, true))) return rc;
             }
         }
         if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;

@@ -9,7 +9,7 @@ namespace sfgpu {
 // Stable LSD radix sort of (key u64, value u32) pairs, ascending by key.  Scratch is allocated
 // and freed inside (synchronising) -- fine for once-per-experiment calls.
 int sort_pairs_u64_u32(const uint64_t* d_keys_in, uint64_t* d_keys_out, const uint32_t* d_vals_in,
-                       uint32_t* d_vals_out, uint64_t n, hipStream_t s);
+                       uint32_t* d_vals_out, uint64_t n, hipStream_t s, int end_bit = 64);
 
 // out[i] = sum_{j<i} in[j] for i in [0, n]; out has n+1 entries (out[n] = total).
 int exclusive_scan_u32(const uint32_t* d_in, uint64_t* d_out, uint64_t n, hipStream_t s);
