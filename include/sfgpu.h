@@ -118,13 +118,13 @@ SFGPU_API int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const
  * a6-a12. CollapsedEMOptimizer   src/CollapsedEMOptimizer.cpp:711-893
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    uint64_t M;               /* transcripts() .size() */
+    uint64_t M;               /* transcripts() .size(); <= 2^31 */
     const double* d_len;      /* per transcript: RefLength if noEffectiveLengthCorrection else
                                  EffectiveLength (:736-737); clamped to >= 1 internally (:738) */
     uint64_t C;               /* eqVec().size() */
     const uint32_t* d_rowptr; /* C+1 */
     const uint32_t* d_ids;    /* rowptr[C] */
-    const uint64_t* d_counts; /* C; every count must be < 2^32 (SFGPU_ERR_RANGE) */
+    const uint64_t* d_counts; /* C; every count must be < 2^31 - 1 (SFGPU_ERR_RANGE) */
     uint64_t num_mapped;      /* ReadExperiment::numMappedFragments() (:792) */
 } sfgpu_problem;
 

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsfgpu.so")
+LIB_PATH = os.environ.get("SFGPU_LIB_PATH", os.path.join(_HERE, "csrc", "libsfgpu.so"))   # override: kernel-tuning builds
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_ACTIVE, ERR_ALPHA_SUM, ERR_RANGE, ERR_STATE = range(7)
 

@@ -99,7 +99,7 @@ __global__ void k_narrow_counts(uint64_t C, const uint64_t* __restrict__ c64, ui
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     uint64_t v = c64[c];
-    if (v >> 32) atomicOr(overflow, 1u);
+    if (v >= 0x7FFFFFFFull) atomicOr(overflow, 1u);      // the sweep's head slot holds the count in 31 bits
     c32[c] = (uint32_t)v;
 }
 
@@ -188,23 +188,42 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
     }
 }
 
-// ---- tiled E-step sweep ------------------------------------------------------------------------
+// ---- tiled, wave-segmented E-step sweep --------------------------------------------------------
 // Classes are stored in the canonical order (first id ascending), so a run of consecutive classes
-// touches a narrow band of transcripts.  A tile is the run of classes whose first nonzero falls
-// into one kTileNnz-sized bucket of the CSR (nnz-balanced; boundaries found once per problem).
-// Per tile, one 256-thread block:
-//   A  nonzero-parallel: coalesced load of the tile's ids, gather x from an LDS-staged window of x
-//      (global gather for members outside the window) -> vals[] in LDS; window offsets stay in VGPRs
-//   B  class-parallel  : denom = sum vals, vals *= count/denom            (EMUpdate_ :251-271)
-//   C  nonzero-parallel: LDS window accumulators += vals   (ds_add_f64; global atomics outside)
-//   D  flush the touched window entries with one global f64 atomic each
-// so HBM sees each label word once per iteration and global atomics drop by the in-tile reuse factor.
-// Any input is handled (labels that span far-apart transcripts or exceed the LDS budget fall back to
-// direct global accesses); locality only buys speed.
-constexpr int kTileNnz = 2048;               // CSR bucket that defines a tile
-constexpr int kTileCap = 3072;               // nonzeros a tile may stage in LDS (bucket + longest label)
-constexpr int kNnzPerThread = kTileCap / kEmBlock;
-constexpr int kWin = 1024;                   // LDS window (transcripts)
+// touches a narrow band of transcripts.  Once per problem the CSR is re-packed into the layout the
+// sweep streams:
+//   * a tile is the run of classes whose first nonzero falls into one kTileNnz-sized bucket of the
+//     CSR (nnz-balanced); its window is the band [lo, lo+span) of transcripts it touches (<= kWin);
+//   * inside a tile the labels are laid out in 64-slot chunks -- one chunk per wavefront step --
+//     padded so that no label straddles a chunk; a label of k ids takes k+1 slots: a head slot
+//     (bit 31 set) carrying the class count, then the k transcript ids (0xFFFFFFFF = padding), so one
+//     coalesced 256-byte load per wavefront step brings everything the step needs;
+//   * labels that do not fit a chunk (> 63 ids; rare) are listed separately and handled by extra blocks.
+// Per tile, one 256-thread block stages the x-window in LDS, then each wavefront walks chunks:
+// coalesced slot load -> x gather from LDS -> ballot of the head flags -> segmented inclusive scan
+// across the 64 lanes (fixed tree order) -> count/denom broadcast -> ds_add_f64 into the LDS window
+// accumulators (EMUpdate_ :251-271 for 64 nonzeros at once, no divergent loops).  The window is
+// published with plain stores and folded per transcript by the update, so the common path has no
+// global atomics and is bit-reproducible.  Members outside the window take global gathers/atomics:
+// any input is handled, locality only buys speed.
+#ifndef SFGPU_TILE_NNZ
+#define SFGPU_TILE_NNZ 2048
+#endif
+#ifndef SFGPU_SWEEP_BLOCK
+#define SFGPU_SWEEP_BLOCK 256
+#endif
+#ifndef SFGPU_SWEEP_UNROLL
+#define SFGPU_SWEEP_UNROLL 4
+#endif
+constexpr int kTileNnz = SFGPU_TILE_NNZ;     // CSR bucket that defines a tile
+constexpr int kWin = 1024;                   // LDS window (transcripts): 2 x 8 KB
+constexpr int kChunk = 64;                   // slots per chunk = wavefront width
+constexpr int kSweepBlock = SFGPU_SWEEP_BLOCK;  // threads per tile block
+constexpr int kUnroll = SFGPU_SWEEP_UNROLL;     // chunks a wavefront fetches per step
+constexpr int kPackCap = 4096;               // classes a tile's packer stages in LDS
+constexpr uint32_t kPad = 0xFFFFFFFFu;
+constexpr uint32_t kHead = 0x80000000u;
+constexpr uint32_t kLongPos = 0xFFFFFFFFu;
 
 // tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*kTileNnz, (i+1)*kTileNnz)
 __global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, uint32_t* tile_c0) {
@@ -242,6 +261,52 @@ k_tile_window(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) tile_span[gridDim.x] = 0;   // scan sentinel
 }
 
+// greedy chunk packing of one tile: slot position of every class (tile relative); labels that do
+// not fit a chunk go to the long list.  The greedy walk is sequential, so one lane does it out of
+// LDS; tiles with more classes than the LDS stage holds walk global memory (slow, rare).
+__global__ void __launch_bounds__(kEmBlock)
+k_tile_pack(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, uint32_t* slotpos,
+            uint32_t* tile_chunks, uint32_t* long_cls, unsigned int* n_long) {
+    __shared__ uint32_t lens[kPackCap];
+    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
+    const uint32_t nc = c1 - c0;
+    const bool staged = nc <= (uint32_t)kPackCap;
+    if (staged) for (uint32_t i = threadIdx.x; i < nc; i += kEmBlock) lens[i] = rowptr[c0 + i + 1] - rowptr[c0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t pos = 0;
+        for (uint32_t i = 0; i < nc; ++i) {
+            uint32_t k = staged ? lens[i] : rowptr[c0 + i + 1] - rowptr[c0 + i];
+            uint32_t p;
+            if (k + 1 > (uint32_t)kChunk) { p = kLongPos; long_cls[atomicAdd(n_long, 1u)] = c0 + i; }
+            else if (k == 0) { p = kLongPos; }              // empty class: occupies nothing
+            else {
+                uint32_t rem = kChunk - (pos & (kChunk - 1));
+                if (k + 1 > rem) pos += rem;                 // pad to the next chunk
+                p = pos; pos += k + 1;
+            }
+            if (staged) lens[i] = p; else slotpos[c0 + i] = p;
+        }
+        tile_chunks[blockIdx.x] = (pos + kChunk - 1) / kChunk;
+        if (blockIdx.x == gridDim.x - 1) tile_chunks[gridDim.x] = 0;
+    }
+    __syncthreads();
+    if (staged) for (uint32_t i = threadIdx.x; i < nc; i += kEmBlock) slotpos[c0 + i] = lens[i];
+}
+
+__global__ void k_fill_slots(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ slotpos,
+                             const uint64_t* __restrict__ tile_chunk0, uint32_t* slots) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    uint32_t p = slotpos[c];
+    if (p == kLongPos) return;
+    uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
+    uint64_t s = tile_chunk0[b / kTileNnz] * kChunk + p;
+    slots[s] = kHead | counts[c];
+    for (uint32_t m = 0; m < k; ++m) slots[s + 1 + m] = ids[b + m];
+}
+
 // one (transcript, slot) pair per window entry; sorted by transcript this is the cover list that the
 // per-transcript update walks to fold the tiles' partial sums in a fixed order
 __global__ void __launch_bounds__(kEmBlock)
@@ -260,15 +325,51 @@ __global__ void k_cover_ptr(uint64_t M, uint64_t P, const uint64_t* __restrict__
     cov_ptr[t] = (uint32_t)lo;
 }
 
+// value of `v` from the lane `N` places lower inside the same 16-lane row (0.0 where there is none):
+// v_mov_b32 with the row_shr:N data-parallel-primitive modifier, one per half of the double
+template <int N>
+__device__ __forceinline__ double row_shr_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// inclusive scan of v over [start, lane] for every lane (start = first lane of the lane's segment),
+// in a fixed order: DPP shifts inside each 16-lane row, then the three row carries in sequence
+__device__ __forceinline__ double segmented_scan64(double v, int lane, int start) {
+    double s = v, up;
+    up = row_shr_f64<1>(s); if (lane >= start + 1) s += up;
+    up = row_shr_f64<2>(s); if (lane >= start + 2) s += up;
+    up = row_shr_f64<4>(s); if (lane >= start + 4) s += up;
+    up = row_shr_f64<8>(s); if (lane >= start + 8) s += up;
+    double c = readlane_f64(s, 15); if (lane >= 16 && lane < 32 && start < 16) s += c;
+    c = readlane_f64(s, 31);        if (lane >= 32 && lane < 48 && start < 32) s += c;
+    c = readlane_f64(s, 47);        if (lane >= 48 && start < 48) s += c;
+    return s;
+}
+
+struct SweepArgs {
+    uint32_t n_tiles;
+    const uint32_t* rowptr; const uint32_t* ids; const uint32_t* counts;        // caller CSR (long labels)
+    const uint32_t* slots;
+    const uint64_t* tile_chunk0; const uint32_t* tile_lo; const uint32_t* tile_span; const uint64_t* tile_off;
+    const uint32_t* long_cls;
+    const double* x; double* alpha_out; double* partial;
+    EmState* st; uint32_t min_iter, max_iter; int ablate;
+};
+
 template <bool VB>
-__global__ void __launch_bounds__(kEmBlock)
-k_sweep_tile(uint64_t M, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
-             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ tile_c0,
-             const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span,
-             const uint64_t* __restrict__ tile_off, const double* __restrict__ x, double* alpha_out,
-             double* __restrict__ partial, EmState* st, uint32_t min_iter, uint32_t max_iter, int ablate) {
+__global__ void __launch_bounds__(kSweepBlock)
+k_sweep_chunk(SweepArgs a) {
+    EmState* st = a.st;
     uint32_t it = st->it_a;
-    bool stop = em_stop(it, st, min_iter, max_iter);
+    bool stop = em_stop(it, st, a.min_iter, a.max_iter);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->it_b = stop ? kDoneMark : it;
         if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
@@ -276,86 +377,92 @@ k_sweep_tile(uint64_t M, const uint32_t* __restrict__ rowptr, const uint32_t* __
     if (stop) return;
     __shared__ double xs[kWin];
     __shared__ double acc[kWin];
-    __shared__ double vals[kTileCap];
-    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
-    if (c0 == c1) return;
-    if (ablate & 16) return;
-    const uint32_t lo = tile_lo[blockIdx.x];
-    const uint32_t span = tile_span[blockIdx.x];          // members at lo + [0, span) live in the LDS window
-    const uint32_t j0 = rowptr[c0], j1 = rowptr[c1];
-    const uint32_t n = j1 - j0;
-    for (uint32_t i = threadIdx.x; i < span; i += kEmBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
-    (void)M;
-    if (n <= (uint32_t)kTileCap) {
-        // ---- A: ids -> window offsets (VGPRs); x gather -> vals[]
-        uint32_t tid_[kNnzPerThread];
+    __shared__ double red[kSweepBlock / kWave];
+    const double* __restrict__ x = a.x;
+    if (blockIdx.x >= a.n_tiles) {
+        // ---- one label longer than a chunk: whole block, direct global accesses
+        uint32_t c = a.long_cls[blockIdx.x - a.n_tiles];
+        uint32_t b = a.rowptr[c], e = a.rowptr[c + 1];
+        double part = 0.0;
+        for (uint32_t j = b + threadIdx.x; j < e; j += kSweepBlock) {
+            double v = x[a.ids[j]];
+            if (VB) { if (v > 0.0) part += v; } else part += v;
+        }
+        part = wave_sum(part);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = part;
+        __syncthreads();
+        double denom = 0.0;
+        for (int i = 0; i < kSweepBlock / kWave; ++i) denom += red[i];   // same order in every thread
+        if (!(denom > kTiny)) return;
+        double inv = (double)a.counts[c] / denom;
+        for (uint32_t j = b + threadIdx.x; j < e; j += kSweepBlock) {
+            uint32_t t = a.ids[j]; double v = x[t];
+            if (VB ? (v > 0.0) : (v == v)) atomicAdd(&a.alpha_out[t], v * inv);
+        }
+        return;
+    }
+    const uint32_t lo = a.tile_lo[blockIdx.x];
+    const uint32_t span = a.tile_span[blockIdx.x];         // members at lo + [0, span) live in the LDS window
+    const uint64_t q0 = a.tile_chunk0[blockIdx.x], q1 = a.tile_chunk0[blockIdx.x + 1];
+    if (span == 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long le_mask = (2ull << lane) - 1ull;          // lanes <= lane
+    // Each wavefront walks groups of kUnroll consecutive chunks.  A group's slots are fetched with
+    // kUnroll independent 256-byte loads (addresses clamped to the tile so the loads are
+    // unconditional) one group ahead of their use, which keeps >= 1 KB per wavefront in flight:
+    // the stream is latency-bound otherwise.
+    const uint64_t qlast = q1 - 1;
+    const uint64_t gstride = (uint64_t)(kSweepBlock / kWave) * kUnroll;
+    uint64_t base = q0 + (uint64_t)(threadIdx.x >> 6) * kUnroll;
+    uint32_t nxt[kUnroll];
 #pragma unroll
-        for (int k = 0; k < kNnzPerThread; ++k) {
-            uint32_t j = threadIdx.x + k * kEmBlock;
-            tid_[k] = (j < n) ? ids[j0 + j] : 0xFFFFFFFFu;
-        }
-        __syncthreads();
+    for (int u = 0; u < kUnroll; ++u) { uint64_t q = base + u; nxt[u] = a.slots[(q < q1 ? q : qlast) * kChunk + lane]; }
+    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
+    __syncthreads();
+    if (!(a.ablate & 1))
+    for (; base < q1; base += gstride) {
+        uint32_t cur[kUnroll];
 #pragma unroll
-        for (int k = 0; k < kNnzPerThread; ++k) {
-            uint32_t j = threadIdx.x + k * kEmBlock;
-            if (j < n && !(ablate & 4)) {
-                uint32_t d = tid_[k] - lo;
-                double v = (d < span) ? xs[d] : x[tid_[k]];
-                if (VB) { if (!(v > 0.0)) v = 0.0; }                   // expTheta == 0 terms are skipped (:344, :356)
-                vals[j] = v;
-            }
-        }
-        __syncthreads();
-        // ---- B: per class, denom and scale
-        if (!(ablate & 1))
-        for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
-            uint32_t b = rowptr[c] - j0, e = rowptr[c + 1] - j0;
-            double cnt = (double)counts[c];
-            if (e - b == 1) { vals[b] = cnt; continue; }               // :275 / :364 the full count
-            double denom = 0.0;
-            for (uint32_t j = b; j < e; ++j) denom += vals[j];
-            double inv = (denom > kTiny) ? cnt / denom : 0.0;          // :260-264 ; skipped class adds nothing
-            for (uint32_t j = b; j < e; ++j) {
-                double v = vals[j];
-                vals[j] = (denom > kTiny && v == v) ? v * inv : 0.0;   // NaN terms are skipped (:269)
-            }
-        }
-        __syncthreads();
-        // ---- C: scatter-add
-        if (!(ablate & 2))
+        for (int u = 0; u < kUnroll; ++u) cur[u] = nxt[u];
 #pragma unroll
-        for (int k = 0; k < kNnzPerThread; ++k) {
-            uint32_t j = threadIdx.x + k * kEmBlock;
-            if (j < n) {
-                double v = vals[j];
-                if (v != 0.0) {
-                    uint32_t d = tid_[k] - lo;
-                    if (d < span) atomicAdd(&acc[d], v); else atomicAdd(&alpha_out[tid_[k]], v);
-                }
-            }
-        }
-    } else {
-        // ---- oversize tile (a label longer than the LDS budget): direct path
-        __syncthreads();
-        for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
-            uint32_t b = rowptr[c], e = rowptr[c + 1];
-            double cnt = (double)counts[c];
-            if (e - b == 1) { atomicAdd(&alpha_out[ids[b]], cnt); continue; }
-            double denom = 0.0;
-            for (uint32_t j = b; j < e; ++j) { double v = x[ids[j]]; if (VB) { if (v > 0.0) denom += v; } else denom += v; }
-            if (!(denom > kTiny)) continue;
-            double inv = cnt / denom;
-            for (uint32_t j = b; j < e; ++j) {
-                uint32_t t = ids[j]; double v = x[t];
-                if (VB ? (v > 0.0) : (v == v)) atomicAdd(&alpha_out[t], v * inv);
+        for (int u = 0; u < kUnroll; ++u) { uint64_t q = base + gstride + u; nxt[u] = a.slots[(q < q1 ? q : qlast) * kChunk + lane]; }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (base + u >= q1) break;                                  // wave-uniform
+            const uint32_t slot = cur[u];
+            const bool valid = slot != kPad;
+            const bool head = valid && (slot & kHead);                  // head slot: carries the class count
+            const bool member = valid && !(slot & kHead);               // member slot: a transcript id
+            const unsigned long long headmask = __ballot(head);
+            const unsigned long long validmask = __ballot(valid);
+            const uint32_t d = slot - lo;
+            const bool inwin = member && d < span;
+            double v = xs[inwin ? d : 0u];                              // LDS gather (ds_read_b64)
+            if (!inwin) v = 0.0;
+            if (__ballot(member && !inwin)) { if (member && !inwin) v = x[slot]; }   // rare: outside the window
+            if (VB) { if (!(v > 0.0)) v = 0.0; }                        // expTheta == 0 terms are skipped (:344, :356)
+            // segment (= head + label) geometry inside the chunk; every chunk starts with a head
+            const unsigned long long below = headmask & le_mask;
+            const int start = 63 - __clzll((long long)below);
+            const unsigned long long above = headmask & ~le_mask;
+            const int end = above ? (__ffsll((long long)above) - 2) : (__popcll(validmask) - 1);
+            // segmented inclusive scan across the wavefront, fixed order
+            const double s = segmented_scan64(v, lane, start);
+            if (a.ablate & 2) { if (s == 123.456) acc[0] = s; continue; }
+            const double total = __shfl(s, end, kWave);
+            const double cnt = __shfl((double)(slot & ~kHead), start, kWave);
+            double contrib;
+            if (end - start == 1) contrib = cnt;                        // singleton label: the full count (:275 / :364)
+            else contrib = (total > kTiny && v == v) ? v * (cnt / total) : 0.0;   // :260-270 (NaN terms skipped :269)
+            if (member && contrib != 0.0 && !(a.ablate & 4)) {
+                if (inwin) atomicAdd(&acc[d], contrib); else atomicAdd(&a.alpha_out[slot], contrib);
             }
         }
     }
     __syncthreads();
-    // ---- D: publish the window (plain coalesced stores; folded per transcript by the update)
-    const uint64_t off = tile_off[blockIdx.x];
-    if (!(ablate & 8))
-    for (uint32_t i = threadIdx.x; i < span; i += kEmBlock) partial[off + i] = acc[i];
+    // ---- publish the window (plain coalesced stores; folded per transcript by the update)
+    const uint64_t off = a.tile_off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) a.partial[off + i] = acc[i];
 }
 
 // alphaOut[t] += sum of the tiles' window entries for t, in cover-list order (deterministic)
@@ -468,6 +575,8 @@ struct sfgpu_em {
     uint64_t* tile_off = nullptr; uint64_t P = 0;          // window slots over all tiles
     double* partial = nullptr;                              // [P] per-tile window sums of one sweep
     uint32_t* cov_ptr = nullptr; uint32_t* cov_pos = nullptr;   // transcript -> its window slots
+    uint32_t* slots = nullptr;                                  // chunked labels (see k_sweep_chunk)
+    uint64_t* tile_chunk0 = nullptr; uint32_t* long_cls = nullptr; uint32_t n_long = 0; uint64_t n_chunks = 0;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
     int ablate = 0;                                         // timing experiments only (SFGPU_EM_ABLATE)
     int sweep_variant = 1;                                  // 0 = lane-per-class/global atomics, 1 = LDS tiles
@@ -486,7 +595,8 @@ static void em_free(sfgpu_em* em) {
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
-                    em->cov_ptr, em->cov_pos, em->blkmax};
+                    em->cov_ptr, em->cov_pos, em->slots, em->tile_chunk0, em->long_cls,
+                    em->blkmax};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (em->h_state) (void)hipHostFree(em->h_state);
     if (em->h_blkmax) (void)hipHostFree(em->h_blkmax);
@@ -518,13 +628,13 @@ static int em_enqueue_sweep(sfgpu_em* em) {
         else hipLaunchKernelGGL(k_sweep_lane<false>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
                                 em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
     } else {
-        dim3 g(em->n_tiles);
-        if (vb) hipLaunchKernelGGL(k_sweep_tile<true>, g, b, 0, em->cur, p.M, p.d_rowptr, p.d_ids, em->counts32, em->tile_c0,
-                                   em->tile_lo, em->tile_span, em->tile_off, em->x, em->alpha_out, em->partial, em->d_state,
-                                   em->opts.min_iter, em->opts.max_iter, em->ablate);
-        else hipLaunchKernelGGL(k_sweep_tile<false>, g, b, 0, em->cur, p.M, p.d_rowptr, p.d_ids, em->counts32, em->tile_c0,
-                                em->tile_lo, em->tile_span, em->tile_off, em->x, em->alpha_out, em->partial, em->d_state,
-                                em->opts.min_iter, em->opts.max_iter, em->ablate);
+        dim3 g(em->n_tiles + em->n_long);
+        b = dim3(kSweepBlock);
+        SweepArgs a{em->n_tiles, p.d_rowptr, p.d_ids, em->counts32, em->slots,
+                    em->tile_chunk0, em->tile_lo, em->tile_span, em->tile_off, em->long_cls, em->x, em->alpha_out,
+                    em->partial, em->d_state, em->opts.min_iter, em->opts.max_iter, em->ablate};
+        if (vb) hipLaunchKernelGGL(k_sweep_chunk<true>, g, b, 0, em->cur, a);
+        else hipLaunchKernelGGL(k_sweep_chunk<false>, g, b, 0, em->cur, a);
     }
     SF_CHECK_LAUNCH();
     return SFGPU_OK;
@@ -589,6 +699,7 @@ extern "C" {
 int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stream) {
     SF_REQUIRE(out && prob, SFGPU_ERR_INVALID, "sfgpu_em_create: null pointer");
     SF_REQUIRE(prob->M > 0 && prob->d_len, SFGPU_ERR_INVALID, "sfgpu_em_create: need M > 0 and d_len");
+    SF_REQUIRE(prob->M <= (1ull << 31), SFGPU_ERR_RANGE, "sfgpu_em_create: transcript ids must fit 31 bits");
     SF_REQUIRE(prob->C == 0 || (prob->d_rowptr && prob->d_ids && prob->d_counts), SFGPU_ERR_INVALID,
                "sfgpu_em_create: null CSR pointer");
     sfgpu_em* em = new sfgpu_em();
@@ -629,7 +740,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipMemcpyAsync(&rp_end, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
-        if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
+        if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^31 - 1"); em_free(em); return SFGPU_ERR_RANGE; }
     } else {
         EM_TRY(hipStreamSynchronize(em->cur));
     }
@@ -650,6 +761,32 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                            em->tile_lo, em->tile_span);
         EM_TRY(hipGetLastError());
         if (exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur)) { em_free(em); return SFGPU_ERR_HIP; }
+        {   // chunk packing of the labels (see k_sweep_chunk)
+            uint32_t *slotpos = nullptr, *t_chunks = nullptr; unsigned int* d_nlong = nullptr;
+            EM_TRY(hipMalloc(&slotpos, C * 4)); EM_TRY(hipMalloc(&t_chunks, ((size_t)nt + 1) * 4));
+            EM_TRY(hipMalloc(&em->tile_chunk0, ((size_t)nt + 1) * 8));
+            EM_TRY(hipMalloc(&em->long_cls, C * 4)); EM_TRY(hipMalloc(&d_nlong, 4));
+            EM_TRY(hipMemsetAsync(d_nlong, 0, 4, em->cur));
+            hipLaunchKernelGGL(k_tile_pack, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, em->tile_c0, slotpos, t_chunks,
+                               em->long_cls, d_nlong);
+            EM_TRY(hipGetLastError());
+            int sr = exclusive_scan_u32(t_chunks, em->tile_chunk0, nt, em->cur);
+            uint64_t nq = 0; unsigned int nl = 0;
+            if (!sr) {
+                EM_TRY(hipMemcpyAsync(&nq, em->tile_chunk0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+                EM_TRY(hipMemcpyAsync(&nl, d_nlong, 4, hipMemcpyDeviceToHost, em->cur));
+                EM_TRY(hipStreamSynchronize(em->cur));
+                em->n_chunks = nq; em->n_long = nl;
+                EM_TRY(hipMalloc(&em->slots, (nq ? nq : 1) * kChunk * 4));
+                EM_TRY(hipMemsetAsync(em->slots, 0xFF, (nq ? nq : 1) * kChunk * 4, em->cur));
+                hipLaunchKernelGGL(k_fill_slots, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_rowptr, prob->d_ids,
+                                   em->counts32, slotpos, em->tile_chunk0, em->slots);
+                EM_TRY(hipGetLastError());
+                EM_TRY(hipStreamSynchronize(em->cur));
+            }
+            (void)hipFree(slotpos); (void)hipFree(t_chunks); (void)hipFree(d_nlong);
+            if (sr) { em_free(em); return sr; }
+        }
         uint64_t P = 0;
         EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
