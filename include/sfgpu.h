@@ -124,7 +124,7 @@ typedef struct {
     uint64_t C;               /* eqVec().size() */
     const uint32_t* d_rowptr; /* C+1 */
     const uint32_t* d_ids;    /* rowptr[C] */
-    const uint64_t* d_counts; /* C; every count must be < 2^31 - 1 (SFGPU_ERR_RANGE) */
+    const uint64_t* d_counts; /* C; every count must be < 2^31 (SFGPU_ERR_RANGE) */
     uint64_t num_mapped;      /* ReadExperiment::numMappedFragments() (:792) */
 } sfgpu_problem;
 

@@ -94,13 +94,14 @@ __global__ void k_clamp_len(uint64_t M, const double* __restrict__ len, double* 
     if (t < M) { double l = len[t]; lenc[t] = (l <= 1.0) ? 1.0 : l; }   // :738
 }
 
-__global__ void k_narrow_counts(uint64_t C, const uint64_t* __restrict__ c64, uint32_t* __restrict__ c32,
-                                unsigned int* overflow) {
+// device-private copy of the counts: 31 bits of count, bit 31 = the class is a singleton
+__global__ void k_narrow_counts(uint64_t C, const uint64_t* __restrict__ c64, const uint32_t* __restrict__ rowptr,
+                                uint32_t* __restrict__ c32, unsigned int* overflow) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     uint64_t v = c64[c];
-    if (v >= 0x7FFFFFFFull) atomicOr(overflow, 1u);      // the sweep's head slot holds the count in 31 bits
-    c32[c] = (uint32_t)v;
+    if (v >= 0x80000000ull) atomicOr(overflow, 1u);
+    c32[c] = (uint32_t)v | ((rowptr[c + 1] - rowptr[c] == 1) ? 0x80000000u : 0u);
 }
 
 // :774-782  every transcript that appears in a class is active
@@ -171,7 +172,7 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
     uint64_t c = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
     if (c >= C) return;
     uint32_t b = rowptr[c], e = rowptr[c + 1];
-    double cnt = (double)counts[c];
+    double cnt = (double)(counts[c] & 0x7FFFFFFFu);
     if (e - b == 1) { atomicAdd(&alpha_out[ids[b]], cnt); return; }     // :275 / :364
     if (e == b) return;
     double denom = 0.0;
@@ -188,42 +189,43 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
     }
 }
 
-// ---- tiled, wave-segmented E-step sweep --------------------------------------------------------
+// ---- tiled E-step sweep with LDS accumulators --------------------------------------------------
 // Classes are stored in the canonical order (first id ascending), so a run of consecutive classes
-// touches a narrow band of transcripts.  Once per problem the CSR is re-packed into the layout the
-// sweep streams:
+// touches a narrow band of transcripts.  Once per problem the CSR is re-packed into the stream the
+// sweep reads:
 //   * a tile is the run of classes whose first nonzero falls into one kTileNnz-sized bucket of the
 //     CSR (nnz-balanced); its window is the band [lo, lo+span) of transcripts it touches (<= kWin);
-//   * inside a tile the labels are laid out in 64-slot chunks -- one chunk per wavefront step --
-//     padded so that no label straddles a chunk; a label of k ids takes k+1 slots: a head slot
-//     (bit 31 set) carrying the class count, then the k transcript ids (0xFFFFFFFF = padding), so one
-//     coalesced 256-byte load per wavefront step brings everything the step needs;
-//   * labels that do not fit a chunk (> 63 ids; rare) are listed separately and handled by extra blocks.
-// Per tile, one 256-thread block stages the x-window in LDS, then each wavefront walks chunks:
-// coalesced slot load -> x gather from LDS -> ballot of the head flags -> segmented inclusive scan
-// across the 64 lanes (fixed tree order) -> count/denom broadcast -> ds_add_f64 into the LDS window
-// accumulators (EMUpdate_ :251-271 for 64 nonzeros at once, no divergent loops).  The window is
-// published with plain stores and folded per transcript by the update, so the common path has no
-// global atomics and is bit-reproducible.  Members outside the window take global gathers/atomics:
-// any input is handled, locality only buys speed.
+//   * one 32-bit word per nonzero:  [31 null][29 single][28..16 class index in the tile]
+//     [15..0 window offset], tiles padded to 8 words so every lane fetches its 8 consecutive words
+//     with two 16-byte loads;
+//   * members outside the window ("escapes": labels spanning far-apart transcripts) are null in the
+//     stream and sit in a per-tile side list (transcript id, class index) that takes global gathers
+//     and global atomics -- any input is handled, locality only buys speed.
+// Per tile, one 1024-thread block (EMUpdate_ :236-277 for ~8000 nonzeros at a time; measured on
+// MI355X: per-block fixed costs -- window staging, barriers, publishing -- dominate below ~4000):
+//   0  stage x[lo, lo+span) in LDS, zero the LDS accumulators
+//   A  nonzero-parallel: v = x[member] (LDS gather); denominators den[class] += v with ds_add_f64.
+//      A lane owns 8 CONSECUTIVE nonzeros, so lanes of one instruction hit different classes (no
+//      same-address serialisation) and a lane first sums its run of equal classes in registers
+//   B  class-parallel  : den[class] <- count/denom   (:260-264; singletons carry the full count :275)
+//   C  nonzero-parallel: window accumulator acc[member] += v * den[class]   (ds_add_f64)
+//   D  publish the window with plain coalesced stores; the update folds the windows per transcript
+// HBM sees 4 bytes per nonzero + 8 per class per iteration and the common path has no global atomic.
 #ifndef SFGPU_TILE_NNZ
-#define SFGPU_TILE_NNZ 2048
+#define SFGPU_TILE_NNZ 8000
 #endif
-#ifndef SFGPU_SWEEP_BLOCK
-#define SFGPU_SWEEP_BLOCK 256
-#endif
-#ifndef SFGPU_SWEEP_UNROLL
-#define SFGPU_SWEEP_UNROLL 4
-#endif
-constexpr int kTileNnz = SFGPU_TILE_NNZ;     // CSR bucket that defines a tile
+constexpr int kTileNnz = SFGPU_TILE_NNZ;     // CSR bucket that defines a tile (<= 8191 classes per tile)
 constexpr int kWin = 1024;                   // LDS window (transcripts): 2 x 8 KB
-constexpr int kChunk = 64;                   // slots per chunk = wavefront width
-constexpr int kSweepBlock = SFGPU_SWEEP_BLOCK;  // threads per tile block
-constexpr int kUnroll = SFGPU_SWEEP_UNROLL;     // chunks a wavefront fetches per step
-constexpr int kPackCap = 4096;               // classes a tile's packer stages in LDS
-constexpr uint32_t kPad = 0xFFFFFFFFu;
-constexpr uint32_t kHead = 0x80000000u;
-constexpr uint32_t kLongPos = 0xFFFFFFFFu;
+#ifndef SFGPU_SWEEP_BLOCK
+#define SFGPU_SWEEP_BLOCK 1024
+#endif
+constexpr int kSweepBlock = SFGPU_SWEEP_BLOCK;
+#ifndef SFGPU_PER_LANE
+#define SFGPU_PER_LANE 8
+#endif
+constexpr int kPerLane = SFGPU_PER_LANE;     // consecutive stream words per lane (8: two 16-byte loads)
+constexpr uint32_t kNull = 0x80000000u, kSingle = 0x20000000u;
+static_assert(kTileNnz <= 8191, "class index field is 13 bits");
 
 // tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*kTileNnz, (i+1)*kTileNnz)
 __global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, uint32_t* tile_c0) {
@@ -235,11 +237,14 @@ __global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __rest
     tile_c0[i] = (uint32_t)lo;
 }
 
-// window of tile i: [lo, lo + span) with lo = smallest member and span <= kWin
+// window of tile i: [lo, lo + span) with lo = smallest member and span <= kWin; also the padded
+// stream length of the tile and its number of escapes (members beyond the window)
 __global__ void __launch_bounds__(kEmBlock)
 k_tile_window(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
-              uint32_t* tile_lo, uint32_t* tile_span) {
+              uint32_t* tile_lo, uint32_t* tile_span, uint32_t* tile_len8, uint32_t* tile_nesc) {
     __shared__ uint32_t rmin[kEmBlock / kWave], rmax[kEmBlock / kWave];
+    __shared__ uint32_t lo_s;
+    __shared__ unsigned int esc_s;
     uint32_t b = rowptr[tile_c0[blockIdx.x]], e = rowptr[tile_c0[blockIdx.x + 1]];
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
     for (uint32_t j = b + threadIdx.x; j < e; j += kEmBlock) { uint32_t v = ids[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
@@ -248,63 +253,54 @@ k_tile_window(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
         uint32_t w = __shfl_down(mx, o, kWave); mx = w > mx ? w : mx;
     }
     if ((threadIdx.x & (kWave - 1)) == 0) { rmin[threadIdx.x / kWave] = mn; rmax[threadIdx.x / kWave] = mx; }
+    if (threadIdx.x == 0) esc_s = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < kEmBlock / kWave; ++i) { mn = rmin[i] < mn ? rmin[i] : mn; mx = rmax[i] > mx ? rmax[i] : mx; }
-        if (e == b) { tile_lo[blockIdx.x] = 0; tile_span[blockIdx.x] = 0; }
-        else {
-            uint32_t span = mx - mn + 1;
-            tile_lo[blockIdx.x] = mn;
-            tile_span[blockIdx.x] = span < (uint32_t)kWin ? span : (uint32_t)kWin;
-        }
+        uint32_t span = 0;
+        if (e == b) mn = 0; else { span = mx - mn + 1; span = span < (uint32_t)kWin ? span : (uint32_t)kWin; }
+        tile_lo[blockIdx.x] = mn; tile_span[blockIdx.x] = span; lo_s = mn;
+        tile_len8[blockIdx.x] = (e - b + kPerLane - 1) / kPerLane * kPerLane;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) tile_span[gridDim.x] = 0;   // scan sentinel
-}
-
-// greedy chunk packing of one tile: slot position of every class (tile relative); labels that do
-// not fit a chunk go to the long list.  The greedy walk is sequential, so one lane does it out of
-// LDS; tiles with more classes than the LDS stage holds walk global memory (slow, rare).
-__global__ void __launch_bounds__(kEmBlock)
-k_tile_pack(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, uint32_t* slotpos,
-            uint32_t* tile_chunks, uint32_t* long_cls, unsigned int* n_long) {
-    __shared__ uint32_t lens[kPackCap];
-    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
-    const uint32_t nc = c1 - c0;
-    const bool staged = nc <= (uint32_t)kPackCap;
-    if (staged) for (uint32_t i = threadIdx.x; i < nc; i += kEmBlock) lens[i] = rowptr[c0 + i + 1] - rowptr[c0 + i];
+    __syncthreads();
+    const uint32_t lo = lo_s;
+    unsigned int mine = 0;
+    for (uint32_t j = b + threadIdx.x; j < e; j += kEmBlock) mine += (ids[j] - lo >= (uint32_t)kWin) ? 1u : 0u;
+    if (mine) atomicAdd(&esc_s, mine);
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t pos = 0;
-        for (uint32_t i = 0; i < nc; ++i) {
-            uint32_t k = staged ? lens[i] : rowptr[c0 + i + 1] - rowptr[c0 + i];
-            uint32_t p;
-            if (k + 1 > (uint32_t)kChunk) { p = kLongPos; long_cls[atomicAdd(n_long, 1u)] = c0 + i; }
-            else if (k == 0) { p = kLongPos; }              // empty class: occupies nothing
-            else {
-                uint32_t rem = kChunk - (pos & (kChunk - 1));
-                if (k + 1 > rem) pos += rem;                 // pad to the next chunk
-                p = pos; pos += k + 1;
-            }
-            if (staged) lens[i] = p; else slotpos[c0 + i] = p;
-        }
-        tile_chunks[blockIdx.x] = (pos + kChunk - 1) / kChunk;
-        if (blockIdx.x == gridDim.x - 1) tile_chunks[gridDim.x] = 0;
+        tile_nesc[blockIdx.x] = esc_s;
+        if (blockIdx.x == gridDim.x - 1) { tile_span[gridDim.x] = 0; tile_len8[gridDim.x] = 0; tile_nesc[gridDim.x] = 0; }   // scan sentinels
     }
-    __syncthreads();
-    if (staged) for (uint32_t i = threadIdx.x; i < nc; i += kEmBlock) slotpos[c0 + i] = lens[i];
 }
 
-__global__ void k_fill_slots(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
-                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ slotpos,
-                             const uint64_t* __restrict__ tile_chunk0, uint32_t* slots) {
-    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    uint32_t p = slotpos[c];
-    if (p == kLongPos) return;
-    uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
-    uint64_t s = tile_chunk0[b / kTileNnz] * kChunk + p;
-    slots[s] = kHead | counts[c];
-    for (uint32_t m = 0; m < k; ++m) slots[s + 1 + m] = ids[b + m];
+// write the tile's stream words (one lane per class walks its label) and its escape list
+__global__ void __launch_bounds__(kEmBlock)
+k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
+              const uint32_t* __restrict__ tile_lo, const uint64_t* __restrict__ tile_s0,
+              const uint64_t* __restrict__ tile_esc0, uint32_t* stream, uint32_t* esc_id, uint32_t* esc_cls) {
+    __shared__ unsigned int esc_cursor;
+    if (threadIdx.x == 0) esc_cursor = 0;
+    __syncthreads();
+    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
+    const uint32_t lo = tile_lo[blockIdx.x];
+    const uint64_t s0 = tile_s0[blockIdx.x], s1 = tile_s0[blockIdx.x + 1], e0 = tile_esc0[blockIdx.x];
+    const uint32_t j0 = rowptr[c0], n = rowptr[c1] - j0;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+        uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
+        uint32_t tag = ((c - c0) << 16) | (k == 1 ? kSingle : 0u);
+        for (uint32_t m = 0; m < k; ++m) {
+            uint32_t t = ids[b + m], d = t - lo, w;
+            if (d < (uint32_t)kWin) w = tag | d;
+            else {
+                unsigned int idx = atomicAdd(&esc_cursor, 1u);
+                esc_id[e0 + idx] = t; esc_cls[e0 + idx] = tag;      // tag = class index << 16 | single flag
+                w = kNull;
+            }
+            stream[s0 + (b - j0) + m] = w;
+        }
+    }
+    for (uint64_t p = s0 + n + threadIdx.x; p < s1; p += kEmBlock) stream[p] = kNull;
 }
 
 // one (transcript, slot) pair per window entry; sorted by transcript this is the cover list that the
@@ -317,6 +313,12 @@ k_cover_pairs(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__
     for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) { keys[off + d] = (uint64_t)lo + d; vals[off + d] = (uint32_t)(off + d); }
 }
 
+// cov_pos[k] = window slot that sorts to position k  ->  pub_pos[slot] = k
+__global__ void k_invert_perm(uint64_t P, const uint32_t* __restrict__ cov_pos, uint32_t* pub_pos) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < P) pub_pos[cov_pos[k]] = (uint32_t)k;
+}
+
 __global__ void k_cover_ptr(uint64_t M, uint64_t P, const uint64_t* __restrict__ sorted_keys, uint32_t* cov_ptr) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > M) return;
@@ -325,48 +327,19 @@ __global__ void k_cover_ptr(uint64_t M, uint64_t P, const uint64_t* __restrict__
     cov_ptr[t] = (uint32_t)lo;
 }
 
-// value of `v` from the lane `N` places lower inside the same 16-lane row (0.0 where there is none):
-// v_mov_b32 with the row_shr:N data-parallel-primitive modifier, one per half of the double
-template <int N>
-__device__ __forceinline__ double row_shr_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// inclusive scan of v over [start, lane] for every lane (start = first lane of the lane's segment),
-// in a fixed order: DPP shifts inside each 16-lane row, then the three row carries in sequence
-__device__ __forceinline__ double segmented_scan64(double v, int lane, int start) {
-    double s = v, up;
-    up = row_shr_f64<1>(s); if (lane >= start + 1) s += up;
-    up = row_shr_f64<2>(s); if (lane >= start + 2) s += up;
-    up = row_shr_f64<4>(s); if (lane >= start + 4) s += up;
-    up = row_shr_f64<8>(s); if (lane >= start + 8) s += up;
-    double c = readlane_f64(s, 15); if (lane >= 16 && lane < 32 && start < 16) s += c;
-    c = readlane_f64(s, 31);        if (lane >= 32 && lane < 48 && start < 32) s += c;
-    c = readlane_f64(s, 47);        if (lane >= 48 && start < 48) s += c;
-    return s;
-}
-
 struct SweepArgs {
-    uint32_t n_tiles;
-    const uint32_t* rowptr; const uint32_t* ids; const uint32_t* counts;        // caller CSR (long labels)
-    const uint32_t* slots;
-    const uint64_t* tile_chunk0; const uint32_t* tile_lo; const uint32_t* tile_span; const uint64_t* tile_off;
-    const uint32_t* long_cls;
+    const uint32_t* rowptr; const uint32_t* counts;                      // caller CSR (class sizes, counts)
+    const uint32_t* stream; const uint32_t* esc_id; const uint32_t* esc_cls;
+    const uint32_t* tile_c0; const uint32_t* tile_lo; const uint32_t* tile_span;
+    const uint64_t* tile_s0; const uint64_t* tile_esc0; const uint64_t* tile_off;
+    const uint32_t* pub_pos;                                             // window slot -> index in `partial`
     const double* x; double* alpha_out; double* partial;
     EmState* st; uint32_t min_iter, max_iter; int ablate;
 };
 
 template <bool VB>
 __global__ void __launch_bounds__(kSweepBlock)
-k_sweep_chunk(SweepArgs a) {
+k_sweep_lds(SweepArgs a) {
     EmState* st = a.st;
     uint32_t it = st->it_a;
     bool stop = em_stop(it, st, a.min_iter, a.max_iter);
@@ -377,99 +350,111 @@ k_sweep_chunk(SweepArgs a) {
     if (stop) return;
     __shared__ double xs[kWin];
     __shared__ double acc[kWin];
-    __shared__ double red[kSweepBlock / kWave];
+    __shared__ double den[kTileNnz];                       // denominators, then count/denom, per class of the tile
     const double* __restrict__ x = a.x;
-    if (blockIdx.x >= a.n_tiles) {
-        // ---- one label longer than a chunk: whole block, direct global accesses
-        uint32_t c = a.long_cls[blockIdx.x - a.n_tiles];
-        uint32_t b = a.rowptr[c], e = a.rowptr[c + 1];
-        double part = 0.0;
-        for (uint32_t j = b + threadIdx.x; j < e; j += kSweepBlock) {
-            double v = x[a.ids[j]];
-            if (VB) { if (v > 0.0) part += v; } else part += v;
-        }
-        part = wave_sum(part);
-        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = part;
-        __syncthreads();
-        double denom = 0.0;
-        for (int i = 0; i < kSweepBlock / kWave; ++i) denom += red[i];   // same order in every thread
-        if (!(denom > kTiny)) return;
-        double inv = (double)a.counts[c] / denom;
-        for (uint32_t j = b + threadIdx.x; j < e; j += kSweepBlock) {
-            uint32_t t = a.ids[j]; double v = x[t];
-            if (VB ? (v > 0.0) : (v == v)) atomicAdd(&a.alpha_out[t], v * inv);
-        }
-        return;
-    }
-    const uint32_t lo = a.tile_lo[blockIdx.x];
-    const uint32_t span = a.tile_span[blockIdx.x];         // members at lo + [0, span) live in the LDS window
-    const uint64_t q0 = a.tile_chunk0[blockIdx.x], q1 = a.tile_chunk0[blockIdx.x + 1];
-    if (span == 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const unsigned long long le_mask = (2ull << lane) - 1ull;          // lanes <= lane
-    // Each wavefront walks groups of kUnroll consecutive chunks.  A group's slots are fetched with
-    // kUnroll independent 256-byte loads (addresses clamped to the tile so the loads are
-    // unconditional) one group ahead of their use, which keeps >= 1 KB per wavefront in flight:
-    // the stream is latency-bound otherwise.
-    const uint64_t qlast = q1 - 1;
-    const uint64_t gstride = (uint64_t)(kSweepBlock / kWave) * kUnroll;
-    uint64_t base = q0 + (uint64_t)(threadIdx.x >> 6) * kUnroll;
-    uint32_t nxt[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) { uint64_t q = base + u; nxt[u] = a.slots[(q < q1 ? q : qlast) * kChunk + lane]; }
-    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
-    __syncthreads();
-    if (!(a.ablate & 1))
-    for (; base < q1; base += gstride) {
-        uint32_t cur[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) cur[u] = nxt[u];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) { uint64_t q = base + gstride + u; nxt[u] = a.slots[(q < q1 ? q : qlast) * kChunk + lane]; }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            if (base + u >= q1) break;                                  // wave-uniform
-            const uint32_t slot = cur[u];
-            const bool valid = slot != kPad;
-            const bool head = valid && (slot & kHead);                  // head slot: carries the class count
-            const bool member = valid && !(slot & kHead);               // member slot: a transcript id
-            const unsigned long long headmask = __ballot(head);
-            const unsigned long long validmask = __ballot(valid);
-            const uint32_t d = slot - lo;
-            const bool inwin = member && d < span;
-            double v = xs[inwin ? d : 0u];                              // LDS gather (ds_read_b64)
-            if (!inwin) v = 0.0;
-            if (__ballot(member && !inwin)) { if (member && !inwin) v = x[slot]; }   // rare: outside the window
-            if (VB) { if (!(v > 0.0)) v = 0.0; }                        // expTheta == 0 terms are skipped (:344, :356)
-            // segment (= head + label) geometry inside the chunk; every chunk starts with a head
-            const unsigned long long below = headmask & le_mask;
-            const int start = 63 - __clzll((long long)below);
-            const unsigned long long above = headmask & ~le_mask;
-            const int end = above ? (__ffsll((long long)above) - 2) : (__popcll(validmask) - 1);
-            // segmented inclusive scan across the wavefront, fixed order
-            const double s = segmented_scan64(v, lane, start);
-            if (a.ablate & 2) { if (s == 123.456) acc[0] = s; continue; }
-            const double total = __shfl(s, end, kWave);
-            const double cnt = __shfl((double)(slot & ~kHead), start, kWave);
-            double contrib;
-            if (end - start == 1) contrib = cnt;                        // singleton label: the full count (:275 / :364)
-            else contrib = (total > kTiny && v == v) ? v * (cnt / total) : 0.0;   // :260-270 (NaN terms skipped :269)
-            if (member && contrib != 0.0 && !(a.ablate & 4)) {
-                if (inwin) atomicAdd(&acc[d], contrib); else atomicAdd(&a.alpha_out[slot], contrib);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- publish the window (plain coalesced stores; folded per transcript by the update)
+    const uint32_t c0 = a.tile_c0[blockIdx.x], nc = a.tile_c0[blockIdx.x + 1] - c0;
+    if (nc == 0) return;
+    const uint32_t lo = a.tile_lo[blockIdx.x], span = a.tile_span[blockIdx.x];
+    const uint64_t s0 = a.tile_s0[blockIdx.x];
+    const uint32_t n8 = (uint32_t)(a.tile_s0[blockIdx.x + 1] - s0);
+    const uint64_t e0 = a.tile_esc0[blockIdx.x];
+    const uint32_t n_esc = (uint32_t)(a.tile_esc0[blockIdx.x + 1] - e0);
+    const uint4* __restrict__ words = reinterpret_cast<const uint4*>(a.stream + s0);
     const uint64_t off = a.tile_off[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) a.partial[off + i] = acc[i];
+
+    auto keep = [](double v) -> double {
+        if (VB) return (v > 0.0) ? v : 0.0;                // expTheta == 0 terms are skipped (:344, :356)
+        return (v == v) ? v : 0.0;                         // NaN terms are skipped (:269)
+    };
+    auto denominators = [&](const uint32_t (&w)[kPerLane]) {
+        uint32_t cur = 0xFFFFFFFFu; double run = 0.0;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            if (w[i] & (kNull | kSingle)) continue;        // singletons never need a denominator
+            uint32_t cls = (w[i] >> 16) & 0x1FFFu;
+            double v = keep(xs[w[i] & 0xFFFFu]);
+            if (cls != cur) { if (cur != 0xFFFFFFFFu && run != 0.0) atomicAdd(&den[cur], run); cur = cls; run = v; }
+            else run += v;
+        }
+        if (cur != 0xFFFFFFFFu && run != 0.0) atomicAdd(&den[cur], run);
+    };
+    auto scatter = [&](const uint32_t (&w)[kPerLane]) {
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            if (w[i] & kNull) continue;
+            double f = den[(w[i] >> 16) & 0x1FFFu];
+            double contrib = (w[i] & kSingle) ? f : keep(xs[w[i] & 0xFFFFu]) * f;
+            if (contrib != 0.0) { if (a.ablate & 4) acc[w[i] & 0xFFFFu] = contrib; else atomicAdd(&acc[w[i] & 0xFFFFu], contrib); }
+        }
+    };
+
+    // Everything the block needs from HBM is requested up front, before the first barrier: the
+    // lane's first 8 stream words (kept in registers through phases A..C), the x window and the
+    // class counts of phase B.  A typical tile (<= 8192 nonzeros) needs nothing else.
+    const uint32_t g0 = threadIdx.x * kPerLane;
+    uint32_t w[kPerLane];
+    {
+        uint4 w0 = make_uint4(kNull, kNull, kNull, kNull), w1 = w0;
+        if (g0 < n8) { w0 = words[g0 / 4]; w1 = words[g0 / 4 + 1]; }
+        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+    }
+    uint32_t cnt0 = (threadIdx.x < nc) ? a.counts[c0 + threadIdx.x] : 0u;          // bit 31: singleton class
+    uint32_t cnt1 = (threadIdx.x + kSweepBlock < nc) ? a.counts[c0 + threadIdx.x + kSweepBlock] : 0u;
+    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
+    for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
+    __syncthreads();
+
+    // ---- A: denominators
+    if (!(a.ablate & 1)) {
+        denominators(w);
+        for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
+            uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
+            uint32_t v[kPerLane] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            denominators(v);
+        }
+        for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global gather
+            uint32_t tag = a.esc_cls[e0 + i];
+            if (tag & kSingle) continue;
+            double v = keep(x[a.esc_id[e0 + i]]);
+            if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
+        }
+    }
+    __syncthreads();
+    // ---- B: count / denom per class (in place); singletons carry the full count (:275 / :364)
+    for (uint32_t c = threadIdx.x, i = 0; c < nc; c += kSweepBlock, ++i) {
+        uint32_t cw = (i == 0) ? cnt0 : (i == 1) ? cnt1 : a.counts[c0 + c];
+        double cnt = (double)(cw & 0x7FFFFFFFu);
+        double d = den[c];
+        den[c] = (cw >> 31) ? cnt : ((d > kTiny) ? cnt / d : 0.0);     // :260-264
+    }
+    __syncthreads();
+    // ---- C: scatter-add into the window
+    if (!(a.ablate & 2)) {
+        scatter(w);
+        for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
+            uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
+            uint32_t v[kPerLane] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            scatter(v);
+        }
+        for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global atomics
+            uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
+            double f = den[(tag >> 16) & 0x1FFFu];
+            double contrib = (tag & kSingle) ? f : keep(x[t]) * f;
+            if (contrib != 0.0) atomicAdd(&a.alpha_out[t], contrib);
+        }
+    }
+    __syncthreads();
+    // ---- D: publish the window into the transcript-major partial array (plain stores): the update
+    //         then folds each transcript's entries with contiguous, coalesced loads
+    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) a.partial[a.pub_pos[off + i]] = acc[i];
 }
 
 // alphaOut[t] += sum of the tiles' window entries for t, in cover-list order (deterministic)
 __device__ __forceinline__ double fold_partials(uint64_t t, const uint32_t* __restrict__ cov_ptr,
                                                 const uint32_t* __restrict__ cov_pos, const double* __restrict__ partial) {
+    (void)cov_pos;                                  // partial is transcript-major: t owns [cov_ptr[t], cov_ptr[t+1])
     double s = 0.0;
-    for (uint32_t k = cov_ptr[t], e = cov_ptr[t + 1]; k < e; ++k) s += partial[cov_pos[k]];
+    for (uint32_t k = cov_ptr[t], e = cov_ptr[t + 1]; k < e; ++k) s += partial[k];
     return s;
 }
 
@@ -574,9 +559,10 @@ struct sfgpu_em {
     uint32_t* tile_lo = nullptr; uint32_t* tile_c0 = nullptr; uint32_t* tile_span = nullptr; uint32_t n_tiles = 0;
     uint64_t* tile_off = nullptr; uint64_t P = 0;          // window slots over all tiles
     double* partial = nullptr;                              // [P] per-tile window sums of one sweep
-    uint32_t* cov_ptr = nullptr; uint32_t* cov_pos = nullptr;   // transcript -> its window slots
-    uint32_t* slots = nullptr;                                  // chunked labels (see k_sweep_chunk)
-    uint64_t* tile_chunk0 = nullptr; uint32_t* long_cls = nullptr; uint32_t n_long = 0; uint64_t n_chunks = 0;
+    uint32_t* cov_ptr = nullptr; uint32_t* cov_pos = nullptr;   // transcript -> its entries of `partial`
+    uint32_t* pub_pos = nullptr;                                // window slot -> its entry of `partial`
+    uint32_t* lstream = nullptr; uint32_t* esc_id = nullptr; uint32_t* esc_cls = nullptr;   // re-packed labels (k_sweep_lds)
+    uint64_t* tile_s0 = nullptr; uint64_t* tile_esc0 = nullptr;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
     int ablate = 0;                                         // timing experiments only (SFGPU_EM_ABLATE)
     int sweep_variant = 1;                                  // 0 = lane-per-class/global atomics, 1 = LDS tiles
@@ -595,7 +581,7 @@ static void em_free(sfgpu_em* em) {
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
-                    em->cov_ptr, em->cov_pos, em->slots, em->tile_chunk0, em->long_cls,
+                    em->cov_ptr, em->cov_pos, em->pub_pos, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
                     em->blkmax};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (em->h_state) (void)hipHostFree(em->h_state);
@@ -628,13 +614,13 @@ static int em_enqueue_sweep(sfgpu_em* em) {
         else hipLaunchKernelGGL(k_sweep_lane<false>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
                                 em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
     } else {
-        dim3 g(em->n_tiles + em->n_long);
+        dim3 g(em->n_tiles);
         b = dim3(kSweepBlock);
-        SweepArgs a{em->n_tiles, p.d_rowptr, p.d_ids, em->counts32, em->slots,
-                    em->tile_chunk0, em->tile_lo, em->tile_span, em->tile_off, em->long_cls, em->x, em->alpha_out,
-                    em->partial, em->d_state, em->opts.min_iter, em->opts.max_iter, em->ablate};
-        if (vb) hipLaunchKernelGGL(k_sweep_chunk<true>, g, b, 0, em->cur, a);
-        else hipLaunchKernelGGL(k_sweep_chunk<false>, g, b, 0, em->cur, a);
+        SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
+                    em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
+                    em->opts.min_iter, em->opts.max_iter, em->ablate};
+        if (vb) hipLaunchKernelGGL(k_sweep_lds<true>, g, b, 0, em->cur, a);
+        else hipLaunchKernelGGL(k_sweep_lds<false>, g, b, 0, em->cur, a);
     }
     SF_CHECK_LAUNCH();
     return SFGPU_OK;
@@ -735,65 +721,56 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         unsigned int* ovf = reinterpret_cast<unsigned int*>(em->partials);
         EM_TRY(hipMemsetAsync(ovf, 0, 4, em->cur));
         hipLaunchKernelGGL(k_narrow_counts, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_counts,
-                           em->counts32, ovf);
+                           prob->d_rowptr, em->counts32, ovf);
         unsigned int h_ovf = 0;
         EM_TRY(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipMemcpyAsync(&rp_end, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
-        if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^31 - 1"); em_free(em); return SFGPU_ERR_RANGE; }
+        if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^31"); em_free(em); return SFGPU_ERR_RANGE; }
     } else {
         EM_TRY(hipStreamSynchronize(em->cur));
     }
     em->L = rp_end;
-    if (C) {   // nnz-balanced tile plan of the sweep + the cover lists of the fold
+    if (C) {   // nnz-balanced tile plan of the sweep, its label stream, and the cover lists of the fold
         em->n_tiles = (uint32_t)(((uint64_t)rp_end + kTileNnz - 1) / kTileNnz);
         if (em->n_tiles == 0) em->n_tiles = 1;
         const uint32_t nt = em->n_tiles;
+        uint32_t *t_len8 = nullptr, *t_nesc = nullptr;
         (void)hipFree(em->tile_lo); em->tile_lo = nullptr;
         EM_TRY(hipMalloc(&em->tile_lo, (size_t)nt * 4));
         EM_TRY(hipMalloc(&em->tile_span, ((size_t)nt + 1) * 4));
         EM_TRY(hipMalloc(&em->tile_c0, ((size_t)nt + 1) * 4));
         EM_TRY(hipMalloc(&em->tile_off, ((size_t)nt + 1) * 8));
+        EM_TRY(hipMalloc(&em->tile_s0, ((size_t)nt + 1) * 8));
+        EM_TRY(hipMalloc(&em->tile_esc0, ((size_t)nt + 1) * 8));
+        EM_TRY(hipMalloc(&t_len8, ((size_t)nt + 1) * 4)); EM_TRY(hipMalloc(&t_nesc, ((size_t)nt + 1) * 4));
         EM_TRY(hipMalloc(&em->cov_ptr, ((size_t)M + 1) * 4));
         hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt,
                            prob->d_rowptr, em->tile_c0);
         hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
-                           em->tile_lo, em->tile_span);
+                           em->tile_lo, em->tile_span, t_len8, t_nesc);
         EM_TRY(hipGetLastError());
-        if (exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur)) { em_free(em); return SFGPU_ERR_HIP; }
-        {   // chunk packing of the labels (see k_sweep_chunk)
-            uint32_t *slotpos = nullptr, *t_chunks = nullptr; unsigned int* d_nlong = nullptr;
-            EM_TRY(hipMalloc(&slotpos, C * 4)); EM_TRY(hipMalloc(&t_chunks, ((size_t)nt + 1) * 4));
-            EM_TRY(hipMalloc(&em->tile_chunk0, ((size_t)nt + 1) * 8));
-            EM_TRY(hipMalloc(&em->long_cls, C * 4)); EM_TRY(hipMalloc(&d_nlong, 4));
-            EM_TRY(hipMemsetAsync(d_nlong, 0, 4, em->cur));
-            hipLaunchKernelGGL(k_tile_pack, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, em->tile_c0, slotpos, t_chunks,
-                               em->long_cls, d_nlong);
-            EM_TRY(hipGetLastError());
-            int sr = exclusive_scan_u32(t_chunks, em->tile_chunk0, nt, em->cur);
-            uint64_t nq = 0; unsigned int nl = 0;
-            if (!sr) {
-                EM_TRY(hipMemcpyAsync(&nq, em->tile_chunk0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-                EM_TRY(hipMemcpyAsync(&nl, d_nlong, 4, hipMemcpyDeviceToHost, em->cur));
-                EM_TRY(hipStreamSynchronize(em->cur));
-                em->n_chunks = nq; em->n_long = nl;
-                EM_TRY(hipMalloc(&em->slots, (nq ? nq : 1) * kChunk * 4));
-                EM_TRY(hipMemsetAsync(em->slots, 0xFF, (nq ? nq : 1) * kChunk * 4, em->cur));
-                hipLaunchKernelGGL(k_fill_slots, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_rowptr, prob->d_ids,
-                                   em->counts32, slotpos, em->tile_chunk0, em->slots);
-                EM_TRY(hipGetLastError());
-                EM_TRY(hipStreamSynchronize(em->cur));
-            }
-            (void)hipFree(slotpos); (void)hipFree(t_chunks); (void)hipFree(d_nlong);
-            if (sr) { em_free(em); return sr; }
-        }
-        uint64_t P = 0;
+        int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur);
+        if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur);
+        if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur);
+        (void)hipFree(t_len8); (void)hipFree(t_nesc);
+        if (sr) { em_free(em); return sr; }
+        uint64_t P = 0, S = 0, E = 0;
         EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(&S, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(&E, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
         em->P = P;
+        EM_TRY(hipMalloc(&em->lstream, (S ? S : 1) * 4 + 32));
+        EM_TRY(hipMalloc(&em->esc_id, (E ? E : 1) * 4));
+        EM_TRY(hipMalloc(&em->esc_cls, (E ? E : 1) * 4));
+        hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
+                           em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls);
+        EM_TRY(hipGetLastError());
         EM_TRY(hipMalloc(&em->partial, (P ? P : 1) * 8));
         EM_TRY(hipMalloc(&em->cov_pos, (P ? P : 1) * 4));
+        EM_TRY(hipMalloc(&em->pub_pos, (P ? P : 1) * 4));
         EM_TRY(hipMemsetAsync(em->partial, 0, (P ? P : 1) * 8, em->cur));
         if (P) {
             uint64_t *k_in = nullptr, *k_out = nullptr; uint32_t* v_in = nullptr;
@@ -803,6 +780,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             int bits = 1; while (bits < 32 && (1ull << bits) <= M) ++bits;
             int src = sort_pairs_u64_u32(k_in, k_out, v_in, em->cov_pos, P, em->cur, bits);
             if (!src) {
+                hipLaunchKernelGGL(k_invert_perm, dim3(blocks_for(P)), dim3(kEmBlock), 0, em->cur, P, em->cov_pos, em->pub_pos);
                 hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, em->cov_ptr);
                 (void)hipStreamSynchronize(em->cur);
             }
