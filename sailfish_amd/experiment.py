@@ -61,9 +61,9 @@ class ReadExperiment:
     (include/ReadExperiment.hpp:65-99, 236-257)."""
 
     def __init__(self, transcripts: Transcripts, sopt: Optional[SailfishOpts] = None):
-        from .eqclass import EquivalenceClassBuilder
         self._transcripts = transcripts
-        self._eq = EquivalenceClassBuilder(logger=(sopt.jointLog if sopt else None), device=transcripts.device)
+        self._eq = None
+        self._logger = sopt.jointLog if sopt else None
         self._num_mapped = 0
         self._num_observed = 0
         self._fld = None
@@ -72,6 +72,9 @@ class ReadExperiment:
         return self._transcripts
 
     def equivalenceClassBuilder(self):
+        if self._eq is None:
+            from .eqclass import EquivalenceClassBuilder
+            self._eq = EquivalenceClassBuilder(logger=self._logger, device=self._transcripts.device)
         return self._eq
 
     def numMappedFragments(self) -> int:

@@ -1,0 +1,237 @@
+"""world_size-2 gloo test of the multi-GPU control flow (sailfish_amd/distributed.py) on CPU.
+
+The product engine (HipEngine) needs GPUs; here the same driver runs with a checker engine backed
+by the CPU oracle, so the exchange (all-gather + weighted merge), the nnz-balanced class slicing
+and the per-iteration all-reduce of alphaOut are exercised for real across two processes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+
+
+class _Vec:
+    def __init__(self, rowptr, ids, counts, total):
+        self.rowptr = torch.from_numpy(rowptr.astype(np.uint32).view(np.int32).copy())
+        self.ids = torch.from_numpy(ids.astype(np.uint32).view(np.int32).copy())
+        self.counts = torch.from_numpy(counts.astype(np.int64))
+        self.hashes = None
+        self.total_reads = int(total)
+
+    def size(self):
+        return self.rowptr.numel() - 1
+
+    @property
+    def nnz(self):
+        return self.ids.numel()
+
+
+class _Builder:
+    """label -> count dictionary with the canonical export order (first id, XXH64, length, label)"""
+
+    def start(self):
+        self.d = {}
+
+    def _add(self, ids, off, w):
+        ids = ids.numpy().view(np.uint32); off = off.numpy().view(np.uint32).astype(np.int64)
+        for r in range(len(off) - 1):
+            lab = tuple(ids[off[r]:off[r + 1]].tolist())
+            if lab:
+                self.d[lab] = self.d.get(lab, 0) + int(w[r])
+
+    def add_batch(self, ids, off):
+        self._add(ids, off, np.ones(len(off) - 1, np.int64))
+
+    def insertGroups(self, ids, off, counts):
+        self._add(ids, off, counts.numpy())
+
+    def finish(self):
+        key = lambda lab: (lab[0], O.xxh64(np.array(lab, np.uint32).tobytes()), len(lab), lab)
+        labs = sorted(self.d, key=key)
+        rowptr = np.zeros(len(labs) + 1, np.int64); rowptr[1:] = np.cumsum([len(l) for l in labs])
+        ids = np.array([t for l in labs for t in l], np.uint32)
+        cnt = np.array([self.d[l] for l in labs], np.int64)
+        self._vec = _Vec(rowptr, ids, cnt, cnt.sum())
+        return True
+
+    def eqVec(self):
+        return self._vec
+
+    def stats(self):
+        return dict(insert_ms=0.0)
+
+
+class _EM:
+    """optimize() = the oracle; begin/init/sweep/update/poll/finish = the same arithmetic in numpy pieces"""
+
+    def __init__(self, length, rowptr, ids, counts, num_mapped):
+        self.len = np.maximum(length.numpy().astype(np.float64), 1.0)
+        self.rp = (rowptr.numpy().view(np.uint32)).astype(np.int64)
+        self.ids = ids.numpy().view(np.uint32).astype(np.int64)
+        self.cnt = counts.numpy().astype(np.float64)
+        self.N = float(num_mapped); self.M = len(self.len)
+        self.alpha = torch.zeros(self.M, dtype=torch.float64); self.mass = torch.zeros(self.M, dtype=torch.float64)
+        self._raw_len = length.numpy().astype(np.float64)
+
+    def optimize(self, use_vbem=False, tol=0.01, min_iter=50, max_iter=10000, **_):
+        rc, a, m, st = O.em_optimize(self._raw_len, self.rp.astype(np.uint64), self.ids.astype(np.uint32),
+                                     self.cnt.astype(np.uint64), int(self.N), use_vbem=use_vbem, tol=tol,
+                                     min_iter=min_iter, max_iter=max_iter)
+        self.alpha.copy_(torch.from_numpy(a)); self.mass.copy_(torch.from_numpy(m))
+        return rc, st
+
+    def begin(self, use_vbem=False, tol=0.01, min_iter=50, max_iter=10000, **_):
+        self.vb, self.tol, self.min_iter, self.max_iter = use_vbem, tol, min_iter, max_iter
+        self.ao = torch.zeros(self.M, dtype=torch.float64)
+        self.ao[np.unique(self.ids)] = 1.0
+
+    def alpha_out_view(self):
+        return self.ao
+
+    def _prep(self):
+        from scipy.special import digamma
+        a = self.a
+        if self.vb:
+            ln = digamma(a.sum())
+            with np.errstate(divide="ignore"):
+                self.x = np.where(a > 0, np.exp(digamma(np.where(a > 0, a, 1.0)) - ln), 0.0) / self.len
+        else:
+            self.x = a / self.len
+
+    def init(self):
+        act = self.ao.numpy() > 0
+        self.n_active = int(act.sum())
+        self.a = np.where(act, (1.0 / self.n_active) * self.N, 0.0)
+        self.ao.zero_(); self.it = 0; self.conv = False; self.done = False
+        self._prep()
+
+    def _stop(self):
+        return self.it >= self.min_iter and (self.it >= self.max_iter or self.conv)
+
+    def sweep(self):
+        self.skip = self._stop()
+        if self.skip or len(self.cnt) == 0:
+            return
+        xv = self.x[self.ids]
+        lens = np.diff(self.rp)
+        den = np.add.reduceat(xv, self.rp[:-1])
+        row = np.repeat(np.arange(len(lens)), lens)
+        single = lens[row] == 1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            contrib = np.where(single, self.cnt[row], np.where(den[row] > 0, xv * (self.cnt[row] / den[row]), 0.0))
+        out = self.ao.numpy()
+        np.add.at(out, self.ids, contrib)
+
+    def update(self):
+        if self.skip:
+            return
+        ap = self.ao.numpy().copy() + (0.01 if self.vb else 0.0)
+        gate = ap > 1e-2
+        rel = np.abs(self.a[gate] - ap[gate]) / ap[gate]
+        self.conv = bool(np.all(rel <= self.tol)); self.maxrel = float(rel.max()) if rel.size else -1.0
+        self.a = ap; self.ao.zero_(); self.it += 1
+        self._prep()
+
+    def poll(self):
+        return self._stop(), dict(iters=self.it, converged=self.conv, n_active=self.n_active)
+
+    def finish(self):
+        cutoff = (0.01 + 1e-8) if self.vb else 1e-8
+        a = np.where(self.a <= cutoff, 0.0, self.a)
+        self.alpha.copy_(torch.from_numpy(a)); self.mass.copy_(torch.from_numpy(a / a.sum()))
+        return 0, dict(iters=self.it, converged=self.conv, n_active=self.n_active, alpha_sum=float(a.sum()), loop_ms=0.0,
+                       max_rel_diff=self.maxrel)
+
+
+class CheckerEngine:
+    device = torch.device("cpu")
+
+    def new_builder(self, expected=0):
+        return _Builder()
+
+    def em_problem(self, length, rowptr, ids, counts, num_mapped):
+        return _EM(length, rowptr, ids, counts, num_mapped)
+
+    def set_effective_lengths(self, exp, sopt, fl_counts, remaining_fl_ops):
+        ref = exp.transcripts().RefLength.numpy().view(np.uint32)
+        exp.transcripts().EffectiveLength.copy_(torch.from_numpy(O.efflen_smoothed(ref, O.cf_gaussian())))
+
+    def tpm(self, exp, sopt):
+        t = exp.transcripts()
+        return torch.from_numpy(O.tpm(t.estCount.numpy(), t.EffectiveLength.numpy(), exp.numMappedFragments()))
+
+    def sync(self):
+        pass
+
+
+def _worker(rank, world, port, mode, vb, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sailfish_amd as sf
+        from sailfish_amd import distributed as sfd, synth
+        M, P, R = 600, 1500, 6000
+        ref_len = synth.transcript_lengths(M)
+        poff, pids = synth.label_pool(M, P)
+        ids, off = synth.reads_from_pool(poff, pids, R, seed=7 + 1000 * rank)       # this rank's shard
+        sopt = sf.SailfishOpts(useVBOpt=vb)
+        exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.numpy().view(np.uint32), device="cpu"), sopt)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, engine=CheckerEngine(), poll_every=7)
+        info = q.run(ids, off)
+        t = exp.transcripts()
+        out.put((rank, info["em_mode"], info["n_classes"], info["nnz"], exp.numMappedFragments(), info["em_stats"]["iters"],
+                 t.estCount.numpy().copy(), info["tpm"].numpy().copy(), ids.numpy().copy(), off.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("mode,vb", [("replicated", False), ("sharded", False), ("sharded", True)])
+def test_two_rank_quant_matches_single_process(built, mode, vb):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, vb, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process oracle over the union of both shards
+    from sailfish_amd import synth
+    M = 600
+    ref_len = synth.transcript_lengths(M).numpy().view(np.uint32)
+    b = O.EqBuilder()
+    for r in res:
+        b.add_batch(r[8].view(np.uint32), r[9].view(np.uint32).astype(np.uint64))
+    rp, ii, cc, hh = b.finish()
+    eff = O.efflen_smoothed(ref_len, O.cf_gaussian())
+    rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, b.total_reads, use_vbem=vb)
+    ot = O.tpm(oa, eff, b.total_reads)
+    for r in res:
+        assert r[1] == mode and r[2] == b.n_classes and r[3] == b.nnz and r[4] == b.total_reads == 12000
+        assert r[5] == ost["iters"]
+        nz = oa > 0
+        assert np.array_equal(r[6] > 0, nz)
+        assert np.max(np.abs(r[6][nz] - oa[nz]) / oa[nz]) < 1e-9
+        assert np.max(np.abs(r[7][nz] - ot[nz]) / ot[nz]) < 1e-9
+    assert np.array_equal(res[0][6], res[1][6])      # both ranks hold the same answer
+
+
+def test_nnz_balanced_slices():
+    from sailfish_amd.distributed import nnz_balanced_slices
+    rp = np.concatenate([[0], np.cumsum(np.r_[np.ones(50, int), np.full(5, 100), np.ones(50, int)])])
+    for w in (1, 2, 3, 8):
+        cuts = nnz_balanced_slices(rp, w)
+        assert cuts[0] == 0 and cuts[-1] == len(rp) - 1 and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        nn = [rp[b] - rp[a] for a, b in zip(cuts, cuts[1:])]
+        assert sum(nn) == rp[-1] and max(nn) <= rp[-1] / w + 100
