@@ -150,13 +150,31 @@ def main():
     b_read = 4.0 * n_hits / R + 20.0
     build_ms = info["t_build_ms"]
     em_ms = info["t_em_ms"]
-    roof_em = dict(bound="hbm", kernel="k_sweep", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                   unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+    # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs of
+    # this same command; FETCH_SIZE x2 for the wide streaming loads of the sweep, raw for the random
+    # probes of the insert kernel -- see profiles/r1_pmc_summary.md).  null when no profile matches.
+    traffic_em = traffic_ins = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if pmc.get("workload") == a.workload and world == 1:
+            k = pmc["kernels"]
+            e = k.get("k_sweep_lds<true>" if use_vbem else "k_sweep_lds<false>")
+            if e:
+                traffic_em = (2 * e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
+            e = k.get("k_insert")
+            if e:
+                traffic_ins = (e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
+    except (OSError, ValueError, KeyError):
+        pass
+    n_ins = max(int(info["insert_launches"]), 1)
+    ins_ms = info["t_insert_ms"] / n_ins
+    roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                   unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em,
                    bytes_per_launch=b_iter, avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
-    roof_build = dict(bound="hbm", kernel="k_insert", achieved=b_read * R / (info["t_insert_ms"] * 1e-3) / 1e9,
+    roof_build = dict(bound="hbm", kernel="k_insert", achieved=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      frac=b_read * R / (info["t_insert_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
-                      bytes_per_launch=b_read * R, avg_launch_ms=info["t_insert_ms"], launches_per_step=1)
+                      frac=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins,
+                      bytes_per_launch=b_read * R / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins)
     dominant = roof_em if sweep_ms * st["iters"] >= info["t_insert_ms"] else roof_build
 
     out = {

@@ -110,7 +110,8 @@ class DistributedQuant:
         b.start(); b.add_batch(ids, off); b.finish()
         vec = b.eqVec()
         eng.sync(); t1 = time.perf_counter()
-        info["t_insert_ms"] = b.stats()["insert_ms"]
+        bst = b.stats()
+        info["t_insert_ms"] = bst["insert_ms"]; info["insert_launches"] = bst.get("insert_launches", 1)
         info["t_build_ms"] = (t1 - t0) * 1e3
         if self.world > 1:
             vec = self._merge(vec)
