@@ -180,6 +180,28 @@ SFGPU_API double* sfgpu_em_alpha_out(sfgpu_em* em);
 SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n, double* avg_ms);
 
 /* ---------------------------------------------------------------------------------------------
+ * a15/a17. Bootstrap   src/CollapsedEMOptimizer.cpp:438-525 (doBootstrap), :557-709 (gatherBootstraps),
+ *                      include/MultinomialSampler.hpp:13-64
+ * Each draw b: class counts ~ Multinomial(N = sum(count) [uint32, as in the reference], p = count/N)
+ * (exact; tree of conditional binomials, Philox4x32-10 streams keyed by (seed, b)), alpha
+ * re-initialised uniformly over the active transcripts, EM/VBEM to convergence with doBootstrap's
+ * loop (no 50-iteration floor, gate on alphas > 1e-2), truncation.  The reference seeds from
+ * std::random_device, so only the DISTRIBUTION of the outputs is comparable.
+ *   d_out   : n_bootstraps x M doubles on the device, or NULL
+ *   cb      : writeBootstrap (std::function<bool(const std::vector<double>&)>): called once per
+ *             draw with a host copy of alpha; return 0 to abort.  May be NULL.
+ *   h_iters : per-draw iteration counts (host), may be NULL
+ * opts->use_vbem / tol / max_iter are honoured; min_iter and check_mode are forced to doBootstrap's.
+ * Synchronous.  The handle's counts are restored afterwards.
+ * ------------------------------------------------------------------------------------------- */
+typedef int (*sfgpu_sample_cb)(const double* h_alpha, uint64_t M, void* user);
+SFGPU_API int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstraps, uint64_t seed,
+                    double* d_out, sfgpu_sample_cb cb, void* user, uint32_t* h_iters);
+/* One multinomial resample of the class counts (the sampCounts of doBootstrap :468) into
+ * d_counts_out[C] (uint32), for draw index `draw` of `seed`.  Synchronous. */
+SFGPU_API int sfgpu_bootstrap_counts(sfgpu_em* em, uint64_t seed, uint64_t draw, uint32_t* d_counts_out);
+
+/* ---------------------------------------------------------------------------------------------
  * a13. quant.sf columns   src/GZipWriter.cpp:216-245
  *   TPM_t = ((estCount_t/numMapped)/len_t) / sum_u((estCount_u/numMapped)/len_u) * 1e6
  * d_len as in sfgpu_problem.  Asynchronous on `stream`.

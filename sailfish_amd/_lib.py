@@ -45,6 +45,7 @@ class EqStats(C.Structure):
 
 
 _LOG_CB = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
+SAMPLE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_uint64, C.c_void_p)
 _lib = None
 _log_keepalive = None
 
@@ -79,6 +80,8 @@ _SIGS = {
     "sfgpu_em_finish": (C.c_int, [_P, _P, _P, C.POINTER(EmStats)]),
     "sfgpu_em_alpha_out": (_P, [_P]),
     "sfgpu_em_time_sweep": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.POINTER(C.c_double)]),
+    "sfgpu_bootstrap": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.c_uint64, _P, SAMPLE_CB, _P, _P]),
+    "sfgpu_bootstrap_counts": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     "sfgpu_tpm": (C.c_int, [_P, _P, C.c_uint64, C.c_double, _P, _P]),
 }
 

@@ -20,6 +20,7 @@
 //     alphaOut, as in the reference's CAS loop (:70-79).
 #include "common.h"
 #include "primitives.h"
+#include "sampling.h"
 
 #include <cfloat>
 #include <vector>
@@ -564,6 +565,8 @@ struct sfgpu_em {
     uint32_t* lstream = nullptr; uint32_t* esc_id = nullptr; uint32_t* esc_cls = nullptr;   // re-packed labels (k_sweep_lds)
     uint64_t* tile_s0 = nullptr; uint64_t* tile_esc0 = nullptr;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
+    uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
+    uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     int ablate = 0;                                         // timing experiments only (SFGPU_EM_ABLATE)
     int sweep_variant = 1;                                  // 0 = lane-per-class/global atomics, 1 = LDS tiles
     EmState* d_state = nullptr;
@@ -581,7 +584,7 @@ static void em_free(sfgpu_em* em) {
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
-                    em->cov_ptr, em->cov_pos, em->pub_pos, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
+                    em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
                     em->blkmax};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (em->h_state) (void)hipHostFree(em->h_state);
@@ -916,11 +919,10 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
     return SFGPU_OK;
 }
 
-int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
-                      sfgpu_em_stats* stats) {
-    SF_REQUIRE(em && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_optimize: null pointer");
+// begin -> init -> iterate to the stop latch -> finish, on the handle's own stream
+static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
+                  sfgpu_em_stats* stats, bool quiet) {
     int rc;
-    if ((rc = em_join_user(em))) return rc;
     if ((rc = em_begin_on(em, opts, em->stream))) return rc;
     if ((rc = sfgpu_em_init_impl(em))) return rc;
     int done = 0;
@@ -931,7 +933,7 @@ int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_o
         if (stats) *stats = st;
         return SFGPU_ERR_NO_ACTIVE;
     }
-    log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
+    if (!quiet) log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
     const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
     const uint32_t chunk = em->opts.iters_per_launch;
     if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
@@ -952,8 +954,97 @@ int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_o
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, em->ev_a, em->ev_b);
     st.loop_ms = ms;
-    log_msg(0, "iteration = %u | max rel diff. = %g", st.iters, st.max_rel_diff);   // :871-872
+    if (!quiet) log_msg(0, "iteration = %u | max rel diff. = %g", st.iters, st.max_rel_diff);   // :871-872
     if (stats) *stats = st;
+    return rc;
+}
+
+int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
+                      sfgpu_em_stats* stats) {
+    SF_REQUIRE(em && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_optimize: null pointer");
+    int rc;
+    if ((rc = em_join_user(em))) return rc;
+    return em_run(em, opts, d_alpha_out, d_mass_out, stats, false);
+}
+
+// ---- bootstrap (a15): gatherBootstraps / doBootstrap, src/CollapsedEMOptimizer.cpp:438-525, 557-709 ----
+__global__ void k_mask_counts(uint64_t C, const uint32_t* __restrict__ c32, uint32_t* __restrict__ out) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = c32[c] & 0x7FFFFFFFu; else if (c == C) out[c] = 0;
+}
+
+static int em_bootstrap_prepare(sfgpu_em* em) {
+    if (em->bs_prefix) return SFGPU_OK;
+    const uint64_t C = em->prob.C;
+    uint32_t* masked = nullptr;
+    SF_HIP(hipMalloc(&masked, (C + 1) * 4));
+    SF_HIP(hipMalloc(&em->bs_prefix, (C + 1) * 8));
+    SF_HIP(hipMalloc(&em->bs_base, (C ? C : 1) * 4));
+    const uint64_t W = multinomial_tree_width(C ? C : 1);
+    SF_HIP(hipMalloc(&em->bs_scratch_a, W * 4)); SF_HIP(hipMalloc(&em->bs_scratch_b, W * 4));
+    hipLaunchKernelGGL(k_mask_counts, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, em->stream, C, em->counts32, masked);
+    int rc = exclusive_scan_u32(masked, em->bs_prefix, C, em->stream);
+    (void)hipFree(masked);
+    if (rc) return rc;
+    SF_HIP(hipMemcpyAsync(em->bs_base, em->counts32, (C ? C : 1) * 4, hipMemcpyDeviceToDevice, em->stream));
+    SF_HIP(hipMemcpyAsync(&em->bs_total, em->bs_prefix + C, 8, hipMemcpyDeviceToHost, em->stream));
+    SF_HIP(hipStreamSynchronize(em->stream));
+    return SFGPU_OK;
+}
+
+int sfgpu_bootstrap_counts(sfgpu_em* em, uint64_t seed, uint64_t draw, uint32_t* d_counts_out) {
+    SF_REQUIRE(em && d_counts_out, SFGPU_ERR_INVALID, "sfgpu_bootstrap_counts: null pointer");
+    int rc;
+    if ((rc = em_join_user(em))) return rc;
+    if ((rc = em_bootstrap_prepare(em))) return rc;
+    // n is a uint32_t in MultinomialSampler::operator() (MultinomialSampler.hpp:15): totals wrap
+    rc = multinomial_tree(em->bs_prefix, em->prob.C, (uint32_t)em->bs_total, seed, draw, nullptr, d_counts_out,
+                          em->bs_scratch_a, em->bs_scratch_b, em->stream);
+    if (rc) return rc;
+    SF_HIP(hipStreamSynchronize(em->stream));
+    return SFGPU_OK;
+}
+
+int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstraps, uint64_t seed,
+                    double* d_out, sfgpu_sample_cb cb, void* user, uint32_t* h_iters) {
+    SF_REQUIRE(em && opts, SFGPU_ERR_INVALID, "sfgpu_bootstrap: null pointer");
+    SF_REQUIRE(em->prob.C > 0, SFGPU_ERR_NO_ACTIVE, "It seems that no transcripts are expressed; something is likely wrong!");
+    int rc;
+    if ((rc = em_join_user(em))) return rc;
+    if ((rc = em_bootstrap_prepare(em))) return rc;
+    const uint64_t M = em->prob.M, C = em->prob.C;
+    log_msg(0, "Will draw %u bootstrap samples", n_bootstraps);                                   // :601
+    log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)C);                 // :602
+    sfgpu_em_opts o = *opts;
+    o.min_iter = 0;            // doBootstrap has no 50-iteration floor (:486)
+    o.check_mode = 1;          // and gates on alphas > 1e-2 (:499)
+    double* d_tmp = nullptr; double* h_tmp = nullptr;
+    if (!d_out) SF_HIP(hipMalloc(&d_tmp, M * 8));
+    if (cb) SF_HIP(hipHostMalloc(&h_tmp, M * 8, hipHostMallocDefault));
+    const uint64_t keep_mapped = em->prob.num_mapped;
+    em->prob.num_mapped = em->bs_total;                 // alpha init uses totalNumFrags = sum of counts (:470-474, :696)
+    rc = SFGPU_OK;
+    for (uint32_t b = 0; b < n_bootstraps && rc == SFGPU_OK; ++b) {
+        rc = multinomial_tree(em->bs_prefix, C, (uint32_t)em->bs_total, seed, b, em->bs_base, em->counts32,
+                              em->bs_scratch_a, em->bs_scratch_b, em->stream);                    // :468
+        if (rc) break;
+        double* dst = d_out ? d_out + (uint64_t)b * M : d_tmp;
+        sfgpu_em_stats st{};
+        rc = em_run(em, &o, dst, nullptr, &st, true);                                              // :486-514
+        if (h_iters) h_iters[b] = st.iters;
+        if (rc) break;
+        if (cb) {
+            hipError_t e = hipMemcpyAsync(h_tmp, dst, M * 8, hipMemcpyDeviceToHost, em->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(em->stream);
+            if (e != hipSuccess) { set_error("bootstrap copy failed: %s", hipGetErrorString(e)); rc = SFGPU_ERR_HIP; break; }
+            if (!cb(h_tmp, M, user)) { set_error("bootstrap writer callback failed"); rc = SFGPU_ERR_INVALID; break; }   // :522
+        }
+    }
+    em->prob.num_mapped = keep_mapped;
+    (void)hipMemcpyAsync(em->counts32, em->bs_base, C * 4, hipMemcpyDeviceToDevice, em->stream);   // observed counts back
+    (void)hipStreamSynchronize(em->stream);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (h_tmp) (void)hipHostFree(h_tmp);
     return rc;
 }
 

@@ -1,0 +1,151 @@
+// rng.h -- counter-based random numbers and an exact binomial sampler, usable from device code
+// (hipcc) and from host code (g++: tests/test_sampling_cpu.py compiles this header as plain C++ to
+// check the samplers' distributions without a GPU).
+//
+// Why not the reference's generator: Sailfish seeds std::mt19937 from std::random_device in every
+// sampling routine (src/CollapsedEMOptimizer.cpp:463-464, src/CollapsedGibbsSampler.cpp:104-105,
+// 227-228), so its draws are not reproducible and only distributional parity is definable.  A
+// sequential Mersenne Twister has no place on a GPU; Philox4x32-10 (Salmon et al., SC'11) is
+// counter-based: every (key, counter) pair is an independent stream, so any lane can draw without
+// shared state and results are reproducible from the seed.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define SF_HD __host__ __device__ __forceinline__
+#else
+#define SF_HD inline
+#endif
+
+namespace sfgpu {
+
+struct Philox {
+    uint32_t key[2];
+    uint32_t ctr[4];
+    uint32_t out[4];
+    int have;   // unread words in out[]
+
+    SF_HD void init(uint64_t seed, uint64_t stream, uint64_t substream) {
+        key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
+        ctr[0] = (uint32_t)stream; ctr[1] = (uint32_t)(stream >> 32);
+        ctr[2] = (uint32_t)substream; ctr[3] = (uint32_t)(substream >> 32) ^ 0x5AF15u;
+        have = 0;
+    }
+    SF_HD static void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+        uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p;
+    }
+    SF_HD void block() {
+        uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+        for (int r = 0; r < 10; ++r) {
+            uint32_t hi0, lo0, hi1, lo1;
+            mulhilo(0xD2511F53u, c0, hi0, lo0);
+            mulhilo(0xCD9E8D57u, c2, hi1, lo1);
+            uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+        // the low counter word advances per block; the stream id lives in the other words
+        if (++ctr[2] == 0) ++ctr[3];
+        have = 4;
+    }
+    SF_HD uint32_t next32() { if (have == 0) block(); return out[--have]; }
+    // uniform in the open interval (0, 1), 53 random bits
+    SF_HD double uniform() {
+        uint64_t hi = next32(), lo = next32();
+        uint64_t x = ((hi << 32) | lo) >> 11;
+        return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
+    }
+};
+
+// Binomial(n, p), exact: inversion (BINV) for small means, BTPE (Kachitvichyanukul & Schmeiser, 1988)
+// otherwise.  n < 2^32.
+SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
+    if (n == 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double r = flip ? 1.0 - p : p;       // r <= 0.5
+    const double q = 1.0 - r;
+    const double dn = (double)n;
+    double y;
+    if (dn * r < 30.0) {
+        // ---- BINV: walk the CDF from 0
+        const double s = r / q, a = (dn + 1.0) * s;
+        const double f0 = exp(dn * log1p(-r));   // q^n >= e^-30 / ... : no underflow
+        for (;;) {
+            double f = f0, u = g.uniform();
+            uint32_t x = 0;
+            bool ok = true;
+            while (u > f) {
+                u -= f; ++x;
+                if (x > n) { ok = false; break; }      // rounding ran off the end: redraw
+                f *= (a / (double)x - s);
+            }
+            if (ok) { y = (double)x; break; }
+        }
+    } else {
+        // ---- BTPE
+        const double fm = dn * r + r;
+        const double m = floor(fm);
+        const double nrq = dn * r * q;
+        const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+        const double xm = m + 0.5, xl = xm - p1, xr = xm + p1;
+        const double c = 0.134 + 20.5 / (15.3 + m);
+        double al = (fm - xl) / (fm - xl * r);
+        const double laml = al * (1.0 + al / 2.0);
+        al = (xr - fm) / (xr * q);
+        const double lamr = al * (1.0 + al / 2.0);
+        const double p2 = p1 * (1.0 + 2.0 * c), p3 = p2 + c / laml, p4 = p3 + c / lamr;
+        for (;;) {
+            const double u = g.uniform() * p4;
+            double v = g.uniform();
+            if (u <= p1) { y = floor(xm - p1 * v + u); break; }            // triangular centre: accept
+            if (u <= p2) {                                                   // parallelograms
+                const double x = xl + (u - p1) / c;
+                v = v * c + 1.0 - fabs(m - x + 0.5) / p1;
+                if (v > 1.0) continue;
+                y = floor(x);
+            } else if (u <= p3) {                                            // left exponential tail
+                y = floor(xl + log(v) / laml);
+                if (y < 0.0) continue;
+                v = v * (u - p2) * laml;
+            } else {                                                         // right exponential tail
+                y = floor(xr - log(v) / lamr);
+                if (y > dn) continue;
+                v = v * (u - p3) * lamr;
+            }
+            const double k = fabs(y - m);
+            if (k <= 20.0 || k >= nrq / 2.0 - 1.0) {
+                // explicit evaluation of f(y)/f(m) by the recurrence
+                const double s = r / q, a = s * (dn + 1.0);
+                double F = 1.0;
+                if (m < y) { for (double i = m + 1.0; i <= y; i += 1.0) F *= (a / i - s); }
+                else if (m > y) { for (double i = y + 1.0; i <= m; i += 1.0) F /= (a / i - s); }
+                if (v > F) continue;
+                break;
+            }
+            // squeeze, then the Stirling-series bound
+            const double rho = (k / nrq) * ((k * (k / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
+            const double t = -k * k / (2.0 * nrq);
+            const double A = log(v);
+            if (A < t - rho) break;
+            if (A > t + rho) continue;
+            const double x1 = y + 1.0, f1 = m + 1.0, z = dn + 1.0 - m, w = dn - y + 1.0;
+            const double x2 = x1 * x1, f2 = f1 * f1, z2 = z * z, w2 = w * w;
+            const double bound = xm * log(f1 / x1) + (dn - m + 0.5) * log(z / w) + (y - m) * log(w * r / (x1 * q))
+                + (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / f2) / f2) / f2) / f2) / f1 / 166320.0
+                + (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / z2) / z2) / z2) / z2) / z / 166320.0
+                + (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x1 / 166320.0
+                + (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / w2) / w2) / w2) / w2) / w / 166320.0;
+            if (A > bound) continue;
+            break;
+        }
+    }
+    if (y < 0.0) y = 0.0;
+    if (y > dn) y = dn;
+    uint32_t k = (uint32_t)y;
+    return flip ? n - k : k;
+}
+
+}  // namespace sfgpu

@@ -74,6 +74,29 @@ class EMProblem:
         _lib.check(self._L.sfgpu_em_time_sweep(self._h, C.byref(o), int(n), C.byref(ms)))
         return ms.value
 
+    def bootstrap(self, n, seed=1, callback=None, use_vbem=False, tol=0.01, max_iter=10000):
+        """n bootstrap replicates (doBootstrap, src/CollapsedEMOptimizer.cpp:438-525).
+        Returns (rc, out[n, M] float64 device tensor, iters[n]); callback(alpha: np.ndarray) -> bool
+        is the writeBootstrap hook."""
+        import numpy as np
+        o = self.opts(use_vbem=use_vbem, tol=tol, min_iter=0, max_iter=max_iter, check_mode=1)
+        out = torch.zeros((n, self.M), dtype=torch.float64, device=self.device)
+        iters = np.zeros(n, np.uint32)
+        if callback is None:
+            cb = _lib.SAMPLE_CB(0)
+        else:
+            def _cb(p, m, _u):
+                return 1 if callback(np.ctypeslib.as_array(p, shape=(m,)).copy()) else 0
+            cb = _lib.SAMPLE_CB(_cb)
+        rc = self._L.sfgpu_bootstrap(self._h, C.byref(o), int(n), int(seed), _lib.ptr(out), cb, None, _lib.ptr(iters))
+        return rc, out, iters
+
+    def bootstrap_counts(self, seed, draw):
+        """one multinomial resample of the class counts (sampCounts, :468) -> int64 tensor[C]"""
+        out = torch.zeros(max(self.C, 1), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.sfgpu_bootstrap_counts(self._h, int(seed), int(draw), _lib.ptr(out)))
+        return out[: self.C].to(torch.int64) & 0xFFFFFFFF
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.sfgpu_em_destroy(self._h); self._h = C.c_void_p()
@@ -121,4 +144,27 @@ class CollapsedEMOptimizer:
         _lib.check(rc)
         txps.estCount.copy_(prob.alpha)    # setEstCount / setMass (:889-890)
         txps.mass.copy_(prob.mass)
+        return True
+
+    def gatherBootstraps(self, readExp: ReadExperiment, sopt: SailfishOpts, writeBootstrap,
+                         relDiffTolerance: float = 0.01, maxIter: int = 1000, seed=None) -> bool:
+        """gatherBootstraps(readExp, sopt, writeBootstrap, 0.01, 10000)
+        (src/SailfishQuantify.cpp:1401-1403; src/CollapsedEMOptimizer.cpp:557-709): draws
+        sopt.numBootstraps replicates and hands each alpha vector (numpy float64[M]) to
+        writeBootstrap.  The reference seeds from std::random_device; `seed` makes a run repeatable."""
+        import os
+        if sopt.jointLog is not None:
+            _lib.set_logger(sopt.jointLog)
+        txps = readExp.transcripts()
+        vec = readExp.equivalenceClassBuilder().eqVec()
+        length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
+        prob = EMProblem(length, vec.rowptr, vec.ids, vec.counts, readExp.numMappedFragments())
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        rc, out, iters = prob.bootstrap(sopt.numBootstraps, seed=seed, callback=writeBootstrap,
+                                        use_vbem=sopt.useVBOpt, tol=relDiffTolerance, max_iter=maxIter)
+        self.last_bootstraps, self.last_bootstrap_iters = out, iters
+        if rc in (_lib.ERR_NO_ACTIVE, _lib.ERR_ALPHA_SUM):
+            return False
+        _lib.check(rc)
         return True

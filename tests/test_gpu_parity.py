@@ -304,3 +304,72 @@ def test_efflen_and_end_to_end_driver(sf, gpu, midsize, tmp_path):
     fl = O.fld_gaussian_counts(1000, 250, 60, 20000).astype(np.uint32)
     sf.efflen.set_effective_lengths(exp, sopt, fl_counts=fl, remaining_fl_ops=0)
     np.testing.assert_array_equal(exp.transcripts().EffectiveLength.cpu().numpy(), O.efflen_smoothed(m["ref_len"], O.cf_counts(fl)))
+
+
+# -------------------------------------------------------------------------------- a15 / a17
+def test_multinomial_resample_is_exact_in_distribution(sf, gpu, midsize):
+    """sampCounts of doBootstrap (:468): every draw sums to N; per-class counts are Binomial(N, p_c)"""
+    m = midsize
+    p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    N = int(m["counts"].sum()); pc = m["counts"] / N
+    D = 400
+    draws = np.stack([p.bootstrap_counts(99, d).cpu().numpy() for d in range(D)])
+    assert np.all(draws.sum(1) == N)
+    assert not np.array_equal(draws[0], draws[1])
+    assert np.array_equal(p.bootstrap_counts(99, 3).cpu().numpy(), draws[3])          # reproducible from (seed, draw)
+    mean = draws.mean(0); sd = np.sqrt(N * pc * (1 - pc))
+    z = (mean - N * pc) / (sd / np.sqrt(D))
+    assert np.abs(z).max() < 6.0 and abs(z.mean()) < 0.2 and 0.85 < z.std() < 1.15
+    big = np.argsort(-pc)[:20]
+    v = draws[:, big].var(0, ddof=1) / (N * pc[big] * (1 - pc[big]))
+    assert np.all((v > 0.7) & (v < 1.35))
+    # the class counts of the handle are untouched afterwards
+    rc, st = p.optimize()
+    orc, oa, _, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    assert st["iters"] == ost["iters"] and _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+
+
+@pytest.mark.parametrize("vb", [False, True])
+def test_bootstrap_distribution_vs_oracle(sf, gpu, vb):
+    """gatherBootstraps: distributional parity (the reference seeds from random_device) -- replicate
+    means and spreads against the oracle's restatement, and against the SURVEY 8c sample means"""
+    k = json.load(open(os.path.join(GOLD, "survey_kat.json")))["em_toy7"]
+    eff = np.array(k["ref_len"], float) - k["eff_len_minus"]
+    rp = np.zeros(len(k["classes"]) + 1, np.uint32); rp[1:] = np.cumsum([len(c) for c in k["classes"]])
+    ii = np.array([x for c in k["classes"] for x in c], np.uint32); cc = np.array(k["counts"], np.uint64)
+    p = _gpu_em(sf, gpu, eff, rp, ii, cc, k["num_mapped"])
+    B = 1500
+    got = []
+    rc, out, iters = p.bootstrap(B, seed=2024, callback=lambda a: got.append(a) or True, use_vbem=vb)
+    assert rc == 0 and len(got) == B and np.array_equal(np.stack(got), out.cpu().numpy())
+    g = out.cpu().numpy()
+    orc, ob, oit = O.bootstrap(eff, rp.astype(np.uint64), ii, cc, B, use_vbem=vb, seed=77)
+    assert orc == 0
+    se = np.sqrt(g.var(0) / B + ob.var(0) / B) + 1e-9
+    assert np.all(np.abs(g.mean(0) - ob.mean(0)) < 5 * se), (g.mean(0), ob.mean(0))
+    assert np.all(np.abs(g.std(0) - ob.std(0)) < 0.15 * ob.std(0) + 0.05)
+    assert abs(iters.mean() - oit.mean()) < 0.2 * oit.mean() + 2
+    if not vb:
+        assert np.all(np.abs(g.mean(0) - np.array(k["bootstrap_mean_200"])) < 6 * g.std(0) / np.sqrt(200) + 0.3)
+        np.testing.assert_allclose(g.sum(1), k["num_mapped"], rtol=1e-9)      # EM conserves the resampled mass
+    rc2, out2, _ = p.bootstrap(5, seed=2024, use_vbem=vb)
+    assert np.array_equal(out2.cpu().numpy(), g[:5])                          # same seed, same replicates
+
+
+def test_gather_bootstraps_driver(sf, gpu, midsize):
+    from sailfish_amd import synth
+    m = midsize
+    _, ids, off = synth.workload(5000, 20000, 400_000)
+    sopt = sf.SailfishOpts(numBootstraps=6)
+    exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(5000)], m["ref_len"], device=gpu), sopt)
+    eq = exp.equivalenceClassBuilder(); eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); eq.finish()
+    exp.setNumMappedFragments(eq.total_reads); sf.efflen.set_effective_lengths(exp, sopt)
+    opt = sf.CollapsedEMOptimizer(); assert opt.optimize(exp, sopt, 0.01, 10000)
+    point = exp.transcripts().estCount.cpu().numpy()
+    rows = []
+    assert opt.gatherBootstraps(exp, sopt, lambda a: rows.append(a) or True, 0.01, 10000, seed=5)
+    b = np.stack(rows)
+    assert b.shape == (6, 5000) and np.all(b >= 0)
+    np.testing.assert_allclose(b.sum(1), m["R"], rtol=1e-6)
+    top = np.argsort(-point)[:50]
+    assert np.all(np.abs(b[:, top].mean(0) - point[top]) < 0.2 * point[top] + 5)

@@ -1,0 +1,74 @@
+"""CPU tests of the sampling primitives the HIP bootstrap / Gibbs kernels are built from
+(sailfish_amd/csrc/rng.h compiled as plain C++): Philox4x32-10 known answers, uniform range,
+and the exact binomial sampler (BINV + BTPE) against scipy's binomial distribution."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy import stats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def H(tmp_path_factory):
+    so = tmp_path_factory.mktemp("h") / "libharness.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), os.path.join(HERE, "sampling_harness.cpp")])
+    L = C.CDLL(str(so))
+    L.draw_binomial.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p]
+    L.draw_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.philox_block.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+    return L
+
+
+def test_philox_known_answers(H):
+    """Random123 kat_vectors for philox4x32-10"""
+    out = np.zeros(4, np.uint32)
+    H.philox_block(0, 0, 0, 0, 0, 0, out.ctypes.data)
+    assert [hex(x) for x in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    H.philox_block(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, out.ctypes.data)
+    assert [hex(x) for x in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    H.philox_block(0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, out.ctypes.data)
+    assert [hex(x) for x in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_uniform_open_interval_and_flat(H):
+    u = np.zeros(200000)
+    H.draw_uniform(42, 7, len(u), u.ctypes.data)
+    assert u.min() > 0.0 and u.max() < 1.0
+    assert stats.kstest(u, "uniform").pvalue > 1e-3
+    v = np.zeros(1000); H.draw_uniform(42, 8, len(v), v.ctypes.data)
+    assert not np.array_equal(u[:1000], v)              # streams differ
+
+
+@pytest.mark.parametrize("n,p", [(1, 0.3), (10, 0.5), (100, 0.01), (1000, 0.02), (50, 0.9), (200, 0.16), (1000, 0.5),
+                                 (100000, 0.001), (100000, 0.3), (3000000, 0.7), (4000000000, 1e-9), (4000000000, 0.25),
+                                 (59, 0.5), (61, 0.5), (400, 0.075)])
+def test_binomial_matches_scipy(H, n, p):
+    N = 60000
+    x = np.zeros(N, np.uint32)
+    H.draw_binomial(12345 + n, n, p, N, x.ctypes.data)
+    x = x.astype(np.float64)
+    mean, var = n * p, n * p * (1 - p)
+    assert x.min() >= 0 and x.max() <= n
+    assert abs(x.mean() - mean) < 5 * np.sqrt(var / N) + 1e-12
+    assert abs(x.var() - var) < 6 * var * np.sqrt(2.0 / N) + 1e-9 + 5 * np.sqrt(var * max(1 - 6 * p * (1 - p), 0) / N)
+    # chi-square on equiprobable-ish bins of the exact pmf
+    qs = np.unique(stats.binom.ppf(np.linspace(0.02, 0.98, 25), n, p))
+    edges = np.concatenate([[-0.5], qs + 0.5, [n + 0.5]])
+    obs, _ = np.histogram(x, edges)
+    cdf = stats.binom.cdf(np.floor(edges[1:]), n, p) - stats.binom.cdf(np.floor(edges[:-1]), n, p)
+    cdf[0] = stats.binom.cdf(np.floor(edges[1]), n, p)
+    keep = cdf * N > 5
+    if keep.sum() >= 3:
+        chi = ((obs[keep] - cdf[keep] * N) ** 2 / (cdf[keep] * N)).sum()
+        assert stats.chi2.sf(chi, keep.sum() - 1) > 1e-4, (chi, keep.sum())
+
+
+def test_binomial_edges(H):
+    x = np.zeros(10, np.uint32)
+    H.draw_binomial(1, 0, 0.5, 10, x.ctypes.data); assert np.all(x == 0)
+    H.draw_binomial(1, 77, 0.0, 10, x.ctypes.data); assert np.all(x == 0)
+    H.draw_binomial(1, 77, 1.0, 10, x.ctypes.data); assert np.all(x == 77)
