@@ -202,6 +202,24 @@ SFGPU_API int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t 
 SFGPU_API int sfgpu_bootstrap_counts(sfgpu_em* em, uint64_t seed, uint64_t draw, uint32_t* d_counts_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * a16. CollapsedGibbsSampler::sample<ReadExperiment>   src/CollapsedGibbsSampler.cpp:198-291
+ * (initCountMap_ :35-94, sampleRound_ :96-186).  Requires Transcript::mass from a prior optimize().
+ * Runs `n_chains` independent chains (0 = default: min(n_samples, 1024) rounded up to 64); every
+ * chain is initialised like initCountMap_ and then yields one sample per sampleRound_, so sample s
+ * comes from chain s % n_chains after s / n_chains + 1 rounds (the reference runs one chain per TBB
+ * chunk of the sample range and one round per sample).  The reference seeds from std::random_device:
+ * parity is distributional.  Unlike the reference this call does NOT overwrite Transcript::mass
+ * (:219-221 mutate it in place); the same transformed values are used internally.
+ *   d_mass : M doubles, mass = alpha / alphaSum as written by optimize()
+ *   d_out  : n_samples x M int32 on the device, or NULL
+ *   cb     : writeSample (std::function<bool(const std::vector<int>&)>), host copy per sample; may be NULL
+ * Device memory: 4 * nnz * n_chains + 4 * M * n_chains bytes of chain state.  Synchronous.
+ * ------------------------------------------------------------------------------------------- */
+typedef int (*sfgpu_gibbs_cb)(const int32_t* h_counts, uint64_t M, void* user);
+SFGPU_API int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t n_samples, uint32_t n_chains,
+                       uint64_t seed, int32_t* d_out, sfgpu_gibbs_cb cb, void* user, sfgpu_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a13. quant.sf columns   src/GZipWriter.cpp:216-245
  *   TPM_t = ((estCount_t/numMapped)/len_t) / sum_u((estCount_u/numMapped)/len_u) * 1e6
  * d_len as in sfgpu_problem.  Asynchronous on `stream`.

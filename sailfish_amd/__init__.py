@@ -5,4 +5,5 @@ reference's interface for that path; it holds no compute and no CPU fallback."""
 from .experiment import ReadExperiment, SailfishOpts, Transcripts  # noqa: F401
 from .eqclass import EquivalenceClassBuilder, EqVec, xxh64_labels  # noqa: F401
 from .optimizer import CollapsedEMOptimizer, EMProblem  # noqa: F401
+from .gibbs import CollapsedGibbsSampler, gibbs_sample  # noqa: F401
 from . import efflen, writer  # noqa: F401

@@ -46,6 +46,7 @@ class EqStats(C.Structure):
 
 _LOG_CB = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
 SAMPLE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_uint64, C.c_void_p)
+GIBBS_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), C.c_uint64, C.c_void_p)
 _lib = None
 _log_keepalive = None
 
@@ -82,6 +83,7 @@ _SIGS = {
     "sfgpu_em_time_sweep": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.POINTER(C.c_double)]),
     "sfgpu_bootstrap": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.c_uint64, _P, SAMPLE_CB, _P, _P]),
     "sfgpu_bootstrap_counts": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
+    "sfgpu_gibbs_sample": (C.c_int, [C.POINTER(Problem), _P, C.c_uint32, C.c_uint32, C.c_uint64, _P, GIBBS_CB, _P, _P]),
     "sfgpu_tpm": (C.c_int, [_P, _P, C.c_uint64, C.c_double, _P, _P]),
 }
 

@@ -373,3 +373,64 @@ def test_gather_bootstraps_driver(sf, gpu, midsize):
     np.testing.assert_allclose(b.sum(1), m["R"], rtol=1e-6)
     top = np.argsort(-point)[:50]
     assert np.all(np.abs(b[:, top].mean(0) - point[top]) < 0.2 * point[top] + 5)
+
+
+# ---------------------------------------------------------------------------------------- a16
+def _toy7():
+    k = json.load(open(os.path.join(GOLD, "survey_kat.json")))["em_toy7"]
+    eff = np.array(k["ref_len"], float) - k["eff_len_minus"]
+    rp = np.zeros(len(k["classes"]) + 1, np.uint32); rp[1:] = np.cumsum([len(c) for c in k["classes"]])
+    ii = np.array([x for c in k["classes"] for x in c], np.uint32); cc = np.array(k["counts"], np.uint64)
+    return k, eff, rp, ii, cc
+
+
+def test_gibbs_toy_distribution(sf, gpu):
+    """collapsed Gibbs: distributional parity with the oracle's restatement of sampleRound_, and with the
+    sample means the reference produced (its posterior mean is NOT the EM point estimate)"""
+    import torch
+    k, eff, rp, ii, cc = _toy7()
+    N = k["num_mapped"]
+    orc, oa, om, _ = O.em_optimize(eff, rp.astype(np.uint64), ii, cc, N)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(gpu)
+    args = (torch.from_numpy(eff).to(gpu), torch.from_numpy(om).to(gpu), t(rp, np.int32), t(ii, np.int32),
+            t(cc.astype(np.uint64), np.int64), N)
+    S = 4096
+    got = []
+    rc, out = sf.gibbs_sample(*args, S, n_chains=64, seed=11, callback=lambda v: got.append(v) or True)
+    assert rc == 0 and len(got) == S
+    g = out.cpu().numpy()
+    assert np.array_equal(np.stack(got), g) and g.dtype == np.int32
+    assert np.all(g.sum(1) == N) and np.all(g >= 0)                 # every read stays assigned to some transcript
+    # members of no multi-transcript class cannot exceed what their classes hold
+    assert np.all(g[:, 3] <= 45) and np.all(g[:, 0] >= 100) and np.all(g[:, 2] >= 10)
+    orc, og = O.gibbs(eff, om, rp.astype(np.uint64), ii, cc, N, 6000, seed=3)
+    og = og[500:]
+    late = g[64 * 8:]                                               # drop each chain's first rounds
+    assert np.all(np.abs(late.mean(0) - og.mean(0)) < 0.06 * N / 10), (late.mean(0), og.mean(0))
+    assert np.all(np.abs(late.std(0) - og.std(0)) < 0.35 * og.std(0) + 1.0), (late.std(0), og.std(0))
+    assert np.all(np.abs(late.mean(0) - np.array(k["gibbs_mean_200"])) < 12.0)
+    rc, out2 = sf.gibbs_sample(*args, 128, n_chains=64, seed=11)
+    assert np.array_equal(out2.cpu().numpy(), g[:128])              # reproducible from the seed
+
+
+def test_gibbs_midsize_and_driver(sf, gpu, midsize):
+    from sailfish_amd import synth
+    m = midsize
+    _, ids, off = synth.workload(5000, 20000, 400_000)
+    sopt = sf.SailfishOpts(numGibbsSamples=96)
+    exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(5000)], m["ref_len"], device=gpu), sopt)
+    eq = exp.equivalenceClassBuilder(); eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); eq.finish()
+    exp.setNumMappedFragments(eq.total_reads); sf.efflen.set_effective_lengths(exp, sopt)
+    assert sf.CollapsedEMOptimizer().optimize(exp, sopt, 0.01, 10000)
+    point = exp.transcripts().estCount.cpu().numpy()
+    rows = []
+    smp = sf.CollapsedGibbsSampler()
+    assert smp.sample(exp, sopt, lambda v: rows.append(v) or True, sopt.numGibbsSamples, seed=9, n_chains=64)
+    g = np.stack(rows)
+    assert g.shape == (96, 5000) and np.all(g.sum(1) == m["R"]) and np.all(g >= 0)
+    top = np.argsort(-point)[:40]
+    assert np.all(np.abs(g[:, top].mean(0) - point[top]) < 0.25 * point[top] + 10)
+    # transcripts in no class never receive reads
+    rp, ii, cc, _ = eq.eqVec().to_numpy()
+    absent = np.setdiff1d(np.arange(5000), ii)
+    assert np.all(g[:, absent] == 0)
