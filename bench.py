@@ -171,7 +171,7 @@ def main():
     roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
                    unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em,
                    bytes_per_launch=b_iter, avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
-    roof_build = dict(bound="hbm", kernel="k_insert", achieved=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9,
+    roof_build = dict(bound="hbm", kernel=info.get("insert_kernels", "k_insert"), achieved=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins,
                       bytes_per_launch=b_read * R / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins)

@@ -51,6 +51,10 @@ __device__ __forceinline__ bool labels_equal(const uint32_t* a, const uint32_t* 
     return true;
 }
 
+}  // namespace sfgpu
+#include "eqclass_part.h"
+namespace sfgpu {
+
 // a1: standalone label hash (sfgpu_xxh64_labels)
 __global__ void k_hash_labels(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t n,
                               uint64_t* __restrict__ out) {
@@ -58,7 +62,8 @@ __global__ void k_hash_labels(const uint32_t* __restrict__ ids, const uint32_t* 
     if (r >= n) return;
     uint32_t b = off[r], len = off[r + 1] - b;
     const uint32_t* lab = ids + b;
-    out[r] = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
+    uint32_t hw[kHead];
+    out[r] = xxh64_label([&](uint32_t k) { return lab[k]; }, len, hw);
 }
 
 // addGroup for a range of reads (list == nullptr: reads [first, first+n); else list[0..n)).
@@ -75,9 +80,11 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
     uint32_t b = off[r], len = off[r + 1] - b;
     if (len == 0) return;  // call-site guard: empty hit lists never reach addGroup
     const uint32_t* lab = ids + b;
-    uint64_t h = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
+    uint32_t hw[kHead];
+    uint64_t h = label_mix64([&](uint32_t k) { return lab[k]; }, len, hw);     // bucket hash (xxh64_device.h)
     uint64_t tag = h >> 32;
     uint64_t s = h & mask;
+    uint32_t probes = 0;
     for (;;) {
         uint64_t w = __hip_atomic_load(&table[2 * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w == kEmpty) {
@@ -107,7 +114,12 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
                 return;
             }
         }
-        s = (s + 1) & mask;
+        if (++probes >= kRegionSlots) {            // home region full: replay after the table has grown
+            unsigned long long d = atomicAdd(&ctr[CTR_DEFER], 1ull);
+            deferred[d] = r;
+            return;
+        }
+        s = region_next(s);
     }
 }
 
@@ -133,10 +145,13 @@ __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __res
 
 // re-insert every class into a larger table, carrying its count
 __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table, uint64_t mask, uint64_t n_cls,
-                         const uint64_t* __restrict__ cls_hash, uint32_t* cls_slot) {
+                         const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ cls_len,
+                         const uint32_t* __restrict__ arena, uint32_t* cls_slot) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cls) return;
-    uint64_t h = cls_hash[c];
+    const uint32_t* lab = arena + cls_off[c];
+    uint32_t hw[kHead];
+    uint64_t h = label_mix64([&](uint32_t k) { return lab[k]; }, cls_len[c], hw);
     uint64_t mine = ((h >> 32) << 32) | (uint64_t)(kArenaBit | (uint32_t)c);
     uint64_t cnt = old_table[2 * (uint64_t)cls_slot[c] + 1];
     uint64_t s = h & mask;
@@ -144,7 +159,7 @@ __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table
         unsigned long long old = atomicCAS((unsigned long long*)&table[2 * s], (unsigned long long)kEmpty,
                                            (unsigned long long)mine);
         if (old == kEmpty) break;
-        s = (s + 1) & mask;
+        s = region_next(s);
     }
     table[2 * s + 1] = cnt;
     cls_slot[c] = (uint32_t)s;
@@ -246,6 +261,10 @@ struct sfgpu_eq {
     uint32_t sub_batch = 1u << 22;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     sfgpu_eq_stats stats{};
+    // radix-partitioned path (eqclass_part.h)
+    bool use_part = true; uint32_t part_sub_batch = 1u << 24;
+    DevBuf<uint32_t> part_words, part_hist, part_cursor, part_long, def_lens, def_ids, def_off;
+    DevBuf<uint64_t> part_off, def_off64;
 };
 
 static int eq_alloc_table(sfgpu_eq* eq, uint64_t cap) {
@@ -265,7 +284,7 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
     if (rc) return rc;
     if (eq->n_classes) {
         hipLaunchKernelGGL(k_rehash, dim3(grid_for(eq->n_classes)), dim3(kBlock), 0, eq->stream, old, eq->table.p,
-                           new_cap - 1, eq->n_classes, eq->cls_hash.p, eq->cls_slot.p);
+                           new_cap - 1, eq->n_classes, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->cls_slot.p);
         SF_CHECK_LAUNCH();
     }
     SF_HIP(hipStreamSynchronize(eq->stream));
@@ -311,7 +330,8 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     sfgpu_eq* eq = new sfgpu_eq();
     eq->stream = as_stream(stream);
     eq->expected = expected_classes;
-    if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) eq->sub_batch = (uint32_t)v; }
+    if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) { eq->sub_batch = (uint32_t)v; eq->part_sub_batch = (uint32_t)v; } }
+    if (const char* e = getenv("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
     hipError_t e1 = hipMalloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
     hipError_t e2 = hipHostMalloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long), hipHostMallocDefault);
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
@@ -343,6 +363,137 @@ int sfgpu_eq_start(sfgpu_eq* eq) {
     return eq_reset(eq);
 }
 
+// generic path: one lane per read probing the table in HBM (any batch size, weights, replays).
+// Handles reads [first, first+todo) or, with `list`, the reads list[0..todo).
+static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t todo,
+                      const uint32_t* list, const uint64_t* d_weights) {
+    hipStream_t st = eq->stream;
+    int rc;
+    bool flip = false;
+    while (todo) {
+        // new-class budget of this launch: keep load <= 1/2 with room for the guard's slack
+        int64_t free_budget = (int64_t)(eq->cap / 2) - (int64_t)eq->n_classes - (int64_t)kSlack;
+        uint64_t need = todo < kMinHeadroom ? todo : kMinHeadroom;
+        if (free_budget < (int64_t)need) { if ((rc = eq_grow(eq, eq->cap * 2))) return rc; continue; }
+        uint64_t limit_new = (uint64_t)free_budget < todo ? (uint64_t)free_budget : todo;
+        if ((rc = eq->newlist.reserve(limit_new + kSlack, st, false))) return rc;
+        DevBuf<uint32_t>& dout = flip ? eq->deferred_b : eq->deferred_a;
+        if ((rc = dout.reserve(todo, st, false))) return rc;
+        uint64_t cls_need = eq->n_classes + limit_new + kSlack;
+        SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
+        if ((rc = eq->cls_hash.reserve(cls_need, st, true, eq->n_classes))) return rc;
+        if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
+        if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
+        if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
+        SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));
+        SF_HIP(hipEventRecord(eq->ev0, st));
+        hipLaunchKernelGGL(k_insert, dim3(grid_for(todo)), dim3(kBlock), 0, st, d_ids, d_offsets, first, todo, list,
+                           eq->table.p, eq->cap - 1, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->d_ctr,
+                           eq->newlist.p, (unsigned long long)limit_new, dout.p, d_weights);
+        SF_CHECK_LAUNCH();
+        SF_HIP(hipEventRecord(eq->ev1, st));
+        SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        { float ms = 0.f; if (hipEventElapsedTime(&ms, eq->ev0, eq->ev1) == hipSuccess) eq->stats.insert_ms += ms; }
+        eq->stats.insert_launches++;
+        uint64_t n_new = eq->h_ctr[CTR_NEW], n_def = eq->h_ctr[CTR_DEFER];
+        if (n_new) {
+            hipLaunchKernelGGL(k_commit, dim3(grid_for(n_new)), dim3(kBlock), 0, st, d_ids, d_offsets, eq->table.p,
+                               eq->newlist.p, n_new, eq->n_classes, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p,
+                               eq->cls_slot.p, eq->arena.p, eq->d_ctr);
+            SF_CHECK_LAUNCH();
+            eq->n_classes += n_new;
+        }
+        if (n_def) {
+            eq->stats.deferred_reads += n_def;
+            if ((rc = eq_grow(eq, eq->cap * 2))) return rc;   // synchronises: commit has finished
+            list = dout.p; todo = (uint32_t)n_def; flip = !flip;
+        } else {
+            todo = 0;
+        }
+    }
+    return SFGPU_OK;
+}
+
+// radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.
+static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t cnt,
+                          uint64_t n_words) {
+    hipStream_t st = eq->stream;
+    int rc;
+    // regions stay sparse (load <= 1/4) so that a region overflowing its LDS image is a non-event
+    while (eq->n_classes + kMinHeadroom > eq->cap / 4) if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
+    const uint32_t n_regions = (uint32_t)(eq->cap >> kRegionBits);
+    uint64_t cls_need = eq->n_classes + cnt + 1;
+    SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
+    if ((rc = eq->cls_hash.reserve(cls_need, st, true, eq->n_classes))) return rc;
+    if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
+    if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
+    if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
+    // every block of passes 1a/1b owns one contiguous tile of reads
+    uint32_t tile_reads = getenv("SFGPU_EQ_TILE") ? (uint32_t)atoi(getenv("SFGPU_EQ_TILE")) : 32768u;
+    uint32_t n_blocks = (cnt + tile_reads - 1) / tile_reads; if (n_blocks > 4096u) n_blocks = 4096u; if (n_blocks == 0) n_blocks = 1;
+    const uint32_t tile = (uint32_t)(((uint64_t)cnt + n_blocks - 1) / n_blocks);
+    const uint64_t mat_n = (uint64_t)n_regions * n_blocks;
+    if ((rc = eq->part_words.reserve(n_words + 8, st, false))) return rc;
+    if ((rc = eq->part_hist.reserve(mat_n + 1, st, false))) return rc;
+    if ((rc = eq->part_off.reserve(mat_n + 2, st, false))) return rc;
+    if ((rc = eq->part_cursor.reserve(((uint64_t)cnt + 1) / 2 + 1, st, false))) return rc;      // uint16 region of every read
+    if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
+    if ((rc = eq->deferred_a.reserve(cnt, st, false))) return rc;
+    uint16_t* reg_of = reinterpret_cast<uint16_t*>(eq->part_cursor.p);
+    SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));     // CTR_NEW, CTR_DEFER
+    SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));     // long-label counter
+    SF_HIP(hipEventRecord(eq->ev0, st));
+    hipLaunchKernelGGL(k_part_hist, dim3(n_blocks), dim3(kPartBlock), 0, st, d_ids, d_offsets, first, cnt, tile, eq->cap - 1,
+                       n_regions, reg_of, eq->part_hist.p, eq->d_ctr + 3, eq->part_long.p, getenv("SFGPU_EQ_ABLATE") ? atoi(getenv("SFGPU_EQ_ABLATE")) : 0);
+    SF_CHECK_LAUNCH();
+    if ((rc = exclusive_scan_u32(eq->part_hist.p, eq->part_off.p, mat_n, st))) return rc;
+    const size_t scatter_lds = (size_t)kSortWords * 4 + ((size_t)3 * n_regions + 1) * 4;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(k_part_scatter, dim3(n_blocks), dim3(kPartBlock), scatter_lds, st, d_ids, d_offsets, first, cnt, tile,
+                       n_regions, reg_of, eq->part_off.p, eq->part_words.p);
+    SF_CHECK_LAUNCH();
+    PartArgs pa{eq->table.p, eq->part_off.p, n_blocks, eq->part_words.p, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+                eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes, getenv("SFGPU_EQ_ABLATE") ? atoi(getenv("SFGPU_EQ_ABLATE")) : 0};
+    hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
+    SF_CHECK_LAUNCH();
+    SF_HIP(hipEventRecord(eq->ev1, st));
+    SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, eq->ev0, eq->ev1) == hipSuccess) eq->stats.insert_ms += ms; }
+    eq->stats.insert_launches++;
+    eq->n_classes += eq->h_ctr[CTR_NEW];
+    eq->arena_used = eq->h_ctr[CTR_ARENA];
+    const uint64_t n_def = eq->h_ctr[CTR_DEFER], n_long = eq->h_ctr[3];
+    if (n_def) {         // labels whose home region was full: copy them out, grow, insert them the generic way
+        eq->stats.deferred_reads += n_def;
+        if ((rc = eq->def_lens.reserve(n_def + 1, st, false)) || (rc = eq->def_off64.reserve(n_def + 2, st, false)) ||
+            (rc = eq->def_off.reserve(n_def + 1, st, false))) return rc;
+        hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p,
+                           eq->part_words.p, n_words, eq->def_lens.p);
+        SF_CHECK_LAUNCH();
+        if ((rc = exclusive_scan_u32(eq->def_lens.p, eq->def_off64.p, n_def, st))) return rc;
+        uint64_t tot = 0;
+        SF_HIP(hipMemcpyAsync(&tot, eq->def_off64.p + n_def, 8, hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        if ((rc = eq->def_ids.reserve(tot + 1, st, false))) return rc;
+        hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p,
+                           eq->part_words.p, eq->def_off64.p, eq->def_ids.p, eq->def_off.p);
+        SF_CHECK_LAUNCH();
+        if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
+        // deferred_a is reused by eq_generic: the copies above are complete (eq_grow synchronised)
+        if ((rc = eq_generic(eq, eq->def_ids.p, eq->def_off.p, 0, (uint32_t)n_def, nullptr, nullptr))) return rc;
+    }
+    if (n_long) {        // labels too long for an LDS tile
+        if ((rc = eq_generic(eq, d_ids, d_offsets, 0, (uint32_t)n_long, eq->part_long.p, nullptr))) return rc;
+    }
+    return SFGPU_OK;
+}
+
 // caller holds eq->mu
 static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads,
                          const uint64_t* d_weights = nullptr) {
@@ -359,51 +510,27 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     int rc;
     if ((rc = eq->arena.reserve(eq->arena_used + batch_ids + 1, st, true, eq->arena_used))) return rc;
 
-    for (uint32_t first = 0; first < n_reads; first += eq->sub_batch) {
-        uint32_t cnt = (n_reads - first < eq->sub_batch) ? (n_reads - first) : eq->sub_batch;
-        const uint32_t* list = nullptr;
-        uint32_t todo = cnt;
-        bool flip = false;
-        while (todo) {
-            // new-class budget of this launch: keep load <= 1/2 with room for the guard's slack
-            int64_t free_budget = (int64_t)(eq->cap / 2) - (int64_t)eq->n_classes - (int64_t)kSlack;
-            uint64_t need = todo < kMinHeadroom ? todo : kMinHeadroom;
-            if (free_budget < (int64_t)need) { if ((rc = eq_grow(eq, eq->cap * 2))) return rc; continue; }
-            uint64_t limit_new = (uint64_t)free_budget < todo ? (uint64_t)free_budget : todo;
-            if ((rc = eq->newlist.reserve(limit_new + kSlack, st, false))) return rc;
-            DevBuf<uint32_t>& dout = flip ? eq->deferred_b : eq->deferred_a;
-            if ((rc = dout.reserve(todo, st, false))) return rc;
-            uint64_t cls_need = eq->n_classes + limit_new + kSlack;
-            SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
-            if ((rc = eq->cls_hash.reserve(cls_need, st, true, eq->n_classes))) return rc;
-            if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
-            if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
-            if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
-            SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));
-            SF_HIP(hipEventRecord(eq->ev0, st));
-            hipLaunchKernelGGL(k_insert, dim3(grid_for(todo)), dim3(kBlock), 0, st, d_ids, d_offsets, first, todo, list,
-                               eq->table.p, eq->cap - 1, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->d_ctr,
-                               eq->newlist.p, (unsigned long long)limit_new, dout.p, d_weights);
-            SF_CHECK_LAUNCH();
-            SF_HIP(hipEventRecord(eq->ev1, st));
-            SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    // big unweighted batches take the radix-partitioned path, everything else the generic one
+    const bool part = eq->use_part && !d_weights && n_reads >= (1u << 16);
+    const uint32_t step = part ? eq->part_sub_batch : eq->sub_batch;
+    for (uint32_t first = 0; first < n_reads; first += step) {
+        uint32_t cnt = (n_reads - first < step) ? (n_reads - first) : step;
+        bool done = false;
+        if (part && (eq->cap >> kRegionBits) <= (uint64_t)kMaxRegions) {
+            uint32_t se[2];
+            SF_HIP(hipMemcpyAsync(&se[0], d_offsets + first, 4, hipMemcpyDeviceToHost, st));
+            SF_HIP(hipMemcpyAsync(&se[1], d_offsets + first + cnt, 4, hipMemcpyDeviceToHost, st));
             SF_HIP(hipStreamSynchronize(st));
-            { float ms = 0.f; if (hipEventElapsedTime(&ms, eq->ev0, eq->ev1) == hipSuccess) eq->stats.insert_ms += ms; }
-            eq->stats.insert_launches++;
-            uint64_t n_new = eq->h_ctr[CTR_NEW], n_def = eq->h_ctr[CTR_DEFER];
-            if (n_new) {
-                hipLaunchKernelGGL(k_commit, dim3(grid_for(n_new)), dim3(kBlock), 0, st, d_ids, d_offsets, eq->table.p,
-                                   eq->newlist.p, n_new, eq->n_classes, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p,
-                                   eq->cls_slot.p, eq->arena.p, eq->d_ctr);
-                SF_CHECK_LAUNCH();
-                eq->n_classes += n_new;
+            uint64_t n_words = (uint64_t)se[1] - se[0];
+            if (n_words < (1ull << 31)) {
+                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words))) return rc;
+                done = true;
             }
-            if (n_def) {
-                eq->stats.deferred_reads += n_def;
-                if ((rc = eq_grow(eq, eq->cap * 2))) return rc;   // synchronises: commit has finished
-                list = dout.p; todo = (uint32_t)n_def; flip = !flip;
-            } else {
-                todo = 0;
+        }
+        if (!done) {
+            for (uint32_t f2 = first; f2 < first + cnt; f2 += eq->sub_batch) {
+                uint32_t c2 = (first + cnt - f2 < eq->sub_batch) ? (first + cnt - f2) : eq->sub_batch;
+                if ((rc = eq_generic(eq, d_ids, d_offsets, f2, c2, nullptr, d_weights))) return rc;
             }
         }
     }

@@ -59,4 +59,87 @@ __device__ __forceinline__ uint64_t xxh64_words(WordFn word, uint32_t n) {
     return h;
 }
 
+
+// ---- short labels from registers -------------------------------------------------------------
+// Most labels have <= 8 ids.  Fetching their words with 8 independent (predicated) loads and hashing
+// from registers removes the load -> multiply -> load dependency chain of the generic loop, which is
+// what bounds a lane-per-label kernel (one memory round trip per 8 bytes otherwise).
+constexpr int kHead = 8;
+
+template <typename WordFn>
+__device__ __forceinline__ void label_head(WordFn word, uint32_t n, uint32_t (&w)[kHead]) {
+#pragma unroll
+    for (int i = 0; i < kHead; ++i) w[i] = ((uint32_t)i < n) ? word(i) : 0u;
+}
+
+// XXH64 of a label of n <= 8 words held in w[] (same arithmetic as xxh64_words)
+__device__ __forceinline__ uint64_t xxh64_head(const uint32_t (&w)[kHead], uint32_t n) {
+    auto w64 = [&](int k) -> uint64_t { return (uint64_t)w[k] | ((uint64_t)w[k + 1] << 32); };
+    uint64_t h;
+    if (n == 8) {   // exactly one 32-byte stripe
+        uint64_t v1 = xx_round(XP1 + XP2, w64(0)), v2 = xx_round(XP2, w64(2));
+        uint64_t v3 = xx_round(0, w64(4)), v4 = xx_round(0 - XP1, w64(6));
+        h = xx_rotl(v1, 1) + xx_rotl(v2, 7) + xx_rotl(v3, 12) + xx_rotl(v4, 18);
+        h = xx_merge(h, v1); h = xx_merge(h, v2); h = xx_merge(h, v3); h = xx_merge(h, v4);
+        h += 32;
+    } else {
+        h = XP5 + (uint64_t)n * 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if ((uint32_t)(2 * j + 2) <= n) { uint64_t k = xx_round(0, w64(2 * j)); h ^= k; h = xx_rotl(h, 27) * XP1 + XP4; }
+        if (n & 1) {
+            uint32_t last = (n == 1) ? w[0] : (n == 3) ? w[2] : (n == 5) ? w[4] : w[6];
+            h ^= (uint64_t)last * XP1; h = xx_rotl(h, 23) * XP2 + XP3;
+        }
+    }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
+
+// ---- bucket hash -----------------------------------------------------------------------------
+// Where a label goes in the device table (region, slot, tag) is decided by a 64-bit mix built from
+// two 32-bit xxHash-style lanes (acc = rotl(acc + w * P2, 13) * P1, the XXH32 round), NOT by XXH64:
+// a 64-bit integer multiply costs ~8 VALU multiplies on CDNA4 and hashing every read with XXH64
+// measured ~0.5 ms per 16.7 M labels per pass.  Class identity never depends on this value (it is
+// decided by a full label compare); XXH64 -- TranscriptGroup::hash -- is computed once per CLASS
+// when the class is committed, and is what the export and the canonical order use.
+constexpr uint32_t MP1 = 2654435761u, MP2 = 2246822519u, MP3 = 3266489917u;   // PRIME32_1..3 (src/xxhash.c:225-227)
+__device__ __forceinline__ uint32_t mix_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t mix_fin(uint32_t h) {
+    h ^= h >> 15; h *= MP2; h ^= h >> 13; h *= MP3; h ^= h >> 16; return h;
+}
+template <typename WordFn>
+__device__ __forceinline__ uint64_t label_mix64_words(WordFn word, uint32_t n) {
+    uint32_t a = MP1 + n, b = 0x27D4EB2Fu ^ (n * MP3);
+    const uint32_t rounds = n < (uint32_t)kHead ? (uint32_t)kHead : n;     // zero-padded to >= 8 rounds
+    for (uint32_t i = 0; i < rounds; ++i) {
+        uint32_t w = (i < n) ? word(i) : 0u;
+        a = mix_rotl(a + w * MP2, 13) * MP1;
+        b = mix_rotl(b ^ w, 11) * 5u + 0xE6546B64u;
+    }
+    return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
+}
+// n <= 8 words in w[] (words past n are zero): all 8 rounds run unconditionally -- the length is in
+// the seeds, so zero padding cannot alias a shorter label -- which keeps the code branch-free.
+// Must agree with label_mix64_words for n <= 8: that loop is padded to 8 rounds the same way.
+__device__ __forceinline__ uint64_t label_mix64_head(const uint32_t (&w)[kHead], uint32_t n) {
+    uint32_t a = MP1 + n, b = 0x27D4EB2Fu ^ (n * MP3);
+#pragma unroll
+    for (int i = 0; i < kHead; ++i) { a = mix_rotl(a + w[i] * MP2, 13) * MP1; b = mix_rotl(b ^ w[i], 11) * 5u + 0xE6546B64u; }
+    return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
+}
+// bucket hash of any label: registers for n <= 8, the loop otherwise
+template <typename WordFn>
+__device__ __forceinline__ uint64_t label_mix64(WordFn word, uint32_t n, uint32_t (&w)[kHead]) {
+    label_head(word, n, w);
+    return (n <= (uint32_t)kHead) ? label_mix64_head(w, n) : label_mix64_words(word, n);
+}
+
+// hash of any label: registers for n <= 8, the generic loop otherwise
+template <typename WordFn>
+__device__ __forceinline__ uint64_t xxh64_label(WordFn word, uint32_t n, uint32_t (&w)[kHead]) {
+    label_head(word, n, w);
+    return (n <= (uint32_t)kHead) ? xxh64_head(w, n) : xxh64_words(word, n);
+}
+
 }  // namespace sfgpu
