@@ -77,3 +77,33 @@ def test_cf_tables_host_side(built):
     np.testing.assert_array_equal(efflen.normal_counts(SailfishOpts()), O.fld_gaussian_counts())
     fl = O.fld_gaussian_counts().astype(np.uint32)
     np.testing.assert_array_equal(efflen.counts_cf(fl), O.cf_counts(fl))
+
+
+def _build_c_host(tmp_path):
+    exe = tmp_path / "c_abi_smoke"
+    csrc = os.path.join(ROOT, "sailfish_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", str(exe),
+                           "-L", csrc, "-lsfgpu", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + csrc + ",-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_c_host_links_against_the_abi(built, tmp_path):
+    """a plain-C program (no Python, no torch) compiles and links against libsfgpu"""
+    exe = _build_c_host(tmp_path)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_c_host_runs_the_toy_kat(built, tmp_path):
+    """...and reproduces the SURVEY 8c EM known answer when run on the GPU box"""
+    exe = _build_c_host(tmp_path)
+    out = subprocess.check_output([str(exe)], text=True)
+    f = out.split()
+    assert f[1] == "50"
+    got = [float(x) for x in f[3:7]]
+    want = [417.47751898139057, 0.0, 67.522481018609454, 0.0]
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-12 * max(1.0, abs(w))
+    assert abs(float(f[8]) - 1e6) < 1e-3
