@@ -46,6 +46,9 @@ SFGPU_API int sfgpu_version(void);
 SFGPU_API const char* sfgpu_last_error(void);
 /* Forwarded to sopt.jointLog by the adaptor (level: 0 info, 1 warn, 2 error).  NULL = silent. */
 SFGPU_API void sfgpu_set_logger(void (*log)(int level, const char* msg));
+/* Scratch device memory is cached inside the library (hipMalloc/hipFree are slow and hipFree
+ * synchronises the device); this returns every cached block to the driver. */
+SFGPU_API int sfgpu_pool_trim(void);
 /* Device name / CU count / HBM bytes of the current device (any pointer may be NULL). */
 SFGPU_API int sfgpu_device_info(char* name, int name_len, int* n_cu, uint64_t* hbm_bytes);
 

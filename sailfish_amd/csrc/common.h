@@ -15,6 +15,17 @@ void log_msg(int level, const char* fmt, ...);
 
 inline hipStream_t as_stream(sfgpu_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Caching device allocator: hipMalloc / hipFree cost tens of microseconds each and hipFree
+// synchronises the whole device; a quantification step creates and drops ~60 scratch buffers.
+// Blocks are rounded up to a power of two (>= 256 B) and kept in per-size free lists for reuse;
+// sfgpu_pool_trim() returns them to the driver.  Callers free only after the work that used the
+// block has been synchronised (handles synchronise their stream before releasing scratch).
+hipError_t pool_malloc(void** p, size_t bytes);
+void pool_free(void* p);
+void pool_trim();
+template <typename T>
+inline hipError_t pool_malloc(T** p, size_t bytes) { return pool_malloc(reinterpret_cast<void**>(p), bytes); }
+
 // HIP call -> SFGPU_ERR_HIP with the failing expression recorded.
 #define SF_HIP(expr)                                                                         \
     do {                                                                                     \
@@ -40,15 +51,15 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     uint64_t cap = 0;  // elements
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) pool_free(p); }
     int reserve(uint64_t n, hipStream_t s, bool keep, uint64_t used = 0) {
         if (n <= cap) return SFGPU_OK;
         uint64_t nc = cap ? cap : 1;
         while (nc < n) nc *= 2;
         T* q = nullptr;
-        SF_HIP(hipMalloc(&q, nc * sizeof(T)));
+        SF_HIP(pool_malloc(&q, nc * sizeof(T)));
         if (keep && p && used) SF_HIP(hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
-        if (p) { SF_HIP(hipStreamSynchronize(s)); SF_HIP(hipFree(p)); }
+        if (p) { SF_HIP(hipStreamSynchronize(s)); pool_free(p); }
         p = q; cap = nc;
         return SFGPU_OK;
     }

@@ -1,6 +1,10 @@
 // core.hip -- error slot, logger hook, device info for libsfgpu.
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 namespace sfgpu {
 
 static thread_local char g_err[512] = "";
@@ -22,9 +26,57 @@ void log_msg(int level, const char* fmt, ...) {
     g_logger(level, buf);
 }
 
+
+// ---- caching device allocator (see common.h) ----
+namespace {
+std::mutex g_pool_mu;
+std::unordered_map<size_t, std::vector<void*>> g_pool_free;    // rounded size -> free blocks
+std::unordered_map<void*, size_t> g_pool_size;                  // live or cached block -> rounded size
+size_t round_up_pow2(size_t n) { size_t r = 256; while (r < n) r <<= 1; return r; }
+}  // namespace
+
+hipError_t pool_malloc(void** p, size_t bytes) {
+    const size_t sz = round_up_pow2(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.find(sz);
+        if (it != g_pool_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); return hipSuccess; }
+    }
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, sz);
+    if (e != hipSuccess) {              // out of memory: give the cache back and retry once
+        pool_trim();
+        e = hipMalloc(&q, sz);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_size[q] = sz;
+    *p = q;
+    return hipSuccess;
+}
+
+void pool_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_size.find(p);
+    if (it == g_pool_size.end()) { (void)hipFree(p); return; }
+    g_pool_free[it->second].push_back(p);
+}
+
+void pool_trim() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& kv : g_pool_free) {
+        for (void* q : kv.second) { g_pool_size.erase(q); (void)hipFree(q); }
+        kv.second.clear();
+    }
+}
+
 }  // namespace sfgpu
 
 extern "C" {
+
+int sfgpu_pool_trim(void) { sfgpu::pool_trim(); return SFGPU_OK; }
+
 
 int sfgpu_version(void) { return SFGPU_VERSION; }
 const char* sfgpu_last_error(void) { return sfgpu::g_err; }

@@ -194,7 +194,7 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
 // Classes are stored in the canonical order (first id ascending), so a run of consecutive classes
 // touches a narrow band of transcripts.  Once per problem the CSR is re-packed into the stream the
 // sweep reads:
-//   * a tile is the run of classes whose first nonzero falls into one kTileNnz-sized bucket of the
+//   * a tile is the run of classes whose first nonzero falls into one tile_nnz-sized bucket of the
 //     CSR (nnz-balanced); its window is the band [lo, lo+span) of transcripts it touches (<= kWin);
 //   * one 32-bit word per nonzero:  [31 null][29 single][28..16 class index in the tile]
 //     [15..0 window offset], tiles padded to 8 words so every lane fetches its 8 consecutive words
@@ -215,7 +215,9 @@ k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __
 #ifndef SFGPU_TILE_NNZ
 #define SFGPU_TILE_NNZ 8000
 #endif
-constexpr int kTileNnz = SFGPU_TILE_NNZ;     // CSR bucket that defines a tile (<= 8191 classes per tile)
+constexpr int kTileNnz = SFGPU_TILE_NNZ;     // largest CSR bucket that defines a tile (<= 8191 classes per tile);
+                                             // the bucket actually used is sized per problem so that the tiles fill
+                                             // the chip in whole rounds (tile_nnz_for)
 constexpr int kWin = 1024;                   // LDS window (transcripts): 2 x 8 KB
 #ifndef SFGPU_SWEEP_BLOCK
 #define SFGPU_SWEEP_BLOCK 1024
@@ -228,11 +230,12 @@ constexpr int kPerLane = SFGPU_PER_LANE;     // consecutive stream words per lan
 constexpr uint32_t kNull = 0x80000000u, kSingle = 0x20000000u;
 static_assert(kTileNnz <= 8191, "class index field is 13 bits");
 
-// tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*kTileNnz, (i+1)*kTileNnz)
-__global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, uint32_t* tile_c0) {
+// tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*tile_nnz, (i+1)*tile_nnz)
+__global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, uint32_t tile_nnz, const uint32_t* __restrict__ rowptr,
+                            uint32_t* tile_c0) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_tiles) return;
-    uint64_t target = (uint64_t)i * kTileNnz;
+    uint64_t target = (uint64_t)i * tile_nnz;
     uint64_t lo = 0, hi = C;                         // first class with rowptr[c] >= target
     while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (rowptr[mid] >= target) hi = mid; else lo = mid + 1; }
     tile_c0[i] = (uint32_t)lo;
@@ -586,7 +589,7 @@ static void em_free(sfgpu_em* em) {
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
                     em->blkmax};
-    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) (void)hipHostFree(em->h_state);
     if (em->h_blkmax) (void)hipHostFree(em->h_blkmax);
     if (em->ev_a) (void)hipEventDestroy(em->ev_a);
@@ -704,14 +707,14 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     em->cur = em->stream;
     EM_TRY(hipEventCreate(&em->ev_a)); EM_TRY(hipEventCreate(&em->ev_b));
     EM_TRY(hipEventCreateWithFlags(&em->ev_join, hipEventDisableTiming));
-    EM_TRY(hipMalloc(&em->alpha, M * 8)); EM_TRY(hipMalloc(&em->alpha_out, M * 8));
-    EM_TRY(hipMalloc(&em->x, M * 8)); EM_TRY(hipMalloc(&em->lenc, M * 8)); EM_TRY(hipMalloc(&em->scratch, M * 8));
-    EM_TRY(hipMalloc(&em->partials, kMaxPartials * 8)); EM_TRY(hipMalloc(&em->sum_partials, kMaxPartials * 8));
-    EM_TRY(hipMalloc(&em->counts32, (C ? C : 1) * 4));
-    EM_TRY(hipMalloc(&em->d_state, sizeof(EmState)));
-    EM_TRY(hipMalloc(&em->blkmax, 2 * kMaxPartials * 8));
+    EM_TRY(pool_malloc(&em->alpha, M * 8)); EM_TRY(pool_malloc(&em->alpha_out, M * 8));
+    EM_TRY(pool_malloc(&em->x, M * 8)); EM_TRY(pool_malloc(&em->lenc, M * 8)); EM_TRY(pool_malloc(&em->scratch, M * 8));
+    EM_TRY(pool_malloc(&em->partials, kMaxPartials * 8)); EM_TRY(pool_malloc(&em->sum_partials, kMaxPartials * 8));
+    EM_TRY(pool_malloc(&em->counts32, (C ? C : 1) * 4));
+    EM_TRY(pool_malloc(&em->d_state, sizeof(EmState)));
+    EM_TRY(pool_malloc(&em->blkmax, 2 * kMaxPartials * 8));
     EM_TRY(hipHostMalloc(&em->h_blkmax, 2 * kMaxPartials * 8, hipHostMallocDefault));
-    EM_TRY(hipMalloc(&em->tile_lo, 4));   // sized once nnz is known (below)
+    EM_TRY(pool_malloc(&em->tile_lo, 4));   // sized once nnz is known (below)
     if (const char* v = getenv("SFGPU_EM_SWEEP")) em->sweep_variant = atoi(v);
     if (const char* v = getenv("SFGPU_EM_ABLATE")) em->ablate = atoi(v);
     EM_TRY(hipHostMalloc(&em->h_state, sizeof(EmState), hipHostMallocDefault));
@@ -735,20 +738,34 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     }
     em->L = rp_end;
     if (C) {   // nnz-balanced tile plan of the sweep, its label stream, and the cover lists of the fold
-        em->n_tiles = (uint32_t)(((uint64_t)rp_end + kTileNnz - 1) / kTileNnz);
+        // two 1024-thread blocks are resident per CU (LDS), so aim at whole rounds of 2 x #CU tiles
+        uint32_t tile_nnz = kTileNnz;
+        {
+            int dev = 0, n_cu = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint64_t slots = 2ull * (uint64_t)(n_cu > 0 ? n_cu : 256);
+            const uint64_t rounds = ((uint64_t)rp_end + slots * kTileNnz - 1) / (slots * kTileNnz);
+            // balancing pays when everything fits one round; with several rounds the per-block fixed cost of
+            // smaller tiles outweighs the tail (measured on the 9.2 M-nonzero problem)
+            uint64_t want = (rounds <= 1) ? ((uint64_t)rp_end + slots - 1) / slots : (uint64_t)kTileNnz;
+            if (want < 2048) want = 2048;
+            if (want > (uint64_t)kTileNnz) want = kTileNnz;
+            tile_nnz = (uint32_t)want;
+        }
+        em->n_tiles = (uint32_t)(((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
         if (em->n_tiles == 0) em->n_tiles = 1;
         const uint32_t nt = em->n_tiles;
         uint32_t *t_len8 = nullptr, *t_nesc = nullptr;
-        (void)hipFree(em->tile_lo); em->tile_lo = nullptr;
-        EM_TRY(hipMalloc(&em->tile_lo, (size_t)nt * 4));
-        EM_TRY(hipMalloc(&em->tile_span, ((size_t)nt + 1) * 4));
-        EM_TRY(hipMalloc(&em->tile_c0, ((size_t)nt + 1) * 4));
-        EM_TRY(hipMalloc(&em->tile_off, ((size_t)nt + 1) * 8));
-        EM_TRY(hipMalloc(&em->tile_s0, ((size_t)nt + 1) * 8));
-        EM_TRY(hipMalloc(&em->tile_esc0, ((size_t)nt + 1) * 8));
-        EM_TRY(hipMalloc(&t_len8, ((size_t)nt + 1) * 4)); EM_TRY(hipMalloc(&t_nesc, ((size_t)nt + 1) * 4));
-        EM_TRY(hipMalloc(&em->cov_ptr, ((size_t)M + 1) * 4));
-        hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt,
+        pool_free(em->tile_lo); em->tile_lo = nullptr;
+        EM_TRY(pool_malloc(&em->tile_lo, (size_t)nt * 4));
+        EM_TRY(pool_malloc(&em->tile_span, ((size_t)nt + 1) * 4));
+        EM_TRY(pool_malloc(&em->tile_c0, ((size_t)nt + 1) * 4));
+        EM_TRY(pool_malloc(&em->tile_off, ((size_t)nt + 1) * 8));
+        EM_TRY(pool_malloc(&em->tile_s0, ((size_t)nt + 1) * 8));
+        EM_TRY(pool_malloc(&em->tile_esc0, ((size_t)nt + 1) * 8));
+        EM_TRY(pool_malloc(&t_len8, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt + 1) * 4));
+        EM_TRY(pool_malloc(&em->cov_ptr, ((size_t)M + 1) * 4));
+        hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
                            prob->d_rowptr, em->tile_c0);
         hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
                            em->tile_lo, em->tile_span, t_len8, t_nesc);
@@ -756,7 +773,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur);
         if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur);
         if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur);
-        (void)hipFree(t_len8); (void)hipFree(t_nesc);
+        pool_free(t_len8); pool_free(t_nesc);
         if (sr) { em_free(em); return sr; }
         uint64_t P = 0, S = 0, E = 0;
         EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
@@ -765,19 +782,19 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(hipStreamSynchronize(em->cur));
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
         em->P = P;
-        EM_TRY(hipMalloc(&em->lstream, (S ? S : 1) * 4 + 32));
-        EM_TRY(hipMalloc(&em->esc_id, (E ? E : 1) * 4));
-        EM_TRY(hipMalloc(&em->esc_cls, (E ? E : 1) * 4));
+        EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
+        EM_TRY(pool_malloc(&em->esc_id, (E ? E : 1) * 4));
+        EM_TRY(pool_malloc(&em->esc_cls, (E ? E : 1) * 4));
         hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
                            em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls);
         EM_TRY(hipGetLastError());
-        EM_TRY(hipMalloc(&em->partial, (P ? P : 1) * 8));
-        EM_TRY(hipMalloc(&em->cov_pos, (P ? P : 1) * 4));
-        EM_TRY(hipMalloc(&em->pub_pos, (P ? P : 1) * 4));
+        EM_TRY(pool_malloc(&em->partial, (P ? P : 1) * 8));
+        EM_TRY(pool_malloc(&em->cov_pos, (P ? P : 1) * 4));
+        EM_TRY(pool_malloc(&em->pub_pos, (P ? P : 1) * 4));
         EM_TRY(hipMemsetAsync(em->partial, 0, (P ? P : 1) * 8, em->cur));
         if (P) {
             uint64_t *k_in = nullptr, *k_out = nullptr; uint32_t* v_in = nullptr;
-            EM_TRY(hipMalloc(&k_in, P * 8)); EM_TRY(hipMalloc(&k_out, P * 8)); EM_TRY(hipMalloc(&v_in, P * 4));
+            EM_TRY(pool_malloc(&k_in, P * 8)); EM_TRY(pool_malloc(&k_out, P * 8)); EM_TRY(pool_malloc(&v_in, P * 4));
             hipLaunchKernelGGL(k_cover_pairs, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off,
                                k_in, v_in);
             int bits = 1; while (bits < 32 && (1ull << bits) <= M) ++bits;
@@ -787,7 +804,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, em->cov_ptr);
                 (void)hipStreamSynchronize(em->cur);
             }
-            (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in);
+            pool_free(k_in); pool_free(k_out); pool_free(v_in);
             if (src) { em_free(em); return src; }
         } else {
             EM_TRY(hipMemsetAsync(em->cov_ptr, 0, ((size_t)M + 1) * 4, em->cur));
@@ -977,14 +994,14 @@ static int em_bootstrap_prepare(sfgpu_em* em) {
     if (em->bs_prefix) return SFGPU_OK;
     const uint64_t C = em->prob.C;
     uint32_t* masked = nullptr;
-    SF_HIP(hipMalloc(&masked, (C + 1) * 4));
-    SF_HIP(hipMalloc(&em->bs_prefix, (C + 1) * 8));
-    SF_HIP(hipMalloc(&em->bs_base, (C ? C : 1) * 4));
+    SF_HIP(pool_malloc(&masked, (C + 1) * 4));
+    SF_HIP(pool_malloc(&em->bs_prefix, (C + 1) * 8));
+    SF_HIP(pool_malloc(&em->bs_base, (C ? C : 1) * 4));
     const uint64_t W = multinomial_tree_width(C ? C : 1);
-    SF_HIP(hipMalloc(&em->bs_scratch_a, W * 4)); SF_HIP(hipMalloc(&em->bs_scratch_b, W * 4));
+    SF_HIP(pool_malloc(&em->bs_scratch_a, W * 4)); SF_HIP(pool_malloc(&em->bs_scratch_b, W * 4));
     hipLaunchKernelGGL(k_mask_counts, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, em->stream, C, em->counts32, masked);
     int rc = exclusive_scan_u32(masked, em->bs_prefix, C, em->stream);
-    (void)hipFree(masked);
+    pool_free(masked);
     if (rc) return rc;
     SF_HIP(hipMemcpyAsync(em->bs_base, em->counts32, (C ? C : 1) * 4, hipMemcpyDeviceToDevice, em->stream));
     SF_HIP(hipMemcpyAsync(&em->bs_total, em->bs_prefix + C, 8, hipMemcpyDeviceToHost, em->stream));
@@ -1019,7 +1036,7 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     o.min_iter = 0;            // doBootstrap has no 50-iteration floor (:486)
     o.check_mode = 1;          // and gates on alphas > 1e-2 (:499)
     double* d_tmp = nullptr; double* h_tmp = nullptr;
-    if (!d_out) SF_HIP(hipMalloc(&d_tmp, M * 8));
+    if (!d_out) SF_HIP(pool_malloc(&d_tmp, M * 8));
     if (cb) SF_HIP(hipHostMalloc(&h_tmp, M * 8, hipHostMallocDefault));
     const uint64_t keep_mapped = em->prob.num_mapped;
     em->prob.num_mapped = em->bs_total;                 // alpha init uses totalNumFrags = sum of counts (:470-474, :696)
@@ -1043,7 +1060,7 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     em->prob.num_mapped = keep_mapped;
     (void)hipMemcpyAsync(em->counts32, em->bs_base, C * 4, hipMemcpyDeviceToDevice, em->stream);   // observed counts back
     (void)hipStreamSynchronize(em->stream);
-    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_tmp) pool_free(d_tmp);
     if (h_tmp) (void)hipHostFree(h_tmp);
     return rc;
 }

@@ -288,7 +288,7 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
         SF_CHECK_LAUNCH();
     }
     SF_HIP(hipStreamSynchronize(eq->stream));
-    if (old) SF_HIP(hipFree(old));
+    if (old) pool_free(old);
     eq->stats.table_grows++;
     log_msg(0, "eq: table grown to %llu slots (%llu classes)", (unsigned long long)new_cap,
             (unsigned long long)eq->n_classes);
@@ -305,7 +305,7 @@ static int eq_reset(sfgpu_eq* eq) {
         hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
         SF_CHECK_LAUNCH();
     } else {
-        if (eq->table.p) { SF_HIP(hipStreamSynchronize(eq->stream)); SF_HIP(hipFree(eq->table.p)); }
+        if (eq->table.p) { SF_HIP(hipStreamSynchronize(eq->stream)); pool_free(eq->table.p); }
         int rc = eq_alloc_table(eq, want);
         if (rc) return rc;
     }
@@ -332,7 +332,7 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     eq->expected = expected_classes;
     if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) { eq->sub_batch = (uint32_t)v; eq->part_sub_batch = (uint32_t)v; } }
     if (const char* e = getenv("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
-    hipError_t e1 = hipMalloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
+    hipError_t e1 = pool_malloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
     hipError_t e2 = hipHostMalloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long), hipHostMallocDefault);
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev1);
@@ -349,7 +349,7 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
 int sfgpu_eq_destroy(sfgpu_eq* eq) {
     if (!eq) return SFGPU_OK;
     (void)hipStreamSynchronize(eq->stream);
-    if (eq->d_ctr) (void)hipFree(eq->d_ctr);
+    if (eq->d_ctr) pool_free(eq->d_ctr);
     if (eq->h_ctr) (void)hipHostFree(eq->h_ctr);
     if (eq->ev0) (void)hipEventDestroy(eq->ev0);
     if (eq->ev1) (void)hipEventDestroy(eq->ev1);

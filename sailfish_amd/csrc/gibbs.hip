@@ -159,10 +159,10 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr;
     int rc = SFGPU_OK;
 #define G_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); rc = SFGPU_ERR_HIP; goto done; } } while (0)
-    G_TRY(hipMalloc(&count_map, ((uint64_t)L * n_chains + 1) * 4));
-    G_TRY(hipMalloc(&txp_count, (uint64_t)M * n_chains * 4));
-    G_TRY(hipMalloc(&inv_len, M * 8)); G_TRY(hipMalloc(&w_mass, M * 8));
-    if (!d_out) G_TRY(hipMalloc(&d_tmp, (uint64_t)n_chains * M * 4));
+    G_TRY(pool_malloc(&count_map, ((uint64_t)L * n_chains + 1) * 4));
+    G_TRY(pool_malloc(&txp_count, (uint64_t)M * n_chains * 4));
+    G_TRY(pool_malloc(&inv_len, M * 8)); G_TRY(pool_malloc(&w_mass, M * 8));
+    if (!d_out) G_TRY(pool_malloc(&d_tmp, (uint64_t)n_chains * M * 4));
     if (cb) G_TRY(hipHostMalloc(&h_tmp, (uint64_t)n_chains * M * 4, hipHostMallocDefault));
     G_TRY(hipMemsetAsync(txp_count, 0, (uint64_t)M * n_chains * 4, st));
     hipLaunchKernelGGL(k_gibbs_weights, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, prob->d_len, d_mass,
@@ -195,12 +195,13 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     }
 #undef G_TRY
 done:
-    if (count_map) (void)hipFree(count_map);
-    if (txp_count) (void)hipFree(txp_count);
-    if (inv_len) (void)hipFree(inv_len);
-    if (w_mass) (void)hipFree(w_mass);
-    if (d_tmp) (void)hipFree(d_tmp);
+    if (count_map) pool_free(count_map);
+    if (txp_count) pool_free(txp_count);
+    if (inv_len) pool_free(inv_len);
+    if (w_mass) pool_free(w_mass);
+    if (d_tmp) pool_free(d_tmp);
     if (h_tmp) (void)hipHostFree(h_tmp);
+    pool_trim();          // the chain state is large (4 * nnz * n_chains bytes): do not keep it cached
     return rc;
 }
 

@@ -108,14 +108,14 @@ int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h
     double* d_cf = nullptr;
     if (h_cf) {
         SF_REQUIRE(max_frag_len > 0, SFGPU_ERR_INVALID, "sfgpu_efflen_smoothed: max_frag_len == 0");
-        SF_HIP(hipMalloc(&d_cf, (size_t)max_frag_len * 8));
+        SF_HIP(pool_malloc(&d_cf, (size_t)max_frag_len * 8));
         hipError_t e = hipMemcpyAsync(d_cf, h_cf, (size_t)max_frag_len * 8, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) { (void)hipFree(d_cf); SF_HIP(e); }
+        if (e != hipSuccess) { pool_free(d_cf); SF_HIP(e); }
     }
     hipLaunchKernelGGL(k_efflen, dim3((unsigned)((M + kMiscBlock - 1) / kMiscBlock)), dim3(kMiscBlock), 0, st, M,
                        d_ref_len, d_cf, max_frag_len, d_eff_len);
     hipError_t le = hipGetLastError();
-    if (d_cf) { (void)hipStreamSynchronize(st); (void)hipFree(d_cf); }
+    if (d_cf) { (void)hipStreamSynchronize(st); pool_free(d_cf); }
     SF_HIP(le);
     return SFGPU_OK;
 }
@@ -128,12 +128,12 @@ int sfgpu_tpm(const double* d_est_count, const double* d_len, uint64_t M, double
     int nb = (int)((M + kMiscBlock - 1) / kMiscBlock);
     if (nb > kMiscMaxBlocks) nb = kMiscMaxBlocks;
     double* partials = nullptr;
-    SF_HIP(hipMalloc(&partials, (size_t)kMiscMaxBlocks * 8));
+    SF_HIP(pool_malloc(&partials, (size_t)kMiscMaxBlocks * 8));
     hipLaunchKernelGGL(k_tpm_partial, dim3(nb), dim3(kMiscBlock), 0, st, M, d_est_count, d_len, num_mapped, partials);
     hipLaunchKernelGGL(k_tpm, dim3(nb), dim3(kMiscBlock), 0, st, M, d_est_count, d_len, num_mapped, partials, nb, d_tpm);
     hipError_t le = hipGetLastError();
     (void)hipStreamSynchronize(st);
-    (void)hipFree(partials);
+    pool_free(partials);
     SF_HIP(le);
     return SFGPU_OK;
 }

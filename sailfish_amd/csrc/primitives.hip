@@ -13,11 +13,11 @@ int sort_pairs_u64_u32(const uint64_t* d_keys_in, uint64_t* d_keys_out, const ui
     SF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out,
                                      (size_t)n, 0, end_bit, s));
     void* tmp = nullptr;
-    SF_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    SF_HIP(pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 8));
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out,
                                              (size_t)n, 0, end_bit, s);
     hipError_t e2 = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
+    pool_free(tmp);
     SF_HIP(e);
     SF_HIP(e2);
     return SFGPU_OK;
@@ -34,11 +34,11 @@ int exclusive_scan_u32(const uint32_t* d_in, uint64_t* d_out, uint64_t n, hipStr
     SF_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, d_out, (uint64_t)0, (size_t)(n + 1),
                                    rocprim::plus<uint64_t>(), s));
     void* tmp = nullptr;
-    SF_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    SF_HIP(pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 8));
     hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, in, d_out, (uint64_t)0, (size_t)(n + 1),
                                            rocprim::plus<uint64_t>(), s);
     hipError_t e2 = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
+    pool_free(tmp);
     SF_HIP(e);
     SF_HIP(e2);
     return SFGPU_OK;
