@@ -157,39 +157,6 @@ __global__ void k_vb_prepare(uint64_t M, const double* __restrict__ alpha, doubl
     }
 }
 
-// E-step sweep, one lane per class (EMUpdate_ :236-277 / VBEMUpdate_ :325-366).
-template <bool VB>
-__global__ void __launch_bounds__(kEmBlock)
-k_sweep_lane(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
-             const uint32_t* __restrict__ counts, const double* __restrict__ x, double* alpha_out,
-             EmState* st, uint32_t min_iter, uint32_t max_iter) {
-    uint32_t it = st->it_a;
-    bool stop = em_stop(it, st, min_iter, max_iter);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->it_b = stop ? kDoneMark : it;
-        if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
-    }
-    if (stop) return;
-    uint64_t c = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
-    if (c >= C) return;
-    uint32_t b = rowptr[c], e = rowptr[c + 1];
-    double cnt = (double)(counts[c] & 0x7FFFFFFFu);
-    if (e - b == 1) { atomicAdd(&alpha_out[ids[b]], cnt); return; }     // :275 / :364
-    if (e == b) return;
-    double denom = 0.0;
-    for (uint32_t j = b; j < e; ++j) {
-        double v = x[ids[j]];
-        if (VB) { if (v > 0.0) denom += v; } else denom += v;
-    }
-    if (!(denom > kTiny)) return;                                       // :260 / :349
-    double inv = cnt / denom;                                           // :264
-    for (uint32_t j = b; j < e; ++j) {
-        uint32_t t = ids[j];
-        double v = x[t];
-        if (VB ? (v > 0.0) : (v == v)) atomicAdd(&alpha_out[t], v * inv);
-    }
-}
-
 // ---- tiled E-step sweep with LDS accumulators --------------------------------------------------
 // Classes are stored in the canonical order (first id ascending), so a run of consecutive classes
 // touches a narrow band of transcripts.  Once per problem the CSR is re-packed into the stream the
@@ -338,7 +305,7 @@ struct SweepArgs {
     const uint64_t* tile_s0; const uint64_t* tile_esc0; const uint64_t* tile_off;
     const uint32_t* pub_pos;                                             // window slot -> index in `partial`
     const double* x; double* alpha_out; double* partial;
-    EmState* st; uint32_t min_iter, max_iter; int ablate;
+    EmState* st; uint32_t min_iter, max_iter;
 };
 
 template <bool VB>
@@ -388,7 +355,7 @@ k_sweep_lds(SweepArgs a) {
             if (w[i] & kNull) continue;
             double f = den[(w[i] >> 16) & 0x1FFFu];
             double contrib = (w[i] & kSingle) ? f : keep(xs[w[i] & 0xFFFFu]) * f;
-            if (contrib != 0.0) { if (a.ablate & 4) acc[w[i] & 0xFFFFu] = contrib; else atomicAdd(&acc[w[i] & 0xFFFFu], contrib); }
+            if (contrib != 0.0) atomicAdd(&acc[w[i] & 0xFFFFu], contrib);
         }
     };
 
@@ -409,7 +376,7 @@ k_sweep_lds(SweepArgs a) {
     __syncthreads();
 
     // ---- A: denominators
-    if (!(a.ablate & 1)) {
+    {
         denominators(w);
         for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
             uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
@@ -433,7 +400,7 @@ k_sweep_lds(SweepArgs a) {
     }
     __syncthreads();
     // ---- C: scatter-add into the window
-    if (!(a.ablate & 2)) {
+    {
         scatter(w);
         for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
             uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
@@ -570,8 +537,6 @@ struct sfgpu_em {
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
-    int ablate = 0;                                         // timing experiments only (SFGPU_EM_ABLATE)
-    int sweep_variant = 1;                                  // 0 = lane-per-class/global atomics, 1 = LDS tiles
     EmState* d_state = nullptr;
     EmState* h_state = nullptr;            // pinned
     sfgpu_em_opts opts{};
@@ -611,23 +576,11 @@ static int em_fill_opts(sfgpu_em* em, const sfgpu_em_opts* o) {
 static int em_enqueue_sweep(sfgpu_em* em) {
     const sfgpu_problem& p = em->prob;
     if (p.C == 0) return SFGPU_OK;
-    dim3 b(kEmBlock);
-    const bool vb = em->opts.use_vbem != 0;
-    if (em->sweep_variant == 0) {
-        dim3 g(blocks_for(p.C));
-        if (vb) hipLaunchKernelGGL(k_sweep_lane<true>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
-                                   em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
-        else hipLaunchKernelGGL(k_sweep_lane<false>, g, b, 0, em->cur, p.C, p.d_rowptr, p.d_ids, em->counts32, em->x,
-                                em->alpha_out, em->d_state, em->opts.min_iter, em->opts.max_iter);
-    } else {
-        dim3 g(em->n_tiles);
-        b = dim3(kSweepBlock);
-        SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
-                    em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                    em->opts.min_iter, em->opts.max_iter, em->ablate};
-        if (vb) hipLaunchKernelGGL(k_sweep_lds<true>, g, b, 0, em->cur, a);
-        else hipLaunchKernelGGL(k_sweep_lds<false>, g, b, 0, em->cur, a);
-    }
+    SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
+                em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
+                em->opts.min_iter, em->opts.max_iter};
+    if (em->opts.use_vbem) hipLaunchKernelGGL(k_sweep_lds<true>, dim3(em->n_tiles), dim3(kSweepBlock), 0, em->cur, a);
+    else hipLaunchKernelGGL(k_sweep_lds<false>, dim3(em->n_tiles), dim3(kSweepBlock), 0, em->cur, a);
     SF_CHECK_LAUNCH();
     return SFGPU_OK;
 }
@@ -637,7 +590,7 @@ static int em_enqueue_sweep(sfgpu_em* em) {
 static int em_enqueue_update(sfgpu_em* em, bool fold) {
     const sfgpu_problem& p = em->prob;
     dim3 g(em->nb), b(kEmBlock);
-    fold = fold && em->sweep_variant != 0 && p.C != 0;
+    fold = fold && p.C != 0;
 #define UPD_ARGS p.M, em->alpha, em->alpha_out, em->x, em->lenc, em->opts.tol, em->opts.check_mode, em->sum_partials, \
                  em->blkmax, em->d_state, em->cov_ptr, em->cov_pos, em->partial
     if (em->opts.use_vbem) {
@@ -657,7 +610,7 @@ static int em_enqueue_update(sfgpu_em* em, bool fold) {
 
 static int em_enqueue_fold(sfgpu_em* em) {
     const sfgpu_problem& p = em->prob;
-    if (em->sweep_variant == 0 || p.C == 0) return SFGPU_OK;
+    if (p.C == 0) return SFGPU_OK;
     hipLaunchKernelGGL(k_fold, dim3(blocks_for(p.M)), dim3(kEmBlock), 0, em->cur, p.M, em->alpha_out, em->cov_ptr,
                        em->cov_pos, em->partial, em->d_state);
     SF_CHECK_LAUNCH();
@@ -715,8 +668,6 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     EM_TRY(pool_malloc(&em->blkmax, 2 * kMaxPartials * 8));
     EM_TRY(hipHostMalloc(&em->h_blkmax, 2 * kMaxPartials * 8, hipHostMallocDefault));
     EM_TRY(pool_malloc(&em->tile_lo, 4));   // sized once nnz is known (below)
-    if (const char* v = getenv("SFGPU_EM_SWEEP")) em->sweep_variant = atoi(v);
-    if (const char* v = getenv("SFGPU_EM_ABLATE")) em->ablate = atoi(v);
     EM_TRY(hipHostMalloc(&em->h_state, sizeof(EmState), hipHostMallocDefault));
     EM_TRY(hipMemsetAsync(em->d_state, 0, sizeof(EmState), em->cur));
     int rc = em_join_user(em);

@@ -430,8 +430,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
     // every block of passes 1a/1b owns one contiguous tile of reads
-    uint32_t tile_reads = getenv("SFGPU_EQ_TILE") ? (uint32_t)atoi(getenv("SFGPU_EQ_TILE")) : 32768u;
-    uint32_t n_blocks = (cnt + tile_reads - 1) / tile_reads; if (n_blocks > 4096u) n_blocks = 4096u; if (n_blocks == 0) n_blocks = 1;
+    uint32_t n_blocks = (cnt + 32767u) / 32768u; if (n_blocks > 4096u) n_blocks = 4096u; if (n_blocks == 0) n_blocks = 1;
     const uint32_t tile = (uint32_t)(((uint64_t)cnt + n_blocks - 1) / n_blocks);
     const uint64_t mat_n = (uint64_t)n_regions * n_blocks;
     if ((rc = eq->part_words.reserve(n_words + 8, st, false))) return rc;
@@ -445,7 +444,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));     // long-label counter
     SF_HIP(hipEventRecord(eq->ev0, st));
     hipLaunchKernelGGL(k_part_hist, dim3(n_blocks), dim3(kPartBlock), 0, st, d_ids, d_offsets, first, cnt, tile, eq->cap - 1,
-                       n_regions, reg_of, eq->part_hist.p, eq->d_ctr + 3, eq->part_long.p, getenv("SFGPU_EQ_ABLATE") ? atoi(getenv("SFGPU_EQ_ABLATE")) : 0);
+                       n_regions, reg_of, eq->part_hist.p, eq->d_ctr + 3, eq->part_long.p);
     SF_CHECK_LAUNCH();
     if ((rc = exclusive_scan_u32(eq->part_hist.p, eq->part_off.p, mat_n, st))) return rc;
     const size_t scatter_lds = (size_t)kSortWords * 4 + ((size_t)3 * n_regions + 1) * 4;
@@ -458,7 +457,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
                        n_regions, reg_of, eq->part_off.p, eq->part_words.p);
     SF_CHECK_LAUNCH();
     PartArgs pa{eq->table.p, eq->part_off.p, n_blocks, eq->part_words.p, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes, getenv("SFGPU_EQ_ABLATE") ? atoi(getenv("SFGPU_EQ_ABLATE")) : 0};
+                eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes};
     hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev1, st));

@@ -38,7 +38,7 @@ __device__ __forceinline__ uint64_t region_next(uint64_t s) {
 __global__ void __launch_bounds__(kPartBlock)
 k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t first, uint32_t n,
             uint32_t tile, uint64_t mask, uint32_t n_regions, uint16_t* __restrict__ reg_of, uint32_t* __restrict__ mat,
-            unsigned long long* n_long, uint32_t* long_list, int ablate) {
+            unsigned long long* n_long, uint32_t* long_list) {
     __shared__ unsigned int lh[kMaxRegions];
     for (uint32_t i = threadIdx.x; i < n_regions; i += kPartBlock) lh[i] = 0;
     __syncthreads();
@@ -47,7 +47,6 @@ k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, 
     // four reads per lane per step: their offset and label loads are issued together, so a step costs
     // two memory round trips instead of eight
     constexpr int kB = 4;
-    if (!(ablate & 64))
     for (uint64_t base = t0; base < t1; base += (uint64_t)kB * kPartBlock) {
         uint32_t bb[kB], ll[kB];
 #pragma unroll
@@ -58,7 +57,7 @@ k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, 
         }
         uint32_t w[kB][kHead];
 #pragma unroll
-        for (int k = 0; k < kB; ++k) { const uint32_t* lab = ids + bb[k]; label_head([&](uint32_t q) { return lab[q]; }, (ll[k] <= kMaxPartLabel && !(ablate & 8)) ? ll[k] : 0u, w[k]); }
+        for (int k = 0; k < kB; ++k) { const uint32_t* lab = ids + bb[k]; label_head([&](uint32_t q) { return lab[q]; }, ll[k] <= kMaxPartLabel ? ll[k] : 0u, w[k]); }
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
             uint64_t i = base + (uint64_t)k * kPartBlock + threadIdx.x;
@@ -71,9 +70,9 @@ k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, 
                 uint64_t h = (len <= (uint32_t)kHead) ? label_mix64_head(w[k], len)
                                                       : label_mix64_words([&](uint32_t q) { return lab[q]; }, len);
                 rg = (uint16_t)((h & mask) >> kRegionBits);
-                if (!(ablate & 16)) atomicAdd(&lh[rg], len);
+                atomicAdd(&lh[rg], len);
             }
-            if (!(ablate & 32)) reg_of[i] = rg;
+            reg_of[i] = rg;
         }
     }
     __syncthreads();
@@ -180,7 +179,6 @@ struct PartArgs {
     unsigned long long* ctr;               // CTR_* counters (classes / arena cursor / deferred)
     uint32_t* deferred;                    // global word offsets of labels that found their region full
     uint64_t base_classes;                 // classes committed before this launch
-    int ablate;                            // timing experiments only (SFGPU_EQ_ABLATE)
 };
 
 // label at `p` (first word head-flagged) of `len` words against the stored representative
@@ -244,7 +242,6 @@ k_part_insert(PartArgs a) {
         const uint32_t nh = s_nheads;
         // the tile's last label may continue in the next tile: leave it for the next round
         const uint32_t n_proc = final_tile ? nh : (nh > 0 ? nh - 1 : 0);
-        if (!(a.ablate & 4))
         for (uint32_t l = threadIdx.x; l < n_proc; l += kPartBlock) {
             const uint32_t st = heads[l];
             const uint32_t en = (l + 1 < nh) ? heads[l + 1] : tlen;
@@ -273,8 +270,7 @@ k_part_insert(PartArgs a) {
                 if ((w >> 32) == tag) {
                     const uint32_t rep = (uint32_t)w;
                     bool same;
-                    if (a.ablate & 1) same = true;
-                    else if (rep & kArenaBit) {
+                    if (rep & kArenaBit) {
                         const uint32_t c = rep & ~kArenaBit;
                         const uint32_t* p = a.arena + a.cls_off[c];
                         same = (a.cls_len[c] == len) && p[0] == w0;

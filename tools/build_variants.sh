@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev tooling: build tuning variants of libsfgpu.so with different sweep geometry into gpurun_out-free paths
 set -e
-cd "$(dirname "$0")/sailfish_amd/csrc"
+cd "$(dirname "$0")/../sailfish_amd/csrc"
 mkdir -p variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -ffp-contract=off"
 for cfg in "$@"; do

@@ -1,7 +1,7 @@
 """dev probe: bootstrap / Gibbs throughput on cfg2-sized classes"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sailfish_amd as sf
 from sailfish_amd import synth
 dev = torch.device("cuda:0")
