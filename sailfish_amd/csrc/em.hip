@@ -311,6 +311,15 @@ struct SweepArgs {
 template <bool VB>
 __global__ void __launch_bounds__(kSweepBlock)
 k_sweep_lds(SweepArgs a) {
+    // the tile descriptors do not depend on the loop state: request them first so that the state test
+    // below costs no extra memory round trip
+    const uint32_t c0 = a.tile_c0[blockIdx.x], nc = a.tile_c0[blockIdx.x + 1] - c0;
+    const uint32_t lo = a.tile_lo[blockIdx.x], span = a.tile_span[blockIdx.x];
+    const uint64_t s0 = a.tile_s0[blockIdx.x];
+    const uint32_t n8 = (uint32_t)(a.tile_s0[blockIdx.x + 1] - s0);
+    const uint64_t e0 = a.tile_esc0[blockIdx.x];
+    const uint32_t n_esc = (uint32_t)(a.tile_esc0[blockIdx.x + 1] - e0);
+    const uint64_t off = a.tile_off[blockIdx.x];
     EmState* st = a.st;
     uint32_t it = st->it_a;
     bool stop = em_stop(it, st, a.min_iter, a.max_iter);
@@ -323,15 +332,8 @@ k_sweep_lds(SweepArgs a) {
     __shared__ double acc[kWin];
     __shared__ double den[kTileNnz];                       // denominators, then count/denom, per class of the tile
     const double* __restrict__ x = a.x;
-    const uint32_t c0 = a.tile_c0[blockIdx.x], nc = a.tile_c0[blockIdx.x + 1] - c0;
     if (nc == 0) return;
-    const uint32_t lo = a.tile_lo[blockIdx.x], span = a.tile_span[blockIdx.x];
-    const uint64_t s0 = a.tile_s0[blockIdx.x];
-    const uint32_t n8 = (uint32_t)(a.tile_s0[blockIdx.x + 1] - s0);
-    const uint64_t e0 = a.tile_esc0[blockIdx.x];
-    const uint32_t n_esc = (uint32_t)(a.tile_esc0[blockIdx.x + 1] - e0);
     const uint4* __restrict__ words = reinterpret_cast<const uint4*>(a.stream + s0);
-    const uint64_t off = a.tile_off[blockIdx.x];
 
     auto keep = [](double v) -> double {
         if (VB) return (v > 0.0) ? v : 0.0;                // expTheta == 0 terms are skipped (:344, :356)
@@ -446,16 +448,28 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
          double tol, int check_mode, double* sum_partials_out, double* blkmax, EmState* st,
          const uint32_t* __restrict__ cov_ptr, const uint32_t* __restrict__ cov_pos,
          const double* __restrict__ partial) {
+    // request this thread's first operands before looking at the loop state (they do not depend on it):
+    // the state test then costs no extra memory round trip
+    const uint64_t t_first = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
+    double a_first = 0.0, ao_first = 0.0; uint32_t k0_first = 0, k1_first = 0;
+    if (t_first < M) {
+        a_first = alpha[t_first]; ao_first = alpha_out[t_first];
+        if (FOLD) { k0_first = cov_ptr[t_first]; k1_first = cov_ptr[t_first + 1]; }
+    }
     uint32_t it = st->it_b;
     if (it == kDoneMark) return;
     __shared__ double lds[kEmBlock / kWave];
     __shared__ double lmax[kEmBlock / kWave];
     double local_sum = 0.0, local_max = -1.0;
     unsigned notconv = 0;
-    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
-        double a = alpha[t];
-        double ap = alpha_out[t];
-        if (FOLD) ap += fold_partials(t, cov_ptr, cov_pos, partial);
+    for (uint64_t t = t_first; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
+        const bool first = (t == t_first);
+        double a = first ? a_first : alpha[t];
+        double ap = first ? ao_first : alpha_out[t];
+        if (FOLD) {
+            const uint32_t k0 = first ? k0_first : cov_ptr[t], k1 = first ? k1_first : cov_ptr[t + 1];
+            for (uint32_t k = k0; k < k1; ++k) ap += partial[k];       // transcript-major: contiguous, fixed order
+        }
         if (VB) ap += kPriorAlpha;                     // alphaOut starts at the prior (:318)
         double gate = check_mode ? a : ap;             // :852 vs :499
         if (gate > kCheckCutoff) {
