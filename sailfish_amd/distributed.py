@@ -192,6 +192,44 @@ class DistributedQuant:
             txps.estCount.copy_(p.alpha); txps.mass.copy_(p.mass)
         return ok, st, mode
 
+    # ---- posterior sampling: draws are independent, so they are split over the ranks ------------
+    def _share(self, n):
+        base, extra = divmod(int(n), self.world)
+        return base + (1 if self.rank < extra else 0)
+
+    def _gather_rows(self, mine, n_total):
+        """concatenate every rank's rows (rank order) on all ranks"""
+        if self.world == 1:
+            return mine
+        flat = _all_gather_var(mine.reshape(-1), self.group, self.world)
+        M = mine.shape[1]
+        return torch.cat([f.reshape(-1, M) for f in flat], 0)[:n_total]
+
+    def bootstrap(self, n, seed=1, tol=0.01, max_iter=10000):
+        """gatherBootstraps over all ranks (classes replicated, draws split, no collective
+        until the results are gathered).  Rank r draws its share with the stream seed + r * golden.
+        Needs a finished run() in replicated / single mode.  -> float64 [n, M] on every rank"""
+        p = self.problem
+        rc, out, _ = p.bootstrap(self._share(n), seed=(int(seed) + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1),
+                                 use_vbem=self.sopt.useVBOpt, tol=tol, max_iter=max_iter)
+        if rc:
+            raise RuntimeError(f"bootstrap failed on rank {self.rank}: rc={rc}")
+        return self._gather_rows(out, n)
+
+    def gibbs(self, n, seed=1, n_chains=0):
+        """CollapsedGibbsSampler::sample over all ranks: every rank runs its own chains for its share of
+        the draws.  -> int32 [n, M] on every rank"""
+        from .gibbs import gibbs_sample
+        exp, sopt = self.exp, self.sopt
+        txps = exp.transcripts()
+        vec = self.merged.eqVec() if self.merged is not None else self.local.eqVec()
+        length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
+        rc, out = gibbs_sample(length, txps.mass, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments(), self._share(n),
+                               n_chains=n_chains, seed=(int(seed) + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1))
+        if rc:
+            raise RuntimeError(f"gibbs failed on rank {self.rank}: rc={rc}")
+        return self._gather_rows(out, n)
+
     def time_sweep(self, n=200):
         p = self.problem
         return p.time_sweep(n, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)

@@ -34,6 +34,13 @@ def _worker(rank, world, port, mode, vb, out):
         q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, poll_every=9)
         info = q.run(ids.to(dev), off.to(dev))
         t = exp.transcripts()
+        if mode == "replicated":                       # posterior draws are split over the ranks
+            bs = q.bootstrap(5, seed=3)
+            gs = q.gibbs(7, seed=3, n_chains=64)
+            N = exp.numMappedFragments()
+            assert bs.shape == (5, M) and gs.shape == (7, M)
+            assert torch.allclose(bs.sum(1), torch.full((5,), float(N), dtype=torch.float64, device=dev), rtol=1e-6)
+            assert bool((gs.sum(1) == N).all())
         out.put((rank, info["em_mode"], info["n_classes"], info["nnz"], exp.numMappedFragments(), info["em_stats"]["iters"],
                  t.estCount.cpu().numpy(), info["tpm"].cpu().numpy(), ids.numpy().copy(), off.numpy().copy()))
     finally:

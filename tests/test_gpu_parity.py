@@ -119,9 +119,14 @@ def test_builder_batching_and_order_independence(sf, gpu):
     eq = _gpu_classes(sf, gpu, parts[::-1], device_batches=False); _assert_same_classes(eq, ob, *oc)
 
 
-def test_builder_growth_and_deferral(sf, gpu, monkeypatch):
-    """more distinct classes than the initial table budget: deferred reads are replayed after growth"""
-    monkeypatch.setenv("SFGPU_EQ_SUBBATCH", "65536")
+@pytest.mark.parametrize("sub_batch", ["65536", None])
+def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
+    """more distinct classes than the table budget: deferred reads are replayed after growth.
+    sub_batch=65536: the table grows between sub-batches; None: one 3.7 M-read sub-batch overflows the
+    regions' LDS images in the partitioned pass, so the deferred-label path (copy out, grow, generic
+    insert) runs"""
+    if sub_batch:
+        monkeypatch.setenv("SFGPU_EQ_SUBBATCH", sub_batch)
     rng = np.random.default_rng(2)
     n = 3_500_000                                   # > 2^21 - slack distinct labels
     a = rng.permutation(n).astype(np.uint32)
@@ -131,6 +136,9 @@ def test_builder_growth_and_deferral(sf, gpu, monkeypatch):
     ids = np.concatenate([ids, ids[:2 * dup]]); off = np.concatenate([off, off[-1] + off[1:dup + 1]])
     eq = _gpu_classes(sf, gpu, [(ids, off)], expected_classes=1000)
     rp, ii, cc, hh = eq.eqVec().to_numpy()
+    st = eq.stats()
+    if sub_batch is None:
+        assert st["deferred_reads"] > 0 and st["table_grows"] >= 1      # the overflow path really ran
     assert eq.n_classes == n and eq.total_reads == n + dup and int(cc.sum()) == n + dup
     lab = ii.reshape(-1, 2)
     assert np.array_equal(np.sort(lab[:, 0]), np.arange(n, dtype=np.uint32))
