@@ -5,30 +5,58 @@
 //
 // The reference runs one chain per TBB chunk of the sample range (:223-246): initCountMap_ assigns
 // every class's reads to its transcripts with one multinomial draw, then each sample is the previous
-// one plus ONE sampleRound_ (`bool numInternalRounds = 10` is 1, :248).  Inside a round the classes are
-// visited in order and each visit reads the transcript counts the previous visits left behind, so a
-// chain is inherently sequential; the parallelism on the device is across chains:
-//   * one LANE per chain, 64 chains per wavefront, walking the classes in lock step.  The class
-//     structure (rowptr / ids / counts / effective lengths) is the same for every chain, so those
-//     loads are wave-uniform, and the per-chain state is laid out chain-minor --
-//     countMap[nonzero][chain], txpCount[transcript][chain] -- so every state access of a
-//     wavefront is one coalesced 256-byte transaction.  No cross-lane traffic at all;
-//   * the multinomial over a class's k members is a chain of k-1 conditional binomials
-//     (exact BINV/BTPE sampler, rng.h) instead of n inverse-CDF draws (MultinomialSampler.hpp:13-64):
-//     cost O(k), not O(reads);
-//   * the aux weight of member t is (count/effLen_t)/sum, i.e. proportional to 1/effLen_t inside a
-//     class; its normaliser cancels in the multinomial probabilities, so 1/effLen_t is used directly.
-// Random numbers: Philox4x32-10 keyed by (seed; chain, round, class) -- reproducible; the reference seeds
-// std::mt19937 from std::random_device (:104-105, :227-228), so parity is distributional.
+// one plus ONE sampleRound_ (`bool numInternalRounds = 10` is 1, :248).  A round visits every class
+// once, in eqVec order -- which is hash-table order, i.e. arbitrary -- and each visit reads the
+// transcript counts earlier visits left behind.
+//
+// Device design.
+//   * Chains: one LANE per chain, 64 chains per wavefront in lock step.  The class structure is the
+//     same for every chain (wave-uniform loads) and the per-chain state is chain-minor --
+//     countMap[nonzero][chain], txpCount[transcript][chain] -- so every state access of a wavefront
+//     is one coalesced 256-byte transaction and there is no cross-lane traffic.
+//   * Visiting order: two class visits commute exactly when the classes share no transcript, so a
+//     round may visit conflict-free classes concurrently and is then identical to SOME sequential
+//     scan.  Classes are cut into tiles of 64 consecutive classes (canonical order = sorted by first
+//     id, so a tile touches a narrow band of transcripts [lo, hi]); with K = the largest number of
+//     following tiles a tile's band reaches into, the tiles {p, p+K, p+2K, ...} of "phase" p have
+//     pairwise disjoint bands.  A round is K phase launches; inside a phase every (tile, 64-chain
+//     group) is an independent block.  The scan order is phase-major instead of index-major -- a
+//     different but equally systematic scan (the reference's own order is an accident of its hash
+//     table).  Classes whose members span more than kWideSpan transcripts would inflate K; they are
+//     taken out of the tiles and visited one after another in a final "wide" phase.
+//     This turns ~0.5 M sequential class visits per round per chain (16 wavefronts on the chip for 1024
+//     chains: 5.9 s per round, measured) into K ~ tens of launches of thousands of blocks.
+//   * The multinomial over a class's k members is a chain of k-1 conditional binomials (exact
+//     BINV/BTPE sampler, rng.h) instead of n inverse-CDF draws (MultinomialSampler.hpp:13-64).
+//   * The aux weight of member t is (count/effLen_t)/sum, proportional to 1/effLen_t inside a class;
+//     its normaliser cancels in the multinomial probabilities, so 1/effLen_t is used directly.
+// Random numbers: Philox4x32-10 keyed by (seed; chain, round, class): results do not depend on how
+// blocks are scheduled.  The reference seeds std::mt19937 from std::random_device (:104-105,
+// :227-228), so parity is distributional.
 #include "common.h"
 #include "rng.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace sfgpu {
 
 constexpr int kGibbsBlock = 64;            // one wavefront of chains per block
+constexpr int kGibbsTile = 64;             // classes per tile
+constexpr uint32_t kWideSpan = 2048;       // classes spanning more transcripts than this are "wide"
+constexpr uint32_t kMaxPhases = 1024;      // more phases than this: fall back to one sequential scan
 constexpr double kGibbsPrior = 1e-8;       // priorAlpha (:215)
+constexpr double kGibbsTiny = 4.9406564584124654e-324;
+
+struct GibbsArgs {
+    uint32_t n_chains; uint64_t C;
+    const uint32_t* rowptr; const uint32_t* ids; const uint64_t* counts;
+    const double* inv_len; const double* w_mass;        // 1/effLen_t ; (prior + mass_t)/effLen_t
+    uint32_t* count_map; int32_t* txp_count;
+    const uint8_t* wide;                                 // per class: visited in the wide phase
+    const uint32_t* wide_list; uint32_t n_wide;
+    uint64_t seed; uint32_t round;
+};
 
 // multinomial(n; p_0..p_{k-1}) as conditional binomials; calls put(i, r_i) for every member
 template <typename ProbFn, typename PutFn>
@@ -49,71 +77,106 @@ __device__ __forceinline__ void multinomial_chain(Philox& g, uint32_t n, uint32_
     }
 }
 
-// initCountMap_ (:35-94): initial assignment from (prior + mass_t) * aux_t
+// initCountMap_ (:45-92) for one class and one chain
+__device__ __forceinline__ void gibbs_init_class(const GibbsArgs& a, uint64_t c, uint32_t ch) {
+    const uint32_t b = a.rowptr[c], k = a.rowptr[c + 1] - b;
+    const uint32_t n = (uint32_t)a.counts[c];            // uint32 n in MultinomialSampler (:15)
+    const uint32_t nch = a.n_chains;
+    if (k == 0) return;
+    if (k == 1) {                                        // :81-83
+        a.count_map[(uint64_t)b * nch + ch] = n;
+        a.txp_count[(uint64_t)a.ids[b] * nch + ch] += (int32_t)n;
+        return;
+    }
+    double denom = 0.0;
+    for (uint32_t i = 0; i < k; ++i) denom += a.w_mass[a.ids[b + i]];                 // :58-63
+    if (!(denom > kGibbsTiny)) {                                                      // :65 -- nothing assigned
+        for (uint32_t i = 0; i < k; ++i) a.count_map[(uint64_t)(b + i) * nch + ch] = 0;
+        return;
+    }
+    Philox g; g.init(a.seed, ch, c);
+    multinomial_chain(g, n, k, denom,
+        [&](uint32_t i) { return a.w_mass[a.ids[b + i]]; },
+        [&](uint32_t i, uint32_t r) {
+            a.count_map[(uint64_t)(b + i) * nch + ch] = r;                            // :76-79
+            a.txp_count[(uint64_t)a.ids[b + i] * nch + ch] += (int32_t)r;             // :86-89
+        });
+}
+
+// sampleRound_ (:113-184) for one class and one chain
+__device__ __forceinline__ void gibbs_round_class(const GibbsArgs& a, uint64_t c, uint32_t ch) {
+    const uint32_t b = a.rowptr[c], k = a.rowptr[c + 1] - b;
+    if (k <= 1) return;                                     // singletons keep their full count (:128)
+    const uint32_t nch = a.n_chains;
+    Philox g; g.init(a.seed, ((uint64_t)(a.round + 1) << 32) | ch, c);
+    const double frac = 0.25 + 0.5 * g.uniform();           // U(0.25, 0.75) per class (:106, :115)
+    // pass 1: take round(frac * current) reads away from every member (:138-148)
+    uint32_t n_res = 0; double denom = 0.0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const uint64_t at = (uint64_t)(b + i) * nch + ch;
+        const uint32_t t = a.ids[b + i];
+        const uint32_t cur = a.count_map[at];
+        const uint32_t r = (uint32_t)(frac * (double)cur + 0.5);                       // std::round, values >= 0 (:142)
+        n_res += r;
+        a.count_map[at] = cur - r;
+        const int32_t tc = a.txp_count[(uint64_t)t * nch + ch] - (int32_t)r;
+        a.txp_count[(uint64_t)t * nch + ch] = tc;
+        denom += (kGibbsPrior + (double)tc) * a.inv_len[t];                            // :147
+    }
+    // pass 2: re-draw them from p_i ~ (prior + txpCount_i) * aux_i (:150-170).  denom >= k*1e-8/len > 0,
+    // so the reference's "did not sample" branch (:172-179) cannot trigger for finite inputs.
+    multinomial_chain(g, n_res, k, denom,
+        [&](uint32_t i) { const uint32_t t = a.ids[b + i]; return (kGibbsPrior + (double)a.txp_count[(uint64_t)t * nch + ch]) * a.inv_len[t]; },
+        [&](uint32_t i, uint32_t r) {
+            if (r) { a.count_map[(uint64_t)(b + i) * nch + ch] += r; a.txp_count[(uint64_t)a.ids[b + i] * nch + ch] += (int32_t)r; }
+        });
+}
+
+// one phase: blockIdx.x -> tile (phase + K * x), blockIdx.y -> group of 64 chains
+template <bool INIT>
 __global__ void __launch_bounds__(kGibbsBlock)
-k_gibbs_init(uint32_t n_chains, uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
-             const uint64_t* __restrict__ counts, const double* __restrict__ w_mass /* (prior+mass_t)/effLen_t */,
-             uint32_t* __restrict__ count_map, int32_t* __restrict__ txp_count, uint64_t seed) {
-    const uint32_t ch = blockIdx.x * kGibbsBlock + threadIdx.x;
-    if (ch >= n_chains) return;
-    for (uint64_t c = 0; c < C; ++c) {
-        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
-        const uint32_t n = (uint32_t)counts[c];          // uint32 n in MultinomialSampler (:15)
-        if (k == 1) {                                    // :81-83
-            count_map[(uint64_t)b * n_chains + ch] = n;
-            txp_count[(uint64_t)ids[b] * n_chains + ch] += (int32_t)n;
-            continue;
-        }
-        if (k == 0) continue;
-        double denom = 0.0;
-        for (uint32_t i = 0; i < k; ++i) denom += w_mass[ids[b + i]];            // :58-63
-        if (!(denom > 4.9406564584124654e-324)) {                                // :65 -- nothing assigned
-            for (uint32_t i = 0; i < k; ++i) count_map[(uint64_t)(b + i) * n_chains + ch] = 0;
-            continue;
-        }
-        Philox g; g.init(seed, ch, c);
-        multinomial_chain(g, n, k, denom,
-            [&](uint32_t i) { return w_mass[ids[b + i]]; },
-            [&](uint32_t i, uint32_t r) {
-                count_map[(uint64_t)(b + i) * n_chains + ch] = r;                // :76-79
-                txp_count[(uint64_t)ids[b + i] * n_chains + ch] += (int32_t)r;  // :86-89
-            });
+k_gibbs_phase(GibbsArgs a, uint32_t phase, uint32_t K, uint32_t n_tiles) {
+    const uint32_t tile = phase + K * blockIdx.x;
+    const uint32_t ch = blockIdx.y * kGibbsBlock + threadIdx.x;
+    if (tile >= n_tiles || ch >= a.n_chains) return;
+    const uint64_t c0 = (uint64_t)tile * kGibbsTile;
+    const uint64_t c1 = (c0 + kGibbsTile < a.C) ? c0 + kGibbsTile : a.C;
+    for (uint64_t c = c0; c < c1; ++c) {
+        if (a.wide[c]) continue;
+        if (INIT) gibbs_init_class(a, c, ch); else gibbs_round_class(a, c, ch);
     }
 }
 
-// sampleRound_ (:96-186)
+// the wide classes, one after another (they may share transcripts with each other)
+template <bool INIT>
 __global__ void __launch_bounds__(kGibbsBlock)
-k_gibbs_round(uint32_t n_chains, uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
-              const double* __restrict__ inv_len, uint32_t* __restrict__ count_map, int32_t* __restrict__ txp_count,
-              uint64_t seed, uint32_t round) {
+k_gibbs_wide(GibbsArgs a) {
     const uint32_t ch = blockIdx.x * kGibbsBlock + threadIdx.x;
-    if (ch >= n_chains) return;
-    for (uint64_t c = 0; c < C; ++c) {
-        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
-        if (k <= 1) continue;                                   // singletons keep their full count (:128)
-        Philox g; g.init(seed, ((uint64_t)(round + 1) << 32) | ch, c);
-        const double frac = 0.25 + 0.5 * g.uniform();           // U(0.25, 0.75) per class (:106, :115)
-        // pass 1: take round(frac * current) reads away from every member (:138-148)
-        uint32_t n_res = 0; double denom = 0.0;
-        for (uint32_t i = 0; i < k; ++i) {
-            const uint64_t at = (uint64_t)(b + i) * n_chains + ch;
-            const uint32_t t = ids[b + i];
-            const uint32_t cur = count_map[at];
-            const uint32_t r = (uint32_t)(frac * (double)cur + 0.5);             // std::round, values >= 0 (:142)
-            n_res += r;
-            count_map[at] = cur - r;
-            const int32_t tc = txp_count[(uint64_t)t * n_chains + ch] - (int32_t)r;
-            txp_count[(uint64_t)t * n_chains + ch] = tc;
-            denom += (kGibbsPrior + (double)tc) * inv_len[t];                    // :147
-        }
-        // pass 2: re-draw them from p_i ~ (prior + txpCount_i) * aux_i (:150-170).  denom >= k*1e-8/len > 0,
-        // so the reference's "did not sample" branch (:172-179) cannot trigger for finite inputs.
-        multinomial_chain(g, n_res, k, denom,
-            [&](uint32_t i) { const uint32_t t = ids[b + i]; return (kGibbsPrior + (double)txp_count[(uint64_t)t * n_chains + ch]) * inv_len[t]; },
-            [&](uint32_t i, uint32_t r) {
-                if (r) { count_map[(uint64_t)(b + i) * n_chains + ch] += r; txp_count[(uint64_t)ids[b + i] * n_chains + ch] += (int32_t)r; }
-            });
+    if (ch >= a.n_chains) return;
+    for (uint32_t i = 0; i < a.n_wide; ++i) {
+        const uint64_t c = a.wide_list[i];
+        if (INIT) gibbs_init_class(a, c, ch); else gibbs_round_class(a, c, ch);
     }
+}
+
+// plan: per class wide flag; per tile the band [lo, hi] of its non-wide classes
+__global__ void k_gibbs_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                             uint8_t* wide, uint32_t* tile_lo, uint32_t* tile_hi, uint32_t* wide_list, unsigned int* n_wide) {
+    uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const uint64_t c0 = (uint64_t)tile * kGibbsTile;
+    const uint64_t c1 = (c0 + kGibbsTile < C) ? c0 + kGibbsTile : C;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (uint64_t c = c0; c < c1; ++c) {
+        uint32_t b = rowptr[c], e = rowptr[c + 1];
+        uint32_t mn = 0xFFFFFFFFu, mx = 0;
+        for (uint32_t j = b; j < e; ++j) { uint32_t t = ids[j]; mn = t < mn ? t : mn; mx = t > mx ? t : mx; }
+        bool w = (e > b) && (mx - mn > kWideSpan);
+        wide[c] = w ? 1 : 0;
+        if (w) wide_list[atomicAdd(n_wide, 1u)] = (uint32_t)c;
+        else if (e > b) { lo = mn < lo ? mn : lo; hi = mx > hi ? mx : hi; }
+    }
+    tile_lo[tile] = lo; tile_hi[tile] = hi;                  // lo > hi: the tile has no banded class
 }
 
 __global__ void k_gibbs_weights(uint64_t M, const double* __restrict__ len, const double* __restrict__ mass, double num_mapped,
@@ -140,6 +203,24 @@ __global__ void k_gibbs_emit(uint32_t n_chains, uint32_t n_emit, uint64_t M, con
 
 using namespace sfgpu;
 
+// number of phases: the smallest K such that every tile's band ends before the band of the K-th
+// following tile begins (suffix minima make the test monotone even if the bands are not)
+static uint32_t gibbs_phase_count(const std::vector<uint32_t>& lo, const std::vector<uint32_t>& hi) {
+    const size_t n = lo.size();
+    std::vector<uint32_t> slo(n + 1, 0xFFFFFFFFu);
+    for (size_t i = n; i-- > 0;) slo[i] = std::min(slo[i + 1], lo[i]);
+    uint32_t K = 1;
+    for (size_t i = 0; i < n; ++i) {
+        if (lo[i] > hi[i]) continue;                       // empty band
+        // first d >= 1 with slo[i + d] > hi[i]  (slo is non-decreasing in its index)
+        size_t a = i + 1, b = n;                           // search in [i+1, n]; slo[n] = +inf
+        while (a < b) { size_t m = (a + b) / 2; if (slo[m] > hi[i]) b = m; else a = m + 1; }
+        uint32_t d = (uint32_t)(a - i);
+        if (d > K) K = d;
+    }
+    return K;
+}
+
 extern "C" {
 
 int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t n_samples, uint32_t n_chains,
@@ -155,28 +236,58 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     }
     uint32_t L = 0;
     if (C) { SF_HIP(hipMemcpyAsync(&L, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, st)); SF_HIP(hipStreamSynchronize(st)); }
+    const uint32_t n_tiles = (uint32_t)((C + kGibbsTile - 1) / kGibbsTile);
     uint32_t* count_map = nullptr; int32_t* txp_count = nullptr; double *inv_len = nullptr, *w_mass = nullptr;
+    uint8_t* wide = nullptr; uint32_t *tile_lo = nullptr, *tile_hi = nullptr, *wide_list = nullptr; unsigned int* d_nwide = nullptr;
     int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr;
     int rc = SFGPU_OK;
 #define G_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); rc = SFGPU_ERR_HIP; goto done; } } while (0)
     G_TRY(pool_malloc(&count_map, ((uint64_t)L * n_chains + 1) * 4));
     G_TRY(pool_malloc(&txp_count, (uint64_t)M * n_chains * 4));
     G_TRY(pool_malloc(&inv_len, M * 8)); G_TRY(pool_malloc(&w_mass, M * 8));
+    G_TRY(pool_malloc(&wide, C ? C : 1)); G_TRY(pool_malloc(&wide_list, (C ? C : 1) * 4)); G_TRY(pool_malloc(&d_nwide, 4));
+    G_TRY(pool_malloc(&tile_lo, (size_t)(n_tiles ? n_tiles : 1) * 4)); G_TRY(pool_malloc(&tile_hi, (size_t)(n_tiles ? n_tiles : 1) * 4));
     if (!d_out) G_TRY(pool_malloc(&d_tmp, (uint64_t)n_chains * M * 4));
     if (cb) G_TRY(hipHostMalloc(&h_tmp, (uint64_t)n_chains * M * 4, hipHostMallocDefault));
     G_TRY(hipMemsetAsync(txp_count, 0, (uint64_t)M * n_chains * 4, st));
+    G_TRY(hipMemsetAsync(d_nwide, 0, 4, st));
     hipLaunchKernelGGL(k_gibbs_weights, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, prob->d_len, d_mass,
                        (double)prob->num_mapped, inv_len, w_mass);
     {
-        const unsigned g = (n_chains + kGibbsBlock - 1) / kGibbsBlock;
-        hipLaunchKernelGGL(k_gibbs_init, dim3(g), dim3(kGibbsBlock), 0, st, n_chains, C, prob->d_rowptr, prob->d_ids,
-                           prob->d_counts, w_mass, count_map, txp_count, seed);
-        G_TRY(hipGetLastError());
-        uint32_t done = 0, round = 0;
-        while (done < n_samples) {
-            hipLaunchKernelGGL(k_gibbs_round, dim3(g), dim3(kGibbsBlock), 0, st, n_chains, C, prob->d_rowptr, prob->d_ids,
-                               inv_len, count_map, txp_count, seed, round);
+        // ---- plan: bands, wide classes, number of phases
+        uint32_t K = 1; unsigned int n_wide = 0;
+        if (n_tiles) {
+            hipLaunchKernelGGL(k_gibbs_plan, dim3((n_tiles + 255) / 256), dim3(256), 0, st, C, n_tiles, prob->d_rowptr, prob->d_ids,
+                               wide, tile_lo, tile_hi, wide_list, d_nwide);
             G_TRY(hipGetLastError());
+            std::vector<uint32_t> lo(n_tiles), hi(n_tiles);
+            G_TRY(hipMemcpyAsync(lo.data(), tile_lo, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, st));
+            G_TRY(hipMemcpyAsync(hi.data(), tile_hi, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, st));
+            G_TRY(hipMemcpyAsync(&n_wide, d_nwide, 4, hipMemcpyDeviceToHost, st));
+            G_TRY(hipStreamSynchronize(st));
+            K = gibbs_phase_count(lo, hi);
+            if (K > kMaxPhases) K = n_tiles;             // no locality to exploit: one tile per launch == a sequential scan
+        }
+        log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes", n_chains, n_tiles, K, n_wide);
+        GibbsArgs a{n_chains, C, prob->d_rowptr, prob->d_ids, prob->d_counts, inv_len, w_mass, count_map, txp_count,
+                    wide, wide_list, n_wide, seed, 0};
+        const unsigned groups = (n_chains + kGibbsBlock - 1) / kGibbsBlock;
+        auto sweep = [&](bool init) -> hipError_t {
+            for (uint32_t p = 0; p < K && p < n_tiles; ++p) {
+                dim3 g((n_tiles - p + K - 1) / K, groups);
+                if (init) hipLaunchKernelGGL(k_gibbs_phase<true>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+                else hipLaunchKernelGGL(k_gibbs_phase<false>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+            }
+            if (n_wide) {
+                if (init) hipLaunchKernelGGL(k_gibbs_wide<true>, dim3(groups), dim3(kGibbsBlock), 0, st, a);
+                else hipLaunchKernelGGL(k_gibbs_wide<false>, dim3(groups), dim3(kGibbsBlock), 0, st, a);
+            }
+            return hipGetLastError();
+        };
+        G_TRY(sweep(true));                                                           // initCountMap_
+        uint32_t done = 0;
+        while (done < n_samples) {
+            G_TRY(sweep(false));                                                      // one sampleRound_ per sample
             uint32_t n_emit = (n_samples - done < n_chains) ? (n_samples - done) : n_chains;
             int32_t* dst = d_out ? d_out + (uint64_t)done * M : d_tmp;
             uint64_t tot = (uint64_t)n_emit * M;
@@ -189,17 +300,16 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                 for (uint32_t s = 0; s < n_emit; ++s)
                     if (!cb(h_tmp + (uint64_t)s * M, M, user)) { set_error("gibbs writer callback failed"); rc = SFGPU_ERR_INVALID; goto done; }
             }
-            done += n_emit; ++round;
+            done += n_emit; ++a.round;
         }
         G_TRY(hipStreamSynchronize(st));
     }
 #undef G_TRY
 done:
-    if (count_map) pool_free(count_map);
-    if (txp_count) pool_free(txp_count);
-    if (inv_len) pool_free(inv_len);
-    if (w_mass) pool_free(w_mass);
-    if (d_tmp) pool_free(d_tmp);
+    (void)hipStreamSynchronize(st);
+    for (void* p : {(void*)count_map, (void*)txp_count, (void*)inv_len, (void*)w_mass, (void*)wide, (void*)wide_list,
+                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp})
+        if (p) pool_free(p);
     if (h_tmp) (void)hipHostFree(h_tmp);
     pool_trim();          // the chain state is large (4 * nnz * n_chains bytes): do not keep it cached
     return rc;
