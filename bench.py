@@ -168,9 +168,11 @@ def main():
             e = k.get("k_sweep_lds<true>" if use_vbem else "k_sweep_lds<false>")
             if e:
                 traffic_em = (2 * e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
-            e = k.get("k_insert")
-            if e:
-                traffic_ins = (e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
+            # class build = the three partition kernels of one sub-batch (k_insert on the generic path)
+            parts = [k[n] for n in ("k_part_hist", "k_part_scatter", "k_part_insert") if n in k] or \
+                    [k[n] for n in ("k_insert",) if n in k]
+            if parts:
+                traffic_ins = sum(e["fetch_kib_per_launch"] + e["write_kib_per_launch"] for e in parts) * 1024
     except (OSError, ValueError, KeyError):
         pass
     n_ins = max(int(info["insert_launches"]), 1)

@@ -8,7 +8,8 @@ dev = torch.device("cuda:0")
 M, P, R = 80_000, 1_000_000, 50_000_000
 poff, pids = synth.label_pool(M, P, device=dev)
 ids, off = synth.reads_from_pool(poff, pids, R, device=dev)
-eq = sf.EquivalenceClassBuilder(device=dev)
+expected = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+eq = sf.EquivalenceClassBuilder(device=dev, expected_classes=expected)
 for it in range(3):
     torch.cuda.synchronize(); t = time.perf_counter()
     eq.start(); eq.add_batch(ids, off)

@@ -1,0 +1,90 @@
+"""Turn the rocprofv3 CSV outputs of one `bench.py` profile session into the files committed under profiles/.
+
+usage: python tools/make_profiles.py <stats_dir> <fetch_dir> <write_dir> <workload> <round-tag>
+
+  stats_dir : output of  rocprofv3 --kernel-trace --stats --output-format csv -d <stats_dir> -- python bench.py ...
+  fetch_dir : output of  rocprofv3 --pmc FETCH_SIZE --output-format csv -d <fetch_dir> -- (same command)
+  write_dir : output of  rocprofv3 --pmc WRITE_SIZE --output-format csv -d <write_dir> -- (same command)
+
+Writes profiles/<tag>_kernel_stats.csv (verbatim kernel_stats), profiles/pmc_latest.json (per-kernel
+FETCH_SIZE / WRITE_SIZE KiB per launch, read by bench.py for roofline.traffic) and
+profiles/<tag>_pmc_summary.md.  FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section); on
+gfx950 FETCH_SIZE counts wide streaming reads at half their size -- bench.py applies the x2 to the sweep kernel
+only (its reads are wide and streaming); the raw figure is stored here.
+"""
+import csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[-1]
+
+
+def short(name):
+    """kernel name without namespaces / argument list, template arguments kept"""
+    name = re.sub(r"^void\s+", "", name)
+    name = re.sub(r"\s*\[clone.*$", "", name)
+    depth, out = 0, []
+    for ch in name:                       # strip the (args) part at template depth 0
+        if ch == "<": depth += 1
+        if ch == ">": depth -= 1
+        if ch == "(" and depth == 0: break
+        out.append(ch)
+    name = "".join(out)
+    head, lt, tail = name.partition("<")
+    return head.split("::")[-1] + lt + tail
+
+
+def counters(d, counter):
+    per = defaultdict(lambda: [0, 0.0])
+    with open(find(d, "counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            per[k][0] += 1
+            per[k][1] += float(row["Counter_Value"])
+    return per
+
+
+def main():
+    stats_dir, fetch_dir, write_dir, workload, tag = sys.argv[1:6]
+    prof = os.path.join(ROOT, "profiles")
+    ks = find(stats_dir, "kernel_stats.csv")
+    shutil.copy(ks, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+    stats = {}
+    with open(ks) as f:
+        for row in csv.DictReader(f):
+            stats[short(row["Name"])] = (int(row["Calls"]), float(row["AverageNs"]), float(row["Percentage"]))
+    fe, wr = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1])):
+        n = max(fe.get(k, [0, 0])[0], wr.get(k, [0, 0])[0], 1)
+        kernels[k] = {"launches": n,
+                      "fetch_kib_per_launch": fe.get(k, [0, 0.0])[1] / max(fe.get(k, [1, 0])[0], 1),
+                      "write_kib_per_launch": wr.get(k, [0, 0.0])[1] / max(wr.get(k, [1, 0])[0], 1)}
+    json.dump({"workload": workload, "source": f"profiles/{tag}_pmc_summary.md", "kernels": kernels},
+              open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
+    with open(os.path.join(prof, f"{tag}_pmc_summary.md"), "w") as f:
+        f.write(f"# {tag}: per-kernel time and HBM traffic, `bench.py --workload {workload}` on one MI355X\n\n"
+                "Three separate rocprofv3 runs of the same command (kernel trace + stats; `--pmc FETCH_SIZE`; "
+                "`--pmc WRITE_SIZE`).\nFETCH/WRITE are KiB per launch, raw counter values (gfx950 reports wide "
+                "streaming reads at half size: x2 for the sweep).\n"
+                "`at::native::*` / `compute_cuda_kernel` rows are torch ops of the synthetic input generator "
+                "(bench set-up, outside the timed region).\n\n"
+                "| kernel | calls | avg us | % time | FETCH KiB/launch | WRITE KiB/launch |\n|---|---:|---:|---:|---:|---:|\n")
+        for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            e = kernels.get(k)
+            k = k if len(k) <= 72 else k[:69] + "..."
+            f.write(f"| `{k}` | {calls} | {avg / 1e3:.2f} | {pct:.2f} | "
+                    + (f"{e['fetch_kib_per_launch']:.1f} | {e['write_kib_per_launch']:.1f} |\n" if e else "- | - |\n"))
+    print("wrote", tag, "with", len(stats), "kernels;", len(kernels), "with counters")
+
+
+if __name__ == "__main__":
+    main()
