@@ -25,6 +25,13 @@ void pool_free(void* p);
 void pool_trim();
 template <typename T>
 inline hipError_t pool_malloc(T** p, size_t bytes) { return pool_malloc(reinterpret_cast<void**>(p), bytes); }
+// same recycling for pinned host blocks and for the handles' private non-blocking streams
+hipError_t pinned_malloc(void** p, size_t bytes);
+void pinned_free(void* p);
+template <typename T>
+inline hipError_t pinned_malloc(T** p, size_t bytes) { return pinned_malloc(reinterpret_cast<void**>(p), bytes); }
+hipError_t stream_acquire(hipStream_t* s);
+void stream_release(hipStream_t s);
 
 // HIP call -> SFGPU_ERR_HIP with the failing expression recorded.
 #define SF_HIP(expr)                                                                         \

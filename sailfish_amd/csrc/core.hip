@@ -27,48 +27,80 @@ void log_msg(int level, const char* fmt, ...) {
 }
 
 
-// ---- caching device allocator (see common.h) ----
+// ---- caching allocators (see common.h) ----
+// Device blocks, pinned host blocks and non-blocking streams are all expensive to create and destroy
+// (hipFree / hipHostFree / hipStreamDestroy synchronise the device: 0.3-0.5 ms each, measured), and a
+// quantification step creates and drops dozens of them: all three are recycled per device.
 namespace {
 std::mutex g_pool_mu;
-std::unordered_map<size_t, std::vector<void*>> g_pool_free;    // rounded size -> free blocks
-std::unordered_map<void*, size_t> g_pool_size;                  // live or cached block -> rounded size
+struct Key { int dev; int kind; size_t sz; bool operator==(const Key& o) const { return dev == o.dev && kind == o.kind && sz == o.sz; } };
+struct KeyHash { size_t operator()(const Key& k) const { return std::hash<size_t>()(k.sz * 31u + (size_t)k.dev * 2u + (size_t)k.kind); } };
+std::unordered_map<Key, std::vector<void*>, KeyHash> g_pool_free;   // (device, kind, rounded size) -> free blocks
+std::unordered_map<void*, Key> g_pool_key;                           // live or cached block -> its key
+std::unordered_map<int, std::vector<hipStream_t>> g_streams;         // device -> idle non-blocking streams
+enum { kDeviceMem = 0, kPinnedMem = 1 };
 size_t round_up_pow2(size_t n) { size_t r = 256; while (r < n) r <<= 1; return r; }
-}  // namespace
+int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
-hipError_t pool_malloc(void** p, size_t bytes) {
-    const size_t sz = round_up_pow2(bytes ? bytes : 1);
+hipError_t pool_get(void** p, size_t bytes, int kind) {
+    const Key key{cur_device(), kind, round_up_pow2(bytes ? bytes : 1)};
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool_free.find(sz);
+        auto it = g_pool_free.find(key);
         if (it != g_pool_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); return hipSuccess; }
     }
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, sz);
+    auto alloc = [&] { return kind == kDeviceMem ? hipMalloc(&q, key.sz) : hipHostMalloc(&q, key.sz, hipHostMallocDefault); };
+    hipError_t e = alloc();
     if (e != hipSuccess) {              // out of memory: give the cache back and retry once
+        (void)hipGetLastError();
         pool_trim();
-        e = hipMalloc(&q, sz);
+        e = alloc();
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool_size[q] = sz;
+    g_pool_key[q] = key;
     *p = q;
     return hipSuccess;
 }
-
-void pool_free(void* p) {
+void pool_put(void* p, int kind) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_size.find(p);
-    if (it == g_pool_size.end()) { (void)hipFree(p); return; }
+    auto it = g_pool_key.find(p);
+    if (it == g_pool_key.end()) { if (kind == kDeviceMem) (void)hipFree(p); else (void)hipHostFree(p); return; }
     g_pool_free[it->second].push_back(p);
+}
+}  // namespace
+
+hipError_t pool_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kDeviceMem); }
+void pool_free(void* p) { pool_put(p, kDeviceMem); }
+hipError_t pinned_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kPinnedMem); }
+void pinned_free(void* p) { pool_put(p, kPinnedMem); }
+
+hipError_t stream_acquire(hipStream_t* s) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto& v = g_streams[cur_device()];
+        if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void stream_release(hipStream_t s) {          // the caller has synchronised it
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_streams[cur_device()].push_back(s);
 }
 
 void pool_trim() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto& kv : g_pool_free) {
-        for (void* q : kv.second) { g_pool_size.erase(q); (void)hipFree(q); }
+        for (void* q : kv.second) {
+            g_pool_key.erase(q);
+            if (kv.first.kind == kDeviceMem) (void)hipFree(q); else (void)hipHostFree(q);
+        }
         kv.second.clear();
     }
+    for (auto& kv : g_streams) { for (hipStream_t s : kv.second) (void)hipStreamDestroy(s); kv.second.clear(); }
 }
 
 }  // namespace sfgpu

@@ -569,12 +569,12 @@ static void em_free(sfgpu_em* em) {
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
                     em->blkmax};
     for (void* b : bufs) if (b) pool_free(b);
-    if (em->h_state) (void)hipHostFree(em->h_state);
-    if (em->h_blkmax) (void)hipHostFree(em->h_blkmax);
+    if (em->h_state) pinned_free(em->h_state);
+    if (em->h_blkmax) pinned_free(em->h_blkmax);
     if (em->ev_a) (void)hipEventDestroy(em->ev_a);
     if (em->ev_b) (void)hipEventDestroy(em->ev_b);
     if (em->ev_join) (void)hipEventDestroy(em->ev_join);
-    if (em->stream) (void)hipStreamDestroy(em->stream);
+    if (em->stream) stream_release(em->stream);    // synchronised above
     delete em;
 }
 
@@ -670,7 +670,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
 #define EM_TRY(expr)                                                                                 \
     do { hipError_t _e = (expr); if (_e != hipSuccess) {                                              \
         set_error("%s failed: %s", #expr, hipGetErrorString(_e)); em_free(em); return SFGPU_ERR_HIP; } } while (0)
-    EM_TRY(hipStreamCreateWithFlags(&em->stream, hipStreamNonBlocking));
+    EM_TRY(stream_acquire(&em->stream));
     em->cur = em->stream;
     EM_TRY(hipEventCreate(&em->ev_a)); EM_TRY(hipEventCreate(&em->ev_b));
     EM_TRY(hipEventCreateWithFlags(&em->ev_join, hipEventDisableTiming));
@@ -680,9 +680,10 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     EM_TRY(pool_malloc(&em->counts32, (C ? C : 1) * 4));
     EM_TRY(pool_malloc(&em->d_state, sizeof(EmState)));
     EM_TRY(pool_malloc(&em->blkmax, 2 * kMaxPartials * 8));
-    EM_TRY(hipHostMalloc(&em->h_blkmax, 2 * kMaxPartials * 8, hipHostMallocDefault));
+    EM_TRY(pinned_malloc(&em->h_blkmax, 2 * kMaxPartials * 8));
     EM_TRY(pool_malloc(&em->tile_lo, 4));   // sized once nnz is known (below)
-    EM_TRY(hipHostMalloc(&em->h_state, sizeof(EmState), hipHostMallocDefault));
+    EM_TRY(pinned_malloc(&em->h_state, sizeof(EmState)));
+    memset(em->h_state, 0, sizeof(EmState));
     EM_TRY(hipMemsetAsync(em->d_state, 0, sizeof(EmState), em->cur));
     int rc = em_join_user(em);
     if (rc) { em_free(em); return rc; }
@@ -1002,7 +1003,7 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     o.check_mode = 1;          // and gates on alphas > 1e-2 (:499)
     double* d_tmp = nullptr; double* h_tmp = nullptr;
     if (!d_out) SF_HIP(pool_malloc(&d_tmp, M * 8));
-    if (cb) SF_HIP(hipHostMalloc(&h_tmp, M * 8, hipHostMallocDefault));
+    if (cb) SF_HIP(pinned_malloc(&h_tmp, M * 8));
     const uint64_t keep_mapped = em->prob.num_mapped;
     em->prob.num_mapped = em->bs_total;                 // alpha init uses totalNumFrags = sum of counts (:470-474, :696)
     rc = SFGPU_OK;
@@ -1026,7 +1027,7 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     (void)hipMemcpyAsync(em->counts32, em->bs_base, C * 4, hipMemcpyDeviceToDevice, em->stream);   // observed counts back
     (void)hipStreamSynchronize(em->stream);
     if (d_tmp) pool_free(d_tmp);
-    if (h_tmp) (void)hipHostFree(h_tmp);
+    if (h_tmp) pinned_free(h_tmp);
     return rc;
 }
 

@@ -36,8 +36,38 @@ constexpr uint64_t kSlack = 1ull << 20;      // >= lanes in flight that can pass
 constexpr uint64_t kMinHeadroom = 1ull << 16;
 constexpr int kBlock = 256;
 
-// ctr[0] = classes created by this launch, ctr[1] = deferred reads, ctr[2] = arena cursor (ids)
-enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_N = 4 };
+// ctr[0] = classes created by this launch, ctr[1] = deferred reads, ctr[2] = arena cursor (words),
+// ctr[3] = scratch (long-label count / read total), ctr[4] = nnz read back at finish
+enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_TMP = 3, CTR_NNZ = 4, CTR_N = 8 };
+
+// ---- label arena ------------------------------------------------------------------------------
+// A committed class keeps its label in the arena as one ENTRY: [len, id0, id1, ...], zero-padded to a
+// multiple of 4 words and 16-byte aligned.  A table slot of a committed class holds kArenaBit | entry/4,
+// so deciding "is this read's label the slot's label" is ONE 16-byte load for labels of <= 3 ids and two
+// for <= 7 -- no class-id indirection, no per-word loads (they bound the insert kernels: a wavefront's 64
+// lanes hit 64 different cache lines per load instruction).  cls_off[c] = entry + 1 (the first id).
+__host__ __device__ __forceinline__ uint32_t entry_words(uint32_t len) { return (len + 4u) & ~3u; }
+
+// label (n words; first 8 in hw[], zero past n; word(k) for the rest) == arena entry e?
+template <typename WordFn>
+__device__ __forceinline__ bool entry_equals(const uint32_t* __restrict__ arena, uint32_t e, WordFn word,
+                                             const uint32_t (&hw)[kHead], uint32_t n) {
+    const uint32_t* p = arena + ((uint64_t)e << 2);
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    if (a.x != n || a.y != hw[0] || a.z != hw[1] || a.w != hw[2]) return false;
+    if (n <= 3) return true;
+    const uint4 b = *reinterpret_cast<const uint4*>(p + 4);
+    if (b.x != hw[3] || b.y != hw[4] || b.z != hw[5] || b.w != hw[6]) return false;
+    for (uint32_t k = 7; k < n; ++k) if (p[1 + k] != word(k)) return false;
+    return true;
+}
+// write entry [len, words..., 0 pad] at arena word offset dst (a multiple of 4)
+template <typename WordFn>
+__device__ __forceinline__ void entry_write(uint32_t* arena, uint64_t dst, WordFn word, uint32_t len) {
+    arena[dst] = len;
+    for (uint32_t k = 0; k < len; ++k) arena[dst + 1 + k] = word(k);
+    for (uint32_t k = len + 1; k < entry_words(len); ++k) arena[dst + k] = 0u;
+}
 
 __global__ void k_table_init(uint64_t* table, uint64_t cap) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,10 +136,10 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
         }
         if ((w >> 32) == tag) {
             uint32_t rep = (uint32_t)w;
-            const uint32_t* p; uint32_t l;
-            if (rep & kArenaBit) { uint32_t c = rep & ~kArenaBit; p = arena + cls_off[c]; l = cls_len[c]; }
-            else { uint32_t rb = off[rep]; p = ids + rb; l = off[rep + 1] - rb; }
-            if (l == len && labels_equal(p, lab, len)) {
+            bool same;
+            if (rep & kArenaBit) same = entry_equals(arena, rep & ~kArenaBit, [&](uint32_t k) { return lab[k]; }, hw, len);
+            else { uint32_t rb = off[rep]; same = (off[rep + 1] - rb == len) && labels_equal(ids + rb, lab, len); }
+            if (same) {
                 atomicAdd((unsigned long long*)&table[2 * s + 1], inc);
                 return;
             }
@@ -135,12 +165,12 @@ __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __res
     uint32_t r = (uint32_t)w;
     uint32_t b = off[r], len = off[r + 1] - b;
     const uint32_t* lab = ids + b;
-    unsigned long long dst = atomicAdd(&ctr[CTR_ARENA], (unsigned long long)len);
-    for (uint32_t k = 0; k < len; ++k) arena[dst + k] = lab[k];
+    unsigned long long dst = atomicAdd(&ctr[CTR_ARENA], (unsigned long long)entry_words(len));
+    entry_write(arena, dst, [&](uint32_t k) { return lab[k]; }, len);
     uint64_t cid = base_cid + i;
     cls_hash[cid] = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
-    cls_off[cid] = dst; cls_len[cid] = len; cls_slot[cid] = s;
-    table[2 * (uint64_t)s] = (w & 0xFFFFFFFF00000000ull) | (uint64_t)(kArenaBit | (uint32_t)cid);
+    cls_off[cid] = dst + 1; cls_len[cid] = len; cls_slot[cid] = s;
+    table[2 * (uint64_t)s] = (w & 0xFFFFFFFF00000000ull) | (uint64_t)(kArenaBit | (uint32_t)(dst >> 2));
 }
 
 // re-insert every class into a larger table, carrying its count
@@ -152,7 +182,7 @@ __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table
     const uint32_t* lab = arena + cls_off[c];
     uint32_t hw[kHead];
     uint64_t h = label_mix64([&](uint32_t k) { return lab[k]; }, cls_len[c], hw);
-    uint64_t mine = ((h >> 32) << 32) | (uint64_t)(kArenaBit | (uint32_t)c);
+    uint64_t mine = ((h >> 32) << 32) | (uint64_t)(kArenaBit | (uint32_t)((cls_off[c] - 1) >> 2));
     uint64_t cnt = old_table[2 * (uint64_t)cls_slot[c] + 1];
     uint64_t s = h & mask;
     for (;;) {
@@ -333,7 +363,7 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) { eq->sub_batch = (uint32_t)v; eq->part_sub_batch = (uint32_t)v; } }
     if (const char* e = getenv("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
     hipError_t e1 = pool_malloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
-    hipError_t e2 = hipHostMalloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long), hipHostMallocDefault);
+    hipError_t e2 = pinned_malloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long));
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev1);
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -350,7 +380,7 @@ int sfgpu_eq_destroy(sfgpu_eq* eq) {
     if (!eq) return SFGPU_OK;
     (void)hipStreamSynchronize(eq->stream);
     if (eq->d_ctr) pool_free(eq->d_ctr);
-    if (eq->h_ctr) (void)hipHostFree(eq->h_ctr);
+    if (eq->h_ctr) pinned_free(eq->h_ctr);
     if (eq->ev0) (void)hipEventDestroy(eq->ev0);
     if (eq->ev1) (void)hipEventDestroy(eq->ev1);
     delete eq;
@@ -507,7 +537,10 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     SF_REQUIRE(ends[1] >= ends[0], SFGPU_ERR_INVALID, "sfgpu_eq_add_batch: offsets not ascending");
     uint64_t batch_ids = (uint64_t)ends[1] - ends[0];
     int rc;
-    if ((rc = eq->arena.reserve(eq->arena_used + batch_ids + 1, st, true, eq->arena_used))) return rc;
+    // worst case every read opens a class: its ids + the entry header and padding (<= 4 words)
+    const uint64_t arena_need = eq->arena_used + batch_ids + 4 * (uint64_t)n_reads + 4;
+    SF_REQUIRE((arena_need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
+    if ((rc = eq->arena.reserve(arena_need, st, true, eq->arena_used))) return rc;
 
     // big unweighted batches take the radix-partitioned path, everything else the generic one
     const bool part = eq->use_part && !d_weights && n_reads >= (1u << 16);
@@ -584,7 +617,7 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
     int rc;
     if ((rc = eq->order.reserve(n + 1, st, false))) return rc;
     if ((rc = eq->rowptr64.reserve(n + 2, st, false))) return rc;
-    eq->nnz = eq->arena_used; eq->total_reads = 0;
+    eq->nnz = 0; eq->total_reads = 0;
     if (n) {
         DevBuf<uint64_t> keys_in, keys_out; DevBuf<uint32_t> vals_in, lens;
         if ((rc = keys_in.reserve(n, st, false)) || (rc = keys_out.reserve(n, st, false)) ||
@@ -604,8 +637,10 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
                            eq->d_ctr + 3);
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_NNZ, eq->rowptr64.p + n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));
         eq->total_reads = eq->h_ctr[3];
+        eq->nnz = eq->h_ctr[CTR_NNZ];
     }
     eq->finished = true;
     if (n_classes) *n_classes = n;

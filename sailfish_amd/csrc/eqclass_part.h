@@ -22,7 +22,7 @@ constexpr int kRegionBits = 12;
 constexpr uint32_t kRegionSlots = 1u << kRegionBits;          // 4096 slots: 32 KB words + 16 KB counts in LDS
 constexpr uint32_t kRegionLimit = kRegionSlots / 4 * 3;       // inserts beyond this occupancy are deferred
 constexpr int kPartBlock = 1024;
-constexpr int kTileWords = 8192;                              // 32 KB LDS tile of the label stream
+constexpr int kTileWords = 4096;                              // 16 KB LDS tile of the label stream
 constexpr int kMaxRegions = 4096;                             // LDS histogram size of passes 1a/1b
 constexpr uint32_t kHeadBit = 0x80000000u;
 constexpr uint32_t kMaxPartLabel = kTileWords / 2;            // longer labels take the generic path
@@ -190,13 +190,13 @@ __device__ __forceinline__ bool stream_label_equals(const uint32_t* a /*label, h
 }
 
 // ---- pass 2: one block per region
-__global__ void __launch_bounds__(kPartBlock)
+__global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_insert(PartArgs a) {
     __shared__ unsigned long long lw[kRegionSlots];     // slot words
     __shared__ unsigned int lc[kRegionSlots];           // count deltas of this launch
     __shared__ uint32_t tile[kTileWords + 4];
     __shared__ uint16_t heads[kTileWords];
-    __shared__ uint16_t new_slots[kRegionSlots];
+    __shared__ uint16_t new_slots[kRegionLimit];
     __shared__ unsigned int s_scan[kPartBlock / kWave];
     __shared__ unsigned int s_nheads, s_occ, s_nnew, s_newwords, s_cid0, s_next;
     __shared__ unsigned long long s_arena0;
@@ -252,12 +252,23 @@ k_part_insert(PartArgs a) {
             const uint64_t h = label_mix64([&](uint32_t k) { return k ? lab[k] : w0; }, len, hw8);
             const uint64_t tag = h >> 32;
             uint32_t s = (uint32_t)h & (kRegionSlots - 1);
-            for (uint32_t probes = 0; ; ++probes) {
+            // Probe in two stages so that a wavefront pays the global round trip of the label compare ONCE:
+            // (1) walk the LDS slots until an empty slot or a tag match (LDS only: lanes that need a few
+            // more steps cost nothing), (2) claim or compare.  With the compare inside the walk, every
+            // extra step of any lane repeated the global load for the whole wavefront.
+            uint32_t probes = 0;
+            for (;;) {
                 unsigned long long w = lw[s];
+                while (w != kEmpty && (w >> 32) != tag && probes < kRegionSlots) {
+                    s = (s + 1) & (kRegionSlots - 1); ++probes; w = lw[s];
+                }
+                if (probes >= kRegionSlots) {                                             // cannot place: defer
+                    a.deferred[atomicAdd(&a.ctr[CTR_DEFER], 1ull)] = (uint32_t)(seg0 + pos + st);
+                    break;
+                }
                 if (w == kEmpty) {
-                    bool full = probes >= kRegionSlots;
-                    if (!full && atomicAdd(&s_occ, 1u) >= kRegionLimit) { atomicSub(&s_occ, 1u); full = true; }
-                    if (full) {                                                               // region full: defer
+                    if (atomicAdd(&s_occ, 1u) >= kRegionLimit) {                              // region full: defer
+                        atomicSub(&s_occ, 1u);
                         a.deferred[atomicAdd(&a.ctr[CTR_DEFER], 1ull)] = (uint32_t)(seg0 + pos + st);
                         break;
                     }
@@ -266,30 +277,23 @@ k_part_insert(PartArgs a) {
                     if (old == kEmpty) { new_slots[atomicAdd(&s_nnew, 1u)] = (uint16_t)s; atomicAdd(&lc[s], 1u); break; }
                     atomicSub(&s_occ, 1u);
                     w = old;
+                    if ((w >> 32) != tag) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
                 }
-                if ((w >> 32) == tag) {
-                    const uint32_t rep = (uint32_t)w;
-                    bool same;
-                    if (rep & kArenaBit) {
-                        const uint32_t c = rep & ~kArenaBit;
-                        const uint32_t* p = a.arena + a.cls_off[c];
-                        same = (a.cls_len[c] == len) && p[0] == w0;
-                        for (uint32_t k = 1; same && k < len; ++k) same = (p[k] == lab[k]);
-                    } else {
-                        // a label of this launch: `rep` words into the partition buffer; equal iff the first
-                        // `len` words match and the representative ends there (next word is a head or the end)
-                        const uint32_t* p = a.words + rep;
-                        const uint64_t rep_end = (uint64_t)rep + len;
-                        same = stream_label_equals(lab, w0, p, len) &&
-                               (rep_end >= seg0 + n_words || (a.words[rep_end] & kHeadBit));
-                    }
-                    if (same) { atomicAdd(&lc[s], 1u); break; }
+                // tag match: full label compare
+                const uint32_t rep = (uint32_t)w;
+                bool same;
+                if (rep & kArenaBit) {
+                    same = entry_equals(a.arena, rep & ~kArenaBit, [&](uint32_t k) { return lab[k]; }, hw8, len);
+                } else {
+                    // a label of this launch: `rep` words into the partition buffer; equal iff the first
+                    // `len` words match and the representative ends there (next word is a head or the end)
+                    const uint32_t* p = a.words + rep;
+                    const uint64_t rep_end = (uint64_t)rep + len;
+                    same = stream_label_equals(lab, w0, p, len) &&
+                           (rep_end >= seg0 + n_words || (a.words[rep_end] & kHeadBit));
                 }
-                if (probes >= kRegionSlots) {                                             // cannot place: defer
-                    a.deferred[atomicAdd(&a.ctr[CTR_DEFER], 1ull)] = (uint32_t)(seg0 + pos + st);
-                    break;
-                }
-                s = (s + 1) & (kRegionSlots - 1);
+                if (same) { atomicAdd(&lc[s], 1u); break; }
+                s = (s + 1) & (kRegionSlots - 1); ++probes;
             }
         }
         __syncthreads();
@@ -308,7 +312,7 @@ k_part_insert(PartArgs a) {
             uint32_t len = 1;
             while ((uint64_t)rep + len < seg0 + n_words && !(a.words[rep + len] & kHeadBit)) ++len;
             heads[i] = (uint16_t)len;                         // heads[] is free now; len <= kMaxPartLabel < 65536
-            atomicAdd(&s_newwords, len);
+            atomicAdd(&s_newwords, entry_words(len));
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -322,14 +326,13 @@ k_part_insert(PartArgs a) {
             const unsigned long long w = lw[s];
             const uint32_t rep = (uint32_t)w, len = heads[i];
             const uint64_t cid = a.base_classes + s_cid0 + i;
-            const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, len);
+            const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
             const uint32_t* p = a.words + rep;
             const uint32_t w0 = p[0] & ~kHeadBit;
-            a.arena[dst] = w0;
-            for (uint32_t k = 1; k < len; ++k) a.arena[dst + k] = p[k];
+            entry_write(a.arena, dst, [&](uint32_t k) { return k ? p[k] : w0; }, len);
             a.cls_hash[cid] = xxh64_words([&](uint32_t k) { return k ? p[k] : w0; }, len);
-            a.cls_off[cid] = dst; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
-            lw[s] = (w & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)cid);
+            a.cls_off[cid] = dst + 1; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
+            lw[s] = (w & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)(dst >> 2));
         }
     }
     __syncthreads();

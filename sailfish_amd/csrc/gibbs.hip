@@ -248,7 +248,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     G_TRY(pool_malloc(&wide, C ? C : 1)); G_TRY(pool_malloc(&wide_list, (C ? C : 1) * 4)); G_TRY(pool_malloc(&d_nwide, 4));
     G_TRY(pool_malloc(&tile_lo, (size_t)(n_tiles ? n_tiles : 1) * 4)); G_TRY(pool_malloc(&tile_hi, (size_t)(n_tiles ? n_tiles : 1) * 4));
     if (!d_out) G_TRY(pool_malloc(&d_tmp, (uint64_t)n_chains * M * 4));
-    if (cb) G_TRY(hipHostMalloc(&h_tmp, (uint64_t)n_chains * M * 4, hipHostMallocDefault));
+    if (cb) G_TRY(pinned_malloc(&h_tmp, (uint64_t)n_chains * M * 4));
     G_TRY(hipMemsetAsync(txp_count, 0, (uint64_t)M * n_chains * 4, st));
     G_TRY(hipMemsetAsync(d_nwide, 0, 4, st));
     hipLaunchKernelGGL(k_gibbs_weights, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, prob->d_len, d_mass,
@@ -310,7 +310,7 @@ done:
     for (void* p : {(void*)count_map, (void*)txp_count, (void*)inv_len, (void*)w_mass, (void*)wide, (void*)wide_list,
                     (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp})
         if (p) pool_free(p);
-    if (h_tmp) (void)hipHostFree(h_tmp);
+    if (h_tmp) pinned_free(h_tmp);
     pool_trim();          // the chain state is large (4 * nnz * n_chains bytes): do not keep it cached
     return rc;
 }

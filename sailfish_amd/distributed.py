@@ -162,6 +162,8 @@ class DistributedQuant:
         txps = exp.transcripts()
         length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
         mode = self._pick_mode(vec.nnz)
+        if self.problem is not None:       # release the previous run's device state before building the next
+            self.problem.close(); self.problem = None
         kw = dict(use_vbem=sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)
         if mode in ("single", "replicated"):
             p = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
