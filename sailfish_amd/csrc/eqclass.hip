@@ -477,7 +477,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
                        n_regions, reg_of, eq->part_hist.p, eq->d_ctr + 3, eq->part_long.p);
     SF_CHECK_LAUNCH();
     if ((rc = exclusive_scan_u32(eq->part_hist.p, eq->part_off.p, mat_n, st))) return rc;
-    const size_t scatter_lds = (size_t)kSortWords * 4 + ((size_t)3 * n_regions + 1) * 4;
+    const size_t scatter_lds = (size_t)(kSortWords + 4) * 4 + ((size_t)3 * n_regions + 1) * 4 + ((size_t)kSortWords / 16 + 2) * 2;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
         SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
