@@ -53,11 +53,14 @@ template <typename WordFn>
 __device__ __forceinline__ bool entry_equals(const uint32_t* __restrict__ arena, uint32_t e, WordFn word,
                                              const uint32_t (&hw)[kHead], uint32_t n) {
     const uint32_t* p = arena + ((uint64_t)e << 2);
-    const uint4 a = *reinterpret_cast<const uint4*>(p);
-    if (a.x != n || a.y != hw[0] || a.z != hw[1] || a.w != hw[2]) return false;
-    if (n <= 3) return true;
-    const uint4 b = *reinterpret_cast<const uint4*>(p + 4);
-    if (b.x != hw[3] || b.y != hw[4] || b.z != hw[5] || b.w != hw[6]) return false;
+    // both 16-byte words are requested together and compared without short-circuits: one round trip
+    // (a 4-word entry is followed by the next entry or by the arena's slack, so p[4..7] is readable)
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
+    const uint4 b = reinterpret_cast<const uint4*>(p)[1];
+    uint32_t d = (a.x ^ n) | (a.y ^ hw[0]) | (a.z ^ hw[1]) | (a.w ^ hw[2]);
+    const uint32_t d2 = (b.x ^ hw[3]) | (b.y ^ hw[4]) | (b.z ^ hw[5]) | (b.w ^ hw[6]);
+    d |= (n > 3u) ? d2 : 0u;
+    if (d) return false;
     for (uint32_t k = 7; k < n; ++k) if (p[1 + k] != word(k)) return false;
     return true;
 }

@@ -7,7 +7,8 @@
 //   1b k_part_scatter : copy every label into its region's segment of a partition buffer -- first word
 //                       flagged with bit 31, so a segment is a self-delimiting stream of labels
 //   2  k_part_insert  : ONE block per region: the region's slots live in LDS (word u64 + count delta
-//                       u32), the segment is streamed through LDS tiles with coalesced loads, labels
+//                       u32); every wavefront streams its own share of the segment through a private
+//                       LDS tile with coalesced loads (no block barriers while streaming); labels
 //                       are hashed, probed and counted with LDS atomics only; new classes get their
 //                       class ids / arena space with one global atomic per block and are committed
 //                       by the same block; finally the region is written back.
@@ -22,10 +23,12 @@ constexpr int kRegionBits = 12;
 constexpr uint32_t kRegionSlots = 1u << kRegionBits;          // 4096 slots: 32 KB words + 16 KB counts in LDS
 constexpr uint32_t kRegionLimit = kRegionSlots / 4 * 3;       // inserts beyond this occupancy are deferred
 constexpr int kPartBlock = 1024;
-constexpr int kTileWords = 4096;                              // 16 KB LDS tile of the label stream
+constexpr int kWaveTile = 256;                                // words of the label stream a wavefront handles at a time
+constexpr int kPartWaves = kPartBlock / 64;
 constexpr int kMaxRegions = 4096;                             // LDS histogram size of passes 1a/1b
 constexpr uint32_t kHeadBit = 0x80000000u;
-constexpr uint32_t kMaxPartLabel = kTileWords / 2;            // longer labels take the generic path
+constexpr uint32_t kMaxPartLabel = kWaveTile / 2;             // longer labels take the generic path
+constexpr int kWaveHeads = 68;                                // label starts a wavefront records per tile (it takes <= 64 labels per round)
 
 __device__ __forceinline__ uint64_t region_next(uint64_t s) {
     return (s & ~(uint64_t)(kRegionSlots - 1)) | ((s + 1) & (kRegionSlots - 1));
@@ -247,15 +250,19 @@ __device__ __forceinline__ bool stream_label_equals(const uint32_t* a /*label, h
 }
 
 // ---- pass 2: one block per region
+// The 16 wavefronts of the block split the region's segment into equal word ranges; a label belongs to
+// the wavefront whose range holds its first word.  Each wavefront works alone: 256 words -> registers
+// (four coalesced loads) -> its private LDS tile; label starts are found with wave ballots (no scan,
+// no barrier); lane j takes the tile's j-th label.  The only block-wide synchronisation is before and
+// after the streaming loop, so the 32 wavefronts resident on a CU hide each other's memory latency.
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_insert(PartArgs a) {
     __shared__ unsigned long long lw[kRegionSlots];     // slot words
     __shared__ unsigned int lc[kRegionSlots];           // count deltas of this launch
-    __shared__ uint32_t tile[kTileWords + 4];
-    __shared__ uint16_t heads[kTileWords];
-    __shared__ uint16_t new_slots[kRegionLimit];
-    __shared__ unsigned int s_scan[kPartBlock / kWave];
-    __shared__ unsigned int s_nheads, s_occ, s_nnew, s_newwords, s_cid0, s_next;
+    __shared__ uint32_t wtile[kPartWaves][kWaveTile + 4];
+    __shared__ uint16_t heads[kPartWaves][kWaveHeads];  // per-wave lists of the first label starts of the tile
+    __shared__ uint32_t new_info[kRegionLimit];         // classes created by this block: slot | len << 16
+    __shared__ unsigned int s_occ, s_nnew, s_newwords, s_cid0;
     __shared__ unsigned long long s_arena0;
     const uint32_t region = blockIdx.x;
     const uint64_t rb = (uint64_t)region * kRegionSlots;
@@ -274,34 +281,44 @@ k_part_insert(PartArgs a) {
     if (occ_local) atomicAdd(&s_occ, occ_local);
     __syncthreads();
 
-    uint32_t pos = 0;
-    while (pos < n_words) {
-        const uint32_t tlen = (n_words - pos < (uint32_t)kTileWords) ? (n_words - pos) : (uint32_t)kTileWords;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* tile = wtile[wave];
+    uint16_t* wh = heads[wave];
+    const uint32_t w_beg = (uint32_t)((uint64_t)n_words * wave / kPartWaves);
+    const uint32_t w_end = (uint32_t)((uint64_t)n_words * (wave + 1) / kPartWaves);
+    uint32_t pos = w_beg;
+    while (pos < w_end) {
+        const uint32_t tlen = (n_words - pos < (uint32_t)kWaveTile) ? (n_words - pos) : (uint32_t)kWaveTile;
         const bool final_tile = (pos + tlen == n_words);
-        for (uint32_t i = threadIdx.x; i < tlen; i += kPartBlock) tile[i] = seg[pos + i];
-        __syncthreads();
-        // ---- head positions, in order (block exclusive scan of per-thread head counts)
-        constexpr int kPer = kTileWords / kPartBlock;   // 8 consecutive words per thread
-        unsigned int mine = 0;
+        // word i of the tile = q * 64 + lane: each of the four loads is one coalesced 256-byte access
+        uint32_t tw[4];
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) { uint32_t i = threadIdx.x * kPer + q; if (i < tlen && (tile[i] & kHeadBit)) ++mine; }
-        unsigned int incl = mine;
-        for (int o = 1; o < kWave; o <<= 1) { unsigned int v = __shfl_up(incl, o, kWave); if ((int)(threadIdx.x & (kWave - 1)) >= o) incl += v; }
-        if ((threadIdx.x & (kWave - 1)) == kWave - 1) s_scan[threadIdx.x / kWave] = incl;
-        __syncthreads();
-        unsigned int wave_base = 0;
-        for (int w = 0; w < (int)(threadIdx.x / kWave); ++w) wave_base += s_scan[w];
-        unsigned int at = wave_base + incl - mine;
+        for (int q = 0; q < 4; ++q) { const uint32_t i = q * 64 + lane; tw[q] = (i < tlen) ? seg[pos + i] : 0u; }
+        uint32_t nh = 0, in_range = 0;
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) { uint32_t i = threadIdx.x * kPer + q; if (i < tlen && (tile[i] & kHeadBit)) heads[at++] = (uint16_t)i; }
-        if (threadIdx.x == kPartBlock - 1) s_nheads = wave_base + incl;
-        __syncthreads();
-        const uint32_t nh = s_nheads;
-        // the tile's last label may continue in the next tile: leave it for the next round
-        const uint32_t n_proc = final_tile ? nh : (nh > 0 ? nh - 1 : 0);
-        for (uint32_t l = threadIdx.x; l < n_proc; l += kPartBlock) {
-            const uint32_t st = heads[l];
-            const uint32_t en = (l + 1 < nh) ? heads[l + 1] : tlen;
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = q * 64 + lane;
+            tile[i] = tw[q];
+            const bool is_head = (i < tlen) && (tw[q] & kHeadBit);
+            const unsigned long long bal = __ballot(is_head);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (is_head && nh + before < (uint32_t)kWaveHeads) wh[nh + before] = (uint16_t)i;
+            nh += (uint32_t)__popcll(bal);
+            // label starts that belong to this wavefront (first word before w_end)
+            in_range += (uint32_t)__popcll(__ballot(is_head && pos + i < w_end));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the tile's last label may continue past the tile: leave it for the next round
+        const uint32_t n_whole = final_tile ? nh : (nh > 0 ? nh - 1 : 0);
+        // at most one label per lane per round: a second, mostly idle pass over the tile would cost as much
+        // as a full one -- the labels past the 64th are simply picked up by the next (overlapping) tile
+        uint32_t n_proc = n_whole < in_range ? n_whole : in_range;
+        if (n_proc > 64u) n_proc = 64u;
+        for (uint32_t l = lane; l < n_proc; l += 64) {
+            const uint32_t st = wh[l];
+            const uint32_t en = (l + 1 < nh) ? wh[l + 1] : tlen;
             const uint32_t len = en - st;
             const uint32_t* lab = tile + st;
             const uint32_t w0 = lab[0] & ~kHeadBit;
@@ -331,7 +348,7 @@ k_part_insert(PartArgs a) {
                     }
                     unsigned long long me = (tag << 32) | (unsigned long long)(uint32_t)(seg0 + pos + st);
                     unsigned long long old = atomicCAS(&lw[s], (unsigned long long)kEmpty, me);
-                    if (old == kEmpty) { new_slots[atomicAdd(&s_nnew, 1u)] = (uint16_t)s; atomicAdd(&lc[s], 1u); break; }
+                    if (old == kEmpty) { new_info[atomicAdd(&s_nnew, 1u)] = s | (len << 16); atomicAdd(&lc[s], 1u); break; }
                     atomicSub(&s_occ, 1u);
                     w = old;
                     if ((w >> 32) != tag) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
@@ -343,7 +360,8 @@ k_part_insert(PartArgs a) {
                     same = entry_equals(a.arena, rep & ~kArenaBit, [&](uint32_t k) { return lab[k]; }, hw8, len);
                 } else {
                     // a label of this launch: `rep` words into the partition buffer; equal iff the first
-                    // `len` words match and the representative ends there (next word is a head or the end)
+                    // `len` words match and the representative ends there (next word is a head or the end).
+                    // Its first 4 words and the word behind it are requested together: one round trip for most labels.
                     const uint32_t* p = a.words + rep;
                     const uint64_t rep_end = (uint64_t)rep + len;
                     same = stream_label_equals(lab, w0, p, len) &&
@@ -353,24 +371,20 @@ k_part_insert(PartArgs a) {
                 s = (s + 1) & (kRegionSlots - 1); ++probes;
             }
         }
-        __syncthreads();
-        // labels are <= kMaxPartLabel = half a tile, so a non-final tile always holds >= 2 heads and advances
-        if (threadIdx.x == 0) s_next = final_tile ? tlen : ((nh > 1) ? heads[nh - 1] : tlen);
-        __syncthreads();
-        pos += s_next;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                      // all lanes are done with the tile before it is refilled
+        // next tile starts at the first label that was not processed; stop once that label is another wavefront's.
+        // Labels are <= kMaxPartLabel = half a tile, so a full tile always holds >= 2 label starts and advances.
+        if (n_proc < in_range) { const uint32_t adv = wh[n_proc]; pos += adv ? adv : tlen; }
+        else if (n_proc < nh || final_tile) break;            // the next label start lies at or beyond w_end (or the segment ended)
+        else pos += tlen;                                     // no label start left in this tile (cannot happen for full tiles)
     }
+    __syncthreads();
 
     // ---- commit the classes this block created: ids, arena space, labels, slot re-pointing
     const uint32_t n_new = s_nnew;
     if (n_new) {
-        // label lengths: scan to the next head inside the segment
-        for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) {
-            const uint32_t rep = (uint32_t)lw[new_slots[i]];
-            uint32_t len = 1;
-            while ((uint64_t)rep + len < seg0 + n_words && !(a.words[rep + len] & kHeadBit)) ++len;
-            heads[i] = (uint16_t)len;                         // heads[] is free now; len <= kMaxPartLabel < 65536
-            atomicAdd(&s_newwords, entry_words(len));
-        }
+        for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, entry_words(new_info[i] >> 16));
         __syncthreads();
         if (threadIdx.x == 0) {
             s_cid0 = (unsigned int)atomicAdd(&a.ctr[CTR_NEW], (unsigned long long)n_new);
@@ -379,9 +393,9 @@ k_part_insert(PartArgs a) {
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) {
-            const uint32_t s = new_slots[i];
+            const uint32_t s = new_info[i] & 0xFFFFu, len = new_info[i] >> 16;
             const unsigned long long w = lw[s];
-            const uint32_t rep = (uint32_t)w, len = heads[i];
+            const uint32_t rep = (uint32_t)w;
             const uint64_t cid = a.base_classes + s_cid0 + i;
             const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
             const uint32_t* p = a.words + rep;

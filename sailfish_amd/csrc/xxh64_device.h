@@ -98,7 +98,7 @@ __device__ __forceinline__ uint64_t xxh64_head(const uint32_t (&w)[kHead], uint3
 
 // ---- bucket hash -----------------------------------------------------------------------------
 // Where a label goes in the device table (region, slot, tag) is decided by a 64-bit mix built from
-// two 32-bit xxHash-style lanes (acc = rotl(acc + w * P2, 13) * P1, the XXH32 round), NOT by XXH64:
+// two 32-bit lanes (a: multiply-rotate chain, one multiply per id; b: add-rotate chain fed by a), NOT by XXH64:
 // a 64-bit integer multiply costs ~8 VALU multiplies on CDNA4 and hashing every read with XXH64
 // measured ~0.5 ms per 16.7 M labels per pass.  Class identity never depends on this value (it is
 // decided by a full label compare); XXH64 -- TranscriptGroup::hash -- is computed once per CLASS
@@ -108,14 +108,19 @@ __device__ __forceinline__ uint32_t mix_rotl(uint32_t x, int r) { return (x << r
 __device__ __forceinline__ uint32_t mix_fin(uint32_t h) {
     h ^= h >> 15; h *= MP2; h ^= h >> 13; h *= MP3; h ^= h >> 16; return h;
 }
+// one id into the two lanes: a single 32-bit multiply (quarter rate on CDNA4), the rest shifts and adds
+__device__ __forceinline__ void mix_round(uint32_t& a, uint32_t& b, uint32_t w) {
+    a = mix_rotl((a ^ w) * MP1, 13);
+    b = mix_rotl(b, 11) + (w ^ a);
+    b += b << 2;
+}
 template <typename WordFn>
 __device__ __forceinline__ uint64_t label_mix64_words(WordFn word, uint32_t n) {
     uint32_t a = MP1 + n, b = 0x27D4EB2Fu ^ (n * MP3);
     const uint32_t rounds = n < (uint32_t)kHead ? (uint32_t)kHead : n;     // zero-padded to >= 8 rounds
     for (uint32_t i = 0; i < rounds; ++i) {
         uint32_t w = (i < n) ? word(i) : 0u;
-        a = mix_rotl(a + w * MP2, 13) * MP1;
-        b = mix_rotl(b ^ w, 11) * 5u + 0xE6546B64u;
+        mix_round(a, b, w);
     }
     return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
 }
@@ -125,7 +130,7 @@ __device__ __forceinline__ uint64_t label_mix64_words(WordFn word, uint32_t n) {
 __device__ __forceinline__ uint64_t label_mix64_head(const uint32_t (&w)[kHead], uint32_t n) {
     uint32_t a = MP1 + n, b = 0x27D4EB2Fu ^ (n * MP3);
 #pragma unroll
-    for (int i = 0; i < kHead; ++i) { a = mix_rotl(a + w[i] * MP2, 13) * MP1; b = mix_rotl(b ^ w[i], 11) * 5u + 0xE6546B64u; }
+    for (int i = 0; i < kHead; ++i) mix_round(a, b, w[i]);
     return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
 }
 // bucket hash of any label: registers for n <= 8, the loop otherwise
