@@ -51,11 +51,25 @@ __device__ __forceinline__ bool em_stop(uint32_t it, const EmState* s, uint32_t 
     return it > 0 && s->notconv[(it - 1) & 1] == 0;
 }
 
-// psi(x), x > 0: recurrence up to x >= 10 then the asymptotic series through B_14
-// (boost::math::digamma at :303, :314 in the reference; |err| ~ 1e-15).
+// psi(x), x > 0: the recurrence psi(x) = psi(x + 10) - sum_{k<10} 1/(x + k) for x < 10, then the asymptotic
+// series through B_14 (boost::math::digamma at :303, :314 in the reference; |err| ~ 1e-15).
+// The ten reciprocals are added as ONE fraction (pairwise n/d merges: every term is positive, so nothing
+// cancels) -- a single f64 division instead of up to ten dependent ones (a wavefront always holds some
+// low-abundance transcript, so the old loop ran all ten rounds for everybody).
 __device__ __forceinline__ double digamma_pos(double x) {
     double r = 0.0;
-    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    if (x < 10.0) {
+        const double a0 = x, a1 = x + 1.0, a2 = x + 2.0, a3 = x + 3.0, a4 = x + 4.0,
+                     a5 = x + 5.0, a6 = x + 6.0, a7 = x + 7.0, a8 = x + 8.0, a9 = x + 9.0;
+        double n01 = a0 + a1, d01 = a0 * a1, n23 = a2 + a3, d23 = a2 * a3, n45 = a4 + a5, d45 = a4 * a5,
+               n67 = a6 + a7, d67 = a6 * a7, n89 = a8 + a9, d89 = a8 * a9;
+        const double n03 = n01 * d23 + n23 * d01, d03 = d01 * d23;
+        const double n47 = n45 * d67 + n67 * d45, d47 = d45 * d67;
+        const double n07 = n03 * d47 + n47 * d03, d07 = d03 * d47;
+        const double n09 = n07 * d89 + n89 * d07, d09 = d07 * d89;
+        r = -(n09 / d09);
+        x += 10.0;
+    }
     double inv = 1.0 / x, inv2 = inv * inv;
     double s = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 * (1.0 / 240.0
              - inv2 * (1.0 / 132.0 - inv2 * (691.0 / 32760.0 - inv2 * (1.0 / 12.0)))))));
