@@ -547,9 +547,15 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
 
     // big unweighted batches take the radix-partitioned path, everything else the generic one
     const bool part = eq->use_part && !d_weights && n_reads >= (1u << 16);
-    const uint32_t step = part ? eq->part_sub_batch : eq->sub_batch;
-    for (uint32_t first = 0; first < n_reads; first += step) {
+    // Sub-batches bound the partition buffer and let the table grow between them.  Each one shows how fast
+    // new classes appear (the rate only falls as the table fills); the next sub-batch is made up to four
+    // times larger (at most 2^26 reads) as long as, at that rate, the table would stay under half full:
+    // fewer launches and longer region segments (400 M reads: 24 sub-batches -> 8).
+    uint32_t step = part ? eq->part_sub_batch : eq->sub_batch;
+    const bool adaptive = part && getenv("SFGPU_EQ_SUBBATCH") == nullptr;
+    for (uint32_t first = 0; first < n_reads; ) {
         uint32_t cnt = (n_reads - first < step) ? (n_reads - first) : step;
+        const uint64_t classes_before = eq->n_classes;
         bool done = false;
         if (part && (eq->cap >> kRegionBits) <= (uint64_t)kMaxRegions) {
             uint32_t se[2];
@@ -557,6 +563,7 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             SF_HIP(hipMemcpyAsync(&se[1], d_offsets + first + cnt, 4, hipMemcpyDeviceToHost, st));
             SF_HIP(hipStreamSynchronize(st));
             uint64_t n_words = (uint64_t)se[1] - se[0];
+            if (n_words >= (1ull << 31) && cnt > (1u << 20)) { step = cnt / 2; continue; }     // too many ids for 31-bit offsets: halve
             if (n_words < (1ull << 31)) {
                 if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words))) return rc;
                 done = true;
@@ -566,6 +573,14 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             for (uint32_t f2 = first; f2 < first + cnt; f2 += eq->sub_batch) {
                 uint32_t c2 = (first + cnt - f2 < eq->sub_batch) ? (first + cnt - f2) : eq->sub_batch;
                 if ((rc = eq_generic(eq, d_ids, d_offsets, f2, c2, nullptr, d_weights))) return rc;
+            }
+        }
+        first += cnt;
+        if (adaptive && done) {
+            const double rate = (double)(eq->n_classes - classes_before + 1) / (double)cnt;
+            for (uint32_t mult = 4; mult >= 2; mult /= 2) {
+                const uint64_t next = (uint64_t)step * mult;
+                if (next <= (1ull << 26) && (double)eq->n_classes + rate * (double)next <= (double)(eq->cap / 2)) { step = (uint32_t)next; break; }
             }
         }
     }

@@ -6,6 +6,7 @@ import sailfish_amd as sf
 from sailfish_amd import synth
 dev = torch.device("cuda:0")
 M, P, R = 80_000, 1_000_000, 50_000_000
+if os.environ.get('EQ_CFG3'): M, P, R = 200_000, 4_000_000, 400_000_000
 poff, pids = synth.label_pool(M, P, device=dev)
 ids, off = synth.reads_from_pool(poff, pids, R, device=dev)
 expected = int(sys.argv[1]) if len(sys.argv) > 1 else 0
