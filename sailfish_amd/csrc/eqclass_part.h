@@ -90,10 +90,26 @@ k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, 
             else if (len != 0) {
                 uint32_t w[kHead];
                 uint64_t h;
-                if (staged) { const uint32_t* lab = stage + (bb[k] - w_lo + mis); h = label_mix64([&](uint32_t q) { return lab[q]; }, len, w); }
-                else { const uint32_t* lab = ids + bb[k]; h = label_mix64([&](uint32_t q) { return lab[q]; }, len, w); }
-                rg = (uint16_t)((h & mask) >> kRegionBits);
-                atomicAdd(&lh[rg], len);
+                uint32_t any = 0;                            // OR of the label's ids
+                if (staged) {
+                    const uint32_t* lab = stage + (bb[k] - w_lo + mis);
+                    h = label_mix64([&](uint32_t q) { return lab[q]; }, len, w);
+                    for (uint32_t q = kHead; q < len; ++q) any |= lab[q];
+                } else {
+                    const uint32_t* lab = ids + bb[k];
+                    h = label_mix64([&](uint32_t q) { return lab[q]; }, len, w);
+                    for (uint32_t q = kHead; q < len; ++q) any |= lab[q];
+                }
+#pragma unroll
+                for (int q = 0; q < kHead; ++q) any |= w[q];
+                if (any & kHeadBit) {
+                    // an id >= 2^31 would collide with the label marker of the partition stream: such
+                    // labels (no real transcriptome has them) take the generic kernel, like over-long ones
+                    long_list[atomicAdd(n_long, 1ull)] = first + (uint32_t)i;
+                } else {
+                    rg = (uint16_t)((h & mask) >> kRegionBits);
+                    atomicAdd(&lh[rg], len);
+                }
             }
             reg_of[i] = rg;
         }

@@ -119,6 +119,47 @@ def test_builder_batching_and_order_independence(sf, gpu):
     eq = _gpu_classes(sf, gpu, parts[::-1], device_batches=False); _assert_same_classes(eq, ob, *oc)
 
 
+def test_builder_partitioned_path_edge_cases(sf, gpu):
+    """a batch big enough for the radix-partitioned kernels (>= 65536 reads) holding everything they
+    special-case: empty reads, labels of 1..8, 9..128 and > 128 ids (the last take the generic kernel),
+    one very hot label, ids with bit 31 set (the partition stream uses that bit as its label marker), and
+    an id array that does not start on a 16-byte boundary (the passes stage ids with 16-byte loads)"""
+    import torch
+    rng = np.random.default_rng(11)
+    pool = []
+    for n in [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 64, 127, 128, 129, 130, 255, 256, 300, 1000]:
+        for _ in range(3):
+            pool.append(np.sort(rng.choice(50_000, n, replace=False)).astype(np.uint32))
+    pool.append(np.array([0x80000000, 0x80000001], np.uint32))           # bit 31 in the first id
+    pool.append(np.array([5, 0xFFFFFFFF], np.uint32))                    # ... and in a later one
+    pool.append(np.array([0x80000000], np.uint32))
+    pool.append(np.array([7, 8, 9], np.uint32))                          # the hot label
+    hot = len(pool) - 1
+    pick = rng.integers(0, len(pool), 200_000)
+    pick[rng.random(200_000) < 0.5] = hot
+    reads = [pool[i] for i in pick]
+    for k in rng.integers(0, len(reads), 500):                           # empty reads in between
+        reads[k] = np.zeros(0, np.uint32)
+    ids, off = _pack(reads)
+    ob, *oc = _oracle_classes([(ids, off)])
+    for shift in (0, 1, 2, 3):                                           # ids pointer = 16-byte aligned + 4 * shift
+        buf = torch.zeros(ids.size + 8, dtype=torch.int32, device=gpu)
+        view = buf[shift:shift + ids.size]
+        view.copy_(torch.from_numpy(ids.view(np.int32)))
+        assert view.data_ptr() % 16 == (4 * shift) % 16
+        eq = sf.EquivalenceClassBuilder(device=gpu)
+        eq.start(); eq.add_batch(view, torch.from_numpy(off.view(np.int32)).to(gpu)); eq.finish()
+        _assert_same_classes(eq, ob, *oc)
+    # the same reads split so that a sub-batch boundary falls inside the batch
+    eq = sf.EquivalenceClassBuilder(device=gpu)
+    eq.start()
+    cut = 100_001
+    eq.add_batch(ids[:off[cut]].copy(), off[:cut + 1].copy())
+    eq.add_batch(ids[off[cut]:].copy(), (off[cut:] - off[cut]).astype(np.uint32))
+    eq.finish()
+    _assert_same_classes(eq, ob, *oc)
+
+
 @pytest.mark.parametrize("sub_batch", ["65536", None])
 def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
     """more distinct classes than the table budget: deferred reads are replayed after growth.
