@@ -133,19 +133,41 @@ class DistributedQuant:
 
     # ---- class-table exchange ----------------------------------------------------------------
     def _merge(self, vec):
+        """One exchange: every rank contributes its class table as one byte block
+        [counts i64[C] | lens i32[C] | ids i32[L]] (sizes first, then the padded blocks), and upserts the
+        tables of all ranks, in rank order, as ONE weighted batch -> the same table on every rank."""
+        import torch.distributed as dist
         w = self.world
+        dev = vec.ids.device
         rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
         lens = (rp[1:] - rp[:-1]).to(torch.int32)
-        g_lens = _all_gather_var(lens, self.group, w)
-        g_ids = _all_gather_var(vec.ids, self.group, w)
-        g_cnt = _all_gather_var(vec.counts, self.group, w)
+        C, L = int(lens.numel()), int(vec.ids.numel())
+        mine = torch.tensor([C, L], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(mine) for _ in range(w)]
+        dist.all_gather(sizes, mine, group=self.group)
+        sizes = torch.stack(sizes).cpu().tolist()                     # one host sync for all sizes
+        nbytes = [12 * c + 4 * l for c, l in sizes]
+        block = torch.zeros(max(max(nbytes), 8), dtype=torch.uint8, device=dev)
+        block[:8 * C] = vec.counts.to(torch.int64).contiguous().view(torch.uint8)
+        block[8 * C:12 * C] = lens.contiguous().view(torch.uint8)
+        block[12 * C:12 * C + 4 * L] = vec.ids.contiguous().view(torch.uint8)
+        blocks = [torch.empty_like(block) for _ in range(w)]
+        dist.all_gather(blocks, block, group=self.group)
+        cnts = [b[:8 * c].view(torch.int64) for b, (c, l) in zip(blocks, sizes)]
+        lns = [b[8 * c:12 * c].view(torch.int32) for b, (c, l) in zip(blocks, sizes)]
+        ids = [b[12 * c:12 * c + 4 * l].view(torch.int32) for b, (c, l) in zip(blocks, sizes)]
         m = self.merged
         m.start()
-        for ln, ii, cc in zip(g_lens, g_ids, g_cnt):     # same order on every rank -> same table
-            off = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=ln.device)
-            torch.cumsum(ln.to(torch.int64), 0, out=off[1:])
-            off32 = torch.where(off >= 2 ** 31, off - 2 ** 32, off).to(torch.int32)
-            m.insertGroups(ii, off32, cc)
+        r0 = 0
+        while r0 < w:                                                 # ranks [r0, r1): < 2^31 ids per upsert
+            r1, tot = r0 + 1, sizes[r0][1]
+            while r1 < w and tot + sizes[r1][1] < 2 ** 31:
+                tot += sizes[r1][1]; r1 += 1
+            ln = torch.cat(lns[r0:r1]).to(torch.int64)
+            off = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(ln, 0, out=off[1:])
+            m.insertGroups(torch.cat(ids[r0:r1]), off.to(torch.int32), torch.cat(cnts[r0:r1]))
+            r0 = r1
         m.finish()
         return m.eqVec()
 
