@@ -26,6 +26,8 @@
 
 #include "common.h"
 #include "primitives.h"
+#include <atomic>
+#include <thread>
 #include "xxh64_device.h"
 
 namespace sfgpu {
@@ -76,6 +78,11 @@ __global__ void k_table_init(uint64_t* table, uint64_t cap) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < cap; i += stride) { table[2 * i] = kEmpty; table[2 * i + 1] = 0; }
+}
+
+__global__ void k_rebase(uint32_t* off, uint64_t n, uint32_t base) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) off[i] -= base;
 }
 
 __device__ __forceinline__ bool labels_equal(const uint32_t* a, const uint32_t* b, uint32_t n) {
@@ -288,6 +295,12 @@ struct sfgpu_eq {
     unsigned long long* d_ctr = nullptr;
     unsigned long long* h_ctr = nullptr;  // pinned
     DevBuf<uint32_t> stage_ids, stage_off;
+    // sfgpu_eq_add_batch_host: small host batches (the mapper threads hand over ~1000 reads at a time) are
+    // appended to ONE pinned CSR and built kAccReads at a time -- a launch per 1000 reads would cap the
+    // builder at a few million reads/s; the copy is one large pinned H2D transfer per flush
+    uint32_t* acc_ids = nullptr; uint32_t* acc_off = nullptr;      // pinned
+    uint64_t acc_n_ids = 0; uint32_t acc_n_reads = 0;
+    std::atomic<int> acc_writers{0};                               // threads still copying into a reserved range
     // finish() products
     DevBuf<uint32_t> order; DevBuf<uint64_t> rowptr64;
     uint64_t nnz = 0, total_reads = 0;
@@ -328,11 +341,15 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
     return SFGPU_OK;
 }
 
+constexpr uint32_t kAccReads = 1u << 21;         // reads per accumulated host batch
+constexpr uint64_t kAccIds = 1ull << 24;          // ids per accumulated host batch (64 MB pinned)
+
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
 static int eq_reset(sfgpu_eq* eq) {
     eq->stats = sfgpu_eq_stats{};
     eq->finished = false; eq->n_classes = 0; eq->arena_used = 0; eq->nnz = 0; eq->total_reads = 0;
+    eq->acc_n_ids = 0; eq->acc_n_reads = 0;
     uint64_t want = pow2_at_least(2 * (eq->expected ? eq->expected : 1000000ull) + 2 * kSlack);
     if (eq->table.p && eq->cap == want) {
         hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
@@ -384,6 +401,8 @@ int sfgpu_eq_destroy(sfgpu_eq* eq) {
     (void)hipStreamSynchronize(eq->stream);
     if (eq->d_ctr) pool_free(eq->d_ctr);
     if (eq->h_ctr) pinned_free(eq->h_ctr);
+    if (eq->acc_ids) pinned_free(eq->acc_ids);
+    if (eq->acc_off) pinned_free(eq->acc_off);
     if (eq->ev0) (void)hipEventDestroy(eq->ev0);
     if (eq->ev1) (void)hipEventDestroy(eq->ev1);
     delete eq;
@@ -592,18 +611,64 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     return SFGPU_OK;
 }
 
+// caller holds eq->mu: build the accumulated host batch
+static int eq_flush_acc_locked(sfgpu_eq* eq) {
+    if (eq->acc_n_reads == 0) return SFGPU_OK;
+    while (eq->acc_writers.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // ranges reserved earlier are filled outside the lock
+    const uint32_t n = eq->acc_n_reads; const uint64_t n_ids = eq->acc_n_ids;
+    eq->acc_off[n] = (uint32_t)n_ids;
+    int rc;
+    if ((rc = eq->stage_ids.reserve(n_ids + 1, eq->stream, false))) return rc;
+    if ((rc = eq->stage_off.reserve((uint64_t)n + 1, eq->stream, false))) return rc;
+    if (n_ids) SF_HIP(hipMemcpyAsync(eq->stage_ids.p, eq->acc_ids, n_ids * 4, hipMemcpyHostToDevice, eq->stream));
+    SF_HIP(hipMemcpyAsync(eq->stage_off.p, eq->acc_off, ((uint64_t)n + 1) * 4, hipMemcpyHostToDevice, eq->stream));
+    eq->acc_n_reads = 0; eq->acc_n_ids = 0;
+    return eq_add_locked(eq, eq->stage_ids.p, eq->stage_off.p, n);     // returns after the stream has drained
+}
+
 int sfgpu_eq_add_batch_host(sfgpu_eq* eq, const uint32_t* h_ids, const uint32_t* h_offsets, uint32_t n_reads) {
     SF_REQUIRE(eq && h_offsets, SFGPU_ERR_INVALID, "sfgpu_eq_add_batch_host: null pointer");
     if (n_reads == 0) return SFGPU_OK;
     SF_REQUIRE(h_offsets[n_reads] >= h_offsets[0], SFGPU_ERR_INVALID, "sfgpu_eq_add_batch_host: offsets not ascending");
-    uint64_t n_ids = h_offsets[n_reads];
-    std::lock_guard<std::mutex> lk(eq->mu);   // mapping threads call this concurrently
-    int rc;
-    if ((rc = eq->stage_ids.reserve(n_ids + 1, eq->stream, false))) return rc;
-    if ((rc = eq->stage_off.reserve((uint64_t)n_reads + 1, eq->stream, false))) return rc;
-    if (n_ids) SF_HIP(hipMemcpyAsync(eq->stage_ids.p, h_ids, n_ids * 4, hipMemcpyHostToDevice, eq->stream));
-    SF_HIP(hipMemcpyAsync(eq->stage_off.p, h_offsets, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, eq->stream));
-    return eq_add_locked(eq, eq->stage_ids.p, eq->stage_off.p, n_reads);
+    const uint32_t base = h_offsets[0];
+    const uint64_t n_ids = (uint64_t)h_offsets[n_reads] - base;
+    SF_REQUIRE(n_ids == 0 || h_ids, SFGPU_ERR_INVALID, "sfgpu_eq_add_batch_host: null ids");
+    // mapping threads call this concurrently: the lock covers only the reservation of a range of the
+    // accumulation buffer (and a flush when it is full); the copy itself runs outside it
+    uint32_t* dst_ids; uint32_t* dst_off; uint32_t shift;
+    {
+        std::lock_guard<std::mutex> lk(eq->mu);
+        SF_REQUIRE(!eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_add_batch: builder already finished (call start)");
+        int rc;
+        if (n_reads >= kAccReads / 2 || n_ids >= kAccIds / 2) {
+            // already a large batch: stage it and build it directly
+            if ((rc = eq->stage_ids.reserve(n_ids + 1, eq->stream, false))) return rc;
+            if ((rc = eq->stage_off.reserve((uint64_t)n_reads + 1, eq->stream, false))) return rc;
+            if (n_ids) SF_HIP(hipMemcpyAsync(eq->stage_ids.p, h_ids + base, n_ids * 4, hipMemcpyHostToDevice, eq->stream));
+            SF_HIP(hipMemcpyAsync(eq->stage_off.p, h_offsets, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, eq->stream));
+            if (base) {     // offsets relative to the staged ids
+                hipLaunchKernelGGL(k_rebase, dim3(grid_for((uint64_t)n_reads + 1)), dim3(kBlock), 0, eq->stream, eq->stage_off.p,
+                                   (uint64_t)n_reads + 1, base);
+                SF_CHECK_LAUNCH();
+            }
+            return eq_add_locked(eq, eq->stage_ids.p, eq->stage_off.p, n_reads);
+        }
+        if (!eq->acc_ids) {
+            SF_HIP(pinned_malloc(&eq->acc_ids, kAccIds * 4));
+            SF_HIP(pinned_malloc(&eq->acc_off, ((uint64_t)kAccReads + 1) * 4));
+        }
+        if (eq->acc_n_reads + n_reads > kAccReads || eq->acc_n_ids + n_ids > kAccIds)
+            if ((rc = eq_flush_acc_locked(eq))) return rc;
+        dst_ids = eq->acc_ids + eq->acc_n_ids;
+        dst_off = eq->acc_off + eq->acc_n_reads;
+        shift = (uint32_t)eq->acc_n_ids - base;                          // modulo 2^32: o[i] = acc_n_ids + (h_off[i] - base)
+        eq->acc_n_reads += n_reads; eq->acc_n_ids += n_ids;
+        eq->acc_writers.fetch_add(1, std::memory_order_acq_rel);
+    }
+    if (n_ids) memcpy(dst_ids, h_ids + base, n_ids * 4);
+    for (uint32_t i = 0; i < n_reads; ++i) dst_off[i] = h_offsets[i] + shift;
+    eq->acc_writers.fetch_sub(1, std::memory_order_release);
+    return SFGPU_OK;
 }
 
 int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads) {
@@ -631,8 +696,9 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
     SF_REQUIRE(eq, SFGPU_ERR_INVALID, "sfgpu_eq_finish: null handle");
     std::lock_guard<std::mutex> lk(eq->mu);
     hipStream_t st = eq->stream;
-    uint64_t n = eq->n_classes;
     int rc;
+    if ((rc = eq_flush_acc_locked(eq))) return rc;          // reads still waiting in the host accumulation buffer
+    uint64_t n = eq->n_classes;
     if ((rc = eq->order.reserve(n + 1, st, false))) return rc;
     if ((rc = eq->rowptr64.reserve(n + 2, st, false))) return rc;
     eq->nnz = 0; eq->total_reads = 0;

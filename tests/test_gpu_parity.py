@@ -160,6 +160,29 @@ def test_builder_partitioned_path_edge_cases(sf, gpu):
     _assert_same_classes(eq, ob, *oc)
 
 
+def test_builder_host_batches_from_threads(sf, gpu):
+    """the reference-side adaptor's call pattern: several mapper threads hand over
+    ~1000-read HOST batches concurrently; the library accumulates them in pinned memory and builds
+    2 M reads at a time.  Same classes as the oracle, whatever the interleaving."""
+    import threading
+    from sailfish_amd import synth
+    _, ids, off = synth.workload(20_000, 200_000, 5_000_000, seed=3)
+    ids = ids.numpy().view(np.uint32); off = off.numpy().view(np.uint32)
+    ob, *oc = _oracle_classes([(ids, off)])
+    eq = sf.EquivalenceClassBuilder(device=gpu)
+    eq.start()
+    T, R = 6, len(off) - 1
+    def work(t):
+        step = 997 + 13 * t                                  # ragged batch sizes, offsets with a non-zero base
+        for r in range(R * t // T, R * (t + 1) // T, step):
+            e = min(r + step, R * (t + 1) // T)
+            eq.add_batch(ids, off[r:e + 1])
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [x.start() for x in th]; [x.join() for x in th]
+    eq.finish()
+    _assert_same_classes(eq, ob, *oc)
+
+
 @pytest.mark.parametrize("sub_batch", ["65536", None])
 def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
     """more distinct classes than the table budget: deferred reads are replayed after growth.
