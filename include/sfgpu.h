@@ -75,8 +75,12 @@ SFGPU_API int sfgpu_eq_start(sfgpu_eq* eq);
  * vector equality, src/TranscriptGroup.cpp:53-55); empty lists are skipped like the call
  * site's `if (txpIDs.size() > 0)` guard.  Thread-safe (calls are serialised per builder).
  * offsets are uint32: one batch holds < 2^32 ids and < 2^31 reads (else SFGPU_ERR_RANGE).
- * _host copies the batch to the device first; _device reads device-resident batches.
- * Both return after the batch has been folded in (the caller may reuse its buffers). */
+ * _device reads a device-resident batch and returns after it has been folded in.
+ * _host takes the caller's (pageable or pinned) host arrays: small batches are copied into a pinned
+ * accumulation buffer (thread-safe: only the reservation of the range is serialised) and built
+ * 2 M reads at a time, large ones are staged directly; offsets may start at a non-zero base (the ids are
+ * read from h_ids + h_offsets[0]).  Either way the caller may reuse its buffers on return, and
+ * sfgpu_eq_finish() folds in whatever is still accumulated. */
 SFGPU_API int sfgpu_eq_add_batch_host(sfgpu_eq* eq, const uint32_t* h_ids, const uint32_t* h_offsets, uint32_t n_reads);
 SFGPU_API int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads);
 /* insertGroup(TranscriptGroup, count) :82-88, batched and with upsert semantics: group g is added
