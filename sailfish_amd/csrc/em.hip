@@ -320,6 +320,7 @@ struct SweepArgs {
     const uint32_t* pub_pos;                                             // window slot -> index in `partial`
     const double* x; double* alpha_out; double* partial;
     EmState* st; uint32_t min_iter, max_iter;
+    double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
 };
 
 template <bool VB>
@@ -416,6 +417,7 @@ k_sweep_lds(SweepArgs a) {
     }
     __syncthreads();
     // ---- C: scatter-add into the window
+    double esc_sum = 0.0;
     {
         scatter(w);
         for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
@@ -427,13 +429,27 @@ k_sweep_lds(SweepArgs a) {
             uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
             double f = den[(tag >> 16) & 0x1FFFu];
             double contrib = (tag & kSingle) ? f : keep(x[t]) * f;
-            if (contrib != 0.0) atomicAdd(&a.alpha_out[t], contrib);
+            if (contrib != 0.0) { atomicAdd(&a.alpha_out[t], contrib); esc_sum += contrib; }
         }
     }
     __syncthreads();
     // ---- D: publish the window into the transcript-major partial array (plain stores): the update
     //         then folds each transcript's entries with contiguous, coalesced loads
-    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) a.partial[a.pub_pos[off + i]] = acc[i];
+    double mine = esc_sum;
+    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { const double v = acc[i]; a.partial[a.pub_pos[off + i]] = v; mine += v; }
+    if (VB && a.tsum) {
+        // everything this tile added to alphaOut, in a fixed order: the update derives sum(alpha) -- the
+        // argument of psi(sum alpha) -- from these n_tiles numbers instead of a second pass over M
+        __shared__ double red[kSweepBlock / kWave];
+        mine = wave_sum(mine);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < kSweepBlock / kWave; ++i) t += red[i];
+            a.tsum[blockIdx.x] = t;
+        }
+    }
 }
 
 // alphaOut[t] += sum of the tiles' window entries for t, in cover-list order (deterministic)
@@ -461,7 +477,7 @@ __global__ void __launch_bounds__(kEmBlock)
 k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* __restrict__ lenc,
          double tol, int check_mode, double* sum_partials_out, double* blkmax, EmState* st,
          const uint32_t* __restrict__ cov_ptr, const uint32_t* __restrict__ cov_pos,
-         const double* __restrict__ partial) {
+         const double* __restrict__ partial, const double* __restrict__ tsum, uint32_t n_tiles) {
     // request this thread's first operands before looking at the loop state (they do not depend on it):
     // the state test then costs no extra memory round trip
     const uint64_t t_first = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
@@ -470,12 +486,24 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
         a_first = alpha[t_first]; ao_first = alpha_out[t_first];
         if (FOLD) { k0_first = cov_ptr[t_first]; k1_first = cov_ptr[t_first + 1]; }
     }
+    double tsum_part = 0.0;
+    const bool fused_vb = VB && tsum != nullptr;      // x for the next sweep is produced here, no k_vb_prepare pass
+    if (fused_vb) for (uint32_t i = threadIdx.x; i < n_tiles; i += kEmBlock) tsum_part += tsum[i];
     uint32_t it = st->it_b;
     if (it == kDoneMark) return;
     __shared__ double lds[kEmBlock / kWave];
     __shared__ double lmax[kEmBlock / kWave];
     double local_sum = 0.0, local_max = -1.0;
     unsigned notconv = 0;
+    double log_norm = 0.0;
+    if (fused_vb) {
+        // sum(alpha) of this update = M * prior + what the tiles added; same order in every block
+        double sacc = block_sum(tsum_part, lds);
+        __shared__ double bc;
+        if (threadIdx.x == 0) bc = digamma_pos((double)M * kPriorAlpha + sacc);
+        __syncthreads();
+        log_norm = bc;
+    }
     for (uint64_t t = t_first; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
         const bool first = (t == t_first);
         double a = first ? a_first : alpha[t];
@@ -493,7 +521,9 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
             if (local_max < 0.0) local_max = 0.0;      // gated at least once
         }
         alpha[t] = ap; alpha_out[t] = 0.0;
-        if (VB) local_sum += ap; else x[t] = ap / lenc[t];
+        if (fused_vb) x[t] = (ap > kTiny) ? exp(digamma_pos(ap) - log_norm) / lenc[t] : 0.0;   // :300-320
+        else if (VB) local_sum += ap;
+        else x[t] = ap / lenc[t];
     }
     for (int o = kWave / 2; o > 0; o >>= 1) {
         double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
@@ -504,7 +534,7 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
         if (notconv) st->notconv[it & 1] = 1;
         lmax[w] = local_max;
     }
-    if (VB) { double s = block_sum(local_sum, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
+    if (VB && !fused_vb) { double s = block_sum(local_sum, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
     else __syncthreads();
     if (threadIdx.x == 0) {
         double m = lmax[0];
@@ -563,6 +593,8 @@ struct sfgpu_em {
     uint32_t* lstream = nullptr; uint32_t* esc_id = nullptr; uint32_t* esc_cls = nullptr;   // re-packed labels (k_sweep_lds)
     uint64_t* tile_s0 = nullptr; uint64_t* tile_esc0 = nullptr;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
+    double* tsum = nullptr;                                 // [n_tiles] what each tile added in the last sweep (VBEM, optimize())
+    bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     EmState* d_state = nullptr;
@@ -581,7 +613,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
-                    em->blkmax};
+                    em->blkmax, em->tsum};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -606,7 +638,7 @@ static int em_enqueue_sweep(sfgpu_em* em) {
     if (p.C == 0) return SFGPU_OK;
     SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                em->opts.min_iter, em->opts.max_iter};
+                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr};
     if (em->opts.use_vbem) hipLaunchKernelGGL(k_sweep_lds<true>, dim3(em->n_tiles), dim3(kSweepBlock), 0, em->cur, a);
     else hipLaunchKernelGGL(k_sweep_lds<false>, dim3(em->n_tiles), dim3(kSweepBlock), 0, em->cur, a);
     SF_CHECK_LAUNCH();
@@ -620,13 +652,17 @@ static int em_enqueue_update(sfgpu_em* em, bool fold) {
     dim3 g(em->nb), b(kEmBlock);
     fold = fold && p.C != 0;
 #define UPD_ARGS p.M, em->alpha, em->alpha_out, em->x, em->lenc, em->opts.tol, em->opts.check_mode, em->sum_partials, \
-                 em->blkmax, em->d_state, em->cov_ptr, em->cov_pos, em->partial
+                 em->blkmax, em->d_state, em->cov_ptr, em->cov_pos, em->partial, fused_tsum, em->n_tiles
+    // inside optimize() the VBEM update gets sum(alpha) from the sweep's per-tile sums and writes the next
+    // x itself; the piecewise API (all-reduce between sweep and update) keeps the separate k_vb_prepare pass
+    const double* fused_tsum = (em->opts.use_vbem && fold && em->in_optimize) ? em->tsum : nullptr;
     if (em->opts.use_vbem) {
         if (fold) hipLaunchKernelGGL((k_update<true, true>), g, b, 0, em->cur, UPD_ARGS);
         else hipLaunchKernelGGL((k_update<true, false>), g, b, 0, em->cur, UPD_ARGS);
         SF_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb,
-                           em->d_state, 0);
+        if (!fused_tsum)
+            hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb,
+                               em->d_state, 0);
     } else {
         if (fold) hipLaunchKernelGGL((k_update<false, true>), g, b, 0, em->cur, UPD_ARGS);
         else hipLaunchKernelGGL((k_update<false, false>), g, b, 0, em->cur, UPD_ARGS);
@@ -745,6 +781,8 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&em->tile_esc0, ((size_t)nt + 1) * 8));
         EM_TRY(pool_malloc(&t_len8, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt + 1) * 4));
         EM_TRY(pool_malloc(&em->cov_ptr, ((size_t)M + 1) * 4));
+        EM_TRY(pool_malloc(&em->tsum, (size_t)nt * 8));
+        EM_TRY(hipMemsetAsync(em->tsum, 0, (size_t)nt * 8, em->cur));      // empty tiles never write theirs
         hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
                            prob->d_rowptr, em->tile_c0);
         hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
@@ -818,6 +856,7 @@ static int em_begin_on(sfgpu_em* em, const sfgpu_em_opts* opts, hipStream_t work
 int sfgpu_em_begin(sfgpu_em* em, const sfgpu_em_opts* opts) {
     SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_begin: null handle");
     (void)hipStreamSynchronize(em->stream);    // nothing of a previous optimize() may be in flight
+    em->in_optimize = false;
     return em_begin_on(em, opts, em->user_stream);
 }
 
@@ -920,6 +959,7 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
 static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
                   sfgpu_em_stats* stats, bool quiet) {
     int rc;
+    em->in_optimize = true;
     if ((rc = em_begin_on(em, opts, em->stream))) return rc;
     if ((rc = sfgpu_em_init_impl(em))) return rc;
     int done = 0;
