@@ -5,21 +5,26 @@
 //           src/TranscriptGroup.cpp (key = ordered id list, hash = XXH64, == is vector ==).
 //
 // Design (not the reference's: that is a lock-striped CPU cuckoo table fed one read at a time):
-//   * reads arrive as packed batches (ids[], offsets[]) resident in HBM; one lane per read
-//     hashes its label with XXH64 and probes an open-addressing table with linear probing;
-//   * a slot is one 16-byte pair {word, count}: word = tag(32) | rep(32).  tag = XXH64 >> 32
-//     filters probes; class identity is ALWAYS decided by a full label compare against the
-//     slot's representative label, exactly like operator== (src/TranscriptGroup.cpp:53-55),
-//     so XXH64 collisions are resolved the way the reference resolves them;
-//   * claiming a slot is a single 64-bit CAS that publishes tag and representative together,
-//     so no lane ever waits on another lane (no spin, no fence): rep is either a read index of
-//     the running batch (label still in the batch buffers, written before the launch) or
-//     0x80000000|class-id (label in the arena, written by an earlier launch);
-//   * after each sub-batch a commit kernel copies the labels of the newly created classes to
-//     the arena and re-points their slots, so batch buffers can be reused by the caller;
-//   * the table is sized from the number of classes actually seen (load <= 1/2), keeping the
-//     randomly probed working set cache-resident; inserts that would exceed the budget are
-//     deferred, the table is doubled, and the deferred reads are replayed;
+//   * reads arrive as packed batches (ids[], offsets[]) resident in HBM (host batches are accumulated in
+//     pinned memory and staged, see sfgpu_eq_add_batch_host);
+//   * the table is open addressing with linear probing inside REGIONS of 4096 slots; a slot is one
+//     16-byte pair {word, count}: word = tag(32) | rep(32).  Where a label lands (region, slot, tag) is
+//     decided by a cheap bucket hash (xxh64_device.h); tag only filters probes -- class identity is
+//     ALWAYS decided by a full label compare against the slot's representative label, exactly like
+//     operator== (src/TranscriptGroup.cpp:53-55); XXH64 (TranscriptGroup::hash) is computed once per
+//     class when it is committed and is what the export and the canonical order use;
+//   * big unweighted batches go through the radix-partitioned kernels of eqclass_part.h (one block per
+//     region, region image in LDS); weighted merges, small batches, over-long labels and overflow take
+//     the generic kernel k_insert below: one lane per read probing the table in HBM, claiming a slot
+//     with a single 64-bit CAS that publishes tag and representative together, so no lane ever waits on
+//     another lane (no spin, no fence): rep is either a read index of the running batch (label still in
+//     the batch buffers, written before the launch) or 0x80000000 | arena entry / 4 (label in the arena,
+//     written by an earlier launch or by the committing block);
+//   * committed labels live in the arena as 16-byte-aligned entries [len, ids..., 0 pad]: one 16-byte
+//     load decides a compare for labels of <= 3 ids;
+//   * the table is sized from the number of classes actually seen (load <= 1/4 partitioned, <= 1/2
+//     generic); inserts that would exceed the budget are deferred, the table is doubled, and the
+//     deferred reads are replayed;
 //   * finish() orders classes canonically (first id, XXH64, length, label) with a radix sort.
 #include <mutex>
 #include <vector>
