@@ -1,0 +1,70 @@
+"""dev stress: random class structures (far-apart ids -> escapes, singletons, wide classes, huge counts,
+tile-size edge cases) through the EM / VBEM loop vs the oracle after a fixed number of iterations"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sailfish_amd as sf
+from oracle import oracle as O
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
+worst = 0.0; n = 0
+while time.time() < t_end:
+    M = int(rng.choice([3, 100, 3000, 70_000, 400_000]))
+    C = int(rng.choice([1, 50, 5000, 120_000]))
+    law = rng.integers(0, 4)
+    if law == 0: k = rng.integers(1, 6, C)                         # short labels
+    elif law == 1: k = np.where(rng.random(C) < 0.5, 1, rng.integers(2, 40, C))   # many singletons
+    elif law == 2: k = np.where(rng.random(C) < 0.002, rng.integers(500, 3000, C), rng.integers(1, 8, C))   # a few very wide
+    else: k = rng.geometric(0.25, C)
+    k = np.minimum(k, M).astype(np.int64)
+    rp = np.zeros(C + 1, np.int64); rp[1:] = np.cumsum(k)
+    local = rng.random() < 0.5
+    ids = np.empty(rp[-1], np.uint32)
+    for c in range(C) if C <= 5000 else []:
+        if local:
+            b = rng.integers(0, M); pool = (b + np.arange(min(M, 4 * k[c] + 8))) % M
+            ids[rp[c]:rp[c + 1]] = np.sort(rng.choice(pool, k[c], replace=False))
+        else:
+            ids[rp[c]:rp[c + 1]] = np.sort(rng.choice(M, k[c], replace=False))
+    if C > 5000:                                                   # vectorised: sorted distinct ids per class
+        base = rng.integers(0, M, C) if local else None
+        cls = np.repeat(np.arange(C), k); j = np.arange(rp[-1]) - rp[:-1][cls]
+        if local: raw = (base[cls] + j * rng.integers(1, 5)) % M
+        else:
+            raw = rng.integers(0, M, rp[-1])
+        key = cls.astype(np.int64) * M + raw
+        key = np.unique(key)                                       # drop duplicate ids inside a class
+        cls2 = (key // M); ids = (key % M).astype(np.uint32)
+        k = np.bincount(cls2, minlength=C).astype(np.int64)
+        keep = k > 0
+        rp = np.zeros(keep.sum() + 1, np.int64); rp[1:] = np.cumsum(k[keep]); C = int(keep.sum())
+    # canonical order (first id ascending) as the builder exports it
+    first = ids[rp[:-1]]
+    order = np.argsort(first, kind="stable")
+    kk = (rp[1:] - rp[:-1])[order]
+    nrp = np.zeros(C + 1, np.int64); nrp[1:] = np.cumsum(kk)
+    nids = np.concatenate([ids[rp[c]:rp[c + 1]] for c in order]) if C <= 5000 else ids[np.concatenate([np.arange(rp[c], rp[c + 1]) for c in order])] if C < 20000 else None
+    if nids is None:
+        idx = np.repeat(rp[:-1][order], kk) + (np.arange(nrp[-1]) - np.repeat(nrp[:-1], kk))
+        nids = ids[idx]
+    rp, ids = nrp, nids
+    cnt = np.where(rng.random(C) < 0.01, rng.integers(1, 2_000_000_000, C), rng.integers(1, 2000, C)).astype(np.uint64)
+    eff = np.exp(rng.normal(6.5, 1.0, M)).clip(1.0, 1e5)
+    N = int(cnt.sum())
+    vb = bool(rng.integers(0, 2)); iters = int(rng.choice([1, 3, 25]))
+    rc, oa, om, ost = O.em_optimize(eff, rp.astype(np.uint64), ids, cnt, N, use_vbem=vb, tol=0.0, min_iter=iters, max_iter=iters)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+    p = sf.EMProblem(torch.from_numpy(eff).to(dev), t(rp.astype(np.uint32), np.int32), t(ids, np.int32), t(cnt, np.int64), N)
+    grc, st = p.optimize(use_vbem=vb, tol=0.0, min_iter=iters, max_iter=iters)
+    ga = p.alpha.cpu().numpy()
+    assert rc == grc, (rc, grc)
+    if rc == 0:
+        nz = oa > 0
+        assert np.array_equal(ga > 0, nz), "support differs"
+        rel = float(np.max(np.abs(ga[nz] - oa[nz]) / oa[nz])) if nz.any() else 0.0
+        worst = max(worst, rel)
+        print(f"M={M} C={C} nnz={rp[-1]} law={law} local={local} vb={vb} iters={iters}: rel {rel:.2e} iters {st['iters']}/{ost['iters']}", flush=True)
+        assert rel < 1e-9 and st["iters"] == ost["iters"], "MISMATCH"
+    p.close(); n += 1
+print("all ok:", n, "worst rel", worst)
