@@ -127,13 +127,16 @@ k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, 
 // The sub-tile's ids are staged in the sort buffer with coalesced 16-byte loads (see k_part_hist), the
 // lanes lift their labels' first 8 ids into registers, and the same buffer is then refilled in region
 // order -- one LDS buffer serves as both the staging area and the sort destination.
+// Two blocks share a CU (48 KB buffer, <= 64 VGPRs): rocprofv3 shows these passes' wavefronts parked on
+// s_waitcnt / barriers for 60-80 % of their cycles, so a second block that works while the first waits is
+// worth more than longer runs (96 KB buffer, 4096-read sub-tiles, one block per CU: 0.35 -> 0.29 ms).
 // (Tried and dropped: prefetching the next sub-tile into registers during the write-out -- vmcnt counts
 // loads and stores together on gfx9, so the block still waits for its stores to drain.)
-constexpr int kSortWords = 24576;                            // 96 KB LDS sort buffer
-constexpr int kSubReads = 4096;                              // reads per sub-tile: 4 per thread
+constexpr int kSortWords = 12288;                            // 48 KB LDS sort buffer: two blocks per CU
+constexpr int kSubReads = 2048;                              // reads per sub-tile: 2 per thread (their label heads stay in registers)
 constexpr int kSubPer = kSubReads / kPartBlock;
 
-__global__ void __launch_bounds__(kPartBlock)
+__global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_scatter(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t first, uint32_t n,
                uint32_t tile, uint32_t n_regions, const uint16_t* __restrict__ reg_of,
                const uint64_t* __restrict__ offs /* scanned matrix */, uint32_t* __restrict__ out) {
@@ -303,13 +306,19 @@ k_part_insert(PartArgs a) {
     const uint32_t w_beg = (uint32_t)((uint64_t)n_words * wave / kPartWaves);
     const uint32_t w_end = (uint32_t)((uint64_t)n_words * (wave + 1) / kPartWaves);
     uint32_t pos = w_beg;
+    // word i of a tile = q * 64 + lane: each of the four loads is one coalesced 256-byte access.  The
+    // NEXT tile's words are requested as soon as this tile's label starts are known, i.e. before the
+    // hash / probe / compare of this tile's labels: its round trip hides behind theirs.
+    uint32_t tw[4];
+    auto request = [&](uint32_t at, uint32_t (&dst)[4]) {
+        const uint32_t len = (n_words - at < (uint32_t)kWaveTile) ? (n_words - at) : (uint32_t)kWaveTile;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t i = q * 64 + lane; dst[q] = (i < len) ? seg[at + i] : 0u; }
+    };
+    if (pos < w_end) request(pos, tw);
     while (pos < w_end) {
         const uint32_t tlen = (n_words - pos < (uint32_t)kWaveTile) ? (n_words - pos) : (uint32_t)kWaveTile;
         const bool final_tile = (pos + tlen == n_words);
-        // word i of the tile = q * 64 + lane: each of the four loads is one coalesced 256-byte access
-        uint32_t tw[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint32_t i = q * 64 + lane; tw[q] = (i < tlen) ? seg[pos + i] : 0u; }
         uint32_t nh = 0, in_range = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -332,6 +341,16 @@ k_part_insert(PartArgs a) {
         // as a full one -- the labels past the 64th are simply picked up by the next (overlapping) tile
         uint32_t n_proc = n_whole < in_range ? n_whole : in_range;
         if (n_proc > 64u) n_proc = 64u;
+        // where the next tile starts: at the first label that is not processed now; stop once that label is
+        // another wavefront's.  Labels are <= kMaxPartLabel = half a tile, so a full tile always holds >= 2
+        // label starts and advances.
+        uint32_t next_pos; bool more;
+        if (n_proc < in_range) { const uint32_t adv = wh[n_proc]; next_pos = pos + (adv ? adv : tlen); more = true; }
+        else if (n_proc < nh || final_tile) { next_pos = pos; more = false; }     // the next label start lies at or beyond w_end (or the segment ended)
+        else { next_pos = pos + tlen; more = true; }                             // no label start left in this tile (cannot happen for full tiles)
+        more = more && next_pos < w_end;
+        uint32_t nw[4] = {0u, 0u, 0u, 0u};
+        if (more) request(next_pos, nw);
         for (uint32_t l = lane; l < n_proc; l += 64) {
             const uint32_t st = wh[l];
             const uint32_t en = (l + 1 < nh) ? wh[l + 1] : tlen;
@@ -389,11 +408,10 @@ k_part_insert(PartArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                      // all lanes are done with the tile before it is refilled
-        // next tile starts at the first label that was not processed; stop once that label is another wavefront's.
-        // Labels are <= kMaxPartLabel = half a tile, so a full tile always holds >= 2 label starts and advances.
-        if (n_proc < in_range) { const uint32_t adv = wh[n_proc]; pos += adv ? adv : tlen; }
-        else if (n_proc < nh || final_tile) break;            // the next label start lies at or beyond w_end (or the segment ended)
-        else pos += tlen;                                     // no label start left in this tile (cannot happen for full tiles)
+        if (!more) break;
+        pos = next_pos;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tw[q] = nw[q];
     }
     __syncthreads();
 
