@@ -477,8 +477,21 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
                           uint64_t n_words) {
     hipStream_t st = eq->stream;
     int rc;
-    // regions stay sparse (load <= 1/4) so that a region overflowing its LDS image is a non-event
-    while (eq->n_classes + kMinHeadroom > eq->cap / 4) if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
+    // regions stay sparse (load <= 1/4) so that a region overflowing its LDS image is a non-event.  At the
+    // largest table these kernels handle (kMaxRegions regions = 16 M slots) the load may reach 1/2 (8 M
+    // classes) before the table doubles again and the generic kernel takes over.
+    const uint64_t max_part_cap = (uint64_t)kMaxRegions << kRegionBits;
+    while (eq->n_classes + kMinHeadroom > eq->cap / 4) {
+        if (eq->cap >= max_part_cap && eq->n_classes + kMinHeadroom <= eq->cap / 2) break;
+        if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
+    }
+    if ((eq->cap >> kRegionBits) > (uint64_t)kMaxRegions) {     // grew past what the partition passes handle
+        for (uint32_t f2 = first; f2 < first + cnt; f2 += eq->sub_batch) {
+            const uint32_t c2 = (first + cnt - f2 < eq->sub_batch) ? (first + cnt - f2) : eq->sub_batch;
+            if ((rc = eq_generic(eq, d_ids, d_offsets, f2, c2, nullptr, nullptr))) return rc;
+        }
+        return SFGPU_OK;
+    }
     const uint32_t n_regions = (uint32_t)(eq->cap >> kRegionBits);
     uint64_t cls_need = eq->n_classes + cnt + 1;
     SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");

@@ -213,6 +213,28 @@ def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
     assert np.all(np.diff(first) >= 0)              # canonical order: first id ascending (then hash)
 
 
+def test_builder_beyond_partition_limit(sf, gpu):
+    """9 M distinct labels: the table passes 16 M slots, the size up to which the radix-partitioned kernels
+    run (load 1/2 there), and the generic kernel takes over -- counts and classes stay exact"""
+    import torch
+    n, dup = 9_000_000, 3_000_000
+    g = torch.Generator(device=gpu); g.manual_seed(1)
+    a = torch.randperm(n, generator=g, device=gpu, dtype=torch.int64)
+    ids = torch.stack([a, (a * 7 + 3) % 1000], 1).reshape(-1).to(torch.int32)
+    ids = torch.cat([ids, ids[:2 * dup]])
+    off = (torch.arange(n + dup + 1, device=gpu, dtype=torch.int64) * 2).to(torch.int32)
+    eq = sf.EquivalenceClassBuilder(device=gpu)
+    eq.start(); eq.add_batch(ids, off); eq.finish()
+    v = eq.eqVec()
+    assert eq.n_classes == n and eq.total_reads == n + dup and eq.stats()["table_slots"] > (1 << 24)
+    cc = v.counts
+    assert int(cc.sum()) == n + dup and int((cc == 2).sum()) == dup and int((cc == 1).sum()) == n - dup
+    first = v.ids.view(-1, 2)[:, 0].to(torch.int64)
+    assert bool((first[1:] > first[:-1]).all())              # canonical order; every first id is distinct here
+    twice = first[cc == 2]
+    assert bool(torch.equal(torch.sort(twice).values, torch.sort(a[:dup]).values))
+
+
 # ------------------------------------------------------------------------------------ a6-a13
 @pytest.fixture(scope="module")
 def midsize(sf, gpu):
