@@ -639,45 +639,65 @@ static int em_fill_opts(sfgpu_em* em, const sfgpu_em_opts* o) {
     return SFGPU_OK;
 }
 
-// enqueue one full iteration on the handle's stream
-static int em_enqueue_sweep(sfgpu_em* em) {
+// Where an iteration's kernels go: straight onto a stream, or into a graph under construction as a chain
+// of kernel nodes.  The graph is built with explicit nodes, not by stream capture: on ROCm 7.2 a capture
+// in one host thread is invalidated by unrelated calls of other threads (allocations, synchronisations --
+// the bootstrap lanes, or any multi-threaded host), whatever the capture mode.
+struct Launcher {
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphNode_t last = nullptr;
+    hipError_t launch(const void* func, dim3 grid, dim3 block, void** args) {
+        if (!graph) return hipLaunchKernel(func, grid, block, args, 0, stream);
+        hipKernelNodeParams kp{};
+        kp.func = const_cast<void*>(func); kp.gridDim = grid; kp.blockDim = block;
+        kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        hipError_t e = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &kp);
+        if (e == hipSuccess) last = node;
+        return e;
+    }
+};
+
+// one sweep of the current iteration
+static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     const sfgpu_problem& p = em->prob;
     if (p.C == 0) return SFGPU_OK;
     SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
                 em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr};
-    if (em->opts.use_vbem) hipLaunchKernelGGL(k_sweep_lds<true>, dim3(em->n_tiles), dim3(kSweepBlock), 0, em->cur, a);
-    else hipLaunchKernelGGL(k_sweep_lds<false>, dim3(em->n_tiles), dim3(kSweepBlock), 0, em->cur, a);
-    SF_CHECK_LAUNCH();
+    void* args[] = {&a};
+    const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true>)
+                                      : reinterpret_cast<const void*>(&k_sweep_lds<false>);
+    SF_HIP(L.launch(f, dim3(em->n_tiles), dim3(kSweepBlock), args));
     return SFGPU_OK;
 }
+static int em_enqueue_sweep(sfgpu_em* em) { Launcher L; L.stream = em->cur; return em_enqueue_sweep(em, L); }
 
 // `fold`: the sweep's per-tile window sums still have to be folded into alphaOut (true inside
 // optimize(); false in the piecewise API, where sfgpu_em_sweep folds before the caller's all-reduce)
-static int em_enqueue_update(sfgpu_em* em, bool fold) {
+static int em_enqueue_update(sfgpu_em* em, bool fold, Launcher& L) {
     const sfgpu_problem& p = em->prob;
     dim3 g(em->nb), b(kEmBlock);
     fold = fold && p.C != 0;
-#define UPD_ARGS p.M, em->alpha, em->alpha_out, em->x, em->lenc, em->opts.tol, em->opts.check_mode, em->sum_partials, \
-                 em->blkmax, em->d_state, em->cov_ptr, em->cov_pos, em->partial, fused_tsum, em->n_tiles
     // inside optimize() the VBEM update gets sum(alpha) from the sweep's per-tile sums and writes the next
     // x itself; the piecewise API (all-reduce between sweep and update) keeps the separate k_vb_prepare pass
     const double* fused_tsum = (em->opts.use_vbem && fold && em->in_optimize) ? em->tsum : nullptr;
-    if (em->opts.use_vbem) {
-        if (fold) hipLaunchKernelGGL((k_update<true, true>), g, b, 0, em->cur, UPD_ARGS);
-        else hipLaunchKernelGGL((k_update<true, false>), g, b, 0, em->cur, UPD_ARGS);
-        SF_CHECK_LAUNCH();
-        if (!fused_tsum)
-            hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb,
-                               em->d_state, 0);
-    } else {
-        if (fold) hipLaunchKernelGGL((k_update<false, true>), g, b, 0, em->cur, UPD_ARGS);
-        else hipLaunchKernelGGL((k_update<false, false>), g, b, 0, em->cur, UPD_ARGS);
+    uint64_t M = p.M; double tol = em->opts.tol; int check_mode = em->opts.check_mode; uint32_t n_tiles = em->n_tiles;
+    void* args[] = {&M, &em->alpha, &em->alpha_out, &em->x, &em->lenc, &tol, &check_mode, &em->sum_partials,
+                    &em->blkmax, &em->d_state, &em->cov_ptr, &em->cov_pos, &em->partial, &fused_tsum, &n_tiles};
+    const void* f;
+    if (em->opts.use_vbem) f = fold ? reinterpret_cast<const void*>(&k_update<true, true>) : reinterpret_cast<const void*>(&k_update<true, false>);
+    else f = fold ? reinterpret_cast<const void*>(&k_update<false, true>) : reinterpret_cast<const void*>(&k_update<false, false>);
+    SF_HIP(L.launch(f, g, b, args));
+    if (em->opts.use_vbem && !fused_tsum) {
+        int nb = em->nb, force = 0;
+        void* vargs[] = {&M, &em->alpha, &em->x, &em->lenc, &em->sum_partials, &nb, &em->d_state, &force};
+        SF_HIP(L.launch(reinterpret_cast<const void*>(&k_vb_prepare), g, b, vargs));
     }
-#undef UPD_ARGS
-    SF_CHECK_LAUNCH();
     return SFGPU_OK;
 }
+static int em_enqueue_update(sfgpu_em* em, bool fold) { Launcher L; L.stream = em->cur; return em_enqueue_update(em, fold, L); }
 
 static int em_enqueue_fold(sfgpu_em* em) {
     const sfgpu_problem& p = em->prob;
@@ -940,23 +960,21 @@ static bool same_opts(const sfgpu_em_opts& a, const sfgpu_em_opts& b) {
            a.check_mode == b.check_mode && a.iters_per_launch == b.iters_per_launch;
 }
 
-// capture `n` iterations into an executable graph (kernel arguments are baked, the iteration
-// index and the stop latch live in device memory)
+// `n` iterations as an executable graph (kernel arguments are baked, the iteration index and the stop
+// latch live in device memory)
 static int em_build_graph(sfgpu_em* em, uint32_t n) {
     if (em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == n) return SFGPU_OK;
     if (em->graph) { (void)hipGraphExecDestroy(em->graph); em->graph = nullptr; }
-    hipGraph_t g = nullptr;
-    SF_HIP(hipStreamBeginCapture(em->cur, hipStreamCaptureModeThreadLocal));
+    Launcher L;
+    SF_HIP(hipGraphCreate(&L.graph, 0));
     int rc = SFGPU_OK;
     for (uint32_t i = 0; i < n && rc == SFGPU_OK; ++i) {
-        rc = em_enqueue_sweep(em);
-        if (rc == SFGPU_OK) rc = em_enqueue_update(em, true);
+        rc = em_enqueue_sweep(em, L);
+        if (rc == SFGPU_OK) rc = em_enqueue_update(em, true, L);
     }
-    hipError_t e = hipStreamEndCapture(em->cur, &g);
-    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    SF_HIP(e);
-    hipError_t ei = hipGraphInstantiate(&em->graph, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
+    if (rc) { (void)hipGraphDestroy(L.graph); return rc; }
+    hipError_t ei = hipGraphInstantiate(&em->graph, L.graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(L.graph);
     SF_HIP(ei);
     em->graph_opts = em->opts; em->graph_iters = n;
     return SFGPU_OK;
