@@ -12,15 +12,10 @@ ids, off = synth.reads_from_pool(poff, pids, R, device=dev)
 eq = sf.EquivalenceClassBuilder(device=dev); eq.start(); eq.add_batch(ids, off); eq.finish(); v = eq.eqVec()
 length = ref_len.to(torch.float64)
 N = 24
-for K in (1,):
-    ps = [sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads) for _ in range(K)]
-    for p in ps: p.bootstrap(1, seed=9)              # warm (plan for the sampler, graph)
+for rep in range(5):
+    p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads)
     torch.cuda.synchronize(); t = time.perf_counter()
-    def work(k):
-        with torch.cuda.device(dev):
-            ps[k].bootstrap(N // K, seed=100 + k)
-    th = [threading.Thread(target=work, args=(k,)) for k in range(K)]
-    [x.start() for x in th]; [x.join() for x in th]
+    rc, out, iters = p.bootstrap(N, seed=100 + rep)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print(f"K={K}: {N} replicates in {dt*1e3:.1f} ms -> {dt/N*1e3:.2f} ms per replicate", flush=True)
-    for p in ps: p.close()
+    print(f"rep {rep}: {N} replicates in {dt*1e3:.1f} ms -> {dt/N*1e3:.2f} ms per replicate (lanes: SFGPU_BS_LANES={os.environ.get('SFGPU_BS_LANES', 'default 3')}), rc {rc}, iters {iters.min()}..{iters.max()}", flush=True)
+    p.close()
