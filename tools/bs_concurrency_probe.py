@@ -1,4 +1,4 @@
-"""dev probe: do bootstrap replicates overlap when K handles run them on their own streams from K host threads?"""
+"""dev probe: bootstrap throughput on cfg2 classes; set SFGPU_BS_LANES=1..4 to compare lane counts"""
 import os, sys, time, threading
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
