@@ -199,6 +199,9 @@ SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint3
  *             draw with a host copy of alpha; return 0 to abort.  May be NULL.
  *   h_iters : per-draw iteration counts (host), may be NULL
  * opts->use_vbem / tol / max_iter are honoured; min_iter and check_mode are forced to doBootstrap's.
+ * Up to three draws run concurrently (the handle plus internal clones of it, each on its own stream
+ * and host thread; SFGPU_BS_LANES=1..8 overrides); draw b is the same whichever lane computes it and
+ * `cb` is still called one draw at a time, in draw order.
  * Synchronous.  The handle's counts are restored afterwards.
  * ------------------------------------------------------------------------------------------- */
 typedef int (*sfgpu_sample_cb)(const double* h_alpha, uint64_t M, void* user);
