@@ -827,6 +827,8 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(hipStreamSynchronize(em->cur));
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
         em->P = P;
+        if (getenv("SFGPU_TIMING")) fprintf(stderr, "em plan: %u tiles (%u nnz each), P = %llu window slots (%.2f per transcript), %llu escapes of %llu nonzeros\n",
+                                            nt, tile_nnz, (unsigned long long)P, (double)P / (double)M, (unsigned long long)E, (unsigned long long)rp_end);
         EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
         EM_TRY(pool_malloc(&em->esc_id, (E ? E : 1) * 4));
         EM_TRY(pool_malloc(&em->esc_cls, (E ? E : 1) * 4));
