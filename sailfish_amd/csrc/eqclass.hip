@@ -560,6 +560,11 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if (n_long) {        // labels too long for an LDS tile
         if ((rc = eq_generic(eq, d_ids, d_offsets, 0, (uint32_t)n_long, eq->part_long.p, nullptr))) return rc;
     }
+    if (n_def || n_long) {      // the generic kernel's commits moved the arena cursor
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        eq->arena_used = eq->h_ctr[CTR_ARENA];
+    }
     return SFGPU_OK;
 }
 
@@ -577,13 +582,18 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     SF_REQUIRE(ends[1] >= ends[0], SFGPU_ERR_INVALID, "sfgpu_eq_add_batch: offsets not ascending");
     uint64_t batch_ids = (uint64_t)ends[1] - ends[0];
     int rc;
-    // worst case every read opens a class: its ids + the entry header and padding (<= 4 words)
-    const uint64_t arena_need = eq->arena_used + batch_ids + 4 * (uint64_t)n_reads + 4;
-    SF_REQUIRE((arena_need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
-    if ((rc = eq->arena.reserve(arena_need, st, true, eq->arena_used))) return rc;
+    // arena room for the reads about to be inserted -- worst case every read opens a class: its ids + the
+    // entry header and padding (<= 4 words).  Reserved per sub-batch on the partitioned path (a 400 M-read
+    // batch would otherwise pin 13 GB for ~30 MB of labels), once per batch on the generic one.
+    auto reserve_arena = [&](uint64_t words, uint64_t reads) -> int {
+        const uint64_t need = eq->arena_used + words + 4 * reads + 4;
+        SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
+        return eq->arena.reserve(need, st, true, eq->arena_used);
+    };
 
     // big unweighted batches take the radix-partitioned path, everything else the generic one
     const bool part = eq->use_part && !d_weights && n_reads >= (1u << 16);
+    if (!part && (rc = reserve_arena(batch_ids, n_reads))) return rc;
     // Sub-batches bound the partition buffer and let the table grow between them.  Each one shows how fast
     // new classes appear (the rate only falls as the table fills); the next sub-batch is made up to four
     // times larger (at most 2^26 reads) as long as, at that rate, the table would stay under half full:
@@ -601,15 +611,28 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             SF_HIP(hipStreamSynchronize(st));
             uint64_t n_words = (uint64_t)se[1] - se[0];
             if (n_words >= (1ull << 31) && cnt > (1u << 20)) { step = cnt / 2; continue; }     // too many ids for 31-bit offsets: halve
+            if ((rc = reserve_arena(n_words, cnt))) return rc;
             if (n_words < (1ull << 31)) {
                 if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words))) return rc;
                 done = true;
             }
+        } else if (part) {
+            // table already beyond the partition kernels: this sub-batch goes to the generic kernel
+            uint32_t se[2];
+            SF_HIP(hipMemcpyAsync(&se[0], d_offsets + first, 4, hipMemcpyDeviceToHost, st));
+            SF_HIP(hipMemcpyAsync(&se[1], d_offsets + first + cnt, 4, hipMemcpyDeviceToHost, st));
+            SF_HIP(hipStreamSynchronize(st));
+            if ((rc = reserve_arena((uint64_t)(se[1] - se[0]), cnt))) return rc;
         }
         if (!done) {
             for (uint32_t f2 = first; f2 < first + cnt; f2 += eq->sub_batch) {
                 uint32_t c2 = (first + cnt - f2 < eq->sub_batch) ? (first + cnt - f2) : eq->sub_batch;
                 if ((rc = eq_generic(eq, d_ids, d_offsets, f2, c2, nullptr, d_weights))) return rc;
+            }
+            if (part) {     // the next sub-batch's reservation starts from the real cursor
+                SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                SF_HIP(hipStreamSynchronize(st));
+                eq->arena_used = eq->h_ctr[CTR_ARENA];
             }
         }
         first += cnt;
