@@ -74,10 +74,35 @@ def cpu_baseline(ref_len_np, ids_t, off_t, target_s, use_vbem):
     per_iter = (time.perf_counter() - t0) / 3
     n_it = int(max(5, min(400, (target_s - t_build) / max(per_iter, 1e-6))))
     t0 = time.perf_counter()
-    O.em_optimize(eff, rp, ii, cc, n_build, use_vbem=use_vbem, tol=0.0, min_iter=0, max_iter=n_it)
+    rc_o, alpha_o, _, _ = O.em_optimize(eff, rp, ii, cc, n_build, use_vbem=use_vbem, tol=0.0, min_iter=n_it, max_iter=n_it)
     per_iter = (time.perf_counter() - t0) / n_it
+    # "TPM delta vs CPU ref" of the metric: the HIP path on the very same sample (same reads -> classes, same
+    # number of iterations), compared with what the oracle just produced
+    parity = None
+    try:
+        import sailfish_amd as sf
+        dev = ids_t.device
+        eq = sf.EquivalenceClassBuilder(device=dev)
+        eq.start(); eq.add_batch(ids_t[: int(off[-1])], off_t[: n_build + 1]); eq.finish()
+        v = eq.eqVec()
+        grp, gii, gcc, _ = v.to_numpy()
+        same_classes = bool(eq.n_classes == b.n_classes and np.array_equal(grp, rp.astype(np.uint32))
+                            and np.array_equal(gii, ii) and np.array_equal(gcc, cc))
+        prob = sf.EMProblem(torch.from_numpy(eff).to(dev), v.rowptr, v.ids, v.counts, eq.total_reads)
+        rc_g, _ = prob.optimize(use_vbem=use_vbem, tol=0.0, min_iter=n_it, max_iter=n_it)
+        alpha_g = prob.alpha.cpu().numpy()
+        tpm_o, tpm_g = O.tpm(alpha_o, eff, n_build), O.tpm(alpha_g, eff, n_build)
+        nz = alpha_o > 0
+        rel = lambda a, r: float(np.max(np.abs(a[nz] - r[nz]) / r[nz])) if nz.any() else 0.0
+        parity = dict(sample=f"first {n_build} reads, {n_it} {'VBEM' if use_vbem else 'EM'} iterations on both sides",
+                      classes_identical=same_classes, support_identical=bool(np.array_equal(alpha_g > 0, nz)),
+                      max_rel_numreads=rel(alpha_g, alpha_o), max_rel_tpm=rel(tpm_g, tpm_o),
+                      rc=[int(rc_o), int(rc_g)])
+        prob.close()
+    except Exception as e:            # the checker leg must never take the benchmark line down
+        parity = dict(error=repr(e))
     return dict(build_reads_per_s=build_rate, em_ms_per_iter=per_iter * 1e3, sample_reads=n_build,
-                sample_classes=int(b.n_classes), sample_nnz=int(b.nnz), sample_em_iters=n_it)
+                sample_classes=int(b.n_classes), sample_nnz=int(b.nnz), sample_em_iters=n_it, parity=parity)
 
 
 def main():
@@ -217,6 +242,7 @@ def main():
             "class_build_reads_per_s": cb["build_reads_per_s"], "em_ms_per_iter_sample": cb["em_ms_per_iter"],
             "host_cores_available": os.cpu_count(),
         }
+        out["parity_vs_cpu"] = cb["parity"]     # the metric's "TPM delta vs CPU ref", on the baseline's sample
     if rank == 0:
         print(json.dumps(out))
     if dist:
