@@ -120,6 +120,12 @@ SFGPU_API int sfgpu_cf_counts(const uint32_t* h_fl_counts, uint32_t max_frag_len
 /* computeSmoothedEffectiveLengths :809-838 ; setEffectiveLengthsDirect :706-715 when h_cf == NULL */
 SFGPU_API int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h_cf, uint32_t max_frag_len,
                           double* d_eff_len, sfgpu_stream stream);
+/* --unsmoothedFLD: computeEmpiricalEffectiveLengths :717-767 over EmpiricalDistribution
+ * (src/EmpiricalDistribution.cpp:29-118; float pdf table, cut where the cumulative mass passes 1 - 1e-6,
+ * two-ended median walk).  h_fl_counts[i] = observed fragments of length i, i in [0, max_frag_len).
+ * eff = RefLength when RefLength <= median, else sum_l pdf(l) * (RefLength - l + 1).  Synchronous. */
+SFGPU_API int sfgpu_efflen_empirical(const uint32_t* h_fl_counts, uint32_t max_frag_len, const uint32_t* d_ref_len, uint64_t M,
+                           double* d_eff_len, sfgpu_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a6-a12. CollapsedEMOptimizer   src/CollapsedEMOptimizer.cpp:711-893

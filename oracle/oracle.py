@@ -47,6 +47,7 @@ def lib():
         L.sfo_fld_gaussian_counts.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p]
         L.sfo_cf_counts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.sfo_efflen_smoothed.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.sfo_efflen_empirical.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
         L.sfo_em_optimize.restype = C.c_int
         L.sfo_em_optimize.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_int, C.c_double, C.c_uint32, C.c_uint32, C.c_int,
@@ -138,6 +139,12 @@ def efflen_smoothed(ref_len, cf):
     """computeSmoothedEffectiveLengths (src/SailfishQuantify.cpp:809-838)."""
     rl = _c(ref_len, np.uint32); cf = _c(cf, np.float64); eff = np.zeros(len(rl))
     lib().sfo_efflen_smoothed(_p(rl), len(rl), _p(cf), len(cf), _p(eff)); return eff
+
+
+def efflen_empirical(fl_counts, ref_len):
+    """--unsmoothedFLD: computeEmpiricalEffectiveLengths (src/SailfishQuantify.cpp:717-767)."""
+    fl = _c(fl_counts, np.uint32); rl = _c(ref_len, np.uint32); eff = np.zeros(len(rl))
+    lib().sfo_efflen_empirical(_p(fl), len(fl), _p(rl), len(rl), _p(eff)); return eff
 
 
 def em_optimize(eff_len, rowptr, ids, counts, num_mapped, use_vbem=False, tol=0.01,

@@ -276,6 +276,53 @@ SFO_API void sfo_cf_counts(const uint32_t* fl_counts, uint32_t max_len, double* 
     }
 }
 
+/* --unsmoothedFLD: computeEmpiricalEffectiveLengths (src/SailfishQuantify.cpp:717-767) over the
+ * EmpiricalDistribution of src/EmpiricalDistribution.cpp:29-96 built from jointMap = {i -> flMap[i]} for
+ * EVERY i in [0, maxFragLen) (:944-946: zero counts included, so vals[i] == i, minVal = 0 and
+ * maxVal = maxFragLen - 1).  pdf values are stored as float (EmpiricalDistribution.hpp:62); the median
+ * is the two-pointer walk of :80-92 on unsigned counts. */
+SFO_API void sfo_efflen_empirical(const uint32_t* fl_counts, uint32_t n, const uint32_t* ref_len, uint64_t M, double* eff) {
+    float* pdf = (float*)calloc(n ? n : 1, sizeof(float));
+    uint32_t min_val = 0xFFFFFFFFu, max_val = 0;
+    double valsum = 0;
+    for (uint32_t i = 0; i < n; ++i) {                          /* :38-42 */
+        if (i < min_val) min_val = i;
+        if (i > max_val) max_val = i;
+        valsum += fl_counts[i];
+    }
+    double cumpr = 0.0;
+    uint32_t lastval = 0, maxval = 1;
+    for (; lastval < n; ++lastval) {                            /* :44-52 */
+        cumpr += fl_counts[lastval] / valsum;
+        maxval = lastval;
+        if (cumpr > 1.0 - 1e-6) break;
+    }
+    valsum = 0.0;                                               /* :54-58 */
+    for (uint32_t i = 0; i < lastval; ++i) valsum += fl_counts[i];
+    for (uint32_t val = 0; val < maxval; ++val) pdf[val] = (float)(fl_counts[val] / valsum);   /* :60-70 */
+    /* median :78-92 */
+    size_t i = 0, j = (size_t)n - 1;
+    unsigned int u = fl_counts[0], v = fl_counts[n - 1];
+    while (i < j) {
+        if (u <= v) { v -= u; u = fl_counts[++i]; }
+        else { u -= v; v = fl_counts[--j]; }
+    }
+    float med = (maxval == 0) ? NAN : (float)i;                 /* median(): NAN when pdfvals is empty (:108-112) */
+    const int valid_support = max_val > min_val;                /* :749 */
+    for (uint64_t t = 0; t < M; ++t) {
+        double ref = (double)ref_len[t];
+        if (ref <= med || !valid_support) { eff[t] = ref; continue; }            /* :751-752 */
+        double e = 0.0;
+        size_t hi = ref_len[t] < max_val ? ref_len[t] : max_val;
+        for (size_t l = min_val; l <= hi; ++l) {                                 /* :755-757 */
+            float p = (l < maxval) ? pdf[l] : 0.0f;                              /* pdf(): 0 beyond the table (:115-118) */
+            e += p * ((double)(ref_len[t] - l) + 1.0);
+        }
+        eff[t] = e;
+    }
+    free(pdf);
+}
+
 /* computeSmoothedEffectiveLengths (:809-838). */
 SFO_API void sfo_efflen_smoothed(const uint32_t* ref_len, uint64_t M, const double* cf,
                                  uint32_t max_len, double* eff) {

@@ -71,6 +71,7 @@ _SIGS = {
     "sfgpu_cf_gaussian": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, _P]),
     "sfgpu_cf_counts": (C.c_int, [_P, C.c_uint32, _P]),
     "sfgpu_efflen_smoothed": (C.c_int, [_P, C.c_uint64, _P, C.c_uint32, _P, _P]),
+    "sfgpu_efflen_empirical": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "sfgpu_em_create": (C.c_int, [C.POINTER(_P), C.POINTER(Problem), _P]),
     "sfgpu_em_destroy": (C.c_int, [_P]),
     "sfgpu_em_optimize": (C.c_int, [_P, C.POINTER(EmOpts), _P, _P, C.POINTER(EmStats)]),

@@ -65,6 +65,26 @@ __global__ void k_tpm(uint64_t M, const double* __restrict__ est, const double* 
     }
 }
 
+// --unsmoothedFLD (computeEmpiricalEffectiveLengths, src/SailfishQuantify.cpp:745-762): one lane per
+// transcript walks the (<= maxFragLen-entry, cache-resident) float pdf table in the reference's order, so the
+// double sum is bit-identical to the serial loop.
+__global__ void k_efflen_empirical(uint64_t M, const uint32_t* __restrict__ ref_len, const float* __restrict__ pdf,
+                                   uint32_t pdf_len, uint32_t max_val, float median, int valid_support,
+                                   double* __restrict__ eff) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    const uint32_t L = ref_len[t];
+    const double ref = (double)L;
+    if (ref <= median || !valid_support) { eff[t] = ref; return; }   // a NaN median (empty table) compares false, as in the reference
+    const uint32_t hi = L < max_val ? L : max_val;
+    double e = 0.0;
+    for (uint32_t l = 0; l <= hi; ++l) {
+        const float p = (l < pdf_len) ? pdf[l] : 0.0f;
+        e += p * ((double)(L - l) + 1.0);
+    }
+    eff[t] = e;
+}
+
 }  // namespace sfgpu
 
 using namespace sfgpu;
@@ -117,6 +137,52 @@ int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h
     hipError_t le = hipGetLastError();
     if (d_cf) { (void)hipStreamSynchronize(st); pool_free(d_cf); }
     SF_HIP(le);
+    return SFGPU_OK;
+}
+
+int sfgpu_efflen_empirical(const uint32_t* h_fl_counts, uint32_t max_frag_len, const uint32_t* d_ref_len, uint64_t M,
+                           double* d_eff_len, sfgpu_stream stream) {
+    SF_REQUIRE(h_fl_counts && d_ref_len && d_eff_len && max_frag_len > 0, SFGPU_ERR_INVALID, "sfgpu_efflen_empirical: bad argument");
+    if (M == 0) return SFGPU_OK;
+    // EmpiricalDistribution::buildDistribution (src/EmpiricalDistribution.cpp:29-96) for vals = 0..n-1 (the
+    // caller's jointMap holds every fragment length, zero counts included: src/SailfishQuantify.cpp:944-946)
+    const uint32_t n = max_frag_len;
+    double total = 0.0;
+    for (uint32_t i = 0; i < n; ++i) total += h_fl_counts[i];
+    uint32_t cut = 0, table_len = 1;                    // table_len = vals[lastval] where the cumulative mass passes 1 - 1e-6
+    {
+        double cum = 0.0;
+        for (; cut < n; ++cut) {
+            cum += h_fl_counts[cut] / total;
+            table_len = cut;
+            if (cum > 1.0 - 1e-6) break;
+        }
+    }
+    double kept = 0.0;
+    for (uint32_t i = 0; i < cut; ++i) kept += h_fl_counts[i];
+    std::vector<float> pdf(table_len ? table_len : 1, 0.0f);
+    for (uint32_t v = 0; v < table_len; ++v) pdf[v] = (float)(h_fl_counts[v] / kept);
+    // median: the two-ended walk of :78-92 on the unsigned counts
+    size_t lo = 0, hi = (size_t)n - 1;
+    unsigned int a = h_fl_counts[lo], b = h_fl_counts[hi];
+    while (lo < hi) {
+        if (a <= b) { b -= a; a = h_fl_counts[++lo]; }
+        else { a -= b; b = h_fl_counts[--hi]; }
+    }
+    const float median = table_len ? (float)lo : std::nanf("");
+    const int valid_support = (n - 1) > 0;              // maxVal > minVal with minVal = 0, maxVal = n - 1
+    hipStream_t st = as_stream(stream);
+    float* d_pdf = nullptr;
+    SF_HIP(pool_malloc(&d_pdf, pdf.size() * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d_pdf, pdf.data(), pdf.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_efflen_empirical, dim3((unsigned)((M + kMiscBlock - 1) / kMiscBlock)), dim3(kMiscBlock), 0, st, M,
+                           d_ref_len, d_pdf, table_len, n - 1, median, valid_support, d_eff_len);
+        e = hipGetLastError();
+    }
+    (void)hipStreamSynchronize(st);                     // pdf is a pageable host vector and d_pdf goes back to the pool
+    pool_free(d_pdf);
+    SF_HIP(e);
     return SFGPU_OK;
 }
 

@@ -42,7 +42,7 @@ def set_effective_lengths(readExp: ReadExperiment, sopt: SailfishOpts, fl_counts
     """The post-mapping block of quasiMapReads: writes Transcript::EffectiveLength on the device.
       single end, or paired end with too few unique-pair observations (remainingFLOps > 0):
           Gaussian prior table (:961-975, :1038-1042)
-      else: empirical cumulative-mean table (:976-990)
+      else: empirical cumulative-mean table (:976-990), or with --unsmoothedFLD the empirical pdf itself
       --noEffectiveLengthCorrection: EffectiveLength = RefLength (:956-958)."""
     txps = readExp.transcripts()
     L = _lib.lib()
@@ -53,9 +53,13 @@ def set_effective_lengths(readExp: ReadExperiment, sopt: SailfishOpts, fl_counts
         readExp.setFragLengthDist(normal_counts(sopt))
         cf = normal_cf(sopt)
     else:
-        if sopt.useUnsmoothedFLD:
-            raise NotImplementedError("--unsmoothedFLD (EmpiricalDistribution) is outside the hot path (SURVEY.md 2)")
         readExp.setFragLengthDist(np.asarray(fl_counts, dtype=np.int32))
+        if sopt.useUnsmoothedFLD:        # computeEmpiricalEffectiveLengths (:985-986, :717-767)
+            fl = np.ascontiguousarray(fl_counts, dtype=np.uint32)
+            with torch.cuda.device(txps.device):
+                _lib.check(L.sfgpu_efflen_empirical(_lib.ptr(fl), len(fl), _lib.ptr(txps.RefLength), M,
+                                                    _lib.ptr(txps.EffectiveLength), _lib.current_stream_ptr()))
+            return None
         cf = counts_cf(fl_counts)
     with torch.cuda.device(txps.device):
         _lib.check(L.sfgpu_efflen_smoothed(_lib.ptr(txps.RefLength), M, _lib.ptr(cf) if cf is not None else None,

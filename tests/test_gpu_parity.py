@@ -398,6 +398,14 @@ def test_efflen_and_end_to_end_driver(sf, gpu, midsize, tmp_path):
     fl = O.fld_gaussian_counts(1000, 250, 60, 20000).astype(np.uint32)
     sf.efflen.set_effective_lengths(exp, sopt, fl_counts=fl, remaining_fl_ops=0)
     np.testing.assert_array_equal(exp.transcripts().EffectiveLength.cpu().numpy(), O.efflen_smoothed(m["ref_len"], O.cf_counts(fl)))
+    # --unsmoothedFLD: the empirical pdf itself (computeEmpiricalEffectiveLengths), bit-exact incl. odd corners
+    rng = np.random.default_rng(8)
+    for fld in (fl, rng.integers(0, 50, 1000).astype(np.uint32), np.r_[np.zeros(300), 7, np.zeros(699)].astype(np.uint32),
+                np.r_[5, np.zeros(999)].astype(np.uint32), np.array([0, 4], np.uint32)):
+        sopt = sf.SailfishOpts(useUnsmoothedFLD=True, maxFragLen=len(fld))
+        exp = sf.ReadExperiment(sf.Transcripts(names, m["ref_len"], device=gpu), sopt)
+        sf.efflen.set_effective_lengths(exp, sopt, fl_counts=fld, remaining_fl_ops=0)
+        np.testing.assert_array_equal(exp.transcripts().EffectiveLength.cpu().numpy(), O.efflen_empirical(fld, m["ref_len"]))
 
 
 # -------------------------------------------------------------------------------- a15 / a17

@@ -149,6 +149,62 @@ def test_efflen_tables(built):
         assert e == (want if want >= 1.0 else float(L))
 
 
+def _empirical_efflen_numpy(fl, ref_len):
+    """independent restatement of --unsmoothedFLD (src/SailfishQuantify.cpp:717-767 over
+    src/EmpiricalDistribution.cpp:29-118) with numpy scalars: float32 pdf table, double accumulation"""
+    fl = np.asarray(fl, np.uint32); n = len(fl)
+    valsum = float(np.sum(fl.astype(np.float64)))          # counts are integers: any order gives the same double
+    cum, last, maxval = 0.0, 0, 1
+    with np.errstate(invalid="ignore", divide="ignore"):
+        while last < n:
+            cum += np.float64(fl[last]) / np.float64(valsum); maxval = last
+            if cum > 1.0 - 1e-6:
+                break
+            last += 1
+        kept = float(np.sum(fl[:last].astype(np.float64)))
+        pdf = (fl[:maxval].astype(np.float64) / np.float64(kept)).astype(np.float32) if maxval else np.zeros(0, np.float32)
+    i, j = 0, n - 1
+    u, v = int(fl[0]), int(fl[n - 1])
+    while i < j:
+        if u <= v:
+            v = (v - u) & 0xFFFFFFFF; i += 1; u = int(fl[i])
+        else:
+            u = (u - v) & 0xFFFFFFFF; j -= 1; v = int(fl[j])
+    med = np.float32(i) if maxval else np.float32(np.nan)
+    out = np.zeros(len(ref_len))
+    for t, L in enumerate(np.asarray(ref_len, np.uint32)):
+        L = int(L)
+        if float(L) <= float(med) or not (n - 1 > 0):
+            out[t] = float(L); continue
+        e = np.float64(0.0)
+        for l in range(0, min(L, n - 1) + 1):
+            p = np.float64(pdf[l]) if l < maxval else np.float64(0.0)
+            e = e + p * (np.float64(L - l) + 1.0)
+        out[t] = float(e)
+    return out
+
+
+def test_efflen_unsmoothed_fld(built):
+    """--unsmoothedFLD branch of a14: oracle vs an independent numpy restatement, incl. the odd corners
+    (all mass in one bin, empty pdf table -> NaN median -> effective length 0, two-bin distributions)"""
+    rng = np.random.default_rng(4)
+    ref_len = np.array([1, 2, 50, 150, 199, 200, 201, 250, 999, 1000, 1001, 5000, 100000], np.uint32)
+    cases = [O.fld_gaussian_counts(1000, 200, 80, 10000).astype(np.uint32),
+             O.fld_gaussian_counts(1000, 250, 60, 20000).astype(np.uint32),
+             rng.integers(0, 50, 1000).astype(np.uint32),
+             np.r_[np.zeros(300), 7, np.zeros(699)].astype(np.uint32),          # one bin
+             np.r_[5, np.zeros(999)].astype(np.uint32),                         # all mass at length 0: empty table
+             np.r_[np.zeros(10), 3, np.zeros(20), 9, np.zeros(968)].astype(np.uint32),
+             np.array([0, 4], np.uint32), np.array([4, 0], np.uint32)]
+    for fl in cases:
+        got = O.efflen_empirical(fl, ref_len)
+        want = _empirical_efflen_numpy(fl, ref_len)
+        np.testing.assert_array_equal(got, want)
+    # sanity on the Gaussian case: long transcripts lose about the mean fragment length
+    eff = O.efflen_empirical(cases[0], ref_len)
+    assert abs((100000 - eff[-1]) - 199.0) < 3.0 and eff[0] == 1.0 and eff[3] == 150.0
+
+
 def test_tpm_columns(built):
     rng = np.random.default_rng(0)
     a = rng.random(100) * 50; a[::7] = 0; ln = rng.integers(200, 5000, 100).astype(float)
