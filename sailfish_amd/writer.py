@@ -1,4 +1,7 @@
-"""quant.sf / eq_classes.txt output -- host mirror of src/GZipWriter.cpp:51-92 and :194-248."""
+"""quant.sf / aux/ output -- host mirror of src/GZipWriter.cpp:51-92 (eq_classes.txt), :94-192 (writeMeta),
+:194-248 (quant.sf) and :249-285 (writeBootstrap)."""
+import gzip
+import json
 import os
 
 import numpy as np
@@ -54,3 +57,69 @@ def write_equiv_counts(path, readExp: ReadExperiment, sopt: SailfishOpts):
             lab = ids[rowptr[c]:rowptr[c + 1]]
             f.write(f"{len(lab)}\t" + "".join(f"{t}\t" for t in lab) + f"{counts[c]}\n")
     return True
+
+
+SAILFISH_VERSION = "0.10.0"        # sailfish::version (include/SailfishConfig.hpp:32), the release mirrored here
+NUM_BIAS_BINS = 4 ** 6             # ReadKmerDist<6>::counts (include/ReadExperiment.hpp:249, ReadKmerDist.hpp:16)
+
+
+def write_meta(path, readExp: ReadExperiment, sopt: SailfishOpts, start_time: str):
+    """writeMeta (GZipWriter.cpp:94-192): aux/bootstrap/names.tsv.gz when sampling is requested, aux/fld.gz and
+    aux/meta_info.json (cereal JSON: same keys, same order).  Differences, both outside the hot path: fld.gz holds
+    the stored fragment-length counts themselves (the reference writes a random_device-seeded 10 000-sample
+    realisation of them, EmpiricalDistribution.cpp:125-143), and the bias-model vectors (expected_/observed_
+    bias / gc) are not written because the bias models are out of scope."""
+    txps = readExp.transcripts()
+    aux = os.path.join(path, sopt.auxDir)
+    os.makedirs(aux, exist_ok=True)
+    n_boot = int(sopt.numBootstraps)
+    n_samp = n_boot if n_boot > 0 else int(sopt.numGibbsSamples)
+    if n_samp > 0:
+        if len(txps) == 0:
+            return False
+        bs = os.path.join(aux, "bootstrap")
+        os.makedirs(bs, exist_ok=True)
+        with gzip.open(os.path.join(bs, "names.tsv.gz"), "wb", compresslevel=6) as f:
+            f.write(("\t".join(txps.RefName) + "\n").encode())
+    fld = readExp.fragLengthDist()
+    fld = np.zeros(sopt.maxFragLen, np.int32) if fld is None else np.asarray(fld, np.int32)
+    with gzip.open(os.path.join(aux, "fld.gz"), "wb", compresslevel=6) as f:
+        f.write(fld.tobytes())                                   # writeVectorToFile: raw little-endian binary
+    samp_type = "bootstrap" if n_boot > 0 else ("gibbs" if n_samp > 0 else "none")
+    n_obs = readExp.numObservedFragments() or readExp.numMappedFragments()
+    info = [("sf_version", SAILFISH_VERSION), ("samp_type", samp_type),
+            ("frag_dist_length", int(len(fld) - 1)),             # EmpiricalDistribution::maxValue() of vals = 0..n-1
+            ("bias_correct", bool(sopt.biasCorrect)), ("num_bias_bins", NUM_BIAS_BINS),
+            ("num_targets", len(txps)), ("num_bootstraps", n_boot),
+            ("num_processed", int(n_obs)), ("num_mapped", int(readExp.numMappedFragments())),
+            ("percent_mapped", (readExp.numMappedFragments() / n_obs * 100.0) if n_obs else 0.0),
+            ("call", "quant"), ("start_time", start_time)]
+    with open(os.path.join(aux, "meta_info.json"), "w") as f:
+        f.write(json.dumps(dict(info), indent=4))
+    return True
+
+
+class BootstrapWriter:
+    """writeBootstrap<T> (GZipWriter.cpp:249-285): every sample is appended as raw binary (float64 for
+    bootstrap replicates, int32 for Gibbs samples) to aux/bootstrap/bootstraps.gz.  An instance is the callback
+    of EMProblem.bootstrap / gibbs_sample (the C ABI calls it one sample at a time, in draw order)."""
+
+    def __init__(self, path, sopt: SailfishOpts, logger=None):
+        self._dir = os.path.join(path, sopt.auxDir, "bootstrap")
+        self._f = None
+        self._log = logger
+        self.written = 0
+
+    def __call__(self, abund):
+        if self._f is None:
+            os.makedirs(self._dir, exist_ok=True)
+            self._f = gzip.open(os.path.join(self._dir, "bootstraps.gz"), "wb", compresslevel=6)
+        self._f.write(np.ascontiguousarray(abund).tobytes())
+        self.written += 1
+        if self._log:
+            self._log(0, f"wrote {self.written} bootstraps")
+        return True
+
+    def close(self):
+        if self._f is not None:
+            self._f.close(); self._f = None

@@ -477,6 +477,39 @@ def test_gather_bootstraps_driver(sf, gpu, midsize):
     assert np.all(np.abs(b[:, top].mean(0) - point[top]) < 0.2 * point[top] + 5)
 
 
+def test_aux_writers(sf, gpu, midsize, tmp_path):
+    """writeMeta + writeBootstrap (GZipWriter.cpp:94-192, 249-285): names.tsv.gz, fld.gz, meta_info.json and the raw
+    binary bootstraps.gz that downstream tools read back"""
+    import gzip
+    from sailfish_amd import synth
+    m = midsize
+    _, ids, off = synth.workload(5000, 20000, 400_000)
+    sopt = sf.SailfishOpts(numBootstraps=4)
+    names = ["tx%d" % i for i in range(5000)]
+    exp = sf.ReadExperiment(sf.Transcripts(names, m["ref_len"], device=gpu), sopt)
+    eq = exp.equivalenceClassBuilder(); eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); eq.finish()
+    exp.setNumMappedFragments(eq.total_reads); exp.setNumObservedFragments(eq.total_reads + 1000)
+    sf.efflen.set_effective_lengths(exp, sopt)
+    opt = sf.CollapsedEMOptimizer(); assert opt.optimize(exp, sopt, 0.01, 10000)
+    out = str(tmp_path / "q")
+    assert sf.writer.write_meta(out, exp, sopt, "Mon Jan  1 00:00:00 2024")
+    w = sf.writer.BootstrapWriter(out, sopt)
+    kept = []
+    assert opt.gatherBootstraps(exp, sopt, lambda a: kept.append(a.copy()) or w(a), 0.01, 10000, seed=5)
+    w.close()
+    aux = os.path.join(out, "aux")
+    assert gzip.open(os.path.join(aux, "bootstrap", "names.tsv.gz")).read().decode() == "\t".join(names) + "\n"
+    fld = np.frombuffer(gzip.open(os.path.join(aux, "fld.gz")).read(), np.int32)
+    np.testing.assert_array_equal(fld, O.fld_gaussian_counts())
+    meta = json.load(open(os.path.join(aux, "meta_info.json")))
+    assert list(meta) == ["sf_version", "samp_type", "frag_dist_length", "bias_correct", "num_bias_bins", "num_targets",
+                          "num_bootstraps", "num_processed", "num_mapped", "percent_mapped", "call", "start_time"]
+    assert meta["samp_type"] == "bootstrap" and meta["num_targets"] == 5000 and meta["num_bootstraps"] == 4
+    assert meta["num_mapped"] == eq.total_reads and abs(meta["percent_mapped"] - 100.0 * eq.total_reads / (eq.total_reads + 1000)) < 1e-9
+    raw = np.frombuffer(gzip.open(os.path.join(aux, "bootstrap", "bootstraps.gz")).read(), np.float64).reshape(4, 5000)
+    np.testing.assert_array_equal(raw, np.stack(kept))
+
+
 # ---------------------------------------------------------------------------------------- a16
 def _toy7():
     k = json.load(open(os.path.join(GOLD, "survey_kat.json")))["em_toy7"]
