@@ -236,6 +236,61 @@ SFGPU_API int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass
                        uint64_t seed, int32_t* d_out, sfgpu_gibbs_cb cb, void* user, sfgpu_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (next) Per-read hit filtering: the loop bodies of processReadsQuasi
+ * (src/SailfishQuantify.cpp:215-417 paired end, :530-626 single end) between "the mapper returned
+ * jointHits for a read" and eqBuilder.addGroup -- maxReadOccs cut (:217, :532), orphan policy (:226),
+ * orphan merge by transcript id (:231-246), library-type compatibility (sailfish::utils::compatibleHit /
+ * hitType, src/SailfishUtils.cpp:157-289; pinned by the reference's tests/LibraryTypeTests.cpp), the
+ * "compatible hits if any, else all hits unless enforceLibCompat" rule (:324-341, :355-368, :395-416) and
+ * the fragment-length sampling of unique proper pairs (:419-434).  Bias / GC sampling is out of scope.
+ * One record per hit, reads in CSR form; the output is the packed hit lists sfgpu_eq_add_batch_device
+ * takes (reads that end up unmapped get an empty list), so labels never visit the host.
+ * Enum values: mate_status 0 SINGLE_END, 1 PAIRED_END_LEFT, 2 PAIRED_END_RIGHT, 3 PAIRED_END_PAIRED (the
+ * adaptor maps rapmap::utils::MateStatus); sfgpu_libfmt fields as include/LibraryFormat.hpp:7-9
+ * (type 0 SE / 1 PE; orientation 0 SAME, 1 AWAY, 2 TOWARD, 3 NONE; strandedness 0 SA, 1 AS, 2 S, 3 A, 4 U).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sfgpu_hit {
+    uint32_t tid;          /* QuasiAlignment::transcriptID() */
+    int32_t  pos;          /* h.pos */
+    int32_t  mate_pos;     /* h.matePos */
+    uint32_t frag_len;     /* h.fragLen */
+    uint16_t read_len;     /* h.readLen */
+    uint16_t mate_len;     /* h.mateLen */
+    uint8_t  fwd;          /* h.fwd */
+    uint8_t  mate_fwd;     /* h.mateIsFwd */
+    uint8_t  mate_status;  /* h.mateStatus */
+    uint8_t  pad_;
+} sfgpu_hit;               /* 24 bytes */
+typedef struct sfgpu_libfmt { uint8_t type, orientation, strandedness, pad_; } sfgpu_libfmt;
+typedef struct sfgpu_filter_opts {
+    uint32_t max_read_occs;     /* sfOpts.maxReadOccs */
+    uint32_t max_frag_len;      /* sfOpts.maxFragLen: size of the fragment-length histogram */
+    int32_t  paired_library;    /* 1: the paired-end loop (:215-417), 0: the single-end loop (:530-626) */
+    int32_t  discard_orphans;   /* !sfOpts.allowOrphans (:139) */
+    int32_t  ignore_compat;     /* sfOpts.ignoreLibCompat (:156) */
+    int32_t  enforce_compat;    /* sfOpts.enforceLibCompat (:160) */
+    int32_t  can_dovetail;      /* sfOpts.allowDovetail (:165) */
+    sfgpu_libfmt expected;      /* rl.format() (:163) */
+} sfgpu_filter_opts;
+typedef struct sfgpu_filter_stats {   /* all ACCUMULATED by the call */
+    uint64_t n_observed;        /* numObservedFragments */
+    uint64_t n_mapped;          /* validHits: reads handed to addGroup */
+    uint64_t total_hits;        /* totalHits (after the maxReadOccs / orphan cuts) */
+    uint64_t upper_bound_hits;  /* upperBoundHits: reads with at least one hit before the cuts */
+    uint64_t n_fwd, n_rc;       /* readExp.addNumFwd / addNumRC */
+    uint64_t fl_sampled;        /* fragment lengths added to the histogram by this call */
+} sfgpu_filter_stats;
+/* d_hits[d_hit_offsets[r] .. d_hit_offsets[r+1]) are read r's hits in the mapper's order (for orphans: left
+ * mate's hits first, each run ascending in tid, as mergeLeftRightHits leaves them).
+ * d_ids_out needs room for d_hit_offsets[n_reads] ids; d_offsets_out for n_reads + 1.
+ * d_fl_counts (max_frag_len uint32, may be NULL) and *remaining_fl_ops (may be NULL) carry the
+ * fragment-length histogram and its sample budget across calls: the first *remaining_fl_ops qualifying
+ * reads in read order are counted, exactly what one mapping thread does.  Synchronous. */
+SFGPU_API int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
+                      const sfgpu_filter_opts* opts, uint32_t* d_ids_out, uint32_t* d_offsets_out,
+                      uint32_t* d_fl_counts, int64_t* remaining_fl_ops, sfgpu_filter_stats* stats, sfgpu_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a13. quant.sf columns   src/GZipWriter.cpp:216-245
  *   TPM_t = ((estCount_t/numMapped)/len_t) / sum_u((estCount_u/numMapped)/len_u) * 1e6
  * d_len as in sfgpu_problem.  Asynchronous on `stream`.

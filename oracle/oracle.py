@@ -191,6 +191,64 @@ def gibbs(eff_len, mass, rowptr, ids, counts, num_mapped, S, seed=1):
 
 
 # --- the compiled reference (oracle/_ref), when present -------------------------------------
+HIT_DTYPE = np.dtype([("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"), ("read_len", "<u2"),
+                      ("mate_len", "<u2"), ("fwd", "u1"), ("mate_fwd", "u1"), ("mate_status", "u1"), ("pad_", "u1")])
+
+
+class _LibFmt(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("orientation", C.c_uint8), ("strandedness", C.c_uint8), ("pad_", C.c_uint8)]
+
+
+class _FilterOpts(C.Structure):
+    _fields_ = [("max_read_occs", C.c_uint32), ("max_frag_len", C.c_uint32), ("paired_library", C.c_int32),
+                ("discard_orphans", C.c_int32), ("ignore_compat", C.c_int32), ("enforce_compat", C.c_int32),
+                ("can_dovetail", C.c_int32), ("expected", _LibFmt)]
+
+
+class _FilterStats(C.Structure):
+    _fields_ = [("n_observed", C.c_uint64), ("n_mapped", C.c_uint64), ("total_hits", C.c_uint64),
+                ("upper_bound_hits", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("fl_sampled", C.c_uint64)]
+
+
+def compatible_single(fmt, is_forward, mate_status):
+    """compatibleHit(expected, start, isForward, ms) (src/SailfishUtils.cpp:157-207); fmt = (type, orientation, strandedness)"""
+    L = lib(); L.sfo_compatible_single.argtypes = [_LibFmt, C.c_int, C.c_int]; L.sfo_compatible_single.restype = C.c_int
+    return bool(L.sfo_compatible_single(_LibFmt(*fmt, 0), int(is_forward), int(mate_status)))
+
+
+def hit_type(end1_start, end1_fwd, len1, end2_start, end2_fwd, len2, can_dovetail):
+    """hitType (src/SailfishUtils.cpp:232-281) -> (type, orientation, strandedness)"""
+    L = lib(); L.sfo_hit_type.argtypes = [C.c_int32, C.c_int, C.c_uint32, C.c_int32, C.c_int, C.c_uint32, C.c_int]
+    L.sfo_hit_type.restype = _LibFmt
+    f = L.sfo_hit_type(int(end1_start), int(end1_fwd), int(len1), int(end2_start), int(end2_fwd), int(len2), int(can_dovetail))
+    return (f.type, f.orientation, f.strandedness)
+
+
+def compatible_pair(expected, observed):
+    """compatibleHit(expected, observed) (src/SailfishUtils.cpp:210-229)"""
+    L = lib(); L.sfo_compatible_pair.argtypes = [_LibFmt, _LibFmt]; L.sfo_compatible_pair.restype = C.c_int
+    return bool(L.sfo_compatible_pair(_LibFmt(*expected, 0), _LibFmt(*observed, 0)))
+
+
+def filter_hits(hits, hit_off, fmt, paired_library, discard_orphans=True, ignore_compat=False, enforce_compat=False,
+                can_dovetail=False, max_read_occs=200, max_frag_len=1000, fl_counts=None, remaining_fl_ops=0):
+    """the per-read loop bodies of processReadsQuasi (src/SailfishQuantify.cpp:215-417, 530-626), serial.
+    Returns (ids, offsets, fl_counts, remaining_fl_ops, stats dict)."""
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE); off = _c(hit_off, np.uint32)
+    R = len(off) - 1
+    ids = np.zeros(max(len(h), 1), np.uint32); out_off = np.zeros(R + 1, np.uint32)
+    fl = np.zeros(max_frag_len, np.uint32) if fl_counts is None else _c(fl_counts, np.uint32).copy()
+    o = _FilterOpts(max_read_occs, max_frag_len, int(paired_library), int(discard_orphans), int(ignore_compat),
+                    int(enforce_compat), int(can_dovetail), _LibFmt(*fmt, 0))
+    st = _FilterStats(); rem = C.c_int64(int(remaining_fl_ops))
+    L = lib()
+    L.sfo_filter_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_FilterOpts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_int64), C.POINTER(_FilterStats)]
+    L.sfo_filter_hits.restype = None
+    L.sfo_filter_hits(h.ctypes.data, _p(off), R, C.byref(o), _p(ids), _p(out_off), _p(fl), C.byref(rem), C.byref(st))
+    return ids[: out_off[-1]], out_off, fl, int(rem.value), {k: int(getattr(st, k)) for k, _ in _FilterStats._fields_}
+
+
 def ref_xxhash():
     """ctypes handle on the reference's own xxhash.c (oracle/_ref/libxxhash_ref.so) or None."""
     so = os.path.join(_HERE, "_ref", "libxxhash_ref.so")

@@ -602,3 +602,138 @@ SFO_API int sfo_gibbs(uint64_t M, const double* eff_in, const double* mass_in,
     free(eff); free(w); free(mass); free(cmap); free(pmap); free(z); free(res);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * (next) per-read hit filtering, restated literally: the loop bodies of processReadsQuasi
+ * (src/SailfishQuantify.cpp:215-417 paired end, :530-626 single end) with their running txpIDsAll /
+ * txpIDsCompat / haveCompat state, std::partition_point + std::inplace_merge for orphans, and
+ * sailfish::utils::compatibleHit / hitType (src/SailfishUtils.cpp:157-289).  Bias / GC sampling is not part
+ * of the path.  Serial, i.e. what ONE mapping thread does with the reads in order.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t tid; int32_t pos; int32_t mate_pos; uint32_t frag_len; uint16_t read_len; uint16_t mate_len;
+                 uint8_t fwd, mate_fwd, mate_status, pad_; } sfo_hit;
+typedef struct { uint8_t type, orientation, strandedness, pad_; } sfo_libfmt;
+typedef struct { uint32_t max_read_occs, max_frag_len; int32_t paired_library, discard_orphans, ignore_compat, enforce_compat,
+                 can_dovetail; sfo_libfmt expected; } sfo_filter_opts;
+typedef struct { uint64_t n_observed, n_mapped, total_hits, upper_bound_hits, n_fwd, n_rc, fl_sampled; } sfo_filter_stats;
+enum { SFO_MS_SINGLE = 0, SFO_MS_LEFT = 1, SFO_MS_RIGHT = 2, SFO_MS_PAIRED = 3 };
+enum { SFO_OR_SAME = 0, SFO_OR_AWAY = 1, SFO_OR_TOWARD = 2, SFO_OR_NONE = 3 };
+enum { SFO_ST_SA = 0, SFO_ST_AS = 1, SFO_ST_S = 2, SFO_ST_A = 3, SFO_ST_U = 4 };
+
+/* compatibleHit(LibraryFormat expected, int32_t start, bool isForward, MateStatus ms)   SailfishUtils.cpp:157-207 */
+SFO_API int sfo_compatible_single(sfo_libfmt expected, int is_forward, int ms) {
+    int es = expected.strandedness;
+    switch (ms) {
+        case SFO_MS_SINGLE:
+            if (is_forward) return es == SFO_ST_U || es == SFO_ST_S;
+            else return es == SFO_ST_U || es == SFO_ST_A;
+        case SFO_MS_LEFT:
+            if (expected.orientation == SFO_OR_SAME)
+                return es == SFO_ST_U || (es == SFO_ST_S && is_forward) || (es == SFO_ST_A && !is_forward);
+            else if (is_forward) return es == SFO_ST_U || es == SFO_ST_S;
+            else return es == SFO_ST_U || es == SFO_ST_A;
+        case SFO_MS_RIGHT:
+            if (expected.orientation == SFO_OR_SAME)
+                return es == SFO_ST_U || (es == SFO_ST_S && is_forward) || (es == SFO_ST_A && !is_forward);
+            else if (is_forward) return es == SFO_ST_U || es == SFO_ST_A;
+            else return es == SFO_ST_U || es == SFO_ST_S;
+        default:
+            return 0;
+    }
+}
+
+/* hitType(end1Start, end1Fwd, len1, end2Start, end2Fwd, len2, canDovetail)   SailfishUtils.cpp:232-281 */
+SFO_API sfo_libfmt sfo_hit_type(int32_t end1_start, int end1_fwd, uint32_t len1, int32_t end2_start, int end2_fwd, uint32_t len2,
+                                int can_dovetail) {
+    sfo_libfmt f; f.type = 1; f.pad_ = 0;
+    if (end1_fwd != end2_fwd) {
+        if (end1_fwd) {
+            int32_t stretch = can_dovetail ? (int32_t)len2 : 0;
+            f.orientation = (end1_start <= end2_start + stretch) ? SFO_OR_TOWARD : SFO_OR_AWAY; f.strandedness = SFO_ST_SA;
+        } else {
+            int32_t stretch = can_dovetail ? (int32_t)len1 : 0;
+            f.orientation = (end2_start <= end1_start + stretch) ? SFO_OR_TOWARD : SFO_OR_AWAY; f.strandedness = SFO_ST_AS;
+        }
+    } else {
+        f.orientation = SFO_OR_SAME; f.strandedness = end1_fwd ? SFO_ST_S : SFO_ST_A;
+    }
+    return f;
+}
+
+/* compatibleHit(LibraryFormat expected, LibraryFormat observed)   SailfishUtils.cpp:210-229 */
+SFO_API int sfo_compatible_pair(sfo_libfmt expected, sfo_libfmt observed) {
+    if (observed.type != 1) return 0;
+    if (expected.orientation != observed.orientation) return 0;
+    return expected.strandedness == SFO_ST_U || expected.strandedness == observed.strandedness;
+}
+
+SFO_API void sfo_filter_hits(const sfo_hit* hits, const uint32_t* hit_off, uint32_t n_reads, const sfo_filter_opts* o,
+                             uint32_t* ids_out, uint32_t* off_out, uint32_t* fl_counts, int64_t* remaining_fl_ops,
+                             sfo_filter_stats* st) {
+    uint32_t max_n = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) { uint32_t n = hit_off[r + 1] - hit_off[r]; if (n > max_n) max_n = n; }
+    sfo_hit* joint = (sfo_hit*)malloc((max_n ? max_n : 1) * sizeof(sfo_hit));
+    sfo_hit* tmp = (sfo_hit*)malloc((max_n ? max_n : 1) * sizeof(sfo_hit));
+    uint32_t* all = (uint32_t*)malloc((max_n ? max_n : 1) * 4);
+    uint32_t* compat_ids = (uint32_t*)malloc((max_n ? max_n : 1) * 4);
+    uint64_t w = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        size_t n = hit_off[r + 1] - hit_off[r];
+        memcpy(joint, hits + hit_off[r], n * sizeof(sfo_hit));
+        int mapped = 0, have_compat = 0;
+        size_t n_all = 0, n_compat = 0;
+        int32_t fw_all = 0, fw_compat = 0, rc_all = 0, rc_compat = 0;
+        st->upper_bound_hits += (n > 0);                                         /* :215 / :530 */
+        if (n > o->max_read_occs) n = 0;                                         /* :217 / :532 */
+        int is_paired = 0;
+        if (n > 0 && o->paired_library) {
+            is_paired = joint[0].mate_status == SFO_MS_PAIRED;                   /* :221 */
+            if (o->discard_orphans && !is_paired) n = 0;                         /* :226 */
+            if (!is_paired && n > 0) {                                           /* :231-246 */
+                size_t left_end = 0;                                             /* partition_point */
+                { size_t lo = 0, len = n; while (len > 0) { size_t half = len / 2; if (joint[lo + half].mate_status == SFO_MS_LEFT) { lo += half + 1; len -= half + 1; } else len = half; } left_end = lo; }
+                /* inplace_merge by transcriptID: stable, left run first on ties */
+                size_t i = 0, j = left_end, k = 0;
+                while (i < left_end && j < n) { if (joint[j].tid < joint[i].tid) tmp[k++] = joint[j++]; else tmp[k++] = joint[i++]; }
+                while (i < left_end) tmp[k++] = joint[i++];
+                while (j < n) tmp[k++] = joint[j++];
+                memcpy(joint, tmp, n * sizeof(sfo_hit));
+            }
+        }
+        for (size_t q = 0; q < n; ++q) {
+            const sfo_hit* h = &joint[q];
+            int compat = o->ignore_compat, fwd_hit;
+            if (o->paired_library && is_paired) {                                /* :341-368 */
+                if (!compat) {
+                    uint32_t end1 = h->fwd ? (uint32_t)h->pos : (uint32_t)h->pos + h->read_len;
+                    uint32_t end2 = h->mate_fwd ? (uint32_t)h->mate_pos : (uint32_t)h->mate_pos + h->mate_len;
+                    sfo_libfmt obs = sfo_hit_type((int32_t)end1, h->fwd, h->read_len, (int32_t)end2, h->mate_fwd, h->mate_len, o->can_dovetail);
+                    compat = sfo_compatible_pair(o->expected, obs);
+                }
+                fwd_hit = h->fwd;
+            } else {
+                if (!compat) compat = sfo_compatible_single(o->expected, h->fwd, h->mate_status);   /* :295-300 / :585-590 */
+                if (o->paired_library) {                                         /* :313-320 */
+                    fwd_hit = 0;
+                    if (h->mate_status == SFO_MS_LEFT) { if (h->fwd) fwd_hit = 1; }
+                    else if (h->mate_status == SFO_MS_RIGHT) { if (!h->fwd) fwd_hit = 1; }
+                } else fwd_hit = h->fwd;                                         /* :595 */
+            }
+            if (compat) { have_compat = 1; compat_ids[n_compat++] = h->tid; if (fwd_hit) fw_compat++; else rc_compat++; }
+            if (!have_compat && !o->enforce_compat) { all[n_all++] = h->tid; if (fwd_hit) fw_all++; else rc_all++; }
+        }
+        off_out[r] = (uint32_t)w;
+        if (have_compat) {                                                       /* :395-416 / :604-624 */
+            if (n_compat > 0) { mapped = 1; memcpy(ids_out + w, compat_ids, n_compat * 4); w += n_compat; st->n_fwd += fw_compat; st->n_rc += rc_compat; }
+        } else if (n_all > 0) { mapped = 1; memcpy(ids_out + w, all, n_all * 4); w += n_all; st->n_fwd += fw_all; st->n_rc += rc_all; }
+        if (o->paired_library && n == 1) {                                       /* :419-434 */
+            const sfo_hit* h = &joint[0];
+            if (h->mate_status == SFO_MS_PAIRED && remaining_fl_ops && *remaining_fl_ops > 0) {
+                if (mapped && h->frag_len < o->max_frag_len) { if (fl_counts) fl_counts[h->frag_len]++; (*remaining_fl_ops)--; st->fl_sampled++; }
+            }
+        }
+        st->n_mapped += mapped; st->total_hits += n; st->n_observed++;           /* :436-439 */
+    }
+    off_out[n_reads] = (uint32_t)w;
+    free(joint); free(tmp); free(all); free(compat_ids);
+}

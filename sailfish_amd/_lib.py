@@ -51,6 +51,21 @@ _lib = None
 _log_keepalive = None
 
 _P = C.c_void_p
+class LibFmt(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("orientation", C.c_uint8), ("strandedness", C.c_uint8), ("pad_", C.c_uint8)]
+
+
+class FilterOpts(C.Structure):
+    _fields_ = [("max_read_occs", C.c_uint32), ("max_frag_len", C.c_uint32), ("paired_library", C.c_int32),
+                ("discard_orphans", C.c_int32), ("ignore_compat", C.c_int32), ("enforce_compat", C.c_int32),
+                ("can_dovetail", C.c_int32), ("expected", LibFmt)]
+
+
+class FilterStats(C.Structure):
+    _fields_ = [("n_observed", C.c_uint64), ("n_mapped", C.c_uint64), ("total_hits", C.c_uint64),
+                ("upper_bound_hits", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("fl_sampled", C.c_uint64)]
+
+
 _SIGS = {
     "sfgpu_version": (C.c_int, []),
     "sfgpu_last_error": (C.c_char_p, []),
@@ -72,6 +87,8 @@ _SIGS = {
     "sfgpu_cf_counts": (C.c_int, [_P, C.c_uint32, _P]),
     "sfgpu_efflen_smoothed": (C.c_int, [_P, C.c_uint64, _P, C.c_uint32, _P, _P]),
     "sfgpu_efflen_empirical": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "sfgpu_filter_hits": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(FilterOpts), _P, _P, _P, C.POINTER(C.c_int64),
+                                    C.POINTER(FilterStats), _P]),
     "sfgpu_em_create": (C.c_int, [C.POINTER(_P), C.POINTER(Problem), _P]),
     "sfgpu_em_destroy": (C.c_int, [_P]),
     "sfgpu_em_optimize": (C.c_int, [_P, C.POINTER(EmOpts), _P, _P, C.POINTER(EmStats)]),

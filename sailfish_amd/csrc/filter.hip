@@ -1,0 +1,248 @@
+// filter.hip -- per-read hit filtering on the device (sfgpu_filter_hits).
+//
+// Replaces the per-read bodies of processReadsQuasi, src/SailfishQuantify.cpp:215-417 (paired end) and
+// :530-626 (single end), and sailfish::utils::compatibleHit / hitType, src/SailfishUtils.cpp:157-289.
+//
+// Shape: one lane per read.  What a read contributes is decided by two facts about its hit list -- how many
+// hits are compatible with the expected library type, and how many hits there are -- because the reference's
+// running "haveCompat" logic (:324-341) amounts to: the compatible hits in order if there is any, else every
+// hit in order (nothing when enforceLibCompat).  So pass 1 counts, an exclusive scan places the reads'
+// output lists, pass 2 walks the hits again and writes them.  Orphan hit lists (left mate's run, then the
+// right mate's) are visited in transcript order with a two-finger merge (:231-246) instead of being
+// rearranged.  The fragment-length sample budget (:419-434) is "the first N qualifying reads": a scan of
+// the qualifying flags gives every read its rank, so the histogram equals a single mapping thread's.
+#include "common.h"
+#include "primitives.h"
+
+namespace sfgpu {
+
+constexpr int kFilterBlock = 256;
+enum : uint8_t { MS_SINGLE = 0, MS_LEFT = 1, MS_RIGHT = 2, MS_PAIRED = 3 };
+enum : uint8_t { OR_SAME = 0, OR_AWAY = 1, OR_TOWARD = 2, OR_NONE = 3 };
+enum : uint8_t { ST_SA = 0, ST_AS = 1, ST_S = 2, ST_A = 3, ST_U = 4 };
+
+// compatibleHit(expected, start, isForward, ms) -- single-end reads and orphans (src/SailfishUtils.cpp:157-207)
+__device__ __forceinline__ bool compat_single(sfgpu_libfmt e, bool fwd, uint8_t ms) {
+    const uint8_t es = e.strandedness;
+    const bool same = e.orientation == OR_SAME;
+    switch (ms) {
+        case MS_SINGLE: return fwd ? (es == ST_U || es == ST_S) : (es == ST_U || es == ST_A);
+        case MS_LEFT:
+            if (same) return es == ST_U || (es == ST_S && fwd) || (es == ST_A && !fwd);
+            return fwd ? (es == ST_U || es == ST_S) : (es == ST_U || es == ST_A);
+        case MS_RIGHT:
+            if (same) return es == ST_U || (es == ST_S && fwd) || (es == ST_A && !fwd);
+            return fwd ? (es == ST_U || es == ST_A) : (es == ST_U || es == ST_S);
+        default: return false;      // "SHOULD NOT GET HERE"
+    }
+}
+
+// hitType (:232-281) followed by compatibleHit(expected, observed) (:210-229) for a proper pair
+__device__ __forceinline__ bool compat_pair(sfgpu_libfmt e, const sfgpu_hit& h, bool dovetail) {
+    const bool f1 = h.fwd != 0, f2 = h.mate_fwd != 0;
+    // :344-345: uint32 arithmetic, then passed as int32
+    const int32_t s1 = (int32_t)(f1 ? (uint32_t)h.pos : (uint32_t)h.pos + (uint32_t)h.read_len);
+    const int32_t s2 = (int32_t)(f2 ? (uint32_t)h.mate_pos : (uint32_t)h.mate_pos + (uint32_t)h.mate_len);
+    uint8_t oo, os;
+    if (f1 != f2) {
+        if (f1) { const int32_t stretch = dovetail ? (int32_t)h.mate_len : 0; oo = (s1 <= s2 + stretch) ? OR_TOWARD : OR_AWAY; os = ST_SA; }
+        else    { const int32_t stretch = dovetail ? (int32_t)h.read_len : 0; oo = (s2 <= s1 + stretch) ? OR_TOWARD : OR_AWAY; os = ST_AS; }
+    } else { oo = OR_SAME; os = f1 ? ST_S : ST_A; }
+    if (e.orientation != oo) return false;
+    return e.strandedness == ST_U || e.strandedness == os;
+}
+
+struct ReadView {
+    const sfgpu_hit* h; uint32_t n_raw, n;     // n: after the maxReadOccs / orphan cuts
+    bool paired_hits;                          // jointHits.front().mateStatus == PAIRED_END_PAIRED
+    uint32_t n_left;                           // orphans of a paired library: length of the left mate's run
+};
+
+// `hits` holds the records from global hit number `first` on: the global array (first = 0) or the block's LDS copy
+__device__ __forceinline__ ReadView view_read(const sfgpu_hit* hits, uint32_t first, const uint32_t* off, uint32_t r,
+                                              const sfgpu_filter_opts& o) {
+    ReadView v;
+    const uint32_t b = off[r];
+    v.h = hits + (b - first); v.n_raw = off[r + 1] - b; v.n = v.n_raw; v.paired_hits = false; v.n_left = 0;
+    if (v.n > o.max_read_occs) v.n = 0;                                   // :217 / :532
+    if (v.n && o.paired_library) {
+        v.paired_hits = v.h[0].mate_status == MS_PAIRED;                  // :221
+        if (o.discard_orphans && !v.paired_hits) v.n = 0;                 // :226
+        if (v.n && !v.paired_hits) while (v.n_left < v.n && v.h[v.n_left].mate_status == MS_LEFT) ++v.n_left;   // :233-237
+    }
+    return v;
+}
+
+// visit the read's hits in the order the reference's loop sees them; f(hit, compatible)
+template <typename F>
+__device__ __forceinline__ void for_each_hit(const ReadView& v, const sfgpu_filter_opts& o, F f) {
+    const bool dovetail = o.can_dovetail != 0, ignore = o.ignore_compat != 0;
+    if (o.paired_library && v.paired_hits) {
+        for (uint32_t i = 0; i < v.n; ++i) f(v.h[i], ignore || compat_pair(o.expected, v.h[i], dovetail));
+    } else if (o.paired_library) {
+        uint32_t i = 0, j = v.n_left;                                     // std::inplace_merge by transcriptID (:241-245): stable
+        while (i < v.n_left || j < v.n) {
+            const bool take_left = (j >= v.n) || (i < v.n_left && !(v.h[j].tid < v.h[i].tid));
+            const sfgpu_hit& h = take_left ? v.h[i++] : v.h[j++];
+            f(h, ignore || compat_single(o.expected, h.fwd != 0, h.mate_status));
+        }
+    } else {
+        for (uint32_t i = 0; i < v.n; ++i) f(v.h[i], ignore || compat_single(o.expected, v.h[i].fwd != 0, v.h[i].mate_status));
+    }
+}
+
+// "forward" for the strand counters: :313-320 for orphans, h.fwd otherwise (:328, :353, :595)
+__device__ __forceinline__ bool counts_as_fwd(const sfgpu_hit& h, bool orphan_of_pair) {
+    if (!orphan_of_pair) return h.fwd != 0;
+    return (h.mate_status == MS_LEFT && h.fwd) || (h.mate_status == MS_RIGHT && !h.fwd);
+}
+
+struct FilterCounters { unsigned long long mapped, total_hits, upper, fwd, rc; };
+
+// A block's reads own one contiguous range of hit records: it is copied to LDS with coalesced 8-byte loads and
+// the lanes then walk their hits there.  A lane walking 24-byte records in global memory makes every load
+// instruction touch 64 different cache lines (the same address-rate limit as in the class builder's passes).
+constexpr uint32_t kStageHits = 1536;                        // 36 KB: four 256-thread blocks per CU
+__device__ __forceinline__ const sfgpu_hit* stage_block_hits(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ off,
+                                                             uint32_t n_reads, sfgpu_hit* lds, uint32_t& first) {
+    first = 0;
+    const uint32_t r0 = blockIdx.x * kFilterBlock;
+    const uint32_t r1 = (r0 + kFilterBlock < n_reads) ? r0 + kFilterBlock : n_reads;
+    if (r0 >= n_reads) return hits;
+    const uint32_t h_lo = off[r0], h_hi = off[r1];
+    if (h_hi - h_lo > kStageHits) return hits;               // uniform: a block with unusually long hit lists reads global memory
+    const uint2* src = reinterpret_cast<const uint2*>(hits + h_lo);          // records are 24 bytes: 8-byte aligned
+    uint2* dst = reinterpret_cast<uint2*>(lds);
+    const uint32_t n8 = (h_hi - h_lo) * 3;
+    for (uint32_t i = threadIdx.x; i < n8; i += kFilterBlock) dst[i] = src[i];
+    __syncthreads();
+    first = h_lo;
+    return lds;
+}
+
+__global__ void __launch_bounds__(kFilterBlock)
+k_filter_count(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ off, uint32_t n_reads, sfgpu_filter_opts o,
+               uint32_t* __restrict__ out_len, uint32_t* __restrict__ fl_flag, FilterCounters* ctr) {
+    const uint32_t r = blockIdx.x * kFilterBlock + threadIdx.x;
+    unsigned long long mapped = 0, total = 0, upper = 0, nf = 0, nr = 0;
+    __shared__ __attribute__((aligned(8))) sfgpu_hit lds_hits[kStageHits];
+    uint32_t first_hit;
+    const sfgpu_hit* my_hits = stage_block_hits(hits, off, n_reads, lds_hits, first_hit);
+    if (r < n_reads) {
+        const ReadView v = view_read(my_hits, first_hit, off, r, o);
+        uint32_t n_compat = 0, fw_c = 0, fw_a = 0;
+        const bool orphan = o.paired_library && !v.paired_hits;
+        for_each_hit(v, o, [&](const sfgpu_hit& h, bool compat) {
+            const bool fw = counts_as_fwd(h, orphan);
+            if (compat) { ++n_compat; fw_c += fw; }
+            fw_a += fw;
+        });
+        const uint32_t len = n_compat ? n_compat : (o.enforce_compat ? 0u : v.n);
+        out_len[r] = len;
+        upper = v.n_raw > 0; total = v.n; mapped = len > 0;
+        if (len) { const uint32_t f = n_compat ? fw_c : fw_a; nf = f; nr = len - f; }
+        // :419-434: a unique, properly paired, mapped fragment shorter than maxFragLen is a length sample
+        uint32_t flag = 0;
+        if (fl_flag) {
+            if (o.paired_library && v.n == 1 && v.paired_hits && len > 0 && v.h[0].frag_len < o.max_frag_len) flag = 1;
+            fl_flag[r] = flag;
+        }
+    } else if (r == n_reads) { out_len[r] = 0; if (fl_flag) fl_flag[r] = 0; }     // scan sentinels
+    // block totals -> five atomics per block
+    __shared__ unsigned long long red[5][kFilterBlock / kWave];
+    unsigned long long v5[5] = {mapped, total, upper, nf, nr};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        unsigned long long x = v5[q];
+        for (int s = kWave / 2; s > 0; s >>= 1) x += __shfl_down(x, s, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[q][threadIdx.x / kWave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kFilterBlock / kWave; ++w) t += red[threadIdx.x][w];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + threadIdx.x, t);
+    }
+}
+
+__global__ void __launch_bounds__(kFilterBlock)
+k_filter_write(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ off, uint32_t n_reads, sfgpu_filter_opts o,
+               const uint64_t* __restrict__ out_off64, uint32_t* __restrict__ ids_out, uint32_t* __restrict__ off_out,
+               const uint32_t* __restrict__ fl_flag, const uint64_t* __restrict__ fl_rank, uint64_t fl_budget,
+               uint32_t* fl_counts) {
+    const uint32_t r = blockIdx.x * kFilterBlock + threadIdx.x;
+    __shared__ __attribute__((aligned(8))) sfgpu_hit lds_hits[kStageHits];
+    uint32_t first_hit;
+    const sfgpu_hit* my_hits = stage_block_hits(hits, off, n_reads, lds_hits, first_hit);
+    if (r > n_reads) return;
+    off_out[r] = (uint32_t)out_off64[r];
+    if (r == n_reads) return;
+    const uint32_t len = (uint32_t)(out_off64[r + 1] - out_off64[r]);
+    const ReadView v = view_read(my_hits, first_hit, off, r, o);
+    if (len) {
+        uint32_t* dst = ids_out + out_off64[r];
+        const bool only_compat = len != v.n;         // fewer outputs than hits: the compatible ones were counted
+        uint32_t k = 0;
+        // when every hit is kept either all are compatible or none is: no test needed
+        for_each_hit(v, o, [&](const sfgpu_hit& h, bool compat) { if (!only_compat || compat) dst[k++] = h.tid; });
+    }
+    if (fl_flag && fl_flag[r] && fl_rank[r] < fl_budget) atomicAdd(&fl_counts[v.h[0].frag_len], 1u);
+}
+
+}  // namespace sfgpu
+
+using namespace sfgpu;
+
+extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
+                                 const sfgpu_filter_opts* opts, uint32_t* d_ids_out, uint32_t* d_offsets_out,
+                                 uint32_t* d_fl_counts, int64_t* remaining_fl_ops, sfgpu_filter_stats* stats,
+                                 sfgpu_stream stream) {
+    SF_REQUIRE(d_hit_offsets && opts && d_offsets_out, SFGPU_ERR_INVALID, "sfgpu_filter_hits: null pointer");
+    SF_REQUIRE(n_reads < 0x7FFFFFFFu, SFGPU_ERR_RANGE, "sfgpu_filter_hits: a batch holds < 2^31 reads");
+    hipStream_t st = as_stream(stream);
+    if (n_reads == 0) { SF_HIP(hipMemsetAsync(d_offsets_out, 0, 4, st)); SF_HIP(hipStreamSynchronize(st)); return SFGPU_OK; }
+    SF_REQUIRE(d_hits && d_ids_out, SFGPU_ERR_INVALID, "sfgpu_filter_hits: null pointer");
+    const bool want_fl = d_fl_counts && remaining_fl_ops && *remaining_fl_ops > 0 && opts->paired_library && opts->max_frag_len > 0;
+    uint32_t *d_len = nullptr, *d_flag = nullptr; uint64_t *d_off64 = nullptr, *d_rank = nullptr; FilterCounters* d_ctr = nullptr;
+    const size_t n1 = (size_t)n_reads + 1;
+    int rc = SFGPU_OK;
+    hipError_t e = pool_malloc(&d_len, n1 * 4);
+    if (e == hipSuccess) e = pool_malloc(&d_off64, (n1 + 1) * 8);
+    if (e == hipSuccess) e = pool_malloc(&d_ctr, sizeof(FilterCounters));
+    if (e == hipSuccess && want_fl) e = pool_malloc(&d_flag, n1 * 4);
+    if (e == hipSuccess && want_fl) e = pool_malloc(&d_rank, (n1 + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ctr, 0, sizeof(FilterCounters), st);
+    const unsigned grid = (unsigned)((n1 + kFilterBlock - 1) / kFilterBlock);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_filter_count, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, d_len, d_flag, d_ctr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) rc = exclusive_scan_u32(d_len, d_off64, n_reads, st);
+    if (e == hipSuccess && rc == SFGPU_OK && want_fl) rc = exclusive_scan_u32(d_flag, d_rank, n_reads, st);
+    uint64_t h_tot[2] = {0, 0};
+    FilterCounters h_ctr{};
+    if (e == hipSuccess && rc == SFGPU_OK) {
+        e = hipMemcpyAsync(&h_tot[0], d_off64 + n_reads, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && want_fl) e = hipMemcpyAsync(&h_tot[1], d_rank + n_reads, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess && rc == SFGPU_OK && h_tot[0] >= (1ull << 32)) { set_error("sfgpu_filter_hits: the batch's output exceeds 2^32 ids"); rc = SFGPU_ERR_RANGE; }
+    const uint64_t budget = want_fl ? (uint64_t)*remaining_fl_ops : 0;
+    if (e == hipSuccess && rc == SFGPU_OK) {
+        hipLaunchKernelGGL(k_filter_write, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, d_off64,
+                           d_ids_out, d_offsets_out, d_flag, d_rank, budget, d_fl_counts);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    for (void* p : {(void*)d_len, (void*)d_off64, (void*)d_ctr, (void*)d_flag, (void*)d_rank}) if (p) pool_free(p);
+    SF_HIP(e);
+    if (rc) return rc;
+    const uint64_t sampled = want_fl ? (h_tot[1] < budget ? h_tot[1] : budget) : 0;
+    if (want_fl) *remaining_fl_ops -= (int64_t)sampled;
+    if (stats) {
+        stats->n_observed += n_reads; stats->n_mapped += h_ctr.mapped; stats->total_hits += h_ctr.total_hits;
+        stats->upper_bound_hits += h_ctr.upper; stats->n_fwd += h_ctr.fwd; stats->n_rc += h_ctr.rc; stats->fl_sampled += sampled;
+    }
+    return SFGPU_OK;
+}
