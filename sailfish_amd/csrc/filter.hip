@@ -6,8 +6,9 @@
 // Shape: one lane per read.  What a read contributes is decided by two facts about its hit list -- how many
 // hits are compatible with the expected library type, and how many hits there are -- because the reference's
 // running "haveCompat" logic (:324-341) amounts to: the compatible hits in order if there is any, else every
-// hit in order (nothing when enforceLibCompat).  So pass 1 counts, an exclusive scan places the reads'
-// output lists, pass 2 walks the hits again and writes them.  Orphan hit lists (left mate's run, then the
+// hit in order (nothing when enforceLibCompat).  So pass 1 counts and parks the kept ids at the read's input
+// offset, an exclusive scan places the reads' output lists, pass 2 moves the ids there (4 bytes per id instead
+// of a second read of the 24-byte records).  Orphan hit lists (left mate's run, then the
 // right mate's) are visited in transcript order with a two-finger merge (:231-246) instead of being
 // rearranged.  The fragment-length sample budget (:419-434) is "the first N qualifying reads": a scan of
 // the qualifying flags gives every read its rank, so the histogram equals a single mapping thread's.
@@ -122,7 +123,8 @@ __device__ __forceinline__ const sfgpu_hit* stage_block_hits(const sfgpu_hit* __
 
 __global__ void __launch_bounds__(kFilterBlock)
 k_filter_count(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ off, uint32_t n_reads, sfgpu_filter_opts o,
-               uint32_t* __restrict__ out_len, uint32_t* __restrict__ fl_flag, FilterCounters* ctr) {
+               uint32_t* __restrict__ out_len, uint32_t* __restrict__ kept, uint32_t* __restrict__ fl_flag,
+               uint32_t* __restrict__ fl_len, FilterCounters* ctr) {
     const uint32_t r = blockIdx.x * kFilterBlock + threadIdx.x;
     unsigned long long mapped = 0, total = 0, upper = 0, nf = 0, nr = 0;
     __shared__ __attribute__((aligned(8))) sfgpu_hit lds_hits[kStageHits];
@@ -130,12 +132,18 @@ k_filter_count(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ 
     const sfgpu_hit* my_hits = stage_block_hits(hits, off, n_reads, lds_hits, first_hit);
     if (r < n_reads) {
         const ReadView v = view_read(my_hits, first_hit, off, r, o);
-        uint32_t n_compat = 0, fw_c = 0, fw_a = 0;
+        uint32_t n_compat = 0, fw_c = 0, fw_a = 0, n_seen = 0;
         const bool orphan = o.paired_library && !v.paired_hits;
+        // The kept ids go to a scratch list at the read's INPUT offset (an upper bound of its output size):
+        // compatible hits are packed at the front as they are found, and while none has been found every hit
+        // is appended too -- the reference's txpIDsCompat / txpIDsAll (:324-341) sharing one buffer, since only
+        // one of the two survives.  Pass 2 then only moves 4-byte ids instead of re-reading 24-byte records.
+        uint32_t* mine = kept + off[r];
         for_each_hit(v, o, [&](const sfgpu_hit& h, bool compat) {
             const bool fw = counts_as_fwd(h, orphan);
-            if (compat) { ++n_compat; fw_c += fw; }
-            fw_a += fw;
+            if (compat) { mine[n_compat++] = h.tid; fw_c += fw; }
+            else if (n_compat == 0 && !o.enforce_compat) mine[n_seen] = h.tid;
+            ++n_seen; fw_a += fw;
         });
         const uint32_t len = n_compat ? n_compat : (o.enforce_compat ? 0u : v.n);
         out_len[r] = len;
@@ -144,7 +152,7 @@ k_filter_count(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ 
         // :419-434: a unique, properly paired, mapped fragment shorter than maxFragLen is a length sample
         uint32_t flag = 0;
         if (fl_flag) {
-            if (o.paired_library && v.n == 1 && v.paired_hits && len > 0 && v.h[0].frag_len < o.max_frag_len) flag = 1;
+            if (o.paired_library && v.n == 1 && v.paired_hits && len > 0 && v.h[0].frag_len < o.max_frag_len) { flag = 1; fl_len[r] = v.h[0].frag_len; }
             fl_flag[r] = flag;
         }
     } else if (r == n_reads) { out_len[r] = 0; if (fl_flag) fl_flag[r] = 0; }     // scan sentinels
@@ -165,28 +173,22 @@ k_filter_count(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ 
     }
 }
 
+// pass 2: move every read's kept ids from its input offset to its output offset; fragment-length samples
 __global__ void __launch_bounds__(kFilterBlock)
-k_filter_write(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ off, uint32_t n_reads, sfgpu_filter_opts o,
-               const uint64_t* __restrict__ out_off64, uint32_t* __restrict__ ids_out, uint32_t* __restrict__ off_out,
-               const uint32_t* __restrict__ fl_flag, const uint64_t* __restrict__ fl_rank, uint64_t fl_budget,
-               uint32_t* fl_counts) {
+k_filter_compact(const uint32_t* __restrict__ off, uint32_t n_reads, const uint32_t* __restrict__ kept,
+                 const uint64_t* __restrict__ out_off64, uint32_t* __restrict__ ids_out, uint32_t* __restrict__ off_out,
+                 const uint32_t* __restrict__ fl_flag, const uint32_t* __restrict__ fl_len, const uint64_t* __restrict__ fl_rank,
+                 uint64_t fl_budget, uint32_t* fl_counts) {
     const uint32_t r = blockIdx.x * kFilterBlock + threadIdx.x;
-    __shared__ __attribute__((aligned(8))) sfgpu_hit lds_hits[kStageHits];
-    uint32_t first_hit;
-    const sfgpu_hit* my_hits = stage_block_hits(hits, off, n_reads, lds_hits, first_hit);
     if (r > n_reads) return;
-    off_out[r] = (uint32_t)out_off64[r];
+    const uint64_t o0 = out_off64[r];
+    off_out[r] = (uint32_t)o0;
     if (r == n_reads) return;
-    const uint32_t len = (uint32_t)(out_off64[r + 1] - out_off64[r]);
-    const ReadView v = view_read(my_hits, first_hit, off, r, o);
-    if (len) {
-        uint32_t* dst = ids_out + out_off64[r];
-        const bool only_compat = len != v.n;         // fewer outputs than hits: the compatible ones were counted
-        uint32_t k = 0;
-        // when every hit is kept either all are compatible or none is: no test needed
-        for_each_hit(v, o, [&](const sfgpu_hit& h, bool compat) { if (!only_compat || compat) dst[k++] = h.tid; });
-    }
-    if (fl_flag && fl_flag[r] && fl_rank[r] < fl_budget) atomicAdd(&fl_counts[v.h[0].frag_len], 1u);
+    const uint32_t len = (uint32_t)(out_off64[r + 1] - o0);
+    const uint32_t* src = kept + off[r];
+    uint32_t* dst = ids_out + o0;
+    for (uint32_t k = 0; k < len; ++k) dst[k] = src[k];
+    if (fl_flag && fl_flag[r] && fl_rank[r] < fl_budget) atomicAdd(&fl_counts[fl_len[r]], 1u);
 }
 
 }  // namespace sfgpu
@@ -203,18 +205,24 @@ extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     if (n_reads == 0) { SF_HIP(hipMemsetAsync(d_offsets_out, 0, 4, st)); SF_HIP(hipStreamSynchronize(st)); return SFGPU_OK; }
     SF_REQUIRE(d_hits && d_ids_out, SFGPU_ERR_INVALID, "sfgpu_filter_hits: null pointer");
     const bool want_fl = d_fl_counts && remaining_fl_ops && *remaining_fl_ops > 0 && opts->paired_library && opts->max_frag_len > 0;
-    uint32_t *d_len = nullptr, *d_flag = nullptr; uint64_t *d_off64 = nullptr, *d_rank = nullptr; FilterCounters* d_ctr = nullptr;
+    uint32_t *d_len = nullptr, *d_flag = nullptr, *d_kept = nullptr, *d_fllen = nullptr;
+    uint64_t *d_off64 = nullptr, *d_rank = nullptr; FilterCounters* d_ctr = nullptr;
+    uint32_t n_hits = 0;
+    SF_HIP(hipMemcpyAsync(&n_hits, d_hit_offsets + n_reads, 4, hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
     const size_t n1 = (size_t)n_reads + 1;
     int rc = SFGPU_OK;
     hipError_t e = pool_malloc(&d_len, n1 * 4);
+    if (e == hipSuccess) e = pool_malloc(&d_kept, ((size_t)n_hits + 1) * 4);
     if (e == hipSuccess) e = pool_malloc(&d_off64, (n1 + 1) * 8);
     if (e == hipSuccess) e = pool_malloc(&d_ctr, sizeof(FilterCounters));
     if (e == hipSuccess && want_fl) e = pool_malloc(&d_flag, n1 * 4);
+    if (e == hipSuccess && want_fl) e = pool_malloc(&d_fllen, n1 * 4);
     if (e == hipSuccess && want_fl) e = pool_malloc(&d_rank, (n1 + 1) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(d_ctr, 0, sizeof(FilterCounters), st);
     const unsigned grid = (unsigned)((n1 + kFilterBlock - 1) / kFilterBlock);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_filter_count, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, d_len, d_flag, d_ctr);
+        hipLaunchKernelGGL(k_filter_count, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, d_len, d_kept, d_flag, d_fllen, d_ctr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) rc = exclusive_scan_u32(d_len, d_off64, n_reads, st);
@@ -230,12 +238,12 @@ extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     if (e == hipSuccess && rc == SFGPU_OK && h_tot[0] >= (1ull << 32)) { set_error("sfgpu_filter_hits: the batch's output exceeds 2^32 ids"); rc = SFGPU_ERR_RANGE; }
     const uint64_t budget = want_fl ? (uint64_t)*remaining_fl_ops : 0;
     if (e == hipSuccess && rc == SFGPU_OK) {
-        hipLaunchKernelGGL(k_filter_write, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, d_off64,
-                           d_ids_out, d_offsets_out, d_flag, d_rank, budget, d_fl_counts);
+        hipLaunchKernelGGL(k_filter_compact, dim3(grid), dim3(kFilterBlock), 0, st, d_hit_offsets, n_reads, d_kept, d_off64,
+                           d_ids_out, d_offsets_out, d_flag, d_fllen, d_rank, budget, d_fl_counts);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    for (void* p : {(void*)d_len, (void*)d_off64, (void*)d_ctr, (void*)d_flag, (void*)d_rank}) if (p) pool_free(p);
+    for (void* p : {(void*)d_len, (void*)d_off64, (void*)d_ctr, (void*)d_flag, (void*)d_rank, (void*)d_kept, (void*)d_fllen}) if (p) pool_free(p);
     SF_HIP(e);
     if (rc) return rc;
     const uint64_t sampled = want_fl ? (h_tot[1] < budget ? h_tot[1] : budget) : 0;

@@ -25,6 +25,6 @@ for it in range(3):
     out_ids, out_off, rem, st = sf.hits.filter_hits(hits, off, "IU", fl_counts=fl, remaining_fl_ops=10000, device=dev)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
 print(f"filter: {R} reads, {H} hits ({H*24/1e9:.2f} GB of records) in {dt*1e3:.2f} ms = {R/dt/1e9:.2f} G reads/s, "
-      f"{(2*H*24 + H*4 + R*16)/dt/1e12:.2f} TB/s of algorithmic traffic; stats {st}")
+      f"{(H*24 + out_ids.numel()*4 + R*8)/dt/1e12:.2f} TB/s on the algorithmic bytes (records once + ids out + offsets); stats {st}")
 eq = sf.EquivalenceClassBuilder(device=dev); eq.start(); eq.add_batch(out_ids, out_off); eq.finish()
 print("classes from the filtered lists:", eq.n_classes, "reads", eq.total_reads)
