@@ -923,10 +923,11 @@ int sfgpu_em_update(sfgpu_em* em) {
     return em_enqueue_update(em, false);
 }
 
-int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
-    SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_poll: null handle");
+// `with_max`: also fetch the per-block maxima behind stats->max_rel_diff.  The loop of optimize() only needs the
+// stop decision between chunks (one 48-byte copy); finish() fetches the maxima once at the end.
+static int em_poll_impl(sfgpu_em* em, int* done, sfgpu_em_stats* stats, bool with_max) {
     SF_HIP(hipMemcpyAsync(em->h_state, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
-    SF_HIP(hipMemcpyAsync(em->h_blkmax, em->blkmax, 2 * kMaxPartials * 8, hipMemcpyDeviceToHost, em->cur));
+    if (with_max) SF_HIP(hipMemcpyAsync(em->h_blkmax, em->blkmax, 2 * kMaxPartials * 8, hipMemcpyDeviceToHost, em->cur));
     SF_HIP(hipStreamSynchronize(em->cur));
     const EmState* h = em->h_state;
     uint32_t it = h->it_a;
@@ -935,6 +936,11 @@ int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
     if (done) *done = stop ? 1 : 0;
     em_stats_from_state(em, stats);
     return SFGPU_OK;
+}
+
+int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
+    SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_poll: null handle");
+    return em_poll_impl(em, done, stats, true);
 }
 
 int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats) {
@@ -1011,7 +1017,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
                 if ((rc = em_enqueue_update(em, true))) return rc;
             }
         }
-        if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+        if ((rc = em_poll_impl(em, &done, &st, false))) return rc;
     }
     SF_HIP(hipEventRecord(em->ev_b, em->cur));
     rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
