@@ -11,6 +11,13 @@
 #define CHECK(x) do { int _rc = (x); if (_rc) { fprintf(stderr, "%s -> %d: %s\n", #x, _rc, sfgpu_last_error()); return 1; } } while (0)
 #define HIPCHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(_e)); return 1; } } while (0)
 
+static int n_boot_cb = 0, n_gibbs_cb = 0;
+static int on_bootstrap(const double* alpha, uint64_t M, void* user) { (void)user; n_boot_cb += (M == 4 && alpha[0] >= 0.0); return 1; }
+static int on_gibbs(const int32_t* counts, uint64_t M, void* user) {
+    long tot = 0; for (uint64_t i = 0; i < M; ++i) tot += counts[i];
+    n_gibbs_cb += (tot == *(long*)user); return 1;
+}
+
 int main(void) {
     /* SURVEY 8c toy: lens [1000,2000,500,1500], classes {0}:100 {0,1}:300 {1,2}:50 {0,1,2}:25 {2}:10 */
     const uint32_t ref_len[4] = {1000, 2000, 500, 1500};
@@ -52,6 +59,39 @@ int main(void) {
     HIPCHECK(hipMemcpy(tpm, d_tpm, 32, hipMemcpyDeviceToHost));
     printf("iters %u alpha %.17g %.17g %.17g %.17g tpm_sum %.6f\n", st.iters, alpha[0], alpha[1], alpha[2], alpha[3],
            tpm[0] + tpm[1] + tpm[2] + tpm[3]);
+
+    /* the rest of the ABI from C: posterior samplers with their writer hooks, the effective-length helpers and
+     * the hit-filtering stage in front of the path */
+    CHECK(sfgpu_bootstrap(em, &o, 3, 7, NULL, on_bootstrap, NULL, NULL));
+    long n_frags = (long)total;
+    CHECK(sfgpu_gibbs_sample(&prob, d_mass, 4, 0, 7, NULL, on_gibbs, &n_frags, NULL));
+    double cf[1000];
+    CHECK(sfgpu_cf_gaussian(1000, 200, 80, cf));
+    CHECK(sfgpu_efflen_smoothed(d_ref, 4, cf, 1000, d_eff, NULL));
+    HIPCHECK(hipMemcpy(eff, d_eff, 32, hipMemcpyDeviceToHost));
+    uint32_t flc[1000]; memset(flc, 0, sizeof flc); flc[180] = 30; flc[220] = 50; flc[400] = 20;
+    CHECK(sfgpu_efflen_empirical(flc, 1000, d_ref, 4, d_alpha /* reuse */, NULL));
+    double eff_emp[4]; HIPCHECK(hipMemcpy(eff_emp, d_alpha, 32, hipMemcpyDeviceToHost));
+    sfgpu_hit recs[4] = {{3, 10, 200, 240, 50, 50, 1, 0, 3, 0}, {9, 10, 200, 240, 50, 50, 0, 1, 3, 0},   /* read 0: ISF keeps tid 3 */
+                         {4, 10, 200, 260, 50, 50, 1, 0, 3, 0},                                          /* read 1: unique pair */
+                         {6, 0, 0, 0, 50, 50, 1, 0, 1, 0}};                                              /* read 2: an orphan, dropped */
+    uint32_t roff[4] = {0, 2, 3, 4};
+    sfgpu_hit* d_recs; uint32_t *d_roff, *d_fids, *d_foff, *d_fl;
+    HIPCHECK(hipMalloc((void**)&d_recs, sizeof recs)); HIPCHECK(hipMalloc((void**)&d_roff, 16));
+    HIPCHECK(hipMalloc((void**)&d_fids, 16)); HIPCHECK(hipMalloc((void**)&d_foff, 16)); HIPCHECK(hipMalloc((void**)&d_fl, 4000));
+    HIPCHECK(hipMemcpy(d_recs, recs, sizeof recs, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(d_roff, roff, 16, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(d_fl, 0, 4000));
+    sfgpu_filter_opts fo = {200, 1000, 1, 1, 0, 0, 0, {1, 2, 0, 0}};       /* paired library, orphans discarded, ISF */
+    sfgpu_filter_stats fs; memset(&fs, 0, sizeof fs);
+    int64_t budget = 10;
+    CHECK(sfgpu_filter_hits(d_recs, d_roff, 3, &fo, d_fids, d_foff, d_fl, &budget, &fs, NULL));
+    uint32_t fids[4], foff[4];
+    HIPCHECK(hipMemcpy(fids, d_fids, 16, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(foff, d_foff, 16, hipMemcpyDeviceToHost));
+    int extras_ok = n_boot_cb == 3 && n_gibbs_cb == 4 && eff[0] > 790.0 && eff[0] < 810.0 && eff_emp[1] > 1700.0 && eff_emp[1] < 1800.0 &&
+                    foff[0] == 0 && foff[1] == 1 && foff[2] == 2 && foff[3] == 2 && fids[0] == 3 && fids[1] == 4 &&
+                    fs.n_observed == 3 && fs.n_mapped == 2 && fs.fl_sampled == 1 && budget == 9;
+    printf("extras %s (boot %d gibbs %d eff %.3f emp %.3f mapped %llu)\n", extras_ok ? "ok" : "FAILED", n_boot_cb, n_gibbs_cb, eff[0], eff_emp[1],
+           (unsigned long long)fs.n_mapped);
     sfgpu_em_destroy(em); sfgpu_eq_destroy(eq);
-    return 0;
+    return extras_ok ? 0 : 2;
 }

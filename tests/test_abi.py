@@ -107,3 +107,4 @@ def test_c_host_runs_the_toy_kat(built, tmp_path):
     for g, w in zip(got, want):
         assert abs(g - w) <= 1e-12 * max(1.0, abs(w))
     assert abs(float(f[8]) - 1e6) < 1e-3
+    assert "extras ok" in out        # bootstrap / Gibbs hooks, effective-length helpers and hit filtering, called from C
