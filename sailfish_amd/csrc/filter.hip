@@ -203,13 +203,14 @@ extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     SF_REQUIRE(n_reads < 0x7FFFFFFFu, SFGPU_ERR_RANGE, "sfgpu_filter_hits: a batch holds < 2^31 reads");
     hipStream_t st = as_stream(stream);
     if (n_reads == 0) { SF_HIP(hipMemsetAsync(d_offsets_out, 0, 4, st)); SF_HIP(hipStreamSynchronize(st)); return SFGPU_OK; }
-    SF_REQUIRE(d_hits && d_ids_out, SFGPU_ERR_INVALID, "sfgpu_filter_hits: null pointer");
+
     const bool want_fl = d_fl_counts && remaining_fl_ops && *remaining_fl_ops > 0 && opts->paired_library && opts->max_frag_len > 0;
     uint32_t *d_len = nullptr, *d_flag = nullptr, *d_kept = nullptr, *d_fllen = nullptr;
     uint64_t *d_off64 = nullptr, *d_rank = nullptr; FilterCounters* d_ctr = nullptr;
     uint32_t n_hits = 0;
     SF_HIP(hipMemcpyAsync(&n_hits, d_hit_offsets + n_reads, 4, hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
+    SF_REQUIRE(n_hits == 0 || (d_hits && d_ids_out), SFGPU_ERR_INVALID, "sfgpu_filter_hits: null pointer");
     const size_t n1 = (size_t)n_reads + 1;
     int rc = SFGPU_OK;
     hipError_t e = pool_malloc(&d_len, n1 * 4);

@@ -141,6 +141,11 @@ def test_filter_hits_device_vs_oracle(built, gpu):
         np.testing.assert_array_equal(gi.cpu().numpy().view(np.uint32), oi)
         np.testing.assert_array_equal(d_fl.cpu().numpy().view(np.uint32), ofl)
         assert grem == orem and gst == ost, (trial, name, kw, gst, ost)
+    # reads without any hit at all, and an empty batch
+    gi, go, _, gst = sf.hits.filter_hits(np.zeros(0, O.HIT_DTYPE), np.zeros(6, np.uint32), "U", device=gpu)
+    assert gi.numel() == 0 and go.cpu().tolist() == [0] * 6 and gst["n_observed"] == 5 and gst["n_mapped"] == 0
+    gi, go, _, gst = sf.hits.filter_hits(np.zeros(0, O.HIT_DTYPE), np.zeros(1, np.uint32), "U", device=gpu)
+    assert gi.numel() == 0 and go.cpu().tolist() == [0] and gst["n_observed"] == 0
     # the filtered lists feed the class builder without leaving the device
     h, off = _random_reads(rng, 120_000, 300, True)
     oi, oo, *_ = O.filter_hits(h, off, FORMATS["IU"], True, discard_orphans=False)
