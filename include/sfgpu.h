@@ -35,7 +35,8 @@ enum {
                                 src/CollapsedEMOptimizer.cpp:794-798 */
     SFGPU_ERR_ALPHA_SUM = 4, /* "total alpha weight was too small" -- :877-881 */
     SFGPU_ERR_RANGE = 5,     /* a size exceeds what the device layout holds (see each call) */
-    SFGPU_ERR_STATE = 6      /* call order violated (e.g. export before finish) */
+    SFGPU_ERR_STATE = 6,     /* call order violated (e.g. export before finish) */
+    SFGPU_ERR_UNSUPPORTED = 7 /* an option of the reference this build does not implement (see each call) */
 };
 
 typedef void* sfgpu_stream;          /* hipStream_t */
@@ -289,6 +290,73 @@ typedef struct sfgpu_filter_stats {   /* all ACCUMULATED by the call */
 SFGPU_API int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
                       const sfgpu_filter_opts* opts, uint32_t* d_ids_out, uint32_t* d_offsets_out,
                       uint32_t* d_fl_counts, int64_t* remaining_fl_ops, sfgpu_filter_stats* stats, sfgpu_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (next) Bias-aware effective lengths: sailfish::utils::updateEffectiveLengths
+ * (src/SailfishUtils.cpp:611-926) -- the sequence-specific (--biasCorrect; 6-mer context model,
+ * include/ReadKmerDist.hpp, include/UtilityFunctions.hpp:40-148) and fragment-GC (--gcBiasCorrect;
+ * Transcript::gcFrac, include/Transcript.hpp:85-95) corrections -- and the optimize() variant that calls it
+ * at iterations 50, 500 and 1000 (src/CollapsedEMOptimizer.cpp:814-840) and hands the corrected lengths back
+ * (:888).  A handle holds what the function reads from ReadExperiment / SailfishOpts and is constant over the
+ * run; sfgpu_bias_update is one call of updateEffectiveLengths.
+ *   d_seq / d_seq_off : RapMapSAIndex::seq on the device and txpOffsets (Transcript::Sequence() =
+ *                       seq + txpOffsets[i], include/ReadExperiment.hpp:115); bytes A C G T U in either case,
+ *                       any other byte counts as 'A' in a k-mer (what nextKmerIndex does; a first k-mer
+ *                       with such a byte is undefined behaviour in the reference)
+ *   d_txp_eff_len     : Transcript::EffectiveLength as the FLD correction left it (:703, :821)
+ *   h_fl_counts       : the vector ReadExperiment::setFragLengthDist received (counts of lengths
+ *                       0..max_frag_len-1); the EmpiricalDistribution is rebuilt from it
+ *   h_read_bias       : 4096 ReadKmerDist<6>::counts, pseudo-count included (may be NULL when !seq_bias)
+ *   h_observed_gc     : 101 ReadExperiment::observedGC counts, pseudo-count included (may be NULL when !gc_bias)
+ *   gc_speed_samp     : SailfishOpts::pdfSampFactor (--gcSpeedSamp)
+ *   gc_size_samp      : SailfishOpts::gcSampFactor (--gcSizeSamp); only 1 is implemented (the option trades
+ *                       accuracy for the memory of a per-base GC table this library does not keep, and its
+ *                       interpolated counts index outside the 101 bins in the reference): other values
+ *                       return SFGPU_ERR_UNSUPPORTED
+ * As in the reference, seq_bias and gc_bias together, or num_fwd + num_rc == 0, make every update a copy
+ * of its input (status 2 / 1).  GC correction needs fld_low >= 1 (the reference divides by the fragment
+ * length) and a 0.995 quantile below 16000 (SFGPU_ERR_RANGE).  Device memory: 808 bytes per transcript in
+ * GC mode (the per-transcript GC-bin profile, built once at create), else O(1).
+ * Floating point: sums run in a different order than the reference's serial loops (and the 4096-bin
+ * expectation is accumulated with atomics), so lengths agree to ~1e-12 relative, not bit for bit.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sfgpu_bias sfgpu_bias;
+typedef struct sfgpu_bias_inputs {
+    uint64_t M;
+    const char* d_seq;
+    const uint64_t* d_seq_off;      /* [M] */
+    const uint32_t* d_ref_len;      /* [M] */
+    const double* d_txp_eff_len;    /* [M] */
+    const uint32_t* h_fl_counts;    /* [max_frag_len] */
+    uint32_t max_frag_len;
+    uint32_t gc_speed_samp;
+    const uint32_t* h_read_bias;    /* [4096] */
+    const uint32_t* h_observed_gc;  /* [101] */
+    int64_t num_fwd, num_rc;        /* ReadExperiment::numFwd() / numRC() */
+    int32_t seq_bias, gc_bias;      /* SailfishOpts::biasCorrect / gcBiasCorrect */
+    uint32_t gc_size_samp;
+    uint32_t pad_;
+} sfgpu_bias_inputs;
+typedef struct sfgpu_bias_stats {
+    int32_t status;                 /* 0 recomputed, 1 no mappings (:625-630), 2 both models on (:633-638) */
+    int32_t fld_low, fld_high;      /* the 0.005 / 0.995 quantiles of the FLD (:669-681), GC mode */
+    int32_t pad_;
+    uint64_t n_corrected, n_uncorrected;   /* numCorrected / numUncorrected (:806-807) of the last update */
+} sfgpu_bias_stats;
+SFGPU_API int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_stream stream);
+SFGPU_API int sfgpu_bias_destroy(sfgpu_bias* b);
+/* effLensOut = updateEffectiveLengths(sopt, readExp, effLensIn, alphas); d_eff_out may alias d_eff_in.
+ * Asynchronous on `stream` when stats is NULL, else synchronises and fills *stats. */
+SFGPU_API int sfgpu_bias_update(sfgpu_bias* b, const double* d_eff_in, const double* d_alpha, double* d_eff_out,
+                      sfgpu_bias_stats* stats, sfgpu_stream stream);
+/* ReadExperiment::expectedSeqBias() (4096) / expectedGCBias() (101) after the last update (the aux/
+ * expected_bias, expected_gc files, src/GZipWriter.cpp:140-165); either pointer may be NULL.  Synchronous. */
+SFGPU_API int sfgpu_bias_expected(sfgpu_bias* b, double* h_expected_seq, double* h_expected_gc);
+/* CollapsedEMOptimizer::optimize with doBiasCorrect (:717): as sfgpu_em_optimize, plus the recompute hook
+ * at iterations 50, 500, 1000 and d_eff_len_out [M] = the lengths to store back into
+ * Transcript::EffectiveLength (:888; may be NULL).  n_recomputes (may be NULL) = hooks taken. */
+SFGPU_API int sfgpu_em_optimize_bias(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_bias* bias, double* d_alpha_out,
+                      double* d_mass_out, double* d_eff_len_out, uint32_t* n_recomputes, sfgpu_em_stats* stats);
 
 /* ---------------------------------------------------------------------------------------------
  * a13. quant.sf columns   src/GZipWriter.cpp:216-245

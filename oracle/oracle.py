@@ -53,6 +53,20 @@ def lib():
                                       C.c_uint64, C.c_int, C.c_double, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
         L.sfo_tpm.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.sfo_fld_cdf.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.sfo_index_for_kmer.restype = C.c_uint32
+        L.sfo_index_for_kmer.argtypes = [C.c_char_p, C.c_uint32, C.c_int]
+        L.sfo_next_kmer_index.restype = C.c_uint32
+        L.sfo_next_kmer_index.argtypes = [C.c_uint32, C.c_char, C.c_uint32, C.c_int]
+        L.sfo_gc_frac.restype = C.c_int32
+        L.sfo_gc_frac.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32]
+        L.sfo_update_efflens.restype = C.c_int
+        L.sfo_update_efflens.argtypes = [C.c_void_p] * 7
+        L.sfo_em_optimize_bias.restype = C.c_int
+        L.sfo_em_optimize_bias.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_uint64, C.c_int, C.c_double, C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
         L.sfo_bootstrap.restype = C.c_int
         L.sfo_bootstrap.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_double, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -163,6 +177,78 @@ def em_optimize(eff_len, rowptr, ids, counts, num_mapped, use_vbem=False, tol=0.
     stats = dict(iters=st.iters, converged=bool(st.converged), max_rel_diff=st.max_rel_diff,
                  alpha_sum=st.alpha_sum, n_active=st.n_active)
     return rc, alpha[:M], mass[:M], stats
+
+
+class BiasModel(C.Structure):
+    """sfo_bias_model: what updateEffectiveLengths reads from ReadExperiment / SailfishOpts."""
+    _fields_ = [("M", C.c_uint64), ("seq", C.c_void_p), ("seq_off", C.c_void_p), ("ref_len", C.c_void_p),
+                ("txp_eff_len", C.c_void_p), ("fl_counts", C.c_void_p), ("n_fl", C.c_uint32),
+                ("read_bias", C.c_void_p), ("observed_gc", C.c_void_p), ("num_fwd", C.c_int64),
+                ("num_rc", C.c_int64), ("seq_bias", C.c_int32), ("gc_bias", C.c_int32),
+                ("gc_speed_samp", C.c_uint32), ("gc_size_samp", C.c_uint32)]
+
+
+def make_bias_model(seq, seq_off, ref_len, txp_eff_len, fl_counts, read_bias=None, observed_gc=None,
+                    num_fwd=1, num_rc=1, seq_bias=False, gc_bias=False, gc_speed_samp=1, gc_size_samp=1):
+    """-> (BiasModel, keepalive list).  seq: bytes / uint8 array holding every transcript (RapMapSAIndex::seq)."""
+    sq = np.frombuffer(seq, dtype=np.uint8).copy() if isinstance(seq, (bytes, bytearray)) else _c(seq, np.uint8)
+    so = _c(seq_off, np.uint64); rl = _c(ref_len, np.uint32); te = _c(txp_eff_len, np.float64)
+    fl = _c(fl_counts, np.uint32)
+    rb = _c(read_bias if read_bias is not None else np.ones(4096), np.uint32)
+    og = _c(observed_gc if observed_gc is not None else np.ones(101), np.uint32)
+    assert len(rb) == 4096 and len(og) == 101 and len(so) == len(rl) == len(te)
+    bm = BiasModel(len(rl), _p(sq).value, _p(so).value, _p(rl).value, _p(te).value, _p(fl).value, len(fl),
+                   _p(rb).value, _p(og).value, int(num_fwd), int(num_rc), int(bool(seq_bias)), int(bool(gc_bias)),
+                   int(gc_speed_samp), int(gc_size_samp))
+    return bm, [sq, so, rl, te, fl, rb, og]
+
+
+def fld_cdf(fl_counts):
+    """EmpiricalDistribution::cdf(i) for i in [0, n) (src/EmpiricalDistribution.cpp:29-77, :121-124)
+    -> (float32[n], table size)."""
+    fl = _c(fl_counts, np.uint32); out = np.zeros(len(fl), np.float32); size = C.c_uint32(0)
+    lib().sfo_fld_cdf(_p(fl), len(fl), _p(out), C.byref(size)); return out, size.value
+
+
+def index_for_kmer(s: bytes, K=6, rc=False):
+    """indexForKmer (include/UtilityFunctions.hpp:93-148)."""
+    return int(lib().sfo_index_for_kmer(s, K, int(rc)))
+
+
+def next_kmer_index(idx, ch: bytes, K=6, rc=False):
+    """nextKmerIndex (include/UtilityFunctions.hpp:40-90)."""
+    return int(lib().sfo_next_kmer_index(idx, ch, K, int(rc)))
+
+
+def gc_frac(seq: bytes, s, e, step=1):
+    """Transcript::gcFrac over the closed interval [s,e] (include/Transcript.hpp:85-95)."""
+    return int(lib().sfo_gc_frac(seq, len(seq), step, s, e))
+
+
+def update_efflens(bm, eff_in, alphas):
+    """sailfish::utils::updateEffectiveLengths (src/SailfishUtils.cpp:611-926).
+    -> (rc, eff_out, expected_seq[4096], expected_gc[101], n_corrected)"""
+    model = bm[0] if isinstance(bm, tuple) else bm
+    ei = _c(eff_in, np.float64); al = _c(alphas, np.float64); out = np.zeros(len(ei))
+    es = np.ones(4096); eg = np.ones(101); nc = C.c_uint64(0)
+    rc = lib().sfo_update_efflens(C.byref(model), _p(ei), _p(al), _p(out), _p(es), _p(eg), C.byref(nc))
+    return rc, out, es, eg, nc.value
+
+
+def em_optimize_bias(bm, eff_len, rowptr, ids, counts, num_mapped, use_vbem=False, tol=0.01,
+                     min_iter=50, max_iter=10000):
+    """optimize() with biasCorrect / gcBiasCorrect (src/CollapsedEMOptimizer.cpp:711-893, hook :814-840).
+    -> (rc, alpha, mass, eff_final, expected_seq, expected_gc, n_recomputes, stats-dict)"""
+    model = bm[0] if isinstance(bm, tuple) else bm
+    eff = _c(eff_len, np.float64); rp = _c(rowptr, np.uint64); ii = _c(ids, np.uint32); cc = _c(counts, np.uint64)
+    M = len(eff); alpha = np.zeros(max(M, 1)); mass = np.zeros(max(M, 1)); efin = np.zeros(max(M, 1))
+    es = np.ones(4096); eg = np.ones(101); nr = C.c_uint32(0); st = EMStats()
+    rc = lib().sfo_em_optimize_bias(M, _p(eff), len(rp) - 1, _p(rp), _p(ii), _p(cc), int(num_mapped), int(use_vbem),
+                                    float(tol), int(min_iter), int(max_iter), C.byref(model), _p(alpha), _p(mass),
+                                    _p(efin), _p(es), _p(eg), C.byref(nr), C.byref(st))
+    stats = dict(iters=st.iters, converged=bool(st.converged), max_rel_diff=st.max_rel_diff,
+                 alpha_sum=st.alpha_sum, n_active=st.n_active)
+    return rc, alpha[:M], mass[:M], efin[:M], es, eg, nr.value, stats
 
 
 def tpm(est_count, length, num_mapped):

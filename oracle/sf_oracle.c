@@ -336,6 +336,365 @@ SFO_API void sfo_efflen_smoothed(const uint32_t* ref_len, uint64_t M, const doub
 }
 
 /* ------------------------------------------------------------------------------------------
+ * (f)-3. Bias-aware effective lengths: sailfish::utils::updateEffectiveLengths
+ * (src/SailfishUtils.cpp:611-926), with the pieces it reads:
+ *   - EmpiricalDistribution (src/EmpiricalDistribution.cpp:29-96, cdf() :121-124; pdf/cdf tables are
+ *     float, include/EmpiricalDistribution.hpp:62-63) built by ReadExperiment::setFragLengthDist
+ *     (include/ReadExperiment.hpp:160-167) from the counts of every length 0..n-1;
+ *   - indexForKmer / nextKmerIndex (include/UtilityFunctions.hpp:40-148), K = 6
+ *     (ReadKmerDist<6>, include/ReadExperiment.hpp:249);
+ *   - Transcript::computeGCContent_ / gcFrac / gcCountInterp_ (include/Transcript.hpp:85-199).
+ * PARITY UNPINNED against a reference binary or golden vectors: the reference's tests hold nothing for
+ * this function and it cannot be built here (RapMap/TBB/Boost); the restatement follows the source
+ * statement by statement, in its evaluation order.
+ * Where the reference has undefined behaviour this restatement makes a choice and says so:
+ *   - a first k-mer holding a non-ACGTU byte indexes transcriptKmerDist with 0xFFFFFFFF (:724-731);
+ *     here the function returns -1 (the index only stores ACGT; RapMap replaces N when indexing);
+ *   - with gcSizeSamp > 1 the interpolated counts of Transcript.hpp:133-162 are not monotone (lambda
+ *     weighs the LEFT sample), so gcFrac can leave [0,100] and index outside the 101 bins; here the
+ *     bin is clamped to [0,100].
+ * ---------------------------------------------------------------------------------------- */
+enum { SFO_K = 6, SFO_NKMER = 4096, SFO_NGC = 101 };
+
+typedef struct { float* pdf; float* cdf; uint32_t size; uint32_t min_val, max_val; } sfo_empdist;
+
+/* EmpiricalDistribution::buildDistribution with vals[i] == i (:29-77); the median is not needed here. */
+static void emp_build(const uint32_t* lens, uint32_t n, sfo_empdist* d) {
+    d->min_val = 0xFFFFFFFFu; d->max_val = 0;
+    double valsum = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i < d->min_val) d->min_val = i;
+        if (i > d->max_val) d->max_val = i;
+        valsum += lens[i];
+    }
+    double cumpr = 0.0;
+    uint32_t lastval = 0, maxval = 1;
+    for (; lastval < n; ++lastval) {
+        cumpr += lens[lastval] / valsum;
+        maxval = lastval;
+        if (cumpr > 1.0 - 1e-6) break;
+    }
+    d->size = maxval;
+    d->pdf = (float*)calloc(maxval ? maxval : 1, sizeof(float));
+    d->cdf = (float*)calloc(maxval ? maxval : 1, sizeof(float));
+    valsum = 0.0;
+    for (uint32_t i = 0; i < lastval; ++i) valsum += lens[i];
+    for (uint32_t val = 0; val < maxval; ++val) d->pdf[val] = (float)(lens[val] / valsum);
+    if (maxval) d->cdf[0] = d->pdf[0];
+    for (uint32_t val = 1; val < maxval; ++val) d->cdf[val] = d->cdf[val - 1] + d->pdf[val];   /* float adds */
+}
+static inline float emp_cdf(const sfo_empdist* d, uint32_t x) { return x < d->size ? d->cdf[x] : 1.0f; }
+
+SFO_API void sfo_fld_cdf(const uint32_t* fl_counts, uint32_t n, float* cdf_out /* [n] */, uint32_t* size_out) {
+    sfo_empdist d; emp_build(fl_counts, n, &d);
+    for (uint32_t i = 0; i < n; ++i) cdf_out[i] = emp_cdf(&d, i);
+    *size_out = d.size;
+    free(d.pdf); free(d.cdf);
+}
+
+/* include/UtilityFunctions.hpp:93-148.  dir: 0 = FORWARD, 1 = REVERSE_COMPLEMENT */
+SFO_API uint32_t sfo_index_for_kmer(const char* s, uint32_t K, int dir) {
+    uint32_t idx = 0;
+    if (dir == 0) {
+        for (int32_t i = 0; i < (int32_t)K; ++i) {
+            switch (s[i]) {
+                case 'A': case 'a': break;
+                case 'C': case 'c': idx += 1; break;
+                case 'G': case 'g': idx += 2; break;
+                case 'T': case 't': case 'U': case 'u': idx += 3; break;
+                default: return 0xFFFFFFFFu;
+            }
+            if (i < (int32_t)K - 1) idx <<= 2;
+        }
+    } else {
+        for (int32_t i = (int32_t)K - 1; i >= 0; --i) {
+            switch (s[i]) {
+                case 'T': case 't': case 'U': case 'u': break;
+                case 'C': case 'c': idx += 2; break;
+                case 'G': case 'g': idx += 1; break;
+                case 'A': case 'a': idx += 3; break;
+                default: return 0xFFFFFFFFu;
+            }
+            if (i > 0) idx <<= 2;
+        }
+    }
+    return idx;
+}
+
+/* include/UtilityFunctions.hpp:40-90 */
+SFO_API uint32_t sfo_next_kmer_index(uint32_t idx, char n, uint32_t K, int dir) {
+    idx <<= 2;
+    if (dir == 1) {
+        switch (n) {
+            case 'A': case 'a': n = 'T'; break;
+            case 'C': case 'c': n = 'G'; break;
+            case 'G': case 'g': n = 'C'; break;
+            case 'T': case 't': case 'U': case 'u': n = 'A'; break;
+            default: break;
+        }
+    }
+    switch (n) {
+        case 'C': case 'c': idx += 1; break;
+        case 'G': case 'g': idx += 2; break;
+        case 'T': case 't': case 'U': case 'u': idx += 3; break;
+        default: break;                       /* 'A' and every other byte add nothing */
+    }
+    return idx & (0xFFFFFFFFu >> (32 - 2 * K));
+}
+
+/* Transcript::computeGCContent_ / computeGCContentSampled_ (include/Transcript.hpp:164-199) */
+typedef struct {
+    uint32_t* cnt; size_t n; uint32_t step; double frac_len; uint32_t last_regular; uint32_t ref_len;
+} sfo_gc;
+
+static void gc_build(sfo_gc* g, const char* seq, uint32_t L, uint32_t step) {
+    g->ref_len = L; g->step = step; g->frac_len = 0.0; g->last_regular = 0;
+    g->cnt = (uint32_t*)malloc(((size_t)L + 2) * sizeof(uint32_t)); g->n = 0;
+    size_t tot = 0;
+    if (step == 1) {
+        for (size_t i = 0; i < L; ++i) {
+            char c = seq[i]; if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+            if (c == 'G' || c == 'C') ++tot;
+            g->cnt[g->n++] = (uint32_t)tot;
+        }
+    } else {
+        size_t last_samp = 0;
+        for (size_t i = 0; i < L; ++i) {
+            char c = seq[i]; if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+            if (c == 'G' || c == 'C') ++tot;
+            if (i % step == 0) { g->cnt[g->n++] = (uint32_t)tot; last_samp = i; }
+        }
+        if (last_samp < (size_t)L - 1) g->cnt[g->n++] = (uint32_t)tot;
+        g->frac_len = (double)(L - 1) / step;
+        g->last_regular = (uint32_t)ceil(g->frac_len);
+    }
+}
+
+/* gcCountInterp_ (:133-162) */
+static double gc_interp(const sfo_gc* g, int32_t p) {
+    if ((uint32_t)p == g->ref_len - 1) return (double)g->cnt[g->n - 1];
+    double frac_p = (double)p / g->step;
+    uint32_t samp = (uint32_t)floor(frac_p);
+    double frac_samp = (double)samp;
+    int32_t next; double frac_next;
+    if (samp >= g->last_regular) { next = (int32_t)g->n - 1; frac_next = g->frac_len; }
+    else { next = (int32_t)samp + 1; frac_next = (double)next; }
+    double lambda = (frac_p - frac_samp) / (frac_next - frac_samp);
+    return lambda * g->cnt[samp] + (1.0 - lambda) * g->cnt[next];
+}
+
+/* gcFrac over the closed interval [s,e] (:85-95); note cnt[e] - cnt[s] leaves base s itself out */
+static int32_t gc_frac(const sfo_gc* g, int32_t s, int32_t e) {
+    long r;
+    if (g->step == 1) {
+        uint32_t cs = g->cnt[s], ce = g->cnt[e];
+        r = lrint((100.0 * (ce - cs)) / (e - s + 1));
+    } else {
+        double cs = gc_interp(g, s), ce = gc_interp(g, e);
+        r = lrint((100.0 * (ce - cs)) / (e - s + 1));
+        if (r < 0) r = 0;                     /* reference: out-of-bounds index (see header) */
+        if (r > 100) r = 100;
+    }
+    return (int32_t)r;
+}
+
+SFO_API int32_t sfo_gc_frac(const char* seq, uint32_t L, uint32_t step, int32_t s, int32_t e) {
+    sfo_gc g; gc_build(&g, seq, L, step);
+    int32_t r = gc_frac(&g, s, e);
+    free(g.cnt);
+    return r;
+}
+
+typedef struct {
+    uint64_t M;
+    const char* seq;                /* RapMapSAIndex::seq */
+    const uint64_t* seq_off;        /* [M] txpOffsets */
+    const uint32_t* ref_len;        /* [M] */
+    const double* txp_eff_len;      /* [M] Transcript::EffectiveLength (the FLD-corrected lengths) */
+    const uint32_t* fl_counts; uint32_t n_fl;      /* ReadExperiment::setFragLengthDist input */
+    const uint32_t* read_bias;      /* [4096] ReadKmerDist<6>::counts (pseudo-count 1 included) */
+    const uint32_t* observed_gc;    /* [101] ReadExperiment::observedGC (pseudo-count 1 included) */
+    int64_t num_fwd, num_rc;
+    int32_t seq_bias, gc_bias;      /* SailfishOpts::biasCorrect / gcBiasCorrect */
+    uint32_t gc_speed_samp;         /* pdfSampFactor (--gcSpeedSamp) */
+    uint32_t gc_size_samp;          /* gcSampFactor (--gcSizeSamp) */
+} sfo_bias_model;
+
+/* Returns 0 = lengths recomputed, 1 = skipped, no mappings (:625-630), 2 = skipped, both models on
+ * (:633-638), -1 = invalid input.  exp_seq [4096] is always reset (:652-653); exp_gc [101] only when
+ * gc_bias (:665-667).  n_corrected may be NULL. */
+SFO_API int sfo_update_efflens(const sfo_bias_model* m, const double* eff_in, const double* alphas,
+                               double* eff_out, double* exp_seq, double* exp_gc, uint64_t* n_corrected) {
+    const double min_alpha = 1e-8;
+    const uint32_t gc_samp = m->gc_speed_samp;
+    const int gc_on = m->gc_bias != 0, seq_on = m->seq_bias != 0;
+    const uint64_t M = m->M;
+    int64_t num_mappings = m->num_fwd + m->num_rc;
+    if (n_corrected) *n_corrected = 0;
+    if (num_mappings == 0 || (gc_on && seq_on)) {
+        for (uint64_t t = 0; t < M; ++t) eff_out[t] = eff_in[t];
+        return num_mappings == 0 ? 1 : 2;
+    }
+    double prob_fwd = (double)m->num_fwd / num_mappings;
+    double prob_rc = (double)m->num_rc / num_mappings;
+
+    const int32_t K = SFO_K;
+    uint32_t tot32 = 0;                                          /* ReadKmerDist::totalCount sums in CountT */
+    for (int i = 0; i < SFO_NKMER; ++i) tot32 += m->read_bias[i];
+    double read_norm = (double)(uint64_t)tot32;
+    for (int i = 0; i < SFO_NKMER; ++i) exp_seq[i] = 1.0;        /* :652-653 */
+
+    sfo_empdist fld; emp_build(m->fl_counts, m->n_fl, &fld);
+    double read_gc_norm = 0.0;
+    int32_t fld_low = 0, fld_high = 1;
+    if (gc_on) {                                                 /* :664-686 */
+        for (int i = 0; i < SFO_NGC; ++i) exp_gc[i] = 1.0;
+        int first = 0, second = 0;
+        for (size_t i = 0; i <= fld.max_val; ++i) {
+            float density = emp_cdf(&fld, (uint32_t)i);
+            if (!first && density >= 0.005) { first = 1; fld_low = (int32_t)i; }
+            if (!second && density >= 0.995) { second = 1; fld_high = (int32_t)i; }
+        }
+        for (int i = 0; i < SFO_NGC; ++i) read_gc_norm += m->observed_gc[i];
+    }
+    const int32_t trunc = K;
+    int rc = 0;
+    sfo_gc* gcs = NULL;
+    if (gc_on && fld_low < 1) { rc = -1; goto done; }            /* gcFrac(i, i-1): division by zero in the reference */
+    if (gc_on) {
+        gcs = (sfo_gc*)calloc(M ? M : 1, sizeof(sfo_gc));
+        for (uint64_t t = 0; t < M; ++t) gc_build(&gcs[t], m->seq + m->seq_off[t], m->ref_len[t], m->gc_size_samp);
+    }
+
+    for (uint64_t it = 0; it < M; ++it) {                        /* :697-785 */
+        int32_t ref_len = (int32_t)m->ref_len[it];
+        int32_t elen = (int32_t)m->txp_eff_len[it];
+        int32_t unprocessed = ref_len - elen; if (unprocessed < 0) unprocessed = 0;
+        if (alphas[it] < min_alpha || unprocessed <= 0) continue;
+        double contribution = alphas[it] / eff_in[it];
+        const char* tseq = m->seq + m->seq_off[it];
+        int first_kmer = 1; uint32_t idx = 0;
+        for (int32_t i = ref_len - trunc - 1; i >= 0; --i) {
+            if (seq_on) {
+                if (first_kmer) {
+                    idx = sfo_index_for_kmer(tseq + i, K, 1); first_kmer = 0;
+                    if (idx == 0xFFFFFFFFu) { rc = -1; goto done; }
+                } else idx = sfo_next_kmer_index(idx, tseq[i], K, 1);
+                int32_t frag_start = i + 2;
+                int32_t max_frag = ref_len - frag_start + 1;
+                if (max_frag >= 0 && max_frag < ref_len)
+                    exp_seq[idx] += prob_fwd * contribution * emp_cdf(&fld, (uint32_t)max_frag);
+            }
+            if (gc_on) {
+                double prev_mass = emp_cdf(&fld, 0);
+                for (int32_t fl = fld_low; fl <= fld_high; fl += (int32_t)gc_samp) {
+                    int32_t fs = i, fe = i + fl - 1;
+                    if (fe < ref_len) {
+                        int32_t g = gc_frac(&gcs[it], fs, fe);
+                        exp_gc[g] += contribution * (emp_cdf(&fld, (uint32_t)fl) - prev_mass);
+                        prev_mass = emp_cdf(&fld, (uint32_t)fl);
+                    } else break;
+                }
+            }
+        }
+        first_kmer = 1; idx = 0;
+        if (seq_on) {
+            for (int32_t i = 0; i <= ref_len - trunc - 1; ++i) {
+                int32_t kmer_end = i + K - 1;
+                int32_t frag_start = i + 4;
+                if (first_kmer) {
+                    idx = sfo_index_for_kmer(tseq, K, 0); first_kmer = 0;
+                    if (idx == 0xFFFFFFFFu) { rc = -1; goto done; }
+                } else idx = sfo_next_kmer_index(idx, tseq[kmer_end], K, 0);
+                int32_t max_frag = frag_start + 1;
+                if (max_frag >= 0 && max_frag < ref_len)
+                    exp_seq[idx] += prob_rc * contribution * emp_cdf(&fld, (uint32_t)max_frag);
+            }
+        }
+    }
+
+    double txome_gc_norm = 0.0, gc_prior = 0.0;                  /* :788-803 */
+    if (gc_on) {
+        for (int i = 0; i < SFO_NGC; ++i) txome_gc_norm += exp_gc[i];
+        double pmass = 101.0;
+        gc_prior = ((pmass / (read_gc_norm - pmass)) * txome_gc_norm) / 101.0;
+    }
+    double txome_norm = 0.0, seq_prior = 0.0;
+    if (seq_on) {
+        for (int i = 0; i < SFO_NKMER; ++i) txome_norm += exp_seq[i];
+        double pmass = (double)SFO_NKMER;
+        seq_prior = ((pmass / (read_norm - pmass)) * txome_norm) / pmass;
+    }
+
+    for (uint64_t it = 0; it < M; ++it) {                        /* :810-923 */
+        double eff_length = 0.0;
+        int32_t ref_len = (int32_t)m->ref_len[it];
+        int32_t elen = (int32_t)m->txp_eff_len[it];
+        int32_t unprocessed = ref_len - elen; if (unprocessed < 0) unprocessed = 0;
+        if (alphas[it] >= min_alpha && unprocessed > 0) {
+            double* seq_f = (double*)calloc((size_t)ref_len + 1, sizeof(double));
+            double* gc_f = (double*)calloc((size_t)ref_len + 1, sizeof(double));
+            const char* tseq = m->seq + m->seq_off[it];
+            int first_kmer = 1; uint32_t idx = 0;
+            for (int32_t i = ref_len - trunc - 1; i >= 0; --i) {
+                if (seq_on) {
+                    int32_t frag_start = i + 2;
+                    if (first_kmer) { idx = sfo_index_for_kmer(tseq + i, K, 1); first_kmer = 0; }
+                    else idx = sfo_next_kmer_index(idx, tseq[i], K, 1);
+                    int32_t max_frag = ref_len - frag_start + 1;
+                    if (frag_start >= 0 && frag_start < ref_len)
+                        seq_f[frag_start] += prob_fwd * (m->read_bias[idx] / (exp_seq[idx] + seq_prior)) *
+                                             emp_cdf(&fld, (uint32_t)max_frag);
+                }
+                if (gc_on) {
+                    double prev_mass = emp_cdf(&fld, 0);
+                    for (int32_t fl = fld_low; fl <= fld_high; fl += (int32_t)gc_samp) {
+                        int32_t fs = i, fe = i + fl - 1;
+                        if (fe < ref_len) {
+                            int32_t g = gc_frac(&gcs[it], fs, fe);
+                            double sample_prob = (m->observed_gc[g] / (gc_prior + exp_gc[g])) *
+                                                 (emp_cdf(&fld, (uint32_t)fl) - prev_mass);
+                            prev_mass = emp_cdf(&fld, (uint32_t)fl);
+                            gc_f[fs] += sample_prob * prob_fwd;
+                            gc_f[fe] += sample_prob * prob_rc;
+                        } else break;
+                    }
+                }
+            }
+            first_kmer = 1; idx = 0;
+            if (seq_on) {
+                for (int32_t i = 0; i <= ref_len - trunc - 1; ++i) {
+                    int32_t kmer_end = i + K - 1;
+                    int32_t frag_start = i + 4;
+                    if (first_kmer) { idx = sfo_index_for_kmer(tseq, K, 0); first_kmer = 0; }
+                    else idx = sfo_next_kmer_index(idx, tseq[kmer_end], K, 0);
+                    int32_t max_frag = frag_start + 1;
+                    if (frag_start >= 0 && frag_start < ref_len)
+                        seq_f[frag_start] += prob_rc * (m->read_bias[idx] / (exp_seq[idx] + seq_prior)) *
+                                             emp_cdf(&fld, (uint32_t)max_frag);
+                }
+            }
+            if (seq_on) {                                        /* (seq && gc never both: returned above) */
+                for (int32_t i = 0; i < ref_len; ++i) eff_length += seq_f[i];
+                eff_length *= (txome_norm / read_norm);
+            } else if (gc_on) {
+                for (int32_t i = 0; i < ref_len; ++i) eff_length += gc_f[i];
+                eff_length *= (txome_gc_norm / read_gc_norm);
+            }
+            free(seq_f); free(gc_f);
+        }
+        if (unprocessed > 0.0 && eff_length > unprocessed) {
+            if (n_corrected) ++*n_corrected;
+            eff_out[it] = eff_length;
+        } else eff_out[it] = eff_in[it];
+    }
+done:
+    if (gcs) { for (uint64_t t = 0; t < M; ++t) free(gcs[t].cnt); free(gcs); }
+    free(fld.pdf); free(fld.cdf);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a6-a12. CollapsedEMOptimizer::optimize (src/CollapsedEMOptimizer.cpp:711-893) with
  * EMUpdate_ (:224-281) / VBEMUpdate_ (:288-369), restated serially in eqVec order, WITH the
  * stored, normalised aux weights exactly as the reference keeps them (:745-772).
@@ -408,11 +767,13 @@ static void vbem_update(uint64_t M, uint64_t C, const uint64_t* rowptr, const ui
     }
 }
 
-SFO_API int sfo_em_optimize(uint64_t M, const double* eff_in,
+static int em_optimize_impl(uint64_t M, const double* eff_in,
                             uint64_t C, const uint64_t* rowptr, const uint32_t* ids, const uint64_t* counts,
                             uint64_t num_mapped, int use_vbem, double tol,
                             uint32_t min_iter, uint32_t max_iter, int check_mode,
-                            double* alpha_out, double* mass_out, sfo_em_stats* st) {
+                            double* alpha_out, double* mass_out, sfo_em_stats* st,
+                            const sfo_bias_model* bm, double* eff_final, double* exp_seq, double* exp_gc,
+                            uint32_t* n_recomputes) {
     uint64_t L = rowptr[C];
     double* eff = (double*)malloc((M ? M : 1) * sizeof(double));
     double* w = (double*)malloc((L ? L : 1) * sizeof(double));
@@ -438,6 +799,14 @@ SFO_API int sfo_em_optimize(uint64_t M, const double* eff_in,
         double cutoff = use_vbem ? (prior + min_alpha) : min_alpha;
         uint32_t it = 0; int conv = 0; double max_rel = -DBL_MAX;
         while (it < min_iter || (it < max_iter && !conv)) {                 /* :820 */
+            if (bm && (it == 50 || it == 500 || it == 1000)) {              /* :814-840 recomputeIt */
+                double* eff_new = (double*)malloc((M ? M : 1) * sizeof(double));
+                int brc = sfo_update_efflens(bm, eff, a, eff_new, exp_seq, exp_gc, NULL);
+                if (brc < 0) { free(eff_new); rc = 3; goto done; }
+                memcpy(eff, eff_new, M * sizeof(double)); free(eff_new);
+                em_weights(C, rowptr, ids, counts, eff, w);                 /* updateEqClassWeights :527-555 */
+                if (n_recomputes) ++*n_recomputes;
+            }
             if (use_vbem) vbem_update(M, C, rowptr, ids, counts, w, prior, a, ap, et);
             else em_update(C, rowptr, ids, counts, w, a, ap);
             conv = 1; max_rel = -DBL_MAX;                                   /* :849-861 / :496-508 */
@@ -459,11 +828,35 @@ SFO_API int sfo_em_optimize(uint64_t M, const double* eff_in,
         for (uint64_t t = 0; t < M; ++t) {                                  /* :885-891 */
             alpha_out[t] = a[t];
             if (mass_out) mass_out[t] = a[t] / asum;
+            if (eff_final) eff_final[t] = eff[t];                           /* :888 EffectiveLength = effLens(i) */
         }
     }
 done:
     free(eff); free(w); free(a); free(ap); free(et); free(active);
     return rc;
+}
+
+SFO_API int sfo_em_optimize(uint64_t M, const double* eff_in,
+                            uint64_t C, const uint64_t* rowptr, const uint32_t* ids, const uint64_t* counts,
+                            uint64_t num_mapped, int use_vbem, double tol,
+                            uint32_t min_iter, uint32_t max_iter, int check_mode,
+                            double* alpha_out, double* mass_out, sfo_em_stats* st) {
+    return em_optimize_impl(M, eff_in, C, rowptr, ids, counts, num_mapped, use_vbem, tol, min_iter, max_iter,
+                            check_mode, alpha_out, mass_out, st, NULL, NULL, NULL, NULL, NULL);
+}
+
+/* optimize() with doBiasCorrect (:717, :814-840, :888): eff_in is what optimize() reads from the transcripts
+ * (bm->txp_eff_len, or RefLength under noEffectiveLengthCorrection); eff_final [M] receives the lengths the
+ * reference stores back into Transcript::EffectiveLength.  Extra return code 3 = invalid sequence byte. */
+SFO_API int sfo_em_optimize_bias(uint64_t M, const double* eff_in,
+                                 uint64_t C, const uint64_t* rowptr, const uint32_t* ids, const uint64_t* counts,
+                                 uint64_t num_mapped, int use_vbem, double tol,
+                                 uint32_t min_iter, uint32_t max_iter,
+                                 const sfo_bias_model* bm, double* alpha_out, double* mass_out, double* eff_final,
+                                 double* exp_seq, double* exp_gc, uint32_t* n_recomputes, sfo_em_stats* st) {
+    if (n_recomputes) *n_recomputes = 0;
+    return em_optimize_impl(M, eff_in, C, rowptr, ids, counts, num_mapped, use_vbem, tol, min_iter, max_iter,
+                            0, alpha_out, mass_out, st, bm, eff_final, exp_seq, exp_gc, n_recomputes);
 }
 
 /* ------------------------------------------------------------------------------------------

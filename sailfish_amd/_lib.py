@@ -11,7 +11,7 @@ import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to torc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFGPU_LIB_PATH", os.path.join(_HERE, "csrc", "libsfgpu.so"))   # override: kernel-tuning builds
 
-OK, ERR_INVALID, ERR_HIP, ERR_NO_ACTIVE, ERR_ALPHA_SUM, ERR_RANGE, ERR_STATE = range(7)
+OK, ERR_INVALID, ERR_HIP, ERR_NO_ACTIVE, ERR_ALPHA_SUM, ERR_RANGE, ERR_STATE, ERR_UNSUPPORTED = range(8)
 
 
 class SfgpuError(RuntimeError):
@@ -66,6 +66,23 @@ class FilterStats(C.Structure):
                 ("upper_bound_hits", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("fl_sampled", C.c_uint64)]
 
 
+class BiasInputs(C.Structure):
+    _fields_ = [("M", C.c_uint64), ("d_seq", C.c_void_p), ("d_seq_off", C.c_void_p), ("d_ref_len", C.c_void_p),
+                ("d_txp_eff_len", C.c_void_p), ("h_fl_counts", C.c_void_p), ("max_frag_len", C.c_uint32),
+                ("gc_speed_samp", C.c_uint32), ("h_read_bias", C.c_void_p), ("h_observed_gc", C.c_void_p),
+                ("num_fwd", C.c_int64), ("num_rc", C.c_int64), ("seq_bias", C.c_int32), ("gc_bias", C.c_int32),
+                ("gc_size_samp", C.c_uint32), ("pad_", C.c_uint32)]
+
+
+class BiasStats(C.Structure):
+    _fields_ = [("status", C.c_int32), ("fld_low", C.c_int32), ("fld_high", C.c_int32), ("pad_", C.c_int32),
+                ("n_corrected", C.c_uint64), ("n_uncorrected", C.c_uint64)]
+
+    def as_dict(self):
+        return dict(status=self.status, fld_low=self.fld_low, fld_high=self.fld_high,
+                    n_corrected=self.n_corrected, n_uncorrected=self.n_uncorrected)
+
+
 _SIGS = {
     "sfgpu_version": (C.c_int, []),
     "sfgpu_last_error": (C.c_char_p, []),
@@ -89,6 +106,11 @@ _SIGS = {
     "sfgpu_efflen_empirical": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "sfgpu_filter_hits": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(FilterOpts), _P, _P, _P, C.POINTER(C.c_int64),
                                     C.POINTER(FilterStats), _P]),
+    "sfgpu_bias_create": (C.c_int, [C.POINTER(_P), C.POINTER(BiasInputs), _P]),
+    "sfgpu_bias_destroy": (C.c_int, [_P]),
+    "sfgpu_bias_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(BiasStats), _P]),
+    "sfgpu_bias_expected": (C.c_int, [_P, _P, _P]),
+    "sfgpu_em_optimize_bias": (C.c_int, [_P, C.POINTER(EmOpts), _P, _P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(EmStats)]),
     "sfgpu_em_create": (C.c_int, [C.POINTER(_P), C.POINTER(Problem), _P]),
     "sfgpu_em_destroy": (C.c_int, [_P]),
     "sfgpu_em_optimize": (C.c_int, [_P, C.POINTER(EmOpts), _P, _P, C.POINTER(EmStats)]),

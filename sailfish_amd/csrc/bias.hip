@@ -1,0 +1,538 @@
+// bias.hip -- bias-aware effective lengths: sailfish::utils::updateEffectiveLengths,
+// /root/reference src/SailfishUtils.cpp:611-926, for gfx950.
+//
+// What the reference does, per call: (1) walk every expressed transcript and accumulate the EXPECTED
+// distribution of the bias feature under the current abundances -- the 6-mer context at a fragment start
+// (4096 bins, both strands) or the GC percentage of every (start, fragment length) pair (101 bins);
+// (2) turn observed / expected into a per-bin weight; (3) walk every transcript again and sum the weights of
+// all positions (x fragment lengths) into its new effective length.  The loops are serial over transcripts in
+// the reference.
+//
+// Device layout.
+//   Sequence model: O(sum of lengths) work.  k_seq_expected keeps the 4096 bins in LDS (f64 LDS atomics),
+//   one block striding over transcripts, and flushes each block's bins with global f64 atomics;
+//   k_seq_efflen is one block per transcript.  Each thread rebuilds its position's two 6-mer indices from the
+//   six bytes (the reference's rolling update gives the same value: a byte that is not ACGTU adds 0).
+//   GC model: O(sum of lengths x fragment lengths) -- 6e10 pairs for a human transcriptome.  The GC bin of
+//   a pair depends only on the sequence and the fragment-length grid, NOT on the abundances, and both passes
+//   of the reference weigh a pair by a factor that depends only on (bin, fragment length) x a per-transcript
+//   scalar.  So the pairs are counted ONCE per handle into a per-transcript profile
+//       S[t][g] = sum_k w_k * #{ i : gcFrac(i, i + fl_k - 1) == g },   w_k = cdf(fl_k) - cdf(fl_{k-1})
+//   (k_gc_profile: lane = fragment length, the block walks the positions; integer counters in LDS, one row of
+//   101 per lane so that lanes never share an address; GC prefix counts staged through LDS chunk by chunk),
+//   and every later update is two passes over S (808 bytes per transcript):
+//       expected[g] = 1 + sum_t (alpha_t / effLen_t) * S[t][g]            (k_gc_expected_*, fixed order)
+//       effLen'_t   = (sum_g observed[g] / (prior + expected[g]) * S[t][g]) * (probFwd + probRC) * norm
+//   gcFrac's lrint((100.0 * d) / fl) is evaluated in integers (round_half_even): 100 d / fl is a tie exactly
+//   when the double quotient is, and a non-tie is at least 1/(2 fl) away from one, far above an ulp.
+#include <cmath>
+#include <vector>
+
+#include "bias.h"
+#include "common.h"
+
+namespace sfgpu {
+namespace {
+
+constexpr int kK = 6;                      // ReadKmerDist<6>, include/ReadExperiment.hpp:249
+constexpr int kNKmer = 4096;
+constexpr int kNGC = 101;
+constexpr int kBlock = 256;
+constexpr double kMinAlphaBias = 1e-8;     // :618
+constexpr int kLanesFl = 64;               // fragment lengths per chunk of k_gc_profile: one per lane
+constexpr uint32_t kMaxFldHigh = 16000;
+constexpr int kSeqBlocks = 1024;
+constexpr int kGcRows = 256;               // transcripts per block of the GC expectation partial sums
+constexpr uint32_t kStageMin = 4096;       // GC prefix counts staged per chunk (words), at least
+
+struct BiasDev {
+    uint64_t M;
+    const char* seq; const uint64_t* seq_off; const uint32_t* ref_len; const double* txp_eff;
+    const float* cdf; uint32_t cdf_size;
+    const uint32_t* read_bias; const uint32_t* observed_gc;
+    double prob_fwd, prob_rc, read_norm, read_gc_norm;
+    const double* w; uint32_t nfl; int32_t fld_low; uint32_t gs; uint32_t stage_cap;
+    double* S;
+    double *exp_seq, *ratio_seq, *exp_gc, *ratio_gc, *gc_partial, *scal;   // scal[0] seq norm ratio, scal[1] gc norm ratio
+    unsigned long long* n_corrected;
+};
+
+__device__ __forceinline__ float cdf_at(const BiasDev& d, uint32_t x) { return x < d.cdf_size ? d.cdf[x] : 1.0f; }   // cdf() :121-124
+
+// :703-712 / :821-832  max(0, RefLength - (int32)EffectiveLength)
+__device__ __forceinline__ int unprocessed_len(uint32_t L, double txp_eff) {
+    int u = (int)L - (int)txp_eff;
+    return u > 0 ? u : 0;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+// deterministic block sum, result in every thread
+__device__ __forceinline__ double block_sum_all(double v, double* lds /* kBlock / kWave + 1 */) {
+    v = wave_sum(v);
+    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < kBlock / kWave; ++i) t += lds[i]; lds[kBlock / kWave] = t; }
+    __syncthreads();
+    double r = lds[kBlock / kWave];
+    __syncthreads();
+    return r;
+}
+
+// forward and reverse-complement 6-mer indices of s[0..5] (indexForKmer / nextKmerIndex,
+// include/UtilityFunctions.hpp:40-148): forward = first base most significant; reverse complement =
+// complement of s[5] most significant.  A byte outside ACGTU (either case) adds 0 to both.
+__device__ __forceinline__ void kmer_indices(const char* s, uint32_t& fwd, uint32_t& rc) {
+    uint32_t f = 0, r = 0;
+#pragma unroll
+    for (int j = 0; j < kK; ++j) {
+        const unsigned c = (unsigned char)s[j] & 0xDFu;
+        uint32_t code = 0, comp = 0;
+        if (c == 'A') { code = 0; comp = 3; }
+        else if (c == 'C') { code = 1; comp = 2; }
+        else if (c == 'G') { code = 2; comp = 1; }
+        else if (c == 'T' || c == 'U') { code = 3; comp = 0; }
+        f = (f << 2) | code;
+        r |= comp << (2 * j);
+    }
+    fwd = f; rc = r;
+}
+
+__global__ void k_fill(double* p, uint32_t n, double v) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- sequence-specific model ---------------------------------------------------------------------------
+// pass 1 (:697-785): transcriptKmerDist[idx] += probFwd * contribution * cdf(refLen - i - 1)   (context of a
+// fragment starting on the forward strand) and += probRC * contribution * cdf(i + 5) (reverse strand)
+__global__ void __launch_bounds__(kBlock) k_seq_expected(BiasDev d, const double* __restrict__ eff_in,
+                                                         const double* __restrict__ alpha) {
+    __shared__ double hist[kNKmer];
+    for (int j = threadIdx.x; j < kNKmer; j += kBlock) hist[j] = 0.0;
+    __syncthreads();
+    for (uint64_t t = blockIdx.x; t < d.M; t += gridDim.x) {
+        const uint32_t L = d.ref_len[t];
+        const double a = alpha[t];
+        if (a < kMinAlphaBias || unprocessed_len(L, d.txp_eff[t]) <= 0 || L <= (uint32_t)kK) continue;
+        const double contribution = a / eff_in[t];
+        const double cf = d.prob_fwd * contribution, cr = d.prob_rc * contribution;
+        const char* s = d.seq + d.seq_off[t];
+        const uint32_t n_pos = L - kK;
+        for (uint32_t i = threadIdx.x; i < n_pos; i += kBlock) {
+            uint32_t fw, rc;
+            kmer_indices(s + i, fw, rc);
+            atomicAdd(&hist[rc], cf * (double)cdf_at(d, L - i - 1));
+            if (i + 5 < L) atomicAdd(&hist[fw], cr * (double)cdf_at(d, i + 5));
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kNKmer; j += kBlock) { double v = hist[j]; if (v != 0.0) atomicAdd(&d.exp_seq[j], v); }
+}
+
+// :795-803  txomeNormFactor, seqPrior; ratio = readBias.counts / (transcriptKmerDist + seqPrior)
+__global__ void __launch_bounds__(kBlock) k_seq_norm(BiasDev d) {
+    __shared__ double lds[kBlock / kWave + 1];
+    double v = 0.0;
+    for (int j = threadIdx.x; j < kNKmer; j += kBlock) v += d.exp_seq[j];
+    const double txome = block_sum_all(v, lds);
+    const double pmass = (double)kNKmer;
+    const double prior = ((pmass / (d.read_norm - pmass)) * txome) / pmass;
+    for (int j = threadIdx.x; j < kNKmer; j += kBlock) d.ratio_seq[j] = (double)d.read_bias[j] / (d.exp_seq[j] + prior);
+    if (threadIdx.x == 0) d.scal[0] = txome / d.read_norm;
+}
+
+// pass 2 (:810-923): effLength = sum over positions of both strands' weights, x txomeNormFactor / readNormFactor
+__global__ void __launch_bounds__(kBlock) k_seq_efflen(BiasDev d, const double* eff_in, const double* __restrict__ alpha,
+                                                       double* eff_out) {
+    __shared__ double lds[kBlock / kWave + 1];
+    const uint64_t t = blockIdx.x;
+    const uint32_t L = d.ref_len[t];
+    const int unproc = unprocessed_len(L, d.txp_eff[t]);
+    const double e_in = eff_in[t];
+    double eff_length = 0.0;
+    if (alpha[t] >= kMinAlphaBias && unproc > 0 && L > (uint32_t)kK) {      // uniform over the block
+        const char* s = d.seq + d.seq_off[t];
+        const uint32_t n_pos = L - kK;
+        double acc = 0.0;
+        for (uint32_t i = threadIdx.x; i < n_pos; i += kBlock) {
+            uint32_t fw, rc;
+            kmer_indices(s + i, fw, rc);
+            acc += (d.prob_fwd * d.ratio_seq[rc]) * (double)cdf_at(d, L - i - 1);
+            acc += (d.prob_rc * d.ratio_seq[fw]) * (double)cdf_at(d, i + 5);
+        }
+        eff_length = block_sum_all(acc, lds) * d.scal[0];
+    }
+    if (threadIdx.x == 0) {
+        const bool corrected = unproc > 0 && eff_length > (double)unproc;   // :915-921
+        eff_out[t] = corrected ? eff_length : e_in;
+        if (corrected) atomicAdd(d.n_corrected, 1ull);
+    }
+}
+
+// ---- fragment-GC model ---------------------------------------------------------------------------------
+// lrint((100.0 * num) / den) with the default rounding mode, in integers (num <= den < 2^14)
+__device__ __forceinline__ uint32_t round_half_even_pct(uint32_t num, uint32_t den, float rden) {
+    const uint32_t n100 = 100u * num;                      // < 2^24: exact as a float
+    int q = (int)((float)n100 * rden);
+    int rem = (int)n100 - q * (int)den;
+    if (rem < 0) { --q; rem += (int)den; }
+    if (rem >= (int)den) { ++q; rem -= (int)den; }
+    const uint32_t twice = 2u * (uint32_t)rem;
+    q += (twice > den || (twice == den && (q & 1))) ? 1 : 0;
+    return (uint32_t)q;
+}
+
+// Gs[j] = number of G/C bases in s[0..j]  (Transcript::computeGCContent_, include/Transcript.hpp:183-196;
+// only differences are used, so a chunk-local origin is enough)
+__device__ __forceinline__ void stage_gc_prefix(const char* s, uint32_t n, uint32_t* Gs, uint32_t* runs) {
+    for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+        const unsigned c = (unsigned char)s[j] & 0xDFu;
+        Gs[j] = (c == 'G' || c == 'C') ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t R = (n + kBlock - 1) / kBlock;
+    const uint32_t b = min(n, threadIdx.x * R), e = min(n, b + R);
+    uint32_t sum = 0;
+    for (uint32_t j = b; j < e; ++j) sum += Gs[j];
+    uint32_t incl = sum;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    for (int o = 1; o < kWave; o <<= 1) { uint32_t v = __shfl_up(incl, o, kWave); if (lane >= o) incl += v; }
+    if (lane == kWave - 1) runs[wv] = incl;
+    __syncthreads();
+    uint32_t off = incl - sum;
+    for (int w = 0; w < wv; ++w) off += runs[w];
+    for (uint32_t j = b; j < e; ++j) { off += Gs[j]; Gs[j] = off; }
+    __syncthreads();
+}
+
+// S[t][g] for one transcript per block (see the header).  Dynamic LDS: 101 f64 | 64 x 101 u32 | kBlock u32 |
+// stage_cap u32.
+__global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* Sacc = reinterpret_cast<double*>(smem);
+    uint32_t* H = reinterpret_cast<uint32_t*>(smem + 816);
+    uint32_t* runs = H + kLanesFl * kNGC;
+    uint32_t* Gs = runs + kBlock;
+    const uint64_t t = blockIdx.x;
+    const uint32_t L = d.ref_len[t];
+    double* Srow = d.S + t * kNGC;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    if (L <= (uint32_t)kK || unprocessed_len(L, d.txp_eff[t]) <= 0) {       // never walked by the reference
+        if (tid < kNGC) Srow[tid] = 0.0;
+        return;
+    }
+    if (tid < kNGC) Sacc[tid] = 0.0;
+    const char* s = d.seq + d.seq_off[t];
+    const uint32_t n_pos = L - kK;                                          // i = refLen - K - 1 .. 0
+    for (uint32_t k0 = 0; k0 < d.nfl; k0 += kLanesFl) {
+        const uint32_t fl_min = (uint32_t)d.fld_low + k0 * d.gs;
+        if (fl_min > L) break;                                              // fragEnd < refLen fails for every i (:742)
+        const uint32_t k_last = min(d.nfl - 1, k0 + kLanesFl - 1);
+        const uint32_t fl_max = (uint32_t)d.fld_low + k_last * d.gs;
+        const uint32_t n_i = min(n_pos, L - fl_min + 1);                    // positions with at least one valid length
+        const uint32_t k = k0 + lane;
+        const bool k_on = k < d.nfl;
+        const uint32_t fl = (uint32_t)d.fld_low + k * d.gs;
+        const float rfl = 1.0f / (float)fl;
+        uint32_t* Hrow = H + lane * kNGC;
+        for (int j = tid; j < kLanesFl * kNGC; j += kBlock) H[j] = 0;
+        const uint32_t T = d.stage_cap - fl_max;
+        for (uint32_t p0 = 0; p0 < n_i; p0 += T) {
+            __syncthreads();
+            stage_gc_prefix(s + p0, min(L - p0, T + fl_max), Gs, runs);
+            const uint32_t i_end = min(n_i, p0 + T);
+            for (uint32_t i = p0 + wv; i < i_end; i += kBlock / kWave) {
+                const uint32_t e = i + fl - 1;
+                if (k_on && e < L) {
+                    const uint32_t g = round_half_even_pct(Gs[e - p0] - Gs[i - p0], fl, rfl);   // gcFrac(i, e)
+                    atomicAdd(&Hrow[g], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < kNGC) {
+            double acc = Sacc[tid];
+            const uint32_t nk = k_last - k0 + 1;
+            for (uint32_t l = 0; l < nk; ++l) acc += d.w[k0 + l] * (double)H[l * kNGC + tid];
+            Sacc[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid < kNGC) Srow[tid] = Sacc[tid];
+}
+
+// expected[g] partial sums over kGcRows transcripts per block, fixed order
+__global__ void __launch_bounds__(128) k_gc_expected_partial(BiasDev d, const double* __restrict__ eff_in,
+                                                             const double* __restrict__ alpha) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * kGcRows;
+    const uint64_t t1 = min(d.M, t0 + kGcRows);
+    const int g = threadIdx.x;
+    double acc = 0.0;
+    for (uint64_t t = t0; t < t1; ++t) {
+        const double a = alpha[t];
+        if (a < kMinAlphaBias || unprocessed_len(d.ref_len[t], d.txp_eff[t]) <= 0) continue;   // uniform
+        const double contribution = a / eff_in[t];
+        if (g < kNGC) acc += contribution * d.S[t * kNGC + g];
+    }
+    if (g < kNGC) d.gc_partial[(uint64_t)blockIdx.x * kNGC + g] = acc;
+}
+
+// :788-794  txomeGCNormFactor, gcPrior; ratio = gcCounts / (gcPrior + transcriptGCDist)
+__global__ void __launch_bounds__(128) k_gc_norm(BiasDev d, uint32_t n_partials) {
+    __shared__ double bins[kNGC];
+    __shared__ double bc[2];
+    const int g = threadIdx.x;
+    if (g < kNGC) {
+        double v = 1.0;                                                     // resize(101, 1.0) :667
+        for (uint32_t b = 0; b < n_partials; ++b) v += d.gc_partial[(uint64_t)b * kNGC + g];
+        d.exp_gc[g] = v; bins[g] = v;
+    }
+    __syncthreads();
+    if (g == 0) {
+        double txome = 0.0;
+        for (int i = 0; i < kNGC; ++i) txome += bins[i];
+        const double pmass = 101.0;
+        bc[0] = ((pmass / (d.read_gc_norm - pmass)) * txome) / 101.0;
+        bc[1] = txome / d.read_gc_norm;
+        d.scal[1] = bc[1];
+    }
+    __syncthreads();
+    if (g < kNGC) d.ratio_gc[g] = (double)d.observed_gc[g] / (bc[0] + bins[g]);
+}
+
+// effLength = gcFactors.sum() * txomeGCNormFactor / readGCNormFactor (:907-909); one wave per transcript
+__global__ void __launch_bounds__(kBlock) k_gc_efflen(BiasDev d, const double* eff_in, const double* __restrict__ alpha,
+                                                      double* eff_out) {
+    const uint64_t t = (uint64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= d.M) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int unproc = unprocessed_len(d.ref_len[t], d.txp_eff[t]);
+    const double e_in = eff_in[t];
+    double eff_length = 0.0;
+    if (alpha[t] >= kMinAlphaBias && unproc > 0) {
+        const double* Srow = d.S + t * kNGC;
+        double acc = d.ratio_gc[lane] * Srow[lane];
+        if (lane + kWave < kNGC) acc += d.ratio_gc[lane + kWave] * Srow[lane + kWave];
+        const double dot = wave_sum(acc);
+        eff_length = (dot * d.prob_fwd + dot * d.prob_rc) * d.scal[1];      // gcFactors[start] += p*probFwd; [end] += p*probRC
+    }
+    if (lane == 0) {
+        const bool corrected = unproc > 0 && eff_length > (double)unproc;
+        eff_out[t] = corrected ? eff_length : e_in;
+        if (corrected) atomicAdd(d.n_corrected, 1ull);
+    }
+}
+
+}  // namespace
+}  // namespace sfgpu
+
+using namespace sfgpu;
+
+struct sfgpu_bias {
+    BiasDev dev{};
+    int status = 0;                        // 0 compute, 1 no mappings, 2 both models
+    bool seq_on = false, gc_on = false;
+    int32_t fld_low = 0, fld_high = 1;
+    uint32_t n_partials = 0;
+    hipStream_t last_stream = nullptr;
+    unsigned long long* h_count = nullptr; // pinned
+    std::vector<void*> bufs;
+};
+
+namespace sfgpu {
+uint64_t bias_num_transcripts(const sfgpu_bias* b) { return b ? b->dev.M : 0; }
+}
+
+static void bias_free(sfgpu_bias* b) {
+    if (!b) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : b->bufs) if (p) pool_free(p);
+    if (b->h_count) pinned_free(b->h_count);
+    delete b;
+}
+
+template <typename T>
+static int bias_alloc(sfgpu_bias* b, T** p, size_t bytes) {
+    SF_HIP(pool_malloc(p, bytes ? bytes : 8));
+    b->bufs.push_back(*p);
+    return SFGPU_OK;
+}
+
+extern "C" {
+
+int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_stream stream) {
+    SF_REQUIRE(out && in, SFGPU_ERR_INVALID, "sfgpu_bias_create: null pointer");
+    *out = nullptr;
+    const bool seq_on = in->seq_bias != 0, gc_on = in->gc_bias != 0;
+    SF_REQUIRE(seq_on || gc_on, SFGPU_ERR_INVALID, "sfgpu_bias_create: neither bias model is enabled");
+    const int64_t n_map = in->num_fwd + in->num_rc;
+    sfgpu_bias* b = new sfgpu_bias();
+    b->seq_on = seq_on; b->gc_on = gc_on;
+    b->dev.M = in->M;
+    b->status = (n_map == 0) ? 1 : ((seq_on && gc_on) ? 2 : 0);          // :625-638
+    hipStream_t st = as_stream(stream);
+    b->last_stream = st;
+    int rc = SFGPU_OK;
+#define B_TRY(expr) do { rc = (expr); if (rc) { bias_free(b); return rc; } } while (0)
+#define B_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); bias_free(b); return SFGPU_ERR_HIP; } } while (0)
+#define B_REQ(cond, code, msg) do { if (!(cond)) { set_error("%s", msg); bias_free(b); return code; } } while (0)
+    B_HIP(pinned_malloc(&b->h_count, 8));
+    *b->h_count = 0;
+    B_TRY(bias_alloc(b, &b->dev.exp_seq, kNKmer * 8));
+    B_TRY(bias_alloc(b, &b->dev.exp_gc, 128 * 8));
+    hipLaunchKernelGGL(k_fill, dim3(kNKmer / kBlock), dim3(kBlock), 0, st, b->dev.exp_seq, (uint32_t)kNKmer, 1.0);
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(kBlock), 0, st, b->dev.exp_gc, (uint32_t)kNGC, 1.0);
+    if (b->status != 0 || in->M == 0) { B_HIP(hipStreamSynchronize(st)); *out = b; return SFGPU_OK; }
+
+    B_REQ(in->d_seq && in->d_seq_off && in->d_ref_len && in->d_txp_eff_len && in->h_fl_counts && in->max_frag_len > 0,
+          SFGPU_ERR_INVALID, "sfgpu_bias_create: null input");
+    B_REQ(!seq_on || in->h_read_bias, SFGPU_ERR_INVALID, "sfgpu_bias_create: seq_bias needs h_read_bias");
+    B_REQ(!gc_on || in->h_observed_gc, SFGPU_ERR_INVALID, "sfgpu_bias_create: gc_bias needs h_observed_gc");
+    B_REQ(!gc_on || in->gc_size_samp == 1, SFGPU_ERR_UNSUPPORTED,
+          "sfgpu_bias_create: gcSizeSamp != 1 is not implemented (see sfgpu.h)");
+    B_REQ(!gc_on || in->gc_speed_samp >= 1, SFGPU_ERR_INVALID, "sfgpu_bias_create: gc_speed_samp must be >= 1");
+
+    // EmpiricalDistribution::buildDistribution (src/EmpiricalDistribution.cpp:29-77) for vals = 0..n-1
+    const uint32_t n = in->max_frag_len;
+    const uint32_t* lens = in->h_fl_counts;
+    double total = 0.0;
+    for (uint32_t i = 0; i < n; ++i) total += lens[i];
+    B_REQ(total > 0.0, SFGPU_ERR_INVALID, "sfgpu_bias_create: empty fragment length distribution");
+    uint32_t cut = 0, table_len = 1;
+    {
+        double cum = 0.0;
+        for (; cut < n; ++cut) {
+            cum += lens[cut] / total;
+            table_len = cut;
+            if (cum > 1.0 - 1e-6) break;
+        }
+    }
+    B_REQ(table_len > 0, SFGPU_ERR_INVALID, "sfgpu_bias_create: degenerate fragment length distribution");
+    double kept = 0.0;
+    for (uint32_t i = 0; i < cut; ++i) kept += lens[i];
+    std::vector<float> cdf(table_len);
+    {
+        float run = 0.0f;
+        for (uint32_t v = 0; v < table_len; ++v) {
+            const float p = (float)(lens[v] / kept);
+            run = (v == 0) ? p : run + p;                                  // float adds, :72-76
+            cdf[v] = run;
+        }
+    }
+    auto cdf_of = [&](uint32_t x) -> float { return x < table_len ? cdf[x] : 1.0f; };
+    B_TRY(bias_alloc(b, const_cast<float**>(&b->dev.cdf), (size_t)table_len * 4));
+    B_HIP(hipMemcpyAsync(const_cast<float*>(b->dev.cdf), cdf.data(), (size_t)table_len * 4, hipMemcpyHostToDevice, st));
+    b->dev.cdf_size = table_len;
+    b->dev.seq = in->d_seq; b->dev.seq_off = in->d_seq_off; b->dev.ref_len = in->d_ref_len; b->dev.txp_eff = in->d_txp_eff_len;
+    b->dev.prob_fwd = (double)in->num_fwd / (double)n_map;                 // :640-641
+    b->dev.prob_rc = (double)in->num_rc / (double)n_map;
+    B_TRY(bias_alloc(b, &b->dev.scal, 16));
+    B_TRY(bias_alloc(b, &b->dev.n_corrected, 8));
+
+    std::vector<double> w;
+    if (seq_on) {
+        uint32_t tot32 = 0;                                                // totalCount() sums in CountT = uint32 (ReadKmerDist.hpp:27-31)
+        for (int i = 0; i < kNKmer; ++i) tot32 += in->h_read_bias[i];
+        b->dev.read_norm = (double)tot32;
+        B_TRY(bias_alloc(b, const_cast<uint32_t**>(&b->dev.read_bias), kNKmer * 4));
+        B_HIP(hipMemcpyAsync(const_cast<uint32_t*>(b->dev.read_bias), in->h_read_bias, kNKmer * 4, hipMemcpyHostToDevice, st));
+        B_TRY(bias_alloc(b, &b->dev.ratio_seq, kNKmer * 8));
+    } else {
+        // :669-684 the 0.005 / 0.995 quantiles of the FLD bound the fragment lengths considered
+        bool first = false, second = false;
+        for (uint32_t i = 0; i <= n - 1; ++i) {
+            const float density = cdf_of(i);
+            if (!first && density >= 0.005) { first = true; b->fld_low = (int32_t)i; }
+            if (!second && density >= 0.995) { second = true; b->fld_high = (int32_t)i; }
+        }
+        B_REQ(b->fld_low >= 1, SFGPU_ERR_INVALID,
+              "sfgpu_bias_create: the FLD's 0.005 quantile is 0 (the reference divides by the fragment length)");
+        B_REQ((uint32_t)b->fld_high < kMaxFldHigh, SFGPU_ERR_RANGE, "sfgpu_bias_create: FLD 0.995 quantile >= 16000");
+        const uint32_t gs = in->gc_speed_samp;
+        double prev = (double)cdf_of(0);                                   // prevFLMass :739
+        for (int64_t fl = b->fld_low; fl <= b->fld_high; fl += gs) {
+            w.push_back((double)cdf_of((uint32_t)fl) - prev);
+            prev = (double)cdf_of((uint32_t)fl);
+        }
+        b->dev.nfl = (uint32_t)w.size(); b->dev.fld_low = b->fld_low; b->dev.gs = gs;
+        double gc_norm = 0.0;
+        for (int i = 0; i < kNGC; ++i) gc_norm += in->h_observed_gc[i];   // :686
+        b->dev.read_gc_norm = gc_norm;
+        B_TRY(bias_alloc(b, const_cast<uint32_t**>(&b->dev.observed_gc), 128 * 4));
+        B_HIP(hipMemcpyAsync(const_cast<uint32_t*>(b->dev.observed_gc), in->h_observed_gc, kNGC * 4, hipMemcpyHostToDevice, st));
+        B_TRY(bias_alloc(b, &b->dev.ratio_gc, 128 * 8));
+        b->n_partials = (uint32_t)((in->M + kGcRows - 1) / kGcRows);
+        B_TRY(bias_alloc(b, &b->dev.gc_partial, (size_t)b->n_partials * kNGC * 8));
+        B_TRY(bias_alloc(b, &b->dev.S, (size_t)in->M * kNGC * 8));
+        if (b->dev.nfl) {
+            B_TRY(bias_alloc(b, const_cast<double**>(&b->dev.w), w.size() * 8));
+            B_HIP(hipMemcpyAsync(const_cast<double*>(b->dev.w), w.data(), w.size() * 8, hipMemcpyHostToDevice, st));
+            uint32_t cap = (uint32_t)b->fld_high + 2048;
+            if (cap < kStageMin) cap = kStageMin;
+            b->dev.stage_cap = cap;
+            const size_t lds = 816 + (size_t)kLanesFl * kNGC * 4 + kBlock * 4 + (size_t)cap * 4;
+            B_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gc_profile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_gc_profile, dim3((unsigned)in->M), dim3(kBlock), lds, st, b->dev);
+            B_HIP(hipGetLastError());
+        } else {
+            B_HIP(hipMemsetAsync(b->dev.S, 0, (size_t)in->M * kNGC * 8, st));
+        }
+    }
+    B_HIP(hipStreamSynchronize(st));                                       // the host tables above are pageable
+#undef B_TRY
+#undef B_HIP
+#undef B_REQ
+    *out = b;
+    return SFGPU_OK;
+}
+
+int sfgpu_bias_destroy(sfgpu_bias* b) { bias_free(b); return SFGPU_OK; }
+
+int sfgpu_bias_update(sfgpu_bias* b, const double* d_eff_in, const double* d_alpha, double* d_eff_out,
+                      sfgpu_bias_stats* stats, sfgpu_stream stream) {
+    SF_REQUIRE(b && d_eff_in && d_alpha && d_eff_out, SFGPU_ERR_INVALID, "sfgpu_bias_update: null pointer");
+    hipStream_t st = as_stream(stream);
+    b->last_stream = st;
+    const uint64_t M = b->dev.M;
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = b->status; stats->fld_low = b->fld_low; stats->fld_high = b->fld_high; }
+    if (b->status != 0 || M == 0) {
+        if (d_eff_out != d_eff_in && M) SF_HIP(hipMemcpyAsync(d_eff_out, d_eff_in, M * 8, hipMemcpyDeviceToDevice, st));
+        if (stats) { SF_HIP(hipStreamSynchronize(st)); stats->n_uncorrected = 0; }
+        return SFGPU_OK;
+    }
+    SF_REQUIRE(M < (1ull << 31), SFGPU_ERR_RANGE, "sfgpu_bias_update: more than 2^31 transcripts");
+    SF_HIP(hipMemsetAsync(b->dev.n_corrected, 0, 8, st));
+    if (b->seq_on) {
+        hipLaunchKernelGGL(k_fill, dim3(kNKmer / kBlock), dim3(kBlock), 0, st, b->dev.exp_seq, (uint32_t)kNKmer, 1.0);   // :652-653
+        const unsigned nb = (unsigned)(M < (uint64_t)kSeqBlocks ? M : (uint64_t)kSeqBlocks);
+        hipLaunchKernelGGL(k_seq_expected, dim3(nb), dim3(kBlock), 0, st, b->dev, d_eff_in, d_alpha);
+        hipLaunchKernelGGL(k_seq_norm, dim3(1), dim3(kBlock), 0, st, b->dev);
+        hipLaunchKernelGGL(k_seq_efflen, dim3((unsigned)M), dim3(kBlock), 0, st, b->dev, d_eff_in, d_alpha, d_eff_out);
+    } else {
+        hipLaunchKernelGGL(k_gc_expected_partial, dim3(b->n_partials), dim3(128), 0, st, b->dev, d_eff_in, d_alpha);
+        hipLaunchKernelGGL(k_gc_norm, dim3(1), dim3(128), 0, st, b->dev, b->n_partials);
+        hipLaunchKernelGGL(k_gc_efflen, dim3((unsigned)((M + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, st,
+                           b->dev, d_eff_in, d_alpha, d_eff_out);
+    }
+    SF_CHECK_LAUNCH();
+    if (stats) {
+        SF_HIP(hipMemcpyAsync(b->h_count, b->dev.n_corrected, 8, hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        stats->n_corrected = *b->h_count;
+        stats->n_uncorrected = M - stats->n_corrected;
+    }
+    return SFGPU_OK;
+}
+
+int sfgpu_bias_expected(sfgpu_bias* b, double* h_expected_seq, double* h_expected_gc) {
+    SF_REQUIRE(b, SFGPU_ERR_INVALID, "sfgpu_bias_expected: null handle");
+    SF_HIP(hipStreamSynchronize(b->last_stream));
+    if (h_expected_seq) SF_HIP(hipMemcpy(h_expected_seq, b->dev.exp_seq, kNKmer * 8, hipMemcpyDeviceToHost));
+    if (h_expected_gc) SF_HIP(hipMemcpy(h_expected_gc, b->dev.exp_gc, kNGC * 8, hipMemcpyDeviceToHost));
+    return SFGPU_OK;
+}
+
+}  // extern "C"

@@ -18,6 +18,7 @@
 //   * all reductions that feed decisions (n_active, sum alpha, alphaSum) are two-stage and
 //     order-deterministic; the only nondeterministic order is the f64 atomic accumulation into
 //     alphaOut, as in the reference's CAS loop (:70-79).
+#include "bias.h"
 #include "common.h"
 #include "primitives.h"
 #include "sampling.h"
@@ -111,6 +112,21 @@ __device__ __forceinline__ double sum_partials(const double* partials, int nb, d
 __global__ void k_clamp_len(uint64_t M, const double* __restrict__ len, double* __restrict__ lenc) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < M) { double l = len[t]; lenc[t] = (l <= 1.0) ? 1.0 : l; }   // :738
+}
+
+// after a bias recompute (:824-840): x for the next sweep from the current alpha and the new lengths
+__global__ void k_x_from_alpha(uint64_t M, const double* __restrict__ alpha, const double* __restrict__ lenc,
+                               double* __restrict__ x) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) x[t] = alpha[t] / lenc[t];
+}
+
+__global__ void k_alpha_partials(uint64_t M, const double* __restrict__ alpha, double* partials) {
+    __shared__ double lds[kEmBlock / kWave];
+    double v = 0.0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) v += alpha[t];
+    double s = block_sum(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // device-private copy of the counts: 31 bits of count, bit 31 = the class is a singleton
@@ -1035,6 +1051,101 @@ int sfgpu_em_optimize(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_o
     int rc;
     if ((rc = em_join_user(em))) return rc;
     return em_run(em, opts, d_alpha_out, d_mass_out, stats, false);
+}
+
+// optimize() with doBiasCorrect (src/CollapsedEMOptimizer.cpp:717, :814-840, :888).  The loop runs in segments
+// that end at the recompute iterations: a segment is the ordinary on-device loop with max_iter set to the
+// next hook (the stop latch is re-evaluated by the first sweep of the next segment, so a segment that ended
+// on its hook simply continues).  At a hook that the reference would reach (its while condition still true)
+// the lengths are recomputed from the current alpha, and x -- alpha / effLen, or expTheta / effLen -- is
+// rebuilt with them (updateEqClassWeights :527-555: the weights are not stored here, x carries 1 / effLen).
+static int em_run_bias(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_bias* bias, double* d_alpha_out, double* d_mass_out,
+                       double* d_eff_len_out, uint32_t* n_recomputes, sfgpu_em_stats* stats) {
+    static const uint32_t kHooks[3] = {50, 500, 1000};                         // recomputeIt :814
+    int rc;
+    em->in_optimize = true;
+    if ((rc = em_begin_on(em, opts, em->stream))) return rc;
+    const sfgpu_em_opts user = em->opts;
+    if ((rc = sfgpu_em_init_impl(em))) return rc;
+    int done = 0;
+    sfgpu_em_stats st{};
+    if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+    if (st.n_active == 0) {
+        set_error("It seems that no transcripts are expressed; something is likely wrong!");
+        if (stats) *stats = st;
+        return SFGPU_ERR_NO_ACTIVE;
+    }
+    log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);
+    const sfgpu_problem& p = em->prob;
+    const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
+    const uint32_t chunk = user.iters_per_launch;
+    uint32_t recomputes = 0;
+    SF_HIP(hipEventRecord(em->ev_a, em->cur));
+    for (;;) {
+        const EmState* h = em->h_state;
+        const uint32_t it = h->it_a;
+        const bool conv = it > 0 && h->notconv[(it - 1) & 1] == 0;
+        if (it >= user.min_iter && (it >= user.max_iter || conv)) break;       // the while condition of :820 is false
+        uint32_t next = user.max_iter;
+        for (uint32_t hk : kHooks) {
+            if (hk == it) {
+                log_msg(0, "iteration %u, recomputing effective lengths", it);    // :827
+                if ((rc = sfgpu_bias_update(bias, em->lenc, em->alpha, em->lenc, nullptr, reinterpret_cast<sfgpu_stream>(em->cur)))) return rc;
+                dim3 g(em->nb), b(kEmBlock);
+                if (user.use_vbem) {
+                    hipLaunchKernelGGL(k_alpha_partials, g, b, 0, em->cur, p.M, em->alpha, em->sum_partials);
+                    hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials,
+                                       em->nb, em->d_state, 1);
+                } else {
+                    hipLaunchKernelGGL(k_x_from_alpha, dim3(blocks_for(p.M)), b, 0, em->cur, p.M, em->alpha, em->lenc, em->x);
+                }
+                SF_CHECK_LAUNCH();
+                ++recomputes;
+            }
+            if (hk > it && hk < next) next = hk;
+        }
+        em->opts = user;
+        em->opts.max_iter = next;
+        if (em->opts.min_iter > next) em->opts.min_iter = next;
+        if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
+        done = 0;
+        while (!done) {
+            if (use_graph) {
+                SF_HIP(hipGraphLaunch(em->graph, em->cur));
+            } else {
+                for (uint32_t i = 0; i < chunk; ++i) {
+                    if ((rc = em_enqueue_sweep(em))) return rc;
+                    if ((rc = em_enqueue_update(em, true))) return rc;
+                }
+            }
+            if ((rc = em_poll_impl(em, &done, &st, false))) return rc;
+        }
+    }
+    em->opts = user;
+    SF_HIP(hipEventRecord(em->ev_b, em->cur));
+    if (d_eff_len_out) SF_HIP(hipMemcpyAsync(d_eff_len_out, em->lenc, p.M * 8, hipMemcpyDeviceToDevice, em->cur));   // :888
+    rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
+    // the handle's clamped lengths go back to the problem's own (a later optimize / bootstrap starts from them)
+    hipLaunchKernelGGL(k_clamp_len, dim3(blocks_for(p.M)), dim3(kEmBlock), 0, em->cur, p.M, p.d_len, em->lenc);
+    SF_HIP(hipStreamSynchronize(em->cur));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, em->ev_a, em->ev_b);
+    st.loop_ms = ms;
+    log_msg(0, "iteration = %u | max rel diff. = %g", st.iters, st.max_rel_diff);
+    if (n_recomputes) *n_recomputes = recomputes;
+    if (stats) *stats = st;
+    return rc;
+}
+
+int sfgpu_em_optimize_bias(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_bias* bias, double* d_alpha_out,
+                           double* d_mass_out, double* d_eff_len_out, uint32_t* n_recomputes, sfgpu_em_stats* stats) {
+    SF_REQUIRE(em && bias && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_optimize_bias: null pointer");
+    SF_REQUIRE(bias_num_transcripts(bias) == em->prob.M, SFGPU_ERR_INVALID,
+               "sfgpu_em_optimize_bias: the bias handle and the problem disagree on the number of transcripts");
+    SF_REQUIRE(em->prob.M > 0, SFGPU_ERR_INVALID, "sfgpu_em_optimize_bias: no transcripts");
+    int rc;
+    if ((rc = em_join_user(em))) return rc;
+    return em_run_bias(em, opts, bias, d_alpha_out, d_mass_out, d_eff_len_out, n_recomputes, stats);
 }
 
 // ---- bootstrap (a15): gatherBootstraps / doBootstrap, src/CollapsedEMOptimizer.cpp:438-525, 557-709 ----

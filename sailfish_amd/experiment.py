@@ -26,6 +26,8 @@ class SailfishOpts:
     numGibbsSamples: int = 0
     biasCorrect: bool = False
     gcBiasCorrect: bool = False
+    gcSampFactor: int = 1               # --gcSizeSamp
+    pdfSampFactor: int = 1              # --gcSpeedSamp
     dumpEq: bool = False
     auxDir: str = "aux"
     jointLog: Optional[object] = None   # callable(level:int, msg:str)
@@ -92,6 +94,58 @@ class ReadExperiment:
 
     def fragLengthDist(self):
         return self._fld
+
+    # ---- what bias correction reads (include/ReadExperiment.hpp:93-97, 178-212, 240-255) ----
+    def setSequences(self, seq, offsets):
+        """The index's concatenated transcript sequence (RapMapSAIndex::seq; bytes / uint8 array / tensor) and
+        txpOffsets -- what loadTranscriptsFromQuasiIndex hands to Transcript::setSequence (:108-117)."""
+        dev = self._transcripts.device
+        if isinstance(seq, (bytes, bytearray)):
+            seq = np.frombuffer(bytes(seq), dtype=np.uint8).copy()
+        if isinstance(seq, np.ndarray):
+            seq = torch.from_numpy(np.ascontiguousarray(seq, dtype=np.uint8))
+        self._seq = seq.to(dev)
+        self._seq_off = torch.as_tensor(np.asarray(offsets, dtype=np.int64)).to(dev)
+
+    def readBias(self):
+        """ReadKmerDist<6>::counts: 4096 uint32, pseudo-count 1 (include/ReadKmerDist.hpp:17-22)."""
+        if getattr(self, "_read_bias", None) is None:
+            self._read_bias = np.ones(4096, np.uint32)
+        return self._read_bias
+
+    def observedGC(self):
+        """101 uint32, pseudo-count 1 (include/ReadExperiment.hpp:47-51)."""
+        if getattr(self, "_observed_gc", None) is None:
+            self._observed_gc = np.ones(101, np.uint32)
+        return self._observed_gc
+
+    def addNumFwd(self, n): self._num_fwd = getattr(self, "_num_fwd", 0) + int(n)
+    def addNumRC(self, n): self._num_rc = getattr(self, "_num_rc", 0) + int(n)
+    def numFwd(self): return getattr(self, "_num_fwd", 0)
+    def numRC(self): return getattr(self, "_num_rc", 0)
+
+    def expectedSeqBias(self):
+        return getattr(self, "_expected_seq", None) if getattr(self, "_expected_seq", None) is not None else np.ones(4096)
+
+    def setExpectedSeqBias(self, v): self._expected_seq = np.asarray(v, dtype=np.float64)
+
+    def expectedGCBias(self):
+        return getattr(self, "_expected_gc", None) if getattr(self, "_expected_gc", None) is not None else np.ones(101)
+
+    def setExpectedGCBias(self, v): self._expected_gc = np.asarray(v, dtype=np.float64)
+
+    def biasModel(self, sopt):
+        """Device handle over everything updateEffectiveLengths reads (src/SailfishUtils.cpp:611-690)."""
+        from .bias import BiasModel
+        if getattr(self, "_seq", None) is None:
+            raise RuntimeError("bias correction needs the transcript sequences: call setSequences first")
+        if self._fld is None:
+            raise RuntimeError("bias correction needs the fragment length distribution: call setFragLengthDist first")
+        t = self._transcripts
+        return BiasModel(self._seq, self._seq_off, t.RefLength, t.EffectiveLength, self._fld.astype(np.uint32),
+                         self.readBias(), self.observedGC(), self.numFwd(), self.numRC(),
+                         seq_bias=sopt.biasCorrect, gc_bias=sopt.gcBiasCorrect,
+                         gc_speed_samp=sopt.pdfSampFactor, gc_size_samp=sopt.gcSampFactor)
 
     def setFragLengthDist(self, fld):
         self._fld = np.asarray(fld, dtype=np.int32)

@@ -40,6 +40,16 @@ class EMProblem:
         rc = self._L.sfgpu_em_optimize(self._h, C.byref(o), _lib.ptr(self.alpha), _lib.ptr(self.mass), C.byref(st))
         return rc, st.as_dict()
 
+    def optimize_bias(self, bias, **kw):
+        """optimize() with doBiasCorrect (src/CollapsedEMOptimizer.cpp:717, :814-840, :888): `bias` is a
+        sailfish_amd.bias.BiasModel.  Returns (rc, stats dict, effLens tensor[M], hooks taken)."""
+        o = self.opts(**kw)
+        st = _lib.EmStats(); nr = C.c_uint32(0)
+        eff = torch.zeros(self.M, dtype=torch.float64, device=self.device)
+        rc = self._L.sfgpu_em_optimize_bias(self._h, C.byref(o), bias._h, _lib.ptr(self.alpha), _lib.ptr(self.mass),
+                                            _lib.ptr(eff), C.byref(nr), C.byref(st))
+        return rc, st.as_dict(), eff, nr.value
+
     # piecewise API (multi-GPU driver, tests)
     def begin(self, **kw):
         self._o = self.opts(**kw)
@@ -127,8 +137,7 @@ class CollapsedEMOptimizer:
 
     def optimize(self, readExp: ReadExperiment, sopt: SailfishOpts, relDiffTolerance: float = 0.01,
                  maxIter: int = 1000) -> bool:
-        if sopt.biasCorrect or sopt.gcBiasCorrect:
-            raise NotImplementedError("bias-aware effective lengths are outside the hot path (SURVEY.md 8f.3)")
+        do_bias = sopt.biasCorrect or sopt.gcBiasCorrect                      # :717
         if sopt.jointLog is not None:
             _lib.set_logger(sopt.jointLog)
         txps = readExp.transcripts()
@@ -137,11 +146,22 @@ class CollapsedEMOptimizer:
         length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
         prob = EMProblem(length, vec.rowptr, vec.ids, vec.counts, readExp.numMappedFragments())
         self._problem = prob
-        rc, st = prob.optimize(use_vbem=sopt.useVBOpt, tol=relDiffTolerance, min_iter=50, max_iter=maxIter)
+        eff = None
+        if do_bias:
+            bias = readExp.biasModel(sopt)
+            rc, st, eff, self.last_recomputes = prob.optimize_bias(bias, use_vbem=sopt.useVBOpt, tol=relDiffTolerance,
+                                                                   min_iter=50, max_iter=maxIter)
+            if rc == _lib.OK:
+                es, eg = bias.expected()
+                readExp.setExpectedSeqBias(es); readExp.setExpectedGCBias(eg)
+        else:
+            rc, st = prob.optimize(use_vbem=sopt.useVBOpt, tol=relDiffTolerance, min_iter=50, max_iter=maxIter)
         self.last_stats = st
         if rc in (_lib.ERR_NO_ACTIVE, _lib.ERR_ALPHA_SUM):
             return False            # the reference logs and returns false (:794-798, :877-881)
         _lib.check(rc)
+        if eff is not None:
+            txps.EffectiveLength.copy_(eff)                                   # :888
         txps.estCount.copy_(prob.alpha)    # setEstCount / setMass (:889-890)
         txps.mass.copy_(prob.mass)
         return True

@@ -1,0 +1,32 @@
+"""dev probe: bias-aware effective lengths at transcriptome scale (M transcripts, synth lengths, random sequence):
+time of the one-off GC profile (sfgpu_bias_create) and of one updateEffectiveLengths per model"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sailfish_amd as sf
+from sailfish_amd import synth
+dev = torch.device("cuda:0")
+M = int(os.environ.get("M", 80_000))
+ref_len = synth.transcript_lengths(M, device=dev)
+L = (ref_len.to(torch.int64) & 0xFFFFFFFF)
+off = torch.cumsum(L + 1, 0) - (L + 1)
+total = int((L + 1).sum())
+g = torch.Generator(device=dev); g.manual_seed(1)
+seq = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (total,), device=dev, generator=g)]
+x = np.arange(1000); fl = np.round(1e6 * np.exp(-0.5 * ((x - 200) / 80.0) ** 2)).astype(np.uint32)
+eff = torch.clamp(L.to(torch.float64) - 190.0, min=1.0)
+alpha = torch.rand(M, dtype=torch.float64, device=dev, generator=g) * 100
+rb = np.random.default_rng(1).integers(1, 500, 4096); og = np.random.default_rng(2).integers(1, 5000, 101)
+print(f"M={M} bases={total/1e6:.1f}M mean len {float(L.double().mean()):.0f} max {int(L.max())}", flush=True)
+for mode, samp in (("seq", 1), ("gc", 1), ("gc", 5)):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    m = sf.bias.BiasModel(seq, off, ref_len, eff, fl, rb, og, num_fwd=6, num_rc=4, seq_bias=mode == "seq", gc_bias=mode == "gc",
+                          gc_speed_samp=samp)
+    torch.cuda.synchronize(); tc = time.perf_counter() - t
+    ts = []
+    for r in range(4):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        out, st = m.update(eff, alpha)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    print(f"{mode} samp={samp}: create {tc*1e3:.1f} ms, update {min(ts)*1e3:.2f} ms (first {ts[0]*1e3:.2f}), stats {st}", flush=True)
+    m.close()
