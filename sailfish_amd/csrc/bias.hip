@@ -23,8 +23,8 @@
 //   and every later update is two passes over S (808 bytes per transcript):
 //       expected[g] = 1 + sum_t (alpha_t / effLen_t) * S[t][g]            (k_gc_expected_*, fixed order)
 //       effLen'_t   = (sum_g observed[g] / (prior + expected[g]) * S[t][g]) * (probFwd + probRC) * norm
-//   gcFrac's lrint((100.0 * d) / fl) is evaluated in integers (round_half_even): 100 d / fl is a tie exactly
-//   when the double quotient is, and a non-tie is at least 1/(2 fl) away from one, far above an ulp.
+//   gcFrac's lrint((100.0 * d) / fl) is evaluated without a division (gc_bin): an f32 product, and an exact
+//   f32 residual that recognises the ties lrint sends to the even neighbour.
 #include <cmath>
 #include <vector>
 
@@ -54,6 +54,7 @@ struct BiasDev {
     const double* w; uint32_t nfl; int32_t fld_low; uint32_t gs; uint32_t stage_cap;
     double* S;
     double *exp_seq, *ratio_seq, *exp_gc, *ratio_gc, *gc_partial, *scal;   // scal[0] seq norm ratio, scal[1] gc norm ratio
+    uint8_t* corrected;                    // [M] 1 = the last update replaced the length (numCorrected :806)
     unsigned long long* n_corrected;
 };
 
@@ -81,23 +82,38 @@ __device__ __forceinline__ double block_sum_all(double v, double* lds /* kBlock 
     return r;
 }
 
-// forward and reverse-complement 6-mer indices of s[0..5] (indexForKmer / nextKmerIndex,
-// include/UtilityFunctions.hpp:40-148): forward = first base most significant; reverse complement =
-// complement of s[5] most significant.  A byte outside ACGTU (either case) adds 0 to both.
-__device__ __forceinline__ void kmer_indices(const char* s, uint32_t& fwd, uint32_t& rc) {
-    uint32_t f = 0, r = 0;
-#pragma unroll
-    for (int j = 0; j < kK; ++j) {
+// The sequence kernels stage a transcript through LDS one byte per base -- bits 0-1 the base code (A0 C1 G2 T/U3),
+// bits 4-5 its complement's code, 0 for any other byte (nextKmerIndex adds nothing for it, include/
+// UtilityFunctions.hpp:40-90) -- and every thread builds the 6-mer indices of four consecutive positions from
+// three LDS words: the first by packing six codes (indexForKmer :93-148: forward = first base most significant,
+// reverse complement = complement of the LAST base most significant), the next three by the rolling update.
+constexpr uint32_t kSeqStage = 4096;       // positions per staging round
+
+__device__ __forceinline__ void stage_codes(const char* s, uint32_t n_bytes, uint8_t* codes) {
+    for (uint32_t j = threadIdx.x; j < n_bytes; j += kBlock) {
         const unsigned c = (unsigned char)s[j] & 0xDFu;
-        uint32_t code = 0, comp = 0;
-        if (c == 'A') { code = 0; comp = 3; }
-        else if (c == 'C') { code = 1; comp = 2; }
-        else if (c == 'G') { code = 2; comp = 1; }
-        else if (c == 'T' || c == 'U') { code = 3; comp = 0; }
-        f = (f << 2) | code;
-        r |= comp << (2 * j);
+        uint32_t v = 0;
+        if (c == 'A') v = 0x30; else if (c == 'C') v = 0x21; else if (c == 'G') v = 0x12; else if (c == 'T' || c == 'U') v = 0x03;
+        codes[j] = (uint8_t)v;
     }
-    fwd = f; rc = r;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void kmer4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t f[4], uint32_t r[4]) {
+    uint32_t c[9], m[9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = (w0 >> (8 * k)) & 3u; m[k] = (w0 >> (8 * k + 4)) & 3u;
+        c[4 + k] = (w1 >> (8 * k)) & 3u; m[4 + k] = (w1 >> (8 * k + 4)) & 3u;
+    }
+    c[8] = w2 & 3u; m[8] = (w2 >> 4) & 3u;
+    f[0] = (c[0] << 10) | (c[1] << 8) | (c[2] << 6) | (c[3] << 4) | (c[4] << 2) | c[5];
+    r[0] = m[0] | (m[1] << 2) | (m[2] << 4) | (m[3] << 6) | (m[4] << 8) | (m[5] << 10);
+#pragma unroll
+    for (int u = 1; u < 4; ++u) {
+        f[u] = ((f[u - 1] << 2) | c[5 + u]) & 0xFFFu;
+        r[u] = (r[u - 1] >> 2) | (m[5 + u] << 10);
+    }
 }
 
 __global__ void k_fill(double* p, uint32_t n, double v) {
@@ -111,21 +127,34 @@ __global__ void k_fill(double* p, uint32_t n, double v) {
 __global__ void __launch_bounds__(kBlock) k_seq_expected(BiasDev d, const double* __restrict__ eff_in,
                                                          const double* __restrict__ alpha) {
     __shared__ double hist[kNKmer];
+    __shared__ __align__(16) uint8_t codes[kSeqStage + 16];
     for (int j = threadIdx.x; j < kNKmer; j += kBlock) hist[j] = 0.0;
     __syncthreads();
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(codes);
     for (uint64_t t = blockIdx.x; t < d.M; t += gridDim.x) {
         const uint32_t L = d.ref_len[t];
         const double a = alpha[t];
-        if (a < kMinAlphaBias || unprocessed_len(L, d.txp_eff[t]) <= 0 || L <= (uint32_t)kK) continue;
+        if (a < kMinAlphaBias || unprocessed_len(L, d.txp_eff[t]) <= 0 || L <= (uint32_t)kK) continue;   // uniform
         const double contribution = a / eff_in[t];
         const double cf = d.prob_fwd * contribution, cr = d.prob_rc * contribution;
         const char* s = d.seq + d.seq_off[t];
-        const uint32_t n_pos = L - kK;
-        for (uint32_t i = threadIdx.x; i < n_pos; i += kBlock) {
-            uint32_t fw, rc;
-            kmer_indices(s + i, fw, rc);
-            atomicAdd(&hist[rc], cf * (double)cdf_at(d, L - i - 1));
-            if (i + 5 < L) atomicAdd(&hist[fw], cr * (double)cdf_at(d, i + 5));
+        const uint32_t n_pos = L - kK;                                      // i = refLen - K - 1 .. 0
+        for (uint32_t c0 = 0; c0 < n_pos; c0 += kSeqStage) {
+            const uint32_t np = min(kSeqStage, n_pos - c0);
+            __syncthreads();
+            stage_codes(s + c0, np + kK - 1, codes);
+            for (uint32_t q = threadIdx.x; 4 * q < np; q += kBlock) {
+                uint32_t f[4], r[4];
+                kmer4(cw[q], cw[q + 1], cw[q + 2], f, r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = c0 + 4 * q + u;
+                    if (4 * q + u < np) {
+                        atomicAdd(&hist[r[u]], cf * (double)cdf_at(d, L - i - 1));
+                        if (i + 5 < L) atomicAdd(&hist[f[u]], cr * (double)cdf_at(d, i + 5));
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -154,35 +183,64 @@ __global__ void __launch_bounds__(kBlock) k_seq_efflen(BiasDev d, const double* 
     const double e_in = eff_in[t];
     double eff_length = 0.0;
     if (alpha[t] >= kMinAlphaBias && unproc > 0 && L > (uint32_t)kK) {      // uniform over the block
+        __shared__ __align__(16) uint8_t codes[kSeqStage + 16];
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(codes);
         const char* s = d.seq + d.seq_off[t];
         const uint32_t n_pos = L - kK;
         double acc = 0.0;
-        for (uint32_t i = threadIdx.x; i < n_pos; i += kBlock) {
-            uint32_t fw, rc;
-            kmer_indices(s + i, fw, rc);
-            acc += (d.prob_fwd * d.ratio_seq[rc]) * (double)cdf_at(d, L - i - 1);
-            acc += (d.prob_rc * d.ratio_seq[fw]) * (double)cdf_at(d, i + 5);
+        for (uint32_t c0 = 0; c0 < n_pos; c0 += kSeqStage) {
+            const uint32_t np = min(kSeqStage, n_pos - c0);
+            __syncthreads();
+            stage_codes(s + c0, np + kK - 1, codes);
+            for (uint32_t q = threadIdx.x; 4 * q < np; q += kBlock) {
+                uint32_t f[4], r[4];
+                kmer4(cw[q], cw[q + 1], cw[q + 2], f, r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = c0 + 4 * q + u;
+                    if (4 * q + u < np) {
+                        acc += (d.prob_fwd * d.ratio_seq[r[u]]) * (double)cdf_at(d, L - i - 1);
+                        acc += (d.prob_rc * d.ratio_seq[f[u]]) * (double)cdf_at(d, i + 5);
+                    }
+                }
+            }
         }
         eff_length = block_sum_all(acc, lds) * d.scal[0];
     }
     if (threadIdx.x == 0) {
         const bool corrected = unproc > 0 && eff_length > (double)unproc;   // :915-921
         eff_out[t] = corrected ? eff_length : e_in;
-        if (corrected) atomicAdd(d.n_corrected, 1ull);
+        d.corrected[t] = corrected ? 1 : 0;
     }
 }
 
+// numCorrected (:806): one atomic per block, only when the caller asks for the statistics
+__global__ void __launch_bounds__(kBlock) k_count_corrected(BiasDev d) {
+    __shared__ double lds[kBlock / kWave + 1];
+    double v = 0.0;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < d.M; t += (uint64_t)gridDim.x * kBlock) v += d.corrected[t];
+    const double s = block_sum_all(v, lds);
+    if (threadIdx.x == 0 && s > 0.0) atomicAdd(d.n_corrected, (unsigned long long)s);
+}
+
 // ---- fragment-GC model ---------------------------------------------------------------------------------
-// lrint((100.0 * num) / den) with the default rounding mode, in integers (num <= den < 2^14)
-__device__ __forceinline__ uint32_t round_half_even_pct(uint32_t num, uint32_t den, float rden) {
-    const uint32_t n100 = 100u * num;                      // < 2^24: exact as a float
-    int q = (int)((float)n100 * rden);
-    int rem = (int)n100 - q * (int)den;
-    if (rem < 0) { --q; rem += (int)den; }
-    if (rem >= (int)den) { ++q; rem -= (int)den; }
-    const uint32_t twice = 2u * (uint32_t)rem;
-    q += (twice > den || (twice == den && (q & 1))) ? 1 : 0;
-    return (uint32_t)q;
+// gcFrac's lrint((100.0 * d) / fl) (default rounding: half to even) without a division.  x = 200 d * (0.5 / fl)
+// in f32 is within 1e-5 of the quotient and rint(x) is the right integer unless the exact quotient is a tie: a
+// non-tie lies at least 1 / (2 fl) > 3e-5 from the nearest tie (fl < 16000).  The residual 200 d - 2 rint(x) fl is
+// an integer below 2^24, so the fma computes it exactly; it is +-fl exactly at a tie m + 1/2, and there the even
+// neighbour is 2 rint(x / 2) (x / 2 sits a quarter away from it, far beyond the error).
+// (tests/test_bias.py checks the formula against lrint for every d < fl < 16000.)
+struct GcLane { float half_rfl, quarter_rfl, flf, neg2fl; };
+__device__ __forceinline__ GcLane gc_lane(uint32_t fl) {
+    const float h = 0.5f / (float)fl;
+    return GcLane{h, 0.5f * h, (float)fl, -2.0f * (float)fl};
+}
+__device__ __forceinline__ uint32_t gc_bin(uint32_t d, const GcLane& l) {
+    const float n200 = (float)__umul24(d, 200u);
+    const float r = rintf(n200 * l.half_rfl);
+    const float rem2 = fmaf(r, l.neg2fl, n200);
+    const float even = rintf(n200 * l.quarter_rfl);
+    return (uint32_t)(int)((fabsf(rem2) == l.flf) ? even + even : r);
 }
 
 // Gs[j] = number of G/C bases in s[0..j]  (Transcript::computeGCContent_, include/Transcript.hpp:183-196;
@@ -235,21 +293,32 @@ __global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
         const uint32_t n_i = min(n_pos, L - fl_min + 1);                    // positions with at least one valid length
         const uint32_t k = k0 + lane;
         const bool k_on = k < d.nfl;
-        const uint32_t fl = (uint32_t)d.fld_low + k * d.gs;
-        const float rfl = 1.0f / (float)fl;
+        const uint32_t one = k_on ? 1u : 0u;                                // lanes past the last length count nothing
+        const uint32_t fl = k_on ? (uint32_t)d.fld_low + k * d.gs : fl_max;
+        const GcLane gl = gc_lane(fl);
         uint32_t* Hrow = H + lane * kNGC;
         for (int j = tid; j < kLanesFl * kNGC; j += kBlock) H[j] = 0;
-        const uint32_t T = d.stage_cap - fl_max;
+        const uint32_t T = (d.stage_cap - fl_max) & ~3u;
         for (uint32_t p0 = 0; p0 < n_i; p0 += T) {
             __syncthreads();
             stage_gc_prefix(s + p0, min(L - p0, T + fl_max), Gs, runs);
             const uint32_t i_end = min(n_i, p0 + T);
-            for (uint32_t i = p0 + wv; i < i_end; i += kBlock / kWave) {
+            // groups of four positions for which every lane's fragment ends inside the transcript: no tests
+            const uint32_t lim = (fl_max <= L) ? min(i_end, L - fl_max + 1) : p0;   // i < lim: the chunk's longest fragment fits
+            const uint32_t n_fast = lim > p0 ? (lim - p0) / 4 : 0;
+            const uint32_t* Ge = Gs + (fl - 1);
+            for (uint32_t j = wv; j < n_fast; j += kBlock / kWave) {
+                const uint32_t o = 4 * j;                                   // i - p0
+                const uint4 cs = *reinterpret_cast<const uint4*>(Gs + o);
+                const uint32_t e0 = Ge[o], e1 = Ge[o + 1], e2 = Ge[o + 2], e3 = Ge[o + 3];
+                const uint32_t g0 = gc_bin(e0 - cs.x, gl), g1 = gc_bin(e1 - cs.y, gl);
+                const uint32_t g2 = gc_bin(e2 - cs.z, gl), g3 = gc_bin(e3 - cs.w, gl);
+                atomicAdd(&Hrow[g0], one); atomicAdd(&Hrow[g1], one);
+                atomicAdd(&Hrow[g2], one); atomicAdd(&Hrow[g3], one);
+            }
+            for (uint32_t i = p0 + 4 * n_fast + wv; i < i_end; i += kBlock / kWave) {
                 const uint32_t e = i + fl - 1;
-                if (k_on && e < L) {
-                    const uint32_t g = round_half_even_pct(Gs[e - p0] - Gs[i - p0], fl, rfl);   // gcFrac(i, e)
-                    atomicAdd(&Hrow[g], 1u);
-                }
+                if (k_on && e < L) atomicAdd(&Hrow[gc_bin(Gs[e - p0] - Gs[i - p0], gl)], 1u);   // gcFrac(i, e)
             }
         }
         __syncthreads();
@@ -264,20 +333,34 @@ __global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
     if (tid < kNGC) Srow[tid] = Sacc[tid];
 }
 
-// expected[g] partial sums over kGcRows transcripts per block, fixed order
+// expected[g] partial sums over kGcRows transcripts per block, fixed order (the loads of eight rows are in
+// flight together; the adds stay in transcript order)
 __global__ void __launch_bounds__(128) k_gc_expected_partial(BiasDev d, const double* __restrict__ eff_in,
                                                              const double* __restrict__ alpha) {
+    __shared__ double contrib[kGcRows];
     const uint64_t t0 = (uint64_t)blockIdx.x * kGcRows;
-    const uint64_t t1 = min(d.M, t0 + kGcRows);
-    const int g = threadIdx.x;
-    double acc = 0.0;
-    for (uint64_t t = t0; t < t1; ++t) {
+    const uint32_t n = (uint32_t)min((uint64_t)kGcRows, d.M - t0);
+    for (uint32_t r = threadIdx.x; r < n; r += 128) {
+        const uint64_t t = t0 + r;
         const double a = alpha[t];
-        if (a < kMinAlphaBias || unprocessed_len(d.ref_len[t], d.txp_eff[t]) <= 0) continue;   // uniform
-        const double contribution = a / eff_in[t];
-        if (g < kNGC) acc += contribution * d.S[t * kNGC + g];
+        const bool live = a >= kMinAlphaBias && unprocessed_len(d.ref_len[t], d.txp_eff[t]) > 0;
+        contrib[r] = live ? a / eff_in[t] : 0.0;                            // :716
     }
-    if (g < kNGC) d.gc_partial[(uint64_t)blockIdx.x * kNGC + g] = acc;
+    __syncthreads();
+    const int g = threadIdx.x;
+    if (g >= kNGC) return;
+    const double* S = d.S + t0 * kNGC + g;
+    double acc = 0.0;
+    uint32_t r = 0;
+    for (; r + 8 <= n; r += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = S[(uint64_t)(r + u) * kNGC];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += contrib[r + u] * v[u];
+    }
+    for (; r < n; ++r) acc += contrib[r] * S[(uint64_t)r * kNGC];
+    d.gc_partial[(uint64_t)blockIdx.x * kNGC + g] = acc;
 }
 
 // :788-794  txomeGCNormFactor, gcPrior; ratio = gcCounts / (gcPrior + transcriptGCDist)
@@ -287,7 +370,15 @@ __global__ void __launch_bounds__(128) k_gc_norm(BiasDev d, uint32_t n_partials)
     const int g = threadIdx.x;
     if (g < kNGC) {
         double v = 1.0;                                                     // resize(101, 1.0) :667
-        for (uint32_t b = 0; b < n_partials; ++b) v += d.gc_partial[(uint64_t)b * kNGC + g];
+        uint32_t b = 0;
+        for (; b + 8 <= n_partials; b += 8) {
+            double p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = d.gc_partial[(uint64_t)(b + u) * kNGC + g];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += p[u];
+        }
+        for (; b < n_partials; ++b) v += d.gc_partial[(uint64_t)b * kNGC + g];
         d.exp_gc[g] = v; bins[g] = v;
     }
     __syncthreads();
@@ -322,7 +413,7 @@ __global__ void __launch_bounds__(kBlock) k_gc_efflen(BiasDev d, const double* e
     if (lane == 0) {
         const bool corrected = unproc > 0 && eff_length > (double)unproc;
         eff_out[t] = corrected ? eff_length : e_in;
-        if (corrected) atomicAdd(d.n_corrected, 1ull);
+        d.corrected[t] = corrected ? 1 : 0;
     }
 }
 
@@ -431,6 +522,7 @@ int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_strea
     b->dev.prob_rc = (double)in->num_rc / (double)n_map;
     B_TRY(bias_alloc(b, &b->dev.scal, 16));
     B_TRY(bias_alloc(b, &b->dev.n_corrected, 8));
+    B_TRY(bias_alloc(b, &b->dev.corrected, in->M));
 
     std::vector<double> w;
     if (seq_on) {
@@ -504,21 +596,39 @@ int sfgpu_bias_update(sfgpu_bias* b, const double* d_eff_in, const double* d_alp
         return SFGPU_OK;
     }
     SF_REQUIRE(M < (1ull << 31), SFGPU_ERR_RANGE, "sfgpu_bias_update: more than 2^31 transcripts");
-    SF_HIP(hipMemsetAsync(b->dev.n_corrected, 0, 8, st));
+    const bool timing = getenv("SFGPU_TIMING") != nullptr;                 // per-kernel times of this update
+    hipEvent_t ev[5] = {};
+    int n_ev = 0;
+    auto mark = [&]() { if (timing && n_ev < 5) { (void)hipEventCreate(&ev[n_ev]); (void)hipEventRecord(ev[n_ev], st); ++n_ev; } };
+    mark();
     if (b->seq_on) {
         hipLaunchKernelGGL(k_fill, dim3(kNKmer / kBlock), dim3(kBlock), 0, st, b->dev.exp_seq, (uint32_t)kNKmer, 1.0);   // :652-653
         const unsigned nb = (unsigned)(M < (uint64_t)kSeqBlocks ? M : (uint64_t)kSeqBlocks);
         hipLaunchKernelGGL(k_seq_expected, dim3(nb), dim3(kBlock), 0, st, b->dev, d_eff_in, d_alpha);
+        mark();
         hipLaunchKernelGGL(k_seq_norm, dim3(1), dim3(kBlock), 0, st, b->dev);
+        mark();
         hipLaunchKernelGGL(k_seq_efflen, dim3((unsigned)M), dim3(kBlock), 0, st, b->dev, d_eff_in, d_alpha, d_eff_out);
     } else {
         hipLaunchKernelGGL(k_gc_expected_partial, dim3(b->n_partials), dim3(128), 0, st, b->dev, d_eff_in, d_alpha);
+        mark();
         hipLaunchKernelGGL(k_gc_norm, dim3(1), dim3(128), 0, st, b->dev, b->n_partials);
+        mark();
         hipLaunchKernelGGL(k_gc_efflen, dim3((unsigned)((M + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, st,
                            b->dev, d_eff_in, d_alpha, d_eff_out);
     }
+    mark();
     SF_CHECK_LAUNCH();
+    if (timing) {
+        (void)hipEventSynchronize(ev[n_ev - 1]);
+        float t[4] = {};
+        for (int i = 0; i + 1 < n_ev; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+        fprintf(stderr, "[sfgpu bias] %s update: expected %.3f ms, norm %.3f ms, lengths %.3f ms\n", b->seq_on ? "seq" : "gc", t[0], t[1], t[2]);
+        for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(ev[i]);
+    }
     if (stats) {
+        SF_HIP(hipMemsetAsync(b->dev.n_corrected, 0, 8, st));
+        hipLaunchKernelGGL(k_count_corrected, dim3((unsigned)((M + kBlock - 1) / kBlock < 512 ? (M + kBlock - 1) / kBlock : 512)), dim3(kBlock), 0, st, b->dev);
         SF_HIP(hipMemcpyAsync(b->h_count, b->dev.n_corrected, 8, hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));
         stats->n_corrected = *b->h_count;

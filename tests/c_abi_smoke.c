@@ -87,7 +87,40 @@ int main(void) {
     CHECK(sfgpu_filter_hits(d_recs, d_roff, 3, &fo, d_fids, d_foff, d_fl, &budget, &fs, NULL));
     uint32_t fids[4], foff[4];
     HIPCHECK(hipMemcpy(fids, d_fids, 16, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(foff, d_foff, 16, hipMemcpyDeviceToHost));
-    int extras_ok = n_boot_cb == 3 && n_gibbs_cb == 4 && eff[0] > 790.0 && eff[0] < 810.0 && eff_emp[1] > 1700.0 && eff_emp[1] < 1800.0 &&
+    /* bias-aware effective lengths: a handle over the (synthetic) transcript sequences, one
+     * updateEffectiveLengths call per model, and optimize() with the recompute hook */
+    static char seq[5004]; uint64_t soff[4]; uint64_t sp = 0; uint32_t lcg = 12345u;
+    for (int t = 0; t < 4; ++t) { soff[t] = sp; for (uint32_t i = 0; i < ref_len[t]; ++i) { lcg = lcg * 1664525u + 1013904223u; seq[sp++] = "ACGT"[lcg >> 30]; } seq[sp++] = '$'; }
+    char* d_seq; uint64_t* d_soff; double *d_teff, *d_bout;
+    HIPCHECK(hipMalloc((void**)&d_seq, sizeof seq)); HIPCHECK(hipMalloc((void**)&d_soff, 32));
+    HIPCHECK(hipMalloc((void**)&d_teff, 32)); HIPCHECK(hipMalloc((void**)&d_bout, 32));
+    HIPCHECK(hipMemcpy(d_seq, seq, sizeof seq, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(d_soff, soff, 32, hipMemcpyHostToDevice));
+    for (int i = 0; i < 4; ++i) eff[i] = ref_len[i] - 199.0;
+    HIPCHECK(hipMemcpy(d_teff, eff, 32, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_eff, eff, 32, hipMemcpyHostToDevice));            /* the problem's lengths again */
+    uint32_t fld[1000], rbias[4096], ogc[101];
+    for (int i = 0; i < 1000; ++i) { int dd = i - 200; fld[i] = (dd > -150 && dd < 150) ? (uint32_t)(150 - (dd < 0 ? -dd : dd)) : 0; }
+    for (int i = 0; i < 4096; ++i) rbias[i] = 1 + (uint32_t)(i % 7);
+    for (int i = 0; i < 101; ++i) ogc[i] = 1 + (uint32_t)(i > 30 && i < 70 ? 50 : 0);
+    int bias_ok = 1;
+    for (int model = 0; model < 2; ++model) {
+        sfgpu_bias_inputs bi; memset(&bi, 0, sizeof bi);
+        bi.M = 4; bi.d_seq = d_seq; bi.d_seq_off = d_soff; bi.d_ref_len = d_ref; bi.d_txp_eff_len = d_teff;
+        bi.h_fl_counts = fld; bi.max_frag_len = 1000; bi.gc_speed_samp = 1; bi.h_read_bias = rbias; bi.h_observed_gc = ogc;
+        bi.num_fwd = 60; bi.num_rc = 40; bi.seq_bias = model == 0; bi.gc_bias = model == 1; bi.gc_size_samp = 1;
+        sfgpu_bias* bias = NULL; sfgpu_bias_stats bs;
+        CHECK(sfgpu_bias_create(&bias, &bi, NULL));
+        CHECK(sfgpu_bias_update(bias, d_teff, d_alpha, d_bout, &bs, NULL));  /* d_alpha: leftovers, any finite values do */
+        double es[4096], eg[101], beff[4]; uint32_t hooks = 0;
+        CHECK(sfgpu_em_optimize_bias(em, &o, bias, d_alpha, d_mass, d_bout, &hooks, &st));
+        CHECK(sfgpu_bias_expected(bias, es, eg));
+        HIPCHECK(hipMemcpy(beff, d_bout, 32, hipMemcpyDeviceToHost));
+        bias_ok = bias_ok && bs.status == 0 && bs.n_corrected + bs.n_uncorrected == 4 && st.iters >= 50 && hooks == (uint32_t)((st.iters > 50) + (st.iters > 500) + (st.iters > 1000)) &&
+                  beff[0] > 1.0 && beff[1] > 1.0 && es[0] >= 1.0 && eg[50] >= 1.0;
+        printf("bias model %d: iters %u hooks %u effLen %.3f %.3f %.3f %.3f\n", model, st.iters, hooks, beff[0], beff[1], beff[2], beff[3]);
+        CHECK(sfgpu_bias_destroy(bias));
+    }
+    int extras_ok = bias_ok && n_boot_cb == 3 && n_gibbs_cb == 4 && eff[0] > 790.0 && eff[0] < 810.0 && eff_emp[1] > 1700.0 && eff_emp[1] < 1800.0 &&
                     foff[0] == 0 && foff[1] == 1 && foff[2] == 2 && foff[3] == 2 && fids[0] == 3 && fids[1] == 4 &&
                     fs.n_observed == 3 && fs.n_mapped == 2 && fs.fl_sampled == 1 && budget == 9;
     printf("extras %s (boot %d gibbs %d eff %.3f emp %.3f mapped %llu)\n", extras_ok ? "ok" : "FAILED", n_boot_cb, n_gibbs_cb, eff[0], eff_emp[1],

@@ -84,6 +84,22 @@ def test_gc_frac_known_answers(built):
     assert O.gc_frac(b"agcgAAAA", 0, 7) == 38    # case-insensitive
 
 
+def test_device_gc_rounding_formula_is_exact():
+    """gc_bin of sailfish_amd/csrc/bias.hip (f32 product + exact f32 residual for the ties) == lrint((100.0 * d) / fl)
+    for every fragment length the library accepts and every count"""
+    for fl in range(1, 16000):
+        d = np.arange(fl + 1, dtype=np.int64)
+        n200 = (200 * d).astype(np.float32)
+        h = np.float32(0.5) / np.float32(fl)
+        r = np.rint(n200 * h)
+        rem2 = r.astype(np.float64) * (-2.0 * fl) + n200.astype(np.float64)          # the fma: exact, integers < 2^24
+        assert np.all(np.abs(rem2) < 2 ** 24)
+        even = np.rint(n200 * (np.float32(0.5) * h))
+        q = np.where(np.abs(rem2) == fl, even + even, r).astype(np.int64)
+        ref = np.rint((100.0 * d) / fl).astype(np.int64)
+        assert np.array_equal(q, ref), fl
+
+
 def test_fld_cdf_is_float_accumulation(built):
     """EmpiricalDistribution (src/EmpiricalDistribution.cpp:29-77, :121-124): float tables, cut at 1 - 1e-6"""
     fl = gaussian_fld()
