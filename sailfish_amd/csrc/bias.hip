@@ -11,8 +11,9 @@
 // Device layout.
 //   Sequence model: O(sum of lengths) work.  k_seq_expected keeps the 4096 bins in LDS (f64 LDS atomics),
 //   one block striding over transcripts, and flushes each block's bins with global f64 atomics;
-//   k_seq_efflen is one block per transcript.  Each thread rebuilds its position's two 6-mer indices from the
-//   six bytes (the reference's rolling update gives the same value: a byte that is not ACGTU adds 0).
+//   k_seq_efflen is one block per transcript.  A transcript is staged through LDS one code byte per base and a
+//   thread builds the 6-mer indices of four consecutive positions (first packed, then the reference's rolling
+//   update; a byte that is not ACGTU adds 0 in both).
 //   GC model: O(sum of lengths x fragment lengths) -- 6e10 pairs for a human transcriptome.  The GC bin of
 //   a pair depends only on the sequence and the fragment-length grid, NOT on the abundances, and both passes
 //   of the reference weigh a pair by a factor that depends only on (bin, fragment length) x a per-transcript

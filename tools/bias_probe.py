@@ -30,3 +30,25 @@ for mode, samp in (("seq", 1), ("gc", 1), ("gc", 5)):
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     print(f"{mode} samp={samp}: create {tc*1e3:.1f} ms, update {min(ts)*1e3:.2f} ms (first {ts[0]*1e3:.2f}), stats {st}", flush=True)
     m.close()
+
+# optimize() with the recompute hook on cfg2-shaped classes (50 M reads over the same 80 k transcripts)
+if os.environ.get("EM", "1") == "1" and M == 80_000:
+    P, R = 1_000_000, 50_000_000
+    poff, pids = synth.label_pool(M, P, device=dev)
+    ids, o2 = synth.reads_from_pool(poff, pids, R, device=dev)
+    eq = sf.EquivalenceClassBuilder(device=dev); eq.start(); eq.add_batch(ids, o2); eq.finish(); v = eq.eqVec()
+    del ids, o2
+    prob = sf.EMProblem(eff, v.rowptr, v.ids, v.counts, eq.total_reads)
+    for rep in range(3):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        rc, st = prob.optimize()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print(f"optimize (no bias): {dt*1e3:.2f} ms, {st['iters']} iterations", flush=True)
+    for mode in ("seq", "gc"):
+        m = sf.bias.BiasModel(seq, off, ref_len, eff, fl, rb, og, num_fwd=6, num_rc=4, seq_bias=mode == "seq", gc_bias=mode == "gc")
+        for rep in range(3):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            rc, st, eff_out, hooks = prob.optimize_bias(m)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print(f"optimize ({mode} bias): {dt*1e3:.2f} ms, {st['iters']} iterations, {hooks} recomputes, rc {rc}", flush=True)
+        m.close()
