@@ -243,7 +243,7 @@ SFGPU_API int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass
  * orphan merge by transcript id (:231-246), library-type compatibility (sailfish::utils::compatibleHit /
  * hitType, src/SailfishUtils.cpp:157-289; pinned by the reference's tests/LibraryTypeTests.cpp), the
  * "compatible hits if any, else all hits unless enforceLibCompat" rule (:324-341, :355-368, :395-416) and
- * the fragment-length sampling of unique proper pairs (:419-434).  Bias / GC sampling is out of scope.
+ * the fragment-length sampling of unique proper pairs (:419-434).  Bias / GC sampling: sfgpu_sample_bias below.
  * One record per hit, reads in CSR form; the output is the packed hit lists sfgpu_eq_add_batch_device
  * takes (reads that end up unmapped get an empty list), so labels never visit the host.
  * Enum values: mate_status 0 SINGLE_END, 1 PAIRED_END_LEFT, 2 PAIRED_END_RIGHT, 3 PAIRED_END_PAIRED (the
@@ -290,6 +290,31 @@ typedef struct sfgpu_filter_stats {   /* all ACCUMULATED by the call */
 SFGPU_API int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
                       const sfgpu_filter_opts* opts, uint32_t* d_ids_out, uint32_t* d_offsets_out,
                       uint32_t* d_fl_counts, int64_t* remaining_fl_ops, sfgpu_filter_stats* stats, sfgpu_stream stream);
+
+/* The samples the same loop collects when bias correction is on (one more pass over the hit records, for the
+ * callers that need it): for every read, the 6-mer context of the FIRST hit that yields one (needBiasSample,
+ * src/SailfishQuantify.cpp:270-287 / :559-581; ReadKmerDist<6>::update, include/ReadKmerDist.hpp:35-73), while
+ * the budget sfOpts.numBiasSamples lasts -- "the first N successful reads in read order", what one mapping thread
+ * does; and, in a paired library, the fragment-GC percentage of every properly paired hit (:375-389; no budget).
+ * The reads and hits considered are those that survive the maxReadOccs / orphan cuts of sfgpu_filter_hits (same
+ * opts).  Counters are ACCUMULATED into d_read_bias (4096 uint32) / d_observed_gc (101 uint32); either may be NULL.
+ * d_gc_prefix: the per-transcript inclusive G/C counts laid out like d_seq (sfgpu_gc_prefix; 4 bytes per base),
+ * required with d_observed_gc -- Transcript::GCCount_ for gcSampFactor 1 (include/Transcript.hpp:183-196).
+ * Synchronous. */
+typedef struct sfgpu_bias_sampler {
+    const char* d_seq;                /* RapMapSAIndex::seq */
+    const uint64_t* d_seq_off;        /* [M] txpOffsets */
+    const uint32_t* d_ref_len;        /* [M] */
+    uint32_t* d_read_bias;            /* [4096] ReadKmerDist<6>::counts, or NULL (biasCorrect off) */
+    int64_t* remaining_bias_samples;  /* sfOpts.numBiasSamples (host), decremented */
+    uint32_t* d_observed_gc;          /* [101] ReadExperiment::observedGC, or NULL (gcBiasCorrect off) */
+    const uint32_t* d_gc_prefix;      /* see above */
+    uint64_t n_bias_sampled, n_gc_sampled;   /* ACCUMULATED by the call */
+} sfgpu_bias_sampler;
+SFGPU_API int sfgpu_gc_prefix(const char* d_seq, const uint64_t* d_seq_off, const uint32_t* d_ref_len, uint64_t M,
+                      uint32_t* d_gc_prefix, sfgpu_stream stream);
+SFGPU_API int sfgpu_sample_bias(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
+                      const sfgpu_filter_opts* opts, sfgpu_bias_sampler* sampler, sfgpu_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (next) Bias-aware effective lengths: sailfish::utils::updateEffectiveLengths

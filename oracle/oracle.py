@@ -335,6 +335,43 @@ def filter_hits(hits, hit_off, fmt, paired_library, discard_orphans=True, ignore
     return ids[: out_off[-1]], out_off, fl, int(rem.value), {k: int(getattr(st, k)) for k, _ in _FilterStats._fields_}
 
 
+class _BiasSampler(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("seq_off", C.c_void_p), ("ref_len", C.c_void_p), ("M", C.c_uint64),
+                ("read_bias", C.c_void_p), ("remaining_bias_samples", C.POINTER(C.c_int64)), ("observed_gc", C.c_void_p),
+                ("n_bias_sampled", C.c_uint64), ("n_gc_sampled", C.c_uint64)]
+
+
+def filter_hits_bias(hits, hit_off, fmt, paired_library, seq, seq_off, ref_len, read_bias=None, remaining_bias_samples=0,
+                     observed_gc=None, **kw):
+    """filter_hits plus the samples the loop collects for bias correction: the read-start 6-mer of the first hit that
+    yields one (src/SailfishQuantify.cpp:270-287 / :559-581, ReadKmerDist.hpp:35-73; budget numBiasSamples) and the
+    fragment GC of every proper pair (:375-389).  read_bias (4096) / observed_gc (101) are accumulated when given.
+    Returns (filter_hits' tuple, read_bias, remaining_bias_samples, observed_gc, n_bias_sampled, n_gc_sampled)."""
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE); off = _c(hit_off, np.uint32)
+    R = len(off) - 1
+    max_frag_len = kw.get("max_frag_len", 1000)
+    ids = np.zeros(max(len(h), 1), np.uint32); out_off = np.zeros(R + 1, np.uint32)
+    fl = np.zeros(max_frag_len, np.uint32) if kw.get("fl_counts") is None else _c(kw["fl_counts"], np.uint32).copy()
+    o = _FilterOpts(kw.get("max_read_occs", 200), max_frag_len, int(paired_library), int(kw.get("discard_orphans", True)),
+                    int(kw.get("ignore_compat", False)), int(kw.get("enforce_compat", False)), int(kw.get("can_dovetail", False)),
+                    _LibFmt(*fmt, 0))
+    st = _FilterStats(); rem = C.c_int64(int(kw.get("remaining_fl_ops", 0)))
+    sq = np.frombuffer(seq, dtype=np.uint8).copy() if isinstance(seq, (bytes, bytearray)) else _c(seq, np.uint8)
+    so = _c(seq_off, np.uint64); rl = _c(ref_len, np.uint32)
+    rb = None if read_bias is None else _c(read_bias, np.uint32).copy()
+    og = None if observed_gc is None else _c(observed_gc, np.uint32).copy()
+    remb = C.c_int64(int(remaining_bias_samples))
+    bs = _BiasSampler(_p(sq).value, _p(so).value, _p(rl).value, len(rl), None if rb is None else _p(rb).value,
+                      C.pointer(remb), None if og is None else _p(og).value, 0, 0)
+    L = lib()
+    L.sfo_filter_hits_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_FilterOpts), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_int64), C.POINTER(_FilterStats), C.POINTER(_BiasSampler)]
+    L.sfo_filter_hits_bias.restype = None
+    L.sfo_filter_hits_bias(h.ctypes.data, _p(off), R, C.byref(o), _p(ids), _p(out_off), _p(fl), C.byref(rem), C.byref(st), C.byref(bs))
+    base = (ids[: out_off[-1]], out_off, fl, int(rem.value), {k: int(getattr(st, k)) for k, _ in _FilterStats._fields_})
+    return base, rb, int(remb.value), og, int(bs.n_bias_sampled), int(bs.n_gc_sampled)
+
+
 def ref_xxhash():
     """ctypes handle on the reference's own xxhash.c (oracle/_ref/libxxhash_ref.so) or None."""
     so = os.path.join(_HERE, "_ref", "libxxhash_ref.so")

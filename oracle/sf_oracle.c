@@ -1060,9 +1060,44 @@ SFO_API int sfo_compatible_pair(sfo_libfmt expected, sfo_libfmt observed) {
     return expected.strandedness == SFO_ST_U || expected.strandedness == observed.strandedness;
 }
 
-SFO_API void sfo_filter_hits(const sfo_hit* hits, const uint32_t* hit_off, uint32_t n_reads, const sfo_filter_opts* o,
+/* What the hit loop reads and writes for bias correction: the read-start 6-mer sample (:270-287 / :559-581,
+ * ReadKmerDist<6>::update, include/ReadKmerDist.hpp:35-73) and the fragment-GC sample of proper pairs (:375-389).
+ * read_bias / observed_gc may be NULL (biasCorrect / gcBiasCorrect off). */
+typedef struct {
+    const char* seq; const uint64_t* seq_off; const uint32_t* ref_len; uint64_t M;
+    uint32_t* read_bias;              /* [4096] */
+    int64_t* remaining_bias_samples;  /* sfOpts.numBiasSamples */
+    uint32_t* observed_gc;            /* [101] */
+    uint64_t n_bias_sampled, n_gc_sampled;
+} sfo_bias_sampler;
+
+/* ReadKmerDist::update (include/ReadKmerDist.hpp:35-73): dir 0 = FORWARD (the context is stored reverse-complemented) */
+static int read_bias_update(uint32_t* counts, const char* start, const char* p, const char* end, int dir) {
+    const int pos_before = 2, pos_after = 4;
+    if (dir == 0) {
+        if ((p - start) >= pos_before && ((p - pos_before + SFO_K) < end)) {
+            p -= pos_before;
+            uint32_t idx = sfo_index_for_kmer(p, SFO_K, 1);
+            if (idx > SFO_NKMER) return 0;
+            counts[idx]++;
+            return 1;
+        }
+    } else {
+        if ((p - start) >= pos_after && ((p - pos_after + SFO_K) < end)) {
+            p -= pos_after;
+            uint32_t idx = sfo_index_for_kmer(p, SFO_K, 0);
+            if (idx > SFO_NKMER) return 0;
+            counts[idx]++;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static void filter_hits_impl(const sfo_hit* hits, const uint32_t* hit_off, uint32_t n_reads, const sfo_filter_opts* o,
                              uint32_t* ids_out, uint32_t* off_out, uint32_t* fl_counts, int64_t* remaining_fl_ops,
-                             sfo_filter_stats* st) {
+                             sfo_filter_stats* st, sfo_bias_sampler* bs) {
+    sfo_gc* gcs = (bs && bs->observed_gc) ? (sfo_gc*)calloc(bs->M ? bs->M : 1, sizeof(sfo_gc)) : NULL;   /* GCCount_, built on first use */
     uint32_t max_n = 0;
     for (uint32_t r = 0; r < n_reads; ++r) { uint32_t n = hit_off[r + 1] - hit_off[r]; if (n > max_n) max_n = n; }
     sfo_hit* joint = (sfo_hit*)malloc((max_n ? max_n : 1) * sizeof(sfo_hit));
@@ -1093,8 +1128,34 @@ SFO_API void sfo_filter_hits(const sfo_hit* hits, const uint32_t* hit_off, uint3
                 memcpy(joint, tmp, n * sizeof(sfo_hit));
             }
         }
+        int need_bias = bs && bs->read_bias != NULL;                             /* :255 / :545 needBiasSample = sfOpts.biasCorrect */
+        const int need_gc = bs && bs->observed_gc != NULL;                       /* :256 needGCSample, :137 estimateGCBias */
         for (size_t q = 0; q < n; ++q) {
             const sfo_hit* h = &joint[q];
+            if (need_bias && *bs->remaining_bias_samples > 0) {                  /* :270-287 / :559-581 */
+                int32_t pos = h->pos;
+                int32_t start_pos = h->fwd ? pos : pos + (int32_t)h->read_len;
+                uint32_t L = bs->ref_len[h->tid];
+                if (start_pos > 0 && (uint32_t)start_pos < L) {
+                    const char* txp_start = bs->seq + bs->seq_off[h->tid];
+                    if (read_bias_update(bs->read_bias, txp_start, txp_start + start_pos, txp_start + L, h->fwd ? 0 : 1)) {
+                        (*bs->remaining_bias_samples)--;
+                        need_bias = 0;
+                        bs->n_bias_sampled++;
+                    }
+                }
+            }
+            if (need_gc && o->paired_library && h->mate_status == SFO_MS_PAIRED) {   /* :375-389 */
+                int32_t start = h->pos < h->mate_pos ? h->pos : h->mate_pos;
+                int32_t stop = (int32_t)((uint32_t)start + h->frag_len);
+                uint32_t L = bs->ref_len[h->tid];
+                if (start > 0 && (uint32_t)stop < L) {
+                    sfo_gc* g = &gcs[h->tid];
+                    if (!g->cnt) gc_build(g, bs->seq + bs->seq_off[h->tid], L, 1);
+                    bs->observed_gc[gc_frac(g, start, stop)]++;
+                    bs->n_gc_sampled++;
+                }
+            }
             int compat = o->ignore_compat, fwd_hit;
             if (o->paired_library && is_paired) {                                /* :341-368 */
                 if (!compat) {
@@ -1129,4 +1190,18 @@ SFO_API void sfo_filter_hits(const sfo_hit* hits, const uint32_t* hit_off, uint3
     }
     off_out[n_reads] = (uint32_t)w;
     free(joint); free(tmp); free(all); free(compat_ids);
+    if (gcs) { for (uint64_t t = 0; t < bs->M; ++t) free(gcs[t].cnt); free(gcs); }
+}
+
+SFO_API void sfo_filter_hits(const sfo_hit* hits, const uint32_t* hit_off, uint32_t n_reads, const sfo_filter_opts* o,
+                             uint32_t* ids_out, uint32_t* off_out, uint32_t* fl_counts, int64_t* remaining_fl_ops,
+                             sfo_filter_stats* st) {
+    filter_hits_impl(hits, hit_off, n_reads, o, ids_out, off_out, fl_counts, remaining_fl_ops, st, NULL);
+}
+
+/* the same loop with the bias / GC samples collected (biasCorrect / gcBiasCorrect) */
+SFO_API void sfo_filter_hits_bias(const sfo_hit* hits, const uint32_t* hit_off, uint32_t n_reads, const sfo_filter_opts* o,
+                                  uint32_t* ids_out, uint32_t* off_out, uint32_t* fl_counts, int64_t* remaining_fl_ops,
+                                  sfo_filter_stats* st, sfo_bias_sampler* bs) {
+    filter_hits_impl(hits, hit_off, n_reads, o, ids_out, off_out, fl_counts, remaining_fl_ops, st, bs);
 }

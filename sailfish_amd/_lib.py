@@ -66,6 +66,12 @@ class FilterStats(C.Structure):
                 ("upper_bound_hits", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("fl_sampled", C.c_uint64)]
 
 
+class BiasSampler(C.Structure):
+    _fields_ = [("d_seq", C.c_void_p), ("d_seq_off", C.c_void_p), ("d_ref_len", C.c_void_p), ("d_read_bias", C.c_void_p),
+                ("remaining_bias_samples", C.POINTER(C.c_int64)), ("d_observed_gc", C.c_void_p), ("d_gc_prefix", C.c_void_p),
+                ("n_bias_sampled", C.c_uint64), ("n_gc_sampled", C.c_uint64)]
+
+
 class BiasInputs(C.Structure):
     _fields_ = [("M", C.c_uint64), ("d_seq", C.c_void_p), ("d_seq_off", C.c_void_p), ("d_ref_len", C.c_void_p),
                 ("d_txp_eff_len", C.c_void_p), ("h_fl_counts", C.c_void_p), ("max_frag_len", C.c_uint32),
@@ -106,6 +112,8 @@ _SIGS = {
     "sfgpu_efflen_empirical": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     "sfgpu_filter_hits": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(FilterOpts), _P, _P, _P, C.POINTER(C.c_int64),
                                     C.POINTER(FilterStats), _P]),
+    "sfgpu_gc_prefix": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
+    "sfgpu_sample_bias": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(FilterOpts), C.POINTER(BiasSampler), _P]),
     "sfgpu_bias_create": (C.c_int, [C.POINTER(_P), C.POINTER(BiasInputs), _P]),
     "sfgpu_bias_destroy": (C.c_int, [_P]),
     "sfgpu_bias_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(BiasStats), _P]),

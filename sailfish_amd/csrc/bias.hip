@@ -267,6 +267,28 @@ __device__ __forceinline__ void stage_gc_prefix(const char* s, uint32_t n, uint3
     __syncthreads();
 }
 
+// Transcript::GCCount_ for gcSampFactor 1 (include/Transcript.hpp:183-196), laid out like the sequence: one block per
+// transcript, chunks through LDS with the running count carried over (sfgpu_gc_prefix; read by the GC sampling of
+// sfgpu_sample_bias)
+constexpr uint32_t kPrefixChunk = 8192;
+__global__ void __launch_bounds__(kBlock) k_gc_prefix(const char* __restrict__ seq, const uint64_t* __restrict__ seq_off,
+                                                      const uint32_t* __restrict__ ref_len, uint32_t* __restrict__ out) {
+    __shared__ uint32_t Gs[kPrefixChunk];
+    __shared__ uint32_t runs[kBlock];
+    const uint64_t t = blockIdx.x;
+    const uint32_t L = ref_len[t];
+    const char* s = seq + seq_off[t];
+    uint32_t* o = out + seq_off[t];
+    uint32_t base = 0;
+    for (uint32_t p0 = 0; p0 < L; p0 += kPrefixChunk) {
+        const uint32_t n = min(kPrefixChunk, L - p0);
+        stage_gc_prefix(s + p0, n, Gs, runs);
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) o[p0 + j] = base + Gs[j];
+        base += Gs[n - 1];
+        __syncthreads();
+    }
+}
+
 // S[t][g] for one transcript per block (see the header).  Dynamic LDS: 101 f64 | 64 x 101 u32 | kBlock u32 |
 // stage_cap u32.
 __global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
@@ -583,6 +605,16 @@ int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_strea
 }
 
 int sfgpu_bias_destroy(sfgpu_bias* b) { bias_free(b); return SFGPU_OK; }
+
+int sfgpu_gc_prefix(const char* d_seq, const uint64_t* d_seq_off, const uint32_t* d_ref_len, uint64_t M,
+                    uint32_t* d_gc_prefix, sfgpu_stream stream) {
+    SF_REQUIRE(M == 0 || (d_seq && d_seq_off && d_ref_len && d_gc_prefix), SFGPU_ERR_INVALID, "sfgpu_gc_prefix: null pointer");
+    SF_REQUIRE(M < (1ull << 31), SFGPU_ERR_RANGE, "sfgpu_gc_prefix: more than 2^31 transcripts");
+    if (M == 0) return SFGPU_OK;
+    hipLaunchKernelGGL(k_gc_prefix, dim3((unsigned)M), dim3(kBlock), 0, as_stream(stream), d_seq, d_seq_off, d_ref_len, d_gc_prefix);
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
 
 int sfgpu_bias_update(sfgpu_bias* b, const double* d_eff_in, const double* d_alpha, double* d_eff_out,
                       sfgpu_bias_stats* stats, sfgpu_stream stream) {

@@ -191,9 +191,140 @@ k_filter_compact(const uint32_t* __restrict__ off, uint32_t n_reads, const uint3
     if (fl_flag && fl_flag[r] && fl_rank[r] < fl_budget) atomicAdd(&fl_counts[fl_len[r]], 1u);
 }
 
+// ---- bias / GC samples of the same loop (sfgpu_sample_bias) ---------------------------------------------
+struct SamplerDev {
+    const char* seq; const uint64_t* seq_off; const uint32_t* ref_len; const uint32_t* gc_prefix;
+    uint32_t* observed_gc; int want_seq;
+};
+
+// indexForKmer (include/UtilityFunctions.hpp:93-148): false when a byte is not ACGTU (the reference then gets
+// 0xFFFFFFFF and ReadKmerDist::update reports no success)
+__device__ __forceinline__ bool kmer_index6(const char* p, bool revcomp, uint32_t& idx) {
+    uint32_t f = 0, r = 0; bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const unsigned c = (unsigned char)p[j] & 0xDFu;
+        uint32_t code = 0;
+        if (c == 'A') code = 0; else if (c == 'C') code = 1; else if (c == 'G') code = 2; else if (c == 'T' || c == 'U') code = 3; else ok = false;
+        f = (f << 2) | code;
+        r |= (3u - code) << (2 * j);
+    }
+    idx = revcomp ? r : f;
+    return ok;
+}
+
+constexpr int kGcBins = 101;
+
+// One lane per read, hits staged as in k_filter_count.  The read-start context is only flagged here (the budget
+// is "the first N successes in read order": ranks come from a scan, k_apply_bias_samples adds the survivors);
+// GC samples have no budget and go to a block-private histogram in LDS.
+__global__ void __launch_bounds__(kFilterBlock)
+k_sample_bias(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ off, uint32_t n_reads, sfgpu_filter_opts o,
+              SamplerDev s, uint32_t* __restrict__ flag, uint32_t* __restrict__ kmer, unsigned long long* n_gc) {
+    const uint32_t r = blockIdx.x * kFilterBlock + threadIdx.x;
+    __shared__ __attribute__((aligned(8))) sfgpu_hit lds_hits[kStageHits];
+    __shared__ uint32_t gc_hist[kGcBins];
+    if (threadIdx.x < kGcBins) gc_hist[threadIdx.x] = 0;                   // stage_block_hits synchronises (or returns uniformly)
+    __syncthreads();
+    uint32_t first_hit;
+    const sfgpu_hit* my_hits = stage_block_hits(hits, off, n_reads, lds_hits, first_hit);
+    if (r < n_reads) {
+        const ReadView v = view_read(my_hits, first_hit, off, r, o);
+        bool need = s.want_seq != 0;                                         // needBiasSample (:255 / :545)
+        uint32_t got = 0, my_idx = 0;
+        for_each_hit(v, o, [&](const sfgpu_hit& h, bool) {
+            const uint32_t L = s.ref_len[h.tid];
+            if (need) {                                                      // :270-287 / :559-581
+                const int32_t start_pos = h.fwd ? h.pos : h.pos + (int32_t)h.read_len;
+                if (start_pos > 0 && (uint32_t)start_pos < L) {
+                    const char* txp = s.seq + s.seq_off[h.tid];
+                    // ReadKmerDist::update: 2 bases before a forward read's start / 4 before a reverse read's, K = 6
+                    const int32_t back = h.fwd ? 2 : 4;
+                    if (start_pos >= back && (uint32_t)(start_pos - back + 6) < L) {
+                        uint32_t idx;
+                        if (kmer_index6(txp + (start_pos - back), h.fwd != 0, idx)) { got = 1; my_idx = idx; need = false; }
+                    }
+                }
+            }
+            if (s.observed_gc && o.paired_library && h.mate_status == MS_PAIRED) {   // :375-389
+                const int32_t start = h.pos < h.mate_pos ? h.pos : h.mate_pos;
+                const int32_t stop = (int32_t)((uint32_t)start + h.frag_len);
+                if (start > 0 && (uint32_t)stop < L) {
+                    const uint32_t* G = s.gc_prefix + s.seq_off[h.tid];
+                    const uint32_t d = G[stop] - G[start];
+                    const long g = lrint((100.0 * (double)d) / (double)(stop - start + 1));    // Transcript::gcFrac
+                    atomicAdd(&gc_hist[g], 1u);
+                }
+            }
+        });
+        if (flag) { flag[r] = got; kmer[r] = my_idx; }
+    } else if (r == n_reads && flag) flag[r] = 0;
+    __syncthreads();
+    if (threadIdx.x < kGcBins && s.observed_gc) {
+        const uint32_t c = gc_hist[threadIdx.x];
+        if (c) { atomicAdd(&s.observed_gc[threadIdx.x], c); atomicAdd(n_gc, (unsigned long long)c); }
+    }
+}
+
+__global__ void __launch_bounds__(kFilterBlock)
+k_apply_bias_samples(uint32_t n_reads, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ kmer,
+                     const uint64_t* __restrict__ rank, uint64_t budget, uint32_t* read_bias) {
+    const uint32_t r = blockIdx.x * kFilterBlock + threadIdx.x;
+    if (r < n_reads && flag[r] && rank[r] < budget) atomicAdd(&read_bias[kmer[r]], 1u);
+}
+
 }  // namespace sfgpu
 
 using namespace sfgpu;
+
+extern "C" int sfgpu_sample_bias(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
+                                 const sfgpu_filter_opts* opts, sfgpu_bias_sampler* sp, sfgpu_stream stream) {
+    SF_REQUIRE(d_hit_offsets && opts && sp, SFGPU_ERR_INVALID, "sfgpu_sample_bias: null pointer");
+    SF_REQUIRE(n_reads < 0x7FFFFFFFu, SFGPU_ERR_RANGE, "sfgpu_sample_bias: a batch holds < 2^31 reads");
+    const bool want_seq = sp->d_read_bias && sp->remaining_bias_samples && *sp->remaining_bias_samples > 0;
+    const bool want_gc = sp->d_observed_gc != nullptr && opts->paired_library;
+    if (n_reads == 0 || (!want_seq && !want_gc)) return SFGPU_OK;
+    SF_REQUIRE(d_hits && sp->d_seq && sp->d_seq_off && sp->d_ref_len, SFGPU_ERR_INVALID, "sfgpu_sample_bias: null pointer");
+    SF_REQUIRE(!want_gc || sp->d_gc_prefix, SFGPU_ERR_INVALID, "sfgpu_sample_bias: GC sampling needs d_gc_prefix (sfgpu_gc_prefix)");
+    hipStream_t st = as_stream(stream);
+    const size_t n1 = (size_t)n_reads + 1;
+    uint32_t *d_flag = nullptr, *d_kmer = nullptr; uint64_t* d_rank = nullptr; unsigned long long* d_ngc = nullptr;
+    int rc = SFGPU_OK;
+    hipError_t e = pool_malloc(&d_ngc, 8);
+    if (e == hipSuccess && want_seq) e = pool_malloc(&d_flag, n1 * 4);
+    if (e == hipSuccess && want_seq) e = pool_malloc(&d_kmer, n1 * 4);
+    if (e == hipSuccess && want_seq) e = pool_malloc(&d_rank, (n1 + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ngc, 0, 8, st);
+    const unsigned grid = (unsigned)((n1 + kFilterBlock - 1) / kFilterBlock);
+    SamplerDev sd{sp->d_seq, sp->d_seq_off, sp->d_ref_len, sp->d_gc_prefix, want_gc ? sp->d_observed_gc : nullptr, want_seq ? 1 : 0};
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sample_bias, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, sd, d_flag, d_kmer, d_ngc);
+        e = hipGetLastError();
+    }
+    uint64_t h_succ = 0; unsigned long long h_ngc = 0;
+    if (e == hipSuccess && want_seq) rc = exclusive_scan_u32(d_flag, d_rank, n_reads, st);
+    if (e == hipSuccess && rc == SFGPU_OK) {
+        if (want_seq) e = hipMemcpyAsync(&h_succ, d_rank + n_reads, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_ngc, d_ngc, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    const uint64_t budget = want_seq ? (uint64_t)*sp->remaining_bias_samples : 0;
+    if (e == hipSuccess && rc == SFGPU_OK && want_seq) {
+        hipLaunchKernelGGL(k_apply_bias_samples, dim3(grid), dim3(kFilterBlock), 0, st, n_reads, d_flag, d_kmer, d_rank, budget, sp->d_read_bias);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    for (void* p : {(void*)d_flag, (void*)d_kmer, (void*)d_rank, (void*)d_ngc}) if (p) pool_free(p);
+    SF_HIP(e);
+    if (rc) return rc;
+    if (want_seq) {
+        const uint64_t taken = h_succ < budget ? h_succ : budget;
+        *sp->remaining_bias_samples -= (int64_t)taken;
+        sp->n_bias_sampled += taken;
+    }
+    sp->n_gc_sampled += h_ngc;
+    return SFGPU_OK;
+}
 
 extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_offsets, uint32_t n_reads,
                                  const sfgpu_filter_opts* opts, uint32_t* d_ids_out, uint32_t* d_offsets_out,

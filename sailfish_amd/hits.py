@@ -63,3 +63,52 @@ def filter_hits(hits, hit_offsets, lib_format, sopt=None, *, paired_library=None
                                                 C.byref(st), _lib.current_stream_ptr()))
     total = int(out_off[-1].item()) & 0xFFFFFFFF if R >= 0 else 0
     return ids[:total], out_off, int(rem.value), {k: int(getattr(st, k)) for k, _ in _lib.FilterStats._fields_}
+
+
+def _device_hits(hits, hit_offsets, dev):
+    if isinstance(hits, torch.Tensor):
+        d_hits = hits.to(dev).contiguous()
+    else:
+        h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        d_hits = torch.from_numpy(h.view(np.uint8).reshape(-1).copy()).to(dev)
+    off = hit_offsets
+    d_off = off.to(dev).contiguous() if isinstance(off, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(off, np.uint32).view(np.int32).copy()).to(dev)
+    return d_hits, d_off
+
+
+def gc_prefix(seq, seq_off, ref_len):
+    """Transcript::GCCount_ of every transcript (include/Transcript.hpp:183-196), laid out like `seq`: int32 device
+    tensor of seq.numel() entries (4 bytes per base) -- what sample_bias reads for the fragment-GC samples."""
+    out = torch.zeros(seq.numel(), dtype=torch.int32, device=seq.device)
+    so = seq_off.to(torch.int64).contiguous()
+    with torch.cuda.device(seq.device):
+        _lib.check(_lib.lib().sfgpu_gc_prefix(_lib.ptr(seq), _lib.ptr(so), _lib.ptr(ref_len), int(ref_len.numel()), _lib.ptr(out),
+                                              _lib.current_stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+    return out
+
+
+def sample_bias(hits, hit_offsets, lib_format, seq, seq_off, ref_len, *, read_bias=None, remaining_bias_samples=0,
+                observed_gc=None, gc_prefix_table=None, paired_library=None, allow_orphans=False, max_read_occs=200,
+                max_frag_len=1000, device="cuda"):
+    """The bias / GC samples the hit loop collects (src/SailfishQuantify.cpp:270-287, 375-389, 559-581) over the reads and
+    hits that survive filter_hits' cuts.  read_bias (int32 device tensor [4096]) and observed_gc ([101]) are updated in
+    place when given.  Returns (remaining_bias_samples, n_bias_sampled, n_gc_sampled)."""
+    dev = torch.device(device)
+    fmt = LIBRARY_FORMATS[lib_format.upper()] if isinstance(lib_format, str) else tuple(lib_format)
+    if paired_library is None:
+        paired_library = fmt[0] == 1
+    d_hits, d_off = _device_hits(hits, hit_offsets, dev)
+    R = int(d_off.numel()) - 1
+    o = _lib.FilterOpts(int(max_read_occs), int(max_frag_len), int(bool(paired_library)), int(not allow_orphans), 0, 0, 0,
+                        _lib.LibFmt(int(fmt[0]), int(fmt[1]), int(fmt[2]), 0))
+    so = seq_off.to(torch.int64).contiguous()
+    rem = C.c_int64(int(remaining_bias_samples))
+    sp = _lib.BiasSampler(_lib.ptr(seq).value, _lib.ptr(so).value, _lib.ptr(ref_len).value,
+                          None if read_bias is None else _lib.ptr(read_bias).value, C.pointer(rem),
+                          None if observed_gc is None else _lib.ptr(observed_gc).value,
+                          None if gc_prefix_table is None else _lib.ptr(gc_prefix_table).value, 0, 0)
+    with torch.cuda.device(dev):
+        torch.cuda.current_stream().synchronize()
+        _lib.check(_lib.lib().sfgpu_sample_bias(_lib.ptr(d_hits), _lib.ptr(d_off), R, C.byref(o), C.byref(sp), _lib.current_stream_ptr()))
+    return int(rem.value), int(sp.n_bias_sampled), int(sp.n_gc_sampled)

@@ -65,10 +65,11 @@ NUM_BIAS_BINS = 4 ** 6             # ReadKmerDist<6>::counts (include/ReadExperi
 
 def write_meta(path, readExp: ReadExperiment, sopt: SailfishOpts, start_time: str):
     """writeMeta (GZipWriter.cpp:94-192): aux/bootstrap/names.tsv.gz when sampling is requested, aux/fld.gz and
-    aux/meta_info.json (cereal JSON: same keys, same order).  Differences, both outside the hot path: fld.gz holds
-    the stored fragment-length counts themselves (the reference writes a random_device-seeded 10 000-sample
-    realisation of them, EmpiricalDistribution.cpp:125-143), and the bias-model vectors (expected_/observed_
-    bias / gc) are not written because the bias models are out of scope."""
+    the bias-model vectors expected_bias.gz (float64[4096]) / observed_bias.gz (int32[4096]) / expected_gc.gz
+    (float64[101]) / observed_gc.gz (int32[101]) (:145-162; all ones without bias correction, as in the reference)
+    and aux/meta_info.json (cereal JSON: same keys, same order).  One difference, outside the hot path: fld.gz
+    holds the stored fragment-length counts themselves (the reference writes a random_device-seeded 10 000-sample
+    realisation of them, EmpiricalDistribution.cpp:125-143)."""
     txps = readExp.transcripts()
     aux = os.path.join(path, sopt.auxDir)
     os.makedirs(aux, exist_ok=True)
@@ -85,6 +86,10 @@ def write_meta(path, readExp: ReadExperiment, sopt: SailfishOpts, start_time: st
     fld = np.zeros(sopt.maxFragLen, np.int32) if fld is None else np.asarray(fld, np.int32)
     with gzip.open(os.path.join(aux, "fld.gz"), "wb", compresslevel=6) as f:
         f.write(fld.tobytes())                                   # writeVectorToFile: raw little-endian binary
+    for name, vec, dt in (("expected_bias.gz", readExp.expectedSeqBias(), np.float64), ("observed_bias.gz", readExp.readBias(), np.int32),
+                          ("expected_gc.gz", readExp.expectedGCBias(), np.float64), ("observed_gc.gz", readExp.observedGC(), np.int32)):
+        with gzip.open(os.path.join(aux, name), "wb", compresslevel=6) as f:
+            f.write(np.ascontiguousarray(vec).astype(dt).tobytes())
     samp_type = "bootstrap" if n_boot > 0 else ("gibbs" if n_samp > 0 else "none")
     n_obs = readExp.numObservedFragments() or readExp.numMappedFragments()
     info = [("sf_version", SAILFISH_VERSION), ("samp_type", samp_type),

@@ -156,3 +156,94 @@ def test_filter_hits_device_vs_oracle(built, gpu):
     assert eq.total_reads == gst["n_mapped"] == ob.total_reads
     np.testing.assert_array_equal(rp, orp.astype(np.uint32)); np.testing.assert_array_equal(ii, oids)
     np.testing.assert_array_equal(cc, ocnt); np.testing.assert_array_equal(hh, ohash)
+
+
+# ---- bias / GC samples of the same loop (sfgpu_sample_bias) ----------------------------------------------------
+def _txome(rng, M, lo=40, hi=3000, alphabet=b"ACGT"):
+    lens = rng.integers(lo, hi, M).astype(np.uint32)
+    off = np.zeros(M, np.uint64); parts = []; pos = 0
+    for t in range(M):
+        off[t] = pos
+        parts.append(bytes(rng.choice(np.frombuffer(alphabet, np.uint8), int(lens[t])).astype(np.uint8)) + b"$")
+        pos += int(lens[t]) + 1
+    return b"".join(parts), off, lens
+
+
+def test_bias_samples_on_hand_built_reads(built):
+    """ReadKmerDist<6>::update (include/ReadKmerDist.hpp:35-73) through the loop (:270-287), and the GC sample (:375-389)"""
+    seq = b"AACCGGTTACGTACGTAAAACCCCGGGGTTTTACGT" + b"$"          # one transcript, L = 36
+    so, rl = np.array([0], np.uint64), np.array([36], np.uint32)
+    base = dict(seq=seq, seq_off=so, ref_len=rl, read_bias=np.ones(4096, np.uint32), remaining_bias_samples=10)
+    one = lambda rows, **kw: O.filter_hits_bias(_hits(rows), np.array([0, len(rows)], np.uint32), FORMATS["U"], False, **{**base, **kw})
+    # forward read starting at 10: window = seq[8:14] = "ACGTAC", stored reverse-complemented
+    _, rb, rem, _, nb, _ = one([(0, 10, True, SINGLE)])
+    assert nb == 1 and rem == 9 and rb[O.index_for_kmer(b"ACGTAC", rc=True)] == 2 and rb.sum() == 4097
+    # reverse read at pos 5, length 20: start = 25, window = seq[21:27] = "CCCGGG", stored forward
+    _, rb, rem, _, nb, _ = one([(0, 5, False, SINGLE, 0, 0, 0, 20, 0)])
+    assert nb == 1 and rb[O.index_for_kmer(b"CCCGGG")] == 2
+    # no room for the window: start 1 (< 2 before), start 33 (33 - 2 + 6 = 37 > 36), start 0, start at the end
+    for rows in ([(0, 1, True, SINGLE)], [(0, 33, True, SINGLE)], [(0, 0, True, SINGLE)], [(0, 36, True, SINGLE)],
+                 [(0, 3, False, SINGLE, 0, 0, 0, 0, 0)]):
+        _, rb, rem, _, nb, _ = one(rows)
+        assert nb == 0 and rem == 10 and rb.sum() == 4096
+    # the first hit that yields a sample is the one counted; the budget stops everything
+    _, rb, rem, _, nb, _ = one([(0, 1, True, SINGLE), (0, 10, True, SINGLE), (0, 12, True, SINGLE)])
+    assert nb == 1 and rb[O.index_for_kmer(b"ACGTAC", rc=True)] == 2
+    _, rb, rem, _, nb, _ = one([(0, 10, True, SINGLE)], remaining_bias_samples=0)
+    assert nb == 0 and rb.sum() == 4096
+    # a byte outside ACGT in the window: no success
+    bad = dict(base); bad["seq"] = seq[:9] + b"N" + seq[10:]
+    _, rb, rem, _, nb, _ = O.filter_hits_bias(_hits([(0, 10, True, SINGLE)]), np.array([0, 1], np.uint32), FORMATS["U"], False, **bad)
+    assert nb == 0
+    # fragment GC of a proper pair: start = min(pos, matePos) = 4, stop = 4 + 20: GC of seq[5:25] over 21
+    rows = [(0, 4, True, PAIRED, 14, False, 20)]
+    (_, _, _, _, st), _, _, og, _, ng = O.filter_hits_bias(_hits(rows), np.array([0, 1], np.uint32), FORMATS["IU"], True, seq=seq, seq_off=so,
+                                                           ref_len=rl, observed_gc=np.ones(101, np.uint32))
+    gc = sum(c in b"GC" for c in seq[5:25])
+    assert ng == 1 and og[int(np.rint(100.0 * gc / 21))] == 2 and og.sum() == 102 and st["n_mapped"] == 1
+    # start 0 or stop at the end: no sample
+    for rows in ([(0, 0, True, PAIRED, 14, False, 20)], [(0, 4, True, PAIRED, 14, False, 32)]):
+        _, _, _, og, _, ng = O.filter_hits_bias(_hits(rows), np.array([0, 1], np.uint32), FORMATS["IU"], True, seq=seq, seq_off=so,
+                                                ref_len=rl, observed_gc=np.ones(101, np.uint32))
+        assert ng == 0 and og.sum() == 101
+
+
+@pytest.mark.gpu
+def test_sample_bias_device_vs_oracle(built, gpu):
+    import torch
+    import sailfish_amd as sf
+    rng = np.random.default_rng(23)
+    M = 400
+    seq, so, rl = _txome(rng, M, alphabet=b"ACGTacgtN")               # a few N: windows with one give no sample
+    d_seq = torch.from_numpy(np.frombuffer(seq, np.uint8).copy()).to(gpu)
+    d_so = torch.from_numpy(so.astype(np.int64)).to(gpu)
+    d_rl = torch.from_numpy(rl.view(np.int32).copy()).to(gpu)
+    pre = sf.hits.gc_prefix(d_seq, d_so, d_rl)
+    # the prefix table is Transcript::GCCount_ per transcript
+    hp = pre.cpu().numpy().view(np.uint32)
+    for t in (0, 17, M - 1):
+        s = np.frombuffer(seq[int(so[t]):int(so[t]) + int(rl[t])], np.uint8)
+        np.testing.assert_array_equal(hp[int(so[t]):int(so[t]) + int(rl[t])], np.cumsum(np.isin(s, np.frombuffer(b"GCgc", np.uint8))))
+    for trial in range(10):
+        paired = trial % 2 == 0
+        name = str(rng.choice(["IU", "ISF", "OSR", "MU"] if paired else ["U", "SF", "SR"]))
+        R = int(rng.choice([1, 1000, 60_000]))
+        h, off = _random_reads(rng, R, M, paired)
+        h["pos"] = rng.integers(-5, 1500, len(h)); h["mate_pos"] = rng.integers(-5, 1500, len(h)); h["frag_len"] = rng.integers(0, 900, len(h))
+        kw = dict(discard_orphans=bool(rng.integers(0, 2)), max_read_occs=int(rng.choice([3, 200])), max_frag_len=1000)
+        budget = int(rng.choice([0, 5, 300, 10_000_000]))
+        want_seq, want_gc = bool(trial % 3 != 2), bool(trial % 3 != 1)
+        rb0 = rng.integers(1, 9, 4096).astype(np.uint32); og0 = rng.integers(1, 9, 101).astype(np.uint32)
+        _, orb, orem, oog, onb, ong = O.filter_hits_bias(h, off, FORMATS[name], paired, seq, so, rl, read_bias=rb0 if want_seq else None,
+                                                         remaining_bias_samples=budget, observed_gc=og0 if want_gc else None, **kw)
+        d_rb = torch.from_numpy(rb0.view(np.int32).copy()).to(gpu) if want_seq else None
+        d_og = torch.from_numpy(og0.view(np.int32).copy()).to(gpu) if want_gc else None
+        grem, gnb, gng = sf.hits.sample_bias(h, off, name, d_seq, d_so, d_rl, read_bias=d_rb, remaining_bias_samples=budget,
+                                             observed_gc=d_og, gc_prefix_table=pre, paired_library=paired,
+                                             allow_orphans=not kw["discard_orphans"], max_read_occs=kw["max_read_occs"], device=gpu)
+        if want_seq:
+            np.testing.assert_array_equal(d_rb.cpu().numpy().view(np.uint32), orb)
+            assert (grem, gnb) == (orem, onb), (trial, grem, orem, gnb, onb)
+        if want_gc:
+            np.testing.assert_array_equal(d_og.cpu().numpy().view(np.uint32), oog)
+            assert gng == ong and (ong > 0) == (paired and ong > 0)

@@ -508,6 +508,10 @@ def test_aux_writers(sf, gpu, midsize, tmp_path):
     assert meta["num_mapped"] == eq.total_reads and abs(meta["percent_mapped"] - 100.0 * eq.total_reads / (eq.total_reads + 1000)) < 1e-9
     raw = np.frombuffer(gzip.open(os.path.join(aux, "bootstrap", "bootstraps.gz")).read(), np.float64).reshape(4, 5000)
     np.testing.assert_array_equal(raw, np.stack(kept))
+    for name, dt, n in (("expected_bias.gz", np.float64, 4096), ("observed_bias.gz", np.int32, 4096),     # :145-162
+                        ("expected_gc.gz", np.float64, 101), ("observed_gc.gz", np.int32, 101)):
+        v = np.frombuffer(gzip.open(os.path.join(aux, name)).read(), dt)
+        assert v.shape == (n,) and np.all(v == 1)                          # no bias correction: the pseudo-counts
 
 
 # ---------------------------------------------------------------------------------------- a16
