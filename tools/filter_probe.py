@@ -28,3 +28,21 @@ print(f"filter: {R} reads, {H} hits ({H*24/1e9:.2f} GB of records) in {dt*1e3:.2
       f"{(H*24 + out_ids.numel()*4 + R*8)/dt/1e12:.2f} TB/s on the algorithmic bytes (records once + ids out + offsets); stats {st}")
 eq = sf.EquivalenceClassBuilder(device=dev); eq.start(); eq.add_batch(out_ids, out_off); eq.finish()
 print("classes from the filtered lists:", eq.n_classes, "reads", eq.total_reads)
+
+# the bias / GC samples of the same loop (sfgpu_sample_bias): random transcript sequences of the synth lengths
+ref_len = synth.transcript_lengths(M, device=dev)
+L = (ref_len.to(torch.int64) & 0xFFFFFFFF)
+soff = torch.cumsum(L + 1, 0) - (L + 1)
+seq = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (int((L + 1).sum()),), device=dev, generator=g)]
+torch.cuda.synchronize(); t = time.perf_counter()
+pre = sf.hits.gc_prefix(seq, soff, ref_len)
+torch.cuda.synchronize(); print(f"gc_prefix: {seq.numel()/1e6:.0f} M bases in {(time.perf_counter()-t)*1e3:.2f} ms")
+for label, kw in (("6-mer samples (budget 1M)", dict(read_bias=torch.ones(4096, dtype=torch.int32, device=dev), remaining_bias_samples=1_000_000)),
+                  ("GC samples", dict(observed_gc=torch.ones(101, dtype=torch.int32, device=dev), gc_prefix_table=pre)),
+                  ("both", dict(read_bias=torch.ones(4096, dtype=torch.int32, device=dev), remaining_bias_samples=1_000_000,
+                                observed_gc=torch.ones(101, dtype=torch.int32, device=dev), gc_prefix_table=pre))):
+    for it in range(3):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        rem, nb, ng = sf.hits.sample_bias(hits, off, "IU", seq, soff, ref_len, device=dev, **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print(f"sample_bias {label}: {dt*1e3:.2f} ms for {R} reads / {H} hits; sampled {nb} 6-mers, {ng} fragments")
