@@ -189,6 +189,15 @@ SFGPU_API int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats);
 SFGPU_API int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats);
 /* device pointer of alphaOut (M doubles) for the caller's collective */
 SFGPU_API double* sfgpu_em_alpha_out(sfgpu_em* em);
+/* The piecewise loop with doBiasCorrect (src/CollapsedEMOptimizer.cpp:814-840): run to a recompute iteration by
+ * lowering the stop bounds (set_bounds, between polls), hand the current abundances (sfgpu_em_alpha) and lengths
+ * (sfgpu_em_lengths: effLens as the loop holds them, clamped at 1) to sfgpu_bias_update, then give the new lengths
+ * back with rebase -- updateEqClassWeights (:527-555): the lengths are replaced (clamped at 1) and x is rebuilt from
+ * the current alpha -- raise the bounds again and continue.  The next begin() restores the problem's own lengths. */
+SFGPU_API double* sfgpu_em_alpha(sfgpu_em* em);
+SFGPU_API double* sfgpu_em_lengths(sfgpu_em* em);
+SFGPU_API int sfgpu_em_set_bounds(sfgpu_em* em, uint32_t min_iter, uint32_t max_iter);
+SFGPU_API int sfgpu_em_rebase(sfgpu_em* em, const double* d_len);
 /* Launch the E-step sweep kernel `n` times back to back (state untouched afterwards) and
  * return its average duration from HIP events on the stream: the live roofline measurement. */
 SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n, double* avg_ms);

@@ -129,6 +129,10 @@ _SIGS = {
     "sfgpu_em_poll": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(EmStats)]),
     "sfgpu_em_finish": (C.c_int, [_P, _P, _P, C.POINTER(EmStats)]),
     "sfgpu_em_alpha_out": (_P, [_P]),
+    "sfgpu_em_alpha": (_P, [_P]),
+    "sfgpu_em_lengths": (_P, [_P]),
+    "sfgpu_em_set_bounds": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "sfgpu_em_rebase": (C.c_int, [_P, _P]),
     "sfgpu_em_time_sweep": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.POINTER(C.c_double)]),
     "sfgpu_bootstrap": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.c_uint64, _P, SAMPLE_CB, _P, _P]),
     "sfgpu_bootstrap_counts": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),

@@ -625,6 +625,7 @@ struct sfgpu_em {
     sfgpu_em_opts graph_opts{};
     uint32_t graph_iters = 0;
     std::vector<sfgpu_em*> bs_clones;      // extra bootstrap lanes (sfgpu_bootstrap)
+    bool lenc_dirty = false;               // sfgpu_em_rebase replaced the lengths: begin() restores the problem's own
 };
 
 static void em_free(sfgpu_em* em) {
@@ -888,6 +889,11 @@ static int em_begin_on(sfgpu_em* em, const sfgpu_em_opts* opts, hipStream_t work
     int rc = em_fill_opts(em, opts);
     if (rc) return rc;
     em->cur = work;
+    if (em->lenc_dirty) {
+        hipLaunchKernelGGL(k_clamp_len, dim3(blocks_for(em->prob.M)), dim3(kEmBlock), 0, em->cur, em->prob.M, em->prob.d_len, em->lenc);
+        SF_CHECK_LAUNCH();
+        em->lenc_dirty = false;
+    }
     SF_HIP(hipMemsetAsync(em->alpha_out, 0, em->prob.M * 8, em->cur));
     if (em->L) {
         hipLaunchKernelGGL(k_mark_active, dim3(blocks_for(em->L)), dim3(kEmBlock), 0, em->cur, em->L, em->prob.d_ids,
@@ -927,6 +933,32 @@ static int sfgpu_em_init_impl(sfgpu_em* em) {
 }
 
 int sfgpu_em_init(sfgpu_em* em) { return sfgpu_em_init_impl(em); }
+
+double* sfgpu_em_alpha(sfgpu_em* em) { return em ? em->alpha : nullptr; }
+double* sfgpu_em_lengths(sfgpu_em* em) { return em ? em->lenc : nullptr; }
+
+int sfgpu_em_set_bounds(sfgpu_em* em, uint32_t min_iter, uint32_t max_iter) {
+    SF_REQUIRE(em && em->begun && !em->in_optimize, SFGPU_ERR_STATE, "sfgpu_em_set_bounds: piecewise API only, after begin");
+    em->opts.min_iter = min_iter; em->opts.max_iter = max_iter;
+    return SFGPU_OK;
+}
+
+// updateEqClassWeights (src/CollapsedEMOptimizer.cpp:527-555) for the piecewise loop: new lengths, x rebuilt from alpha
+int sfgpu_em_rebase(sfgpu_em* em, const double* d_len) {
+    SF_REQUIRE(em && em->begun && !em->in_optimize && d_len, SFGPU_ERR_STATE, "sfgpu_em_rebase: piecewise API only, after init");
+    const sfgpu_problem& p = em->prob;
+    dim3 g(em->nb), b(kEmBlock);
+    hipLaunchKernelGGL(k_clamp_len, dim3(blocks_for(p.M)), b, 0, em->cur, p.M, d_len, em->lenc);
+    em->lenc_dirty = true;
+    if (em->opts.use_vbem) {
+        hipLaunchKernelGGL(k_alpha_partials, g, b, 0, em->cur, p.M, em->alpha, em->sum_partials);
+        hipLaunchKernelGGL(k_vb_prepare, g, b, 0, em->cur, p.M, em->alpha, em->x, em->lenc, em->sum_partials, em->nb, em->d_state, 1);
+    } else {
+        hipLaunchKernelGGL(k_x_from_alpha, dim3(blocks_for(p.M)), b, 0, em->cur, p.M, em->alpha, em->lenc, em->x);
+    }
+    SF_CHECK_LAUNCH();
+    return SFGPU_OK;
+}
 
 int sfgpu_em_sweep(sfgpu_em* em) {
     SF_REQUIRE(em && em->begun, SFGPU_ERR_STATE, "sfgpu_em_sweep: call begin/init first");

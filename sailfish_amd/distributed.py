@@ -33,6 +33,7 @@ from .experiment import ReadExperiment, SailfishOpts
 from .optimizer import EMProblem
 
 kShardNnz = 1 << 27
+RECOMPUTE_ITERS = (50, 500, 1000)      # recomputeIt, src/CollapsedEMOptimizer.cpp:814
 
 
 class HipEngine:
@@ -49,6 +50,9 @@ class HipEngine:
 
     def set_effective_lengths(self, exp, sopt, fl_counts, remaining_fl_ops):
         return _efflen.set_effective_lengths(exp, sopt, fl_counts=fl_counts, remaining_fl_ops=remaining_fl_ops)
+
+    def bias_model(self, exp, sopt):
+        return exp.biasModel(sopt)
 
     def tpm(self, exp, sopt):
         return _writer.tpm(exp, sopt)[0]
@@ -187,9 +191,16 @@ class DistributedQuant:
         if self.problem is not None:       # release the previous run's device state before building the next
             self.problem.close(); self.problem = None
         kw = dict(use_vbem=sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)
+        # doBiasCorrect (src/CollapsedEMOptimizer.cpp:717): lengths are recomputed at iterations 50 / 500 / 1000
+        bias = self.engine.bias_model(exp, sopt) if (sopt.biasCorrect or sopt.gcBiasCorrect) else None
+        eff = None
+        self.recomputes = 0
         if mode in ("single", "replicated"):
             p = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
-            rc, st = p.optimize(**kw)
+            if bias is not None:
+                rc, st, eff, self.recomputes = p.optimize_bias(bias, **kw)
+            else:
+                rc, st = p.optimize(**kw)
         else:
             import torch.distributed as dist
             rp_cpu = (vec.rowptr.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
@@ -202,18 +213,39 @@ class DistributedQuant:
             ao = p.alpha_out_view()
             dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)     # union of the active sets
             p.init()
-            done = False
-            while not done:
-                for _ in range(self.poll_every):
-                    p.sweep()
-                    dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)
-                    p.update()
-                done, _ = p.poll()
+            # The loop runs in segments that end at the recompute iterations (one segment without bias): the stop
+            # bounds are lowered to the next hook, and at a hook the reference would reach (its while condition
+            # still true, :820) every rank recomputes the lengths from the replicated alpha; rank 0's result is
+            # broadcast so that the ranks stay bit-identical (the 4096-bin expectation is summed with atomics).
+            user_min, user_max = kw["min_iter"], kw["max_iter"]
+            it, conv = 0, False
+            while not (it >= user_min and (it >= user_max or conv)):
+                if bias is not None and it in RECOMPUTE_ITERS:
+                    new_len, _ = bias.update(p.length_view(), p.alpha_view())
+                    dist.broadcast(new_len, src=dist.get_global_rank(self.group, 0), group=self.group)
+                    p.rebase(new_len)
+                    self.recomputes += 1
+                nxt = min([h for h in RECOMPUTE_ITERS if h > it] + [user_max]) if bias is not None else user_max
+                p.set_bounds(min(user_min, nxt), nxt)
+                done = False
+                while not done:
+                    for _ in range(self.poll_every):
+                        p.sweep()
+                        dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)
+                        p.update()
+                    done, seg = p.poll()
+                it, conv = int(seg["iters"]), bool(seg["converged"])
+            if bias is not None:
+                eff = p.length_view().clone()
             rc, st = p.finish()
         self.problem = p
         ok = rc == 0
         if ok:
             txps.estCount.copy_(p.alpha); txps.mass.copy_(p.mass)
+            if eff is not None:
+                txps.EffectiveLength.copy_(eff)                                # :888
+                es, eg = bias.expected()
+                exp.setExpectedSeqBias(es); exp.setExpectedGCBias(eg)
         return ok, st, mode
 
     # ---- posterior sampling: draws are independent, so they are split over the ranks ------------

@@ -79,6 +79,23 @@ class EMProblem:
         p = self._L.sfgpu_em_alpha_out(self._h)
         return _tensor_from_ptr(p, self.M, self.device)
 
+    def alpha_view(self):
+        """the loop's current alpha (M float64), aliasing the library's buffer"""
+        return _tensor_from_ptr(self._L.sfgpu_em_alpha(self._h), self.M, self.device)
+
+    def length_view(self):
+        """effLens as the loop holds them (clamped at 1), aliasing the library's buffer"""
+        return _tensor_from_ptr(self._L.sfgpu_em_lengths(self._h), self.M, self.device)
+
+    def set_bounds(self, min_iter, max_iter):
+        _lib.check(self._L.sfgpu_em_set_bounds(self._h, int(min_iter), int(max_iter)))
+
+    def rebase(self, length):
+        """updateEqClassWeights (:527-555) for the piecewise loop: new lengths, x rebuilt from the current alpha"""
+        length = length.to(torch.float64).contiguous()
+        _lib.check(self._L.sfgpu_em_rebase(self._h, _lib.ptr(length)))
+        torch.cuda.current_stream().synchronize()      # `length` may be a temporary
+
     def time_sweep(self, n=100, **kw):
         o = self.opts(**kw); ms = C.c_double()
         _lib.check(self._L.sfgpu_em_time_sweep(self._h, C.byref(o), int(n), C.byref(ms)))

@@ -375,3 +375,50 @@ def test_reference_style_driver_with_bias(built):
     np.testing.assert_allclose(exp.expectedSeqBias(), es, rtol=1e-6)
     big = a > 1e-3
     np.testing.assert_allclose(txps.estCount.cpu().numpy()[big], a[big], rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vb", [False, True])
+def test_piecewise_loop_with_rebase_matches_optimize_bias(built, vb):
+    """the multi-GPU driver's form of the hook (set_bounds / sfgpu_bias_update / rebase between polls) gives what
+    sfgpu_em_optimize_bias gives"""
+    import torch
+    import sailfish_amd as sf
+    dev = torch.device("cuda:0")
+    M = 400
+    w = workload(78, M=M, hi=3000)
+    rng = np.random.default_rng(9)
+    rowptr, ids, counts = _classes(rng, M, 3000, 400000)
+    n = int(counts.sum())
+    model = _device_model(w, dev, num_fwd=52, num_rc=48, seq_bias=True)
+    t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).astype(dt)).to(dev)
+    prob = sf.EMProblem(t(w["txp_eff"], np.float64), t(rowptr.astype(np.uint32).view(np.int32), np.int32),
+                        t(ids.view(np.int32), np.int32), t(counts, np.int64), n)
+    rc, st, eff, hooks = prob.optimize_bias(model, use_vbem=vb, tol=1e-5, min_iter=50, max_iter=10000)
+    assert rc == 0 and hooks >= 1
+    a_ref = prob.alpha.clone()
+    prob.begin(use_vbem=vb, tol=1e-5, min_iter=50, max_iter=10000)
+    prob.init()
+    it, conv, taken = 0, False, 0
+    while not (it >= 50 and (it >= 10000 or conv)):
+        if it in (50, 500, 1000):
+            new_len, _ = model.update(prob.length_view(), prob.alpha_view())
+            prob.rebase(new_len); taken += 1
+        nxt = min([h for h in (50, 500, 1000) if h > it] + [10000])
+        prob.set_bounds(min(50, nxt), nxt)
+        done = False
+        while not done:
+            for _ in range(16):
+                prob.sweep(); prob.update()
+            done, seg = prob.poll()
+        it, conv = seg["iters"], seg["converged"]
+    eff2 = prob.length_view().clone()
+    rc2, st2 = prob.finish()
+    assert rc2 == 0 and taken == hooks and abs(int(st2["iters"]) - int(st["iters"])) <= 1
+    np.testing.assert_allclose(eff2.cpu().numpy(), eff.cpu().numpy(), rtol=1e-9)
+    big = a_ref.cpu().numpy() > 1e-3
+    np.testing.assert_allclose(prob.alpha.cpu().numpy()[big], a_ref.cpu().numpy()[big], rtol=1e-5)
+    # begin() restores the problem's own lengths
+    prob.begin(use_vbem=vb, min_iter=60, max_iter=60); prob.init()
+    np.testing.assert_array_equal(prob.length_view().cpu().numpy(), np.maximum(w["txp_eff"], 1.0))
+    prob.close(); model.close()

@@ -140,6 +140,28 @@ class _EM:
     def poll(self):
         return self._stop(), dict(iters=self.it, converged=self.conv, n_active=self.n_active)
 
+    # the piecewise loop with the bias hook
+    def set_bounds(self, min_iter, max_iter):
+        self.min_iter, self.max_iter = min_iter, max_iter
+
+    def alpha_view(self):
+        return torch.from_numpy(self.a)
+
+    def length_view(self):
+        return torch.from_numpy(self.len)
+
+    def rebase(self, length):
+        self.len = np.maximum(length.numpy().astype(np.float64), 1.0)
+        self._prep()
+
+    def optimize_bias(self, bias, use_vbem=False, tol=0.01, min_iter=50, max_iter=10000, **_):
+        rc, a, m, eff, es, eg, nr, st = O.em_optimize_bias(bias.bm, self._raw_len, self.rp.astype(np.uint64), self.ids.astype(np.uint32),
+                                                           self.cnt.astype(np.uint64), int(self.N), use_vbem=use_vbem, tol=tol,
+                                                           min_iter=min_iter, max_iter=max_iter)
+        self.alpha.copy_(torch.from_numpy(a)); self.mass.copy_(torch.from_numpy(m))
+        bias.es, bias.eg = es, eg
+        return rc, st, torch.from_numpy(eff), nr
+
     def finish(self):
         cutoff = (0.01 + 1e-8) if self.vb else 1e-8
         a = np.where(self.a <= cutoff, 0.0, self.a)
@@ -148,8 +170,29 @@ class _EM:
                        max_rel_diff=self.maxrel)
 
 
+class _Bias:
+    """updateEffectiveLengths = the oracle's"""
+
+    def __init__(self, exp, sopt):
+        t = exp.transcripts()
+        self.bm = O.make_bias_model(exp._seq.numpy().tobytes(), exp._seq_off.numpy().astype(np.uint64), t.RefLength.numpy().view(np.uint32),
+                                    t.EffectiveLength.numpy(), exp.fragLengthDist().astype(np.uint32), exp.readBias(), exp.observedGC(),
+                                    num_fwd=exp.numFwd(), num_rc=exp.numRC(), seq_bias=sopt.biasCorrect, gc_bias=sopt.gcBiasCorrect)
+        self.es, self.eg = np.ones(4096), np.ones(101)
+
+    def update(self, eff_in, alpha):
+        rc, out, self.es, self.eg, nc = O.update_efflens(self.bm, eff_in.numpy(), alpha.numpy())
+        return torch.from_numpy(out), dict(status=rc, n_corrected=nc)
+
+    def expected(self):
+        return self.es, self.eg
+
+
 class CheckerEngine:
     device = torch.device("cpu")
+
+    def bias_model(self, exp, sopt):
+        return _Bias(exp, sopt)
 
     def new_builder(self, expected=0):
         return _Builder()
@@ -235,3 +278,76 @@ def test_nnz_balanced_slices():
         assert cuts[0] == 0 and cuts[-1] == len(rp) - 1 and all(a <= b for a, b in zip(cuts, cuts[1:]))
         nn = [rp[b] - rp[a] for a, b in zip(cuts, cuts[1:])]
         assert sum(nn) == rp[-1] and max(nn) <= rp[-1] / w + 100
+
+
+def _bias_inputs(M, ref_len):
+    rng = np.random.default_rng(99)
+    off = np.zeros(M, np.int64); parts = []; pos = 0
+    for t in range(M):
+        off[t] = pos
+        parts.append(bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(ref_len[t])).astype(np.uint8)) + b"$")
+        pos += int(ref_len[t]) + 1
+    x = np.arange(1000)
+    fl = np.round(1e6 * np.exp(-0.5 * ((x - 200) / 60.0) ** 2)).astype(np.int32)
+    return b"".join(parts), off, fl, rng.integers(1, 300, 4096).astype(np.uint32), rng.integers(1, 900, 101).astype(np.uint32)
+
+
+def _bias_worker(rank, world, port, mode, which, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sailfish_amd as sf
+        from sailfish_amd import distributed as sfd, synth
+        M, P, R = 300, 900, 5000
+        ref_len = synth.transcript_lengths(M)
+        poff, pids = synth.label_pool(M, P)
+        ids, off = synth.reads_from_pool(poff, pids, R, seed=3 + 1000 * rank)
+        sopt = sf.SailfishOpts(biasCorrect=which == "seq", gcBiasCorrect=which == "gc")
+        exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.numpy().view(np.uint32), device="cpu"), sopt)
+        seq, soff, fl, rb, og = _bias_inputs(M, ref_len.numpy().view(np.uint32))
+        exp.setSequences(seq, soff); exp.setFragLengthDist(fl)
+        exp.readBias()[:] = rb; exp.observedGC()[:] = og; exp.addNumFwd(55); exp.addNumRC(45)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, engine=CheckerEngine(), poll_every=7, tol=1e-4)
+        info = q.run(ids, off)
+        t = exp.transcripts()
+        out.put((rank, info["em_stats"]["iters"], q.recomputes, t.estCount.numpy().copy(), t.EffectiveLength.numpy().copy(),
+                 exp.expectedSeqBias().copy(), exp.expectedGCBias().copy(), ids.numpy().copy(), off.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,which", [("sharded", "seq"), ("sharded", "gc"), ("replicated", "seq")])
+def test_two_rank_quant_with_bias_hook(built, mode, which):
+    """doBiasCorrect across ranks: the recompute iterations are reached with lowered stop bounds, the lengths are
+    recomputed from the replicated alpha and broadcast, the loop continues -- same answer as one process"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bias_worker, args=(r, 2, port, mode, which, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from sailfish_amd import synth
+    M = 300
+    ref_len = synth.transcript_lengths(M).numpy().view(np.uint32)
+    b = O.EqBuilder()
+    for r in res:
+        b.add_batch(r[7].view(np.uint32), r[8].view(np.uint32).astype(np.uint64))
+    rp, ii, cc, hh = b.finish()
+    eff0 = O.efflen_smoothed(ref_len, O.cf_gaussian())
+    seq, soff, fl, rb, og = _bias_inputs(M, ref_len)
+    bm = O.make_bias_model(seq, soff.astype(np.uint64), ref_len, eff0, fl.astype(np.uint32), rb, og, num_fwd=55, num_rc=45,
+                           seq_bias=which == "seq", gc_bias=which == "gc")
+    rc, oa, om, oeff, oes, oeg, onr, ost = O.em_optimize_bias(bm, eff0, rp, ii, cc, b.total_reads, tol=1e-4)
+    assert rc == 0 and onr >= 1
+    for r in res:
+        assert r[1] == ost["iters"] and r[2] == onr
+        nz = oa > 0
+        assert np.array_equal(r[3] > 0, nz)
+        assert np.max(np.abs(r[3][nz] - oa[nz]) / oa[nz]) < 1e-9
+        np.testing.assert_allclose(r[4], oeff, rtol=1e-12)
+        np.testing.assert_allclose(r[5], oes, rtol=1e-12); np.testing.assert_allclose(r[6], oeg, rtol=1e-12)
+    assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])
