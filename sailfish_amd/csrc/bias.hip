@@ -41,6 +41,7 @@ constexpr int kNGC = 101;
 constexpr int kBlock = 256;
 constexpr double kMinAlphaBias = 1e-8;     // :618
 constexpr int kLanesFl = 64;               // fragment lengths per chunk of k_gc_profile: one per lane
+constexpr int kGcBlock = 512;              // k_gc_profile: eight wavefronts share one chunk's counters and staged counts
 constexpr uint32_t kMaxFldHigh = 16000;
 constexpr int kSeqBlocks = 1024;
 constexpr int kGcRows = 256;               // transcripts per block of the GC expectation partial sums
@@ -246,13 +247,14 @@ __device__ __forceinline__ uint32_t gc_bin(uint32_t d, const GcLane& l) {
 
 // Gs[j] = number of G/C bases in s[0..j]  (Transcript::computeGCContent_, include/Transcript.hpp:183-196;
 // only differences are used, so a chunk-local origin is enough)
+template <int BLOCK>
 __device__ __forceinline__ void stage_gc_prefix(const char* s, uint32_t n, uint32_t* Gs, uint32_t* runs) {
-    for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) {
         const unsigned c = (unsigned char)s[j] & 0xDFu;
         Gs[j] = (c == 'G' || c == 'C') ? 1u : 0u;
     }
     __syncthreads();
-    const uint32_t R = (n + kBlock - 1) / kBlock;
+    const uint32_t R = (n + BLOCK - 1) / BLOCK;
     const uint32_t b = min(n, threadIdx.x * R), e = min(n, b + R);
     uint32_t sum = 0;
     for (uint32_t j = b; j < e; ++j) sum += Gs[j];
@@ -282,21 +284,21 @@ __global__ void __launch_bounds__(kBlock) k_gc_prefix(const char* __restrict__ s
     uint32_t base = 0;
     for (uint32_t p0 = 0; p0 < L; p0 += kPrefixChunk) {
         const uint32_t n = min(kPrefixChunk, L - p0);
-        stage_gc_prefix(s + p0, n, Gs, runs);
+        stage_gc_prefix<kBlock>(s + p0, n, Gs, runs);
         for (uint32_t j = threadIdx.x; j < n; j += kBlock) o[p0 + j] = base + Gs[j];
         base += Gs[n - 1];
         __syncthreads();
     }
 }
 
-// S[t][g] for one transcript per block (see the header).  Dynamic LDS: 101 f64 | 64 x 101 u32 | kBlock u32 |
+// S[t][g] for one transcript per block (see the header).  Dynamic LDS: 101 f64 | 64 x 101 u32 | kGcBlock u32 |
 // stage_cap u32.
-__global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
+__global__ void __launch_bounds__(kGcBlock) k_gc_profile(BiasDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* Sacc = reinterpret_cast<double*>(smem);
     uint32_t* H = reinterpret_cast<uint32_t*>(smem + 816);
     uint32_t* runs = H + kLanesFl * kNGC;
-    uint32_t* Gs = runs + kBlock;
+    uint32_t* Gs = runs + kGcBlock;
     const uint64_t t = blockIdx.x;
     const uint32_t L = d.ref_len[t];
     double* Srow = d.S + t * kNGC;
@@ -320,17 +322,17 @@ __global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
         const uint32_t fl = k_on ? (uint32_t)d.fld_low + k * d.gs : fl_max;
         const GcLane gl = gc_lane(fl);
         uint32_t* Hrow = H + lane * kNGC;
-        for (int j = tid; j < kLanesFl * kNGC; j += kBlock) H[j] = 0;
+        for (int j = tid; j < kLanesFl * kNGC; j += kGcBlock) H[j] = 0;
         const uint32_t T = (d.stage_cap - fl_max) & ~3u;
         for (uint32_t p0 = 0; p0 < n_i; p0 += T) {
             __syncthreads();
-            stage_gc_prefix(s + p0, min(L - p0, T + fl_max), Gs, runs);
+            stage_gc_prefix<kGcBlock>(s + p0, min(L - p0, T + fl_max), Gs, runs);
             const uint32_t i_end = min(n_i, p0 + T);
             // groups of four positions for which every lane's fragment ends inside the transcript: no tests
             const uint32_t lim = (fl_max <= L) ? min(i_end, L - fl_max + 1) : p0;   // i < lim: the chunk's longest fragment fits
             const uint32_t n_fast = lim > p0 ? (lim - p0) / 4 : 0;
             const uint32_t* Ge = Gs + (fl - 1);
-            for (uint32_t j = wv; j < n_fast; j += kBlock / kWave) {
+            for (uint32_t j = wv; j < n_fast; j += kGcBlock / kWave) {
                 const uint32_t o = 4 * j;                                   // i - p0
                 const uint4 cs = *reinterpret_cast<const uint4*>(Gs + o);
                 const uint32_t e0 = Ge[o], e1 = Ge[o + 1], e2 = Ge[o + 2], e3 = Ge[o + 3];
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(kBlock) k_gc_profile(BiasDev d) {
                 atomicAdd(&Hrow[g0], one); atomicAdd(&Hrow[g1], one);
                 atomicAdd(&Hrow[g2], one); atomicAdd(&Hrow[g3], one);
             }
-            for (uint32_t i = p0 + 4 * n_fast + wv; i < i_end; i += kBlock / kWave) {
+            for (uint32_t i = p0 + 4 * n_fast + wv; i < i_end; i += kGcBlock / kWave) {
                 const uint32_t e = i + fl - 1;
                 if (k_on && e < L) atomicAdd(&Hrow[gc_bin(Gs[e - p0] - Gs[i - p0], gl)], 1u);   // gcFrac(i, e)
             }
@@ -588,9 +590,9 @@ int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_strea
             uint32_t cap = (uint32_t)b->fld_high + 2048;
             if (cap < kStageMin) cap = kStageMin;
             b->dev.stage_cap = cap;
-            const size_t lds = 816 + (size_t)kLanesFl * kNGC * 4 + kBlock * 4 + (size_t)cap * 4;
+            const size_t lds = 816 + (size_t)kLanesFl * kNGC * 4 + kGcBlock * 4 + (size_t)cap * 4;
             B_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gc_profile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_gc_profile, dim3((unsigned)in->M), dim3(kBlock), lds, st, b->dev);
+            hipLaunchKernelGGL(k_gc_profile, dim3((unsigned)in->M), dim3(kGcBlock), lds, st, b->dev);
             B_HIP(hipGetLastError());
         } else {
             B_HIP(hipMemsetAsync(b->dev.S, 0, (size_t)in->M * kNGC * 8, st));
