@@ -280,6 +280,37 @@ def test_update_matches_oracle(built, mode, samp, fld):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["seq", "gc"])
+def test_update_with_unknown_bases_inside(built, mode):
+    """a byte outside ACGTU away from a transcript's first k-mers: nextKmerIndex shifts in 0 for it in both directions
+    (include/UtilityFunctions.hpp:40-90) and it is not G/C; the device's direct 6-mer evaluation agrees"""
+    import torch
+    dev = torch.device("cuda:0")
+    w = workload(55, M=150, lo=40, hi=3000)
+    w["lens"][:4] = np.maximum(w["lens"][:4], 40)          # workload() plants lengths 3, 6, 7, 12 there: regenerate those
+    rng = np.random.default_rng(1)
+    seq, off, lens = make_txome(rng, np.maximum(w["lens"], 40))
+    sq = bytearray(seq)
+    for t in range(len(lens)):
+        L = int(lens[t])
+        for p in rng.integers(6, L - 7, max(1, L // 50)):  # never inside [0,6) or [L-7, L): the two first k-mers
+            sq[int(off[t]) + int(p)] = ord(rng.choice(list("NnRY-")))
+    w.update(seq=bytes(sq), off=off, lens=lens, txp_eff=np.maximum(lens - 180.0, 1.0))
+    w["eff_in"] = np.maximum(w["txp_eff"], 1.0)
+    kw = dict(num_fwd=3, num_rc=7, seq_bias=mode == "seq", gc_bias=mode == "gc")
+    bm = O.make_bias_model(w["seq"], w["off"], w["lens"], w["txp_eff"], w["fl"], w["rb"], w["og"], **kw)
+    rc, out, es, eg, nc = O.update_efflens(bm, w["eff_in"], w["alphas"])
+    assert rc == 0 and nc > 0
+    model = _device_model(w, dev, **kw)
+    got, st = model.update(torch.from_numpy(w["eff_in"]).to(dev), torch.from_numpy(w["alphas"]).to(dev))
+    assert st["n_corrected"] == nc
+    np.testing.assert_allclose(got.cpu().numpy(), out, rtol=RTOL)
+    ges, geg = model.expected()
+    np.testing.assert_allclose(ges, es, rtol=RTOL); np.testing.assert_allclose(geg, eg, rtol=RTOL)
+    model.close()
+
+
+@pytest.mark.gpu
 def test_update_skip_and_unsupported(built):
     import torch
     import sailfish_amd as sf
