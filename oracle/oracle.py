@@ -115,6 +115,17 @@ class EqBuilder:
             ids = np.zeros(1, np.uint32)
         lib().sfo_eq_add(self._h, _p(ids), _p(off), len(off) - 1)
 
+    def add_batch_mt(self, ids, off, n_threads):
+        """the same batch over n_threads host threads (per-thread tables, then folded); returns the seconds taken
+        (bench.py's all-cores cpu_baseline)"""
+        ids = _c(ids, np.uint32); off = _c(off, np.uint64)
+        if len(ids) == 0:
+            ids = np.zeros(1, np.uint32)
+        L = lib()
+        L.sfo_eq_add_mt.restype = C.c_double
+        L.sfo_eq_add_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        return float(L.sfo_eq_add_mt(self._h, _p(ids), _p(off), len(off) - 1, int(n_threads)))
+
     def finish(self):
         n = C.c_uint64(); nnz = C.c_uint64(); tot = C.c_uint64()
         lib().sfo_eq_finish(self._h, C.byref(n), C.byref(nnz), C.byref(tot))
@@ -249,6 +260,20 @@ def em_optimize_bias(bm, eff_len, rowptr, ids, counts, num_mapped, use_vbem=Fals
     stats = dict(iters=st.iters, converged=bool(st.converged), max_rel_diff=st.max_rel_diff,
                  alpha_sum=st.alpha_sum, n_active=st.n_active)
     return rc, alpha[:M], mass[:M], efin[:M], es, eg, nr.value, stats
+
+
+def em_iterations_mt(eff_len, rowptr, ids, counts, num_mapped, n_iters, n_threads, use_vbem=False):
+    """n_iters EM / VBEM updates over n_threads host threads (classes cut into nnz-balanced ranges, private alphaOut
+    copies summed in thread order): bench.py's all-cores cpu_baseline.  -> (seconds per iteration, alpha)"""
+    eff = _c(eff_len, np.float64); rp = _c(rowptr, np.uint64); ii = _c(ids, np.uint32); cc = _c(counts, np.uint64)
+    out = np.zeros(max(len(eff), 1))
+    L = lib()
+    L.sfo_em_iterations_mt.restype = C.c_double
+    L.sfo_em_iterations_mt.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                       C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+    sec = L.sfo_em_iterations_mt(len(eff), _p(eff), len(rp) - 1, _p(rp), _p(ii), _p(cc), int(num_mapped), int(use_vbem),
+                                 int(n_iters), int(n_threads), _p(out))
+    return float(sec), out[: len(eff)]
 
 
 def tpm(est_count, length, num_mapped):

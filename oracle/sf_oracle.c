@@ -21,7 +21,10 @@
  *     larger cases are "parity unpinned" against the reference binary.
  *   - bootstrap / Gibbs: distributional only (the reference seeds from std::random_device).
  */
+#define _POSIX_C_SOURCE 200809L
 #include <math.h>
+#include <pthread.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -143,33 +146,73 @@ static void eq_rehash(sfo_eq* e) {
 
 /* one batch of packed hit lists; empty lists are skipped, mirroring the call-site guard
  * `if (txpIDs.size() > 0)` (src/SailfishQuantify.cpp:399-416, 608-625). */
+static void eq_upsert(sfo_eq* e, const uint32_t* lab, uint32_t len, uint64_t hv, uint64_t count) {
+    uint64_t s = hv & (e->nbuckets - 1);
+    int64_t c = e->buckets[s];
+    while (c >= 0) {
+        sfo_class* k = &e->cls[c];
+        if (k->hash == hv && k->len == len && memcmp(e->arena + k->off, lab, 4ull * len) == 0) break;
+        c = k->next;
+    }
+    if (c >= 0) { e->cls[c].count += count; }
+    else {
+        if (e->ncls == e->cap_cls) { e->cap_cls *= 2; e->cls = (sfo_class*)realloc(e->cls, e->cap_cls * sizeof(sfo_class)); }
+        while (e->arena_used + len > e->arena_cap) { e->arena_cap *= 2; e->arena = (uint32_t*)realloc(e->arena, e->arena_cap * 4); }
+        memcpy(e->arena + e->arena_used, lab, 4ull * len);
+        sfo_class* k = &e->cls[e->ncls];
+        k->hash = hv; k->count = count; k->off = e->arena_used; k->len = len;
+        k->next = e->buckets[s]; e->buckets[s] = (int64_t)e->ncls;
+        e->arena_used += len; e->ncls++;
+        if (e->ncls > 2 * e->nbuckets) eq_rehash(e);
+    }
+    e->total_reads += count;
+}
+
 SFO_API void sfo_eq_add(void* h, const uint32_t* ids, const uint64_t* off, uint64_t n) {
     sfo_eq* e = (sfo_eq*)h;
     for (uint64_t r = 0; r < n; ++r) {
         uint32_t len = (uint32_t)(off[r + 1] - off[r]);
         if (len == 0) continue;
         const uint32_t* lab = ids + off[r];
-        uint64_t hv = sfo_xxh64(lab, 4ull * len, 0);
-        uint64_t s = hv & (e->nbuckets - 1);
-        int64_t c = e->buckets[s];
-        while (c >= 0) {
-            sfo_class* k = &e->cls[c];
-            if (k->hash == hv && k->len == len && memcmp(e->arena + k->off, lab, 4ull * len) == 0) break;
-            c = k->next;
-        }
-        if (c >= 0) { e->cls[c].count++; }
-        else {
-            if (e->ncls == e->cap_cls) { e->cap_cls *= 2; e->cls = (sfo_class*)realloc(e->cls, e->cap_cls * sizeof(sfo_class)); }
-            while (e->arena_used + len > e->arena_cap) { e->arena_cap *= 2; e->arena = (uint32_t*)realloc(e->arena, e->arena_cap * 4); }
-            memcpy(e->arena + e->arena_used, lab, 4ull * len);
-            sfo_class* k = &e->cls[e->ncls];
-            k->hash = hv; k->count = 1; k->off = e->arena_used; k->len = len;
-            k->next = e->buckets[s]; e->buckets[s] = (int64_t)e->ncls;
-            e->arena_used += len; e->ncls++;
-            if (e->ncls > 2 * e->nbuckets) eq_rehash(e);
-        }
-        e->total_reads++;
+        eq_upsert(e, lab, len, sfo_xxh64(lab, 4ull * len, 0), 1);
     }
+}
+
+/* bench.py's cpu_baseline on ALL host cores: every thread builds the table of its contiguous shard
+ * of reads, then the tables are folded into the first one (insertGroup with counts) -- the same split the
+ * multi-GPU driver uses.  Returns the elapsed seconds; the merged table is left in `h`. */
+typedef struct { sfo_eq* e; const uint32_t* ids; const uint64_t* off; uint64_t r0, r1; } eq_mt_job;
+static void* eq_mt_worker(void* p) {
+    eq_mt_job* j = (eq_mt_job*)p;
+    for (uint64_t r = j->r0; r < j->r1; ++r) {
+        uint32_t len = (uint32_t)(j->off[r + 1] - j->off[r]);
+        if (len == 0) continue;
+        const uint32_t* lab = j->ids + j->off[r];
+        eq_upsert(j->e, lab, len, sfo_xxh64(lab, 4ull * len, 0), 1);
+    }
+    return NULL;
+}
+SFO_API double sfo_eq_add_mt(void* h, const uint32_t* ids, const uint64_t* off, uint64_t n, int n_threads) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (n_threads < 1) n_threads = 1;
+    eq_mt_job* jobs = (eq_mt_job*)calloc((size_t)n_threads, sizeof(eq_mt_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t].e = t == 0 ? (sfo_eq*)h : (sfo_eq*)sfo_eq_create();
+        jobs[t].ids = ids; jobs[t].off = off;
+        jobs[t].r0 = n * (uint64_t)t / (uint64_t)n_threads; jobs[t].r1 = n * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        pthread_create(&th[t], NULL, eq_mt_worker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    for (int t = 1; t < n_threads; ++t) {
+        sfo_eq* o = jobs[t].e;
+        for (uint64_t c = 0; c < o->ncls; ++c) eq_upsert((sfo_eq*)h, o->arena + o->cls[c].off, o->cls[c].len, o->cls[c].hash, o->cls[c].count);
+        sfo_eq_destroy(o);
+    }
+    free(jobs); free(th);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 static sfo_eq* g_sort_ctx;
@@ -857,6 +900,98 @@ SFO_API int sfo_em_optimize_bias(uint64_t M, const double* eff_in,
     if (n_recomputes) *n_recomputes = 0;
     return em_optimize_impl(M, eff_in, C, rowptr, ids, counts, num_mapped, use_vbem, tol, min_iter, max_iter,
                             0, alpha_out, mass_out, st, bm, eff_final, exp_seq, exp_gc, n_recomputes);
+}
+
+/* bench.py's cpu_baseline on ALL host cores: n_iters EM / VBEM updates with the classes cut into
+ * nnz-balanced contiguous ranges, one per thread, all adding into ONE alphaOut with compare-and-swap adds -- the
+ * reference's own scheme (sailfish::utils::incLoop on tbb::atomic<double>, src/CollapsedEMOptimizer.cpp:264, :351).
+ * Same per-class arithmetic as em_update / vbem_update above; the order of the adds is arbitrary, as in the
+ * reference.  Returns the seconds per iteration; alpha_out = alpha after n_iters. */
+static inline void atomic_add_f64(double* p, double v) {
+    uint64_t* q = (uint64_t*)p;
+    uint64_t old = __atomic_load_n(q, __ATOMIC_RELAXED), nw;
+    do { double d; memcpy(&d, &old, 8); d += v; memcpy(&nw, &d, 8); }
+    while (!__atomic_compare_exchange_n(q, &old, nw, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+typedef struct {
+    int tid, n_threads; pthread_barrier_t* bar;
+    uint64_t M, C; const uint64_t* rowptr; const uint32_t* ids; const uint64_t* counts; const double* w;
+    int use_vbem; uint32_t n_iters; double* a; double* et; double* ap; uint64_t c0, c1; double* asum_part; double* log_norm;
+} em_mt_job;
+static void* em_mt_worker(void* p) {
+    em_mt_job* j = (em_mt_job*)p;
+    const double tiny = 4.9406564584124654e-324, prior = 0.01;
+    const uint64_t M = j->M, t0 = M * (uint64_t)j->tid / (uint64_t)j->n_threads, t1 = M * (uint64_t)(j->tid + 1) / (uint64_t)j->n_threads;
+    for (uint32_t it = 0; it < j->n_iters; ++it) {
+        if (j->use_vbem) {
+            double part = 0.0;
+            for (uint64_t t = t0; t < t1; ++t) part += j->a[t];
+            j->asum_part[j->tid] = part;
+            pthread_barrier_wait(j->bar);
+            if (j->tid == 0) { double s = 0.0; for (int q = 0; q < j->n_threads; ++q) s += j->asum_part[q]; *j->log_norm = sfo_digamma(s); }
+            pthread_barrier_wait(j->bar);
+            for (uint64_t t = t0; t < t1; ++t) j->et[t] = (j->a[t] > tiny) ? exp(sfo_digamma(j->a[t]) - *j->log_norm) : 0.0;
+        }
+        for (uint64_t t = t0; t < t1; ++t) j->ap[t] = j->use_vbem ? prior : 0.0;
+        pthread_barrier_wait(j->bar);
+        const double* x = j->use_vbem ? j->et : j->a;
+        for (uint64_t c = j->c0; c < j->c1; ++c) {
+            uint64_t b = j->rowptr[c], e = j->rowptr[c + 1];
+            if (e - b > 1) {
+                double denom = 0.0;
+                for (uint64_t q = b; q < e; ++q) if (!j->use_vbem || x[j->ids[q]] > 0.0) denom += x[j->ids[q]] * j->w[q];
+                if (denom <= tiny) continue;
+                double inv = (double)j->counts[c] / denom;
+                for (uint64_t q = b; q < e; ++q) {
+                    if (j->use_vbem) { if (x[j->ids[q]] > 0.0) atomic_add_f64(&j->ap[j->ids[q]], x[j->ids[q]] * j->w[q] * inv); }
+                    else { double v = x[j->ids[q]] * j->w[q]; if (!isnan(v)) atomic_add_f64(&j->ap[j->ids[q]], v * inv); }
+                }
+            } else if (e - b == 1) atomic_add_f64(&j->ap[j->ids[b]], (double)j->counts[c]);
+        }
+        pthread_barrier_wait(j->bar);
+        for (uint64_t t = t0; t < t1; ++t) j->a[t] = j->ap[t];
+        pthread_barrier_wait(j->bar);
+    }
+    return NULL;
+}
+SFO_API double sfo_em_iterations_mt(uint64_t M, const double* eff_in, uint64_t C, const uint64_t* rowptr, const uint32_t* ids,
+                                    const uint64_t* counts, uint64_t num_mapped, int use_vbem, uint32_t n_iters, int n_threads,
+                                    double* alpha_out) {
+    if (n_threads < 1) n_threads = 1;
+    uint64_t L = rowptr[C];
+    double* eff = (double*)malloc((M ? M : 1) * sizeof(double));
+    double* w = (double*)malloc((L ? L : 1) * sizeof(double));
+    double* a = (double*)calloc(M ? M : 1, sizeof(double));
+    double* et = (double*)calloc(M ? M : 1, sizeof(double));
+    uint8_t* active = (uint8_t*)calloc(M ? M : 1, 1);
+    for (uint64_t t = 0; t < M; ++t) { eff[t] = eff_in[t]; if (eff[t] <= 1.0) eff[t] = 1.0; }
+    em_weights(C, rowptr, ids, counts, eff, w);
+    uint64_t n_active = 0;
+    for (uint64_t q = 0; q < L; ++q) if (!active[ids[q]]) { active[ids[q]] = 1; ++n_active; }
+    for (uint64_t t = 0; t < M; ++t) a[t] = (active[t] && n_active) ? (1.0 / (double)n_active) * (double)num_mapped : 0.0;
+    pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)n_threads);
+    em_mt_job* jobs = (em_mt_job*)calloc((size_t)n_threads, sizeof(em_mt_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    double* ap = (double*)calloc(M ? M : 1, sizeof(double));
+    double* asum_part = (double*)calloc((size_t)n_threads, sizeof(double)); double log_norm = 0.0;
+    uint64_t c = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        uint64_t target = L * (uint64_t)(t + 1) / (uint64_t)n_threads, c0 = c;
+        while (c < C && rowptr[c + 1] <= target) ++c;
+        if (t == n_threads - 1) c = C;
+        em_mt_job jb = {t, n_threads, &bar, M, C, rowptr, ids, counts, w, use_vbem, n_iters, a, et, ap, c0, c, asum_part, &log_norm};
+        jobs[t] = jb;
+    }
+    struct timespec s0, s1;
+    clock_gettime(CLOCK_MONOTONIC, &s0);
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, em_mt_worker, &jobs[t]);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &s1);
+    if (alpha_out) memcpy(alpha_out, a, M * sizeof(double));
+    pthread_barrier_destroy(&bar);
+    free(ap); free(jobs); free(th); free(asum_part); free(eff); free(w); free(a); free(et); free(active);
+    double sec = (double)(s1.tv_sec - s0.tv_sec) + 1e-9 * (double)(s1.tv_nsec - s0.tv_nsec);
+    return n_iters ? sec / n_iters : 0.0;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -211,3 +211,26 @@ def test_tpm_columns(built):
     t = O.tpm(a, ln, a.sum())
     assert abs(t.sum() - 1e6) < 1e-6 and np.all(t[::7] == 0)
     np.testing.assert_allclose(t, (a / ln) / (a / ln).sum() * 1e6, rtol=1e-12)
+
+
+def test_all_cores_legs_agree_with_one_thread(built):
+    """the multi-threaded timing legs of bench.py's cpu_baseline compute what the serial restatement computes"""
+    rng = np.random.default_rng(12)
+    M, R = 3000, 120_000
+    pool = [np.sort(rng.choice(M, k, replace=False)) for k in rng.integers(1, 7, 9000)]
+    pick = rng.integers(0, len(pool), R)
+    ids = np.concatenate([pool[p] for p in pick]).astype(np.uint32)
+    off = np.concatenate([[0], np.cumsum([len(pool[p]) for p in pick])]).astype(np.uint64)
+    b1 = O.EqBuilder(); b1.add_batch(ids, off); r1 = b1.finish()
+    for T in (1, 3, 8):
+        b = O.EqBuilder(); assert b.add_batch_mt(ids, off, T) > 0.0
+        r = b.finish()
+        assert b.total_reads == b1.total_reads and all(np.array_equal(x, y) for x, y in zip(r, r1))
+    rp, ii, cc, _ = r1
+    eff = rng.integers(200, 3000, M).astype(np.float64)
+    for vb in (False, True):
+        rc, a, m, st = O.em_optimize(eff, rp, ii, cc, R, use_vbem=vb, tol=0.0, min_iter=25, max_iter=25)
+        for T in (1, 4):
+            sec, am = O.em_iterations_mt(eff, rp, ii, cc, R, 25, T, use_vbem=vb)
+            nz = a > 0
+            assert sec > 0 and np.max(np.abs(am[nz] - a[nz]) / a[nz]) < 1e-11
