@@ -1118,7 +1118,7 @@ static int em_run_bias(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_bias* bias
         const uint32_t it = h->it_a;
         const bool conv = it > 0 && h->notconv[(it - 1) & 1] == 0;
         if (it >= user.min_iter && (it >= user.max_iter || conv)) break;       // the while condition of :820 is false
-        uint32_t next = user.max_iter;
+        uint32_t next = user.max_iter > user.min_iter ? user.max_iter : user.min_iter;   // the loop cannot end before either
         for (uint32_t hk : kHooks) {
             if (hk == it) {
                 log_msg(0, "iteration %u, recomputing effective lengths", it);    // :827

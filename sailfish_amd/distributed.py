@@ -225,7 +225,8 @@ class DistributedQuant:
                     dist.broadcast(new_len, src=dist.get_global_rank(self.group, 0), group=self.group)
                     p.rebase(new_len)
                     self.recomputes += 1
-                nxt = min([h for h in RECOMPUTE_ITERS if h > it] + [user_max]) if bias is not None else user_max
+                bound = max(user_min, user_max)                            # the loop cannot end before either
+                nxt = min([h for h in RECOMPUTE_ITERS if h > it] + [bound]) if bias is not None else bound
                 p.set_bounds(min(user_min, nxt), nxt)
                 done = False
                 while not done:
