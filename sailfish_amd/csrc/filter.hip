@@ -284,7 +284,7 @@ extern "C" int sfgpu_sample_bias(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     const bool want_seq = sp->d_read_bias && sp->remaining_bias_samples && *sp->remaining_bias_samples > 0;
     const bool want_gc = sp->d_observed_gc != nullptr && opts->paired_library;
     if (n_reads == 0 || (!want_seq && !want_gc)) return SFGPU_OK;
-    SF_REQUIRE(d_hits && sp->d_seq && sp->d_seq_off && sp->d_ref_len, SFGPU_ERR_INVALID, "sfgpu_sample_bias: null pointer");
+    SF_REQUIRE(sp->d_seq && sp->d_seq_off && sp->d_ref_len, SFGPU_ERR_INVALID, "sfgpu_sample_bias: null pointer");   // d_hits may be NULL when no read has a hit
     SF_REQUIRE(!want_gc || sp->d_gc_prefix, SFGPU_ERR_INVALID, "sfgpu_sample_bias: GC sampling needs d_gc_prefix (sfgpu_gc_prefix)");
     hipStream_t st = as_stream(stream);
     const size_t n1 = (size_t)n_reads + 1;

@@ -247,3 +247,7 @@ def test_sample_bias_device_vs_oracle(built, gpu):
         if want_gc:
             np.testing.assert_array_equal(d_og.cpu().numpy().view(np.uint32), oog)
             assert gng == ong and (ong > 0) == (paired and ong > 0)
+    # reads without any hit: nothing sampled, nothing dereferenced
+    d_rb = torch.ones(4096, dtype=torch.int32, device=gpu)
+    assert sf.hits.sample_bias(np.zeros(0, O.HIT_DTYPE), np.zeros(6, np.uint32), "U", d_seq, d_so, d_rl, read_bias=d_rb,
+                               remaining_bias_samples=9, device=gpu) == (9, 0, 0) and int(d_rb.sum()) == 4096
