@@ -253,10 +253,12 @@ __global__ void k_sorted_lens(uint64_t n, const uint32_t* __restrict__ order, co
     else if (i == n) lens[i] = 0;
 }
 
+// grid-stride: a few hundred same-address atomics in all (one per wavefront of a capped grid), not one per 64 classes
 __global__ void k_sum_counts(uint64_t n, const uint64_t* __restrict__ table, const uint32_t* __restrict__ cls_slot,
                              unsigned long long* total) {
-    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = (c < n) ? table[2 * (uint64_t)cls_slot[c] + 1] : 0ull;
+    unsigned long long v = 0;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x)
+        v += table[2 * (uint64_t)cls_slot[c] + 1];
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(total, v);
 }
@@ -758,7 +760,7 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
         SF_CHECK_LAUNCH();
         if ((rc = exclusive_scan_u32(lens.p, eq->rowptr64.p, n, st))) return rc;
         SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(n)), dim3(kBlock), 0, st, n, eq->table.p, eq->cls_slot.p,
+        hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(n) < 512 ? grid_for(n) : 512), dim3(kBlock), 0, st, n, eq->table.p, eq->cls_slot.p,
                            eq->d_ctr + 3);
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));

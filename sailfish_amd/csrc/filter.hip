@@ -99,6 +99,7 @@ __device__ __forceinline__ bool counts_as_fwd(const sfgpu_hit& h, bool orphan_of
 }
 
 struct FilterCounters { unsigned long long mapped, total_hits, upper, fwd, rc; };
+constexpr int kCtrCopies = 64;      // block totals go to copy blockIdx % 64: same-address atomics serialise (~6 ns each)
 
 // A block's reads own one contiguous range of hit records: it is copied to LDS with coalesced 8-byte loads and
 // the lanes then walk their hits there.  A lane walking 24-byte records in global memory makes every load
@@ -169,7 +170,7 @@ k_filter_count(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ 
     if (threadIdx.x < 5) {
         unsigned long long t = 0;
         for (int w = 0; w < kFilterBlock / kWave; ++w) t += red[threadIdx.x][w];
-        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + threadIdx.x, t);
+        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(ctr + (blockIdx.x % kCtrCopies)) + threadIdx.x, t);
     }
 }
 
@@ -260,9 +261,12 @@ k_sample_bias(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ o
         if (flag) { flag[r] = got; kmer[r] = my_idx; }
     } else if (r == n_reads && flag) flag[r] = 0;
     __syncthreads();
-    if (threadIdx.x < kGcBins && s.observed_gc) {
-        const uint32_t c = gc_hist[threadIdx.x];
-        if (c) { atomicAdd(&s.observed_gc[threadIdx.x], c); atomicAdd(n_gc, (unsigned long long)c); }
+    if (threadIdx.x < 2 * kWave && s.observed_gc) {                          // 101 bins: the first two wavefronts
+        const uint32_t c = threadIdx.x < kGcBins ? gc_hist[threadIdx.x] : 0u;
+        if (c) atomicAdd(&s.observed_gc[threadIdx.x], c);
+        unsigned long long t = c;
+        for (int o = kWave / 2; o > 0; o >>= 1) t += __shfl_down(t, o, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && t) atomicAdd(n_gc, t);
     }
 }
 
@@ -347,11 +351,11 @@ extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     hipError_t e = pool_malloc(&d_len, n1 * 4);
     if (e == hipSuccess) e = pool_malloc(&d_kept, ((size_t)n_hits + 1) * 4);
     if (e == hipSuccess) e = pool_malloc(&d_off64, (n1 + 1) * 8);
-    if (e == hipSuccess) e = pool_malloc(&d_ctr, sizeof(FilterCounters));
+    if (e == hipSuccess) e = pool_malloc(&d_ctr, kCtrCopies * sizeof(FilterCounters));
     if (e == hipSuccess && want_fl) e = pool_malloc(&d_flag, n1 * 4);
     if (e == hipSuccess && want_fl) e = pool_malloc(&d_fllen, n1 * 4);
     if (e == hipSuccess && want_fl) e = pool_malloc(&d_rank, (n1 + 1) * 8);
-    if (e == hipSuccess) e = hipMemsetAsync(d_ctr, 0, sizeof(FilterCounters), st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ctr, 0, kCtrCopies * sizeof(FilterCounters), st);
     const unsigned grid = (unsigned)((n1 + kFilterBlock - 1) / kFilterBlock);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_filter_count, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, d_len, d_kept, d_flag, d_fllen, d_ctr);
@@ -361,11 +365,15 @@ extern "C" int sfgpu_filter_hits(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     if (e == hipSuccess && rc == SFGPU_OK && want_fl) rc = exclusive_scan_u32(d_flag, d_rank, n_reads, st);
     uint64_t h_tot[2] = {0, 0};
     FilterCounters h_ctr{};
+    FilterCounters h_copies[kCtrCopies];
     if (e == hipSuccess && rc == SFGPU_OK) {
         e = hipMemcpyAsync(&h_tot[0], d_off64 + n_reads, 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && want_fl) e = hipMemcpyAsync(&h_tot[1], d_rank + n_reads, 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_copies, d_ctr, sizeof(h_copies), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) for (const FilterCounters& c : h_copies) {
+            h_ctr.mapped += c.mapped; h_ctr.total_hits += c.total_hits; h_ctr.upper += c.upper; h_ctr.fwd += c.fwd; h_ctr.rc += c.rc;
+        }
     }
     if (e == hipSuccess && rc == SFGPU_OK && h_tot[0] >= (1ull << 32)) { set_error("sfgpu_filter_hits: the batch's output exceeds 2^32 ids"); rc = SFGPU_ERR_RANGE; }
     const uint64_t budget = want_fl ? (uint64_t)*remaining_fl_ops : 0;
