@@ -215,6 +215,8 @@ struct SailfishOpts {
     uint32_t numBootstraps = 0;
     uint32_t numGibbsSamples = 0;
     bool biasCorrect = false, gcBiasCorrect = false;
+    uint32_t gcSampFactor = 1;      // --gcSizeSamp
+    uint32_t pdfSampFactor = 1;     // --gcSpeedSamp
     Logger jointLog;
 };
 
@@ -231,10 +233,29 @@ class ReadExperiment {
         const double obs = static_cast<double>(numObservedFragments_.load());
         return obs > 0.0 ? static_cast<double>(numMappedFragments_.load()) / obs : 0.0;
     }
+    // what bias correction reads and writes (:93-97, 160-212, 240-255)
+    void setSequences(std::string seq, std::vector<uint64_t> txpOffsets) { seq_ = std::move(seq); seqOff_ = std::move(txpOffsets); }   // RapMapSAIndex::seq / txpOffsets (:108-117)
+    const std::string& sequences() const { return seq_; }
+    const std::vector<uint64_t>& sequenceOffsets() const { return seqOff_; }
+    void setFragLengthDist(const std::vector<int32_t>& fldIn) { fld_.assign(fldIn.begin(), fldIn.end()); }
+    const std::vector<uint32_t>& fragLengthCounts() const { return fld_; }
+    std::vector<uint32_t>& readBias() { return readBias_; }                      // ReadKmerDist<6>::counts, pseudo-count 1
+    std::vector<uint32_t>& observedGC() { return observedGC_; }                  // 101 bins, pseudo-count 1
+    std::vector<double>& expectedSeqBias() { return expectedSeqBias_; }
+    std::vector<double>& expectedGCBias() { return expectedGC_; }
+    void addNumFwd(int32_t n) { numFwd_ += n; }
+    void addNumRC(int32_t n) { numRC_ += n; }
+    int64_t numFwd() const { return numFwd_.load(); }
+    int64_t numRC() const { return numRC_.load(); }
   private:
     std::vector<Transcript> transcripts_;
     EquivalenceClassBuilder eqBuilder_;
     std::atomic<uint64_t> numMappedFragments_{0}, numObservedFragments_{0};
+    std::string seq_; std::vector<uint64_t> seqOff_;
+    std::vector<uint32_t> fld_;
+    std::vector<uint32_t> readBias_ = std::vector<uint32_t>(4096, 1), observedGC_ = std::vector<uint32_t>(101, 1);
+    std::vector<double> expectedSeqBias_ = std::vector<double>(4096, 1.0), expectedGC_ = std::vector<double>(101, 1.0);
+    std::atomic<int64_t> numFwd_{0}, numRC_{0};
 };
 
 namespace detail {
@@ -278,21 +299,50 @@ class CollapsedEMOptimizer {
     // src/CollapsedEMOptimizer.cpp:711-893.  false where the reference logs an error and returns false
     // ("no transcripts expressed" :794-798, "total alpha weight was too small" :877-881).
     bool optimize(ReadExperiment& readExp, SailfishOpts& sopt, double tolerance = 0.01, uint32_t maxIter = 1000) {
-        if (sopt.biasCorrect || sopt.gcBiasCorrect)
-            throw std::invalid_argument("bias correction: create a sfgpu_bias handle and call sfgpu_em_optimize_bias (INTEGRATION.md 5a)");
+        const bool doBiasCorrect = sopt.biasCorrect || sopt.gcBiasCorrect;         // :717
         detail::LoggerScope scope(sopt.jointLog);
         auto& txps = readExp.transcripts();
+        const uint64_t M = txps.size();
         detail::DeviceProblem dp(readExp, sopt);
-        DeviceBuf<double> alpha(txps.size()), mass(txps.size());
+        DeviceBuf<double> alpha(M), mass(M);
         sfgpu_em* em = nullptr;
         check(sfgpu_em_create(&em, &dp.prob, nullptr), "sfgpu_em_create");
         sfgpu_em_opts o{sopt.useVBOpt ? 1 : 0, tolerance, /*minIter :716*/ 50, maxIter, /*check_mode*/ 0, 0};
         sfgpu_em_stats st{};
-        const int rc = sfgpu_em_optimize(em, &o, alpha.get(), mass.get(), &st);
+        int rc;
+        std::vector<double> newEffLens;
+        lastRecomputes = 0;
+        if (doBiasCorrect) {
+            // everything updateEffectiveLengths reads from the experiment (src/SailfishUtils.cpp:611-690), then the
+            // loop with the recompute hook (:814-840); the corrected lengths come back for :888
+            std::vector<char> seq(readExp.sequences().begin(), readExp.sequences().end());
+            std::vector<uint32_t> refLens(M); std::vector<double> txpEff(M);
+            for (uint64_t i = 0; i < M; ++i) { refLens[i] = txps[i].RefLength; txpEff[i] = txps[i].EffectiveLength; }
+            DeviceBuf<char> dSeq(seq); DeviceBuf<uint64_t> dOff(readExp.sequenceOffsets());
+            DeviceBuf<uint32_t> dRef(refLens); DeviceBuf<double> dTxpEff(txpEff), dEffOut(M);
+            sfgpu_bias_inputs bi{};
+            bi.M = M; bi.d_seq = dSeq.get(); bi.d_seq_off = dOff.get(); bi.d_ref_len = dRef.get(); bi.d_txp_eff_len = dTxpEff.get();
+            bi.h_fl_counts = readExp.fragLengthCounts().data(); bi.max_frag_len = static_cast<uint32_t>(readExp.fragLengthCounts().size());
+            bi.gc_speed_samp = sopt.pdfSampFactor; bi.h_read_bias = readExp.readBias().data(); bi.h_observed_gc = readExp.observedGC().data();
+            bi.num_fwd = readExp.numFwd(); bi.num_rc = readExp.numRC();
+            bi.seq_bias = sopt.biasCorrect; bi.gc_bias = sopt.gcBiasCorrect; bi.gc_size_samp = sopt.gcSampFactor;
+            sfgpu_bias* bias = nullptr;
+            rc = sfgpu_bias_create(&bias, &bi, nullptr);
+            if (rc != SFGPU_OK) { sfgpu_em_destroy(em); check(rc, "sfgpu_bias_create"); }
+            rc = sfgpu_em_optimize_bias(em, &o, bias, alpha.get(), mass.get(), dEffOut.get(), &lastRecomputes, &st);
+            if (rc == SFGPU_OK) {
+                (void)sfgpu_bias_expected(bias, readExp.expectedSeqBias().data(), readExp.expectedGCBias().data());
+                newEffLens = dEffOut.download();
+            }
+            sfgpu_bias_destroy(bias);
+        } else {
+            rc = sfgpu_em_optimize(em, &o, alpha.get(), mass.get(), &st);
+        }
         sfgpu_em_destroy(em);
         lastIterations = st.iters;
         if (rc == SFGPU_ERR_NO_ACTIVE || rc == SFGPU_ERR_ALPHA_SUM) return false;
         check(rc, "sfgpu_em_optimize");
+        for (size_t i = 0; i < newEffLens.size(); ++i) txps[i].EffectiveLength = newEffLens[i];   // :888
         const std::vector<double> a = alpha.download(), m = mass.download();
         std::vector<uint32_t> members = dp.ids.download();
         for (uint32_t t : members) txps[t].setActive();                            // :774-782
@@ -324,6 +374,7 @@ class CollapsedEMOptimizer {
     }
 
     uint32_t lastIterations = 0;       // the N of the reference's log line "iteration = N | max rel diff. = x" (:871-872)
+    uint32_t lastRecomputes = 0;       // how often "recomputing effective lengths" (:827) happened
 };
 
 // ---- include/CollapsedGibbsSampler.hpp:22-32 ---------------------------------------------------------------

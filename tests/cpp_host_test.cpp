@@ -110,6 +110,49 @@ int main() {
     for (auto& l : lines) { saw_iter_line = saw_iter_line || l.find("iteration = 50") != std::string::npos; saw_classes_line = saw_classes_line || l.find("Optimizing over 5 equivalence classes") != std::string::npos; }
     EXPECT(saw_iter_line && saw_classes_line);                     // what the reference logs through jointLog (:790, :871)
 
+    // ---- optimize() with doBiasCorrect (:717, :814-840, :888): pairs of transcripts sharing most fragments, the second
+    //      of each pair without unique evidence (the EM runs well past iteration 50), both bias models
+    for (int model = 0; model < 2; ++model) {
+        ReadExperiment exp;
+        std::mt19937_64 g(99);
+        const int M = 40;
+        std::string seq; std::vector<uint64_t> off;
+        for (int t = 0; t < M; ++t) {
+            const uint32_t L = 600 + g() % 1500;
+            off.push_back(seq.size());
+            for (uint32_t i = 0; i < L; ++i) seq.push_back("ACGT"[g() % 4]);
+            seq.push_back('$');
+            exp.transcripts().emplace_back(t, ("t" + std::to_string(t)).c_str(), L);
+            exp.transcripts().back().EffectiveLength = L - 199.0;
+        }
+        exp.setSequences(seq, off);
+        std::vector<int32_t> fld(1000, 0);
+        for (int i = 0; i < 1000; ++i) { const int d = i - 200; fld[i] = (d > -150 && d < 150) ? 150 - std::abs(d) : 0; }
+        exp.setFragLengthDist(fld);
+        for (int i = 0; i < 4096; ++i) exp.readBias()[i] = 1 + (g() % 50);
+        for (int i = 0; i < 101; ++i) exp.observedGC()[i] = 1 + ((i > 30 && i < 70) ? 200 + g() % 50 : g() % 3);
+        exp.addNumFwd(600); exp.addNumRC(400);
+        auto& b = exp.equivalenceClassBuilder();
+        b.start();
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < M / 2; ++j) {
+            const uint32_t s = 3000 + g() % 2000, u = 150 + g() % 100;
+            b.insertGroup(TranscriptGroup({2 * j, 2 * j + 1}), s); b.insertGroup(TranscriptGroup({2 * j}), u);
+            total += s + u;
+        }
+        EXPECT(b.finish());
+        exp.numMappedFragmentsAtomic() = total;
+        SailfishOpts bo; bo.biasCorrect = model == 0; bo.gcBiasCorrect = model == 1;
+        CollapsedEMOptimizer opt;
+        EXPECT(opt.optimize(exp, bo, 0.01, 10000));
+        EXPECT(opt.lastIterations > 50 && opt.lastRecomputes >= 1);
+        int changed = 0; double est = 0.0, exp_sum = 0.0;
+        for (int t = 0; t < M; ++t) { changed += exp.transcripts()[t].EffectiveLength != exp.transcripts()[t].RefLength - 199.0; est += exp.transcripts()[t].estCount(); }
+        for (double v : (model == 0 ? exp.expectedSeqBias() : exp.expectedGCBias())) exp_sum += v;
+        EXPECT(changed > 0 && close_to(est, (double)total, 1e-9) && exp_sum > (model == 0 ? 4096.0 : 101.0) + 1.0);
+        std::printf("bias model %d: %u iterations, %u recomputes, %d lengths corrected\n", model, opt.lastIterations, opt.lastRecomputes, changed);
+    }
+
     // ---- optimize() returns false where the reference does: no transcript is expressed (:794-798)
     {
         ReadExperiment exp; toy(exp);
