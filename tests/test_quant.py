@@ -121,3 +121,47 @@ def test_quantify_option_checks(built, gpu, tmp_path):
     # no reads at all: "no transcripts expressed" -> 1, as the reference
     rc, _ = sf.quant.quantify(["a", "b"], np.array([100, 200], np.uint32), [], "U", str(tmp_path / "o3"), sf.SailfishOpts(), device=gpu)
     assert rc == 1
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_sample_data_fixture_is_consistent(built):
+    """tests/golden/sample_data_hits.npz (BASELINE config 1's bundled data through the stand-in mapper): every record
+    names the transcript its read was simulated from among its hits"""
+    d = np.load(os.path.join(GOLD, "sample_data_hits.npz"))
+    hits = d["hits"].view(O.HIT_DTYPE); off = d["offsets"]
+    assert len(d["names"]) == 15 and len(off) == 10001 and off[-1] == len(hits)
+    assert all(d["truth"][r] in hits["tid"][off[r]:off[r + 1]] for r in range(10000))
+    assert np.all(hits["frag_len"] < 1000) and np.all(hits["tid"] < 15)
+
+
+@pytest.mark.gpu
+def test_quantify_bundled_sample_data(built, gpu, tmp_path):
+    """BASELINE config 1 ("sailfish quant on the bundled sample_data", plumbing / correctness): the reference's own
+    15-transcript sample through quantify(), against the oracle chain on the same hit records and against the
+    simulator's truth carried by the read names"""
+    import sailfish_amd as sf
+    d = np.load(os.path.join(GOLD, "sample_data_hits.npz"))
+    names = [str(n) for n in d["names"]]; rl = d["ref_len"]
+    hits = d["hits"].view(O.HIT_DTYPE); off = d["offsets"]
+    cuts = [0, 1000, 2000, 5000, 10000]                                    # parser jobs of different sizes
+    batches = [(hits[off[a]:off[b]], (off[a:b + 1] - off[a]).astype(np.uint32)) for a, b in zip(cuts, cuts[1:])]
+    out = str(tmp_path / "out")
+    sopt = sf.SailfishOpts(numFragSamples=5000)
+    rc, exp = sf.quant.quantify(names, rl, batches, "IU", out, sopt, cmd_options={"libType": "IU"}, device=gpu)
+    assert rc == 0
+    (ids, oo, fl, rem, st) = O.filter_hits(hits, off, FORMATS["IU"], True, fl_counts=np.zeros(1000, np.uint32), remaining_fl_ops=5000)
+    assert st["n_mapped"] == 10000 and rem == 0 and exp.numMappedFragments() == 10000
+    ob = O.EqBuilder(); ob.add_batch(ids, oo.astype(np.uint64)); rp, ii, cc, hh = ob.finish()
+    eff = O.efflen_smoothed(rl, O.cf_counts(fl))
+    rc_o, a, m, st_o = O.em_optimize(eff, rp, ii, cc, 10000, max_iter=10000)
+    tpm = O.tpm(a, eff, 10000)
+    q = _read_quant(os.path.join(out, "quant.sf"))
+    got = np.array([q[n] for n in names])
+    np.testing.assert_allclose(got[:, 1], eff, rtol=2e-5)
+    big = a > 1e-2
+    np.testing.assert_allclose(got[big, 3], a[big], rtol=1e-4); np.testing.assert_allclose(got[big, 2], tpm[big], rtol=1e-4)
+    truth = np.bincount(d["truth"], minlength=15).astype(np.float64)
+    assert abs(got[:, 3].sum() - 10000) < 1e-6 * 10000
+    assert np.abs(got[:, 3] - truth).sum() / 10000 < 0.1, (got[:, 3], truth)     # the EM recovers the simulated abundances (isoforms 0-2 are hard)
