@@ -36,7 +36,7 @@ enum {
     SFGPU_ERR_ALPHA_SUM = 4, /* "total alpha weight was too small" -- :877-881 */
     SFGPU_ERR_RANGE = 5,     /* a size exceeds what the device layout holds (see each call) */
     SFGPU_ERR_STATE = 6,     /* call order violated (e.g. export before finish) */
-    SFGPU_ERR_UNSUPPORTED = 7 /* an option of the reference this build does not implement (see each call) */
+    SFGPU_ERR_UNSUPPORTED = 7 /* reserved: an option of the reference this build does not implement (none at present) */
 };
 
 typedef void* sfgpu_stream;          /* hipStream_t */
@@ -319,6 +319,8 @@ typedef struct sfgpu_bias_sampler {
     uint32_t* d_observed_gc;          /* [101] ReadExperiment::observedGC, or NULL (gcBiasCorrect off) */
     const uint32_t* d_gc_prefix;      /* see above */
     uint64_t n_bias_sampled, n_gc_sampled;   /* ACCUMULATED by the call */
+    uint32_t gc_size_samp;            /* SailfishOpts::gcSampFactor: 0 or 1 = exact counts, > 1 = the reference's interpolation (bin clamped to [0,100]) */
+    uint32_t pad_;
 } sfgpu_bias_sampler;
 SFGPU_API int sfgpu_gc_prefix(const char* d_seq, const uint64_t* d_seq_off, const uint32_t* d_ref_len, uint64_t M,
                       uint32_t* d_gc_prefix, sfgpu_stream stream);
@@ -343,10 +345,12 @@ SFGPU_API int sfgpu_sample_bias(const sfgpu_hit* d_hits, const uint32_t* d_hit_o
  *   h_read_bias       : 4096 ReadKmerDist<6>::counts, pseudo-count included (may be NULL when !seq_bias)
  *   h_observed_gc     : 101 ReadExperiment::observedGC counts, pseudo-count included (may be NULL when !gc_bias)
  *   gc_speed_samp     : SailfishOpts::pdfSampFactor (--gcSpeedSamp)
- *   gc_size_samp      : SailfishOpts::gcSampFactor (--gcSizeSamp); only 1 is implemented (the option trades
- *                       accuracy for the memory of a per-base GC table this library does not keep, and its
- *                       interpolated counts index outside the 101 bins in the reference): other values
- *                       return SFGPU_ERR_UNSUPPORTED
+ *   gc_size_samp      : SailfishOpts::gcSampFactor (--gcSizeSamp).  Above 1 the reference keeps the G/C count at every
+ *                       gc_size_samp-th base only and interpolates (Transcript::gcCountInterp_, include/Transcript.hpp:
+ *                       133-162, lambda on the LEFT sample as written); the same values are used here (slow path:
+ *                       per-base table built for the duration of sfgpu_bias_create).  The interpolated difference
+ *                       can leave [0, fragment length], where the reference indexes outside its 101 bins: the bin is
+ *                       clamped to [0,100]
  * As in the reference, seq_bias and gc_bias together, or num_fwd + num_rc == 0, make every update a copy
  * of its input (status 2 / 1).  GC correction needs fld_low >= 1 (the reference divides by the fragment
  * length) and a 0.995 quantile below 16000 (SFGPU_ERR_RANGE).  Device memory: 808 bytes per transcript in

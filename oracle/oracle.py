@@ -363,7 +363,7 @@ def filter_hits(hits, hit_off, fmt, paired_library, discard_orphans=True, ignore
 class _BiasSampler(C.Structure):
     _fields_ = [("seq", C.c_void_p), ("seq_off", C.c_void_p), ("ref_len", C.c_void_p), ("M", C.c_uint64),
                 ("read_bias", C.c_void_p), ("remaining_bias_samples", C.POINTER(C.c_int64)), ("observed_gc", C.c_void_p),
-                ("n_bias_sampled", C.c_uint64), ("n_gc_sampled", C.c_uint64)]
+                ("n_bias_sampled", C.c_uint64), ("n_gc_sampled", C.c_uint64), ("gc_size_samp", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 def filter_hits_bias(hits, hit_off, fmt, paired_library, seq, seq_off, ref_len, read_bias=None, remaining_bias_samples=0,
@@ -387,7 +387,7 @@ def filter_hits_bias(hits, hit_off, fmt, paired_library, seq, seq_off, ref_len, 
     og = None if observed_gc is None else _c(observed_gc, np.uint32).copy()
     remb = C.c_int64(int(remaining_bias_samples))
     bs = _BiasSampler(_p(sq).value, _p(so).value, _p(rl).value, len(rl), None if rb is None else _p(rb).value,
-                      C.pointer(remb), None if og is None else _p(og).value, 0, 0)
+                      C.pointer(remb), None if og is None else _p(og).value, 0, 0, int(kw.get("gc_size_samp", 1)), 0)
     L = lib()
     L.sfo_filter_hits_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(_FilterOpts), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(C.c_int64), C.POINTER(_FilterStats), C.POINTER(_BiasSampler)]

@@ -1204,6 +1204,7 @@ typedef struct {
     int64_t* remaining_bias_samples;  /* sfOpts.numBiasSamples */
     uint32_t* observed_gc;            /* [101] */
     uint64_t n_bias_sampled, n_gc_sampled;
+    uint32_t gc_size_samp; uint32_t pad_;   /* sfOpts.gcSampFactor: 0/1 exact table, > 1 sampled + interpolated */
 } sfo_bias_sampler;
 
 /* ReadKmerDist::update (include/ReadKmerDist.hpp:35-73): dir 0 = FORWARD (the context is stored reverse-complemented) */
@@ -1286,7 +1287,7 @@ static void filter_hits_impl(const sfo_hit* hits, const uint32_t* hit_off, uint3
                 uint32_t L = bs->ref_len[h->tid];
                 if (start > 0 && (uint32_t)stop < L) {
                     sfo_gc* g = &gcs[h->tid];
-                    if (!g->cnt) gc_build(g, bs->seq + bs->seq_off[h->tid], L, 1);
+                    if (!g->cnt) gc_build(g, bs->seq + bs->seq_off[h->tid], L, bs->gc_size_samp > 1 ? bs->gc_size_samp : 1);
                     bs->observed_gc[gc_frac(g, start, stop)]++;
                     bs->n_gc_sampled++;
                 }

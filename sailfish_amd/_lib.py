@@ -69,7 +69,7 @@ class FilterStats(C.Structure):
 class BiasSampler(C.Structure):
     _fields_ = [("d_seq", C.c_void_p), ("d_seq_off", C.c_void_p), ("d_ref_len", C.c_void_p), ("d_read_bias", C.c_void_p),
                 ("remaining_bias_samples", C.POINTER(C.c_int64)), ("d_observed_gc", C.c_void_p), ("d_gc_prefix", C.c_void_p),
-                ("n_bias_sampled", C.c_uint64), ("n_gc_sampled", C.c_uint64)]
+                ("n_bias_sampled", C.c_uint64), ("n_gc_sampled", C.c_uint64), ("gc_size_samp", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 class BiasInputs(C.Structure):

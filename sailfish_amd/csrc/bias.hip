@@ -26,6 +26,7 @@
 //       effLen'_t   = (sum_g observed[g] / (prior + expected[g]) * S[t][g]) * (probFwd + probRC) * norm
 //   gcFrac's lrint((100.0 * d) / fl) is evaluated without a division (gc_bin): an f32 product, and an exact
 //   f32 residual that recognises the ties lrint sends to the even neighbour.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -358,6 +359,64 @@ __global__ void __launch_bounds__(kGcBlock) k_gc_profile(BiasDev d) {
     if (tid < kNGC) Srow[tid] = Sacc[tid];
 }
 
+// gcSampFactor > 1 (--gcSizeSamp): Transcript::gcFrac through gcCountInterp_ (include/Transcript.hpp:91-94, 133-162).
+// The reference keeps the G/C count only at every step-th base (plus the last) and interpolates between the two
+// samples around a position -- with lambda weighing the LEFT sample, as written: count(p) = lambda * cnt[a] +
+// (1 - lambda) * cnt[a + 1], lambda = p / step - a (its "last bin" branch is unreachable: a < ceil((L-1)/step) for
+// every p < L - 1).  The sampled counts are the per-base counts at multiples of step, so they are read from the
+// per-base table (G, as k_gc_prefix lays it out, offset to this transcript).  The bin is clamped to [0,100] -- the
+// interpolated difference can leave that range, where the reference indexes outside its 101 bins.
+__device__ __forceinline__ double gc_count_interp(const uint32_t* __restrict__ G, uint32_t L, uint32_t step, uint32_t p) {
+    if (p == L - 1) return (double)G[L - 1];
+    const double frac_p = (double)p / (double)step;
+    const uint32_t samp = (uint32_t)floor(frac_p);
+    const double lambda = (frac_p - (double)samp) / ((double)(samp + 1) - (double)samp);
+    const uint32_t nxt = min((samp + 1) * step, L - 1);
+    return lambda * (double)G[samp * step] + (1.0 - lambda) * (double)G[nxt];
+}
+__device__ __forceinline__ uint32_t gc_frac_sampled(const uint32_t* __restrict__ G, uint32_t L, uint32_t step, uint32_t s, uint32_t e) {
+    const double cs = gc_count_interp(G, L, step, s), ce = gc_count_interp(G, L, step, e);
+    long r = lrint((100.0 * (ce - cs)) / (double)(e - s + 1));
+    r = r < 0 ? 0 : (r > 100 ? 100 : r);
+    return (uint32_t)r;
+}
+
+// the slow path of k_gc_profile for gcSampFactor > 1: same counting, bins through the interpolation, counts from the table
+__global__ void __launch_bounds__(kBlock) k_gc_profile_sampled(BiasDev d, const uint32_t* __restrict__ gc_table, uint32_t step) {
+    __shared__ double Sacc[kNGC];
+    __shared__ uint32_t H[kLanesFl * kNGC];
+    const uint64_t t = blockIdx.x;
+    const uint32_t L = d.ref_len[t];
+    double* Srow = d.S + t * kNGC;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    if (L <= (uint32_t)kK || unprocessed_len(L, d.txp_eff[t]) <= 0) { if (tid < kNGC) Srow[tid] = 0.0; return; }
+    if (tid < kNGC) Sacc[tid] = 0.0;
+    const uint32_t* G = gc_table + d.seq_off[t];
+    const uint32_t n_pos = L - kK;
+    for (uint32_t k0 = 0; k0 < d.nfl; k0 += kLanesFl) {
+        const uint32_t fl_min = (uint32_t)d.fld_low + k0 * d.gs;
+        if (fl_min > L) break;
+        const uint32_t k_last = min(d.nfl - 1, k0 + kLanesFl - 1);
+        const uint32_t n_i = min(n_pos, L - fl_min + 1);
+        const uint32_t k = k0 + lane;
+        const uint32_t fl = (uint32_t)d.fld_low + k * d.gs;
+        for (int j = tid; j < kLanesFl * kNGC; j += kBlock) H[j] = 0;
+        __syncthreads();
+        for (uint32_t i = wv; i < n_i; i += kBlock / kWave) {
+            const uint32_t e = i + fl - 1;
+            if (k < d.nfl && e < L) atomicAdd(&H[lane * kNGC + gc_frac_sampled(G, L, step, i, e)], 1u);
+        }
+        __syncthreads();
+        if (tid < kNGC) {
+            double acc = Sacc[tid];
+            for (uint32_t l = 0; l <= k_last - k0; ++l) acc += d.w[k0 + l] * (double)H[l * kNGC + tid];
+            Sacc[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid < kNGC) Srow[tid] = Sacc[tid];
+}
+
 // expected[g] partial sums over kGcRows transcripts per block, fixed order (the loads of eight rows are in
 // flight together; the adds stay in transcript order)
 __global__ void __launch_bounds__(128) k_gc_expected_partial(BiasDev d, const double* __restrict__ eff_in,
@@ -507,8 +566,7 @@ int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_strea
           SFGPU_ERR_INVALID, "sfgpu_bias_create: null input");
     B_REQ(!seq_on || in->h_read_bias, SFGPU_ERR_INVALID, "sfgpu_bias_create: seq_bias needs h_read_bias");
     B_REQ(!gc_on || in->h_observed_gc, SFGPU_ERR_INVALID, "sfgpu_bias_create: gc_bias needs h_observed_gc");
-    B_REQ(!gc_on || in->gc_size_samp == 1, SFGPU_ERR_UNSUPPORTED,
-          "sfgpu_bias_create: gcSizeSamp != 1 is not implemented (see sfgpu.h)");
+    B_REQ(!gc_on || in->gc_size_samp >= 1, SFGPU_ERR_INVALID, "sfgpu_bias_create: gc_size_samp must be >= 1");
     B_REQ(!gc_on || in->gc_speed_samp >= 1, SFGPU_ERR_INVALID, "sfgpu_bias_create: gc_speed_samp must be >= 1");
 
     // EmpiricalDistribution::buildDistribution (src/EmpiricalDistribution.cpp:29-77) for vals = 0..n-1
@@ -587,6 +645,24 @@ int sfgpu_bias_create(sfgpu_bias** out, const sfgpu_bias_inputs* in, sfgpu_strea
         if (b->dev.nfl) {
             B_TRY(bias_alloc(b, const_cast<double**>(&b->dev.w), w.size() * 8));
             B_HIP(hipMemcpyAsync(const_cast<double*>(b->dev.w), w.data(), w.size() * 8, hipMemcpyHostToDevice, st));
+        }
+        if (b->dev.nfl && in->gc_size_samp > 1) {
+            // --gcSizeSamp: the interpolated counts of the reference, read from a per-base table that lives only here
+            std::vector<uint64_t> h_off(in->M); std::vector<uint32_t> h_len(in->M);
+            B_HIP(hipMemcpyAsync(h_off.data(), in->d_seq_off, in->M * 8, hipMemcpyDeviceToHost, st));
+            B_HIP(hipMemcpyAsync(h_len.data(), in->d_ref_len, in->M * 4, hipMemcpyDeviceToHost, st));
+            B_HIP(hipStreamSynchronize(st));
+            uint64_t extent = 0;
+            for (uint64_t t = 0; t < in->M; ++t) extent = std::max(extent, h_off[t] + h_len[t]);
+            uint32_t* table = nullptr;
+            B_HIP(pool_malloc(&table, (extent ? extent : 1) * 4));
+            hipLaunchKernelGGL(k_gc_prefix, dim3((unsigned)in->M), dim3(kBlock), 0, st, in->d_seq, in->d_seq_off, in->d_ref_len, table);
+            hipLaunchKernelGGL(k_gc_profile_sampled, dim3((unsigned)in->M), dim3(kBlock), 0, st, b->dev, table, in->gc_size_samp);
+            hipError_t le = hipGetLastError();
+            (void)hipStreamSynchronize(st);
+            pool_free(table);
+            B_HIP(le);
+        } else if (b->dev.nfl) {
             uint32_t cap = (uint32_t)b->fld_high + 2048;
             if (cap < kStageMin) cap = kStageMin;
             b->dev.stage_cap = cap;

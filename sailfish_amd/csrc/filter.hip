@@ -195,8 +195,18 @@ k_filter_compact(const uint32_t* __restrict__ off, uint32_t n_reads, const uint3
 // ---- bias / GC samples of the same loop (sfgpu_sample_bias) ---------------------------------------------
 struct SamplerDev {
     const char* seq; const uint64_t* seq_off; const uint32_t* ref_len; const uint32_t* gc_prefix;
-    uint32_t* observed_gc; int want_seq;
+    uint32_t* observed_gc; int want_seq; uint32_t gc_step;
 };
+
+// Transcript::gcCountInterp_ (include/Transcript.hpp:133-162) on the per-base table: see bias.hip (gc_count_interp)
+__device__ __forceinline__ double sampled_gc_count(const uint32_t* __restrict__ G, uint32_t L, uint32_t step, uint32_t p) {
+    if (p == L - 1) return (double)G[L - 1];
+    const double frac_p = (double)p / (double)step;
+    const uint32_t samp = (uint32_t)floor(frac_p);
+    const double lambda = (frac_p - (double)samp) / ((double)(samp + 1) - (double)samp);
+    const uint32_t nxt = (samp + 1) * step < L - 1 ? (samp + 1) * step : L - 1;
+    return lambda * (double)G[samp * step] + (1.0 - lambda) * (double)G[nxt];
+}
 
 // indexForKmer (include/UtilityFunctions.hpp:93-148): false when a byte is not ACGTU (the reference then gets
 // 0xFFFFFFFF and ReadKmerDist::update reports no success)
@@ -252,8 +262,15 @@ k_sample_bias(const sfgpu_hit* __restrict__ hits, const uint32_t* __restrict__ o
                 const int32_t stop = (int32_t)((uint32_t)start + h.frag_len);
                 if (start > 0 && (uint32_t)stop < L) {
                     const uint32_t* G = s.gc_prefix + s.seq_off[h.tid];
-                    const uint32_t d = G[stop] - G[start];
-                    const long g = lrint((100.0 * (double)d) / (double)(stop - start + 1));    // Transcript::gcFrac
+                    long g;
+                    if (s.gc_step <= 1) {
+                        const uint32_t d = G[stop] - G[start];
+                        g = lrint((100.0 * (double)d) / (double)(stop - start + 1));           // Transcript::gcFrac
+                    } else {
+                        const double cs = sampled_gc_count(G, L, s.gc_step, (uint32_t)start), ce = sampled_gc_count(G, L, s.gc_step, (uint32_t)stop);
+                        g = lrint((100.0 * (ce - cs)) / (double)(stop - start + 1));
+                        g = g < 0 ? 0 : (g > 100 ? 100 : g);                                   // the reference indexes out of range here
+                    }
                     atomicAdd(&gc_hist[g], 1u);
                 }
             }
@@ -300,7 +317,7 @@ extern "C" int sfgpu_sample_bias(const sfgpu_hit* d_hits, const uint32_t* d_hit_
     if (e == hipSuccess && want_seq) e = pool_malloc(&d_rank, (n1 + 1) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(d_ngc, 0, 8, st);
     const unsigned grid = (unsigned)((n1 + kFilterBlock - 1) / kFilterBlock);
-    SamplerDev sd{sp->d_seq, sp->d_seq_off, sp->d_ref_len, sp->d_gc_prefix, want_gc ? sp->d_observed_gc : nullptr, want_seq ? 1 : 0};
+    SamplerDev sd{sp->d_seq, sp->d_seq_off, sp->d_ref_len, sp->d_gc_prefix, want_gc ? sp->d_observed_gc : nullptr, want_seq ? 1 : 0, sp->gc_size_samp};
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_sample_bias, dim3(grid), dim3(kFilterBlock), 0, st, d_hits, d_hit_offsets, n_reads, *opts, sd, d_flag, d_kmer, d_ngc);
         e = hipGetLastError();

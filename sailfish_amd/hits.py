@@ -89,8 +89,8 @@ def gc_prefix(seq, seq_off, ref_len):
 
 
 def sample_bias(hits, hit_offsets, lib_format, seq, seq_off, ref_len, *, read_bias=None, remaining_bias_samples=0,
-                observed_gc=None, gc_prefix_table=None, paired_library=None, allow_orphans=False, max_read_occs=200,
-                max_frag_len=1000, device="cuda"):
+                observed_gc=None, gc_prefix_table=None, gc_size_samp=1, paired_library=None, allow_orphans=False,
+                max_read_occs=200, max_frag_len=1000, device="cuda"):
     """The bias / GC samples the hit loop collects (src/SailfishQuantify.cpp:270-287, 375-389, 559-581) over the reads and
     hits that survive filter_hits' cuts.  read_bias (int32 device tensor [4096]) and observed_gc ([101]) are updated in
     place when given.  Returns (remaining_bias_samples, n_bias_sampled, n_gc_sampled)."""
@@ -107,7 +107,7 @@ def sample_bias(hits, hit_offsets, lib_format, seq, seq_off, ref_len, *, read_bi
     sp = _lib.BiasSampler(_lib.ptr(seq).value, _lib.ptr(so).value, _lib.ptr(ref_len).value,
                           None if read_bias is None else _lib.ptr(read_bias).value, C.pointer(rem),
                           None if observed_gc is None else _lib.ptr(observed_gc).value,
-                          None if gc_prefix_table is None else _lib.ptr(gc_prefix_table).value, 0, 0)
+                          None if gc_prefix_table is None else _lib.ptr(gc_prefix_table).value, 0, 0, int(gc_size_samp), 0)
     with torch.cuda.device(dev):
         torch.cuda.current_stream().synchronize()
         _lib.check(_lib.lib().sfgpu_sample_bias(_lib.ptr(d_hits), _lib.ptr(d_off), R, C.byref(o), C.byref(sp), _lib.current_stream_ptr()))

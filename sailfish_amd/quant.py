@@ -83,7 +83,7 @@ def quantify(names, ref_len, hit_batches, lib_format, out_dir, sopt: SailfishOpt
         if do_bias:
             rem_bias, _, _ = _hits.sample_bias(hits, off, fmt, exp._seq, exp._seq_off, exp.transcripts().RefLength, read_bias=d_rb,
                                                remaining_bias_samples=rem_bias, observed_gc=d_gc, gc_prefix_table=gc_table,
-                                               paired_library=paired, allow_orphans=allow_orphans,
+                                               gc_size_samp=sopt.gcSampFactor, paired_library=paired, allow_orphans=allow_orphans,
                                                max_read_occs=sopt.maxReadOccs, max_frag_len=sopt.maxFragLen, device=dev)
         eq.add_batch(ids, out_off)
     eq.finish()                                                              # :1324

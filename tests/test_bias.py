@@ -280,6 +280,28 @@ def test_update_matches_oracle(built, mode, samp, fld):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("step,samp", [(2, 1), (4, 3), (7, 1), (25, 1)])
+def test_gc_model_with_sampled_gc_counts(built, step, samp):
+    """--gcSizeSamp > 1: Transcript::gcCountInterp_'s interpolated counts (include/Transcript.hpp:133-162), bins clamped
+    to [0,100] where the reference would index out of range"""
+    import torch
+    dev = torch.device("cuda:0")
+    w = workload(300 + step, M=120, hi=2500)
+    kw = dict(num_fwd=7, num_rc=5, gc_bias=True, gc_speed_samp=samp, gc_size_samp=step)
+    bm = O.make_bias_model(w["seq"], w["off"], w["lens"], w["txp_eff"], w["fl"], w["rb"], w["og"], **kw)
+    rc, out, es, eg, nc = O.update_efflens(bm, w["eff_in"], w["alphas"])
+    exact = O.update_efflens(O.make_bias_model(w["seq"], w["off"], w["lens"], w["txp_eff"], w["fl"], w["rb"], w["og"], **{**kw, "gc_size_samp": 1}),
+                             w["eff_in"], w["alphas"])
+    assert rc == 0 and nc > 0 and not np.array_equal(out, exact[1])          # the interpolation does change the answer
+    model = _device_model(w, dev, **kw)
+    got, st = model.update(torch.from_numpy(w["eff_in"]).to(dev), torch.from_numpy(w["alphas"]).to(dev))
+    assert st["n_corrected"] == nc
+    np.testing.assert_allclose(got.cpu().numpy(), out, rtol=RTOL)
+    np.testing.assert_allclose(model.expected()[1], eg, rtol=RTOL)
+    model.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["seq", "gc"])
 def test_update_with_unknown_bases_inside(built, mode):
     """a byte outside ACGTU away from a transcript's first k-mers: nextKmerIndex shifts in 0 for it in both directions
@@ -311,7 +333,7 @@ def test_update_with_unknown_bases_inside(built, mode):
 
 
 @pytest.mark.gpu
-def test_update_skip_and_unsupported(built):
+def test_update_skip_and_invalid(built):
     import torch
     import sailfish_amd as sf
     dev = torch.device("cuda:0")
@@ -322,9 +344,6 @@ def test_update_skip_and_unsupported(built):
         got, st = m.update(e, a)
         assert st["status"] == code and torch.equal(got, e)
         m.close()
-    with pytest.raises(sf._lib.SfgpuError) as ei:
-        _device_model(w, dev, gc_bias=True, num_fwd=1, num_rc=1, gc_size_samp=4)
-    assert ei.value.code == sf._lib.ERR_UNSUPPORTED
     with pytest.raises(sf._lib.SfgpuError):                               # 0.005 quantile at length 0
         w0 = dict(w); w0["fl"] = np.array([50, 30, 10, 5, 5], np.uint32)
         _device_model(w0, dev, gc_bias=True, num_fwd=1, num_rc=1)

@@ -238,8 +238,13 @@ def test_sample_bias_device_vs_oracle(built, gpu):
                                                          remaining_bias_samples=budget, observed_gc=og0 if want_gc else None, **kw)
         d_rb = torch.from_numpy(rb0.view(np.int32).copy()).to(gpu) if want_seq else None
         d_og = torch.from_numpy(og0.view(np.int32).copy()).to(gpu) if want_gc else None
+        gstep = int(rng.choice([1, 1, 3, 10]))
+        if gstep > 1:                                                  # --gcSizeSamp: the interpolated counts
+            _, orb, orem, oog, onb, ong = O.filter_hits_bias(h, off, FORMATS[name], paired, seq, so, rl, read_bias=rb0 if want_seq else None,
+                                                             remaining_bias_samples=budget, observed_gc=og0 if want_gc else None,
+                                                             gc_size_samp=gstep, **kw)
         grem, gnb, gng = sf.hits.sample_bias(h, off, name, d_seq, d_so, d_rl, read_bias=d_rb, remaining_bias_samples=budget,
-                                             observed_gc=d_og, gc_prefix_table=pre, paired_library=paired,
+                                             observed_gc=d_og, gc_prefix_table=pre, gc_size_samp=gstep, paired_library=paired,
                                              allow_orphans=not kw["discard_orphans"], max_read_occs=kw["max_read_occs"], device=gpu)
         if want_seq:
             np.testing.assert_array_equal(d_rb.cpu().numpy().view(np.uint32), orb)
