@@ -33,7 +33,8 @@ while time.time() < t_end:
     eff_in = np.maximum(txp_eff * (0.8 + 0.4 * rng.random(M)), 1.0)
     rb = rng.integers(1, 1000, 4096).astype(np.uint32); og = rng.integers(1, 5000, 101).astype(np.uint32)
     nf, nr = int(rng.integers(0, 1000)), int(rng.integers(1, 1000))
-    kw = dict(num_fwd=nf, num_rc=nr, seq_bias=mode == "seq", gc_bias=mode == "gc", gc_speed_samp=samp)
+    step = int(rng.choice([1, 1, 1, 2, 5, 16]))                       # --gcSizeSamp: the interpolated counts
+    kw = dict(num_fwd=nf, num_rc=nr, seq_bias=mode == "seq", gc_bias=mode == "gc", gc_speed_samp=samp, gc_size_samp=step)
     bm = O.make_bias_model(seq, off, lens, txp_eff, fl, rb, og, **kw)
     rc, out, es, eg, nc = O.update_efflens(bm, eff_in, alphas)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
@@ -47,7 +48,7 @@ while time.time() < t_end:
     got, st = model.update(t(eff_in, np.float64), t(alphas, np.float64))
     g = got.cpu().numpy()
     ges, geg = model.expected()
-    desc = f"M={M} hi={hi} n={n} mean={mean:.0f} sd={sd:.0f} {mode} samp={samp} fld=[{st['fld_low']},{st['fld_high']}] corrected={nc}"
+    desc = f"M={M} hi={hi} n={n} mean={mean:.0f} sd={sd:.0f} {mode} samp={samp} step={step} fld=[{st['fld_low']},{st['fld_high']}] corrected={nc}"
     assert st["n_corrected"] == nc, (desc, st)
     for a, b, what in ((g, out, "lengths"), (ges, es, "expected seq"), (geg, eg, "expected gc")):
         rel = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
