@@ -80,3 +80,69 @@ def test_two_ranks_on_one_gpu_match_the_oracle(gpu, mode, vb):
         assert np.array_equal(r[6] > 0, nz)
         assert np.max(np.abs(r[6][nz] - oa[nz]) / oa[nz]) < 1e-9
         assert np.max(np.abs(r[7][nz] - ot[nz]) / ot[nz]) < 1e-9
+
+
+def _bias_worker(rank, world, port, mode, which, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sailfish_amd as sf
+        from sailfish_amd import distributed as sfd, synth
+        from test_distributed_cpu import _bias_inputs
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        M, P, R = 300, 900, 5000
+        ref_len = synth.transcript_lengths(M)
+        poff, pids = synth.label_pool(M, P)
+        ids, off = synth.reads_from_pool(poff, pids, R, seed=3 + 1000 * rank)
+        sopt = sf.SailfishOpts(biasCorrect=which == "seq", gcBiasCorrect=which == "gc")
+        exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.numpy().view(np.uint32), device=dev), sopt)
+        seq, soff, fl, rb, og = _bias_inputs(M, ref_len.numpy().view(np.uint32))
+        exp.setSequences(seq, soff)
+        exp.readBias()[:] = rb; exp.observedGC()[:] = og; exp.addNumFwd(55); exp.addNumRC(45)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, poll_every=7, tol=1e-4)
+        info = q.run(ids.to(dev), off.to(dev))
+        t = exp.transcripts()
+        out.put((rank, info["em_stats"]["iters"], q.recomputes, t.estCount.cpu().numpy(), t.EffectiveLength.cpu().numpy(),
+                 exp.expectedSeqBias().copy(), exp.expectedGCBias().copy(), ids.numpy().copy(), off.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,which", [("sharded", "seq"), ("sharded", "gc"), ("replicated", "seq")])
+def test_two_ranks_on_one_gpu_with_the_bias_hook(gpu, mode, which):
+    """doBiasCorrect across ranks with the product engine: lowered stop bounds, sfgpu_bias_update on the replicated alpha,
+    broadcast, sfgpu_em_rebase (sharded); sfgpu_em_optimize_bias on every rank (replicated)"""
+    from test_distributed_cpu import _bias_inputs
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bias_worker, args=(r, 2, port, mode, which, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from sailfish_amd import synth
+    M = 300
+    ref_len = synth.transcript_lengths(M).numpy().view(np.uint32)
+    b = O.EqBuilder()
+    for r in res:
+        b.add_batch(r[7].view(np.uint32), r[8].view(np.uint32).astype(np.uint64))
+    rp, ii, cc, hh = b.finish()
+    eff0 = O.efflen_smoothed(ref_len, O.cf_gaussian())
+    seq, soff, fl, rb, og = _bias_inputs(M, ref_len)
+    # the driver's effective-length stage (single-end synth reads) stores the Gaussian-prior FLD in the experiment
+    bm = O.make_bias_model(seq, soff.astype(np.uint64), ref_len, eff0, O.fld_gaussian_counts().astype(np.uint32), rb, og, num_fwd=55, num_rc=45,
+                           seq_bias=which == "seq", gc_bias=which == "gc")
+    rc, oa, om, oeff, oes, oeg, onr, ost = O.em_optimize_bias(bm, eff0, rp, ii, cc, b.total_reads, tol=1e-4)
+    assert rc == 0 and onr >= 1
+    for r in res:
+        assert abs(int(r[1]) - int(ost["iters"])) <= 1 and r[2] == onr
+        np.testing.assert_allclose(r[4], oeff, rtol=1e-6)
+        big = oa > 1e-3
+        np.testing.assert_allclose(r[3][big], oa[big], rtol=1e-4)
+        np.testing.assert_allclose(r[5], oes, rtol=1e-6); np.testing.assert_allclose(r[6], oeg, rtol=1e-6)
+    if mode == "sharded":
+        assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])     # broadcast lengths: ranks bit-identical
