@@ -355,6 +355,7 @@ SFGPU_API int sfgpu_sample_bias(const sfgpu_hit* d_hits, const uint32_t* d_hit_o
  * of its input (status 2 / 1).  GC correction needs fld_low >= 1 (the reference divides by the fragment
  * length) and a 0.995 quantile below 16000 (SFGPU_ERR_RANGE).  Device memory: 808 bytes per transcript in
  * GC mode (the per-transcript GC-bin profile, built once at create), else O(1).
+ * A handle carries the state of its last update (the expectation vectors): use one per optimize() that runs at a time.
  * Floating point: sums run in a different order than the reference's serial loops (and the 4096-bin
  * expectation is accumulated with atomics), so lengths agree to ~1e-12 relative, not bit for bit.
  * ------------------------------------------------------------------------------------------- */
