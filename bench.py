@@ -8,8 +8,9 @@ quasi-mapper are third-party code outside the path and outside ev
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|small]
 
-N = 1 : configs[1] of BASELINE.json ("cfg2": 50M single-end reads, 80k-transcript index, EM to
-        convergence), the configuration the metric is quoted on.
+N = 1 : the configuration BASELINE.json's metric is quoted on ("... 200k-txp index"): configs[2], "cfg3" -- 400M
+        paired-end fragments, 200k-transcript index, VBEM + empirical fragment-length correction; it fits one GPU
+        (8 GB of hit lists).  --workload cfg2 is configs[1] (50M single-end reads, 80k transcripts, EM).
 N > 1 : launched by torch.distributed.run, one rank per GPU.  Weak scaling: every rank quantifies
         its own R-read shard of ONE experiment; class tables are merged with one all-gather and the
         EM runs on the merged classes (see sailfish_amd/distributed.py for the exchange).
@@ -42,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--em-mode", default="auto", choices=["auto", "replicated", "sharded"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
@@ -208,10 +209,13 @@ def main():
     em_ms = info["t_em_ms"]
     # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs of
     # this same command; FETCH_SIZE x2 for the wide streaming loads of the sweep, raw for the random
-    # probes of the insert kernel -- see profiles/r1_pmc_summary.md).  null when no profile matches.
+    # probes of the insert kernel -- see profiles/r1*_pmc_summary.md).  null when no profile matches.
     traffic_em = traffic_ins = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{a.workload}.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        pmc = json.load(open(pmc_path))
         if pmc.get("workload") == a.workload and world == 1:
             k = pmc["kernels"]
             e = k.get("k_sweep_lds<true>" if use_vbem else "k_sweep_lds<false>")

@@ -6,7 +6,7 @@ usage: python tools/make_profiles.py <stats_dir> <fetch_dir> <write_dir> <worklo
   fetch_dir : output of  rocprofv3 --pmc FETCH_SIZE --output-format csv -d <fetch_dir> -- (same command)
   write_dir : output of  rocprofv3 --pmc WRITE_SIZE --output-format csv -d <write_dir> -- (same command)
 
-Writes profiles/<tag>_kernel_stats.csv (verbatim kernel_stats), profiles/pmc_latest.json (per-kernel
+Writes profiles/<tag>_kernel_stats.csv (verbatim kernel_stats), profiles/pmc_<workload>.json + pmc_latest.json (per-kernel
 FETCH_SIZE / WRITE_SIZE KiB per launch, read by bench.py for roofline.traffic) and
 profiles/<tag>_pmc_summary.md.  FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section); on
 gfx950 FETCH_SIZE counts wide streaming reads at half their size -- bench.py applies the x2 to the sweep kernel
@@ -68,8 +68,9 @@ def main():
         kernels[k] = {"launches": n,
                       "fetch_kib_per_launch": fe.get(k, [0, 0.0])[1] / max(fe.get(k, [1, 0])[0], 1),
                       "write_kib_per_launch": wr.get(k, [0, 0.0])[1] / max(wr.get(k, [1, 0])[0], 1)}
-    json.dump({"workload": workload, "source": f"profiles/{tag}_pmc_summary.md", "kernels": kernels},
-              open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
+    for name in (f"pmc_{workload}.json", "pmc_latest.json"):     # bench.py reads the file of its workload
+        json.dump({"workload": workload, "source": f"profiles/{tag}_pmc_summary.md", "kernels": kernels},
+                  open(os.path.join(prof, name), "w"), indent=1)
     with open(os.path.join(prof, f"{tag}_pmc_summary.md"), "w") as f:
         f.write(f"# {tag}: per-kernel time and HBM traffic, `bench.py --workload {workload}` on one MI355X\n\n"
                 "Three separate rocprofv3 runs of the same command (kernel trace + stats; `--pmc FETCH_SIZE`; "
