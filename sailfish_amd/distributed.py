@@ -8,7 +8,8 @@ Data flow for N ranks:
      all-gathered and every rank folds all of them into one table with the weighted upsert
      (sfgpu_eq_add_weighted_device).  Equal labels from different ranks add their counts, so every
      rank ends with the same canonical class list as a single-GPU run over all reads (integer
-     work: bit-exact);
+     work: bit-exact).  Above two ranks every class is first reduced at the rank that owns its hash
+     (one all-to-all), so the all-gather carries each merged class once;
   3. EM over the merged classes, in one of two modes:
        "sharded"   : classes are cut into N contiguous, nnz-balanced slices; each iteration is
                      local sweep -> SUM all-reduce of alphaOut (M doubles, RCCL) -> update.  This is
@@ -91,7 +92,7 @@ def nnz_balanced_slices(rowptr_cpu, world):
 
 class DistributedQuant:
     def __init__(self, exp: ReadExperiment, sopt: SailfishOpts, group=None, em_mode="auto", engine=None,
-                 tol=0.01, max_iter=10000, poll_every=16):
+                 tol=0.01, max_iter=10000, poll_every=16, merge_mode="auto"):
         self.exp, self.sopt, self.group = exp, sopt, group
         self.world = 1
         self.rank = 0
@@ -103,6 +104,10 @@ class DistributedQuant:
         self.tol, self.max_iter, self.poll_every = tol, max_iter, poll_every
         self.local = self.engine.new_builder()
         self.merged = self.engine.new_builder() if self.world > 1 else None
+        # "owner": classes are first reduced at the rank that owns their hash (one all-to-all), then the disjoint
+        # partitions are all-gathered; "allgather": every rank receives and folds every rank's whole table
+        self.merge_mode = merge_mode if merge_mode != "auto" else ("owner" if self.world > 2 else "allgather")
+        self.part = self.engine.new_builder() if (self.world > 1 and self.merge_mode == "owner") else None
         self.problem = None
 
     # ---- one pass of the hot path ------------------------------------------------------------
@@ -137,6 +142,84 @@ class DistributedQuant:
 
     # ---- class-table exchange ----------------------------------------------------------------
     def _merge(self, vec):
+        if self.merge_mode == "owner":
+            vec = self._reduce_at_owner(vec)
+        return self._merge_allgather(vec)
+
+    def _reduce_at_owner(self, vec):
+        """Pre-reduction for N > 2 (owner(class) = hash mod G, one all-to-all of (label, count) partials):
+        every class goes to the rank that owns its XXH64, which adds up the counts of the ranks' copies.  The result
+        is this rank's partition of the merged table -- disjoint from the others' -- so the all-gather that follows
+        moves and folds every merged class once instead of every rank's copy of it (N x less merge work, ~N/2 x
+        less traffic).  Integer work: the merged table is bit-identical to the all-gather-only merge."""
+        import torch.distributed as dist
+        w, me = self.world, self.rank
+        dev = vec.ids.device
+        rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
+        lens = rp[1:] - rp[:-1]
+        C = int(lens.numel())
+        owner = ((vec.hashes.to(torch.int64) >> 33) & 0x3FFFFFFF) % w       # any function of the label every rank agrees on
+        order = torch.argsort(owner, stable=True)
+        per_owner_c = torch.bincount(owner, minlength=w)
+        lens_s = lens[order]
+        off_s = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens_s, 0, out=off_s[1:])
+        L = int(off_s[-1].item()) if C else 0
+        # ids in owner order: entry j of the new list comes from  rp[order[c]] + (j - off_s[c])
+        shift = torch.repeat_interleave(rp[:-1][order] - off_s[:-1], lens_s)
+        ids_s = vec.ids[(torch.arange(L, device=dev) + shift)] if L else vec.ids[:0]
+        cnt_s = vec.counts.to(torch.int64)[order]
+        cb = torch.zeros(w + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(per_owner_c, 0, out=cb[1:])
+        lb = off_s[cb]                                                      # id offsets at the owner boundaries
+        mine = torch.stack([per_owner_c, lb[1:] - lb[:-1]], 1).reshape(-1)   # [c_0, l_0, c_1, l_1, ...]
+        sizes = [torch.zeros_like(mine) for _ in range(w)]
+        dist.all_gather(sizes, mine, group=self.group)
+        S = torch.stack(sizes).cpu().reshape(w, w, 2).tolist()               # S[src][dst] = (classes, ids); one host sync
+        cb_h, lb_h = cb.cpu().tolist(), lb.cpu().tolist()
+        blk = lambda c, l: (12 * c + 4 * l + 7) & ~7                        # blocks are padded to 8 bytes (int64 views)
+        send_bytes = [blk(*S[me][d]) for d in range(w)]
+        recv_bytes = [blk(*S[src][me]) for src in range(w)]
+        pad4 = torch.zeros(4, dtype=torch.uint8, device=dev)
+        parts = []
+        for d in range(w):                                                  # block for rank d: [counts i64 | lens i32 | ids i32 | pad]
+            c0, c1, l0, l1 = cb_h[d], cb_h[d + 1], lb_h[d], lb_h[d + 1]
+            parts += [cnt_s[c0:c1].contiguous().view(torch.uint8), lens_s[c0:c1].to(torch.int32).contiguous().view(torch.uint8),
+                      ids_s[l0:l1].contiguous().view(torch.uint8)]
+            if (12 * (c1 - c0) + 4 * (l1 - l0)) % 8:
+                parts.append(pad4)
+        send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+        recv = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=dev)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all_single(recv, send, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
+        else:
+            # gloo (CPU tests, single-device dry runs) has no all-to-all: every rank's whole send buffer is gathered
+            # and the block meant for this rank is cut out -- same result, more traffic
+            full = _all_gather_var(send, self.group, w)
+            pos = 0
+            for src in range(w):
+                start = sum(blk(*S[src][d]) for d in range(me))
+                recv[pos:pos + recv_bytes[src]] = full[src][start:start + recv_bytes[src]]
+                pos += recv_bytes[src]
+        cnts, lns, idl, pos = [], [], [], 0
+        for src in range(w):
+            c, l = S[src][me]
+            cnts.append(recv[pos:pos + 8 * c].view(torch.int64))
+            lns.append(recv[pos + 8 * c:pos + 12 * c].view(torch.int32))
+            idl.append(recv[pos + 12 * c:pos + 12 * c + 4 * l].view(torch.int32))
+            pos += recv_bytes[src]
+        b = self.part
+        b.start()
+        ln = torch.cat(lns).to(torch.int64)
+        off = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(ln, 0, out=off[1:])
+        if int(off[-1].item()) >= 2 ** 31:
+            raise RuntimeError("a rank's partition holds >= 2^31 ids: use merge_mode='allgather'")
+        b.insertGroups(torch.cat(idl), off.to(torch.int32), torch.cat(cnts))
+        b.finish()
+        return b.eqVec()
+
+    def _merge_allgather(self, vec):
         """One exchange: every rank contributes its class table as one byte block
         [counts i64[C] | lens i32[C] | ids i32[L]] (sizes first, then the padded blocks), and upserts the
         tables of all ranks, in rank order, as ONE weighted batch -> the same table on every rank."""

@@ -57,6 +57,7 @@ class _Builder:
         ids = np.array([t for l in labs for t in l], np.uint32)
         cnt = np.array([self.d[l] for l in labs], np.int64)
         self._vec = _Vec(rowptr, ids, cnt, cnt.sum())
+        self._vec.hashes = torch.from_numpy(np.array([O.xxh64(np.array(l, np.uint32).tobytes()) for l in labs], np.uint64).view(np.int64).copy())
         return True
 
     def eqVec(self):
@@ -212,7 +213,7 @@ class CheckerEngine:
         pass
 
 
-def _worker(rank, world, port, mode, vb, out):
+def _worker(rank, world, port, mode, vb, out, merge_mode="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -224,7 +225,8 @@ def _worker(rank, world, port, mode, vb, out):
         ids, off = synth.reads_from_pool(poff, pids, R, seed=7 + 1000 * rank)       # this rank's shard
         sopt = sf.SailfishOpts(useVBOpt=vb)
         exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.numpy().view(np.uint32), device="cpu"), sopt)
-        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, engine=CheckerEngine(), poll_every=7)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, engine=CheckerEngine(), poll_every=7,
+                                 merge_mode=merge_mode)
         info = q.run(ids, off)
         t = exp.transcripts()
         out.put((rank, info["em_mode"], info["n_classes"], info["nnz"], exp.numMappedFragments(), info["em_stats"]["iters"],
@@ -237,12 +239,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("mode,vb", [("replicated", False), ("sharded", False), ("sharded", True)])
-def test_two_rank_quant_matches_single_process(built, mode, vb):
+@pytest.mark.parametrize("mode,vb,merge,world", [("replicated", False, "auto", 2), ("sharded", False, "auto", 2), ("sharded", True, "auto", 2),
+                                                 ("replicated", False, "owner", 2), ("sharded", False, "auto", 3)])
+def test_two_rank_quant_matches_single_process(built, mode, vb, merge, world):
+    """world 2 merges by all-gather; merge="owner" / world 3 reduce every class at the rank that owns its hash first"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, vb, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, vb, out, merge)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([out.get(timeout=240) for _ in procs], key=lambda r: r[0])
@@ -261,7 +265,7 @@ def test_two_rank_quant_matches_single_process(built, mode, vb):
     rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, b.total_reads, use_vbem=vb)
     ot = O.tpm(oa, eff, b.total_reads)
     for r in res:
-        assert r[1] == mode and r[2] == b.n_classes and r[3] == b.nnz and r[4] == b.total_reads == 12000
+        assert r[1] == mode and r[2] == b.n_classes and r[3] == b.nnz and r[4] == b.total_reads == 6000 * world
         assert r[5] == ost["iters"]
         nz = oa > 0
         assert np.array_equal(r[6] > 0, nz)

@@ -17,7 +17,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, mode, vb, out):
+def _worker(rank, world, port, mode, vb, out, merge_mode="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -31,7 +31,7 @@ def _worker(rank, world, port, mode, vb, out):
         ids, off = synth.reads_from_pool(poff, pids, R, seed=7 + 1000 * rank)
         sopt = sf.SailfishOpts(useVBOpt=vb)
         exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.numpy().view(np.uint32), device=dev), sopt)
-        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, poll_every=9)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, poll_every=9, merge_mode=merge_mode)
         info = q.run(ids.to(dev), off.to(dev))
         t = exp.transcripts()
         if mode == "replicated":                       # posterior draws are split over the ranks
@@ -51,12 +51,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("mode,vb", [("replicated", False), ("sharded", False), ("sharded", True)])
-def test_two_ranks_on_one_gpu_match_the_oracle(gpu, mode, vb):
+@pytest.mark.parametrize("mode,vb,merge,world", [("replicated", False, "auto", 2), ("sharded", False, "auto", 2), ("sharded", True, "auto", 2),
+                                                 ("sharded", False, "owner", 3)])
+def test_two_ranks_on_one_gpu_match_the_oracle(gpu, mode, vb, merge, world):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, vb, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, vb, out, merge)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([out.get(timeout=300) for _ in procs], key=lambda r: r[0])
@@ -74,7 +75,7 @@ def test_two_ranks_on_one_gpu_match_the_oracle(gpu, mode, vb):
     rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, b.total_reads, use_vbem=vb)
     ot = O.tpm(oa, eff, b.total_reads)
     for r in res:
-        assert r[1] == mode and r[2] == b.n_classes and r[3] == b.nnz and r[4] == b.total_reads == 300_000
+        assert r[1] == mode and r[2] == b.n_classes and r[3] == b.nnz and r[4] == b.total_reads == 150_000 * world
         assert r[5] == ost["iters"]
         nz = oa > 0
         assert np.array_equal(r[6] > 0, nz)
@@ -146,3 +147,31 @@ def test_two_ranks_on_one_gpu_with_the_bias_hook(gpu, mode, which):
         np.testing.assert_allclose(r[5], oes, rtol=1e-6); np.testing.assert_allclose(r[6], oeg, rtol=1e-6)
     if mode == "sharded":
         assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])     # broadcast lengths: ranks bit-identical
+
+
+def _a2a_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        send = torch.arange(0, 4096, dtype=torch.int64, device=dev).view(torch.uint8)[: 4096 * 8 - 8]
+        recv = torch.empty_like(send)
+        n = int(send.numel())
+        dist.all_to_all_single(recv, send, output_split_sizes=[n], input_split_sizes=[n])
+        torch.cuda.synchronize()
+        out.put(bool(torch.equal(recv, send)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_to_all_single_takes_byte_blocks(gpu):
+    """the exchange primitive of the owner-partitioned merge (all_to_all_single of uint8 blocks with explicit split
+    sizes) on the RCCL backend -- one rank is all this box can offer, which still covers the call and its dtypes"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_a2a_worker, args=(_free_port(), out))
+    p.start()
+    assert out.get(timeout=240) is True
+    p.join(60)
+    assert p.exitcode == 0
