@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's quoted size (config 2: 50M single-end reads, 80k transcripts):
+"""GPU tests at BASELINE.json's quoted sizes (config 2: 50M single-end reads, 80k transcripts; config 3: 400M fragments, 200k):
 the oracle cannot finish this in seconds, so parity is asserted through size-independent
 properties of the domain."""
 import numpy as np
@@ -56,6 +56,63 @@ def test_cfg2_properties(gpu):
     assert st["converged"] and 50 <= st["iters"] < 10000 and st["max_rel_diff"] <= 0.01
     a = exp.transcripts().estCount
     assert abs(float(a.sum()) - R) / R < 1e-9
+    assert float(a.min()) >= 0 and float(exp.transcripts().mass.sum()) == pytest.approx(1.0, abs=1e-9)
+    t, _ = sf.writer.tpm(exp, sopt)
+    assert float(t.sum()) == pytest.approx(1e6, rel=1e-9)
+    a1 = a.clone(); it1 = st["iters"]
+    assert opt.optimize(exp, sopt, 0.01, 10000) and opt.last_stats["iters"] == it1
+    rel = ((exp.transcripts().estCount - a1).abs() / a1.clamp_min(1e-300))[a1 > 0].max()
+    assert float(rel) < 1e-9
+
+
+def test_cfg3_properties(gpu):
+    """BASELINE config 3 -- the configuration the metric is quoted on and bench.py's default: 400 M paired-end fragments,
+    200 k transcripts, VBEM, empirical fragment-length correction"""
+    import torch
+    import sailfish_amd as sf
+    from sailfish_amd import synth
+    M, P, R = 200_000, 4_000_000, 400_000_000
+    ref_len = synth.transcript_lengths(M, device=gpu)
+    poff, pids = synth.label_pool(M, P, device=gpu)
+    ids, off = synth.reads_from_pool(poff, pids, R, device=gpu)
+    del poff, pids
+    torch.cuda.synchronize()
+    sopt = sf.SailfishOpts(useVBOpt=True)
+    exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.cpu().numpy().view(np.uint32), device=gpu), sopt)
+    eq = exp.equivalenceClassBuilder()
+    eq.start(); eq.add_batch(ids, off); eq.finish()
+    v = eq.eqVec()
+    assert eq.total_reads == R and int(v.counts.sum()) == R and 0 < eq.n_classes <= P
+    first = v.ids[v.rowptr[:-1].long()].long()
+    assert bool((first[1:] >= first[:-1]).all())
+    assert bool((sf.xxh64_labels(v.ids, v.rowptr, device=gpu) == v.hashes).all())
+    # linearity: a quarter of the reads four times gives a quarter's classes with four times the counts
+    q = R // 4
+    cut = int(off[q].item()) & 0xFFFFFFFF
+    eq2 = sf.EquivalenceClassBuilder(device=gpu)
+    eq2.start(); eq2.add_batch(ids[:cut], off[:q + 1]); eq2.finish()
+    v1 = eq2.eqVec(); ids1, cnt1 = v1.ids.clone(), v1.counts.clone()
+    eq2.start()
+    for _ in range(4):
+        eq2.add_batch(ids[:cut], off[:q + 1])
+    eq2.finish()
+    v4 = eq2.eqVec()
+    assert torch.equal(v4.ids, ids1) and torch.equal(v4.counts, 4 * cnt1)
+    eq2.close(); del eq2, v1, v4, ids1, cnt1
+    # VBEM with the empirical fragment-length table (the paired-end branch with enough observations)
+    i = np.arange(1000.0)
+    fl = np.floor(np.exp(-0.5 * ((i - 200.0) / 80.0) ** 2) * 4000 + 0.5).astype(np.uint32)
+    exp.setNumMappedFragments(eq.total_reads)
+    sf.efflen.set_effective_lengths(exp, sopt, fl_counts=fl, remaining_fl_ops=0)
+    eff = exp.transcripts().EffectiveLength
+    assert float(eff.min()) >= 1.0 and bool((eff <= exp.transcripts().ref_length_f64() + 1e-9).all())
+    opt = sf.CollapsedEMOptimizer()
+    assert opt.optimize(exp, sopt, 0.01, 10000)
+    st = opt.last_stats
+    assert st["converged"] and 50 <= st["iters"] < 10000 and st["max_rel_diff"] <= 0.01
+    a = exp.transcripts().estCount
+    # the prior adds at most 0.01 per transcript and truncation removes at most 0.01 + 1e-8 per transcript
+    assert abs(float(a.sum()) - R) <= 0.011 * M + 1e-6 * R
     assert float(a.min()) >= 0 and float(exp.transcripts().mass.sum()) == pytest.approx(1.0, abs=1e-9)
     t, _ = sf.writer.tpm(exp, sopt)
     assert float(t.sum()) == pytest.approx(1e6, rel=1e-9)
