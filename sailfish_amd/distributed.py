@@ -190,9 +190,14 @@ class DistributedQuant:
                 parts.append(pad4)
         send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
         recv = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=dev)
+        done = False
         if dist.get_backend(self.group) == "nccl":
-            dist.all_to_all_single(recv, send, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
-        else:
+            try:
+                dist.all_to_all_single(recv, send, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
+                done = True
+            except RuntimeError:          # an argument the backend rejects fails on every rank alike: take the portable route
+                done = False
+        if not done:
             # gloo (CPU tests, single-device dry runs) has no all-to-all: every rank's whole send buffer is gathered
             # and the block meant for this rank is cut out -- same result, more traffic
             full = _all_gather_var(send, self.group, w)
