@@ -129,6 +129,7 @@ class DistributedQuant:
             eng.sync(); t2 = time.perf_counter()
             info["t_merge_ms"] = (t2 - t1) * 1e3
             t1 = t2
+        self.last_vec = vec                               # the (merged) class table the EM ran on
         exp.setNumMappedFragments(vec.total_reads)        # every read with a non-empty hit list is mapped
         eng.set_effective_lengths(exp, sopt, fl_counts, remaining_fl_ops)
         eng.sync(); t2 = time.perf_counter()
@@ -143,8 +144,61 @@ class DistributedQuant:
     # ---- class-table exchange ----------------------------------------------------------------
     def _merge(self, vec):
         if self.merge_mode == "owner":
-            vec = self._reduce_at_owner(vec)
+            part = self._reduce_at_owner(vec)
+            merged = self._concat_disjoint(part)
+            return merged if merged is not None else self._merge_allgather(part)
         return self._merge_allgather(vec)
+
+    def _concat_disjoint(self, vec):
+        """All-gather of the ranks' DISJOINT partitions and assembly of the merged table without hashing anything
+        again: the union of disjoint class sets only has to be put into the canonical order (first id, XXH64,
+        length, label), a sort of (first id, hash) keys.  Two different labels with the same first id and the same
+        64-bit hash would need the last two keys: then None is returned and the caller folds the partitions
+        through a builder instead."""
+        import torch.distributed as dist
+        from .eqclass import EqVec
+        w = self.world
+        dev = vec.ids.device
+        rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
+        lens = (rp[1:] - rp[:-1]).to(torch.int32)
+        C, L = int(lens.numel()), int(vec.ids.numel())
+        mine = torch.tensor([C, L], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(mine) for _ in range(w)]
+        dist.all_gather(sizes, mine, group=self.group)
+        sizes = torch.stack(sizes).cpu().tolist()
+        nbytes = [20 * c + 4 * l for c, l in sizes]                   # [counts i64 | hashes i64 | lens i32 | ids i32]
+        block = torch.zeros(max(max(nbytes), 8), dtype=torch.uint8, device=dev)
+        block[:8 * C] = vec.counts.to(torch.int64).contiguous().view(torch.uint8)
+        block[8 * C:16 * C] = vec.hashes.to(torch.int64).contiguous().view(torch.uint8)
+        block[16 * C:20 * C] = lens.contiguous().view(torch.uint8)
+        block[20 * C:20 * C + 4 * L] = vec.ids.contiguous().view(torch.uint8)
+        blocks = [torch.empty_like(block) for _ in range(w)]
+        dist.all_gather(blocks, block, group=self.group)
+        cnt = torch.cat([b[:8 * c].view(torch.int64) for b, (c, l) in zip(blocks, sizes)])
+        hsh = torch.cat([b[8 * c:16 * c].view(torch.int64) for b, (c, l) in zip(blocks, sizes)])
+        ln = torch.cat([b[16 * c:20 * c].view(torch.int32) for b, (c, l) in zip(blocks, sizes)]).to(torch.int64)
+        ids = torch.cat([b[20 * c:20 * c + 4 * l].view(torch.int32) for b, (c, l) in zip(blocks, sizes)])
+        n = int(cnt.numel())
+        if int(ids.numel()) >= 2 ** 32:
+            return None
+        src = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(ln, 0, out=src[1:])
+        if n == 0:
+            return EqVec(torch.zeros(1, dtype=torch.int32, device=dev), ids, cnt, hsh, 0)
+        first = ids[src[:-1]].to(torch.int64) & 0xFFFFFFFF            # every class has at least one id
+        o1 = torch.argsort(hsh ^ (-0x8000000000000000), stable=True)  # unsigned order of the hashes
+        order = o1[torch.argsort(first[o1], stable=True)]
+        f_o, h_o = first[order], hsh[order]
+        if n > 1 and bool(((f_o[1:] == f_o[:-1]) & (h_o[1:] == h_o[:-1])).any()):
+            return None
+        ln_o = ln[order]
+        dst = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(ln_o, 0, out=dst[1:])
+        Ltot = int(dst[-1].item())
+        shift = torch.repeat_interleave(src[:-1][order] - dst[:-1], ln_o)
+        ids_o = ids[torch.arange(Ltot, device=dev) + shift]
+        cnt_o = cnt[order]
+        return EqVec(dst.to(torch.int32), ids_o, cnt_o, h_o, int(cnt_o.sum().item()))
 
     def _reduce_at_owner(self, vec):
         """Pre-reduction for N > 2 (owner(class) = hash mod G, one all-to-all of (label, count) partials):

@@ -229,8 +229,10 @@ def _worker(rank, world, port, mode, vb, out, merge_mode="auto"):
                                  merge_mode=merge_mode)
         info = q.run(ids, off)
         t = exp.transcripts()
+        v = q.last_vec
         out.put((rank, info["em_mode"], info["n_classes"], info["nnz"], exp.numMappedFragments(), info["em_stats"]["iters"],
-                 t.estCount.numpy().copy(), info["tpm"].numpy().copy(), ids.numpy().copy(), off.numpy().copy()))
+                 t.estCount.numpy().copy(), info["tpm"].numpy().copy(), ids.numpy().copy(), off.numpy().copy(),
+                 v.rowptr.numpy().view(np.uint32).copy(), v.ids.numpy().view(np.uint32).copy(), v.counts.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -271,6 +273,8 @@ def test_two_rank_quant_matches_single_process(built, mode, vb, merge, world):
         assert np.array_equal(r[6] > 0, nz)
         assert np.max(np.abs(r[6][nz] - oa[nz]) / oa[nz]) < 1e-9
         assert np.max(np.abs(r[7][nz] - ot[nz]) / ot[nz]) < 1e-9
+        # the merged table is the single-process table, class for class, in the canonical order
+        assert np.array_equal(r[10], rp.astype(np.uint32)) and np.array_equal(r[11], ii) and np.array_equal(r[12].astype(np.uint64), cc)
     assert np.array_equal(res[0][6], res[1][6])      # both ranks hold the same answer
 
 
