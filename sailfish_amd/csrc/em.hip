@@ -810,6 +810,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             uint64_t want = (rounds <= 1) ? ((uint64_t)rp_end + slots - 1) / slots : (uint64_t)kTileNnz;
             if (want < 2048) want = 2048;
             if (want > (uint64_t)kTileNnz) want = kTileNnz;
+            if (const char* e = getenv("SFGPU_EM_TILE")) { long v = atol(e); if (v >= 2048 && v <= kTileNnz) want = (uint64_t)v; }   // tuning
             tile_nnz = (uint32_t)want;
         }
         em->n_tiles = (uint32_t)(((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
