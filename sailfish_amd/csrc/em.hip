@@ -18,6 +18,7 @@
 //   * all reductions that feed decisions (n_active, sum alpha, alphaSum) are two-stage and
 //     order-deterministic; the only nondeterministic order is the f64 atomic accumulation into
 //     alphaOut, as in the reference's CAS loop (:70-79).
+#include <algorithm>
 #include "bias.h"
 #include "common.h"
 #include "primitives.h"
@@ -216,6 +217,7 @@ __global__ void k_vb_prepare(uint64_t M, const double* __restrict__ alpha, doubl
 #ifndef SFGPU_TILE_NNZ
 #define SFGPU_TILE_NNZ 8000
 #endif
+constexpr int kTileNnzMax = 1 << 17;         // nonzeros a tile may hold when its class count allows (see the plan in sfgpu_em_create)
 constexpr int kTileNnz = SFGPU_TILE_NNZ;     // largest CSR bucket that defines a tile (<= 8191 classes per tile);
                                              // the bucket actually used is sized per problem so that the tiles fill
                                              // the chip in whole rounds (tile_nnz_for)
@@ -798,38 +800,60 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     }
     em->L = rp_end;
     if (C) {   // nnz-balanced tile plan of the sweep, its label stream, and the cover lists of the fold
-        // two 1024-thread blocks are resident per CU (LDS), so aim at whole rounds of 2 x #CU tiles
-        uint32_t tile_nnz = kTileNnz;
-        {
-            int dev = 0, n_cu = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-            const uint64_t slots = 2ull * (uint64_t)(n_cu > 0 ? n_cu : 256);
-            const uint64_t rounds = ((uint64_t)rp_end + slots * kTileNnz - 1) / (slots * kTileNnz);
-            // balancing pays when everything fits one round; with several rounds the per-block fixed cost of
-            // smaller tiles outweighs the tail (measured on the 9.2 M-nonzero problem)
-            uint64_t want = (rounds <= 1) ? ((uint64_t)rp_end + slots - 1) / slots : (uint64_t)kTileNnz;
+        // Two 1024-thread blocks are resident per CU (LDS), so the tiles come in rounds of 2 x #CU, and a round costs
+        // about the same whether its tiles hold 5 000 or 18 000 nonzeros (it is latency, not volume: cfg3's 9.3 M
+        // nonzeros take 26.1 us as 2.3 rounds of 8 000 and 21.9 us as one round of 18 300).  So: as few rounds as
+        // possible, tiles of equal size.  What bounds a tile is its number of CLASSES (the 13-bit class field of the
+        // stream words, the size of den[]), not its nonzeros: the plan is checked and, if a tile holds more than
+        // kTileNnz classes, redone with one more round -- down to kTileNnz nonzeros per tile, which cannot fail.
+        int n_cu = 256;
+        { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+        const uint64_t slots = 2ull * (uint64_t)(n_cu > 0 ? n_cu : 256);
+        auto tile_for = [&](uint64_t rounds) -> uint32_t {
+            uint64_t want = ((uint64_t)rp_end + slots * rounds - 1) / (slots * rounds);
             if (want < 2048) want = 2048;
-            if (want > (uint64_t)kTileNnz) want = kTileNnz;
-            if (const char* e = getenv("SFGPU_EM_TILE")) { long v = atol(e); if (v >= 2048 && v <= kTileNnz) want = (uint64_t)v; }   // tuning
-            tile_nnz = (uint32_t)want;
-        }
-        em->n_tiles = (uint32_t)(((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
-        if (em->n_tiles == 0) em->n_tiles = 1;
-        const uint32_t nt = em->n_tiles;
+            if (want > (uint64_t)kTileNnzMax) want = kTileNnzMax;
+            return (uint32_t)want;
+        };
+        // first guess: rounds such that a tile holds at most kTileNnzMax nonzeros and about 3/4 kTileNnz classes
+        uint64_t rounds = std::max<uint64_t>(1, ((uint64_t)rp_end + slots * kTileNnzMax - 1) / (slots * kTileNnzMax));
+        rounds = std::max<uint64_t>(rounds, (C + slots * (kTileNnz * 3 / 4) - 1) / (slots * (kTileNnz * 3 / 4)));
+        uint32_t tile_nnz = tile_for(rounds);
+        if (const char* e = getenv("SFGPU_EM_TILE")) { long v = atol(e); if (v >= 2048 && v <= kTileNnzMax) tile_nnz = (uint32_t)v; }   // tuning
+        em->n_tiles = (uint32_t)std::max<uint64_t>(1, ((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
+        const uint32_t nt_small = (uint32_t)std::max<uint64_t>(1, ((uint64_t)rp_end + kTileNnz - 1) / kTileNnz);
+        const uint32_t nt_cap = std::max(em->n_tiles, nt_small);
+        uint32_t nt = em->n_tiles;
         uint32_t *t_len8 = nullptr, *t_nesc = nullptr;
         pool_free(em->tile_lo); em->tile_lo = nullptr;
-        EM_TRY(pool_malloc(&em->tile_lo, (size_t)nt * 4));
-        EM_TRY(pool_malloc(&em->tile_span, ((size_t)nt + 1) * 4));
-        EM_TRY(pool_malloc(&em->tile_c0, ((size_t)nt + 1) * 4));
-        EM_TRY(pool_malloc(&em->tile_off, ((size_t)nt + 1) * 8));
-        EM_TRY(pool_malloc(&em->tile_s0, ((size_t)nt + 1) * 8));
-        EM_TRY(pool_malloc(&em->tile_esc0, ((size_t)nt + 1) * 8));
-        EM_TRY(pool_malloc(&t_len8, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt + 1) * 4));
+        EM_TRY(pool_malloc(&em->tile_lo, (size_t)nt_cap * 4));
+        EM_TRY(pool_malloc(&em->tile_span, ((size_t)nt_cap + 1) * 4));
+        EM_TRY(pool_malloc(&em->tile_c0, ((size_t)nt_cap + 1) * 4));
+        EM_TRY(pool_malloc(&em->tile_off, ((size_t)nt_cap + 1) * 8));
+        EM_TRY(pool_malloc(&em->tile_s0, ((size_t)nt_cap + 1) * 8));
+        EM_TRY(pool_malloc(&em->tile_esc0, ((size_t)nt_cap + 1) * 8));
+        EM_TRY(pool_malloc(&t_len8, ((size_t)nt_cap + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt_cap + 1) * 4));
         EM_TRY(pool_malloc(&em->cov_ptr, ((size_t)M + 1) * 4));
-        EM_TRY(pool_malloc(&em->tsum, (size_t)nt * 8));
-        EM_TRY(hipMemsetAsync(em->tsum, 0, (size_t)nt * 8, em->cur));      // empty tiles never write theirs
+        EM_TRY(pool_malloc(&em->tsum, (size_t)nt_cap * 8));
+        EM_TRY(hipMemsetAsync(em->tsum, 0, (size_t)nt_cap * 8, em->cur));      // empty tiles never write theirs
         hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
                            prob->d_rowptr, em->tile_c0);
+        while (tile_nnz > (uint32_t)kTileNnz) {
+            std::vector<uint32_t> c0(nt + 1);
+            EM_TRY(hipMemcpyAsync(c0.data(), em->tile_c0, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipStreamSynchronize(em->cur));
+            uint32_t most = 0;
+            for (uint32_t i = 0; i < nt; ++i) most = std::max(most, c0[i + 1] - c0[i]);
+            if (most <= (uint32_t)kTileNnz) break;
+            ++rounds;
+            tile_nnz = tile_for(rounds);
+            if (tile_nnz < (uint32_t)kTileNnz) tile_nnz = kTileNnz;
+            nt = (uint32_t)std::max<uint64_t>(1, ((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
+            if (nt > nt_cap) { nt = nt_small; tile_nnz = kTileNnz; }
+            em->n_tiles = nt;
+            hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
+                               prob->d_rowptr, em->tile_c0);
+        }
         hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
                            em->tile_lo, em->tile_span, t_len8, t_nesc);
         EM_TRY(hipGetLastError());
