@@ -125,10 +125,10 @@ class EquivalenceClassBuilder:
         if self._vec is None:
             n, nnz = self.n_classes, self.nnz
             dev = self.device
-            rowptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-            ids = torch.zeros(nnz, dtype=torch.int32, device=dev)
-            counts = torch.zeros(n, dtype=torch.int64, device=dev)
-            hashes = torch.zeros(n, dtype=torch.int64, device=dev)
+            rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)      # every element is written by the export
+            ids = torch.empty(nnz, dtype=torch.int32, device=dev)
+            counts = torch.empty(n, dtype=torch.int64, device=dev)
+            hashes = torch.empty(n, dtype=torch.int64, device=dev)
             torch.cuda.current_stream().synchronize()
             _lib.check(self._L.sfgpu_eq_export_device(self._h, _lib.ptr(rowptr), _lib.ptr(ids), _lib.ptr(counts),
                                                       _lib.ptr(hashes)))
