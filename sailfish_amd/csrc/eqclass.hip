@@ -22,7 +22,7 @@
 //     written by an earlier launch or by the committing block);
 //   * committed labels live in the arena as 16-byte-aligned entries [len, ids..., 0 pad]: one 16-byte
 //     load decides a compare for labels of <= 3 ids;
-//   * the table is sized from the number of classes actually seen (load <= 1/4 partitioned, <= 1/2
+//   * the table is sized from the number of classes actually seen (load <= 1/2 partitioned, <= 1/2
 //     generic); inserts that would exceed the budget are deferred, the table is doubled, and the
 //     deferred reads are replayed;
 //   * finish() orders classes canonically (first id, XXH64, length, label) with a radix sort.
@@ -479,12 +479,14 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
                           uint64_t n_words) {
     hipStream_t st = eq->stream;
     int rc;
-    // regions stay sparse (load <= 1/4) so that a region overflowing its LDS image is a non-event.  At the
-    // largest table these kernels handle (kMaxRegions regions = 16 M slots) the load may reach 1/2 (8 M
-    // classes) before the table doubles again and the generic kernel takes over.
-    const uint64_t max_part_cap = (uint64_t)kMaxRegions << kRegionBits;
-    while (eq->n_classes + kMinHeadroom > eq->cap / 4) {
-        if (eq->cap >= max_part_cap && eq->n_classes + kMinHeadroom <= eq->cap / 2) break;
+    // The table doubles when the classes seen so far would fill more than half of it (SFGPU_EQ_LOAD_DIV: 1/div).  A
+    // region's LDS image overflows at 3/4 (kRegionLimit) -- 22 standard deviations above a half-full region of 4096
+    // slots -- and an overflowing region only defers its reads to the generic kernel.  Half rather than a quarter
+    // halves the number of regions: pass 2 is one block per region, two blocks per CU, and fewer, longer-lived
+    // blocks amortise the region load / write-back and the per-block ramp (cfg3, 1.6 M classes: 2048 -> 1024
+    // regions, class build 22.8 -> 21.5 ms; cfg2 unchanged).
+    static const uint64_t load_div = []() { const char* e = getenv("SFGPU_EQ_LOAD_DIV"); long v = e ? atol(e) : 2; return (uint64_t)(v >= 2 && v <= 8 ? v : 2); }();
+    while (eq->n_classes + kMinHeadroom > eq->cap / load_div) {
         if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
     }
     if ((eq->cap >> kRegionBits) > (uint64_t)kMaxRegions) {     // grew past what the partition passes handle
