@@ -120,7 +120,33 @@ int main(void) {
         printf("bias model %d: iters %u hooks %u effLen %.3f %.3f %.3f %.3f\n", model, st.iters, hooks, beff[0], beff[1], beff[2], beff[3]);
         CHECK(sfgpu_bias_destroy(bias));
     }
-    int extras_ok = bias_ok && n_boot_cb == 3 && n_gibbs_cb == 4 && eff[0] > 790.0 && eff[0] < 810.0 && eff_emp[1] > 1700.0 && eff_emp[1] < 1800.0 &&
+    /* the samples the hit loop collects for the bias models, and the piecewise form of the recompute hook */
+    uint32_t *d_gcp, *d_rb, *d_og;
+    HIPCHECK(hipMalloc((void**)&d_gcp, sizeof seq * 4)); HIPCHECK(hipMalloc((void**)&d_rb, 4096 * 4)); HIPCHECK(hipMalloc((void**)&d_og, 101 * 4));
+    HIPCHECK(hipMemset(d_rb, 0, 4096 * 4)); HIPCHECK(hipMemset(d_og, 0, 101 * 4));
+    CHECK(sfgpu_gc_prefix(d_seq, d_soff, d_ref, 4, d_gcp, NULL));
+    sfgpu_hit srec[2] = {{0, 10, 160, 200, 50, 50, 1, 0, 3, 0}, {1, 300, 450, 200, 50, 50, 0, 1, 3, 0}};   /* two proper pairs */
+    uint32_t sroff[3] = {0, 1, 2};
+    HIPCHECK(hipMemcpy(d_recs, srec, sizeof srec, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(d_roff, sroff, 12, hipMemcpyHostToDevice));
+    int64_t bias_budget = 5;
+    sfgpu_bias_sampler smp; memset(&smp, 0, sizeof smp);
+    smp.d_seq = d_seq; smp.d_seq_off = d_soff; smp.d_ref_len = d_ref; smp.d_read_bias = d_rb; smp.remaining_bias_samples = &bias_budget;
+    smp.d_observed_gc = d_og; smp.d_gc_prefix = d_gcp; smp.gc_size_samp = 1;
+    CHECK(sfgpu_sample_bias(d_recs, d_roff, 2, &fo, &smp, NULL));
+    int sample_ok = smp.n_bias_sampled == 2 && smp.n_gc_sampled == 2 && bias_budget == 3;
+    CHECK(sfgpu_em_begin(em, &o)); CHECK(sfgpu_em_init(em));
+    CHECK(sfgpu_em_set_bounds(em, 3, 3));
+    for (int i = 0; i < 4; ++i) { CHECK(sfgpu_em_sweep(em)); CHECK(sfgpu_em_update(em)); }   /* the fourth pair is a no-op: stopped at 3 */
+    int em_done = 0; CHECK(sfgpu_em_poll(em, &em_done, &st));
+    CHECK(sfgpu_em_rebase(em, sfgpu_em_lengths(em)));                     /* same lengths: x is rebuilt from alpha */
+    CHECK(sfgpu_em_set_bounds(em, 5, 5));
+    for (int i = 0; i < 2; ++i) { CHECK(sfgpu_em_sweep(em)); CHECK(sfgpu_em_update(em)); }
+    int em_done2 = 0; sfgpu_em_stats st2; CHECK(sfgpu_em_poll(em, &em_done2, &st2));
+    CHECK(sfgpu_em_finish(em, d_alpha, d_mass, &st2));
+    int piecewise_ok = em_done == 1 && st.iters == 3 && em_done2 == 1 && st2.iters == 5 && sfgpu_em_alpha(em) != NULL;
+    printf("samples %s (6-mers %llu, fragments %llu)  piecewise %s (iters %u then %u)\n", sample_ok ? "ok" : "FAILED",
+           (unsigned long long)smp.n_bias_sampled, (unsigned long long)smp.n_gc_sampled, piecewise_ok ? "ok" : "FAILED", st.iters, st2.iters);
+    int extras_ok = sample_ok && piecewise_ok && bias_ok && n_boot_cb == 3 && n_gibbs_cb == 4 && eff[0] > 790.0 && eff[0] < 810.0 && eff_emp[1] > 1700.0 && eff_emp[1] < 1800.0 &&
                     foff[0] == 0 && foff[1] == 1 && foff[2] == 2 && foff[3] == 2 && fids[0] == 3 && fids[1] == 4 &&
                     fs.n_observed == 3 && fs.n_mapped == 2 && fs.fl_sampled == 1 && budget == 9;
     printf("extras %s (boot %d gibbs %d eff %.3f emp %.3f mapped %llu)\n", extras_ok ? "ok" : "FAILED", n_boot_cb, n_gibbs_cb, eff[0], eff_emp[1],
