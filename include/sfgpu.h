@@ -75,7 +75,11 @@ SFGPU_API int sfgpu_eq_start(sfgpu_eq* eq);
  * label r = ids[offsets[r] .. offsets[r+1]); the ORDERED list is the key (equality ==
  * vector equality, src/TranscriptGroup.cpp:53-55); empty lists are skipped like the call
  * site's `if (txpIDs.size() > 0)` guard.  Thread-safe (calls are serialised per builder).
- * offsets are uint32: one batch holds < 2^32 ids and < 2^31 reads (else SFGPU_ERR_RANGE).
+ * offsets are uint32: one batch holds < 2^32 ids and < 2^31 reads (else SFGPU_ERR_RANGE); a larger
+ * experiment is handed over in several batches (counts are uint64 and accumulate across batches).
+ * The EXPORT has the same ceiling: rowptr is uint32, so the finished table must hold < 2^32 label
+ * ids in total (sum of class sizes; sfgpu_eq_export_* return SFGPU_ERR_RANGE beyond) -- ~460x the
+ * 9.3 M of the 400 M-read / 200 k-transcript configuration.
  * _device reads a device-resident batch and returns after it has been folded in.
  * _host takes the caller's (pageable or pinned) host arrays: small batches are copied into a pinned
  * accumulation buffer (thread-safe: only the reservation of the range is serialised) and built

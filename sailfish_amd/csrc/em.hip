@@ -137,6 +137,9 @@ __global__ void k_narrow_counts(uint64_t C, const uint64_t* __restrict__ c64, co
     if (c >= C) return;
     uint64_t v = c64[c];
     if (v >= 0x80000000ull) atomicOr(overflow, 1u);
+    // a class without members never comes out of the builder (addGroup is only called with hits); the tile plan
+    // bounds classes per tile through nonzeros, so an empty class in a caller-made CSR is refused, not planned
+    if (rowptr[c + 1] <= rowptr[c]) atomicOr(overflow, 2u);
     c32[c] = (uint32_t)v | ((rowptr[c + 1] - rowptr[c] == 1) ? 0x80000000u : 0u);
 }
 
@@ -794,6 +797,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipMemcpyAsync(&rp_end, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
+        if (h_ovf & 2u) { set_error("sfgpu_em_create: rowptr not strictly ascending (a class without members)"); em_free(em); return SFGPU_ERR_INVALID; }
         if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^31"); em_free(em); return SFGPU_ERR_RANGE; }
     } else {
         EM_TRY(hipStreamSynchronize(em->cur));

@@ -267,6 +267,17 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
             G_TRY(hipStreamSynchronize(st));
             K = gibbs_phase_count(lo, hi);
             if (K > kMaxPhases) K = n_tiles;             // no locality to exploit: one tile per launch == a sequential scan
+            if (n_wide > 1) {
+                // the plan appends wide classes with an atomic cursor: put them into class order, so that the wide
+                // phase visits them in the same order on every run (they may share transcripts -> order matters
+                // for the draws of a fixed seed)
+                std::vector<uint32_t> wl(n_wide);
+                G_TRY(hipMemcpyAsync(wl.data(), wide_list, (size_t)n_wide * 4, hipMemcpyDeviceToHost, st));
+                G_TRY(hipStreamSynchronize(st));
+                std::sort(wl.begin(), wl.end());
+                G_TRY(hipMemcpyAsync(wide_list, wl.data(), (size_t)n_wide * 4, hipMemcpyHostToDevice, st));
+                G_TRY(hipStreamSynchronize(st));
+            }
         }
         log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes", n_chains, n_tiles, K, n_wide);
         GibbsArgs a{n_chains, C, prob->d_rowptr, prob->d_ids, prob->d_counts, inv_len, w_mass, count_map, txp_count,

@@ -55,6 +55,10 @@ class HipEngine:
     def bias_model(self, exp, sopt):
         return exp.biasModel(sopt)
 
+    def gibbs_sample(self, length, mass, rowptr, ids, counts, num_mapped, n, n_chains=0, seed=1):
+        from .gibbs import gibbs_sample
+        return gibbs_sample(length, mass, rowptr, ids, counts, num_mapped, n, n_chains=n_chains, seed=seed)
+
     def tpm(self, exp, sopt):
         return _writer.tpm(exp, sopt)[0]
 
@@ -244,14 +248,11 @@ class DistributedQuant:
                 parts.append(pad4)
         send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
         recv = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=dev)
-        done = False
+        # the route is a function of the backend alone, so every rank takes the same one (a fallback chosen from a
+        # caught exception could split the ranks between two different collectives)
         if dist.get_backend(self.group) == "nccl":
-            try:
-                dist.all_to_all_single(recv, send, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
-                done = True
-            except RuntimeError:          # an argument the backend rejects fails on every rank alike: take the portable route
-                done = False
-        if not done:
+            dist.all_to_all_single(recv, send, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
+        else:
             # gloo (CPU tests, single-device dry runs) has no all-to-all: every rank's whole send buffer is gathered
             # and the block meant for this rank is cut out -- same result, more traffic
             full = _all_gather_var(send, self.group, w)
@@ -382,6 +383,7 @@ class DistributedQuant:
                 eff = p.length_view().clone()
             rc, st = p.finish()
         self.problem = p
+        self.problem_mode = mode                          # "sharded": self.problem holds this rank's class slice only
         ok = rc == 0
         if ok:
             txps.estCount.copy_(p.alpha); txps.mass.copy_(p.mass)
@@ -408,7 +410,7 @@ class DistributedQuant:
         """gatherBootstraps over all ranks (classes replicated, draws split, no collective
         until the results are gathered).  Rank r draws its share with the stream seed + r * golden.
         Needs a finished run() in replicated / single mode.  -> float64 [n, M] on every rank"""
-        p = self.problem
+        p = self._full_problem()
         rc, out, _ = p.bootstrap(self._share(n), seed=(int(seed) + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1),
                                  use_vbem=self.sopt.useVBOpt, tol=tol, max_iter=max_iter)
         if rc:
@@ -418,17 +420,36 @@ class DistributedQuant:
     def gibbs(self, n, seed=1, n_chains=0):
         """CollapsedGibbsSampler::sample over all ranks: every rank runs its own chains for its share of
         the draws.  -> int32 [n, M] on every rank"""
-        from .gibbs import gibbs_sample
         exp, sopt = self.exp, self.sopt
         txps = exp.transcripts()
-        vec = self.merged.eqVec() if self.merged is not None else self.local.eqVec()
+        vec = self.last_vec                               # the table the EM ran on (any merge mode)
         length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
-        rc, out = gibbs_sample(length, txps.mass, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments(), self._share(n),
-                               n_chains=n_chains, seed=(int(seed) + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1))
+        rc, out = self.engine.gibbs_sample(length, txps.mass, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments(),
+                                           self._share(n), n_chains=n_chains,
+                                           seed=(int(seed) + self.rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1))
         if rc:
             raise RuntimeError(f"gibbs failed on rank {self.rank}: rc={rc}")
         return self._gather_rows(out, n)
 
+    def _full_problem(self):
+        """The EM problem over ALL merged classes.  After a "sharded" run self.problem holds only this rank's slice
+        (resampling or timing it would silently use 1/N of the classes), so a problem over the whole table is built
+        once and kept for the samplers."""
+        if self.problem is None:
+            raise RuntimeError("run() first")
+        if getattr(self, "problem_mode", "single") != "sharded":
+            return self.problem
+        if getattr(self, "_full", None) is None or self._full_vec is not self.last_vec:
+            if getattr(self, "_full", None) is not None:
+                self._full.close()
+            exp, sopt, vec = self.exp, self.sopt, self.last_vec
+            txps = exp.transcripts()
+            length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
+            self._full = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
+            self._full_vec = vec
+        return self._full
+
     def time_sweep(self, n=200):
+        """average duration of one sweep launch of THIS rank's problem (its class slice in sharded mode)"""
         p = self.problem
         return p.time_sweep(n, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)

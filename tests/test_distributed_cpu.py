@@ -163,6 +163,14 @@ class _EM:
         bias.es, bias.eg = es, eg
         return rc, st, torch.from_numpy(eff), nr
 
+    def bootstrap(self, n, seed=1, use_vbem=False, tol=0.01, max_iter=10000, **_):
+        rc, out, iters = O.bootstrap(self._raw_len, self.rp.astype(np.uint64), self.ids.astype(np.uint32), self.cnt.astype(np.uint64),
+                                     int(n), use_vbem=use_vbem, tol=tol, max_iter=max_iter, seed=seed & 0x7FFFFFFF)
+        return rc, torch.from_numpy(out), iters
+
+    def close(self):
+        pass
+
     def finish(self):
         cutoff = (0.01 + 1e-8) if self.vb else 1e-8
         a = np.where(self.a <= cutoff, 0.0, self.a)
@@ -197,6 +205,11 @@ class CheckerEngine:
 
     def new_builder(self, expected=0):
         return _Builder()
+
+    def gibbs_sample(self, length, mass, rowptr, ids, counts, num_mapped, n, n_chains=0, seed=1):
+        rc, out = O.gibbs(length.numpy(), mass.numpy(), rowptr.numpy().view(np.uint32).astype(np.uint64), ids.numpy().view(np.uint32),
+                          counts.numpy().astype(np.uint64), int(num_mapped), int(n), seed=seed & 0x7FFFFFFF)
+        return rc, torch.from_numpy(out)
 
     def em_problem(self, length, rowptr, ids, counts, num_mapped):
         return _EM(length, rowptr, ids, counts, num_mapped)
@@ -235,6 +248,57 @@ def _worker(rank, world, port, mode, vb, out, merge_mode="auto"):
                  v.rowptr.numpy().view(np.uint32).copy(), v.ids.numpy().view(np.uint32).copy(), v.counts.numpy().copy()))
     finally:
         dist.destroy_process_group()
+
+
+def _sampler_worker(rank, world, port, mode, merge_mode, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sailfish_amd as sf
+        from sailfish_amd import distributed as sfd, synth
+        M, P, R = 200, 500, 3000
+        ref_len = synth.transcript_lengths(M)
+        poff, pids = synth.label_pool(M, P)
+        ids, off = synth.reads_from_pool(poff, pids, R, seed=7 + 1000 * rank)
+        sopt = sf.SailfishOpts()
+        exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.numpy().view(np.uint32), device="cpu"), sopt)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, engine=CheckerEngine(), poll_every=7, merge_mode=merge_mode)
+        info = q.run(ids, off)
+        bs = q.bootstrap(7, seed=5)
+        gs = q.gibbs(8, seed=5)
+        out.put((rank, info["n_classes"], exp.numMappedFragments(), bs.numpy().copy(), gs.numpy().copy(),
+                 exp.transcripts().estCount.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,merge", [("replicated", "owner"), ("sharded", "owner"), ("sharded", "allgather")])
+def test_three_rank_samplers_use_the_whole_merged_table(built, mode, merge):
+    """gibbs() and bootstrap() after an owner-partitioned merge (no `merged` builder is ever finished) and after a
+    sharded EM (self.problem holds one rank's class slice): both must sample over ALL merged classes"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sampler_worker, args=(r, world, port, mode, merge, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    N = res[0][2]
+    assert N == 3000 * world
+    for r in res:
+        bs, gs, est = r[3], r[4], r[5]
+        assert bs.shape == (7, 200) and gs.shape == (8, 200)
+        # every replicate / draw distributes ALL reads of ALL ranks (a rank's slice would hold ~1/3 of them)
+        np.testing.assert_allclose(bs.sum(1), N, rtol=1e-6)
+        assert np.array_equal(gs.sum(1), np.full(8, N))
+        # and tracks the point estimate
+        big = est > 0.01 * N / 200
+        assert np.all(np.abs(bs.mean(0)[big] - est[big]) < 0.5 * est[big] + 30)
+    assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[2][4])     # gathered rows are the same everywhere
 
 
 def _free_port():

@@ -34,8 +34,8 @@ def _worker(rank, world, port, mode, vb, out, merge_mode="auto"):
         q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=mode, poll_every=9, merge_mode=merge_mode)
         info = q.run(ids.to(dev), off.to(dev))
         t = exp.transcripts()
-        if mode == "replicated":                       # posterior draws are split over the ranks
-            bs = q.bootstrap(5, seed=3)
+        if True:                                       # posterior draws are split over the ranks; after a sharded run
+            bs = q.bootstrap(5, seed=3)                # the samplers use a problem over ALL merged classes
             gs = q.gibbs(7, seed=3, n_chains=64)
             N = exp.numMappedFragments()
             assert bs.shape == (5, M) and gs.shape == (7, M)
@@ -52,7 +52,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("mode,vb,merge,world", [("replicated", False, "auto", 2), ("sharded", False, "auto", 2), ("sharded", True, "auto", 2),
-                                                 ("sharded", False, "owner", 3)])
+                                                 ("sharded", False, "owner", 3), ("replicated", True, "owner", 3)])
 def test_two_ranks_on_one_gpu_match_the_oracle(gpu, mode, vb, merge, world):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
