@@ -11,9 +11,12 @@ quasi-mapper are third-party code outside the path and outside ev
 N = 1 : the configuration BASELINE.json's metric is quoted on ("... 200k-txp index"): configs[2], "cfg3" -- 400M
         paired-end fragments, 200k-transcript index, VBEM + empirical fragment-length correction; it fits one GPU
         (8 GB of hit lists).  --workload cfg2 is configs[1] (50M single-end reads, 80k transcripts, EM).
-N > 1 : launched by torch.distributed.run, one rank per GPU.  Weak scaling: every rank quantifies
-        its own R-read shard of ONE experiment; class tables are merged with one all-gather and the
-        EM runs on the merged classes (see sailfish_amd/distributed.py for the exchange).
+N > 1 : launched by torch.distributed.run, one rank per GPU.  STRONG scaling (BASELINE configs[3], "cfg4": the same
+        400M PE reads / 200k transcripts sharded across the GPUs): rank r holds reads [r R/N, (r+1) R/N) of the very
+        experiment N = 1 runs (synth.reads_slice: the read stream is defined chunk by chunk, so the union of the
+        shards IS the single-GPU input and the merged class table is the single-GPU table); the class tables are merged
+        with one exchange and the EM runs on the merged classes (sailfish_amd/distributed.py).  --weak gives every
+        rank its own R reads instead (the job grows with N).
 
 Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline ...).
 """
@@ -45,6 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--em-mode", default="auto", choices=["auto", "replicated", "sharded"])
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank gets its own R reads (weak scaling) instead of R/N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--one-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
@@ -156,7 +160,14 @@ def main():
     # ---- synthetic inputs, generated on the device and left resident in HBM (untimed) ----------
     ref_len = synth.transcript_lengths(M, device=dev)
     poff, pids = synth.label_pool(M, P, device=dev)
-    ids, off = synth.reads_from_pool(poff, pids, R, seed=7 + 1000 * rank, device=dev)   # this rank's shard
+    if a.weak or world == 1:
+        lo, hi = rank * R, (rank + 1) * R                  # weak scaling: N x R reads in all
+        R_total = R * world
+    else:
+        lo, hi = R * rank // world, R * (rank + 1) // world    # strong scaling: the same R reads, sharded
+        R_total = R
+    ids, off = synth.reads_slice(poff, pids, lo, hi, seed=7, device=dev)                 # this rank's shard
+    R_local = hi - lo
     del poff, pids
     ref_len_np = ref_len.cpu().numpy().view(np.uint32)
     n_hits = ids.numel()
@@ -192,7 +203,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    total_reads = R * world * a.steps
+    total_reads = R_total * a.steps
     value = total_reads / dt
     st = info["em_stats"]
     C, L = info["n_classes"], info["nnz"]
@@ -204,7 +215,7 @@ def main():
     sweep_ms = quant.time_sweep(200)
     em_loop_ms_per_iter = st["loop_ms"] / max(st["iters"], 1)
     # class build: B_read = 4*h + 4 (offset) + 16 (one slot probe) bytes per read
-    b_read = 4.0 * n_hits / R + 20.0
+    b_read = 4.0 * n_hits / R_local + 20.0
     build_ms = info["t_build_ms"]
     em_ms = info["t_em_ms"]
     # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs of
@@ -233,26 +244,27 @@ def main():
     roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
                    unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em,
                    bytes_per_launch=b_iter, avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
-    roof_build = dict(bound="hbm", kernel=info.get("insert_kernels", "k_insert"), achieved=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9,
+    roof_build = dict(bound="hbm", kernel=info.get("insert_kernels", "k_insert"), achieved=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      frac=b_read * R / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins,
-                      bytes_per_launch=b_read * R / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins)
+                      frac=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins,
+                      bytes_per_launch=b_read * R_local / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins)
     dominant = roof_em if sweep_ms * st["iters"] >= info["t_insert_ms"] else roof_build
 
     out = {
         "metric": "reads quantified/sec (hit lists -> eq-classes -> EM to convergence -> TPM)",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": ("weak" if (a.weak or world == 1) else "strong"), "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{a.workload}: {R} reads/GPU x {world} GPU, {M}-transcript index, label pool {P}, "
+        "config": {"workload": f"{'cfg4 = ' if (a.workload == 'cfg3' and world > 1 and not a.weak) else ''}{a.workload}: "
+                               f"{R_total} reads in all over {world} GPU ({R_local} on rank 0), {M}-transcript index, label pool {P}, "
                                f"{'VBEM' if use_vbem else 'EM'} to convergence (tol 0.01, minIter 50)",
-                   "reads_per_gpu": R, "transcripts": M, "hits": n_hits, "classes": C, "nnz": L,
+                   "reads_total": R_total, "reads_per_gpu": R_local, "transcripts": M, "hits": n_hits, "classes": C, "nnz": L,
                    "em_mode": info["em_mode"]},
         "em_iters": st["iters"], "em_iters_per_s": st["iters"] / (em_ms * 1e-3),
         "em_us_per_iter_loop": em_loop_ms_per_iter * 1e3,
         "phase_ms": {"class_build": build_ms, "insert_kernel": info["t_insert_ms"], "merge": info.get("t_merge_ms", 0.0),
                      "efflen": info["t_efflen_ms"], "em": em_ms, "tpm": info["t_tpm_ms"]},
-        "class_build_reads_per_s": R / (build_ms * 1e-3),
+        "class_build_reads_per_s": R_local / (build_ms * 1e-3),
         "roofline": dominant, "roofline_em_sweep": roof_em, "roofline_class_build": roof_build,
     }
 

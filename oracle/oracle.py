@@ -406,3 +406,57 @@ def ref_xxhash():
     L.XXH64.restype = C.c_uint64
     L.XXH64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
     return L
+
+
+def multinomial(n, probs, seed=1):
+    """the restated MultinomialSampler::operator() (sf_oracle.c `multinomial`) -> uint64[k]"""
+    p = _c(probs, np.float64); out = np.zeros(len(p), np.uint64)
+    L = lib(); L.sfo_multinomial.restype = None
+    L.sfo_multinomial.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.sfo_multinomial(int(seed), int(n), len(p), _p(p), _p(out))
+    return out
+
+
+def ref_sailfish():
+    """ctypes handle on oracle/_ref/libsailfish_ref.so -- ref_glue.cpp around the reference units that build unmodified
+    with the standard library alone (LibraryFormat.cpp, MultinomialSampler.hpp, cuckoohash_map.hh, xxhash.c) -- or None."""
+    so = os.path.join(_HERE, "_ref", "libsailfish_ref.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.ref_format_id.restype = C.c_uint8; L.ref_format_id.argtypes = [C.c_int] * 3
+    L.ref_format_from_id.restype = None; L.ref_format_from_id.argtypes = [C.c_uint8, C.c_void_p]
+    L.ref_format_check.restype = C.c_int; L.ref_format_check.argtypes = [C.c_int] * 3
+    L.ref_format_max_id.restype = C.c_int
+    L.ref_format_str.restype = C.c_int; L.ref_format_str.argtypes = [C.c_int] * 3 + [C.c_char_p, C.c_int]
+    L.ref_multinomial.restype = None; L.ref_multinomial.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.ref_eq_build.restype = C.c_long
+    L.ref_eq_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    return L
+
+
+def ref_multinomial(n, probs):
+    """one call of the REFERENCE's MultinomialSampler (random_device-seeded) -> uint64[k]"""
+    p = _c(probs, np.float64); out = np.zeros(len(p), np.uint64)
+    ref_sailfish().ref_multinomial(int(n), len(p), _p(p), _p(out))
+    return out
+
+
+def ref_eq_build(ids, off, n_threads=1):
+    """label -> count through the REFERENCE's cuckoohash_map::upsert + XXH64, as addGroup uses them
+    (ref_glue.cpp).  -> dict {label tuple: (count, hash)} (table order is history dependent)"""
+    ids = _c(ids, np.uint32); off = _c(off, np.uint64)
+    n = len(off) - 1
+    if len(ids) == 0:
+        ids = np.zeros(1, np.uint32)
+    out_ids = np.zeros(max(len(ids), 1), np.uint32); out_len = np.zeros(max(n, 1), np.uint32)
+    out_cnt = np.zeros(max(n, 1), np.uint64); out_hash = np.zeros(max(n, 1), np.uint64)
+    nc = ref_sailfish().ref_eq_build(_p(ids), _p(off), n, int(n_threads), _p(out_ids), len(out_ids), _p(out_len), _p(out_cnt),
+                                     _p(out_hash), len(out_len))
+    assert nc >= 0
+    res, pos = {}, 0
+    for c in range(nc):
+        lab = tuple(out_ids[pos:pos + out_len[c]].tolist()); pos += int(out_len[c])
+        assert lab not in res
+        res[lab] = (int(out_cnt[c]), int(out_hash[c]))
+    return res

@@ -1040,6 +1040,15 @@ static void multinomial(sfo_rng* r, uint64_t* out, uint64_t n, uint64_t k, const
     }
 }
 
+/* the restated sampler on its own (tests pin it distributionally against the reference's MultinomialSampler,
+ * oracle/_ref/libsailfish_ref.so) */
+SFO_API void sfo_multinomial(uint64_t seed, uint64_t n, uint64_t k, const double* p, uint64_t* out) {
+    sfo_rng rng; rng.s = seed ? seed : 0x9E3779B97F4A7C15ULL;
+    double* z = (double*)malloc((k + 1) * sizeof(double));
+    multinomial(&rng, out, n, k, p, z);
+    free(z);
+}
+
 /* a15. gatherBootstraps / doBootstrap (src/CollapsedEMOptimizer.cpp:438-525, 557-709).
  * B draws; each: multinomial(N = sum count, p = count/N) over the classes, alpha re-initialised
  * uniformly over active transcripts (:470-474), serial EM/VBEM with NO 50-iteration floor and the

@@ -24,6 +24,40 @@ LIBRARY_FORMATS = {"IU": (1, TOWARD, U), "ISF": (1, TOWARD, SA), "ISR": (1, TOWA
                    "MSR": (1, SAME, A), "U": (0, NONE, U), "SF": (0, NONE, S), "SR": (0, NONE, A)}
 
 
+def format_id(fmt):
+    """LibraryFormat::formatID (include/LibraryFormat.hpp:89-98): type | orientation << 1 | strandedness << 3"""
+    t, o, s = fmt
+    return (int(t) & 0x01) | ((int(o) & 0x3) << 1) | ((int(s) & 0x7) << 3)
+
+
+def format_from_id(i):
+    """LibraryFormat::formatFromID (include/LibraryFormat.hpp:34-85)"""
+    return (int(i) & 0x01, (int(i) >> 1) & 0x3, (int(i) >> 3) & 0x7)
+
+
+MAX_LIB_TYPE_ID = format_id((1, NONE, U))            # LibraryFormat::maxLibTypeID (:25-30)
+
+
+def format_check(fmt):
+    """LibraryFormat::check (src/LibraryFormat.cpp:6-51): is the combination meaningful?"""
+    t, o, s = fmt
+    if t == 0:                                       # single end: no orientation, no two-strand protocol
+        return o == NONE and s not in (SA, AS)
+    if o == NONE:
+        return False
+    if o == SAME:
+        return s in (S, A, U)
+    return s in (SA, AS, U)                          # AWAY / TOWARD: the mates come from different strands
+
+
+def format_str(fmt):
+    """operator<<(ostream&, LibraryFormat) (src/LibraryFormat.cpp:53-100), the text of the log lines"""
+    t, o, s = fmt
+    return ("Library format { type:" + ("single end", "paired end")[t] + ", relative orientation:" +
+            {TOWARD: "inward", AWAY: "outward", SAME: "matching", NONE: "none"}[o] + ", strandedness:" +
+            {SA: "(sense, antisense)", AS: "(antisense, sense)", S: "sense", A: "antisense", U: "unstranded"}[s] + " }")
+
+
 def filter_hits(hits, hit_offsets, lib_format, sopt=None, *, paired_library=None, allow_orphans=False,
                 ignore_lib_compat=False, enforce_lib_compat=False, allow_dovetail=False, max_read_occs=200,
                 max_frag_len=1000, fl_counts=None, remaining_fl_ops=0, stats=None, device="cuda"):

@@ -71,6 +71,47 @@ def reads_from_pool(pool_off, pool_ids, R, seed=7, device=None, chunk=1 << 23):
     return ids, off32
 
 
+kSliceChunk = 1 << 22
+
+
+def reads_slice(pool_off, pool_ids, lo, hi, seed=7, device=None):
+    """Reads [lo, hi) of ONE experiment whose read stream is defined chunk by chunk (chunk c of 2^22 reads draws
+    its labels from a generator seeded with (seed, c)), so any slice is reproducible on its own: N ranks holding
+    [r R/N, (r+1) R/N) together hold exactly the reads a single process generates as [0, R) -- the strong-scaling
+    shards of bench.py and of the multi-rank tests.  -> (ids int32[H], offsets int32[hi-lo+1])"""
+    device = device or pool_ids.device
+    P = pool_off.numel() - 1
+    k = (pool_off[1:] - pool_off[:-1])
+    n = hi - lo
+    picks = torch.empty(n, dtype=torch.int64, device=device)
+    for c in range(lo // kSliceChunk, (max(hi, lo + 1) - 1) // kSliceChunk + 1):
+        g = torch.Generator(device=device); g.manual_seed((int(seed) * 1000003 + c) & 0x7FFFFFFFFFFFFFFF)
+        a = torch.randint(0, P, (kSliceChunk,), generator=g, device=device)
+        b = torch.randint(0, P, (kSliceChunk,), generator=g, device=device)
+        p = torch.minimum(a, b)
+        c0 = c * kSliceChunk
+        s, e = max(lo, c0), min(hi, c0 + kSliceChunk)
+        if e > s:
+            picks[s - lo:e - lo] = p[s - c0:e - c0]
+    lens = k[picks]
+    off = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=off[1:])
+    H = int(off[-1])
+    assert H < 2 ** 32, "one batch holds < 2^32 ids"
+    ids = torch.empty(H, dtype=torch.int32, device=device)
+    step = 1 << 23
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        ln = lens[s:s + m]
+        tot = int(off[s + m] - off[s])
+        rr = torch.repeat_interleave(torch.arange(m, device=device), ln, output_size=tot)
+        j = torch.arange(tot, device=device) + int(off[s]) - off[s:s + m][rr]
+        ids[int(off[s]):int(off[s]) + tot] = pool_ids[pool_off[picks[s:s + m]][rr] + j]
+    off32 = (off & 0xFFFFFFFF).to(torch.int64)
+    off32 = torch.where(off32 >= 2 ** 31, off32 - 2 ** 32, off32).to(torch.int32)   # uint32 bits in int32
+    return ids, off32
+
+
 def workload(M, P, R, seed=42, device="cpu"):
     """Convenience: (ref_len int32[M], ids, offsets) for one synthetic experiment."""
     ref_len = transcript_lengths(M, seed, device)

@@ -1,0 +1,210 @@
+"""GPU tests of BASELINE.json's configs[3] and configs[4] at their quoted sizes on ONE GPU.
+
+cfg4 ("8xMI355X: same 400M PE / 200k-txp, eq-classes sharded across GPUs, per-iter all-reduce of alpha"): eight ranks share
+the test box's GPU (gloo between them -- RCCL refuses several ranks on one device), rank r holds reads [r R/8, (r+1) R/8) of
+the very experiment a single process runs; the merged class table must equal the single-process table and the sharded EM
+(classes cut into 8 nnz-balanced slices, SUM all-reduce of alphaOut between sweep and update, every iteration) must stop at
+the single-GPU iteration with the same alpha.
+
+cfg5 ("1000 Gibbs draws over the converged eq-classes"): the draws at size through size-independent properties, plus
+distributional parity with the oracle's sequential sampleRound_ on a problem whose round needs several phases."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFG3 = (200_000, 4_000_000, 400_000_000)
+
+
+def _fl_counts():
+    i = np.arange(1000.0)
+    return np.floor(np.exp(-0.5 * ((i - 200.0) / 80.0) ** 2) * 4000 + 0.5).astype(np.uint32)
+
+
+def _cfg4_worker(rank, world, port, sizes, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sailfish_amd as sf
+        from sailfish_amd import distributed as sfd, synth
+        M, P, R = sizes
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        ref_len = synth.transcript_lengths(M, device=dev)
+        poff, pids = synth.label_pool(M, P, device=dev)
+        ids, off = synth.reads_slice(poff, pids, R * rank // world, R * (rank + 1) // world, seed=7, device=dev)
+        del poff, pids
+        sopt = sf.SailfishOpts(useVBOpt=True)
+        exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.cpu().numpy().view(np.uint32), device=dev), sopt)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode="sharded", poll_every=16)
+        info = q.run(ids, off, fl_counts=_fl_counts(), remaining_fl_ops=0)
+        v = q.last_vec
+        np.save(os.path.join(outdir, f"alpha{rank}.npy"), exp.transcripts().estCount.cpu().numpy())
+        if rank == 0:
+            np.savez(os.path.join(outdir, "table.npz"), rowptr=v.rowptr.cpu().numpy(), ids=v.ids.cpu().numpy(), counts=v.counts.cpu().numpy(),
+                     meta=np.array([info["n_classes"], info["nnz"], exp.numMappedFragments(), info["em_stats"]["iters"],
+                                    int(info["em_stats"]["converged"]), int(info["em_mode"] == "sharded"), q.problem.C]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_cfg4_eight_ranks_share_the_gpu(gpu):
+    import sailfish_amd as sf
+    from sailfish_amd import distributed as sfd, synth
+    M, P, R = CFG3
+    world = 8
+    outdir = tempfile.mkdtemp(prefix="cfg4_")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg4_worker, args=(r, world, port, CFG3, outdir)) for r in range(world)]
+    for p in procs:
+        p.start()
+    # meanwhile: the single-process run over all R reads (the children take a while to import torch)
+    ref_len = synth.transcript_lengths(M, device=gpu)
+    poff, pids = synth.label_pool(M, P, device=gpu)
+    ids, off = synth.reads_slice(poff, pids, 0, R, seed=7, device=gpu)
+    del poff, pids
+    sopt = sf.SailfishOpts(useVBOpt=True)
+    exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.cpu().numpy().view(np.uint32), device=gpu), sopt)
+    q1 = sfd.DistributedQuant(exp, sopt)
+    info1 = q1.run(ids, off, fl_counts=_fl_counts(), remaining_fl_ops=0)
+    v1 = q1.last_vec
+    a1 = exp.transcripts().estCount.cpu().numpy()
+    del ids, off
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    tab = np.load(os.path.join(outdir, "table.npz"))
+    n_classes, nnz, n_mapped, iters, conv, sharded, c_local = [int(x) for x in tab["meta"]]
+    # the merged table IS the single-process table: same classes, same canonical order, same counts (integer work: bit exact)
+    assert n_mapped == R == exp.numMappedFragments() and n_classes == info1["n_classes"] and nnz == info1["nnz"]
+    assert np.array_equal(tab["rowptr"], v1.rowptr.cpu().numpy())
+    assert np.array_equal(tab["ids"], v1.ids.cpu().numpy())
+    assert np.array_equal(tab["counts"], v1.counts.cpu().numpy())
+    # sharded EM: each rank swept ~1/8 of the classes, and the loop stopped where the single-GPU loop stops
+    assert sharded == 1 and 0 < c_local < n_classes // 4
+    assert conv == 1 and iters == info1["em_stats"]["iters"], (iters, info1["em_stats"])
+    alphas = [np.load(os.path.join(outdir, f"alpha{r}.npy")) for r in range(world)]
+    for a in alphas[1:]:
+        assert np.array_equal(a, alphas[0])                        # the all-reduce leaves every rank with the same bits
+    nz = a1 > 0
+    assert np.array_equal(alphas[0] > 0, nz)
+    assert float(np.max(np.abs(alphas[0][nz] - a1[nz]) / a1[nz])) < 1e-9
+
+
+def test_cfg5_thousand_draws_over_cfg3_classes(gpu):
+    """BASELINE configs[4]: 1000 Gibbs draws (1024 chains) over the converged classes of cfg3"""
+    import sailfish_amd as sf
+    from sailfish_amd import _lib, synth
+    M, P, R = CFG3
+    ref_len = synth.transcript_lengths(M, device=gpu)
+    poff, pids = synth.label_pool(M, P, device=gpu)
+    ids, off = synth.reads_slice(poff, pids, 0, R, seed=7, device=gpu)
+    del poff, pids
+    eq = sf.EquivalenceClassBuilder(device=gpu); eq.start(); eq.add_batch(ids, off); eq.finish(); v = eq.eqVec()
+    del ids, off
+    length = ref_len.to(torch.float64)
+    p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads)
+    rc, st = p.optimize(use_vbem=True)
+    assert rc == 0 and st["converged"]
+    logs = []
+    _lib.set_logger(lambda lvl, msg: logs.append(msg))
+    try:
+        rc, g = sf.gibbs_sample(length, p.mass, v.rowptr, v.ids, v.counts, eq.total_reads, 1000, n_chains=1024, seed=1)
+        assert rc == 0 and tuple(g.shape) == (1000, M) and g.dtype == torch.int32
+        plan = [m for m in logs if "gibbs:" in m][-1]              # "gibbs: 1024 chains, T tiles in K phases, W wide classes"
+        K = int(plan.split(" tiles in ")[1].split()[0])
+        assert K >= 2, plan                                         # cfg3's classes need a multi-phase round
+        # every draw distributes every read: sum over transcripts = numMapped, no negative count
+        assert bool((g.sum(1, dtype=torch.int64) == R).all()) and int(g.min()) >= 0
+        # transcripts that appear in no class never receive a read
+        present = torch.zeros(M, dtype=torch.bool, device=gpu); present[v.ids.long()] = True
+        assert int(g[:, ~present].abs().sum()) == 0
+        # a transcript's count can never exceed what its classes hold
+        cap = torch.zeros(M, dtype=torch.int64, device=gpu)
+        rp = v.rowptr.long() & 0xFFFFFFFF
+        cap.index_add_(0, v.ids.long(), torch.repeat_interleave(v.counts.long(), rp[1:] - rp[:-1]))
+        assert bool((g.max(0).values.long() <= cap).all())
+        # the draws scatter around the point estimate for the well-covered transcripts
+        a = p.alpha
+        top = torch.argsort(a, descending=True)[:2000]
+        mean = g[:, top].double().mean(0)
+        assert float(((mean - a[top]).abs() / a[top]).median()) < 0.05
+        # reproducible from the seed (incl. the order in which the wide classes are visited)
+        rc, g2 = sf.gibbs_sample(length, p.mass, v.rowptr, v.ids, v.counts, eq.total_reads, 8, n_chains=1024, seed=1)
+        assert rc == 0 and torch.equal(g2, g[:8])
+        rc, g3 = sf.gibbs_sample(length, p.mass, v.rowptr, v.ids, v.counts, eq.total_reads, 8, n_chains=1024, seed=2)
+        assert rc == 0 and not torch.equal(g3, g[:8])
+    finally:
+        _lib.set_logger(None)
+        p.close()
+
+
+def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu):
+    """per-transcript mean and spread of the phase-parallel sampler vs the oracle's sequential sampleRound_
+    (src/CollapsedGibbsSampler.cpp:113-184) on a problem with thousands of classes, a multi-phase round and wide classes"""
+    import sailfish_amd as sf
+    from sailfish_amd import _lib, synth
+    M, P, R = 3000, 6000, 120_000
+    ref_len, ids, off = synth.workload(M, P, R)
+    # a few labels spanning the whole transcript range ("wide" classes: visited one after another after the phases)
+    rng = np.random.default_rng(5)
+    wide = [np.sort(rng.choice(M, 6, replace=False)).astype(np.int32) for _ in range(3)]
+    extra_ids = np.concatenate([np.tile(w, 400) for w in wide])
+    extra_off = int(off[-1]) + 6 * np.arange(1, 1201)
+    ids = torch.cat([ids, torch.from_numpy(extra_ids)])
+    off = torch.cat([off, torch.from_numpy(extra_off.astype(np.int32))])
+    R += 1200
+    eq = sf.EquivalenceClassBuilder(device=gpu); eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); eq.finish(); v = eq.eqVec()
+    assert eq.total_reads == R and eq.n_classes > 2000
+    eff = O.efflen_smoothed(ref_len.numpy().view(np.uint32), O.cf_gaussian())
+    length = torch.from_numpy(eff).to(gpu)
+    p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, R)
+    rc, st = p.optimize()
+    assert rc == 0
+    logs = []
+    _lib.set_logger(lambda lvl, msg: logs.append(msg))
+    try:
+        n_chains, rounds, burn = 256, 40, 12
+        rc, g = sf.gibbs_sample(length, p.mass, v.rowptr, v.ids, v.counts, R, n_chains * rounds, n_chains=n_chains, seed=21)
+    finally:
+        _lib.set_logger(None)
+    assert rc == 0
+    plan = [m for m in logs if "gibbs:" in m][-1]
+    K = int(plan.split(" tiles in ")[1].split()[0]); n_wide = int(plan.split(" phases, ")[1].split()[0])
+    assert K >= 2 and n_wide >= 3, plan
+    g = g.cpu().numpy()[n_chains * burn:]                           # sample s = chain s % n_chains after s // n_chains + 1 rounds
+    rp, ii, cc, _ = v.to_numpy()
+    S_o, burn_o = 3000, 600
+    orc, og = O.gibbs(eff, p.mass.cpu().numpy(), rp.astype(np.uint64), ii, cc, R, S_o, seed=3)
+    assert orc == 0
+    og = og[burn_o:]
+    assert np.all(g.sum(1) == R) and np.all(og.sum(1) == R)
+    mo, so = og.mean(0), og.std(0)
+    mg, sg = g.mean(0), g.std(0)
+    # the sequential chain is autocorrelated: its mean carries an error of a few so / sqrt(effective samples); the bound
+    # below is ~6 standard errors at an effective sample size of ~150, plus one read
+    tol = 0.5 * so + 0.004 * mo + 1.0
+    bad = np.flatnonzero(np.abs(mg - mo) > tol)
+    assert bad.size <= M // 500, (bad[:10], mg[bad[:10]], mo[bad[:10]], so[bad[:10]])
+    # spread: transcripts whose count really moves must move alike in both samplers
+    mv = so > 4.0
+    assert mv.sum() > 100
+    ratio = sg[mv] / so[mv]
+    assert 0.8 < float(np.median(ratio)) < 1.25 and float(np.mean((ratio > 0.5) & (ratio < 2.0))) > 0.97
+    # members of the wide classes are part of it
+    wt = np.unique(np.concatenate(wide))
+    assert np.all(np.abs(mg[wt] - mo[wt]) <= tol[wt] + 0.5 * so[wt])
