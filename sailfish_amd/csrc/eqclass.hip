@@ -63,11 +63,20 @@ __device__ __forceinline__ bool entry_equals(const uint32_t* __restrict__ arena,
     // both 16-byte words are requested together and compared without short-circuits: one round trip
     // (a 4-word entry is followed by the next entry or by the arena's slack, so p[4..7] is readable)
     const uint4 a = reinterpret_cast<const uint4*>(p)[0];
+#ifdef SFGPU_EQ_COND_SECOND
+    uint32_t d = (a.x ^ n) | (a.y ^ hw[0]) | (a.z ^ hw[1]) | (a.w ^ hw[2]);
+    if (d) return false;
+    if (n > 3u) {
+        const uint4 b = reinterpret_cast<const uint4*>(p)[1];
+        if ((b.x ^ hw[3]) | (b.y ^ hw[4]) | (b.z ^ hw[5]) | (b.w ^ hw[6])) return false;
+    }
+#else
     const uint4 b = reinterpret_cast<const uint4*>(p)[1];
     uint32_t d = (a.x ^ n) | (a.y ^ hw[0]) | (a.z ^ hw[1]) | (a.w ^ hw[2]);
     const uint32_t d2 = (b.x ^ hw[3]) | (b.y ^ hw[4]) | (b.z ^ hw[5]) | (b.w ^ hw[6]);
     d |= (n > 3u) ? d2 : 0u;
     if (d) return false;
+#endif
     for (uint32_t k = 7; k < n; ++k) if (p[1 + k] != word(k)) return false;
     return true;
 }
@@ -476,7 +485,7 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
 
 // radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.
 static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t cnt,
-                          uint64_t n_words) {
+                          uint64_t n_words, uint32_t ids_end) {
     hipStream_t st = eq->stream;
     int rc;
     // The table doubles when the classes seen so far would fill more than half of it (SFGPU_EQ_LOAD_DIV: 1/div).  A
@@ -503,34 +512,38 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
-    // every block of passes 1a/1b owns one contiguous tile of reads
-    uint32_t n_blocks = (cnt + 32767u) / 32768u; if (n_blocks > 4096u) n_blocks = 4096u; if (n_blocks == 0) n_blocks = 1;
+    // every block of pass 1 owns one contiguous tile of reads and one bin per region
+    uint32_t n_blocks = (cnt + 32767u) / 32768u; if (n_blocks > 512u) n_blocks = 512u; if (n_blocks == 0) n_blocks = 1;
     const uint32_t tile = (uint32_t)(((uint64_t)cnt + n_blocks - 1) / n_blocks);
-    const uint64_t mat_n = (uint64_t)n_regions * n_blocks;
-    if ((rc = eq->part_words.reserve(n_words + 8, st, false))) return rc;
-    if ((rc = eq->part_hist.reserve(mat_n + 1, st, false))) return rc;
-    if ((rc = eq->part_off.reserve(mat_n + 2, st, false))) return rc;
-    if ((rc = eq->part_cursor.reserve(((uint64_t)cnt + 1) / 2 + 1, st, false))) return rc;      // uint16 region of every read
+    // Bin capacity (stream words: ids + one hash word per read): the mean share of a (region, block) pair plus 30 %
+    // and a constant -- the share is a sum of ~mean/5 independent labels, so this is > 6 standard deviations for
+    // hashed labels; a region far above its share (one label holding a large part of the reads) overflows into the
+    // generic kernel's list.  Rounded to whole 128-byte lines.
+    const uint64_t n_bins = (uint64_t)n_regions * n_blocks;
+    const uint64_t stream_words = n_words + cnt;
+    uint64_t cap = (stream_words + n_bins - 1) / n_bins;
+    cap = cap + cap * 3 / 10 + 160;
+    cap = (cap + 31) & ~31ull;
+    // positions inside the bins are 31-bit (bit 31 of a slot's rep marks arena entries)
+    SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 words");
+    if ((rc = eq->part_words.reserve(n_bins * cap + 8, st, false))) return rc;
+    if ((rc = eq->part_hist.reserve(n_bins + 1, st, false))) return rc;          // fill of every bin
     if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
-    if ((rc = eq->deferred_a.reserve(cnt, st, false))) return rc;
-    uint16_t* reg_of = reinterpret_cast<uint16_t*>(eq->part_cursor.p);
+    if ((rc = eq->deferred_a.reserve(2ull * cnt, st, false))) return rc;
     SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));     // CTR_NEW, CTR_DEFER
     SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));     // long-label counter
     SF_HIP(hipEventRecord(eq->ev0, st));
-    hipLaunchKernelGGL(k_part_hist, dim3(n_blocks), dim3(kPartBlock), 0, st, d_ids, d_offsets, first, cnt, tile, eq->cap - 1,
-                       n_regions, reg_of, eq->part_hist.p, eq->d_ctr + 3, eq->part_long.p);
-    SF_CHECK_LAUNCH();
-    if ((rc = exclusive_scan_u32(eq->part_hist.p, eq->part_off.p, mat_n, st))) return rc;
-    const size_t scatter_lds = (size_t)(kSortWords + 4) * 4 + ((size_t)3 * n_regions + 1) * 4 + ((size_t)kSortWords / 16 + 2) * 2;
+    const size_t route_lds = (size_t)(kSortWords + 8) * 4 + ((size_t)3 * n_regions + 1) * 4 + ((size_t)kSortWords / 16 + 2) * 2;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
-        SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_route), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL(k_part_scatter, dim3(n_blocks), dim3(kPartBlock), scatter_lds, st, d_ids, d_offsets, first, cnt, tile,
-                       n_regions, reg_of, eq->part_off.p, eq->part_words.p);
+    RouteArgs ra{d_ids, d_offsets, first, cnt, tile, ids_end, eq->cap - 1, n_regions, (uint32_t)cap, eq->part_words.p, eq->part_hist.p,
+                 eq->d_ctr + 3, eq->part_long.p};
+    hipLaunchKernelGGL(k_part_route, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
     SF_CHECK_LAUNCH();
-    PartArgs pa{eq->table.p, eq->part_off.p, n_blocks, eq->part_words.p, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+    PartArgs pa{eq->table.p, eq->part_words.p, eq->part_hist.p, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
                 eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes};
     hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
@@ -546,8 +559,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         eq->stats.deferred_reads += n_def;
         if ((rc = eq->def_lens.reserve(n_def + 1, st, false)) || (rc = eq->def_off64.reserve(n_def + 2, st, false)) ||
             (rc = eq->def_off.reserve(n_def + 1, st, false))) return rc;
-        hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p,
-                           eq->part_words.p, n_words, eq->def_lens.p);
+        hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p, eq->def_lens.p);
         SF_CHECK_LAUNCH();
         if ((rc = exclusive_scan_u32(eq->def_lens.p, eq->def_off64.p, n_def, st))) return rc;
         uint64_t tot = 0;
@@ -617,7 +629,7 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             if (n_words >= (1ull << 31) && cnt > (1u << 20)) { step = cnt / 2; continue; }     // too many ids for 31-bit offsets: halve
             if ((rc = reserve_arena(n_words, cnt))) return rc;
             if (n_words < (1ull << 31)) {
-                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words))) return rc;
+                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words, se[1]))) return rc;
                 done = true;
             }
         } else if (part) {

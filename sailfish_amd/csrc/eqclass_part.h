@@ -2,19 +2,25 @@
 //
 // The global table is an array of REGIONS of kRegionSlots consecutive slots; a label's home region is
 // the high bits of its slot index and linear probing wraps inside the region.  One pass of a sub-batch:
-//   1a k_part_hist    : hash every label, histogram label WORDS per region (LDS histogram per block)
-//      (scan)
-//   1b k_part_scatter : copy every label into its region's segment of a partition buffer -- first word
-//                       flagged with bit 31, so a segment is a self-delimiting stream of labels
-//   2  k_part_insert  : ONE block per region: the region's slots live in LDS (word u64 + count delta
-//                       u32); every wavefront streams its own share of the segment through a private
-//                       LDS tile with coalesced loads (no block barriers while streaming); labels
-//                       are hashed, probed and counted with LDS atomics only; new classes get their
-//                       class ids / arena space with one global atomic per block and are committed
-//                       by the same block; finally the region is written back.
-// HBM sees each label ~3 times, always streaming; there are no global atomics per read and no host
-// round trip per sub-batch.  (The one-lane-per-read kernel k_insert probes the table in HBM: three
-// random 64-byte sectors per read -- profiles/r1_pmc_summary.md.)
+//   1  k_part_route  : every label is read ONCE and hashed ONCE (bucket hash, xxh64_device.h); a block counting-sorts
+//                      sub-tiles of its reads by region inside LDS and appends each region's run to ITS OWN bin of
+//                      that region -- bin (region, block), fixed capacity, no histogram pass, no scan, no global
+//                      atomics.  The label travels as  [id0 | head bit][H][id1] ... [id_{n-1}]  where H carries what
+//                      pass 2 needs from the hash (19 tag bits, 12 slot bits): pass 2 never hashes a read.
+//                      Labels that do not fit their bin (a region far above its share), over-long labels and ids
+//                      >= 2^31 go to a list that the generic kernel k_insert takes.
+//   2  k_part_insert : ONE block per region: the region's slots live in LDS (word u64 + count delta u32); every
+//                      wavefront streams whole bins through a private LDS tile with coalesced loads (no block
+//                      barriers while streaming); labels are probed and counted with LDS atomics only; new classes
+//                      get their class ids / arena space with one global atomic per block and are committed by the
+//                      same block (XXH64 and the full bucket hash are computed here, once per CLASS); finally the
+//                      region is written back.
+// HBM sees each label twice after the caller's copy (written once, read once), always streaming.
+//
+// Round-2 rewrite: hardware counters (profiles/r2_eq_counters_before.txt) showed the three kernels of the first
+// version (histogram, scatter, insert) issue-bound, not bandwidth-bound: 287 + 262 + 503 vector and 114 + 154 +
+// 419 scalar instructions per label (every pass hashed or re-derived the region, predicated loads compiled to
+// branch chains).  The route pass replaces histogram + scan + scatter; the insert pass reads H instead of hashing.
 #pragma once
 
 namespace sfgpu {
@@ -25,270 +31,248 @@ constexpr uint32_t kRegionLimit = kRegionSlots / 4 * 3;       // inserts beyond 
 constexpr int kPartBlock = 1024;
 constexpr int kWaveTile = 256;                                // words of the label stream a wavefront handles at a time
 constexpr int kPartWaves = kPartBlock / 64;
-constexpr int kMaxRegions = 4096;                             // LDS histogram size of passes 1a/1b
+constexpr int kMaxRegions = 4096;
+constexpr int kMaxRouteBlocks = 1024;                         // bins per region: <= 64 per wavefront of pass 2
 constexpr uint32_t kHeadBit = 0x80000000u;
-constexpr uint32_t kMaxPartLabel = kWaveTile / 2;             // longer labels take the generic path
+constexpr uint32_t kMaxPartLabel = kWaveTile / 2 - 8;         // ids; a label is n + 1 stream words: always < half a tile
 constexpr int kWaveHeads = 68;                                // label starts a wavefront records per tile (it takes <= 64 labels per round)
+constexpr int kTagBits = 19;                                  // tag bits carried in H (the table keeps 32)
 
 __device__ __forceinline__ uint64_t region_next(uint64_t s) {
     return (s & ~(uint64_t)(kRegionSlots - 1)) | ((s + 1) & (kRegionSlots - 1));
 }
 
-// ---- pass 1a: hash every label once; remember its region; count label words per (block, region).
-// Block b owns the reads [b*tile, (b+1)*tile) in both 1a and 1b, and writes its histogram row into a
-// region-major matrix mat[region * n_blocks + b]; an exclusive scan of that matrix is then every
-// (region, block) pair's output offset -- no global atomics, and the partition is stable across blocks.
-// The ids of a block's reads are one contiguous range, so a chunk of reads is first STAGED in LDS with
-// 16-byte coalesced loads and the lanes then pick their labels out of LDS.  Reading labels lane-per-read
-// straight from global memory costs one load instruction per id with 64 different cache lines behind
-// it; that address-processing rate, not HBM, bounded the pass (0.30 ms per 16.7 M reads; 0.16 ms staged).
-constexpr int kHistPer = 2;                                   // reads per lane per chunk
-constexpr int kHistChunk = kHistPer * kPartBlock;             // 2048 reads
-constexpr int kStageWords = 15872;                            // 62 KB: two blocks per CU with the 16 KB histogram
+// 16 bytes from a 4-byte-aligned address (global memory takes unaligned vector loads on gfx950)
+struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 ld4(const uint32_t* p) { return *reinterpret_cast<const U4*>(p); }
 
-__global__ void __launch_bounds__(kPartBlock)
-k_part_hist(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t first, uint32_t n,
-            uint32_t tile, uint64_t mask, uint32_t n_regions, uint16_t* __restrict__ reg_of, uint32_t* __restrict__ mat,
-            unsigned long long* n_long, uint32_t* long_list) {
-    __shared__ unsigned int lh[kMaxRegions];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kStageWords + 4];
-    for (uint32_t i = threadIdx.x; i < n_regions; i += kPartBlock) lh[i] = 0;
-    const uint64_t t0 = (uint64_t)blockIdx.x * tile;
-    const uint64_t t1 = (t0 + tile < n) ? t0 + tile : n;
-    for (uint64_t base = t0; base < t1; base += kHistChunk) {
-        const uint64_t cend = (base + kHistChunk < t1) ? base + kHistChunk : t1;
-        // id range of the chunk (uniform): [w_lo, w_hi), staged from the 16-byte boundary at or below
-        // ids + w_lo.  Only 16-byte granules that hold at least one word of the range are touched.
-        const uint32_t w_lo = off[first + (uint32_t)base], w_hi = off[first + (uint32_t)cend];
-        const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(ids + w_lo) >> 2) & 3u);
-        const uint32_t span = w_hi - w_lo + mis;
-        const bool staged = span <= (uint32_t)kStageWords;
-        uint32_t bb[kHistPer], ll[kHistPer];
-#pragma unroll
-        for (int k = 0; k < kHistPer; ++k) {
-            uint64_t i = base + (uint64_t)k * kPartBlock + threadIdx.x;
-            bb[k] = 0; ll[k] = 0;
-            if (i < cend) { uint32_t r = first + (uint32_t)i; bb[k] = off[r]; ll[k] = off[r + 1] - bb[k]; }
-        }
-        __syncthreads();                                      // previous chunk's labels are consumed (and lh is zeroed)
-        if (staged) {
-            const uint4* src = reinterpret_cast<const uint4*>(ids + w_lo - mis);
-            const uint32_t n4 = (span + 3) >> 2;
-            for (uint32_t i = threadIdx.x; i < n4; i += kPartBlock) {
-                const uint4 v = src[i];
-                *reinterpret_cast<uint4*>(stage + 4 * i) = v;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kHistPer; ++k) {
-            uint64_t i = base + (uint64_t)k * kPartBlock + threadIdx.x;
-            if (i >= cend) continue;
-            const uint32_t len = ll[k];
-            uint16_t rg = 0xFFFFu;                           // 0xFFFF: not in the partition buffer
-            if (len > kMaxPartLabel) long_list[atomicAdd(n_long, 1ull)] = first + (uint32_t)i;
-            else if (len != 0) {
-                uint32_t w[kHead];
-                uint64_t h;
-                uint32_t any = 0;                            // OR of the label's ids
-                if (staged) {
-                    const uint32_t* lab = stage + (bb[k] - w_lo + mis);
-                    h = label_mix64([&](uint32_t q) { return lab[q]; }, len, w);
-                    for (uint32_t q = kHead; q < len; ++q) any |= lab[q];
-                } else {
-                    const uint32_t* lab = ids + bb[k];
-                    h = label_mix64([&](uint32_t q) { return lab[q]; }, len, w);
-                    for (uint32_t q = kHead; q < len; ++q) any |= lab[q];
-                }
-#pragma unroll
-                for (int q = 0; q < kHead; ++q) any |= w[q];
-                if (any & kHeadBit) {
-                    // an id >= 2^31 would collide with the label marker of the partition stream: such
-                    // labels (no real transcriptome has them) take the generic kernel, like over-long ones
-                    long_list[atomicAdd(n_long, 1ull)] = first + (uint32_t)i;
-                } else {
-                    rg = (uint16_t)((h & mask) >> kRegionBits);
-                    atomicAdd(&lh[rg], len);
-                }
-            }
-            reg_of[i] = rg;
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_regions; i += kPartBlock) mat[(uint64_t)i * gridDim.x + blockIdx.x] = lh[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) mat[(uint64_t)n_regions * gridDim.x] = 0;      // scan sentinel
-}
-
-// ---- pass 1b: copy the labels into their region segments (first word head-flagged).
-// Writing each label straight to its region would scatter 4-byte stores over n_blocks x n_regions
-// open cache lines (measured: 0.72 ms per 16.7 M reads, no better than the random probes it replaces).
-// Instead a block counting-sorts a sub-tile of its reads by region inside LDS and then writes the sorted
-// buffer out word-parallel, so HBM sees whole 64..128-byte runs and each store instruction few lines.
-// The sub-tile's ids are staged in the sort buffer with coalesced 16-byte loads (see k_part_hist), the
-// lanes lift their labels' first 8 ids into registers, and the same buffer is then refilled in region
-// order -- one LDS buffer serves as both the staging area and the sort destination.
-// Two blocks share a CU (48 KB buffer, <= 64 VGPRs): rocprofv3 shows these passes' wavefronts parked on
-// s_waitcnt / barriers for 60-80 % of their cycles, so a second block that works while the first waits is
-// worth more than longer runs (96 KB buffer, 4096-read sub-tiles, one block per CU: 0.35 -> 0.29 ms).
-// (Tried and dropped: prefetching the next sub-tile into registers during the write-out -- vmcnt counts
-// loads and stores together on gfx9, so the block still waits for its stores to drain.)
+// ---- pass 1: route every label to the bin (region, this block) ------------------------------------------------
+// Writing each label straight to its region would scatter 4-byte stores over n_blocks x n_regions open cache lines
+// (measured in round 1: no better than the random probes it replaces).  Instead a block counting-sorts a sub-tile of
+// its reads by region inside LDS and then writes the sorted buffer out word-parallel, so HBM sees runs and each
+// store instruction few lines.  A thread owns kSubPer reads of the sub-tile: it fetches the first 8 ids of each with
+// two unaligned 16-byte loads (labels are packed back to back, so a wavefront's loads cover one contiguous range),
+// hashes from registers, takes the label's rank inside its region with one LDS atomic, and after the block's scan
+// of the region histogram writes the label into the sort buffer.  The offsets of the NEXT sub-tile are requested
+// while this one is hashed.
 constexpr int kSortWords = 12288;                            // 48 KB LDS sort buffer: two blocks per CU
 constexpr int kSubReads = 2048;                              // reads per sub-tile: 2 per thread (their label heads stay in registers)
 constexpr int kSubPer = kSubReads / kPartBlock;
 
+struct RouteArgs {
+    const uint32_t* ids; const uint32_t* off; uint32_t first, n;
+    uint32_t tile;                         // reads per block
+    uint32_t ids_end;                      // first id index that must not be read (end of the sub-batch's ids)
+    uint64_t mask; uint32_t n_regions;
+    uint32_t cap;                          // words per bin
+    uint32_t* out;                         // bins: bin (r, b) starts at word (r * n_blocks + b) * cap
+    uint32_t* fill;                        // fill[r * n_blocks + b] = words written to bin (r, b)
+    unsigned long long* n_long; uint32_t* long_list;     // reads for the generic kernel
+};
+
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_part_scatter(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uint32_t first, uint32_t n,
-               uint32_t tile, uint32_t n_regions, const uint16_t* __restrict__ reg_of,
-               const uint64_t* __restrict__ offs /* scanned matrix */, uint32_t* __restrict__ out) {
+k_part_route(RouteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* buf = reinterpret_cast<uint32_t*>(smem);                               // kSortWords (+4 slack)
-    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)(kSortWords + 4) * 4);   // n_regions
-    unsigned int* sbase = hist + n_regions;                                          // n_regions + 1
-    unsigned int* gpos = sbase + n_regions + 1;                                      // n_regions: next free word of this block in each region
-    uint16_t* first_reg = reinterpret_cast<uint16_t*>(gpos + n_regions);             // kSortWords / 16 + 1: region of every 16th sorted word
+    const uint32_t NR = a.n_regions;
+    uint32_t* buf = reinterpret_cast<uint32_t*>(smem);                                // kSortWords (+8 slack)
+    unsigned int* hs = reinterpret_cast<unsigned int*>(smem + (size_t)(kSortWords + 8) * 4);   // NR + 1: histogram, then its exclusive scan
+    unsigned int* gpos = hs + NR + 1;                                                 // NR: next free word of my bin (absolute word index)
+    unsigned int* cut = gpos + NR;                                                    // NR: lowered when a label does not fit the bin
+    uint16_t* first_reg = reinterpret_cast<uint16_t*>(cut + NR);                      // kSortWords / 16 + 2: region of every 16th sorted word
     __shared__ unsigned int s_scan[kPartBlock / kWave];
-    __shared__ uint32_t s_end;
-    for (uint32_t i = threadIdx.x; i < n_regions; i += kPartBlock) gpos[i] = (unsigned int)offs[(uint64_t)i * gridDim.x + blockIdx.x];
-    const uint64_t t0 = (uint64_t)blockIdx.x * tile;
-    const uint64_t t1 = (t0 + tile < n) ? t0 + tile : n;
-    const uint32_t per = (n_regions + kPartBlock - 1) / kPartBlock;                  // regions per thread in the scans
-    uint64_t s0 = t0;
-    while (s0 < t1) {
-        // sub-tile [s0, s0 + cnt): at most kSubReads reads whose ids fit the buffer (uniform decision)
-        uint32_t cnt = (uint32_t)((s0 + kSubReads < t1) ? kSubReads : (t1 - s0));
-        const uint32_t w_lo = off[first + (uint32_t)s0];
-        const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(ids + w_lo) >> 2) & 3u);
-        uint32_t w_hi = off[first + (uint32_t)(s0 + cnt)];
-        if (w_hi - w_lo + mis > (uint32_t)kSortWords) {       // rare: halve until it fits (or one read is left)
-            if (threadIdx.x == 0) {
-                uint32_t c = cnt;
-                while (c > 1 && off[first + (uint32_t)(s0 + c)] - w_lo + mis > (uint32_t)kSortWords) c /= 2;
-                s_end = c;
-            }
-            __syncthreads();
-            cnt = s_end;
-            w_hi = off[first + (uint32_t)(s0 + cnt)];
-        }
-        const uint32_t span = w_hi - w_lo + mis;
-        const bool staged = span <= (uint32_t)kSortWords;    // false only for a single over-long label (which is skipped)
-        for (uint32_t i = threadIdx.x; i < n_regions; i += kPartBlock) hist[i] = 0;
-        uint32_t rg[kSubPer], rk[kSubPer], ln[kSubPer], bs[kSubPer];
+    const uint32_t B1 = gridDim.x, blk = blockIdx.x, cap = a.cap, tid = threadIdx.x;
+    for (uint32_t r = tid; r < NR; r += kPartBlock) { gpos[r] = (r * B1 + blk) * cap; cut[r] = 0xFFFFFFFFu; hs[r] = 0; }
+    if (tid == 0) hs[NR] = 0;
+    const uint64_t t0 = (uint64_t)blk * a.tile;
+    const uint64_t t1 = (t0 + a.tile < a.n) ? t0 + a.tile : a.n;
+    const uint32_t per = (NR + kPartBlock - 1) / kPartBlock;                          // regions per thread in the scans
+    const uint32_t* __restrict__ off = a.off + a.first;
+    const uint32_t* __restrict__ ids = a.ids;
+
+    // offsets of the first sub-tile
+    uint32_t nb[kSubPer], ne[kSubPer];
 #pragma unroll
-        for (int k = 0; k < kSubPer; ++k) {
-            const uint32_t j = threadIdx.x + k * kPartBlock;
-            ln[k] = 0; rg[k] = 0xFFFFu; bs[k] = 0;
-            if (j < cnt) {
-                rg[k] = reg_of[s0 + j];
-                const uint32_t r = first + (uint32_t)(s0 + j);
-                bs[k] = off[r]; ln[k] = off[r + 1] - bs[k];
-                if (rg[k] == 0xFFFFu || ln[k] > (uint32_t)kSortWords) ln[k] = 0;     // not partitioned (empty / over-long label)
-            }
-        }
-        if (staged) {
-            const uint4* src = reinterpret_cast<const uint4*>(ids + w_lo - mis);
-            const uint32_t n4 = (span + 3) >> 2;
-            for (uint32_t i = threadIdx.x; i < n4; i += kPartBlock) *reinterpret_cast<uint4*>(buf + 4 * i) = src[i];
-        }
-        __syncthreads();                                      // ids staged, hist zeroed
+    for (int k = 0; k < kSubPer; ++k) {
+        const uint64_t j = t0 + (uint64_t)k * kPartBlock + tid;
+        nb[k] = 0; ne[k] = 0;
+        if (j < t1) { nb[k] = off[j]; ne[k] = off[j + 1]; }
+    }
+    __syncthreads();
+    for (uint64_t s0 = t0; s0 < t1; s0 += kSubReads) {
+        const uint32_t cnt = (uint32_t)((s0 + kSubReads < t1) ? kSubReads : (t1 - s0));
+        uint32_t bs[kSubPer], ln[kSubPer];
+#pragma unroll
+        for (int k = 0; k < kSubPer; ++k) { bs[k] = nb[k]; ln[k] = ne[k] - nb[k]; }
+        // the sub-tile's words (ids + one H per read; uniform): does it fit the sort buffer at once?
+        const uint32_t w_all = off[s0 + cnt] - off[s0] + cnt;
+        const bool one_round = w_all <= (uint32_t)kSortWords;
+        // label heads: first 8 ids of every read, zero past the label
         uint32_t w[kSubPer][kHead];
 #pragma unroll
         for (int k = 0; k < kSubPer; ++k) {
-            rk[k] = 0;
-            if (ln[k]) {
-                rk[k] = atomicAdd(&hist[rg[k]], ln[k]);
-                if (staged) { const uint32_t* lab = buf + (bs[k] - w_lo + mis); label_head([&](uint32_t q) { return lab[q]; }, ln[k], w[k]); }
-                else { const uint32_t* lab = ids + bs[k]; label_head([&](uint32_t q) { return lab[q]; }, ln[k], w[k]); }
+            const uint32_t* lab = ids + bs[k];
+            if (ln[k] != 0 && (uint64_t)bs[k] + 8u <= (uint64_t)a.ids_end) {
+                const U4 x = ld4(lab), y = ld4(lab + 4);
+                w[k][0] = x.x; w[k][1] = x.y; w[k][2] = x.z; w[k][3] = x.w; w[k][4] = y.x; w[k][5] = y.y; w[k][6] = y.z; w[k][7] = y.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < kHead; ++q) w[k][q] = ((uint32_t)q < ln[k]) ? lab[q] : 0u;
             }
+#pragma unroll
+            for (int q = 0; q < kHead; ++q) w[k][q] = ((uint32_t)q < ln[k]) ? w[k][q] : 0u;
         }
-        __syncthreads();                                      // label heads are in registers: the buffer may be overwritten
-        // exclusive scan of hist -> sbase (thread t owns regions [t*per, (t+1)*per))
-        unsigned int mine = 0;
-        for (uint32_t q = 0; q < per; ++q) { uint32_t r = threadIdx.x * per + q; if (r < n_regions) mine += hist[r]; }
-        unsigned int incl = mine;
-        for (int o = 1; o < kWave; o <<= 1) { unsigned int v = __shfl_up(incl, o, kWave); if ((int)(threadIdx.x & (kWave - 1)) >= o) incl += v; }
-        if ((threadIdx.x & (kWave - 1)) == kWave - 1) s_scan[threadIdx.x / kWave] = incl;
-        __syncthreads();
-        unsigned int run = 0;
-        for (int q = 0; q < (int)(threadIdx.x / kWave); ++q) run += s_scan[q];
-        run += incl - mine;
-        for (uint32_t q = 0; q < per; ++q) {
-            uint32_t r = threadIdx.x * per + q;
-            if (r < n_regions) {
-                const unsigned int h = hist[r];
-                sbase[r] = run;
-                // 16-word blocks of the sorted buffer whose first word falls into region r
-                for (uint32_t b = (run + 15u) >> 4; b < ((run + h + 15u) >> 4); ++b) first_reg[b] = (uint16_t)r;
-                run += h;
-            }
-        }
-        if (threadIdx.x == kPartBlock - 1) sbase[n_regions] = run;                   // = words in the sub-tile (sentinel)
-        __syncthreads();
-        // labels -> LDS in region order (ids past the 8th come from global memory: rare)
+        // the next sub-tile's offsets travel while this one is hashed
 #pragma unroll
         for (int k = 0; k < kSubPer; ++k) {
-            if (ln[k] == 0) continue;
-            uint32_t* dst = buf + sbase[rg[k]] + rk[k];
-            dst[0] = w[k][0] | kHeadBit;
+            const uint64_t j = s0 + kSubReads + (uint64_t)k * kPartBlock + tid;
+            nb[k] = 0; ne[k] = 0;
+            if (j < t1) { nb[k] = off[j]; ne[k] = off[j + 1]; }
+        }
+        // hash; labels the partition stream cannot carry go to the generic kernel's list
+        uint32_t rg[kSubPer], hh[kSubPer];
 #pragma unroll
-            for (int q = 1; q < kHead; ++q) if ((uint32_t)q < ln[k]) dst[q] = w[k][q];
-            if (ln[k] > (uint32_t)kHead) { const uint32_t* lab = ids + bs[k]; for (uint32_t q = kHead; q < ln[k]; ++q) dst[q] = lab[q]; }
+        for (int k = 0; k < kSubPer; ++k) {
+            rg[k] = 0; hh[k] = 0;
+            const uint32_t len = ln[k];
+            if (len == 0) continue;
+            uint32_t mx = w[k][0];
+#pragma unroll
+            for (int q = 1; q < kHead; ++q) mx = mx > w[k][q] ? mx : w[k][q];
+            uint64_t h;
+            bool generic = len > kMaxPartLabel;
+            if (len <= (uint32_t)kHead) h = label_mix64_head(w[k], len);
+            else {
+                const uint32_t* lab = ids + bs[k];
+                h = label_mix64_words([&](uint32_t q) { return lab[q]; }, len);
+                if (!generic) for (uint32_t q = kHead; q < len; ++q) { const uint32_t v = lab[q]; mx = mx > v ? mx : v; }
+            }
+            // an id >= 2^31 would collide with the label marker of the partition stream (no real transcriptome has one)
+            generic = generic || (mx & kHeadBit);
+            if (generic) {
+                a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + (uint32_t)(s0 + (uint64_t)k * kPartBlock + tid);
+                ln[k] = 0;
+            } else {
+                rg[k] = (uint32_t)((h & a.mask) >> kRegionBits);
+                hh[k] = ((uint32_t)(h >> (64 - kTagBits)) << kRegionBits) | ((uint32_t)h & (kRegionSlots - 1));
+            }
         }
-        __syncthreads();
-        // write-out, lane i <-> sorted word i: adjacent lanes write adjacent addresses inside a run, so a
-        // store instruction touches a handful of cache lines (one per run it spans) instead of 64.  The
-        // word's region comes from the 16-word block table plus a short walk over region boundaries.
-        const uint32_t total = sbase[n_regions];
-        for (uint32_t i = threadIdx.x; i < total; i += kPartBlock) {
-            uint32_t r = first_reg[i >> 4];
-            while (sbase[r + 1] <= i) ++r;
-            out[gpos[r] + (i - sbase[r])] = buf[i];
+        for (int round = 0; round < (one_round ? 1 : kSubPer); ++round) {
+            // ---- rank inside the region (stream words: n ids + H)
+            uint32_t rk[kSubPer];
+            bool in_round[kSubPer];
+#pragma unroll
+            for (int k = 0; k < kSubPer; ++k) {
+                in_round[k] = ln[k] != 0 && (one_round || k == round);
+                rk[k] = 0;
+                if (in_round[k]) rk[k] = atomicAdd(&hs[rg[k]], ln[k] + 1u);
+            }
+            __syncthreads();
+            // ---- exclusive scan of the histogram, in place (thread t owns regions [t*per, (t+1)*per))
+            unsigned int mine = 0;
+            for (uint32_t q = 0; q < per; ++q) { const uint32_t r = tid * per + q; if (r < NR) mine += hs[r]; }
+            unsigned int incl = mine;
+            for (int o = 1; o < kWave; o <<= 1) { const unsigned int v = __shfl_up(incl, o, kWave); if ((int)(tid & (kWave - 1)) >= o) incl += v; }
+            if ((tid & (kWave - 1)) == kWave - 1) s_scan[tid / kWave] = incl;
+            __syncthreads();
+            unsigned int run = 0;
+            for (int q = 0; q < (int)(tid / kWave); ++q) run += s_scan[q];
+            run += incl - mine;
+            for (uint32_t q = 0; q < per; ++q) {
+                const uint32_t r = tid * per + q;
+                if (r < NR) {
+                    const unsigned int h = hs[r];
+                    hs[r] = run;
+                    // 16-word blocks of the sorted buffer whose first word falls into region r
+                    for (uint32_t bq = (run + 15u) >> 4; bq < ((run + h + 15u) >> 4); ++bq) first_reg[bq] = (uint16_t)r;
+                    run += h;
+                }
+            }
+            if (tid == kPartBlock - 1) hs[NR] = run;                                    // = words in this round (sentinel)
+            __syncthreads();
+            const uint32_t total = hs[NR];
+            if (total > (uint32_t)kSortWords) {
+                // a half sub-tile that still does not fit (labels of > 10 ids on average): the generic kernel takes it
+#pragma unroll
+                for (int k = 0; k < kSubPer; ++k)
+                    if (in_round[k]) { a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + (uint32_t)(s0 + (uint64_t)k * kPartBlock + tid); ln[k] = 0; }
+            } else {
+                // ---- labels -> LDS in region order: [id0 | head][H][id1] ...   (ids past the 8th come from global memory: rare)
+#pragma unroll
+                for (int k = 0; k < kSubPer; ++k) {
+                    if (!in_round[k]) continue;
+                    const uint32_t len = ln[k];
+                    const uint32_t at = gpos[rg[k]] + rk[k];
+                    if (at + len + 1u > (rg[k] * B1 + blk + 1u) * cap) {                  // does not fit the bin: this label and all later ones of the run
+                        atomicMin(&cut[rg[k]], at);
+                        a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + (uint32_t)(s0 + (uint64_t)k * kPartBlock + tid);
+                        ln[k] = 0;
+                        continue;
+                    }
+                    uint32_t* dst = buf + hs[rg[k]] + rk[k];
+                    dst[0] = w[k][0] | kHeadBit;
+                    dst[1] = hh[k];
+#pragma unroll
+                    for (int q = 1; q < kHead; ++q) if ((uint32_t)q < len) dst[q + 1] = w[k][q];
+                    if (len > (uint32_t)kHead) { const uint32_t* lab = ids + bs[k]; for (uint32_t q = kHead; q < len; ++q) dst[q + 1] = lab[q]; }
+                    ln[k] = one_round ? len : 0u;                                       // done (the flag only matters in two-round mode)
+                }
+                __syncthreads();
+                // ---- write-out, lane i <-> sorted word i: adjacent lanes write adjacent addresses inside a run
+                for (uint32_t i = tid; i < total; i += kPartBlock) {
+                    uint32_t r = first_reg[i >> 4];
+                    while (hs[r + 1] <= i) ++r;
+                    const uint32_t pos = gpos[r] + (i - hs[r]);
+                    if (pos < cut[r]) a.out[pos] = buf[i];
+                }
+            }
+            __syncthreads();
+            for (uint32_t r = tid; r < NR; r += kPartBlock) {
+                const unsigned int end = gpos[r] + (hs[r + 1] - hs[r]);
+                const unsigned int c = cut[r];
+                if (total <= (uint32_t)kSortWords) gpos[r] = end < c ? end : c;
+                cut[r] = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            for (uint32_t r = tid; r < NR; r += kPartBlock) hs[r] = 0;                   // (hs[r + 1] of the neighbour was read above)
+            if (tid == 0) hs[NR] = 0;
+            __syncthreads();
         }
-        __syncthreads();
-        for (uint32_t r = threadIdx.x; r < n_regions; r += kPartBlock) gpos[r] += hist[r];
-        __syncthreads();
-        s0 += cnt;
     }
+    for (uint32_t r = tid; r < NR; r += kPartBlock) a.fill[(uint64_t)r * B1 + blk] = gpos[r] - (r * B1 + blk) * cap;
 }
 
 struct PartArgs {
     uint64_t* table;                       // {word, count} pairs
-    const uint64_t* offs; uint32_t n_blocks;   // scanned (region, block) matrix: region r starts at offs[r * n_blocks]
-    const uint32_t* words;                 // partition buffer (labels, head-flagged)
+    const uint32_t* words;                 // bins (labels: [id0 | head][H][id1] ...)
+    const uint32_t* fill; uint32_t n_blocks; uint32_t cap;     // region r: bins (r, 0 .. n_blocks), fill words each
     uint64_t* cls_hash; uint64_t* cls_off; uint32_t* cls_len; uint32_t* cls_slot; uint32_t* arena;
     unsigned long long* ctr;               // CTR_* counters (classes / arena cursor / deferred)
-    uint32_t* deferred;                    // global word offsets of labels that found their region full
+    uint32_t* deferred;                    // (word index of the label in `words`, length) of labels that found their region full
     uint64_t base_classes;                 // classes committed before this launch
 };
 
-// label at `p` (first word head-flagged) of `len` words against the stored representative
-__device__ __forceinline__ bool stream_label_equals(const uint32_t* a /*label, head masked by caller*/, uint32_t a0,
-                                                    const uint32_t* rep, uint32_t len) {
-    if ((rep[0] & ~kHeadBit) != a0) return false;
-    for (uint32_t i = 1; i < len; ++i) if (rep[i] != a[i]) return false;
-    return true;
-}
-
 // ---- pass 2: one block per region
-// The 16 wavefronts of the block split the region's segment into equal word ranges; a label belongs to
-// the wavefront whose range holds its first word.  Each wavefront works alone: 256 words -> registers
-// (four coalesced loads) -> its private LDS tile; label starts are found with wave ballots (no scan,
-// no barrier); lane j takes the tile's j-th label.  The only block-wide synchronisation is before and
-// after the streaming loop, so the 32 wavefronts resident on a CU hide each other's memory latency.
+// A slot word is tag(32) | rep(32) in the table.  While a launch runs, the slot of a class CREATED by it is
+// provisional: tag(19) | length(13) | position of its label in the bins (bit 31 clear); it is rewritten with the full
+// tag and the arena entry when the block commits its new classes.  Probing compares the 19 tag bits H carries.
+// Wavefront w streams the bins w, w + 16, ... of the region, 256 words at a time: four coalesced loads -> its private
+// LDS tile; label starts are found with wave ballots (no scan, no barrier); lane j takes the tile's j-th label.  The
+// only block-wide synchronisation is before and after the streaming loop.
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_insert(PartArgs a) {
     __shared__ unsigned long long lw[kRegionSlots];     // slot words
     __shared__ unsigned int lc[kRegionSlots];           // count deltas of this launch
-    __shared__ uint32_t wtile[kPartWaves][kWaveTile + 4];
+    __shared__ uint32_t wtile[kPartWaves][kWaveTile + 12];
     __shared__ uint16_t heads[kPartWaves][kWaveHeads];  // per-wave lists of the first label starts of the tile
     __shared__ uint32_t new_info[kRegionLimit];         // classes created by this block: slot | len << 16
     __shared__ unsigned int s_occ, s_nnew, s_newwords, s_cid0;
     __shared__ unsigned long long s_arena0;
     const uint32_t region = blockIdx.x;
     const uint64_t rb = (uint64_t)region * kRegionSlots;
-    const uint64_t seg0 = a.offs[(uint64_t)region * a.n_blocks];
-    const uint32_t n_words = (uint32_t)(a.offs[(uint64_t)(region + 1) * a.n_blocks] - seg0);
-    if (n_words == 0) return;
-    const uint32_t* __restrict__ seg = a.words + seg0;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // this wavefront's bins: lane t holds the fill of bin wave + 16 t
+    const uint32_t my_bin = wave + kPartWaves * lane;
+    const uint32_t my_fill = (my_bin < a.n_blocks) ? a.fill[(uint64_t)region * a.n_blocks + my_bin] : 0u;
 
     unsigned int occ_local = 0;
     for (uint32_t s = threadIdx.x; s < kRegionSlots; s += kPartBlock) {
@@ -300,26 +284,34 @@ k_part_insert(PartArgs a) {
     if (occ_local) atomicAdd(&s_occ, occ_local);
     __syncthreads();
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* tile = wtile[wave];
     uint16_t* wh = heads[wave];
-    const uint32_t w_beg = (uint32_t)((uint64_t)n_words * wave / kPartWaves);
-    const uint32_t w_end = (uint32_t)((uint64_t)n_words * (wave + 1) / kPartWaves);
-    uint32_t pos = w_beg;
-    // word i of a tile = q * 64 + lane: each of the four loads is one coalesced 256-byte access.  The
-    // NEXT tile's words are requested as soon as this tile's label starts are known, i.e. before the
-    // hash / probe / compare of this tile's labels: its round trip hides behind theirs.
-    uint32_t tw[4];
-    auto request = [&](uint32_t at, uint32_t (&dst)[4]) {
-        const uint32_t len = (n_words - at < (uint32_t)kWaveTile) ? (n_words - at) : (uint32_t)kWaveTile;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint32_t i = q * 64 + lane; dst[q] = (i < len) ? seg[at + i] : 0u; }
+    const unsigned long long have = __ballot(my_fill != 0u);
+    auto next_bin = [&](int after) -> int {             // first bin t > after with words in it, -1 if none
+        const unsigned long long m = (after >= 63) ? 0ull : (have & (~0ull << (after + 1)));
+        return m ? (int)__builtin_ctzll(m) : -1;
     };
-    if (pos < w_end) request(pos, tw);
-    while (pos < w_end) {
+    int t = next_bin(-1);
+    uint32_t seg0 = 0, n_words = 0, pos = 0;             // current bin: first word (index into a.words), words, position
+    // word i of a tile = q * 64 + lane: each of the four loads is one coalesced 256-byte access.  The NEXT tile's
+    // words (of this bin or of the wavefront's next bin) are requested as soon as this tile's label starts are known,
+    // i.e. before the probe / compare of this tile's labels: its round trip hides behind theirs.
+    uint32_t tw[4] = {0u, 0u, 0u, 0u};
+    auto request = [&](uint32_t s0, uint32_t nw, uint32_t at, uint32_t (&dst)[4]) {
+        const uint32_t len = (nw - at < (uint32_t)kWaveTile) ? (nw - at) : (uint32_t)kWaveTile;
+        const uint32_t* __restrict__ p = a.words + s0 + at;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t i = q * 64 + lane; dst[q] = (i < len) ? p[i] : 0u; }
+    };
+    if (t >= 0) {
+        seg0 = ((uint32_t)region * a.n_blocks + wave + kPartWaves * (uint32_t)t) * a.cap;
+        n_words = __shfl(my_fill, t, kWave);
+        request(seg0, n_words, 0u, tw);
+    }
+    while (t >= 0) {
         const uint32_t tlen = (n_words - pos < (uint32_t)kWaveTile) ? (n_words - pos) : (uint32_t)kWaveTile;
         const bool final_tile = (pos + tlen == n_words);
-        uint32_t nh = 0, in_range = 0;
+        uint32_t nh = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = q * 64 + lane;
@@ -329,78 +321,83 @@ k_part_insert(PartArgs a) {
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             if (is_head && nh + before < (uint32_t)kWaveHeads) wh[nh + before] = (uint16_t)i;
             nh += (uint32_t)__popcll(bal);
-            // label starts that belong to this wavefront (first word before w_end)
-            in_range += (uint32_t)__popcll(__ballot(is_head && pos + i < w_end));
         }
+        if (lane < 8u) tile[kWaveTile + lane] = 0u;           // the compare reads up to 7 words past a label
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the tile's last label may continue past the tile: leave it for the next round
+        // the tile's last label may continue past the tile: leave it for the next round.  At most one label per lane
+        // per round: the labels past the 64th are picked up by the next (overlapping) tile.
         const uint32_t n_whole = final_tile ? nh : (nh > 0 ? nh - 1 : 0);
-        // at most one label per lane per round: a second, mostly idle pass over the tile would cost as much
-        // as a full one -- the labels past the 64th are simply picked up by the next (overlapping) tile
-        uint32_t n_proc = n_whole < in_range ? n_whole : in_range;
-        if (n_proc > 64u) n_proc = 64u;
-        // where the next tile starts: at the first label that is not processed now; stop once that label is
-        // another wavefront's.  Labels are <= kMaxPartLabel = half a tile, so a full tile always holds >= 2
-        // label starts and advances.
-        uint32_t next_pos; bool more;
-        if (n_proc < in_range) { const uint32_t adv = wh[n_proc]; next_pos = pos + (adv ? adv : tlen); more = true; }
-        else if (n_proc < nh || final_tile) { next_pos = pos; more = false; }     // the next label start lies at or beyond w_end (or the segment ended)
-        else { next_pos = pos + tlen; more = true; }                             // no label start left in this tile (cannot happen for full tiles)
-        more = more && next_pos < w_end;
+        const uint32_t n_proc = n_whole < 64u ? n_whole : 64u;
+        // where the next tile starts: at the first label that is not processed now.  Labels are < half a tile, so a
+        // full tile always holds >= 2 label starts and advances.
+        int nt = t; uint32_t nseg0 = seg0, nn_words = n_words, npos = pos;
+        if (n_proc < nh) npos = pos + wh[n_proc];
+        else if (!final_tile) npos = pos + tlen;           // (cannot happen for full tiles: the last start is never whole)
+        else {                                               // this bin is done: the wavefront's next one
+            nt = next_bin(t);
+            if (nt >= 0) {
+                nseg0 = ((uint32_t)region * a.n_blocks + wave + kPartWaves * (uint32_t)nt) * a.cap;
+                nn_words = __shfl(my_fill, nt, kWave); npos = 0;
+            }
+        }
         uint32_t nw[4] = {0u, 0u, 0u, 0u};
-        if (more) request(next_pos, nw);
-        for (uint32_t l = lane; l < n_proc; l += 64) {
-            const uint32_t st = wh[l];
-            const uint32_t en = (l + 1 < nh) ? wh[l + 1] : tlen;
-            const uint32_t len = en - st;
+        if (nt >= 0) request(nseg0, nn_words, npos, nw);
+        if (lane < n_proc) {
+            const uint32_t st = wh[lane];
+            const uint32_t en = (lane + 1 < nh) ? wh[lane + 1] : tlen;
+            const uint32_t len = en - st - 1u;               // ids (the stream label is [id0|head][H][id1]...)
             const uint32_t* lab = tile + st;
-            const uint32_t w0 = lab[0] & ~kHeadBit;
+            const uint32_t H = lab[1];
+            const uint32_t tagq = H >> kRegionBits;
+            uint32_t s = H & (kRegionSlots - 1);
+            // first 7 ids for the 16-byte compares, zero past the label (word k of the label is lab[k + 1] for k >= 1)
             uint32_t hw8[kHead];
-            const uint64_t h = label_mix64([&](uint32_t k) { return k ? lab[k] : w0; }, len, hw8);
-            const uint64_t tag = h >> 32;
-            uint32_t s = (uint32_t)h & (kRegionSlots - 1);
+            hw8[0] = lab[0] & ~kHeadBit;
+#pragma unroll
+            for (int k = 1; k < kHead; ++k) { const uint32_t v = lab[k + 1]; hw8[k] = ((uint32_t)k < len) ? v : 0u; }
+            const uint32_t here = seg0 + pos + st;           // where this label sits in the bins
             // Probe in two stages so that a wavefront pays the global round trip of the label compare ONCE:
-            // (1) walk the LDS slots until an empty slot or a tag match (LDS only: lanes that need a few
-            // more steps cost nothing), (2) claim or compare.  With the compare inside the walk, every
-            // extra step of any lane repeated the global load for the whole wavefront.
+            // (1) walk the LDS slots until an empty slot or a tag match (LDS only), (2) claim or compare.
             uint32_t probes = 0;
             for (;;) {
                 unsigned long long w = lw[s];
-                while (w != kEmpty && (w >> 32) != tag && probes < kRegionSlots) {
+                while (w != kEmpty && (uint32_t)(w >> (64 - kTagBits)) != tagq && probes < kRegionSlots) {
                     s = (s + 1) & (kRegionSlots - 1); ++probes; w = lw[s];
                 }
                 if (probes >= kRegionSlots) {                                             // cannot place: defer
-                    a.deferred[atomicAdd(&a.ctr[CTR_DEFER], 1ull)] = (uint32_t)(seg0 + pos + st);
+                    const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull);
+                    a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len;
                     break;
                 }
                 if (w == kEmpty) {
                     if (atomicAdd(&s_occ, 1u) >= kRegionLimit) {                              // region full: defer
                         atomicSub(&s_occ, 1u);
-                        a.deferred[atomicAdd(&a.ctr[CTR_DEFER], 1ull)] = (uint32_t)(seg0 + pos + st);
+                        const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull);
+                        a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len;
                         break;
                     }
-                    unsigned long long me = (tag << 32) | (unsigned long long)(uint32_t)(seg0 + pos + st);
-                    unsigned long long old = atomicCAS(&lw[s], (unsigned long long)kEmpty, me);
+                    const unsigned long long me = ((unsigned long long)tagq << (64 - kTagBits)) | ((unsigned long long)len << 32) | (unsigned long long)here;
+                    const unsigned long long old = atomicCAS(&lw[s], (unsigned long long)kEmpty, me);
                     if (old == kEmpty) { new_info[atomicAdd(&s_nnew, 1u)] = s | (len << 16); atomicAdd(&lc[s], 1u); break; }
                     atomicSub(&s_occ, 1u);
                     w = old;
-                    if ((w >> 32) != tag) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
+                    if ((uint32_t)(w >> (64 - kTagBits)) != tagq) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
                 }
                 // tag match: full label compare
                 const uint32_t rep = (uint32_t)w;
                 bool same;
                 if (rep & kArenaBit) {
-                    same = entry_equals(a.arena, rep & ~kArenaBit, [&](uint32_t k) { return lab[k]; }, hw8, len);
+                    same = entry_equals(a.arena, rep & ~kArenaBit, [&](uint32_t k) { return lab[k + 1]; }, hw8, len);
                 } else {
-                    // a label of this launch: `rep` words into the partition buffer; equal iff the first
-                    // `len` words match and the representative ends there (next word is a head or the end).
-                    // Its first 4 words and the word behind it are requested together: one round trip for most labels.
-                    const uint32_t* p = a.words + rep;
-                    const uint64_t rep_end = (uint64_t)rep + len;
-                    same = stream_label_equals(lab, w0, p, len) &&
-                           (rep_end >= seg0 + n_words || (a.words[rep_end] & kHeadBit));
+                    // a class of this launch: its label sits in the bins at `rep`, its length in the slot word
+                    same = ((uint32_t)(w >> 32) & 0x1FFFu) == len;
+                    if (same) {
+                        const uint32_t* p = a.words + rep;
+                        same = (p[0] & ~kHeadBit) == hw8[0];
+                        for (uint32_t k = 1; same && k < len; ++k) same = p[k + 1] == lab[k + 1];
+                    }
                 }
                 if (same) { atomicAdd(&lc[s], 1u); break; }
                 s = (s + 1) & (kRegionSlots - 1); ++probes;
@@ -408,14 +405,13 @@ k_part_insert(PartArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                      // all lanes are done with the tile before it is refilled
-        if (!more) break;
-        pos = next_pos;
+        t = nt; seg0 = nseg0; n_words = nn_words; pos = npos;
 #pragma unroll
         for (int q = 0; q < 4; ++q) tw[q] = nw[q];
     }
     __syncthreads();
 
-    // ---- commit the classes this block created: ids, arena space, labels, slot re-pointing
+    // ---- commit the classes this block created: ids, arena space, labels, hashes, slot re-pointing
     const uint32_t n_new = s_nnew;
     if (n_new) {
         for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, entry_words(new_info[i] >> 16));
@@ -434,10 +430,13 @@ k_part_insert(PartArgs a) {
             const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
             const uint32_t* p = a.words + rep;
             const uint32_t w0 = p[0] & ~kHeadBit;
-            entry_write(a.arena, dst, [&](uint32_t k) { return k ? p[k] : w0; }, len);
-            a.cls_hash[cid] = xxh64_words([&](uint32_t k) { return k ? p[k] : w0; }, len);
+            auto word = [&](uint32_t k) { return k ? p[k + 1] : w0; };
+            entry_write(a.arena, dst, word, len);
+            a.cls_hash[cid] = xxh64_words(word, len);
             a.cls_off[cid] = dst + 1; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
-            lw[s] = (w & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)(dst >> 2));
+            uint32_t tmp[kHead];
+            const uint64_t h = label_mix64(word, len, tmp);                               // the table keeps the full 32-bit tag
+            lw[s] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)(dst >> 2));
         }
     }
     __syncthreads();
@@ -448,16 +447,12 @@ k_part_insert(PartArgs a) {
     }
 }
 
-// deferred labels (region full): copy them out of the partition buffer into a small CSR batch that the
-// generic path can insert after the table has grown
-__global__ void k_deferred_lens(uint64_t n, const uint32_t* __restrict__ deferred, const uint32_t* __restrict__ words,
-                                uint64_t total_words, uint32_t* lens) {
+// deferred labels (region full): copy them out of the bins into a small CSR batch that the generic path can insert
+// after the table has grown.  deferred[2 i] = word index of the label in the bins, deferred[2 i + 1] = its length.
+__global__ void k_deferred_lens(uint64_t n, const uint32_t* __restrict__ deferred, uint32_t* lens) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    if (i == n) { lens[i] = 0; return; }
-    uint64_t at = deferred[i]; uint32_t len = 1;
-    while (at + len < total_words && !(words[at + len] & kHeadBit)) ++len;
-    lens[i] = len;
+    lens[i] = (i == n) ? 0u : deferred[2 * i + 1];
 }
 __global__ void k_deferred_copy(uint64_t n, const uint32_t* __restrict__ deferred, const uint32_t* __restrict__ words,
                                 const uint64_t* __restrict__ off64, uint32_t* ids_out, uint32_t* off_out) {
@@ -466,10 +461,10 @@ __global__ void k_deferred_copy(uint64_t n, const uint32_t* __restrict__ deferre
     off_out[i] = (uint32_t)off64[i];
     if (i == n) return;
     uint32_t len = (uint32_t)(off64[i + 1] - off64[i]);
-    const uint32_t* p = words + deferred[i];
+    const uint32_t* p = words + deferred[2 * i];
     uint32_t* q = ids_out + off64[i];
     q[0] = p[0] & ~kHeadBit;
-    for (uint32_t k = 1; k < len; ++k) q[k] = p[k];
+    for (uint32_t k = 1; k < len; ++k) q[k] = p[k + 1];
 }
 
 }  // namespace sfgpu

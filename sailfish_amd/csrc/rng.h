@@ -26,10 +26,14 @@ struct Philox {
     uint32_t out[4];
     int have;   // unread words in out[]
 
+    // (seed, stream, substream) name one sequence; the BLOCK counter has a counter word of its own (ctr[0]), so that no
+    // two sequences ever share a block.  (Round 1 advanced the word that also held the substream: block k of substream
+    // d was block 0 of substream d + k -- consecutive bootstrap draws, and consecutive classes of a Gibbs chain, shared
+    // random numbers.  Found by the two-sample tests against the reference's MultinomialSampler, tests/test_ref_units.py.)
     SF_HD void init(uint64_t seed, uint64_t stream, uint64_t substream) {
-        key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
-        ctr[0] = (uint32_t)stream; ctr[1] = (uint32_t)(stream >> 32);
-        ctr[2] = (uint32_t)substream; ctr[3] = (uint32_t)(substream >> 32) ^ 0x5AF15u;
+        key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32) ^ ((uint32_t)(substream >> 32) * 0x9E3779B1u);
+        ctr[0] = 0u; ctr[1] = (uint32_t)substream;
+        ctr[2] = (uint32_t)stream; ctr[3] = (uint32_t)(stream >> 32) ^ 0x5AF15u;
         have = 0;
     }
     SF_HD static void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
@@ -46,8 +50,7 @@ struct Philox {
             k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
         }
         out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-        // the low counter word advances per block; the stream id lives in the other words
-        if (++ctr[2] == 0) ++ctr[3];
+        ++ctr[0];                                   // 2^32 blocks per sequence; the sequence id lives in the other words
         have = 4;
     }
     SF_HD uint32_t next32() { if (have == 0) block(); return out[--have]; }

@@ -186,25 +186,35 @@ def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu):
     plan = [m for m in logs if "gibbs:" in m][-1]
     K = int(plan.split(" tiles in ")[1].split()[0]); n_wide = int(plan.split(" phases, ")[1].split()[0])
     assert K >= 2 and n_wide >= 3, plan
-    g = g.cpu().numpy()[n_chains * burn:]                           # sample s = chain s % n_chains after s // n_chains + 1 rounds
+    # Chains are sticky: with priorAlpha = 1e-8 a transcript whose count reaches 0 practically never gets a read back, so
+    # chains settle into different supports and ONE sequential chain is not comparable with an average over chains.
+    # Both samplers are therefore run as many independent chains from the same start (initCountMap_ from the EM's mass)
+    # and compared through their per-chain late means: same rounds, z-test with the between-chain variances.
+    g = g.cpu().numpy().reshape(rounds, n_chains, M)                # sample s = chain s % n_chains after s // n_chains + 1 rounds
+    assert np.all(g.sum(2) == R)
+    gm = g[burn:].mean(0)                                           # [n_chains, M]
     rp, ii, cc, _ = v.to_numpy()
-    S_o, burn_o = 3000, 600
-    orc, og = O.gibbs(eff, p.mass.cpu().numpy(), rp.astype(np.uint64), ii, cc, R, S_o, seed=3)
-    assert orc == 0
-    og = og[burn_o:]
-    assert np.all(g.sum(1) == R) and np.all(og.sum(1) == R)
-    mo, so = og.mean(0), og.std(0)
-    mg, sg = g.mean(0), g.std(0)
-    # the sequential chain is autocorrelated: its mean carries an error of a few so / sqrt(effective samples); the bound
-    # below is ~6 standard errors at an effective sample size of ~150, plus one read
-    tol = 0.5 * so + 0.004 * mo + 1.0
-    bad = np.flatnonzero(np.abs(mg - mo) > tol)
-    assert bad.size <= M // 500, (bad[:10], mg[bad[:10]], mo[bad[:10]], so[bad[:10]])
-    # spread: transcripts whose count really moves must move alike in both samplers
-    mv = so > 4.0
-    assert mv.sum() > 100
-    ratio = sg[mv] / so[mv]
-    assert 0.8 < float(np.median(ratio)) < 1.25 and float(np.mean((ratio > 0.5) & (ratio < 2.0))) > 0.97
-    # members of the wide classes are part of it
-    wt = np.unique(np.concatenate(wide))
-    assert np.all(np.abs(mg[wt] - mo[wt]) <= tol[wt] + 0.5 * so[wt])
+    mass = p.mass.cpu().numpy()
+    n_oc = 64
+    om = []
+    for c in range(n_oc):
+        orc, og = O.gibbs(eff, mass, rp.astype(np.uint64), ii, cc, R, rounds, seed=1000 + c)
+        assert orc == 0 and np.all(og.sum(1) == R)
+        om.append(og[burn:].mean(0))
+    om = np.stack(om)                                               # [n_oc, M]
+    mg, mo = gm.mean(0), om.mean(0)
+    vg, vo = gm.var(0, ddof=1), om.var(0, ddof=1)
+    # transcripts whose count is the same in every chain of both samplers (only singleton classes, or none): exact
+    fixed = (vg == 0) & (vo == 0)
+    assert fixed.sum() > 0 and np.array_equal(mg[fixed], mo[fixed])
+    z = (mg - mo) / np.sqrt(vg / n_chains + vo / n_oc + 0.02)
+    assert float(np.mean(np.abs(z) > 4.0)) < 0.01 and float(np.max(np.abs(z))) < 8.0, (np.sort(np.abs(z))[-10:],)
+    assert abs(float(np.mean(z))) < 0.15                            # no systematic shift
+    # spread between chains: transcripts that really differ from chain to chain do so alike in both samplers
+    mv = vo > 9.0
+    assert mv.sum() > 50
+    ratio = np.sqrt(vg[mv] / vo[mv])
+    assert 0.8 < float(np.median(ratio)) < 1.25 and float(np.mean((ratio > 0.5) & (ratio < 2.0))) > 0.95
+    # the share of chains in which a transcript ends without reads (the sticky state) agrees
+    wt = np.unique(np.concatenate(wide))                           # members of the wide classes are part of it
+    assert float(np.max(np.abs(z[wt]))) < 6.0

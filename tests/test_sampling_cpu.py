@@ -72,3 +72,42 @@ def test_binomial_edges(H):
     H.draw_binomial(1, 0, 0.5, 10, x.ctypes.data); assert np.all(x == 0)
     H.draw_binomial(1, 77, 0.0, 10, x.ctypes.data); assert np.all(x == 0)
     H.draw_binomial(1, 77, 1.0, 10, x.ctypes.data); assert np.all(x == 77)
+
+
+def test_sequences_share_no_block(H):
+    """(seed, stream, substream) sequences are disjoint: neighbouring substreams (consecutive bootstrap draws, consecutive
+    classes of a Gibbs chain) and neighbouring streams must not run into each other when a sequence needs many blocks"""
+    H.draw_uniform_sub.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+    seqs = {}
+    for stream in (5, 6, (1 << 32) | 5):
+        for sub in (0, 1, 2, 3, 1 << 32, (1 << 32) + 1):
+            u = np.zeros(4096)
+            H.draw_uniform_sub(77, stream, sub, len(u), u.ctypes.data)
+            seqs[(stream, sub)] = u
+    keys = list(seqs)
+    for i, a in enumerate(keys):
+        for b in keys[i + 1:]:
+            assert len(np.intersect1d(seqs[a], seqs[b])) == 0, (a, b)
+
+
+def test_multinomial_tree_draws_are_independent(H):
+    """the bootstrap's resample (csrc/sampling.hip, restated node for node in the harness): pooled over the draws of one
+    seed the category totals must fit n p -- correlated draws (round 1: consecutive draws shared random numbers) inflate
+    the pooled statistic, which shows as a non-uniform p-value distribution over seeds"""
+    H.tree_multinomial.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(4)
+    k, n = 150, 60000
+    p = rng.random(k); p /= p.sum()
+    cnt = np.floor(p * n + 0.5).astype(np.int64); cnt[np.argmax(cnt)] += n - cnt.sum()
+    q = cnt / n
+    prefix = np.zeros(k + 1, np.uint64); prefix[1:] = np.cumsum(cnt)
+    ps = []
+    for seed in range(200, 240):
+        tot = np.zeros(k, np.int64)
+        for d in range(24):
+            out = np.zeros(k, np.uint32)
+            H.tree_multinomial(seed, d, k, prefix.ctypes.data, n, out.ctypes.data)
+            assert out.sum() == n
+            tot += out
+        ps.append(stats.chisquare(tot, q * tot.sum()).pvalue)
+    assert stats.kstest(ps, "uniform").pvalue > 1e-3 and min(ps) > 1e-5, (min(ps),)
