@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--em-mode", default="auto", choices=["auto", "replicated", "sharded"])
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank gets its own R reads (weak scaling) instead of R/N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-pinned", action="store_true", help="skip the leg that re-runs the step with the hit lists in pinned host memory")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--one-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -205,6 +206,39 @@ def main():
 
     total_reads = R_total * a.steps
     value = total_reads / dt
+
+    # ---- the same step with the hit lists in HOST-PINNED memory (SURVEY 8d / BASELINE.md "Timed region": packed hit lists
+    # resident in host-pinned memory -> ... -> TPM).  sfgpu_eq_add_batch_host streams the batch through two device staging
+    # buffers (copy of chunk k + 1 on its own stream while chunk k is built), so the step costs its PCIe transfer plus
+    # the build of the last chunk plus EM.  PCIe-inclusive: reported next to `value`, never as `value`.
+    host_leg = None
+    if not a.no_host_pinned:
+        try:
+            h_ids = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True); h_ids.copy_(ids)
+            h_off = torch.empty(off.shape, dtype=off.dtype, pin_memory=True); h_off.copy_(off)
+            torch.cuda.synchronize()
+            hsteps = max(1, min(a.steps, 3))
+            infoh = quant.run(h_ids, h_off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))      # warm-up (staging buffers)
+            barrier()
+            th0 = time.perf_counter(); tb = 0.0
+            for _ in range(hsteps):
+                infoh = quant.run(h_ids, h_off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))
+                tb += infoh["t_build_ms"]
+            barrier()
+            dth = time.perf_counter() - th0
+            if dist:
+                t = torch.tensor([dth], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dth = float(t.item())
+            same = bool(infoh["n_classes"] == info["n_classes"] and infoh["nnz"] == info["nnz"] and
+                        infoh["em_stats"]["iters"] == info["em_stats"]["iters"])
+            nbytes = (ids.numel() + off.numel()) * 4
+            host_leg = dict(value=R_total * hsteps / dth, unit="reads/s", steps=hsteps, ms_per_step=dth / hsteps * 1e3,
+                            class_build_ms=tb / hsteps, h2d_bytes_per_gpu=nbytes, pcie_gbps_per_gpu=nbytes / (tb / hsteps * 1e-3) / 1e9,
+                            same_result_as_hbm_resident_step=same)
+            del h_ids, h_off
+        except Exception as e:                    # never take the headline line down
+            host_leg = dict(error=repr(e))
     st = info["em_stats"]
     C, L = info["n_classes"], info["nnz"]
 
@@ -221,7 +255,7 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs of
     # this same command; FETCH_SIZE x2 for the wide streaming loads of the sweep, raw for the random
     # probes of the insert kernel -- see profiles/r1*_pmc_summary.md).  null when no profile matches.
-    traffic_em = traffic_ins = None
+    traffic_em = traffic_ins = traffic_src = None
     try:
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{a.workload}.json")
         if not os.path.exists(pmc_path):
@@ -229,24 +263,27 @@ def main():
         pmc = json.load(open(pmc_path))
         if pmc.get("workload") == a.workload and world == 1:
             k = pmc["kernels"]
+            bytes_of = lambda e: ((2 if e.get("fetch_x2") else 1) * e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
             e = k.get("k_sweep_lds<true>" if use_vbem else "k_sweep_lds<false>")
             if e:
-                traffic_em = (2 * e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
-            # class build = the three partition kernels of one sub-batch (k_insert on the generic path)
-            parts = [k[n] for n in ("k_part_hist", "k_part_scatter", "k_part_insert") if n in k] or \
-                    [k[n] for n in ("k_insert",) if n in k]
+                traffic_em = bytes_of(e)
+            # class build = the partition kernels of one sub-batch (k_insert on the generic path)
+            parts = [k[n] for n in ("k_part_route", "k_part_insert") if n in k] or [k[n] for n in ("k_insert",) if n in k]
             if parts:
-                traffic_ins = sum(e["fetch_kib_per_launch"] + e["write_kib_per_launch"] for e in parts) * 1024
+                traffic_ins = sum(bytes_of(e) for e in parts)
+            # not re-measured by this run: it comes from the committed PMC passes of the same command
+            traffic_src = f"{os.path.relpath(pmc_path, ROOT)} ({pmc.get('source', '?')}; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+                          f"FETCH x2 for 16-B-per-lane streaming kernels)"
     except (OSError, ValueError, KeyError):
         pass
     n_ins = max(int(info["insert_launches"]), 1)
     ins_ms = info["t_insert_ms"] / n_ins
     roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                   unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em,
+                   unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em, traffic_source=traffic_src,
                    bytes_per_launch=b_iter, avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
     roof_build = dict(bound="hbm", kernel=info.get("insert_kernels", "k_insert"), achieved=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      frac=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins,
+                      frac=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins, traffic_source=traffic_src,
                       bytes_per_launch=b_read * R_local / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins)
     dominant = roof_em if sweep_ms * st["iters"] >= info["t_insert_ms"] else roof_build
 
@@ -267,6 +304,9 @@ def main():
         "class_build_reads_per_s": R_local / (build_ms * 1e-3),
         "roofline": dominant, "roofline_em_sweep": roof_em, "roofline_class_build": roof_build,
     }
+    if host_leg is not None:
+        out["value_host_pinned"] = host_leg.get("value")
+        out["host_pinned"] = host_leg
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(ref_len_np, ids, off, a.cpu_seconds, use_vbem)

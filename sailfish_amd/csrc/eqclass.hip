@@ -311,6 +311,8 @@ struct sfgpu_eq {
     unsigned long long* d_ctr = nullptr;
     unsigned long long* h_ctr = nullptr;  // pinned
     DevBuf<uint32_t> stage_ids, stage_off;
+    DevBuf<uint32_t> stage2_ids[2], stage2_off[2];          // large host batches: double-buffered chunks
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[2] = {nullptr, nullptr};
     // sfgpu_eq_add_batch_host: small host batches (the mapper threads hand over ~1000 reads at a time) are
     // appended to ONE pinned CSR and built kAccReads at a time -- a launch per 1000 reads would cap the
     // builder at a few million reads/s; the copy is one large pinned H2D transfer per flush
@@ -357,7 +359,13 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
     return SFGPU_OK;
 }
 
+constexpr uint32_t kHostChunkReads = 1u << 24;   // reads per chunk of a large host batch (copy of chunk k + 1 overlaps the build of chunk k)
+constexpr uint64_t kHostChunkIds = 1ull << 27;    // ... and ids (512 MB)
 constexpr uint32_t kAccReads = 1u << 21;         // reads per accumulated host batch
+#ifndef SFGPU_MAX_SUBBATCH_LOG2
+#define SFGPU_MAX_SUBBATCH_LOG2 26
+#endif
+constexpr uint64_t kMaxSubBatch = 1ull << SFGPU_MAX_SUBBATCH_LOG2;   // reads per partitioned sub-batch (they grow x4 up to this)
 constexpr uint64_t kAccIds = 1ull << 24;          // ids per accumulated host batch (64 MB pinned)
 
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
@@ -421,6 +429,8 @@ int sfgpu_eq_destroy(sfgpu_eq* eq) {
     if (eq->acc_off) pinned_free(eq->acc_off);
     if (eq->ev0) (void)hipEventDestroy(eq->ev0);
     if (eq->ev1) (void)hipEventDestroy(eq->ev1);
+    if (eq->copy_stream) { (void)hipStreamSynchronize(eq->copy_stream); stream_release(eq->copy_stream); }
+    for (int i = 0; i < 2; ++i) if (eq->ev_copy[i]) (void)hipEventDestroy(eq->ev_copy[i]);
     delete eq;
     return SFGPU_OK;
 }
@@ -485,7 +495,7 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
 
 // radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.
 static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t cnt,
-                          uint64_t n_words, uint32_t ids_end) {
+                          uint64_t n_words) {
     hipStream_t st = eq->stream;
     int rc;
     // The table doubles when the classes seen so far would fill more than half of it (SFGPU_EQ_LOAD_DIV: 1/div).  A
@@ -513,37 +523,35 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
     // every block of pass 1 owns one contiguous tile of reads and one bin per region
-    uint32_t n_blocks = (cnt + 32767u) / 32768u; if (n_blocks > 512u) n_blocks = 512u; if (n_blocks == 0) n_blocks = 1;
-    const uint32_t tile = (uint32_t)(((uint64_t)cnt + n_blocks - 1) / n_blocks);
-    // Bin capacity (stream words: ids + one hash word per read): the mean share of a (region, block) pair plus 30 %
-    // and a constant -- the share is a sum of ~mean/5 independent labels, so this is > 6 standard deviations for
-    // hashed labels; a region far above its share (one label holding a large part of the reads) overflows into the
-    // generic kernel's list.  Rounded to whole 128-byte lines.
+    static const uint32_t max_blocks = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long v = e ? atol(e) : 512; return (uint32_t)(v >= 1 && v <= 1024 ? v : 512); }();
+    uint32_t n_blocks = (cnt + 32767u) / 32768u; if (n_blocks > max_blocks) n_blocks = max_blocks; if (n_blocks == 0) n_blocks = 1;
+    const uint32_t tile = (uint32_t)((((uint64_t)cnt + n_blocks - 1) / n_blocks + 63) & ~63ull);     // whole wavefront steps
+    // Bin capacity in 16-byte granules.  A label of n ids takes ceil((n + 1) / 4) <= (n + 4) / 4 granules, so
+    // (ids + 4 reads) / 4 bounds the stream from above; a bin gets its share of that bound plus 25 % and a constant --
+    // the share is a sum of ~mean / 1.6 independent labels, so this is > 6 standard deviations for hashed labels.  A
+    // region far above its share (one label holding a large part of the reads) overflows into the generic kernel's
+    // list.  Rounded to whole 128-byte lines.
     const uint64_t n_bins = (uint64_t)n_regions * n_blocks;
-    const uint64_t stream_words = n_words + cnt;
-    uint64_t cap = (stream_words + n_bins - 1) / n_bins;
-    cap = cap + cap * 3 / 10 + 160;
-    cap = (cap + 31) & ~31ull;
-    // positions inside the bins are 31-bit (bit 31 of a slot's rep marks arena entries)
-    SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 words");
-    if ((rc = eq->part_words.reserve(n_bins * cap + 8, st, false))) return rc;
+    const uint64_t stream_gr = (n_words + 4ull * cnt) / 4 + 1;
+    uint64_t cap = (stream_gr + n_bins - 1) / n_bins;
+    cap = cap + cap / 4 + 48;
+    cap = (cap + 7) & ~7ull;
+    // positions inside the bins are 31-bit granule indices (bit 31 of a slot's rep marks arena entries)
+    SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 granules");
+    if ((rc = eq->part_words.reserve(n_bins * cap * 4 + 8, st, false))) return rc;
     if ((rc = eq->part_hist.reserve(n_bins + 1, st, false))) return rc;          // fill of every bin
     if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
     if ((rc = eq->deferred_a.reserve(2ull * cnt, st, false))) return rc;
     SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));     // CTR_NEW, CTR_DEFER
     SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));     // long-label counter
     SF_HIP(hipEventRecord(eq->ev0, st));
-    const size_t route_lds = (size_t)(kSortWords + 8) * 4 + ((size_t)3 * n_regions + 1) * 4 + ((size_t)kSortWords / 16 + 2) * 2;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
-        SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_route), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        lds_attr_set = true;
-    }
-    RouteArgs ra{d_ids, d_offsets, first, cnt, tile, ids_end, eq->cap - 1, n_regions, (uint32_t)cap, eq->part_words.p, eq->part_hist.p,
+    uint4* bins = reinterpret_cast<uint4*>(eq->part_words.p);
+    RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, eq->part_hist.p,
                  eq->d_ctr + 3, eq->part_long.p};
+    const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16;
     hipLaunchKernelGGL(k_part_route, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
     SF_CHECK_LAUNCH();
-    PartArgs pa{eq->table.p, eq->part_words.p, eq->part_hist.p, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+    PartArgs pa{eq->table.p, bins, eq->part_hist.p, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
                 eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes};
     hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
@@ -567,7 +575,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         SF_HIP(hipStreamSynchronize(st));
         if ((rc = eq->def_ids.reserve(tot + 1, st, false))) return rc;
         hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p,
-                           eq->part_words.p, eq->def_off64.p, eq->def_ids.p, eq->def_off.p);
+                           reinterpret_cast<const uint4*>(eq->part_words.p), eq->def_off64.p, eq->def_ids.p, eq->def_off.p);
         SF_CHECK_LAUNCH();
         if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
         // deferred_a is reused by eq_generic: the copies above are complete (eq_grow synchronised)
@@ -628,8 +636,8 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             uint64_t n_words = (uint64_t)se[1] - se[0];
             if (n_words >= (1ull << 31) && cnt > (1u << 20)) { step = cnt / 2; continue; }     // too many ids for 31-bit offsets: halve
             if ((rc = reserve_arena(n_words, cnt))) return rc;
-            if (n_words < (1ull << 31)) {
-                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words, se[1]))) return rc;
+            if (n_words < (1ull << 31) && n_words >= 64) {       // (a sub-batch of next to no ids is not worth a partition)
+                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words))) return rc;
                 done = true;
             }
         } else if (part) {
@@ -656,7 +664,7 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             const double rate = (double)(eq->n_classes - classes_before + 1) / (double)cnt;
             for (uint32_t mult = 4; mult >= 2; mult /= 2) {
                 const uint64_t next = (uint64_t)step * mult;
-                if (next <= (1ull << 26) && (double)eq->n_classes + rate * (double)next <= (double)(eq->cap / 2)) { step = (uint32_t)next; break; }
+                if (next <= kMaxSubBatch && (double)eq->n_classes + rate * (double)next <= (double)(eq->cap / 2)) { step = (uint32_t)next; break; }
             }
         }
     }
@@ -698,17 +706,49 @@ int sfgpu_eq_add_batch_host(sfgpu_eq* eq, const uint32_t* h_ids, const uint32_t*
         SF_REQUIRE(!eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_add_batch: builder already finished (call start)");
         int rc;
         if (n_reads >= kAccReads / 2 || n_ids >= kAccIds / 2) {
-            // already a large batch: stage it and build it directly
-            if ((rc = eq->stage_ids.reserve(n_ids + 1, eq->stream, false))) return rc;
-            if ((rc = eq->stage_off.reserve((uint64_t)n_reads + 1, eq->stream, false))) return rc;
-            if (n_ids) SF_HIP(hipMemcpyAsync(eq->stage_ids.p, h_ids + base, n_ids * 4, hipMemcpyHostToDevice, eq->stream));
-            SF_HIP(hipMemcpyAsync(eq->stage_off.p, h_offsets, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, eq->stream));
-            if (base) {     // offsets relative to the staged ids
-                hipLaunchKernelGGL(k_rebase, dim3(grid_for((uint64_t)n_reads + 1)), dim3(kBlock), 0, eq->stream, eq->stage_off.p,
-                                   (uint64_t)n_reads + 1, base);
-                SF_CHECK_LAUNCH();
+            // Already a large batch: it streams through two device staging buffers in chunks of kHostChunkReads reads --
+            // the copy of chunk k + 1 (its own stream) runs while chunk k is built, so a batch that sits in pinned host
+            // memory costs its PCIe transfer plus the build of the LAST chunk (SURVEY 8d's timed region: "packed hit lists
+            // resident in host-pinned memory -> final device CSR").  Pageable memory works too (the runtime stages it).
+            if (!eq->copy_stream) {
+                SF_HIP(stream_acquire(&eq->copy_stream));
+                SF_HIP(hipEventCreateWithFlags(&eq->ev_copy[0], hipEventDisableTiming));
+                SF_HIP(hipEventCreateWithFlags(&eq->ev_copy[1], hipEventDisableTiming));
             }
-            return eq_add_locked(eq, eq->stage_ids.p, eq->stage_off.p, n_reads);
+            const uint32_t chunk_reads = []() { const char* e = getenv("SFGPU_EQ_HOST_CHUNK"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1024 ? v : kHostChunkReads); }();
+            auto chunk_end = [&](uint32_t r0) -> uint32_t {                       // reads [r0, r1): <= chunk_reads reads, <= kHostChunkIds ids
+                uint32_t r1 = (n_reads - r0 > chunk_reads) ? r0 + chunk_reads : n_reads;
+                while (r1 > r0 + 1 && (uint64_t)h_offsets[r1] - h_offsets[r0] > kHostChunkIds) r1 = r0 + (r1 - r0) / 2;
+                return r1;
+            };
+            auto enqueue_copy = [&](uint32_t r0, uint32_t r1, int slot) -> int {
+                const uint64_t c_ids = (uint64_t)h_offsets[r1] - h_offsets[r0];
+                const uint32_t c = r1 - r0;
+                int rc2;
+                if ((rc2 = eq->stage2_ids[slot].reserve(c_ids + 1, eq->copy_stream, false))) return rc2;
+                if ((rc2 = eq->stage2_off[slot].reserve((uint64_t)c + 1, eq->copy_stream, false))) return rc2;
+                if (c_ids) SF_HIP(hipMemcpyAsync(eq->stage2_ids[slot].p, h_ids + h_offsets[r0], c_ids * 4, hipMemcpyHostToDevice, eq->copy_stream));
+                SF_HIP(hipMemcpyAsync(eq->stage2_off[slot].p, h_offsets + r0, ((uint64_t)c + 1) * 4, hipMemcpyHostToDevice, eq->copy_stream));
+                if (h_offsets[r0]) {     // offsets relative to the staged ids
+                    hipLaunchKernelGGL(k_rebase, dim3(grid_for((uint64_t)c + 1)), dim3(kBlock), 0, eq->copy_stream, eq->stage2_off[slot].p,
+                                       (uint64_t)c + 1, h_offsets[r0]);
+                    SF_CHECK_LAUNCH();
+                }
+                SF_HIP(hipEventRecord(eq->ev_copy[slot], eq->copy_stream));
+                return SFGPU_OK;
+            };
+            uint32_t r0 = 0, r1 = chunk_end(0);
+            int slot = 0;
+            if ((rc = enqueue_copy(r0, r1, slot))) return rc;
+            while (r0 < n_reads) {
+                const uint32_t nr0 = r1, nr1 = (nr0 < n_reads) ? chunk_end(nr0) : nr0;
+                // the other buffer is free: the build that used it has returned (eq_add_locked drains the stream)
+                if (nr0 < n_reads && (rc = enqueue_copy(nr0, nr1, slot ^ 1))) return rc;
+                SF_HIP(hipStreamWaitEvent(eq->stream, eq->ev_copy[slot], 0));
+                if ((rc = eq_add_locked(eq, eq->stage2_ids[slot].p, eq->stage2_off[slot].p, r1 - r0))) return rc;
+                r0 = nr0; r1 = nr1; slot ^= 1;
+            }
+            return SFGPU_OK;
         }
         if (!eq->acc_ids) {
             SF_HIP(pinned_malloc(&eq->acc_ids, kAccIds * 4));

@@ -2,13 +2,13 @@
 //
 // The global table is an array of REGIONS of kRegionSlots consecutive slots; a label's home region is
 // the high bits of its slot index and linear probing wraps inside the region.  One pass of a sub-batch:
-//   1  k_part_route  : every label is read ONCE and hashed ONCE (bucket hash, xxh64_device.h); a block counting-sorts
-//                      sub-tiles of its reads by region inside LDS and appends each region's run to ITS OWN bin of
-//                      that region -- bin (region, block), fixed capacity, no histogram pass, no scan, no global
-//                      atomics.  The label travels as  [id0 | head bit][H][id1] ... [id_{n-1}]  where H carries what
-//                      pass 2 needs from the hash (19 tag bits, 12 slot bits): pass 2 never hashes a read.
-//                      Labels that do not fit their bin (a region far above its share), over-long labels and ids
-//                      >= 2^31 go to a list that the generic kernel k_insert takes.
+//   1  k_part_route  : every label is read ONCE and hashed ONCE (bucket hash, xxh64_device.h) by one lane, which then
+//                      stores it into ITS BLOCK'S bin of the label's region -- bin (region, block), fixed capacity,
+//                      position from one LDS atomic; no histogram pass, no scan, no sort, no barrier, no global
+//                      atomics.  The label travels as 16-byte granules  [id0 | head bit][H][id1][id2] [id3..id6] ...
+//                      where H carries what pass 2 needs (length, 12 tag bits, 12 slot bits): pass 2 never hashes a
+//                      read.  Labels that do not fit their bin (a region far above its share), over-long labels and
+//                      ids >= 2^31 go to a list that the generic kernel k_insert takes.
 //   2  k_part_insert : ONE block per region: the region's slots live in LDS (word u64 + count delta u32); every
 //                      wavefront streams whole bins through a private LDS tile with coalesced loads (no block
 //                      barriers while streaming); labels are probed and counted with LDS atomics only; new classes
@@ -20,250 +20,212 @@
 // Round-2 rewrite: hardware counters (profiles/r2_eq_counters_before.txt) showed the three kernels of the first
 // version (histogram, scatter, insert) issue-bound, not bandwidth-bound: 287 + 262 + 503 vector and 114 + 154 +
 // 419 scalar instructions per label (every pass hashed or re-derived the region, predicated loads compiled to
-// branch chains).  The route pass replaces histogram + scan + scatter; the insert pass reads H instead of hashing.
+// branch chains).  The route pass replaces histogram + scan + scatter; the insert pass reads H instead of hashing
+// and takes one granule per lane instead of searching label starts in a word stream.
 #pragma once
 
 namespace sfgpu {
 
-constexpr int kRegionBits = 12;
+#ifndef SFGPU_REGION_BITS
+#define SFGPU_REGION_BITS 12
+#endif
+constexpr int kRegionBits = SFGPU_REGION_BITS;
 constexpr uint32_t kRegionSlots = 1u << kRegionBits;          // 4096 slots: 32 KB words + 16 KB counts in LDS
 constexpr uint32_t kRegionLimit = kRegionSlots / 4 * 3;       // inserts beyond this occupancy are deferred
 constexpr int kPartBlock = 1024;
-constexpr int kWaveTile = 256;                                // words of the label stream a wavefront handles at a time
 constexpr int kPartWaves = kPartBlock / 64;
-constexpr int kMaxRegions = 4096;
-constexpr int kMaxRouteBlocks = 1024;                         // bins per region: <= 64 per wavefront of pass 2
+constexpr int kMaxRegions = 8192;
 constexpr uint32_t kHeadBit = 0x80000000u;
-constexpr uint32_t kMaxPartLabel = kWaveTile / 2 - 8;         // ids; a label is n + 1 stream words: always < half a tile
-constexpr int kWaveHeads = 68;                                // label starts a wavefront records per tile (it takes <= 64 labels per round)
-constexpr int kTagBits = 19;                                  // tag bits carried in H (the table keeps 32)
+constexpr uint32_t kMaxPartLabel = 123;                       // ids: the length travels in 7 bits of H, a label is <= 31 granules
+constexpr int kTagBits = 24 - kRegionBits;                    // tag bits carried in H next to the slot (the table keeps 32)
 
 __device__ __forceinline__ uint64_t region_next(uint64_t s) {
     return (s & ~(uint64_t)(kRegionSlots - 1)) | ((s + 1) & (kRegionSlots - 1));
 }
 
-// 16 bytes from a 4-byte-aligned address (global memory takes unaligned vector loads on gfx950)
-struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ U4 ld4(const uint32_t* p) { return *reinterpret_cast<const U4*>(p); }
+// The partition stream is made of 16-byte GRANULES.  A label of n ids takes ceil((n + 1) / 4) of them:
+//    [id0 | head bit][H][id1][id2]   [id3][id4][id5][id6]   ...   (zero padded)
+// i.e. label word k >= 1 sits k + 1 words after the label's start.  H = n << 24 | tag << 12 | slot: everything pass 2
+// needs from the bucket hash (12 tag bits, the slot inside the region) and the length, so pass 2 hashes nothing and
+// finds label boundaries with one ballot.
+__device__ __forceinline__ uint32_t label_granules(uint32_t n) { return (n + 4u) >> 2; }
 
 // ---- pass 1: route every label to the bin (region, this block) ------------------------------------------------
-// Writing each label straight to its region would scatter 4-byte stores over n_blocks x n_regions open cache lines
-// (measured in round 1: no better than the random probes it replaces).  Instead a block counting-sorts a sub-tile of
-// its reads by region inside LDS and then writes the sorted buffer out word-parallel, so HBM sees runs and each
-// store instruction few lines.  A thread owns kSubPer reads of the sub-tile: it fetches the first 8 ids of each with
-// two unaligned 16-byte loads (labels are packed back to back, so a wavefront's loads cover one contiguous range),
-// hashes from registers, takes the label's rank inside its region with one LDS atomic, and after the block's scan
-// of the region histogram writes the label into the sort buffer.  The offsets of the NEXT sub-tile are requested
-// while this one is hashed.
-constexpr int kSortWords = 12288;                            // 48 KB LDS sort buffer: two blocks per CU
-constexpr int kSubReads = 2048;                              // reads per sub-tile: 2 per thread (their label heads stay in registers)
-constexpr int kSubPer = kSubReads / kPartBlock;
+// No sort, no scan, no block barrier.  A wavefront takes 64 consecutive reads per step, copies their ids (one contiguous
+// range) into its own LDS buffer with coalesced 16-byte loads, and every lane then hashes its label out of LDS, takes
+// its place in the bin with ONE LDS atomic on the block's cursor of that region, and stores the label itself -- one
+// 16-byte store for <= 3 ids, two for <= 7.  The stores of a wavefront go to 64 different bins; what keeps that
+// affordable is their width (1.6 stores per label instead of one per id).  What round 2 measured on the way
+// (profiles/r2_class_build_notes.md): counting-sorting sub-tiles in LDS first (runs instead of single labels) cost five
+// barriers and ~90 LDS + ~630 vector instructions per label; lane-per-label 16-byte loads of the ids were bound by the
+// texture addresser (one cycle per lane and dword); ids past the 8th read one word at a time made a chain of dependent
+// loads that some lane of every wavefront had to walk (13 % of the labels hold more than 7 ids).  With those gone the
+// pass is bound by its scattered stores: 0.51 ms of 1.55 ms per 67 M reads without them, 0.88 ms with all stores
+// confined to 1 MB -- the rest is partial lines leaving the L2 (64 K open lines per XCD).
+constexpr int kStageWords = 512;                             // ids a wavefront stages per step (64 consecutive reads): 2 KB
 
 struct RouteArgs {
-    const uint32_t* ids; const uint32_t* off; uint32_t first, n;
-    uint32_t tile;                         // reads per block
-    uint32_t ids_end;                      // first id index that must not be read (end of the sub-batch's ids)
-    uint64_t mask; uint32_t n_regions;
-    uint32_t cap;                          // words per bin
-    uint32_t* out;                         // bins: bin (r, b) starts at word (r * n_blocks + b) * cap
-    uint32_t* fill;                        // fill[r * n_blocks + b] = words written to bin (r, b)
+    const uint32_t* ids; const uint32_t* off;      // off is already advanced to the sub-batch's first read
+    uint32_t first;                                // index of that read in the caller's batch (for the generic kernel's list)
+    uint32_t n;                                    // reads in the sub-batch
+    uint32_t tile;                                 // reads per block (a multiple of 64)
+    uint32_t region_mask;                          // n_regions - 1
+    uint32_t cap;                                  // granules per bin
+    uint4* out;                                    // bins: bin (r, b) starts at granule (b * n_regions + r) * cap -- a block's bins are one window
+                                                   // of memory (region-major, every store of a block hit a different 2 MB page)
+    uint32_t* fill;                                // fill[r * n_blocks + b] = granules written to bin (r, b)
     unsigned long long* n_long; uint32_t* long_list;     // reads for the generic kernel
 };
 
+// A wavefront takes 64 CONSECUTIVE reads per step: their ids are one contiguous range, which it copies into its own LDS
+// buffer with coalesced, 16-byte-aligned loads (lane-per-label loads from global memory cost the texture addresser one
+// cycle per lane and dword: measured TA-bound, profiles/r2_class_build_notes.md); the lanes then pick their labels out
+// of LDS.  The next step's offsets and ids are requested before this step's labels are hashed.
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_route(RouteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t NR = a.n_regions;
-    uint32_t* buf = reinterpret_cast<uint32_t*>(smem);                                // kSortWords (+8 slack)
-    unsigned int* hs = reinterpret_cast<unsigned int*>(smem + (size_t)(kSortWords + 8) * 4);   // NR + 1: histogram, then its exclusive scan
-    unsigned int* gpos = hs + NR + 1;                                                 // NR: next free word of my bin (absolute word index)
-    unsigned int* cut = gpos + NR;                                                    // NR: lowered when a label does not fit the bin
-    uint16_t* first_reg = reinterpret_cast<uint16_t*>(cut + NR);                      // kSortWords / 16 + 2: region of every 16th sorted word
-    __shared__ unsigned int s_scan[kPartBlock / kWave];
+    const uint32_t NR = a.region_mask + 1u;
+    unsigned int* cur = reinterpret_cast<unsigned int*>(smem);                        // NR: granules taken from my bin of region r
+    unsigned int* cut = cur + NR;                                                     // NR: first granule of a label that did not fit
     const uint32_t B1 = gridDim.x, blk = blockIdx.x, cap = a.cap, tid = threadIdx.x;
-    for (uint32_t r = tid; r < NR; r += kPartBlock) { gpos[r] = (r * B1 + blk) * cap; cut[r] = 0xFFFFFFFFu; hs[r] = 0; }
-    if (tid == 0) hs[NR] = 0;
-    const uint64_t t0 = (uint64_t)blk * a.tile;
-    const uint64_t t1 = (t0 + a.tile < a.n) ? t0 + a.tile : a.n;
-    const uint32_t per = (NR + kPartBlock - 1) / kPartBlock;                          // regions per thread in the scans
-    const uint32_t* __restrict__ off = a.off + a.first;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    uint4* stage4 = reinterpret_cast<uint4*>(cut + NR) + wave * (kStageWords / 4 + 4);   // this wavefront's staging buffer (+ slack)
+    const uint32_t* stage = reinterpret_cast<const uint32_t*>(stage4);
+    for (uint32_t r = tid; r < NR; r += kPartBlock) { cur[r] = 0; cut[r] = 0xFFFFFFFFu; }
+    const uint32_t t0 = blk * a.tile;
+    const uint32_t t1 = (t0 + a.tile < a.n && t0 + a.tile > t0) ? t0 + a.tile : a.n;
+    const uint32_t* __restrict__ off = a.off;
     const uint32_t* __restrict__ ids = a.ids;
+    __syncthreads();
 
-    // offsets of the first sub-tile
-    uint32_t nb[kSubPer], ne[kSubPer];
+    // step c of this wavefront: reads [r0, r0 + 64) with r0 = t0 + 64 (wave + 16 c)
+    auto offsets = [&](uint32_t r0, uint32_t& o, uint32_t& oe) {                     // o = off[r0 + lane], oe = off[end of the step]
+        const uint32_t re = (r0 + 64u < t1) ? r0 + 64u : t1;
+        const uint32_t j = r0 + lane;
+        o = off[j < re ? j : re]; oe = off[re];
+    };
+    // the staged range starts at the 16-byte boundary at or below ids + w_lo: lane i fetches 16-byte words i and i + 64
+    auto fetch = [&](uint32_t w_lo, uint32_t w_hi, uint4& x0, uint4& x1) {
+        const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(ids + w_lo) >> 2) & 3u);
+        const uint32_t n4 = (w_hi - w_lo + mis + 3u) >> 2;
+        const uint4* src = reinterpret_cast<const uint4*>(ids + w_lo - mis);
+        x0 = make_uint4(0u, 0u, 0u, 0u); x1 = x0;
+        if (lane < n4 && n4 <= (uint32_t)kStageWords / 4) x0 = src[lane];
+        if (lane + 64u < n4 && n4 <= (uint32_t)kStageWords / 4) x1 = src[lane + 64u];
+    };
+    uint32_t r0 = t0 + 64u * wave;
+    uint32_t o = 0, oe = 0, no = 0, noe = 0;
+    uint4 x0 = make_uint4(0u, 0u, 0u, 0u), x1 = x0;
+    if (r0 < t1) {
+        offsets(r0, o, oe);
+        fetch(__shfl(o, 0, kWave), oe, x0, x1);
+    }
+    for (; r0 < t1; r0 += 64u * kPartWaves) {
+        const uint32_t nr0 = r0 + 64u * kPartWaves;
+        if (nr0 < t1) offsets(nr0, no, noe);                                            // the next step's offsets travel now
+        const uint32_t re = (r0 + 64u < t1) ? r0 + 64u : t1;
+        const uint32_t w_lo = __shfl(o, 0, kWave), w_hi = oe;
+        const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(ids + w_lo) >> 2) & 3u);
+        const bool staged = ((w_hi - w_lo + mis + 3u) >> 2) <= (uint32_t)kStageWords / 4;
+        stage4[lane] = x0; stage4[lane + 64u] = x1;
+        // my label: [b, e)
+        const uint32_t nxt = __shfl_down(o, 1, kWave);
+        const uint32_t b = o, e = (lane == 63u || r0 + lane + 1u >= re) ? oe : nxt;
+        const uint32_t len = (r0 + lane < re) ? e - b : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (nr0 < t1) fetch(__shfl(no, 0, kWave), noe, x0, x1);                         // ... and its ids (used after this step's labels)
+        const uint32_t* lab_g = ids + b;
+        const uint32_t* lab_s = stage + mis + (b - w_lo);
+        uint32_t w[kHead];
+        uint32_t mx = 0;
+        if (staged) {
 #pragma unroll
-    for (int k = 0; k < kSubPer; ++k) {
-        const uint64_t j = t0 + (uint64_t)k * kPartBlock + tid;
-        nb[k] = 0; ne[k] = 0;
-        if (j < t1) { nb[k] = off[j]; ne[k] = off[j + 1]; }
+            for (int q = 0; q < kHead; ++q) w[q] = lab_s[q];                            // (the buffer has 16 words of slack)
+        } else {                                                                        // labels of > 8 ids on average: straight from global memory
+#pragma unroll
+            for (int q = 0; q < kHead; ++q) w[q] = ((uint32_t)q < len) ? lab_g[q] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kHead; ++q) { w[q] = ((uint32_t)q < len) ? w[q] : 0u; mx = mx > w[q] ? mx : w[q]; }
+        const bool unfit = len > kMaxPartLabel;
+        // bucket hash: 8 rounds over the (zero padded) head, then one round per further id (label_mix64_words' chain)
+        uint32_t ha = MP1 + len, hb = 0x27D4EB2Fu ^ (len * MP3);
+#pragma unroll
+        for (int q = 0; q < kHead; ++q) mix_round(ha, hb, w[q]);
+        const uint32_t ng = label_granules(len);
+        // ids 7.. come one granule (ids 4g-1 .. 4g+2) at a time; labels of > 7 ids are 13 % of the reads, so this path is
+        // taken by some lane of nearly every wavefront and must not be a chain of dependent global loads
+        if (len > (uint32_t)kHead && !unfit) {
+            for (uint32_t g = 2; g < ng; ++g) {
+                const uint32_t q = 4u * g - 1u;
+                uint32_t v0, v1, v2, v3;
+                if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
+                else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
+                v1 = q + 1 < len ? v1 : 0u; v2 = q + 2 < len ? v2 : 0u; v3 = q + 3 < len ? v3 : 0u;
+                if (q >= (uint32_t)kHead) mix_round(ha, hb, v0);
+                if (q + 1 < len) mix_round(ha, hb, v1);
+                if (q + 2 < len) mix_round(ha, hb, v2);
+                if (q + 3 < len) mix_round(ha, hb, v3);
+                mx = mx > v0 ? mx : v0; mx = mx > v1 ? mx : v1; mx = mx > v2 ? mx : v2; mx = mx > v3 ? mx : v3;
+            }
+        }
+        const uint64_t h = ((uint64_t)mix_fin(ha ^ hb) << 32) | mix_fin(hb + (ha >> 3));
+        // an id >= 2^31 would collide with the label marker of the partition stream (no real transcriptome has one)
+        bool generic = unfit || (mx & kHeadBit);
+        const uint32_t rg = ((uint32_t)h >> kRegionBits) & a.region_mask;
+        const uint32_t H = (len << 24) | ((uint32_t)(h >> (64 - kTagBits)) << kRegionBits) | ((uint32_t)h & (kRegionSlots - 1));
+        if (len != 0 && !generic) {
+            const uint32_t at = atomicAdd(&cur[rg], ng);                                // my granules in the bin (rg, blk)
+            if (at + ng <= cap) {
+                uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
+                dst[0] = make_uint4(w[0] | kHeadBit, H, w[1], w[2]);
+                if (len > 3u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                for (uint32_t g = 2; g < ng; ++g) {
+                    const uint32_t q = 4u * g - 1u;
+                    uint32_t v0, v1, v2, v3;
+                    if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
+                    else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
+                    dst[g] = make_uint4(v0, q + 1 < len ? v1 : 0u, q + 2 < len ? v2 : 0u, q + 3 < len ? v3 : 0u);
+                }
+            } else {
+                atomicMin(&cut[rg], at);                                                // the bin ends before this label
+                generic = true;
+            }
+        }
+        if (len != 0 && generic) a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + r0 + lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                      // every lane is done with the staged ids before they are replaced
+        o = no; oe = noe;
     }
     __syncthreads();
-    for (uint64_t s0 = t0; s0 < t1; s0 += kSubReads) {
-        const uint32_t cnt = (uint32_t)((s0 + kSubReads < t1) ? kSubReads : (t1 - s0));
-        uint32_t bs[kSubPer], ln[kSubPer];
-#pragma unroll
-        for (int k = 0; k < kSubPer; ++k) { bs[k] = nb[k]; ln[k] = ne[k] - nb[k]; }
-        // the sub-tile's words (ids + one H per read; uniform): does it fit the sort buffer at once?
-        const uint32_t w_all = off[s0 + cnt] - off[s0] + cnt;
-        const bool one_round = w_all <= (uint32_t)kSortWords;
-        // label heads: first 8 ids of every read, zero past the label
-        uint32_t w[kSubPer][kHead];
-#pragma unroll
-        for (int k = 0; k < kSubPer; ++k) {
-            const uint32_t* lab = ids + bs[k];
-            if (ln[k] != 0 && (uint64_t)bs[k] + 8u <= (uint64_t)a.ids_end) {
-                const U4 x = ld4(lab), y = ld4(lab + 4);
-                w[k][0] = x.x; w[k][1] = x.y; w[k][2] = x.z; w[k][3] = x.w; w[k][4] = y.x; w[k][5] = y.y; w[k][6] = y.z; w[k][7] = y.w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < kHead; ++q) w[k][q] = ((uint32_t)q < ln[k]) ? lab[q] : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < kHead; ++q) w[k][q] = ((uint32_t)q < ln[k]) ? w[k][q] : 0u;
-        }
-        // the next sub-tile's offsets travel while this one is hashed
-#pragma unroll
-        for (int k = 0; k < kSubPer; ++k) {
-            const uint64_t j = s0 + kSubReads + (uint64_t)k * kPartBlock + tid;
-            nb[k] = 0; ne[k] = 0;
-            if (j < t1) { nb[k] = off[j]; ne[k] = off[j + 1]; }
-        }
-        // hash; labels the partition stream cannot carry go to the generic kernel's list
-        uint32_t rg[kSubPer], hh[kSubPer];
-#pragma unroll
-        for (int k = 0; k < kSubPer; ++k) {
-            rg[k] = 0; hh[k] = 0;
-            const uint32_t len = ln[k];
-            if (len == 0) continue;
-            uint32_t mx = w[k][0];
-#pragma unroll
-            for (int q = 1; q < kHead; ++q) mx = mx > w[k][q] ? mx : w[k][q];
-            uint64_t h;
-            bool generic = len > kMaxPartLabel;
-            if (len <= (uint32_t)kHead) h = label_mix64_head(w[k], len);
-            else {
-                const uint32_t* lab = ids + bs[k];
-                h = label_mix64_words([&](uint32_t q) { return lab[q]; }, len);
-                if (!generic) for (uint32_t q = kHead; q < len; ++q) { const uint32_t v = lab[q]; mx = mx > v ? mx : v; }
-            }
-            // an id >= 2^31 would collide with the label marker of the partition stream (no real transcriptome has one)
-            generic = generic || (mx & kHeadBit);
-            if (generic) {
-                a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + (uint32_t)(s0 + (uint64_t)k * kPartBlock + tid);
-                ln[k] = 0;
-            } else {
-                rg[k] = (uint32_t)((h & a.mask) >> kRegionBits);
-                hh[k] = ((uint32_t)(h >> (64 - kTagBits)) << kRegionBits) | ((uint32_t)h & (kRegionSlots - 1));
-            }
-        }
-        for (int round = 0; round < (one_round ? 1 : kSubPer); ++round) {
-            // ---- rank inside the region (stream words: n ids + H)
-            uint32_t rk[kSubPer];
-            bool in_round[kSubPer];
-#pragma unroll
-            for (int k = 0; k < kSubPer; ++k) {
-                in_round[k] = ln[k] != 0 && (one_round || k == round);
-                rk[k] = 0;
-                if (in_round[k]) rk[k] = atomicAdd(&hs[rg[k]], ln[k] + 1u);
-            }
-            __syncthreads();
-            // ---- exclusive scan of the histogram, in place (thread t owns regions [t*per, (t+1)*per))
-            unsigned int mine = 0;
-            for (uint32_t q = 0; q < per; ++q) { const uint32_t r = tid * per + q; if (r < NR) mine += hs[r]; }
-            unsigned int incl = mine;
-            for (int o = 1; o < kWave; o <<= 1) { const unsigned int v = __shfl_up(incl, o, kWave); if ((int)(tid & (kWave - 1)) >= o) incl += v; }
-            if ((tid & (kWave - 1)) == kWave - 1) s_scan[tid / kWave] = incl;
-            __syncthreads();
-            unsigned int run = 0;
-            for (int q = 0; q < (int)(tid / kWave); ++q) run += s_scan[q];
-            run += incl - mine;
-            for (uint32_t q = 0; q < per; ++q) {
-                const uint32_t r = tid * per + q;
-                if (r < NR) {
-                    const unsigned int h = hs[r];
-                    hs[r] = run;
-                    // 16-word blocks of the sorted buffer whose first word falls into region r
-                    for (uint32_t bq = (run + 15u) >> 4; bq < ((run + h + 15u) >> 4); ++bq) first_reg[bq] = (uint16_t)r;
-                    run += h;
-                }
-            }
-            if (tid == kPartBlock - 1) hs[NR] = run;                                    // = words in this round (sentinel)
-            __syncthreads();
-            const uint32_t total = hs[NR];
-            if (total > (uint32_t)kSortWords) {
-                // a half sub-tile that still does not fit (labels of > 10 ids on average): the generic kernel takes it
-#pragma unroll
-                for (int k = 0; k < kSubPer; ++k)
-                    if (in_round[k]) { a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + (uint32_t)(s0 + (uint64_t)k * kPartBlock + tid); ln[k] = 0; }
-            } else {
-                // ---- labels -> LDS in region order: [id0 | head][H][id1] ...   (ids past the 8th come from global memory: rare)
-#pragma unroll
-                for (int k = 0; k < kSubPer; ++k) {
-                    if (!in_round[k]) continue;
-                    const uint32_t len = ln[k];
-                    const uint32_t at = gpos[rg[k]] + rk[k];
-                    if (at + len + 1u > (rg[k] * B1 + blk + 1u) * cap) {                  // does not fit the bin: this label and all later ones of the run
-                        atomicMin(&cut[rg[k]], at);
-                        a.long_list[atomicAdd(a.n_long, 1ull)] = a.first + (uint32_t)(s0 + (uint64_t)k * kPartBlock + tid);
-                        ln[k] = 0;
-                        continue;
-                    }
-                    uint32_t* dst = buf + hs[rg[k]] + rk[k];
-                    dst[0] = w[k][0] | kHeadBit;
-                    dst[1] = hh[k];
-#pragma unroll
-                    for (int q = 1; q < kHead; ++q) if ((uint32_t)q < len) dst[q + 1] = w[k][q];
-                    if (len > (uint32_t)kHead) { const uint32_t* lab = ids + bs[k]; for (uint32_t q = kHead; q < len; ++q) dst[q + 1] = lab[q]; }
-                    ln[k] = one_round ? len : 0u;                                       // done (the flag only matters in two-round mode)
-                }
-                __syncthreads();
-                // ---- write-out, lane i <-> sorted word i: adjacent lanes write adjacent addresses inside a run
-                for (uint32_t i = tid; i < total; i += kPartBlock) {
-                    uint32_t r = first_reg[i >> 4];
-                    while (hs[r + 1] <= i) ++r;
-                    const uint32_t pos = gpos[r] + (i - hs[r]);
-                    if (pos < cut[r]) a.out[pos] = buf[i];
-                }
-            }
-            __syncthreads();
-            for (uint32_t r = tid; r < NR; r += kPartBlock) {
-                const unsigned int end = gpos[r] + (hs[r + 1] - hs[r]);
-                const unsigned int c = cut[r];
-                if (total <= (uint32_t)kSortWords) gpos[r] = end < c ? end : c;
-                cut[r] = 0xFFFFFFFFu;
-            }
-            __syncthreads();
-            for (uint32_t r = tid; r < NR; r += kPartBlock) hs[r] = 0;                   // (hs[r + 1] of the neighbour was read above)
-            if (tid == 0) hs[NR] = 0;
-            __syncthreads();
-        }
-    }
-    for (uint32_t r = tid; r < NR; r += kPartBlock) a.fill[(uint64_t)r * B1 + blk] = gpos[r] - (r * B1 + blk) * cap;
+    for (uint32_t r = tid; r < NR; r += kPartBlock) { const unsigned int c = cur[r], x = cut[r]; a.fill[r * B1 + blk] = c < x ? c : x; }
 }
 
 struct PartArgs {
     uint64_t* table;                       // {word, count} pairs
-    const uint32_t* words;                 // bins (labels: [id0 | head][H][id1] ...)
-    const uint32_t* fill; uint32_t n_blocks; uint32_t cap;     // region r: bins (r, 0 .. n_blocks), fill words each
+    const uint4* bins;                     // granules
+    const uint32_t* fill; uint32_t n_blocks; uint32_t cap;     // region r: bins (r, 0 .. n_blocks), fill granules of cap each
     uint64_t* cls_hash; uint64_t* cls_off; uint32_t* cls_len; uint32_t* cls_slot; uint32_t* arena;
     unsigned long long* ctr;               // CTR_* counters (classes / arena cursor / deferred)
-    uint32_t* deferred;                    // (word index of the label in `words`, length) of labels that found their region full
+    uint32_t* deferred;                    // (granule index of the label in the bins, length) of labels that found their region full
     uint64_t base_classes;                 // classes committed before this launch
 };
 
 // ---- pass 2: one block per region
 // A slot word is tag(32) | rep(32) in the table.  While a launch runs, the slot of a class CREATED by it is
-// provisional: tag(19) | length(13) | position of its label in the bins (bit 31 clear); it is rewritten with the full
-// tag and the arena entry when the block commits its new classes.  Probing compares the 19 tag bits H carries.
-// Wavefront w streams the bins w, w + 16, ... of the region, 256 words at a time: four coalesced loads -> its private
-// LDS tile; label starts are found with wave ballots (no scan, no barrier); lane j takes the tile's j-th label.  The
-// only block-wide synchronisation is before and after the streaming loop.
+// provisional: tag(12) << 52 | granule index of its label in the bins (bit 31 clear); it is rewritten with the full tag
+// and the arena entry when the block commits its new classes.  Probing compares the 12 tag bits H carries.
+// Wavefront w streams the bins w, w + 16, ... of the region, 64 granules at a time: ONE coalesced 16-byte load per lane;
+// a lane whose granule starts a label handles that label (ids 0..2 are in its registers, ids 3..6 in its neighbour's
+// granule, read back from the wavefront's LDS copy of the step).  The only block-wide synchronisation is before and
+// after the streaming loop.
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_insert(PartArgs a) {
     __shared__ unsigned long long lw[kRegionSlots];     // slot words
     __shared__ unsigned int lc[kRegionSlots];           // count deltas of this launch
-    __shared__ uint32_t wtile[kPartWaves][kWaveTile + 12];
-    __shared__ uint16_t heads[kPartWaves][kWaveHeads];  // per-wave lists of the first label starts of the tile
+    __shared__ __attribute__((aligned(16))) uint4 wtile[kPartWaves][64 + 2];
     __shared__ uint32_t new_info[kRegionLimit];         // classes created by this block: slot | len << 16
     __shared__ unsigned int s_occ, s_nnew, s_newwords, s_cid0;
     __shared__ unsigned long long s_arena0;
@@ -272,7 +234,7 @@ k_part_insert(PartArgs a) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // this wavefront's bins: lane t holds the fill of bin wave + 16 t
     const uint32_t my_bin = wave + kPartWaves * lane;
-    const uint32_t my_fill = (my_bin < a.n_blocks) ? a.fill[(uint64_t)region * a.n_blocks + my_bin] : 0u;
+    const uint32_t my_fill = (my_bin < a.n_blocks) ? a.fill[region * a.n_blocks + my_bin] : 0u;
 
     unsigned int occ_local = 0;
     for (uint32_t s = threadIdx.x; s < kRegionSlots; s += kPartBlock) {
@@ -284,80 +246,52 @@ k_part_insert(PartArgs a) {
     if (occ_local) atomicAdd(&s_occ, occ_local);
     __syncthreads();
 
-    uint32_t* tile = wtile[wave];
-    uint16_t* wh = heads[wave];
+    uint4* tile = wtile[wave];
     const unsigned long long have = __ballot(my_fill != 0u);
-    auto next_bin = [&](int after) -> int {             // first bin t > after with words in it, -1 if none
+    auto next_bin = [&](int after) -> int {             // first bin t > after with granules in it, -1 if none
         const unsigned long long m = (after >= 63) ? 0ull : (have & (~0ull << (after + 1)));
         return m ? (int)__builtin_ctzll(m) : -1;
     };
     int t = next_bin(-1);
-    uint32_t seg0 = 0, n_words = 0, pos = 0;             // current bin: first word (index into a.words), words, position
-    // word i of a tile = q * 64 + lane: each of the four loads is one coalesced 256-byte access.  The NEXT tile's
-    // words (of this bin or of the wavefront's next bin) are requested as soon as this tile's label starts are known,
-    // i.e. before the probe / compare of this tile's labels: its round trip hides behind theirs.
-    uint32_t tw[4] = {0u, 0u, 0u, 0u};
-    auto request = [&](uint32_t s0, uint32_t nw, uint32_t at, uint32_t (&dst)[4]) {
-        const uint32_t len = (nw - at < (uint32_t)kWaveTile) ? (nw - at) : (uint32_t)kWaveTile;
-        const uint32_t* __restrict__ p = a.words + s0 + at;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint32_t i = q * 64 + lane; dst[q] = (i < len) ? p[i] : 0u; }
-    };
+    uint32_t base = 0, n_gr = 0, pos = 0;                // current bin: first granule (index into a.bins), granules, position
+    uint4 g = make_uint4(0u, 0u, 0u, 0u);
     if (t >= 0) {
-        seg0 = ((uint32_t)region * a.n_blocks + wave + kPartWaves * (uint32_t)t) * a.cap;
-        n_words = __shfl(my_fill, t, kWave);
-        request(seg0, n_words, 0u, tw);
+        base = ((wave + kPartWaves * (uint32_t)t) * gridDim.x + region) * a.cap;
+        n_gr = __shfl(my_fill, t, kWave);
+        if (lane < n_gr) g = a.bins[base + lane];
     }
+    if (lane < 2u) tile[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     while (t >= 0) {
-        const uint32_t tlen = (n_words - pos < (uint32_t)kWaveTile) ? (n_words - pos) : (uint32_t)kWaveTile;
-        const bool final_tile = (pos + tlen == n_words);
-        uint32_t nh = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = q * 64 + lane;
-            tile[i] = tw[q];
-            const bool is_head = (i < tlen) && (tw[q] & kHeadBit);
-            const unsigned long long bal = __ballot(is_head);
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (is_head && nh + before < (uint32_t)kWaveHeads) wh[nh + before] = (uint16_t)i;
-            nh += (uint32_t)__popcll(bal);
+        const uint32_t cnt = (n_gr - pos < 64u) ? (n_gr - pos) : 64u;
+        const bool is_head = lane < cnt && (g.x & kHeadBit);
+        const uint32_t H = g.y;
+        const uint32_t len = H >> 24;
+        const uint32_t ng = label_granules(len);
+        // labels whose granules are not all in this step wait for the next one, which starts at the first of them (a label
+        // is <= 31 granules, so the label at lane 0 is always whole; the last step of a bin holds whole labels only)
+        const unsigned long long inc = __ballot(is_head && lane + ng > cnt);
+        uint32_t adv = inc ? (uint32_t)__builtin_ctzll(inc) : cnt;
+        if (adv == 0u) adv = cnt;                            // (cannot happen with well-formed bins: never spin on a corrupt one)
+        tile[lane] = g;
+        // the NEXT step's granule (of this bin or of the wavefront's next bin) is requested before this step's labels
+        // are probed and compared: its round trip hides behind theirs
+        int nt = t; uint32_t nbase = base, nn_gr = n_gr, npos = pos + adv;
+        if (npos >= n_gr) {
+            nt = next_bin(t);
+            if (nt >= 0) { nbase = ((wave + kPartWaves * (uint32_t)nt) * gridDim.x + region) * a.cap; nn_gr = __shfl(my_fill, nt, kWave); npos = 0; }
         }
-        if (lane < 8u) tile[kWaveTile + lane] = 0u;           // the compare reads up to 7 words past a label
+        uint4 gn = make_uint4(0u, 0u, 0u, 0u);
+        if (nt >= 0 && npos + lane < nn_gr) gn = a.bins[nbase + npos + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the tile's last label may continue past the tile: leave it for the next round.  At most one label per lane
-        // per round: the labels past the 64th are picked up by the next (overlapping) tile.
-        const uint32_t n_whole = final_tile ? nh : (nh > 0 ? nh - 1 : 0);
-        const uint32_t n_proc = n_whole < 64u ? n_whole : 64u;
-        // where the next tile starts: at the first label that is not processed now.  Labels are < half a tile, so a
-        // full tile always holds >= 2 label starts and advances.
-        int nt = t; uint32_t nseg0 = seg0, nn_words = n_words, npos = pos;
-        if (n_proc < nh) npos = pos + wh[n_proc];
-        else if (!final_tile) npos = pos + tlen;           // (cannot happen for full tiles: the last start is never whole)
-        else {                                               // this bin is done: the wavefront's next one
-            nt = next_bin(t);
-            if (nt >= 0) {
-                nseg0 = ((uint32_t)region * a.n_blocks + wave + kPartWaves * (uint32_t)nt) * a.cap;
-                nn_words = __shfl(my_fill, nt, kWave); npos = 0;
-            }
-        }
-        uint32_t nw[4] = {0u, 0u, 0u, 0u};
-        if (nt >= 0) request(nseg0, nn_words, npos, nw);
-        if (lane < n_proc) {
-            const uint32_t st = wh[lane];
-            const uint32_t en = (lane + 1 < nh) ? wh[lane + 1] : tlen;
-            const uint32_t len = en - st - 1u;               // ids (the stream label is [id0|head][H][id1]...)
-            const uint32_t* lab = tile + st;
-            const uint32_t H = lab[1];
-            const uint32_t tagq = H >> kRegionBits;
+        if (is_head && lane < adv) {
+            const uint4 g1 = tile[lane + 1];                 // ids 3..6 (whatever follows for shorter labels: masked below)
+            const uint32_t w0 = g.x & ~kHeadBit, w1 = g.z, w2 = g.w;
+            const uint32_t w3 = len > 3u ? g1.x : 0u, w4 = len > 4u ? g1.y : 0u, w5 = len > 5u ? g1.z : 0u, w6 = len > 6u ? g1.w : 0u;
+            const uint32_t tagq = (H >> kRegionBits) & ((1u << kTagBits) - 1u);
             uint32_t s = H & (kRegionSlots - 1);
-            // first 7 ids for the 16-byte compares, zero past the label (word k of the label is lab[k + 1] for k >= 1)
-            uint32_t hw8[kHead];
-            hw8[0] = lab[0] & ~kHeadBit;
-#pragma unroll
-            for (int k = 1; k < kHead; ++k) { const uint32_t v = lab[k + 1]; hw8[k] = ((uint32_t)k < len) ? v : 0u; }
-            const uint32_t here = seg0 + pos + st;           // where this label sits in the bins
+            const uint32_t here = base + pos + lane;         // where this label sits in the bins (granule index)
             // Probe in two stages so that a wavefront pays the global round trip of the label compare ONCE:
             // (1) walk the LDS slots until an empty slot or a tag match (LDS only), (2) claim or compare.
             uint32_t probes = 0;
@@ -378,25 +312,37 @@ k_part_insert(PartArgs a) {
                         a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len;
                         break;
                     }
-                    const unsigned long long me = ((unsigned long long)tagq << (64 - kTagBits)) | ((unsigned long long)len << 32) | (unsigned long long)here;
+                    const unsigned long long me = ((unsigned long long)tagq << (64 - kTagBits)) | (unsigned long long)here;
                     const unsigned long long old = atomicCAS(&lw[s], (unsigned long long)kEmpty, me);
                     if (old == kEmpty) { new_info[atomicAdd(&s_nnew, 1u)] = s | (len << 16); atomicAdd(&lc[s], 1u); break; }
                     atomicSub(&s_occ, 1u);
                     w = old;
                     if ((uint32_t)(w >> (64 - kTagBits)) != tagq) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
                 }
-                // tag match: full label compare
+                // tag match: full label compare, 16 bytes at a time
                 const uint32_t rep = (uint32_t)w;
-                bool same;
-                if (rep & kArenaBit) {
-                    same = entry_equals(a.arena, rep & ~kArenaBit, [&](uint32_t k) { return lab[k + 1]; }, hw8, len);
-                } else {
-                    // a class of this launch: its label sits in the bins at `rep`, its length in the slot word
-                    same = ((uint32_t)(w >> 32) & 0x1FFFu) == len;
-                    if (same) {
-                        const uint32_t* p = a.words + rep;
-                        same = (p[0] & ~kHeadBit) == hw8[0];
-                        for (uint32_t k = 1; same && k < len; ++k) same = p[k + 1] == lab[k + 1];
+                // The representative label lies in 16-byte granules either way, and from the second granule on (ids 3..6,
+                // 7..10, ...) an arena entry [n, id0, id1, id2][id3 ..] and a stream label [id0|head, H, id1, id2][id3 ..]
+                // are word for word the same: whole-granule compares, the first three requested together.
+                // The representative label lies in 16-byte granules either way, and from the second granule on (ids 3..6,
+                // 7..10, ...) an arena entry [n, id0, id1, id2][id3 ..] and a stream label [id0|head, H, id1, id2][id3 ..]
+                // are word for word the same: whole-granule compares, the first three requested together.  (Measured and
+                // dropped: the first granule of every slot's label cached in LDS -- no gain with 2048-slot regions, a loss
+                // with 4096-slot regions at one block per CU.)
+                const bool in_arena = rep & kArenaBit;
+                const uint4* e = in_arena ? reinterpret_cast<const uint4*>(a.arena) + (rep & ~kArenaBit) : a.bins + rep;
+                const uint4 e0 = e[0];
+                uint4 e1 = make_uint4(0u, 0u, 0u, 0u), e2 = e1;
+                if (len > 3u) e1 = e[1];
+                if (len > 7u) e2 = e[2];
+                bool same = in_arena ? (e0.x == len && e0.y == w0) : (e0.x == g.x && (e0.y >> 24) == len);
+                same = same && e0.z == w1 && e0.w == w2 && e1.x == w3 && e1.y == w4 && e1.z == w5 && e1.w == w6;
+                if (len > 7u) {
+                    const uint4 t2 = tile[lane + 2];
+                    same = same && e2.x == t2.x && e2.y == t2.y && e2.z == t2.z && e2.w == t2.w;
+                    for (uint32_t j = 3; same && j < ng; ++j) {
+                        const uint4 ej = e[j], tj = tile[lane + j];
+                        same = ej.x == tj.x && ej.y == tj.y && ej.z == tj.z && ej.w == tj.w;
                     }
                 }
                 if (same) { atomicAdd(&lc[s], 1u); break; }
@@ -404,10 +350,8 @@ k_part_insert(PartArgs a) {
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                      // all lanes are done with the tile before it is refilled
-        t = nt; seg0 = nseg0; n_words = nn_words; pos = npos;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tw[q] = nw[q];
+        __builtin_amdgcn_wave_barrier();                      // all lanes are done with the step before its LDS copy is replaced
+        t = nt; base = nbase; n_gr = nn_gr; pos = npos; g = gn;
     }
     __syncthreads();
 
@@ -428,7 +372,7 @@ k_part_insert(PartArgs a) {
             const uint32_t rep = (uint32_t)w;
             const uint64_t cid = a.base_classes + s_cid0 + i;
             const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
-            const uint32_t* p = a.words + rep;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(a.bins + rep);
             const uint32_t w0 = p[0] & ~kHeadBit;
             auto word = [&](uint32_t k) { return k ? p[k + 1] : w0; };
             entry_write(a.arena, dst, word, len);
@@ -448,20 +392,20 @@ k_part_insert(PartArgs a) {
 }
 
 // deferred labels (region full): copy them out of the bins into a small CSR batch that the generic path can insert
-// after the table has grown.  deferred[2 i] = word index of the label in the bins, deferred[2 i + 1] = its length.
+// after the table has grown.  deferred[2 i] = granule index of the label in the bins, deferred[2 i + 1] = its length.
 __global__ void k_deferred_lens(uint64_t n, const uint32_t* __restrict__ deferred, uint32_t* lens) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     lens[i] = (i == n) ? 0u : deferred[2 * i + 1];
 }
-__global__ void k_deferred_copy(uint64_t n, const uint32_t* __restrict__ deferred, const uint32_t* __restrict__ words,
+__global__ void k_deferred_copy(uint64_t n, const uint32_t* __restrict__ deferred, const uint4* __restrict__ bins,
                                 const uint64_t* __restrict__ off64, uint32_t* ids_out, uint32_t* off_out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     off_out[i] = (uint32_t)off64[i];
     if (i == n) return;
     uint32_t len = (uint32_t)(off64[i + 1] - off64[i]);
-    const uint32_t* p = words + deferred[2 * i];
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(bins + deferred[2 * i]);
     uint32_t* q = ids_out + off64[i];
     q[0] = p[0] & ~kHeadBit;
     for (uint32_t k = 1; k < len; ++k) q[k] = p[k + 1];

@@ -125,8 +125,8 @@ class DistributedQuant:
         eng.sync(); t1 = time.perf_counter()
         bst = b.stats()
         info["t_insert_ms"] = bst["insert_ms"]; info["insert_launches"] = bst.get("insert_launches", 1)
-        # a "launch" of the class build is one sub-batch: pass 1a + 1b + 2 of the radix-partitioned path
-        info["insert_kernels"] = "k_part_hist+k_part_scatter+k_part_insert (per sub-batch)"
+        # a "launch" of the class build is one sub-batch: pass 1 (route) + pass 2 (insert) of the radix-partitioned path
+        info["insert_kernels"] = "k_part_route+k_part_insert (per sub-batch)"
         info["t_build_ms"] = (t1 - t0) * 1e3
         if self.world > 1:
             vec = self._merge(vec)

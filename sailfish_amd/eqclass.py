@@ -87,8 +87,11 @@ class EquivalenceClassBuilder:
             torch.cuda.current_stream().synchronize()   # the builder works on its creation stream
             _lib.check(self._L.sfgpu_eq_add_batch_device(self._h, _lib.ptr(ids_t), _lib.ptr(off_t), n))
         else:
-            ids_h = np.ascontiguousarray(ids.cpu().numpy() if isinstance(ids, torch.Tensor) else ids).astype(np.uint32, copy=False)
-            off_h = np.ascontiguousarray(offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else offsets).astype(np.uint32, copy=False)
+            def _host_u32(a):          # no copy for 32-bit integer arrays (a pinned 8 GB batch must stay where it is)
+                a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+                a = np.ascontiguousarray(a)
+                return a.view(np.uint32) if a.dtype in (np.int32, np.uint32) else a.astype(np.uint32)
+            ids_h, off_h = _host_u32(ids), _host_u32(offsets)
             if ids_h.size == 0:
                 ids_h = np.zeros(1, np.uint32)
             _lib.check(self._L.sfgpu_eq_add_batch_host(self._h, _lib.ptr(ids_h), _lib.ptr(off_h), n))

@@ -39,7 +39,8 @@ def _worker(rank, world, port, mode, vb, out, merge_mode="auto"):
             gs = q.gibbs(7, seed=3, n_chains=64)
             N = exp.numMappedFragments()
             assert bs.shape == (5, M) and gs.shape == (7, M)
-            assert torch.allclose(bs.sum(1), torch.full((5,), float(N), dtype=torch.float64, device=dev), rtol=1e-6)
+            # EM conserves the reads; VBEM adds the prior (0.01 per transcript) and the truncation removes at most as much
+            assert float((bs.sum(1) - float(N)).abs().max()) <= (0.011 * M if vb else 0.0) + 1e-6 * N
             assert bool((gs.sum(1) == N).all())
         out.put((rank, info["em_mode"], info["n_classes"], info["nnz"], exp.numMappedFragments(), info["em_stats"]["iters"],
                  t.estCount.cpu().numpy(), info["tpm"].cpu().numpy(), ids.numpy().copy(), off.numpy().copy()))

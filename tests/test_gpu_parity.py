@@ -183,6 +183,31 @@ def test_builder_host_batches_from_threads(sf, gpu):
     _assert_same_classes(eq, ob, *oc)
 
 
+@pytest.mark.parametrize("chunk", ["250000", None])
+def test_builder_large_host_batch_is_streamed_in_chunks(sf, gpu, monkeypatch, chunk):
+    """ONE large host batch (the pinned-memory entry of SURVEY 8d): it goes through two device staging buffers in
+    chunks, the copy of chunk k + 1 overlapping the build of chunk k.  chunk=250000 forces ~20 chunks with ragged
+    boundaries and an offsets array that does not start at 0; None is the production chunk size (one chunk here)."""
+    import torch
+    from sailfish_amd import synth
+    if chunk:
+        monkeypatch.setenv("SFGPU_EQ_HOST_CHUNK", chunk)
+    _, ids, off = synth.workload(20_000, 300_000, 5_000_000, seed=5)
+    ids_np = ids.numpy().view(np.uint32); off_np = off.numpy().view(np.uint32)
+    ob, *oc = _oracle_classes([(ids_np, off_np)])
+    h_ids = torch.empty(ids.shape, dtype=torch.int32, pin_memory=True); h_ids.copy_(ids)
+    h_off = torch.empty(off.shape, dtype=torch.int32, pin_memory=True); h_off.copy_(off)
+    eq = sf.EquivalenceClassBuilder(device=gpu)
+    eq.start(); eq.add_batch(h_ids, h_off); eq.finish()
+    _assert_same_classes(eq, ob, *oc)
+    # a slice of a larger array: offsets with a non-zero base, handed over in two calls
+    eq.start()
+    cut = 2_222_223
+    eq.add_batch(h_ids, h_off[:cut + 1]); eq.add_batch(h_ids, h_off[cut:])
+    eq.finish()
+    _assert_same_classes(eq, ob, *oc)
+
+
 @pytest.mark.parametrize("sub_batch", ["65536", None])
 def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
     """more distinct classes than the table budget: deferred reads are replayed after growth.

@@ -7,15 +7,17 @@ G2="TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum T
 G3="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 G4="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY"
 G5="TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
+G6="FETCH_SIZE"
+G7="WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
 i=0
-for G in "$G1" "$G2" "$G3" "$G4" "$G5"; do
+for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6" "$G7"; do
   i=$((i+1)); cd /tmp; rm -rf /tmp/eqc$i
   EQ_CFG3=1 rocprofv3 --pmc $G --output-format csv -d /tmp/eqc$i -- python $GRAFT_REPO_ROOT/tools/eq_probe.py > /tmp/eqc$i.out 2>&1 || echo "pass $i failed: $(tail -2 /tmp/eqc$i.out)"
 done
 python - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.Counter())
-for i in range(1, 6):
+for i in range(1, 8):
     fs = glob.glob(f'/tmp/eqc{i}/**/*counter_collection.csv', recursive=True)
     if not fs: continue
     for r in csv.DictReader(open(fs[0])):

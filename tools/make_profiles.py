@@ -16,6 +16,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FETCH_X2 = ("k_sweep_lds", "k_part_route", "k_part_insert", "k_filter", "k_export")
 
 
 def find(d, suffix):
@@ -64,26 +65,33 @@ def main():
     fe, wr = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1])):
+        if not k.startswith("k_"):
+            continue                        # torch ops of the input generator: not part of the path
         n = max(fe.get(k, [0, 0])[0], wr.get(k, [0, 0])[0], 1)
         kernels[k] = {"launches": n,
                       "fetch_kib_per_launch": fe.get(k, [0, 0.0])[1] / max(fe.get(k, [1, 0])[0], 1),
-                      "write_kib_per_launch": wr.get(k, [0, 0.0])[1] / max(wr.get(k, [1, 0])[0], 1)}
+                      "write_kib_per_launch": wr.get(k, [0, 0.0])[1] / max(wr.get(k, [1, 0])[0], 1),
+                      # MI355X_MICROARCH.md, HBM: gfx950 reports a wide (16 B per lane) coalesced streaming read at half its
+                      # size.  Which kernels read that way: the sweep (label stream), the route pass (ids staged with
+                      # 16-byte loads), the insert pass (one 16-byte granule per lane); the EM update reads 8 B per lane.
+                      "fetch_x2": any(k.startswith(p) for p in FETCH_X2)}
     for name in (f"pmc_{workload}.json", "pmc_latest.json"):     # bench.py reads the file of its workload
         json.dump({"workload": workload, "source": f"profiles/{tag}_pmc_summary.md", "kernels": kernels},
                   open(os.path.join(prof, name), "w"), indent=1)
     with open(os.path.join(prof, f"{tag}_pmc_summary.md"), "w") as f:
         f.write(f"# {tag}: per-kernel time and HBM traffic, `bench.py --workload {workload}` on one MI355X\n\n"
                 "Three separate rocprofv3 runs of the same command (kernel trace + stats; `--pmc FETCH_SIZE`; "
-                "`--pmc WRITE_SIZE`).\nFETCH/WRITE are KiB per launch, raw counter values (gfx950 reports wide "
-                "streaming reads at half size: x2 for the sweep).\n"
+                "`--pmc WRITE_SIZE`).\nFETCH/WRITE are KiB per launch, raw counter values.  gfx950 reports wide (16 B per lane) "
+                "coalesced streaming reads at half their size (MI355X_MICROARCH.md, HBM): kernels marked x2 read that way and "
+                "bench.py doubles their FETCH before comparing with byte counts; WRITE_SIZE is taken as reported.\n"
                 "`at::native::*` / `compute_cuda_kernel` rows are torch ops of the synthetic input generator "
                 "(bench set-up, outside the timed region).\n\n"
-                "| kernel | calls | avg us | % time | FETCH KiB/launch | WRITE KiB/launch |\n|---|---:|---:|---:|---:|---:|\n")
+                "| kernel | calls | avg us | % time | FETCH KiB/launch | WRITE KiB/launch | FETCH correction |\n|---|---:|---:|---:|---:|---:|---|\n")
         for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
             e = kernels.get(k)
             k = k if len(k) <= 72 else k[:69] + "..."
             f.write(f"| `{k}` | {calls} | {avg / 1e3:.2f} | {pct:.2f} | "
-                    + (f"{e['fetch_kib_per_launch']:.1f} | {e['write_kib_per_launch']:.1f} |\n" if e else "- | - |\n"))
+                    + (f"{e['fetch_kib_per_launch']:.1f} | {e['write_kib_per_launch']:.1f} | {'x2' if e['fetch_x2'] else 'x1'} |\n" if e else "- | - | |\n"))
     print("wrote", tag, "with", len(stats), "kernels;", len(kernels), "with counters")
 
 
