@@ -93,6 +93,36 @@ SFGPU_API int sfgpu_eq_add_batch_device(sfgpu_eq* eq, const uint32_t* d_ids, con
  * different GPUs; same limits and synchronisation as sfgpu_eq_add_batch_device. */
 SFGPU_API int sfgpu_eq_add_weighted_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets,
                                  const uint64_t* d_counts, uint32_t n_groups);
+/* ---- the class-table exchange of a multi-GPU run (the reference has one table in one process) ----------
+ * One process / thread per GPU builds the table of ITS reads; afterwards every rank must hold the table a single
+ * builder would have produced from all reads.  The library does the device work on class tables in CSR form (the
+ * sfgpu_eq_export_device arrays); the HOST moves the byte blocks (RCCL, MPI, ...):
+ *   1. owner(class) = a function of its XXH64 mod N.  sfgpu_eqvec_owner_sizes -> classes / ids per owner;
+ *      sfgpu_eqvec_pack_by_owner -> N blocks, block d = [counts u64[c_d] | lens u32[c_d] | ids u32[l_d] | pad to 8 B]
+ *      at d_blocks + h_block_off[d] (SFGPU_BLOCK_BYTES(c_d, l_d) bytes; classes keep their canonical order).
+ *   2. all-to-all: block d goes to rank d.  The owner folds what it received with sfgpu_eq_add_block_device (upsert:
+ *      equal labels add their counts), finish()es and exports ITS partition of the merged table.
+ *   3. sfgpu_eqvec_export_block -> the partition as one block [counts u64[C] | hashes u64[C] | lens u32[C] | ids u32[L]]
+ *      (SFGPU_GATHER_BYTES(C, L) bytes); all-gather of the blocks: the partitions are DISJOINT.
+ *   4. sfgpu_eqvec_merge_disjoint -> the union in the canonical order (first id, XXH64, length, label), as CSR: a sort
+ *      of (first id, hash) keys and a gather, nothing is hashed again.  *same_key_twice = 1 (and no output) if two
+ *      different labels share first id and XXH64: fold the blocks through a builder instead (never seen).
+ * Integer work throughout: the result equals the single-builder table class for class, in order.  n_owners <= 256,
+ * n_parts <= 64; the h_* arrays are host arrays; calls are synchronous on `stream`. */
+#define SFGPU_BLOCK_BYTES(c, l) ((12ull * (uint64_t)(c) + 4ull * (uint64_t)(l) + 7ull) & ~7ull)
+#define SFGPU_GATHER_BYTES(c, l) (20ull * (uint64_t)(c) + 4ull * (uint64_t)(l))
+SFGPU_API int sfgpu_eqvec_owner_sizes(const uint32_t* d_rowptr, const uint64_t* d_hashes, uint64_t n_classes, uint32_t n_owners,
+                                      uint64_t* h_classes, uint64_t* h_ids, sfgpu_stream stream);
+SFGPU_API int sfgpu_eqvec_pack_by_owner(const uint32_t* d_rowptr, const uint32_t* d_ids, const uint64_t* d_counts, const uint64_t* d_hashes,
+                                        uint64_t n_classes, uint32_t n_owners, const uint64_t* h_classes, const uint64_t* h_ids,
+                                        void* d_blocks, uint64_t* h_block_off /* [n_owners + 1] */, sfgpu_stream stream);
+SFGPU_API int sfgpu_eq_add_block_device(sfgpu_eq* eq, const void* d_block, uint64_t n_classes, uint64_t n_ids, sfgpu_stream stream);
+SFGPU_API int sfgpu_eqvec_export_block(const uint32_t* d_rowptr, const uint32_t* d_ids, const uint64_t* d_counts, const uint64_t* d_hashes,
+                                       uint64_t n_classes, uint64_t n_ids, void* d_block, sfgpu_stream stream);
+SFGPU_API int sfgpu_eqvec_merge_disjoint(const void* const* d_blocks, const uint64_t* n_classes, const uint64_t* n_ids, uint32_t n_parts,
+                                         uint32_t* d_rowptr, uint32_t* d_ids, uint64_t* d_counts, uint64_t* d_hashes,
+                                         int* same_key_twice, sfgpu_stream stream);
+
 /* Builder counters since the last start(): device time of the insert kernel (HIP events on the
  * builder's stream), launches, table growths, deferred-and-replayed reads, current table slots. */
 typedef struct {
@@ -202,6 +232,19 @@ SFGPU_API double* sfgpu_em_alpha(sfgpu_em* em);
 SFGPU_API double* sfgpu_em_lengths(sfgpu_em* em);
 SFGPU_API int sfgpu_em_set_bounds(sfgpu_em* em, uint32_t min_iter, uint32_t max_iter);
 SFGPU_API int sfgpu_em_rebase(sfgpu_em* em, const double* d_len);
+/* The sharded loop as ONE call (classes partitioned over the GPUs, alpha replicated, one SUM all-reduce of
+ * alphaOut per iteration): `em` holds THIS rank's slice of the classes; `allreduce` must leave the element-wise sum over
+ * all ranks in d_buf on every rank (in place; it may enqueue on `stream`, the stream the loop runs on, or synchronise --
+ * e.g. ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, comm, stream)).  Runs begin -> all-reduce (union of the
+ * active sets) -> init -> { sweep, all-reduce, update } with the stop latch polled every `poll_every` iterations ->
+ * finish: every rank stops at the same iteration with the same alpha (the reference's stop iteration for the union of
+ * the classes).  Same outputs and return codes as sfgpu_em_optimize.  Replaces the reference's
+ * CollapsedEMOptimizer::optimize call (src/SailfishQuantify.cpp:1343) in a multi-GPU host. */
+typedef int (*sfgpu_allreduce_fn)(double* d_buf, uint64_t n, void* user, sfgpu_stream stream);
+SFGPU_API int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_allreduce_fn allreduce, void* user,
+                                        uint32_t poll_every, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats);
+/* the stream the handle's kernels run on (what to pass to a collective that must be ordered with them) */
+SFGPU_API sfgpu_stream sfgpu_em_stream(sfgpu_em* em);
 /* Launch the E-step sweep kernel `n` times back to back (state untouched afterwards) and
  * return its average duration from HIP events on the stream: the live roofline measurement. */
 SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n, double* avg_ms);

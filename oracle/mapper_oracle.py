@@ -1,0 +1,93 @@
+"""CPU restatement of the quasi-mapping front end's CONTRACT (test infrastructure: only tests/ may import it).
+
+PARITY UNPINNED.  The reference maps reads with RapMap (COMBINE-lab/RapMap @ sf-v0.10.1, fetched by
+scripts/fetchRapMap.sh:20; call sites src/SailfishQuantify.cpp:141-142, 192-213, 487-488, 526-528), which is absent
+from the reference tree and cannot be built here; nothing in the reference pins its output.  What is restated below is
+therefore not RapMap but the contract of this repository's mapper (sailfish_amd/csrc/mapper.hip): the simplest
+exact-seed scheme that yields the KIND of record the hot path consumes (the QuasiAlignment fields sfgpu_hit carries),
+checked against the ground truth the reference's bundled sample_data carries in its read names.
+
+  index   : every k-mer (k = 31) of every transcript that consists of A/C/G/T only (case folded), with its
+            (transcript, position); occurrences of a k-mer in (transcript, position) order, at most `max_occ` kept.
+  a read  : two seeds, at offsets 0 and len - k (reads shorter than k do not map), looked up on the forward strand
+            (fwd = 1) and as reverse complement (fwd = 0), in the order fwd-seed0, fwd-seed1, rc-seed0, rc-seed1; the FIRST
+            occurrence seen for a (transcript, strand) fixes the read's position there: p - seed offset (may be negative).
+            The read's hits are sorted by (transcript, strand).
+  a pair  : every (left hit, right hit) on one transcript with opposite strands is a PAIRED_END_PAIRED record (status 3,
+            fragment length = max end - min start); if there is none, the left hits (status 1) then the right hits
+            (status 2) are kept as orphans.
+  single  : status 0 records."""
+import numpy as np
+
+from .oracle import HIT_DTYPE
+
+_CODE = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}     # ACGTacgt
+
+
+def _codes(seq: bytes):
+    return np.array([_CODE.get(b, 4) for b in seq], np.uint8)
+
+
+def build_index(transcripts, k=31, max_occ=1000):
+    """transcripts: list of bytes -> dict kmer tuple-free key (python int, 2 bits per base, first base most significant)"""
+    index = {}
+    for t, s in enumerate(transcripts):
+        c = _codes(s)
+        for p in range(len(c) - k + 1):
+            w = c[p:p + k]
+            if (w > 3).any():
+                continue
+            key = 0
+            for x in w:
+                key = (key << 2) | int(x)
+            lst = index.setdefault(key, [])
+            if len(lst) < max_occ:
+                lst.append((t, p))
+    return index
+
+
+def _key(codes):
+    if len(codes) == 0 or (codes > 3).any():
+        return None
+    key = 0
+    for x in codes:
+        key = (key << 2) | int(x)
+    return key
+
+
+def map_read(index, read: bytes, k=31):
+    c = _codes(read)
+    n = len(c)
+    if n < k:
+        return []
+    rc = (3 - c[::-1]).astype(np.uint8); rc[c[::-1] > 3] = 4
+    found = {}
+    for fwd, q in ((1, c), (0, rc)):
+        for o in (0, n - k):
+            key = _key(q[o:o + k])
+            if key is None:
+                continue
+            for t, p in index.get(key, ()):
+                found.setdefault((t, fwd), p - o)
+    return sorted((t, fwd, p) for (t, fwd), p in found.items())
+
+
+def map_reads(index, reads1, reads2=None, k=31):
+    """-> (hits HIT_DTYPE[n], offsets uint32[R + 1])"""
+    recs, off = [], [0]
+    for i, r1 in enumerate(reads1):
+        left = map_read(index, r1, k)
+        if reads2 is None:
+            recs += [(t, p, 0, 0, len(r1), 0, f, 0, 0, 0) for t, f, p in left]
+        else:
+            r2 = reads2[i]
+            right = map_read(index, r2, k)
+            paired = [(t, f, p, f2, p2) for t, f, p in left for t2, f2, p2 in right if t2 == t and f2 != f]
+            if paired:
+                for t, f, p, f2, p2 in paired:
+                    recs.append((t, p, p2, max(p + len(r1), p2 + len(r2)) - min(p, p2), len(r1), len(r2), f, f2, 3, 0))
+            else:
+                recs += [(t, p, 0, 0, len(r1), len(r2), f, 0, 1, 0) for t, f, p in left]
+                recs += [(t, p, 0, 0, len(r2), len(r1), f, 0, 2, 0) for t, f, p in right]
+        off.append(len(recs))
+    return np.array(recs, dtype=HIT_DTYPE), np.array(off, np.uint32)

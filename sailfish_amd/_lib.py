@@ -45,6 +45,7 @@ class EqStats(C.Structure):
 
 
 _LOG_CB = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p)      # sfgpu_allreduce_fn
 SAMPLE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_uint64, C.c_void_p)
 GIBBS_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), C.c_uint64, C.c_void_p)
 _lib = None
@@ -128,6 +129,13 @@ _SIGS = {
     "sfgpu_em_update": (C.c_int, [_P]),
     "sfgpu_em_poll": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(EmStats)]),
     "sfgpu_em_finish": (C.c_int, [_P, _P, _P, C.POINTER(EmStats)]),
+    "sfgpu_em_optimize_sharded": (C.c_int, [_P, C.POINTER(EmOpts), ALLREDUCE_CB, _P, C.c_uint32, _P, _P, C.POINTER(EmStats)]),
+    "sfgpu_em_stream": (_P, [_P]),
+    "sfgpu_eqvec_owner_sizes": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P, _P, _P]),
+    "sfgpu_eqvec_pack_by_owner": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P]),
+    "sfgpu_eq_add_block_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
+    "sfgpu_eqvec_export_block": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
+    "sfgpu_eqvec_merge_disjoint": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, _P, _P, C.POINTER(C.c_int), _P]),
     "sfgpu_em_alpha_out": (_P, [_P]),
     "sfgpu_em_alpha": (_P, [_P]),
     "sfgpu_em_lengths": (_P, [_P]),

@@ -1040,6 +1040,41 @@ int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu
     return SFGPU_OK;
 }
 
+sfgpu_stream sfgpu_em_stream(sfgpu_em* em) { return em ? reinterpret_cast<sfgpu_stream>(em->cur) : nullptr; }
+
+// classes partitioned over the ranks, alpha replicated, one SUM all-reduce of alphaOut per iteration; the
+// transport is the caller's (RCCL in a multi-GPU host), the loop is the piecewise one
+int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_allreduce_fn allreduce, void* user, uint32_t poll_every,
+                              double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats) {
+    SF_REQUIRE(em && opts && allreduce && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_optimize_sharded: null pointer");
+    int rc;
+    if ((rc = sfgpu_em_begin(em, opts))) return rc;
+    const uint64_t M = em->prob.M;
+    auto reduce = [&]() -> int {
+        const int cr = allreduce(em->alpha_out, M, user, reinterpret_cast<sfgpu_stream>(em->cur));
+        if (cr) { set_error("sfgpu_em_optimize_sharded: the all-reduce callback returned %d", cr); return SFGPU_ERR_STATE; }
+        return SFGPU_OK;
+    };
+    if ((rc = reduce())) return rc;                                             // union of the ranks' active sets
+    if ((rc = sfgpu_em_init(em))) return rc;
+    int done = 0;
+    sfgpu_em_stats st{};
+    if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+    if (st.n_active == 0) {                                                      // :794-798
+        set_error("It seems that no transcripts are expressed; something is likely wrong!");
+        if (stats) *stats = st;
+        return SFGPU_ERR_NO_ACTIVE;
+    }
+    if (poll_every == 0) poll_every = 16;
+    while (!done) {
+        for (uint32_t i = 0; i < poll_every; ++i) {                              // iterations past the stop are no-ops on every rank alike
+            if ((rc = sfgpu_em_sweep(em)) || (rc = reduce()) || (rc = sfgpu_em_update(em))) return rc;
+        }
+        if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+    }
+    return sfgpu_em_finish(em, d_alpha_out, d_mass_out, stats);
+}
+
 static bool same_opts(const sfgpu_em_opts& a, const sfgpu_em_opts& b) {
     return a.use_vbem == b.use_vbem && a.tol == b.tol && a.min_iter == b.min_iter && a.max_iter == b.max_iter &&
            a.check_mode == b.check_mode && a.iters_per_launch == b.iters_per_launch;

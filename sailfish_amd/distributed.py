@@ -55,6 +55,72 @@ class HipEngine:
     def bias_model(self, exp, sopt):
         return exp.biasModel(sopt)
 
+    # ---- class-table exchange: the device work of sfgpu_eqvec_* / sfgpu_eq_add_block_device (csrc/merge.hip) ----
+    def pack_by_owner(self, vec, n_owners):
+        """-> (uint8 device tensor holding the n_owners blocks back to back, [(classes, ids)] per owner)"""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        n = int(vec.size())
+        hc = (C.c_uint64 * n_owners)(); hi = (C.c_uint64 * n_owners)(); off = (C.c_uint64 * (n_owners + 1))()
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            st = _lib.current_stream_ptr()
+            _lib.check(L.sfgpu_eqvec_owner_sizes(_lib.ptr(vec.rowptr), _lib.ptr(vec.hashes), n, n_owners, hc, hi, st))
+            sizes = [(int(hc[d]), int(hi[d])) for d in range(n_owners)]
+            total = sum(block_bytes(c, l) for c, l in sizes)
+            buf = torch.empty(max(total, 8), dtype=torch.uint8, device=self.device)
+            _lib.check(L.sfgpu_eqvec_pack_by_owner(_lib.ptr(vec.rowptr), _lib.ptr(vec.ids), _lib.ptr(vec.counts), _lib.ptr(vec.hashes), n,
+                                                   n_owners, hc, hi, _lib.ptr(buf), off, st))
+        return buf[:total], sizes
+
+    def fold_block(self, builder, block, n_classes, n_ids):
+        """upsert the classes of one [counts | lens | ids] block into a started builder"""
+        from . import _lib
+        if n_classes == 0:
+            return
+        assert block.data_ptr() % 8 == 0
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(_lib.lib().sfgpu_eq_add_block_device(builder._h, _lib.ptr(block), int(n_classes), int(n_ids), _lib.current_stream_ptr()))
+
+    def export_block(self, vec):
+        """the table as one [counts | hashes | lens | ids] block (uint8 device tensor)"""
+        from . import _lib
+        n, l = int(vec.size()), int(vec.ids.numel())
+        buf = torch.empty(max(20 * n + 4 * l, 8), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            st = _lib.current_stream_ptr()
+            _lib.check(_lib.lib().sfgpu_eqvec_export_block(_lib.ptr(vec.rowptr), _lib.ptr(vec.ids), _lib.ptr(vec.counts), _lib.ptr(vec.hashes),
+                                                           n, l, _lib.ptr(buf), st))
+            torch.cuda.current_stream().synchronize()
+        return buf[:20 * n + 4 * l]
+
+    def merge_disjoint(self, blocks, sizes):
+        """disjoint partitions in export_block format -> the merged table in canonical order, or None if two labels share
+        first id and XXH64 (the caller then folds the partitions through a builder)"""
+        import ctypes as C
+        from . import _lib
+        from .eqclass import EqVec
+        w = len(blocks)
+        n = sum(c for c, _ in sizes); l = sum(x for _, x in sizes)
+        if l >= 2 ** 32 or n >= 2 ** 32:
+            return None
+        dev = self.device
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev); ids = torch.empty(l, dtype=torch.int32, device=dev)
+        counts = torch.empty(n, dtype=torch.int64, device=dev); hashes = torch.empty(n, dtype=torch.int64, device=dev)
+        ptrs = (C.c_void_p * w)(*[b.data_ptr() if b.numel() else 0 for b in blocks])
+        nc = (C.c_uint64 * w)(*[c for c, _ in sizes]); ni = (C.c_uint64 * w)(*[x for _, x in sizes])
+        tie = C.c_int(0)
+        with torch.cuda.device(dev):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(_lib.lib().sfgpu_eqvec_merge_disjoint(ptrs, nc, ni, w, _lib.ptr(rowptr), _lib.ptr(ids), _lib.ptr(counts), _lib.ptr(hashes),
+                                                             C.byref(tie), _lib.current_stream_ptr()))
+        if tie.value:
+            return None
+        return EqVec(rowptr, ids, counts, hashes, int(counts.sum().item()) if n else 0)
+
     def gibbs_sample(self, length, mass, rowptr, ids, counts, num_mapped, n, n_chains=0, seed=1):
         from .gibbs import gibbs_sample
         return gibbs_sample(length, mass, rowptr, ids, counts, num_mapped, n, n_chains=n_chains, seed=seed)
@@ -64,6 +130,11 @@ class HipEngine:
 
     def sync(self):
         torch.cuda.synchronize(self.device)
+
+
+def block_bytes(c, l):
+    """SFGPU_BLOCK_BYTES: [counts u64[c] | lens u32[c] | ids u32[l]] padded to 8 bytes"""
+    return (12 * c + 4 * l + 7) & ~7
 
 
 def _all_gather_var(t, group, world):
@@ -156,53 +227,23 @@ class DistributedQuant:
     def _concat_disjoint(self, vec):
         """All-gather of the ranks' DISJOINT partitions and assembly of the merged table without hashing anything
         again: the union of disjoint class sets only has to be put into the canonical order (first id, XXH64,
-        length, label), a sort of (first id, hash) keys.  Two different labels with the same first id and the same
+        length, label) -- sfgpu_eqvec_merge_disjoint.  Two different labels with the same first id and the same
         64-bit hash would need the last two keys: then None is returned and the caller folds the partitions
         through a builder instead."""
         import torch.distributed as dist
-        from .eqclass import EqVec
         w = self.world
-        dev = vec.ids.device
-        rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
-        lens = (rp[1:] - rp[:-1]).to(torch.int32)
-        C, L = int(lens.numel()), int(vec.ids.numel())
-        mine = torch.tensor([C, L], dtype=torch.int64, device=dev)
+        block = self.engine.export_block(vec)                             # [counts i64 | hashes i64 | lens i32 | ids i32]
+        dev = block.device
+        mine = torch.tensor([int(vec.size()), int(vec.ids.numel())], dtype=torch.int64, device=dev)
         sizes = [torch.zeros_like(mine) for _ in range(w)]
         dist.all_gather(sizes, mine, group=self.group)
-        sizes = torch.stack(sizes).cpu().tolist()
-        nbytes = [20 * c + 4 * l for c, l in sizes]                   # [counts i64 | hashes i64 | lens i32 | ids i32]
-        block = torch.zeros(max(max(nbytes), 8), dtype=torch.uint8, device=dev)
-        block[:8 * C] = vec.counts.to(torch.int64).contiguous().view(torch.uint8)
-        block[8 * C:16 * C] = vec.hashes.to(torch.int64).contiguous().view(torch.uint8)
-        block[16 * C:20 * C] = lens.contiguous().view(torch.uint8)
-        block[20 * C:20 * C + 4 * L] = vec.ids.contiguous().view(torch.uint8)
-        blocks = [torch.empty_like(block) for _ in range(w)]
-        dist.all_gather(blocks, block, group=self.group)
-        cnt = torch.cat([b[:8 * c].view(torch.int64) for b, (c, l) in zip(blocks, sizes)])
-        hsh = torch.cat([b[8 * c:16 * c].view(torch.int64) for b, (c, l) in zip(blocks, sizes)])
-        ln = torch.cat([b[16 * c:20 * c].view(torch.int32) for b, (c, l) in zip(blocks, sizes)]).to(torch.int64)
-        ids = torch.cat([b[20 * c:20 * c + 4 * l].view(torch.int32) for b, (c, l) in zip(blocks, sizes)])
-        n = int(cnt.numel())
-        if int(ids.numel()) >= 2 ** 32:
-            return None
-        src = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(ln, 0, out=src[1:])
-        if n == 0:
-            return EqVec(torch.zeros(1, dtype=torch.int32, device=dev), ids, cnt, hsh, 0)
-        first = ids[src[:-1]].to(torch.int64) & 0xFFFFFFFF            # every class has at least one id
-        o1 = torch.argsort(hsh ^ (-0x8000000000000000), stable=True)  # unsigned order of the hashes
-        order = o1[torch.argsort(first[o1], stable=True)]
-        f_o, h_o = first[order], hsh[order]
-        if n > 1 and bool(((f_o[1:] == f_o[:-1]) & (h_o[1:] == h_o[:-1])).any()):
-            return None
-        ln_o = ln[order]
-        dst = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(ln_o, 0, out=dst[1:])
-        Ltot = int(dst[-1].item())
-        shift = torch.repeat_interleave(src[:-1][order] - dst[:-1], ln_o)
-        ids_o = ids[torch.arange(Ltot, device=dev) + shift]
-        cnt_o = cnt[order]
-        return EqVec(dst.to(torch.int32), ids_o, cnt_o, h_o, int(cnt_o.sum().item()))
+        sizes = [tuple(x) for x in torch.stack(sizes).cpu().tolist()]      # one host sync for all sizes
+        nbytes = [20 * c + 4 * l for c, l in sizes]
+        pad = torch.zeros(max(max(nbytes), 8), dtype=torch.uint8, device=dev)
+        pad[:block.numel()] = block
+        blocks = [torch.empty_like(pad) for _ in range(w)]
+        dist.all_gather(blocks, pad, group=self.group)
+        return self.engine.merge_disjoint([b[:nb] for b, nb in zip(blocks, nbytes)], sizes)
 
     def _reduce_at_owner(self, vec):
         """Pre-reduction for N > 2 (owner(class) = hash mod G, one all-to-all of (label, count) partials):
@@ -212,42 +253,15 @@ class DistributedQuant:
         less traffic).  Integer work: the merged table is bit-identical to the all-gather-only merge."""
         import torch.distributed as dist
         w, me = self.world, self.rank
-        dev = vec.ids.device
-        rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
-        lens = rp[1:] - rp[:-1]
-        C = int(lens.numel())
-        owner = ((vec.hashes.to(torch.int64) >> 33) & 0x3FFFFFFF) % w       # any function of the label every rank agrees on
-        order = torch.argsort(owner, stable=True)
-        per_owner_c = torch.bincount(owner, minlength=w)
-        lens_s = lens[order]
-        off_s = torch.zeros(C + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(lens_s, 0, out=off_s[1:])
-        L = int(off_s[-1].item()) if C else 0
-        # ids in owner order: entry j of the new list comes from  rp[order[c]] + (j - off_s[c])
-        shift = torch.repeat_interleave(rp[:-1][order] - off_s[:-1], lens_s)
-        ids_s = vec.ids[(torch.arange(L, device=dev) + shift)] if L else vec.ids[:0]
-        cnt_s = vec.counts.to(torch.int64)[order]
-        cb = torch.zeros(w + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(per_owner_c, 0, out=cb[1:])
-        lb = off_s[cb]                                                      # id offsets at the owner boundaries
-        mine = torch.stack([per_owner_c, lb[1:] - lb[:-1]], 1).reshape(-1)   # [c_0, l_0, c_1, l_1, ...]
+        send, mine_sizes = self.engine.pack_by_owner(vec, w)               # w blocks [counts | lens | ids | pad], owner order
+        dev = send.device
+        mine = torch.tensor([x for cl in mine_sizes for x in cl], dtype=torch.int64, device=dev)     # [c_0, l_0, c_1, l_1, ...]
         sizes = [torch.zeros_like(mine) for _ in range(w)]
         dist.all_gather(sizes, mine, group=self.group)
         S = torch.stack(sizes).cpu().reshape(w, w, 2).tolist()               # S[src][dst] = (classes, ids); one host sync
-        cb_h, lb_h = cb.cpu().tolist(), lb.cpu().tolist()
-        blk = lambda c, l: (12 * c + 4 * l + 7) & ~7                        # blocks are padded to 8 bytes (int64 views)
-        send_bytes = [blk(*S[me][d]) for d in range(w)]
-        recv_bytes = [blk(*S[src][me]) for src in range(w)]
-        pad4 = torch.zeros(4, dtype=torch.uint8, device=dev)
-        parts = []
-        for d in range(w):                                                  # block for rank d: [counts i64 | lens i32 | ids i32 | pad]
-            c0, c1, l0, l1 = cb_h[d], cb_h[d + 1], lb_h[d], lb_h[d + 1]
-            parts += [cnt_s[c0:c1].contiguous().view(torch.uint8), lens_s[c0:c1].to(torch.int32).contiguous().view(torch.uint8),
-                      ids_s[l0:l1].contiguous().view(torch.uint8)]
-            if (12 * (c1 - c0) + 4 * (l1 - l0)) % 8:
-                parts.append(pad4)
-        send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
-        recv = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=dev)
+        send_bytes = [block_bytes(*S[me][d]) for d in range(w)]
+        recv_bytes = [block_bytes(*S[src][me]) for src in range(w)]
+        recv = torch.empty(max(sum(recv_bytes), 8), dtype=torch.uint8, device=dev)[:sum(recv_bytes)]
         # the route is a function of the backend alone, so every rank takes the same one (a fallback chosen from a
         # caught exception could split the ranks between two different collectives)
         if dist.get_backend(self.group) == "nccl":
@@ -258,63 +272,40 @@ class DistributedQuant:
             full = _all_gather_var(send, self.group, w)
             pos = 0
             for src in range(w):
-                start = sum(blk(*S[src][d]) for d in range(me))
+                start = sum(block_bytes(*S[src][d]) for d in range(me))
                 recv[pos:pos + recv_bytes[src]] = full[src][start:start + recv_bytes[src]]
                 pos += recv_bytes[src]
-        cnts, lns, idl, pos = [], [], [], 0
-        for src in range(w):
-            c, l = S[src][me]
-            cnts.append(recv[pos:pos + 8 * c].view(torch.int64))
-            lns.append(recv[pos + 8 * c:pos + 12 * c].view(torch.int32))
-            idl.append(recv[pos + 12 * c:pos + 12 * c + 4 * l].view(torch.int32))
-            pos += recv_bytes[src]
         b = self.part
         b.start()
-        ln = torch.cat(lns).to(torch.int64)
-        off = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(ln, 0, out=off[1:])
-        if int(off[-1].item()) >= 2 ** 31:
-            raise RuntimeError("a rank's partition holds >= 2^31 ids: use merge_mode='allgather'")
-        b.insertGroups(torch.cat(idl), off.to(torch.int32), torch.cat(cnts))
+        pos = 0
+        for src in range(w):                                                 # upsert what every rank sent, in rank order
+            c, l = S[src][me]
+            self.engine.fold_block(b, recv[pos:pos + recv_bytes[src]], c, l)
+            pos += recv_bytes[src]
         b.finish()
         return b.eqVec()
 
     def _merge_allgather(self, vec):
-        """One exchange: every rank contributes its class table as one byte block
-        [counts i64[C] | lens i32[C] | ids i32[L]] (sizes first, then the padded blocks), and upserts the
-        tables of all ranks, in rank order, as ONE weighted batch -> the same table on every rank."""
+        """One exchange: every rank contributes its class table as one byte block [counts i64[C] | lens i32[C] | ids i32[L]]
+        (sizes first, then the padded blocks), and upserts the tables of all ranks, in rank order -> the same table on
+        every rank."""
         import torch.distributed as dist
         w = self.world
-        dev = vec.ids.device
-        rp = vec.rowptr.to(torch.int64) & 0xFFFFFFFF
-        lens = (rp[1:] - rp[:-1]).to(torch.int32)
-        C, L = int(lens.numel()), int(vec.ids.numel())
-        mine = torch.tensor([C, L], dtype=torch.int64, device=dev)
+        block, (cl,) = self.engine.pack_by_owner(vec, 1)                   # one owner: the whole table, canonical order
+        dev = block.device
+        mine = torch.tensor(list(cl), dtype=torch.int64, device=dev)
         sizes = [torch.zeros_like(mine) for _ in range(w)]
         dist.all_gather(sizes, mine, group=self.group)
         sizes = torch.stack(sizes).cpu().tolist()                     # one host sync for all sizes
-        nbytes = [12 * c + 4 * l for c, l in sizes]
-        block = torch.zeros(max(max(nbytes), 8), dtype=torch.uint8, device=dev)
-        block[:8 * C] = vec.counts.to(torch.int64).contiguous().view(torch.uint8)
-        block[8 * C:12 * C] = lens.contiguous().view(torch.uint8)
-        block[12 * C:12 * C + 4 * L] = vec.ids.contiguous().view(torch.uint8)
-        blocks = [torch.empty_like(block) for _ in range(w)]
-        dist.all_gather(blocks, block, group=self.group)
-        cnts = [b[:8 * c].view(torch.int64) for b, (c, l) in zip(blocks, sizes)]
-        lns = [b[8 * c:12 * c].view(torch.int32) for b, (c, l) in zip(blocks, sizes)]
-        ids = [b[12 * c:12 * c + 4 * l].view(torch.int32) for b, (c, l) in zip(blocks, sizes)]
+        nbytes = [block_bytes(c, l) for c, l in sizes]
+        pad = torch.zeros(max(max(nbytes), 8), dtype=torch.uint8, device=dev)
+        pad[:block.numel()] = block
+        blocks = [torch.empty_like(pad) for _ in range(w)]
+        dist.all_gather(blocks, pad, group=self.group)
         m = self.merged
         m.start()
-        r0 = 0
-        while r0 < w:                                                 # ranks [r0, r1): < 2^31 ids per upsert
-            r1, tot = r0 + 1, sizes[r0][1]
-            while r1 < w and tot + sizes[r1][1] < 2 ** 31:
-                tot += sizes[r1][1]; r1 += 1
-            ln = torch.cat(lns[r0:r1]).to(torch.int64)
-            off = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(ln, 0, out=off[1:])
-            m.insertGroups(torch.cat(ids[r0:r1]), off.to(torch.int32), torch.cat(cnts[r0:r1]))
-            r0 = r1
+        for b, (c, l), nb in zip(blocks, sizes, nbytes):
+            self.engine.fold_block(m, b[:nb], c, l)
         m.finish()
         return m.eqVec()
 

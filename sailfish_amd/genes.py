@@ -11,8 +11,11 @@ including two quirks a drop-in must keep:
   * a transcript absent from the map is looked up with lower_bound and no equality test (:94-99): it lands on the
     next name in sorted order, and is "its own gene" only past the last name.
 Lines of the output are in first-appearance order of the genes (the reference iterates an unordered_map: any order).
-The GTF form of the map goes through libgff (GffReader) in the reference and is not mirrored: pass the two-column
-transcript<TAB>gene form."""
+The GTF form of the map (`--geneMap x.gtf`, transcriptGeneMapFromGTF, :322-436) goes through libgff's GffReader in the
+reference -- a third-party library that is not in the reference tree (CMakeLists.txt:408-419 fetches it), so its record
+handling is restated from its use there: every record that carries a transcript_id makes (or extends) a transcript;
+the grouping key is gene_id, gene_name, or any attribute named by `agg_key`; transcripts are ordered by name, genes
+numbered by first appearance in that order.  Parity unpinned for this reader (no reference vector exists for it)."""
 import bisect
 import os
 
@@ -39,6 +42,38 @@ class TranscriptGeneMap:
     def from_file(cls, path):
         toks = open(path).read().split()                                  # `ifile >> transcript >> gene` until it fails
         return cls(list(zip(toks[0::2], toks[1::2])))
+
+    @classmethod
+    def from_gtf(cls, path, agg_key="gene_id"):
+        """transcriptGeneMapFromGTF (src/SailfishUtils.cpp:322-436).  GFF2/GTF records: 9 tab-separated columns, the last
+        one `key "value"; key "value"; ...`; lines starting with # are comments."""
+        first_key = {}                                                    # transcript_id -> value of the grouping key (first seen)
+        for line in open(path):
+            if not line.strip() or line.startswith("#"):
+                continue
+            cols = line.rstrip("\n").split("\t")
+            if len(cols) < 9:
+                continue
+            attrs = {}
+            for field in cols[8].split(";"):
+                field = field.strip()
+                if not field:
+                    continue
+                k, _, v = field.partition(" ")
+                attrs.setdefault(k, v.strip().strip('"'))
+            t = attrs.get("transcript_id")
+            if not t:
+                continue                                                  # gene records and the like: not a transcript (isTranscript())
+            if t not in first_key or first_key[t] is None:
+                first_key[t] = attrs.get(agg_key, first_key.get(t))
+        obj = cls.__new__(cls)
+        gene_id, obj.gene_names, obj.transcript_names, obj.t2g = {}, [], [], []
+        for t in sorted(first_key):                                       # std::sort by strcmp on the transcript ids (:392-395)
+            g = first_key[t] if first_key[t] is not None else ""
+            if g not in gene_id:
+                gene_id[g] = len(obj.gene_names); obj.gene_names.append(g)
+            obj.transcript_names.append(t); obj.t2g.append(gene_id[g])
+        return obj
 
     def num_transcripts(self): return len(self.transcript_names)
     def num_genes(self): return len(self.gene_names)
@@ -89,11 +124,13 @@ def aggregate_estimates_to_gene_level(tgm: TranscriptGeneMap, quant_path: str) -
     return out_path
 
 
-def generate_gene_level_estimates(gene_map_path: str, est_dir: str) -> str:
-    """generateGeneLevelEstimates (:1039-1088) for the simple map format."""
-    if gene_map_path.endswith(".gtf"):
-        raise NotImplementedError("GTF gene maps go through libgff in the reference; pass a transcript<TAB>gene file")
-    tgm = TranscriptGeneMap.from_file(gene_map_path)
+def generate_gene_level_estimates(gene_map_path: str, est_dir: str, agg_key: str = "gene_id") -> str:
+    """generateGeneLevelEstimates (:1039-1088): a map whose extension is .gtf is read as GTF, anything else as the
+    two-column format."""
+    if os.path.splitext(gene_map_path)[1] == ".gtf":
+        tgm = TranscriptGeneMap.from_gtf(gene_map_path, agg_key)
+    else:
+        tgm = TranscriptGeneMap.from_file(gene_map_path)
     est = os.path.join(est_dir, "quant.sf")
     if not os.path.exists(est):
         raise ValueError(f"Attempting to compute gene-level esimtates, but could not \nfind isoform-level file {est}")

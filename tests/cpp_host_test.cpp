@@ -2,9 +2,13 @@
 // classes on the hot path, written as its maintainers would -- mapping threads calling addGroup, finish(), optimize(),
 // the samplers with their std::function writers -- and checked against the known answers of SURVEY.md 8c (outputs of
 // the reference's own optimize()) and against a std::map.  Compiled by tests/test_abi.py; run on the GPU box.
+#include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <map>
+#include <mutex>
+#include <random>
 #include <thread>
 
 #include "sfgpu_sailfish.hpp"
@@ -18,6 +22,152 @@ static bool close_to(double a, double b, double rel) { return std::fabs(a - b) <
 static void toy(ReadExperiment& exp) {          // lens [1000,2000,500,1500], EffectiveLength = len - 199
     const uint32_t lens[4] = {1000, 2000, 500, 1500};
     for (size_t i = 0; i < 4; ++i) { exp.transcripts().emplace_back(i, ("t" + std::to_string(i)).c_str(), lens[i]); exp.transcripts().back().EffectiveLength = lens[i] - 199.0; }
+}
+
+// ---- SURVEY 8e through the C ABI alone: two ranks (threads) share this box's GPU.  Each builds the table of its half of
+// the reads; owner-partitioned exchange (pack -> "all-to-all" -> fold -> export -> "all-gather" -> merge); then the sharded
+// EM, classes cut in two, alphaOut summed over the ranks by the caller's all-reduce between sweep and update.  The
+// transport here is device pointers handed over at a barrier -- a multi-GPU host puts ncclSend / ncclAllReduce there.
+namespace {
+struct Barrier {
+    std::mutex m; std::condition_variable cv; int n, count = 0, gen = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() { std::unique_lock<std::mutex> lk(m); const int g = gen; if (++count == n) { count = 0; ++gen; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+};
+struct Table { std::vector<uint32_t> rowptr, ids; std::vector<uint64_t> counts, hashes; };
+struct Shared {
+    Barrier bar{2};
+    const void* blk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // blk[src][dst]
+    uint64_t sz[2][2][2] = {};                                          // [src][dst] -> (classes, ids)
+    const void* part[2] = {nullptr, nullptr}; uint64_t part_c[2] = {0, 0}, part_l[2] = {0, 0};
+    std::vector<double> red[2];
+    Table merged[2]; std::vector<double> alpha[2]; sfgpu_em_stats st[2];
+};
+struct ReduceCtx { Shared* sh; int rank; };
+int allreduce_two_threads(double* d_buf, uint64_t n, void* user, sfgpu_stream stream) {
+    ReduceCtx* c = static_cast<ReduceCtx*>(user);
+    if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return 1;
+    c->sh->red[c->rank].resize(n);
+    if (hipMemcpy(c->sh->red[c->rank].data(), d_buf, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    c->sh->bar.wait();
+    std::vector<double> sum(n);
+    for (uint64_t i = 0; i < n; ++i) sum[i] = c->sh->red[0][i] + c->sh->red[1][i];       // same order on both ranks: same bits
+    c->sh->bar.wait();
+    return hipMemcpy(d_buf, sum.data(), n * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : 3;
+}
+}  // namespace
+
+static int two_ranks_on_one_gpu() {
+    const int before = failures;
+    const uint32_t M = 3000;
+    // reads: labels {base + 7 j}, a few thousand distinct; every label shows up on both ranks
+    std::vector<std::vector<uint32_t>> reads;
+    std::mt19937_64 g(2026);
+    for (int i = 0; i < 200000; ++i) {
+        const uint32_t base = g() % 2500, k = 1 + g() % 9;
+        std::vector<uint32_t> lab;
+        for (uint32_t j = 0; j < k; ++j) lab.push_back((base + 7 * j) % M);
+        std::sort(lab.begin(), lab.end()); lab.erase(std::unique(lab.begin(), lab.end()), lab.end());
+        reads.push_back(lab);
+    }
+    auto pack = [&](size_t lo, size_t hi, std::vector<uint32_t>& ids, std::vector<uint32_t>& off) {
+        ids.clear(); off.assign(1, 0);
+        for (size_t r = lo; r < hi; ++r) { ids.insert(ids.end(), reads[r].begin(), reads[r].end()); off.push_back((uint32_t)ids.size()); }
+    };
+    auto build = [&](sfgpu_eq* eq, const std::vector<uint32_t>& ids, const std::vector<uint32_t>& off) {
+        check(sfgpu_eq_start(eq), "start");
+        check(sfgpu_eq_add_batch_host(eq, ids.data(), off.data(), (uint32_t)off.size() - 1), "add");
+    };
+    struct Dev { DeviceBuf<uint32_t> rowptr, ids; DeviceBuf<uint64_t> counts, hashes; uint64_t C = 0, L = 0; };
+    auto finish_export = [&](sfgpu_eq* eq, Dev& d) {
+        uint64_t tot = 0;
+        check(sfgpu_eq_finish(eq, &d.C, &d.L, &tot), "finish");
+        d.rowptr.resize(d.C + 1); d.ids.resize(d.L); d.counts.resize(d.C); d.hashes.resize(d.C);
+        check(sfgpu_eq_export_device(eq, d.rowptr.get(), d.ids.get(), d.counts.get(), d.hashes.get()), "export");
+        check_hip(hipDeviceSynchronize(), "sync");
+    };
+    // the single-builder table over all reads, and its EM
+    Table want; std::vector<double> want_alpha(M); sfgpu_em_stats want_st{};
+    std::vector<double> len(M);
+    for (uint32_t t = 0; t < M; ++t) len[t] = 300.0 + (double)((t * 2654435761u) % 3000);
+    DeviceBuf<double> d_len(len);
+    sfgpu_em_opts opts{}; opts.use_vbem = 0; opts.tol = 0.01; opts.min_iter = 50; opts.max_iter = 10000; opts.check_mode = 0; opts.iters_per_launch = 32;
+    {
+        sfgpu_eq* eq = nullptr; check(sfgpu_eq_create(&eq, 0, nullptr), "create");
+        std::vector<uint32_t> ids, off; pack(0, reads.size(), ids, off); build(eq, ids, off);
+        Dev d; finish_export(eq, d);
+        want.rowptr = d.rowptr.download(); want.ids = d.ids.download(); want.counts = d.counts.download(); want.hashes = d.hashes.download();
+        sfgpu_problem pr{}; pr.M = M; pr.d_len = d_len.get(); pr.C = d.C; pr.d_rowptr = d.rowptr.get(); pr.d_ids = d.ids.get(); pr.d_counts = d.counts.get();
+        pr.num_mapped = reads.size();
+        sfgpu_em* em = nullptr; check(sfgpu_em_create(&em, &pr, nullptr), "em_create");
+        DeviceBuf<double> a(M), ms(M);
+        check(sfgpu_em_optimize(em, &opts, a.get(), ms.get(), &want_st), "optimize");
+        want_alpha = a.download();
+        sfgpu_em_destroy(em); sfgpu_eq_destroy(eq);
+    }
+    Shared sh;
+    auto rank_main = [&](int me) {
+        try {
+            sfgpu_eq *local = nullptr, *part = nullptr;
+            check(sfgpu_eq_create(&local, 0, nullptr), "create"); check(sfgpu_eq_create(&part, 0, nullptr), "create");
+            std::vector<uint32_t> ids, off; pack(me ? reads.size() / 2 : 0, me ? reads.size() : reads.size() / 2, ids, off); build(local, ids, off);
+            Dev d; finish_export(local, d);
+            // 1. my classes by owner
+            uint64_t hc[2], hi[2], boff[3];
+            check(sfgpu_eqvec_owner_sizes(d.rowptr.get(), d.hashes.get(), d.C, 2, hc, hi, nullptr), "owner_sizes");
+            DeviceBuf<unsigned char> blocks(SFGPU_BLOCK_BYTES(hc[0], hi[0]) + SFGPU_BLOCK_BYTES(hc[1], hi[1]) + 8);
+            check(sfgpu_eqvec_pack_by_owner(d.rowptr.get(), d.ids.get(), d.counts.get(), d.hashes.get(), d.C, 2, hc, hi, blocks.get(), boff, nullptr), "pack");
+            for (int dst = 0; dst < 2; ++dst) { sh.blk[me][dst] = blocks.get() + boff[dst]; sh.sz[me][dst][0] = hc[dst]; sh.sz[me][dst][1] = hi[dst]; }
+            sh.bar.wait();                                                  // "all-to-all": block [src][me] is mine
+            // 2. the owner adds up the copies
+            check(sfgpu_eq_start(part), "start");
+            for (int src = 0; src < 2; ++src) check(sfgpu_eq_add_block_device(part, sh.blk[src][me], sh.sz[src][me][0], sh.sz[src][me][1], nullptr), "add_block");
+            Dev p; finish_export(part, p);
+            // 3. my partition of the merged table as one block
+            DeviceBuf<unsigned char> pblock(SFGPU_GATHER_BYTES(p.C, p.L) + 8);
+            check(sfgpu_eqvec_export_block(p.rowptr.get(), p.ids.get(), p.counts.get(), p.hashes.get(), p.C, p.L, pblock.get(), nullptr), "export_block");
+            check_hip(hipDeviceSynchronize(), "sync");
+            sh.part[me] = pblock.get(); sh.part_c[me] = p.C; sh.part_l[me] = p.L;
+            sh.bar.wait();                                                  // "all-gather"
+            // 4. the union, canonical order
+            const uint64_t n = sh.part_c[0] + sh.part_c[1], l = sh.part_l[0] + sh.part_l[1];
+            Dev m; m.C = n; m.L = l; m.rowptr.resize(n + 1); m.ids.resize(l); m.counts.resize(n); m.hashes.resize(n);
+            int tie = -1;
+            check(sfgpu_eqvec_merge_disjoint(sh.part, sh.part_c, sh.part_l, 2, m.rowptr.get(), m.ids.get(), m.counts.get(), m.hashes.get(), &tie, nullptr), "merge");
+            if (tie != 0) throw std::runtime_error("unexpected key tie");
+            sh.merged[me].rowptr = m.rowptr.download(); sh.merged[me].ids = m.ids.download(); sh.merged[me].counts = m.counts.download(); sh.merged[me].hashes = m.hashes.download();
+            sh.bar.wait();                                                  // nobody frees a block another rank still reads
+            // 5. sharded EM: my half of the classes (cut at half the nonzeros)
+            const std::vector<uint32_t>& rp = sh.merged[me].rowptr;
+            uint64_t cut = 0; while (cut < n && rp[cut] < l / 2) ++cut;
+            const uint64_t c0 = me ? cut : 0, c1 = me ? n : cut;
+            std::vector<uint32_t> rp_loc(c1 - c0 + 1); for (uint64_t c = c0; c <= c1; ++c) rp_loc[c - c0] = rp[c] - rp[c0];
+            DeviceBuf<uint32_t> d_rp(rp_loc);
+            sfgpu_problem pr{}; pr.M = M; pr.d_len = d_len.get(); pr.C = c1 - c0; pr.d_rowptr = d_rp.get(); pr.d_ids = m.ids.get() + rp[c0]; pr.d_counts = m.counts.get() + c0;
+            pr.num_mapped = reads.size();
+            sfgpu_em* em = nullptr; check(sfgpu_em_create(&em, &pr, nullptr), "em_create");
+            DeviceBuf<double> a(M), ms(M);
+            ReduceCtx ctx{&sh, me};
+            check(sfgpu_em_optimize_sharded(em, &opts, allreduce_two_threads, &ctx, 8, a.get(), ms.get(), &sh.st[me]), "optimize_sharded");
+            sh.alpha[me] = a.download();
+            sfgpu_em_destroy(em); sfgpu_eq_destroy(local); sfgpu_eq_destroy(part);
+        } catch (const std::exception& e) { std::fprintf(stderr, "rank %d: %s\n", me, e.what()); ++failures; }
+    };
+    std::thread t0(rank_main, 0), t1(rank_main, 1);
+    t0.join(); t1.join();
+    if (failures == before) {
+        for (int r = 0; r < 2; ++r) {
+            EXPECT(sh.merged[r].rowptr == want.rowptr && sh.merged[r].ids == want.ids && sh.merged[r].counts == want.counts && sh.merged[r].hashes == want.hashes);
+            EXPECT(sh.st[r].iters == want_st.iters && sh.st[r].converged == want_st.converged);
+            bool ok = sh.alpha[r].size() == M;
+            for (uint32_t t = 0; ok && t < M; ++t) ok = (want_alpha[t] > 0) == (sh.alpha[r][t] > 0) && close_to(sh.alpha[r][t], want_alpha[t], 1e-9);
+            EXPECT(ok);
+        }
+        EXPECT(sh.alpha[0] == sh.alpha[1]);                                 // the all-reduce leaves both ranks with the same bits
+        std::printf("two ranks through the ABI: %zu classes merged, sharded EM stopped at iteration %u (single GPU: %u)\n",
+                    want.counts.size(), sh.st[0].iters, want_st.iters);
+    }
+    return failures - before;
 }
 
 int main() {
@@ -161,6 +311,7 @@ int main() {
         CollapsedEMOptimizer opt;
         EXPECT(!opt.optimize(exp, quiet, 0.01, 10000));
     }
+    failures += two_ranks_on_one_gpu();
     std::printf(failures ? "cpp host FAILED (%d)\n" : "cpp host ok\n", failures);
     return failures ? 1 : 0;
 }

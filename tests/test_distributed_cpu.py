@@ -206,6 +206,56 @@ class CheckerEngine:
     def new_builder(self, expected=0):
         return _Builder()
 
+    # ---- the exchange primitives (csrc/merge.hip in the product), restated with numpy for the control-flow tests
+    @staticmethod
+    def _csr(vec):
+        return (vec.rowptr.numpy().view(np.uint32).astype(np.int64), vec.ids.numpy().view(np.uint32), vec.counts.numpy().astype(np.uint64),
+                vec.hashes.numpy().view(np.uint64))
+
+    def pack_by_owner(self, vec, n):
+        from sailfish_amd.distributed import block_bytes
+        rp, ids, cnt, hs = self._csr(vec)
+        owner = ((hs >> np.uint64(33)) & np.uint64(0x3FFFFFFF)) % np.uint64(n)
+        parts, sizes = [], []
+        for d in range(n):
+            sel = np.flatnonzero(owner == d)
+            lens = (rp[sel + 1] - rp[sel]).astype("<u4")
+            idl = np.concatenate([ids[rp[c]:rp[c + 1]] for c in sel]).astype("<u4") if len(sel) else np.zeros(0, "<u4")
+            blk = cnt[sel].astype("<u8").tobytes() + lens.tobytes() + idl.tobytes()
+            parts.append(blk + b"\0" * (block_bytes(len(sel), len(idl)) - len(blk)))
+            sizes.append((len(sel), len(idl)))
+        raw = b"".join(parts)
+        return torch.frombuffer(bytearray(raw + b"\0" * 8), dtype=torch.uint8)[:len(raw)], sizes
+
+    def fold_block(self, builder, block, c, l):
+        if c == 0:
+            return
+        b = block.numpy().tobytes()
+        cnt = np.frombuffer(b[:8 * c], "<u8"); lens = np.frombuffer(b[8 * c:12 * c], "<u4"); ids = np.frombuffer(b[12 * c:12 * c + 4 * l], "<u4")
+        off = np.zeros(c + 1, np.int64); off[1:] = np.cumsum(lens)
+        builder._add(torch.from_numpy(ids.view(np.int32).copy()), torch.from_numpy(off.astype(np.uint32).view(np.int32).copy()), cnt.astype(np.int64))
+
+    def export_block(self, vec):
+        rp, ids, cnt, hs = self._csr(vec)
+        raw = cnt.astype("<u8").tobytes() + hs.astype("<u8").tobytes() + np.diff(rp).astype("<u4").tobytes() + ids.astype("<u4").tobytes()
+        return torch.frombuffer(bytearray(raw + b"\0" * 8), dtype=torch.uint8)[:len(raw)]
+
+    def merge_disjoint(self, blocks, sizes):
+        rows = []
+        for blk, (c, l) in zip(blocks, sizes):
+            b = blk.numpy().tobytes()
+            cnt = np.frombuffer(b[:8 * c], "<u8"); hs = np.frombuffer(b[8 * c:16 * c], "<u8"); lens = np.frombuffer(b[16 * c:20 * c], "<u4")
+            ids = np.frombuffer(b[20 * c:20 * c + 4 * l], "<u4")
+            o = np.zeros(c + 1, np.int64); o[1:] = np.cumsum(lens)
+            rows += [(int(ids[o[k]]), int(hs[k]), tuple(ids[o[k]:o[k + 1]].tolist()), int(cnt[k])) for k in range(c)]
+        rows.sort(key=lambda r: (r[0], r[1], len(r[2]), r[2]))
+        if any(a[0] == b[0] and a[1] == b[1] for a, b in zip(rows, rows[1:])):
+            return None
+        rowptr = np.zeros(len(rows) + 1, np.int64); rowptr[1:] = np.cumsum([len(r[2]) for r in rows])
+        v = _Vec(rowptr, np.array([t for r in rows for t in r[2]], np.uint32), np.array([r[3] for r in rows], np.int64), sum(r[3] for r in rows))
+        v.hashes = torch.from_numpy(np.array([r[1] for r in rows], np.uint64).view(np.int64).copy())
+        return v
+
     def gibbs_sample(self, length, mass, rowptr, ids, counts, num_mapped, n, n_chains=0, seed=1):
         rc, out = O.gibbs(length.numpy(), mass.numpy(), rowptr.numpy().view(np.uint32).astype(np.uint64), ids.numpy().view(np.uint32),
                           counts.numpy().astype(np.uint64), int(num_mapped), int(n), seed=seed & 0x7FFFFFFF)

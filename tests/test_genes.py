@@ -22,3 +22,29 @@ def test_gene_level_aggregation(tmp_path):
     assert lines[3] == "g2\t500\t300\t0\t0"
     # tZ is its own gene: totalTPM = 5, weights 1
     assert lines[4] == "tZ\t700\t500\t5\t7" and lines[5] == ""
+
+
+def test_gene_map_from_gtf(tmp_path):
+    """--geneMap x.gtf (transcriptGeneMapFromGTF, src/SailfishUtils.cpp:322-436): transcripts are the distinct
+    transcript_id values (transcript, exon and CDS records alike), ordered by name; the key is gene_id, gene_name or a
+    caller-named attribute"""
+    from sailfish_amd import genes
+    gtf = "\n".join([
+        "##description: toy",
+        'chr1\tsrc\tgene\t1\t900\t.\t+\t.\tgene_id "G1"; gene_name "alpha";',
+        'chr1\tsrc\ttranscript\t1\t900\t.\t+\t.\tgene_id "G1"; transcript_id "tB"; gene_name "alpha"; tag "x";',
+        'chr1\tsrc\texon\t1\t300\t.\t+\t.\tgene_id "G1"; transcript_id "tB"; gene_name "alpha";',
+        'chr1\tsrc\texon\t1\t200\t.\t+\t.\tgene_id "G1"; transcript_id "tA"; gene_name "alpha"; tag "y";',      # no transcript record: made from its exon
+        'chr2\tsrc\ttranscript\t5\t700\t.\t-\t.\tgene_id "G2"; transcript_id "tC"; gene_name "beta"; tag "x";',
+        'chr2\tsrc\tCDS\t5\t100\t.\t-\t0\tgene_id "G2"; transcript_id "tC"; gene_name "beta";',
+        ""])
+    (tmp_path / "map.gtf").write_text(gtf)
+    tgm = genes.TranscriptGeneMap.from_gtf(str(tmp_path / "map.gtf"))
+    assert tgm.transcript_names == ["tA", "tB", "tC"] and tgm.gene_names == ["G1", "G2"] and tgm.t2g == [0, 0, 1]
+    assert genes.TranscriptGeneMap.from_gtf(str(tmp_path / "map.gtf"), "gene_name").gene_names == ["alpha", "beta"]
+    by_tag = genes.TranscriptGeneMap.from_gtf(str(tmp_path / "map.gtf"), "tag")
+    assert by_tag.gene_names == ["y", "x"] and by_tag.t2g == [0, 1, 1]           # genes numbered by first appearance in transcript order
+    (tmp_path / "quant.sf").write_text("Name\tLength\tEffectiveLength\tTPM\tNumReads\ntA\t1000\t800\t30\t60\ntB\t2000\t1800\t10\t40\ntC\t500\t300\t2\t3\n")
+    out = genes.generate_gene_level_estimates(str(tmp_path / "map.gtf"), str(tmp_path))      # the .gtf extension selects the reader (:1050-1053)
+    lines = open(out).read().split("\n")
+    assert lines[1] == "G1\t714.286\t600\t40\t100" and lines[2] == "G2\t500\t300\t2\t3"
