@@ -293,6 +293,31 @@ SFGPU_API int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass
                        uint64_t seed, int32_t* d_out, sfgpu_gibbs_cb cb, void* user, sfgpu_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (next) A quasi-mapping front end: reads in, sfgpu_hit records out -- what the reference gets from RapMap's
+ * SACollector inside processReadsQuasi (src/SailfishQuantify.cpp:141-142, 192-213 paired end, :487-488, 526-528 single
+ * end), so that the hit lists the path consumes have a producer on the device.  RapMap (COMBINE-lab/RapMap @ sf-v0.10.1,
+ * scripts/fetchRapMap.sh:20) is not in the reference tree; this is NOT its algorithm and parity with it is unpinned.
+ * The contract (csrc/mapper.hip; oracle/mapper_oracle.py restates it): exact k-mer seeds at read offsets 0 and len - k,
+ * forward strand then reverse complement; the first occurrence seen for a (transcript, strand) fixes the position;
+ * hits sorted by (transcript, strand); mates on one transcript with opposite strands pair up (PAIRED_END_PAIRED,
+ * fragment length = max end - min start), otherwise both mates' hits are kept as orphans (left run, right run).
+ *   sfgpu_index_build : d_seq / d_seq_off / d_ref_len as for sfgpu_bias_create (transcript t = d_seq[d_seq_off[t] ..
+ *                       + d_ref_len[t])); 8 <= k <= 31; max_occ = occurrences kept per lookup (0: 1000).
+ *   sfgpu_map_reads   : reads of one batch, read r = d_seq1[d_off1[r] .. d_off1[r + 1]) (bytes; any case; other letters
+ *                       than ACGT never match); d_seq2 / d_off2 = the mates or NULL.  Writes d_hit_offsets[n_reads + 1]
+ *                       and, if they fit hit_capacity, the records (else SFGPU_ERR_RANGE with *n_hits set: size and
+ *                       call again).  The output feeds sfgpu_filter_hits directly.  Synchronous. */
+typedef struct sfgpu_index sfgpu_index;
+struct sfgpu_hit;
+SFGPU_API int sfgpu_index_build(sfgpu_index** out, const char* d_seq, const uint64_t* d_seq_off, const uint32_t* d_ref_len, uint64_t M,
+                                uint32_t k, uint32_t max_occ, sfgpu_stream stream);
+SFGPU_API int sfgpu_index_destroy(sfgpu_index* idx);
+SFGPU_API int sfgpu_index_info(const sfgpu_index* idx, uint32_t* k, uint64_t* n_positions, uint64_t* n_kmers);
+SFGPU_API int sfgpu_map_reads(const sfgpu_index* idx, const char* d_seq1, const uint64_t* d_off1, const char* d_seq2, const uint64_t* d_off2,
+                              uint32_t n_reads, struct sfgpu_hit* d_hits, uint64_t hit_capacity, uint32_t* d_hit_offsets, uint64_t* n_hits,
+                              sfgpu_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (next) Per-read hit filtering: the loop bodies of processReadsQuasi
  * (src/SailfishQuantify.cpp:215-417 paired end, :530-626 single end) between "the mapper returned
  * jointHits for a read" and eqBuilder.addGroup -- maxReadOccs cut (:217, :532), orphan policy (:226),

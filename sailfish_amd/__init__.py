@@ -6,4 +6,4 @@ from .experiment import ReadExperiment, SailfishOpts, Transcripts  # noqa: F401
 from .eqclass import EquivalenceClassBuilder, EqVec, xxh64_labels  # noqa: F401
 from .optimizer import CollapsedEMOptimizer, EMProblem  # noqa: F401
 from .gibbs import CollapsedGibbsSampler, gibbs_sample  # noqa: F401
-from . import bias, efflen, genes, hits, quant, writer  # noqa: F401
+from . import bias, efflen, genes, hits, mapper, quant, writer  # noqa: F401

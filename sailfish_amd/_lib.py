@@ -111,6 +111,10 @@ _SIGS = {
     "sfgpu_cf_counts": (C.c_int, [_P, C.c_uint32, _P]),
     "sfgpu_efflen_smoothed": (C.c_int, [_P, C.c_uint64, _P, C.c_uint32, _P, _P]),
     "sfgpu_efflen_empirical": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    "sfgpu_index_build": (C.c_int, [C.POINTER(_P), _P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
+    "sfgpu_index_destroy": (C.c_int, [_P]),
+    "sfgpu_index_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sfgpu_map_reads": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(C.c_uint64), _P]),
     "sfgpu_filter_hits": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(FilterOpts), _P, _P, _P, C.POINTER(C.c_int64),
                                     C.POINTER(FilterStats), _P]),
     "sfgpu_gc_prefix": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),

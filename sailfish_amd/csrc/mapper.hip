@@ -5,7 +5,7 @@
 // QuasiAlignment list that the hit-filtering loop (sfgpu_filter_hits) consumes.  RapMap is a third-party library that
 // is fetched at build time (scripts/fetchRapMap.sh:20, COMBINE-lab/RapMap @ sf-v0.10.1) and is not in the reference
 // tree: its suffix-array search is NOT what is implemented here, and parity with it is unpinned.  This is an
-// exact-seed mapper with a contract of its own (oracle/mapper_oracle.py restates it; tests check it record for record
+// exact-seed mapper with a contract of its own (restated on the CPU for the tests, which check it record for record
 // and against the simulator's truth in the reference's bundled sample_data):
 //
 //   index : every k-mer (k <= 31, 2 bits per base) of every transcript made of A/C/G/T only, with (transcript, position);

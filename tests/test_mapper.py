@@ -1,0 +1,111 @@
+"""The quasi-mapping front end (sailfish_amd/mapper.py, csrc/mapper.hip): record-for-record against the CPU
+restatement of its contract (oracle/mapper_oracle.py), against the committed hit records of the reference's bundled
+sample_data (tests/golden/sample_data_hits.npz), and -- the only ground truth there is for a mapper here, RapMap being
+unavailable -- against the transcript each simulated read names in its header."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mapper_oracle as MO
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sample_reads():
+    d = np.load(os.path.join(GOLD, "sample_data_reads.npz"))
+    n, L = len(d["truth"]), int(d["read_len"])
+
+    def unpack(p):
+        b = np.unpackbits(p).reshape(-1, 2)
+        return np.frombuffer(b"ACGT", np.uint8)[(b[:, 0] * 2 + b[:, 1])[: n * L]].reshape(n, L)
+    seqs = [bytes(d["seq"][d["seq_off"][t]:d["seq_off"][t + 1]]) for t in range(len(d["names"]))]
+    m1, m2 = unpack(d["mate1_2bit"]), unpack(d["mate2_2bit"])
+    return [str(x) for x in d["names"]], seqs, [bytes(r) for r in m1], [bytes(r) for r in m2], d["truth"]
+
+
+def test_contract_restatement_reproduces_the_committed_hit_records(built):
+    """the CPU restatement of the mapper's contract, run on the bundled reads, gives the committed fixture (first 1500 pairs)"""
+    names, seqs, r1, r2, truth = _sample_reads()
+    gold = np.load(os.path.join(GOLD, "sample_data_hits.npz"))
+    gh = gold["hits"].view(O.HIT_DTYPE); go = gold["offsets"]
+    n = 1500
+    hits, off = MO.map_reads(MO.build_index(seqs), r1[:n], r2[:n])
+    assert np.array_equal(off, go[: n + 1]) and np.array_equal(hits, gh[: go[n]])
+    assert [str(x) for x in gold["names"]] == names and np.array_equal(gold["ref_len"], [len(s) for s in seqs])
+
+
+def _random_case(rng, M=40, n_reads=3000, read_len=60, k=31):
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), 4000)
+    seqs = []
+    for t in range(M):                                  # isoform-like: shared segments, so k-mers occur in several transcripts
+        a = rng.integers(0, 3000); ln = rng.integers(k - 5, 900)          # a few transcripts shorter than k
+        s = base[a:a + ln].copy()
+        if t % 7 == 0 and ln > 100:
+            s[rng.integers(0, ln, 3)] = ord("N")       # bases that never match
+        if t % 5 == 0:
+            s = np.frombuffer(s.tobytes().lower(), np.uint8)                                     # case is folded
+        seqs.append(bytes(s))
+    comp = bytes.maketrans(b"ACGTacgtN", b"TGCAtgcaN")
+    r1, r2 = [], []
+    for _ in range(n_reads):
+        t = rng.integers(0, M); s = seqs[t]
+        if len(s) < read_len + 20 or rng.random() < 0.05:
+            r1.append(bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), rng.integers(10, read_len + 1)))); r2.append(r1[-1][::-1])      # noise / short reads
+            continue
+        frag = rng.integers(read_len, min(len(s), 300) + 1); p = rng.integers(0, len(s) - frag + 1)
+        left = s[p:p + read_len]; right = s[p + frag - read_len:p + frag].translate(comp)[::-1]
+        if rng.random() < 0.5:
+            left, right = right, left                   # the fragment came from the other strand
+        if rng.random() < 0.1:
+            left = left[:rng.integers(k, read_len)]      # ragged lengths
+        if rng.random() < 0.05:
+            b = bytearray(right); b[rng.integers(0, len(b))] = ord("N"); right = bytes(b)
+        r1.append(bytes(left)); r2.append(bytes(right))
+    return seqs, r1, r2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [True, False])
+def test_device_mapper_matches_its_contract(gpu, paired):
+    import sailfish_amd as sf
+    rng = np.random.default_rng(17 + paired)
+    seqs, r1, r2 = _random_case(rng)
+    idx = sf.mapper.QuasiIndex(seqs, k=31, max_occ=1000, device=gpu)
+    assert idx.n_positions == sum(max(len(s) - 30, 0) for s in seqs)
+    hits, off = idx.map_reads(r1, r2 if paired else None)
+    gh, go = sf.mapper.hits_to_numpy(hits, off)
+    oh, oo = MO.map_reads(MO.build_index(seqs, 31, 1000), r1, r2 if paired else None)
+    assert np.array_equal(go, oo)
+    assert np.array_equal(gh, oh)
+    assert len(oh) > len(r1) // 2 and (not paired or int((oh["mate_status"] == 3).sum()) > len(r1) // 4)
+    # a repeat that exceeds max_occ: the same cut on both sides
+    rep = [b"ACGT" * 40] * 6 + seqs[:5]
+    idx2 = sf.mapper.QuasiIndex(rep, k=31, max_occ=3, device=gpu)
+    h2, o2 = sf.mapper.hits_to_numpy(*idx2.map_reads([b"ACGT" * 15, b"TTTT" * 15, b"AC"]))
+    eh, eo = MO.map_reads(MO.build_index(rep, 31, 3), [b"ACGT" * 15, b"TTTT" * 15, b"AC"])
+    assert np.array_equal(o2, eo) and np.array_equal(h2, eh)
+
+
+@pytest.mark.gpu
+def test_bundled_sample_data_from_the_reads(gpu, tmp_path):
+    """BASELINE config 1 from the READS on: index the 15 transcripts, map the 10 000 pairs on the device -- the records are
+    the committed fixture's, byte for byte -- and quantify; every read's simulated transcript is among its hits and the EM
+    recovers the simulated abundances"""
+    import sailfish_amd as sf
+    names, seqs, r1, r2, truth = _sample_reads()
+    gold = np.load(os.path.join(GOLD, "sample_data_hits.npz"))
+    idx = sf.mapper.QuasiIndex(seqs, device=gpu)
+    hits, off = sf.mapper.hits_to_numpy(*idx.map_reads(r1, r2))
+    assert np.array_equal(off, gold["offsets"]) and np.array_equal(hits, gold["hits"].view(O.HIT_DTYPE))
+    assert all(truth[r] in hits["tid"][off[r]:off[r + 1]] for r in range(len(truth)))
+    out = str(tmp_path / "out")
+    rc, exp = sf.mapper.quantify_reads(names, seqs, r1, r2, "IU", out, sf.SailfishOpts(numFragSamples=5000), batch_reads=3000,
+                                       cmd_options={"libType": "IU"}, device=gpu)
+    assert rc == 0 and exp.numMappedFragments() == 10000
+    rows = [l.split("\t") for l in open(os.path.join(out, "quant.sf")).read().strip().split("\n")[1:]]
+    assert [r[0] for r in rows] == names
+    num_reads = np.array([float(r[4]) for r in rows])
+    want = np.bincount(truth, minlength=15).astype(np.float64)
+    assert abs(num_reads.sum() - 10000) < 1e-2 and np.abs(num_reads - want).sum() / 10000 < 0.1
