@@ -233,6 +233,10 @@ constexpr int kSweepBlock = SFGPU_SWEEP_BLOCK;
 #define SFGPU_PER_LANE 8
 #endif
 constexpr int kPerLane = SFGPU_PER_LANE;     // consecutive stream words per lane (8: two 16-byte loads)
+#ifndef SFGPU_SWEEP_REGCHUNKS
+#define SFGPU_SWEEP_REGCHUNKS 1
+#endif
+constexpr int kRegChunks = SFGPU_SWEEP_REGCHUNKS;
 constexpr uint32_t kNull = 0x80000000u, kSingle = 0x20000000u;
 static_assert(kTileNnz <= 8191, "class index field is 13 bits");
 
@@ -404,12 +408,17 @@ k_sweep_lds(SweepArgs a) {
     // Everything the block needs from HBM is requested up front, before the first barrier: the
     // lane's first 8 stream words (kept in registers through phases A..C), the x window and the
     // class counts of phase B.  A typical tile (<= 8192 nonzeros) needs nothing else.
+    // kRegChunks x 8 stream words per lane stay in registers through phases A..C.  (Measured in round 2 on cfg3, whose
+    // one-round tiles hold ~18 000 nonzeros = 2.2 chunks of 8192: 1 chunk in registers 21.9 us per sweep, 2 chunks 23.8,
+    // 3 chunks 25.1 -- the re-fetch of the other chunks hits the L2 and costs less than the registers do.)
     const uint32_t g0 = threadIdx.x * kPerLane;
-    uint32_t w[kPerLane];
-    {
+    uint32_t w[kRegChunks][kPerLane];
+#pragma unroll
+    for (int c = 0; c < kRegChunks; ++c) {
+        const uint32_t g = g0 + (uint32_t)c * kSweepBlock * kPerLane;
         uint4 w0 = make_uint4(kNull, kNull, kNull, kNull), w1 = w0;
-        if (g0 < n8) { w0 = words[g0 / 4]; w1 = words[g0 / 4 + 1]; }
-        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+        if (g < n8) { w0 = words[g / 4]; w1 = words[g / 4 + 1]; }
+        w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
     }
     uint32_t cnt0 = (threadIdx.x < nc) ? a.counts[c0 + threadIdx.x] : 0u;          // bit 31: singleton class
     uint32_t cnt1 = (threadIdx.x + kSweepBlock < nc) ? a.counts[c0 + threadIdx.x + kSweepBlock] : 0u;
@@ -419,8 +428,9 @@ k_sweep_lds(SweepArgs a) {
 
     // ---- A: denominators
     {
-        denominators(w);
-        for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
+#pragma unroll
+        for (int c = 0; c < kRegChunks; ++c) denominators(w[c]);
+        for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
             uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
             uint32_t v[kPerLane] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
             denominators(v);
@@ -444,8 +454,9 @@ k_sweep_lds(SweepArgs a) {
     // ---- C: scatter-add into the window
     double esc_sum = 0.0;
     {
-        scatter(w);
-        for (uint32_t g = g0 + kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
+#pragma unroll
+        for (int c = 0; c < kRegChunks; ++c) scatter(w[c]);
+        for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
             uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
             uint32_t v[kPerLane] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
             scatter(v);
