@@ -214,21 +214,34 @@ struct PartArgs {
 };
 
 // ---- pass 2: one block per region
-// A slot word is tag(32) | rep(32) in the table.  While a launch runs, the slot of a class CREATED by it is
-// provisional: tag(12) << 52 | granule index of its label in the bins (bit 31 clear); it is rewritten with the full tag
-// and the arena entry when the block commits its new classes.  Probing compares the 12 tag bits H carries.
+// A slot word is tag(32) | rep(32) in the table.  In LDS the region is kept COMPACT: `slot32[s]` = tag(12) | length(7) |
+// local class index(13) (or empty), and per local class its label's FIRST GRANULE with the representative's address in
+// place of the length -- `chead[idx]` = (rep, id0, id1, id2) -- plus a count delta.  A label of <= 3 ids (58 % of the reads)
+// is therefore probed, compared and counted without leaving the CU; a longer one fetches only its further granules.  The
+// scattered 16-byte compare loads, not the stream, bounded this pass before (texture addresser ~3.5 cycles per lane and load,
+// profiles/r2_class_build_notes.md); a slot-indexed copy of the heads (64 KB) would not leave room for two blocks per CU,
+// the class-indexed one does: 16 KB slots + 2304 x (16 + 4) B classes + 17 KB wavefront tiles = 79 KB.
+// rep = kArenaBit | arena granule for classes committed before this launch, else the granule index of the label in the bins
+// (a class CREATED by this launch; it is committed -- arena entry, XXH64, full bucket hash, table word -- after the stream).
 // Wavefront w streams the bins w, w + 16, ... of the region, 64 granules at a time: ONE coalesced 16-byte load per lane;
 // a lane whose granule starts a label handles that label (ids 0..2 are in its registers, ids 3..6 in its neighbour's
 // granule, read back from the wavefront's LDS copy of the step).  The only block-wide synchronisation is before and
 // after the streaming loop.
+constexpr uint32_t kMaxRegionClasses = 2400;             // local classes per region (mean <= 2048 at the table load limit of 1/2: + 7.8 sigma); what 80 KB leave
+constexpr uint32_t kSlotEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kSlotKeyMask = 0xFFFFE000u;            // tag(12) << 20 | length(7) << 13
+constexpr uint32_t kSlotIdxMask = 0x1FFFu;
+constexpr uint32_t kDeadRep = 0xFFFFFFFFu;                // a class index that lost the race for its slot
+
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_part_insert(PartArgs a) {
-    __shared__ unsigned long long lw[kRegionSlots];     // slot words
-    __shared__ unsigned int lc[kRegionSlots];           // count deltas of this launch
+    __shared__ unsigned int slot32[kRegionSlots];
+    __shared__ __attribute__((aligned(16))) uint4 chead[kMaxRegionClasses];
+    __shared__ unsigned int ccnt[kMaxRegionClasses];
     __shared__ __attribute__((aligned(16))) uint4 wtile[kPartWaves][64 + 2];
-    __shared__ uint32_t new_info[kRegionLimit];         // classes created by this block: slot | len << 16
-    __shared__ unsigned int s_occ, s_nnew, s_newwords, s_cid0;
+    __shared__ unsigned int s_occ, s_ncls, s_nold, s_nnew, s_newwords, s_cid0;
     __shared__ unsigned long long s_arena0;
+    static_assert(kRegionBits == 12, "slot32 packs a 12-bit tag, a 7-bit length and a 13-bit class index");
     const uint32_t region = blockIdx.x;
     const uint64_t rb = (uint64_t)region * kRegionSlots;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -236,15 +249,30 @@ k_part_insert(PartArgs a) {
     const uint32_t my_bin = wave + kPartWaves * lane;
     const uint32_t my_fill = (my_bin < a.n_blocks) ? a.fill[region * a.n_blocks + my_bin] : 0u;
 
-    unsigned int occ_local = 0;
+    if (threadIdx.x == 0) { s_occ = 0; s_ncls = 0; s_nnew = 0; s_newwords = 0; }
+    for (uint32_t c = threadIdx.x; c < kMaxRegionClasses; c += kPartBlock) ccnt[c] = 0;
+    __syncthreads();
+    // ---- the region's committed classes: slot -> local class, label head from the arena (one scattered 16-byte load per
+    //      CLASS and launch instead of one per READ)
+    bool overfull = false;
     for (uint32_t s = threadIdx.x; s < kRegionSlots; s += kPartBlock) {
-        unsigned long long w = a.table[2 * (rb + s)];
-        lw[s] = w; lc[s] = 0; occ_local += (w != kEmpty);
+        const unsigned long long w = a.table[2 * (rb + s)];
+        uint32_t e = kSlotEmpty;
+        if (w != kEmpty) {
+            const uint32_t idx = atomicAdd(&s_ncls, 1u);
+            if (idx < kMaxRegionClasses) {
+                const uint32_t rep = (uint32_t)w;
+                const uint4 h = reinterpret_cast<const uint4*>(a.arena)[rep & ~kArenaBit];       // [n, id0, id1, id2]
+                chead[idx] = make_uint4(rep, h.y, h.z, h.w);
+                e = ((uint32_t)(w >> 52) << 20) | ((h.x & 0x7Fu) << 13) | idx;
+            } else overfull = true;                          // (a table loaded beyond 1/2 by the generic kernel: see below)
+        }
+        slot32[s] = e;
     }
-    if (threadIdx.x == 0) { s_occ = 0; s_nnew = 0; s_newwords = 0; }
     __syncthreads();
-    if (occ_local) atomicAdd(&s_occ, occ_local);
-    __syncthreads();
+    if (threadIdx.x == 0) { s_nold = s_ncls < kMaxRegionClasses ? s_ncls : kMaxRegionClasses; s_occ = s_ncls; }
+    const bool region_overfull = __syncthreads_or(overfull);
+    const uint32_t n_old = s_nold;
 
     uint4* tile = wtile[wave];
     const unsigned long long have = __ballot(my_fill != 0u);
@@ -285,68 +313,81 @@ k_part_insert(PartArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (is_head && lane < adv) {
-            const uint4 g1 = tile[lane + 1];                 // ids 3..6 (whatever follows for shorter labels: masked below)
-            const uint32_t w0 = g.x & ~kHeadBit, w1 = g.z, w2 = g.w;
-            const uint32_t w3 = len > 3u ? g1.x : 0u, w4 = len > 4u ? g1.y : 0u, w5 = len > 5u ? g1.z : 0u, w6 = len > 6u ? g1.w : 0u;
-            const uint32_t tagq = (H >> kRegionBits) & ((1u << kTagBits) - 1u);
-            uint32_t s = H & (kRegionSlots - 1);
-            const uint32_t here = base + pos + lane;         // where this label sits in the bins (granule index)
-            // Probe in two stages so that a wavefront pays the global round trip of the label compare ONCE:
-            // (1) walk the LDS slots until an empty slot or a tag match (LDS only), (2) claim or compare.
-            uint32_t probes = 0;
-            for (;;) {
-                unsigned long long w = lw[s];
-                while (w != kEmpty && (uint32_t)(w >> (64 - kTagBits)) != tagq && probes < kRegionSlots) {
-                    s = (s + 1) & (kRegionSlots - 1); ++probes; w = lw[s];
+        // ---- phase 1 (head lanes): probe the LDS slots, compare the first granule in LDS.  A label of <= 3 ids is finished
+        //      here; a longer one leaves phase 1 with a CANDIDATE class (tag, length and ids 0..2 agree)
+        const uint32_t w0 = g.x & ~kHeadBit, w1 = g.z, w2 = g.w;
+        const uint32_t key = (((H >> kRegionBits) & 0xFFFu) << 20) | (len << 13);
+        const uint32_t here = base + pos + lane;             // where this lane's granule sits in the bins (granule index)
+        uint32_t s = H & (kRegionSlots - 1), probes = 0, c_idx = 0, c_rep = 0;
+        auto defer = [&]() { const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull); a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len; };
+        // -> true if the label is left with a candidate to verify (only when !serial: the serial form compares the further
+        //    granules itself, one dependent load after the other -- the rare path after a failed verification)
+        auto probe = [&](const bool serial) -> bool {
+            while (probes <= kRegionSlots) {
+                uint32_t e = slot32[s];
+                while (e != kSlotEmpty && (e & kSlotKeyMask) != key && probes < kRegionSlots) {
+                    s = (s + 1) & (kRegionSlots - 1); ++probes; e = slot32[s];
                 }
-                if (probes >= kRegionSlots) {                                             // cannot place: defer
-                    const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull);
-                    a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len;
-                    break;
-                }
-                if (w == kEmpty) {
-                    if (atomicAdd(&s_occ, 1u) >= kRegionLimit) {                              // region full: defer
-                        atomicSub(&s_occ, 1u);
-                        const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull);
-                        a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len;
-                        break;
+                if (probes >= kRegionSlots) { defer(); return false; }                  // cannot place
+                if (e == kSlotEmpty) {
+                    // claim: the class's head is written BEFORE the slot names it, so a prober that sees the slot reads a whole head
+                    const uint32_t idx = atomicAdd(&s_ncls, 1u);
+                    if (idx >= kMaxRegionClasses || atomicAdd(&s_occ, 1u) >= kRegionLimit) {      // region full: defer
+                        if (idx < kMaxRegionClasses) { atomicSub(&s_occ, 1u); chead[idx].x = kDeadRep; }
+                        defer(); return false;
                     }
-                    const unsigned long long me = ((unsigned long long)tagq << (64 - kTagBits)) | (unsigned long long)here;
-                    const unsigned long long old = atomicCAS(&lw[s], (unsigned long long)kEmpty, me);
-                    if (old == kEmpty) { new_info[atomicAdd(&s_nnew, 1u)] = s | (len << 16); atomicAdd(&lc[s], 1u); break; }
+                    chead[idx] = make_uint4(here, w0, w1, w2);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    const uint32_t old = atomicCAS(&slot32[s], kSlotEmpty, key | idx);
+                    if (old == kSlotEmpty) { atomicAdd(&ccnt[idx], 1u); atomicAdd(&s_nnew, 1u); return false; }
+                    chead[idx].x = kDeadRep;                 // lost the race: this index stays unused
                     atomicSub(&s_occ, 1u);
-                    w = old;
-                    if ((uint32_t)(w >> (64 - kTagBits)) != tagq) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
+                    e = old;
+                    if ((e & kSlotKeyMask) != key) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
                 }
-                // tag match: full label compare, 16 bytes at a time
-                const uint32_t rep = (uint32_t)w;
-                // The representative label lies in 16-byte granules either way, and from the second granule on (ids 3..6,
-                // 7..10, ...) an arena entry [n, id0, id1, id2][id3 ..] and a stream label [id0|head, H, id1, id2][id3 ..]
-                // are word for word the same: whole-granule compares, the first three requested together.
-                // The representative label lies in 16-byte granules either way, and from the second granule on (ids 3..6,
-                // 7..10, ...) an arena entry [n, id0, id1, id2][id3 ..] and a stream label [id0|head, H, id1, id2][id3 ..]
-                // are word for word the same: whole-granule compares, the first three requested together.  (Measured and
-                // dropped: the first granule of every slot's label cached in LDS -- no gain with 2048-slot regions, a loss
-                // with 4096-slot regions at one block per CU.)
-                const bool in_arena = rep & kArenaBit;
-                const uint4* e = in_arena ? reinterpret_cast<const uint4*>(a.arena) + (rep & ~kArenaBit) : a.bins + rep;
-                const uint4 e0 = e[0];
-                uint4 e1 = make_uint4(0u, 0u, 0u, 0u), e2 = e1;
-                if (len > 3u) e1 = e[1];
-                if (len > 7u) e2 = e[2];
-                bool same = in_arena ? (e0.x == len && e0.y == w0) : (e0.x == g.x && (e0.y >> 24) == len);
-                same = same && e0.z == w1 && e0.w == w2 && e1.x == w3 && e1.y == w4 && e1.z == w5 && e1.w == w6;
-                if (len > 7u) {
-                    const uint4 t2 = tile[lane + 2];
-                    same = same && e2.x == t2.x && e2.y == t2.y && e2.z == t2.z && e2.w == t2.w;
-                    for (uint32_t j = 3; same && j < ng; ++j) {
-                        const uint4 ej = e[j], tj = tile[lane + j];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t idx = e & kSlotIdxMask;
+                const uint4 hd = chead[idx];
+                bool same = hd.y == w0 && hd.z == w1 && hd.w == w2;
+                if (same && len > 3u) {
+                    if (!serial) { c_idx = idx; c_rep = hd.x; return true; }
+                    const uint4* r = (hd.x & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (hd.x & ~kArenaBit) : a.bins + hd.x;
+                    for (uint32_t j = 1; same && j < ng; ++j) {
+                        const uint4 ej = r[j], tj = tile[lane + j];
                         same = ej.x == tj.x && ej.y == tj.y && ej.z == tj.z && ej.w == tj.w;
                     }
                 }
-                if (same) { atomicAdd(&lc[s], 1u); break; }
+                if (same) { atomicAdd(&ccnt[idx], 1u); return false; }
                 s = (s + 1) & (kRegionSlots - 1); ++probes;
+            }
+            return false;
+        };
+        bool pending = false;
+        if (is_head && lane < adv) {
+            if (region_overfull) defer();
+            else pending = probe(false);
+        }
+        // ---- phase 2 (the OTHER lanes): from the second granule on (ids 3..6, 7..10, ...) an arena entry and a label in the
+        //      bins are word for word the same, so the lane that holds granule j of a label compares it with granule j of the
+        //      candidate's representative: every further granule of every label of the step in ONE round of loads (a label's
+        //      own lane walking them one after the other cost 2.5 of this pass's 6 ms: some label of every step is long)
+        const unsigned long long heads = __ballot(is_head);
+        if (__ballot(pending)) {
+            const unsigned long long below = heads & (~0ull >> (63u - lane));
+            const int hl = below ? 63 - (int)__builtin_clzll(below) : 0;     // the lane of this granule's head (lane 0 starts a label)
+            const uint32_t rep_h = __shfl(c_rep, hl, kWave);
+            const bool pend_h = __shfl((int)pending, hl, kWave) != 0;
+            bool bad = false;
+            if (pend_h && !is_head && lane < cnt) {
+                const uint4* r = (rep_h & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (rep_h & ~kArenaBit) : a.bins + rep_h;
+                const uint4 ej = r[lane - (uint32_t)hl];
+                bad = ej.x != g.x || ej.y != g.y || ej.z != g.z || ej.w != g.w;
+            }
+            const unsigned long long badm = __ballot(bad);
+            if (pending) {
+                const unsigned long long mine = (badm >> lane) & ((2ull << (ng - 1)) - 2ull);     // bits 1 .. ng - 1: this label's lanes
+                if (!mine) atomicAdd(&ccnt[c_idx], 1u);
+                else { s = (s + 1) & (kRegionSlots - 1); ++probes; probe(true); }        // another label with this tag, length and head
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -355,10 +396,22 @@ k_part_insert(PartArgs a) {
     }
     __syncthreads();
 
-    // ---- commit the classes this block created: ids, arena space, labels, hashes, slot re-pointing
+    // ---- counts of the committed classes, and the classes this block created: ids, arena space, labels, hashes, table words
     const uint32_t n_new = s_nnew;
+    uint32_t* new_slots = reinterpret_cast<uint32_t*>(&wtile[0][0]);            // (the tiles are free now: 4224 words)
+    for (uint32_t s = threadIdx.x; s < kRegionSlots; s += kPartBlock) {
+        const uint32_t e = slot32[s];
+        if (e == kSlotEmpty) continue;
+        const uint32_t idx = e & kSlotIdxMask;
+        if (idx < n_old) { const uint32_t c = ccnt[idx]; if (c) a.table[2 * (rb + s) + 1] += c; }
+        else { new_slots[atomicAdd(&s_newwords, 1u)] = s; }                      // s_newwords doubles as the list cursor here
+    }
+    __syncthreads();
     if (n_new) {
-        for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, entry_words(new_info[i] >> 16));
+        // (n_new == s_newwords: every class that won its slot is in the list once)
+        if (threadIdx.x == 0) s_newwords = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, entry_words((slot32[new_slots[i]] >> 13) & 0x7Fu));
         __syncthreads();
         if (threadIdx.x == 0) {
             s_cid0 = (unsigned int)atomicAdd(&a.ctr[CTR_NEW], (unsigned long long)n_new);
@@ -367,9 +420,10 @@ k_part_insert(PartArgs a) {
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) {
-            const uint32_t s = new_info[i] & 0xFFFFu, len = new_info[i] >> 16;
-            const unsigned long long w = lw[s];
-            const uint32_t rep = (uint32_t)w;
+            const uint32_t s = new_slots[i];
+            const uint32_t e = slot32[s];
+            const uint32_t idx = e & kSlotIdxMask, len = (e >> 13) & 0x7Fu;
+            const uint32_t rep = chead[idx].x;
             const uint64_t cid = a.base_classes + s_cid0 + i;
             const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
             const uint32_t* p = reinterpret_cast<const uint32_t*>(a.bins + rep);
@@ -380,14 +434,9 @@ k_part_insert(PartArgs a) {
             a.cls_off[cid] = dst + 1; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
             uint32_t tmp[kHead];
             const uint64_t h = label_mix64(word, len, tmp);                               // the table keeps the full 32-bit tag
-            lw[s] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)(dst >> 2));
+            a.table[2 * (rb + s)] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)(dst >> 2));
+            a.table[2 * (rb + s) + 1] = ccnt[idx];                                         // (the slot was empty: count 0 before)
         }
-    }
-    __syncthreads();
-    // ---- write the region back
-    for (uint32_t s = threadIdx.x; s < kRegionSlots; s += kPartBlock) {
-        a.table[2 * (rb + s)] = lw[s];
-        if (lc[s]) a.table[2 * (rb + s) + 1] += lc[s];
     }
 }
 
