@@ -45,7 +45,7 @@ constexpr int kBlock = 256;
 
 // ctr[0] = classes created by this launch, ctr[1] = deferred reads, ctr[2] = arena cursor (words),
 // ctr[3] = scratch (long-label count / read total), ctr[4] = nnz read back at finish
-enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_TMP = 3, CTR_NNZ = 4, CTR_N = 8 };
+enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_TMP = 3, CTR_NNZ = 4, CTR_PEEK = 5, CTR_N = 8 };     // CTR_PEEK..+2: offsets read ahead for the host
 
 // ---- label arena ------------------------------------------------------------------------------
 // A committed class keeps its label in the arena as one ENTRY: [len, id0, id1, ...], zero-padded to a
@@ -493,9 +493,19 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
     return SFGPU_OK;
 }
 
-// radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.
+// start of a partitioned sub-batch: zero its counters and fetch the offsets the host will want for the NEXT sub-batch (its
+// possible ends), so that they come back with this sub-batch's counters instead of in a round trip of their own
+__global__ void k_sub_batch_begin(unsigned long long* ctr, const uint32_t* __restrict__ offsets, uint64_t p0, uint64_t p1, uint64_t p2) {
+    if (threadIdx.x == 0) { ctr[CTR_NEW] = 0; ctr[CTR_DEFER] = 0; ctr[CTR_TMP] = 0; }
+    if (threadIdx.x == 1) ctr[CTR_PEEK + 0] = offsets[p0];
+    if (threadIdx.x == 2) ctr[CTR_PEEK + 1] = offsets[p1];
+    if (threadIdx.x == 3) ctr[CTR_PEEK + 2] = offsets[p2];
+}
+
+// radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.  peek[3] = positions in
+// d_offsets whose values are returned in eq->h_ctr[CTR_PEEK..]
 static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t cnt,
-                          uint64_t n_words) {
+                          uint64_t n_words, const uint64_t* peek) {
     hipStream_t st = eq->stream;
     int rc;
     // The table doubles when the classes seen so far would fill more than half of it (SFGPU_EQ_LOAD_DIV: 1/div).  A
@@ -542,8 +552,8 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->part_hist.reserve(n_bins + 1, st, false))) return rc;          // fill of every bin
     if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
     if ((rc = eq->deferred_a.reserve(2ull * cnt, st, false))) return rc;
-    SF_HIP(hipMemsetAsync(eq->d_ctr, 0, 2 * sizeof(unsigned long long), st));     // CTR_NEW, CTR_DEFER
-    SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));     // long-label counter
+    hipLaunchKernelGGL(k_sub_batch_begin, dim3(1), dim3(64), 0, st, eq->d_ctr, d_offsets, peek[0], peek[1], peek[2]);   // CTR_NEW, CTR_DEFER, long-label counter
+    SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev0, st));
     uint4* bins = reinterpret_cast<uint4*>(eq->part_words.p);
     RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, eq->part_hist.p,
@@ -599,10 +609,24 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     SF_REQUIRE(!eq->finished, SFGPU_ERR_STATE, "sfgpu_eq_add_batch: builder already finished (call start)");
     if (n_reads == 0) return SFGPU_OK;
     hipStream_t st = eq->stream;
-    uint32_t ends[2];
+    // big unweighted batches take the radix-partitioned path, everything else the generic one
+    const bool part = eq->use_part && !d_weights && n_reads >= (1u << 16);
+    uint32_t step = part ? eq->part_sub_batch : eq->sub_batch;
+    // offsets the host has seen: (position, value).  A partitioned sub-batch brings the possible ends of the next one back
+    // with its counters (k_sub_batch_begin), so the loop below needs a round trip of its own only when it has to guess again
+    uint64_t known_pos[8]; uint32_t known_val[8]; int n_known = 0;
+    auto remember = [&](uint64_t pos, uint32_t val) { known_pos[n_known & 7] = pos; known_val[n_known & 7] = val; ++n_known; };
+    auto recall = [&](uint64_t pos, uint32_t* val) -> bool {
+        for (int i = 0; i < (n_known < 8 ? n_known : 8); ++i) if (known_pos[i] == pos) { *val = known_val[i]; return true; }
+        return false;
+    };
+    uint32_t ends[3];
+    const uint64_t first_end = (n_reads < step) ? n_reads : step;
     SF_HIP(hipMemcpyAsync(&ends[0], d_offsets, 4, hipMemcpyDeviceToHost, st));
     SF_HIP(hipMemcpyAsync(&ends[1], d_offsets + n_reads, 4, hipMemcpyDeviceToHost, st));
+    SF_HIP(hipMemcpyAsync(&ends[2], d_offsets + first_end, 4, hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
+    remember(0, ends[0]); remember(n_reads, ends[1]); remember(first_end, ends[2]);
     SF_REQUIRE(ends[1] >= ends[0], SFGPU_ERR_INVALID, "sfgpu_eq_add_batch: offsets not ascending");
     uint64_t batch_ids = (uint64_t)ends[1] - ends[0];
     int rc;
@@ -615,14 +639,11 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
         return eq->arena.reserve(need, st, true, eq->arena_used);
     };
 
-    // big unweighted batches take the radix-partitioned path, everything else the generic one
-    const bool part = eq->use_part && !d_weights && n_reads >= (1u << 16);
     if (!part && (rc = reserve_arena(batch_ids, n_reads))) return rc;
     // Sub-batches bound the partition buffer and let the table grow between them.  Each one shows how fast
     // new classes appear (the rate only falls as the table fills); the next sub-batch is made up to four
     // times larger (at most 2^26 reads) as long as, at that rate, the table would stay under half full:
     // fewer launches and longer region segments (400 M reads: 24 sub-batches -> 8).
-    uint32_t step = part ? eq->part_sub_batch : eq->sub_batch;
     const bool adaptive = part && getenv("SFGPU_EQ_SUBBATCH") == nullptr;
     for (uint32_t first = 0; first < n_reads; ) {
         uint32_t cnt = (n_reads - first < step) ? (n_reads - first) : step;
@@ -630,14 +651,22 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
         bool done = false;
         if (part && (eq->cap >> kRegionBits) <= (uint64_t)kMaxRegions) {
             uint32_t se[2];
-            SF_HIP(hipMemcpyAsync(&se[0], d_offsets + first, 4, hipMemcpyDeviceToHost, st));
-            SF_HIP(hipMemcpyAsync(&se[1], d_offsets + first + cnt, 4, hipMemcpyDeviceToHost, st));
-            SF_HIP(hipStreamSynchronize(st));
+            if (!recall(first, &se[0]) || !recall((uint64_t)first + cnt, &se[1])) {
+                SF_HIP(hipMemcpyAsync(&se[0], d_offsets + first, 4, hipMemcpyDeviceToHost, st));
+                SF_HIP(hipMemcpyAsync(&se[1], d_offsets + first + cnt, 4, hipMemcpyDeviceToHost, st));
+                SF_HIP(hipStreamSynchronize(st));
+            }
             uint64_t n_words = (uint64_t)se[1] - se[0];
             if (n_words >= (1ull << 31) && cnt > (1u << 20)) { step = cnt / 2; continue; }     // too many ids for 31-bit offsets: halve
             if ((rc = reserve_arena(n_words, cnt))) return rc;
             if (n_words < (1ull << 31) && n_words >= 64) {       // (a sub-batch of next to no ids is not worth a partition)
-                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words))) return rc;
+                // the next sub-batch starts at `nf` and is step, 2 step or 4 step reads long (see below)
+                const uint64_t nf = (uint64_t)first + cnt, left = n_reads - nf;
+                uint64_t peek[3];
+                for (int i = 0; i < 3; ++i) { const uint64_t len = (uint64_t)step << i; peek[i] = nf + (len < left ? len : left); }
+                if ((rc = eq_partitioned(eq, d_ids, d_offsets, first, cnt, n_words, peek))) return rc;
+                remember(nf, se[1]);
+                for (int i = 0; i < 3; ++i) remember(peek[i], (uint32_t)eq->h_ctr[CTR_PEEK + i]);
                 done = true;
             }
         } else if (part) {
