@@ -115,11 +115,18 @@ __global__ void k_clamp_len(uint64_t M, const double* __restrict__ len, double* 
     if (t < M) { double l = len[t]; lenc[t] = (l <= 1.0) ? 1.0 : l; }   // :738
 }
 
+// The sweep skips NaN terms (EM, :269) and expTheta <= 0 terms (VBEM, :344, :356).  Both tests depend on the transcript only,
+// so they are applied ONCE, where x_t is produced, and the sweep's inner loops carry no guard: x_t = 0 is the skipped term.
+template <bool VB> __device__ __forceinline__ double sweep_x(double v) {
+    if (VB) return (v > 0.0) ? v : 0.0;
+    return (v == v) ? v : 0.0;
+}
+
 // after a bias recompute (:824-840): x for the next sweep from the current alpha and the new lengths
 __global__ void k_x_from_alpha(uint64_t M, const double* __restrict__ alpha, const double* __restrict__ lenc,
                                double* __restrict__ x) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M) x[t] = alpha[t] / lenc[t];
+    if (t < M) x[t] = sweep_x<false>(alpha[t] / lenc[t]);
 }
 
 __global__ void k_alpha_partials(uint64_t M, const double* __restrict__ alpha, double* partials) {
@@ -171,7 +178,7 @@ __global__ void k_init_alpha(uint64_t M, double* alpha, double* alpha_out, doubl
     for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
         double a = (alpha_out[t] > 0.0) ? scale * total_frags : 0.0;
         alpha[t] = a; alpha_out[t] = 0.0;
-        if (VB) local += a; else x[t] = a / lenc[t];
+        if (VB) local += a; else x[t] = sweep_x<false>(a / lenc[t]);
     }
     if (VB) { double s = block_sum(local, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -191,7 +198,7 @@ __global__ void k_vb_prepare(uint64_t M, const double* __restrict__ alpha, doubl
     double log_norm = digamma_pos(asum);
     for (uint64_t t = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x; t < M; t += (uint64_t)gridDim.x * kEmBlock) {
         double a = alpha[t];
-        x[t] = (a > kTiny) ? exp(digamma_pos(a) - log_norm) / lenc[t] : 0.0;
+        x[t] = (a > kTiny) ? sweep_x<true>(exp(digamma_pos(a) - log_norm) / lenc[t]) : 0.0;
     }
 }
 
@@ -237,7 +244,15 @@ constexpr int kPerLane = SFGPU_PER_LANE;     // consecutive stream words per lan
 #define SFGPU_SWEEP_REGCHUNKS 1
 #endif
 constexpr int kRegChunks = SFGPU_SWEEP_REGCHUNKS;
-constexpr uint32_t kNull = 0x80000000u, kSingle = 0x20000000u;
+#ifndef SFGPU_SWEEP_CNTAHEAD
+#define SFGPU_SWEEP_CNTAHEAD 4
+#endif
+constexpr int kCntAhead = SFGPU_SWEEP_CNTAHEAD;    // class counts per thread requested ahead of phase B
+// A NULL word (padding, or a member that escaped the window) names a slot and a class of its own -- window slot kWin, which
+// holds x = 0, and class kTileNnz, whose count/denom is 0 -- so the sweep treats it like any other word: no test per word.
+constexpr uint32_t kNullBit = 0x80000000u, kSingle = 0x20000000u;
+constexpr uint32_t kNull = kNullBit | ((uint32_t)kTileNnz << 16) | (uint32_t)kWin;
+static_assert(kTileNnz < (1 << 13) && kWin < (1 << 16), "stream word: 13-bit class, 16-bit window slot");
 static_assert(kTileNnz <= 8191, "class index field is 13 bits");
 
 // tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*tile_nnz, (i+1)*tile_nnz)
@@ -353,7 +368,7 @@ struct SweepArgs {
 };
 
 template <bool VB>
-__global__ void __launch_bounds__(kSweepBlock)
+__global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two 1024-thread blocks per CU: 64 VGPRs
 k_sweep_lds(SweepArgs a) {
     // the tile descriptors do not depend on the loop state: request them first so that the state test
     // below costs no extra memory round trip
@@ -372,37 +387,64 @@ k_sweep_lds(SweepArgs a) {
         if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
     }
     if (stop) return;
-    __shared__ double xs[kWin];
-    __shared__ double acc[kWin];
-    __shared__ double den[kTileNnz];                       // denominators, then count/denom, per class of the tile
+    __shared__ double xs[kWin + 1];                        // (+ the slot of the null words: x = 0)
+    __shared__ double acc[kWin + 1];
+    __shared__ double den[kTileNnz + 1];                   // denominators, then count/denom, per class of the tile (+ the null class)
     const double* __restrict__ x = a.x;
     if (nc == 0) return;
     const uint4* __restrict__ words = reinterpret_cast<const uint4*>(a.stream + s0);
 
-    auto keep = [](double v) -> double {
-        if (VB) return (v > 0.0) ? v : 0.0;                // expTheta == 0 terms are skipped (:344, :356)
-        return (v == v) ? v : 0.0;                         // NaN terms are skipped (:269)
-    };
-    auto denominators = [&](const uint32_t (&w)[kPerLane]) {
-        uint32_t cur = 0xFFFFFFFFu; double run = 0.0;
+    // The inner loops carry no test per word: x is clean (sweep_x), null words have a slot and a class of their own, a
+    // singleton's denominator is never used (phase B overwrites it with the count), and adding a zero changes nothing.  The only
+    // branch is the run boundary.  The register chunks keep their gathered x values (xv) for phase C and count/denom is read
+    // once per run of a class.  N words at a time; (cur, run) / (cur, f) carry over between calls.
+    // What bounds the sweep (round 2, cfg3, 21 us): the LDS f64 atomics -- phase C with plain stores instead of atomics is 5.3 us
+    // shorter, 9.3 M + 3.7 M atomics at ~0.3 cycles per lane and CU (tools/probes/lds_atomic_probe.hip: 0.14 conflict free,
+    // 0.29 random in 1024 slots, 0.37 random in 300) -- then the fixed costs of a one-round tile (launch + state 2.3 us, staging
+    // 0.8, phase B 1.8, D 1.0) and the third, quarter-full chunk pass.  Halving the instructions per nonzero (28 + 24 -> 12 + 12)
+    // alone changed nothing (22.0 -> 22.5 us).
+    auto den_words = [&](const uint32_t* w, auto n_tag, double* v, uint32_t& cur, double& run) {
+        constexpr int N = decltype(n_tag)::value;
 #pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {
-            if (w[i] & (kNull | kSingle)) continue;        // singletons never need a denominator
-            uint32_t cls = (w[i] >> 16) & 0x1FFFu;
-            double v = keep(xs[w[i] & 0xFFFFu]);
-            if (cls != cur) { if (cur != 0xFFFFFFFFu && run != 0.0) atomicAdd(&den[cur], run); cur = cls; run = v; }
-            else run += v;
-        }
-        if (cur != 0xFFFFFFFFu && run != 0.0) atomicAdd(&den[cur], run);
-    };
-    auto scatter = [&](const uint32_t (&w)[kPerLane]) {
+        for (int i = 0; i < N; ++i) v[i] = xs[w[i] & 0xFFFFu];
 #pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {
-            if (w[i] & kNull) continue;
-            double f = den[(w[i] >> 16) & 0x1FFFu];
-            double contrib = (w[i] & kSingle) ? f : keep(xs[w[i] & 0xFFFFu]) * f;
-            if (contrib != 0.0) atomicAdd(&acc[w[i] & 0xFFFFu], contrib);
+        for (int i = 0; i < N; ++i) {
+            const uint32_t cls = (w[i] >> 16) & 0x1FFFu;
+            if (cls != cur) { atomicAdd(&den[cur], run); cur = cls; run = v[i]; }
+            else run += v[i];
         }
+    };
+    auto acc_words = [&](const uint32_t* w, auto n_tag, const double* v, uint32_t& cur, double& f) {
+        constexpr int N = decltype(n_tag)::value;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t cls = (w[i] >> 16) & 0x1FFFu;
+            if (cls != cur) { f = den[cls]; cur = cls; }
+            const double m = (w[i] & kSingle) ? 1.0 : v[i];                 // a singleton adds its count (:275 / :364)
+            atomicAdd(&acc[w[i] & 0xFFFFu], m * f);
+        }
+    };
+    using N4 = std::integral_constant<int, 4>; using N8 = std::integral_constant<int, kPerLane>;
+    static_assert(kPerLane == 8, "two 16-byte loads per lane and chunk");
+    // a chunk that is not held in registers: 4 words at a time (x values in registers only while they are used)
+    auto den_chunk = [&](const uint4& w0, const uint4& w1) {
+        const uint32_t a4[4] = {w0.x, w0.y, w0.z, w0.w}, b4[4] = {w1.x, w1.y, w1.z, w1.w};
+        double v[4];
+        uint32_t cur = kTileNnz; double run = 0.0;                           // (starts on the null class: adds 0 to it)
+        den_words(a4, N4{}, v, cur, run);
+        den_words(b4, N4{}, v, cur, run);
+        atomicAdd(&den[cur], run);
+    };
+    auto acc_chunk = [&](const uint4& w0, const uint4& w1) {
+        const uint32_t a4[4] = {w0.x, w0.y, w0.z, w0.w}, b4[4] = {w1.x, w1.y, w1.z, w1.w};
+        double v[4];
+        uint32_t cur = kTileNnz; double f = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = xs[a4[i] & 0xFFFFu];
+        acc_words(a4, N4{}, v, cur, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = xs[b4[i] & 0xFFFFu];
+        acc_words(b4, N4{}, v, cur, f);
     };
 
     // Everything the block needs from HBM is requested up front, before the first barrier: the
@@ -413,6 +455,7 @@ k_sweep_lds(SweepArgs a) {
     // 3 chunks 25.1 -- the re-fetch of the other chunks hits the L2 and costs less than the registers do.)
     const uint32_t g0 = threadIdx.x * kPerLane;
     uint32_t w[kRegChunks][kPerLane];
+    double xv[kRegChunks][kPerLane];                      // x of the register chunks' words, phase A -> phase C
 #pragma unroll
     for (int c = 0; c < kRegChunks; ++c) {
         const uint32_t g = g0 + (uint32_t)c * kSweepBlock * kPerLane;
@@ -420,51 +463,56 @@ k_sweep_lds(SweepArgs a) {
         if (g < n8) { w0 = words[g / 4]; w1 = words[g / 4 + 1]; }
         w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
     }
-    uint32_t cnt0 = (threadIdx.x < nc) ? a.counts[c0 + threadIdx.x] : 0u;          // bit 31: singleton class
-    uint32_t cnt1 = (threadIdx.x + kSweepBlock < nc) ? a.counts[c0 + threadIdx.x + kSweepBlock] : 0u;
     for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
+    if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
     __syncthreads();
 
     // ---- A: denominators
     {
 #pragma unroll
-        for (int c = 0; c < kRegChunks; ++c) denominators(w[c]);
-        for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
-            uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
-            uint32_t v[kPerLane] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            denominators(v);
+        for (int c = 0; c < kRegChunks; ++c) {
+            uint32_t cur = kTileNnz; double run = 0.0;
+            den_words(w[c], N8{}, xv[c], cur, run);
+            atomicAdd(&den[cur], run);
         }
+        for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) den_chunk(words[g / 4], words[g / 4 + 1]);
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global gather
             uint32_t tag = a.esc_cls[e0 + i];
             if (tag & kSingle) continue;
-            double v = keep(x[a.esc_id[e0 + i]]);
+            double v = x[a.esc_id[e0 + i]];
             if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
         }
     }
+    // the class counts of phase B are requested here, behind phase A's last atomics: their round trip overlaps the barrier
+    // (requested at the top of the kernel they held registers through phase A; requested in phase B they were 2.3 us of it)
+    uint32_t cw[kCntAhead];                                                         // bit 31: singleton class
+#pragma unroll
+    for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = threadIdx.x + i * kSweepBlock; cw[i] = (c < nc) ? a.counts[c0 + c] : 0u; }
     __syncthreads();
     // ---- B: count / denom per class (in place); singletons carry the full count (:275 / :364)
-    for (uint32_t c = threadIdx.x, i = 0; c < nc; c += kSweepBlock, ++i) {
-        uint32_t cw = (i == 0) ? cnt0 : (i == 1) ? cnt1 : a.counts[c0 + c];
-        double cnt = (double)(cw & 0x7FFFFFFFu);
+    auto invert = [&](uint32_t c, uint32_t cwc) {
+        double cnt = (double)(cwc & 0x7FFFFFFFu);
         double d = den[c];
-        den[c] = (cw >> 31) ? cnt : ((d > kTiny) ? cnt / d : 0.0);     // :260-264
-    }
+        den[c] = (cwc >> 31) ? cnt : ((d > kTiny) ? cnt / d : 0.0);     // :260-264
+    };
+#pragma unroll
+    for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = threadIdx.x + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
+    for (uint32_t c = threadIdx.x + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, a.counts[c0 + c]);
     __syncthreads();
     // ---- C: scatter-add into the window
     double esc_sum = 0.0;
     {
 #pragma unroll
-        for (int c = 0; c < kRegChunks; ++c) scatter(w[c]);
-        for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) {
-            uint4 w0 = words[g / 4], w1 = words[g / 4 + 1];
-            uint32_t v[kPerLane] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            scatter(v);
+        for (int c = 0; c < kRegChunks; ++c) {
+            uint32_t cur = kTileNnz; double f = 0.0;
+            acc_words(w[c], N8{}, xv[c], cur, f);
         }
+        for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) acc_chunk(words[g / 4], words[g / 4 + 1]);
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global atomics
             uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
             double f = den[(tag >> 16) & 0x1FFFu];
-            double contrib = (tag & kSingle) ? f : keep(x[t]) * f;
+            double contrib = (tag & kSingle) ? f : x[t] * f;
             if (contrib != 0.0) { atomicAdd(&a.alpha_out[t], contrib); esc_sum += contrib; }
         }
     }
@@ -557,9 +605,9 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
             if (local_max < 0.0) local_max = 0.0;      // gated at least once
         }
         alpha[t] = ap; alpha_out[t] = 0.0;
-        if (fused_vb) x[t] = (ap > kTiny) ? exp(digamma_pos(ap) - log_norm) / lenc[t] : 0.0;   // :300-320
+        if (fused_vb) x[t] = (ap > kTiny) ? sweep_x<true>(exp(digamma_pos(ap) - log_norm) / lenc[t]) : 0.0;   // :300-320
         else if (VB) local_sum += ap;
-        else x[t] = ap / lenc[t];
+        else x[t] = sweep_x<false>(ap / lenc[t]);
     }
     for (int o = kWave / 2; o > 0; o >>= 1) {
         double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
