@@ -20,10 +20,10 @@ FETCH_X2 = ("k_sweep_lds", "k_part_route", "k_part_insert", "k_filter", "k_expor
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit(f"no *{suffix} under {d}")
-    return hits[-1]
+    return hits[-1]                        # the newest: gpurun merges a session's files into what earlier sessions left
 
 
 def short(name):
