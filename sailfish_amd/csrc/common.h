@@ -22,6 +22,7 @@ inline hipStream_t as_stream(sfgpu_stream s) { return reinterpret_cast<hipStream
 // block has been synchronised (handles synchronise their stream before releasing scratch).
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);
+void pool_free_on(void* p, hipStream_t s);     // back to the cache once the work enqueued on s so far is done (no host wait)
 void pool_trim();
 template <typename T>
 inline hipError_t pool_malloc(T** p, size_t bytes) { return pool_malloc(reinterpret_cast<void**>(p), bytes); }

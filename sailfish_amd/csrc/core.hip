@@ -42,10 +42,28 @@ enum { kDeviceMem = 0, kPinnedMem = 1 };
 size_t round_up_pow2(size_t n) { size_t r = 256; while (r < n) r <<= 1; return r; }
 int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
+struct Pending { void* p; hipEvent_t ev; };
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_events;
+void reap_pending_locked(bool wait) {
+    size_t keep = 0;
+    for (size_t i = 0; i < g_pending.size(); ++i) {
+        Pending& x = g_pending[i];
+        hipError_t q = wait ? hipEventSynchronize(x.ev) : hipEventQuery(x.ev);
+        if (q == hipErrorNotReady) { g_pending[keep++] = x; continue; }
+        (void)hipGetLastError();
+        auto it = g_pool_key.find(x.p);
+        if (it != g_pool_key.end()) g_pool_free[it->second].push_back(x.p); else (void)hipFree(x.p);
+        g_events.push_back(x.ev);
+    }
+    g_pending.resize(keep);
+}
+
 hipError_t pool_get(void** p, size_t bytes, int kind) {
     const Key key{cur_device(), kind, round_up_pow2(bytes ? bytes : 1)};
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pending.empty()) reap_pending_locked(false);
         auto it = g_pool_free.find(key);
         if (it != g_pool_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); return hipSuccess; }
     }
@@ -72,6 +90,22 @@ void pool_put(void* p, int kind) {
 }
 }  // namespace
 
+// Stream-ordered free: the block goes back to the cache once the work enqueued on `s` so far has completed (an event is
+// recorded now and polled when the allocator next runs) -- callers that would otherwise synchronise just to free a scratch
+// buffer (the rocPRIM wrappers: ~25 us of idle GPU each time) use this.
+void pool_free_on(void* p, hipStream_t s) {
+    if (!p) return;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_events.empty()) { ev = g_events.back(); g_events.pop_back(); }
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamSynchronize(s); pool_free(p); return; }
+    if (hipEventRecord(ev, s) != hipSuccess) { (void)hipStreamSynchronize(s); pool_free(p); std::lock_guard<std::mutex> lk(g_pool_mu); g_events.push_back(ev); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pending.push_back({p, ev});
+}
+
 hipError_t pool_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kDeviceMem); }
 void pool_free(void* p) { pool_put(p, kDeviceMem); }
 hipError_t pinned_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kPinnedMem); }
@@ -93,6 +127,9 @@ void stream_release(hipStream_t s) {          // the caller has synchronised it
 
 void pool_trim() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    reap_pending_locked(true);
+    for (hipEvent_t ev : g_events) (void)hipEventDestroy(ev);
+    g_events.clear();
     for (auto& kv : g_pool_free) {
         for (void* q : kv.second) {
             g_pool_key.erase(q);

@@ -920,10 +920,11 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
                            em->tile_lo, em->tile_span, t_len8, t_nesc);
         EM_TRY(hipGetLastError());
-        int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur);
-        if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur);
-        if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur);
-        pool_free(t_len8); pool_free(t_nesc);
+        // (no host wait inside the scans: the totals are read back with one synchronisation below)
+        int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur, false);
+        if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur, false);
+        if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur, false);
+        pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur);
         if (sr) { em_free(em); return sr; }
         uint64_t P = 0, S = 0, E = 0;
         EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
@@ -950,12 +951,13 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             hipLaunchKernelGGL(k_cover_pairs, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off,
                                k_in, v_in);
             int bits = 1; while (bits < 32 && (1ull << bits) <= M) ++bits;
-            int src = sort_pairs_u64_u32(k_in, k_out, v_in, em->cov_pos, P, em->cur, bits);
+            int src = sort_pairs_u64_u32(k_in, k_out, v_in, em->cov_pos, P, em->cur, bits, false);     // (synchronised below, before the frees)
             if (!src) {
                 hipLaunchKernelGGL(k_invert_perm, dim3(blocks_for(P)), dim3(kEmBlock), 0, em->cur, P, em->cov_pos, em->pub_pos);
                 hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, em->cov_ptr);
                 (void)hipStreamSynchronize(em->cur);
             }
+            if (src) (void)hipStreamSynchronize(em->cur);
             pool_free(k_in); pool_free(k_out); pool_free(v_in);
             if (src) { em_free(em); return src; }
         } else {
@@ -1139,6 +1141,8 @@ static bool same_opts(const sfgpu_em_opts& a, const sfgpu_em_opts& b) {
            a.check_mode == b.check_mode && a.iters_per_launch == b.iters_per_launch;
 }
 
+constexpr uint32_t kPreLaunched = 8;      // iterations enqueued directly while the host builds the graph (em_run)
+
 // `n` iterations as an executable graph (kernel arguments are baked, the iteration index and the stop
 // latch live in device memory)
 static int em_build_graph(sfgpu_em* em, uint32_t n) {
@@ -1177,8 +1181,16 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     if (!quiet) log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
     const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
     const uint32_t chunk = em->opts.iters_per_launch;
-    if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
     SF_HIP(hipEventRecord(em->ev_a, em->cur));
+    if (use_graph && !(em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == chunk)) {
+        // building the graph takes the host ~170 us: the first iterations go straight onto the stream and run meanwhile
+        // (iterations past the stop are no-ops, so it does not matter how many of them there are)
+        for (uint32_t i = 0; i < kPreLaunched; ++i) {
+            if ((rc = em_enqueue_sweep(em))) return rc;
+            if ((rc = em_enqueue_update(em, true))) return rc;
+        }
+    }
+    if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
     while (!done) {
         if (use_graph) {
             SF_HIP(hipGraphLaunch(em->graph, em->cur));

@@ -282,10 +282,27 @@ __global__ void k_export(uint64_t n, const uint32_t* __restrict__ order, const u
     rowptr[i] = (uint32_t)rowptr64[i];
     if (i == n) return;
     uint32_t c = order[i];
-    const uint32_t* p = arena + cls_off[c];
+    // an arena entry is 16-byte aligned: [n, id0, id1, id2][id3 .. id6] ...; read by granules, not by words
+    const uint4* e = reinterpret_cast<const uint4*>(arena + cls_off[c] - 1);
     uint32_t* q = ids + rowptr64[i];
-    uint32_t len = cls_len[c];
-    for (uint32_t k = 0; k < len; ++k) q[k] = p[k];
+    const uint32_t len = cls_len[c];
+    const uint4 g0 = e[0];
+    uint4 g1 = make_uint4(0u, 0u, 0u, 0u);
+    if (len > 3u) g1 = e[1];
+    if (len > 0u) q[0] = g0.y;
+    if (len > 1u) q[1] = g0.z;
+    if (len > 2u) q[2] = g0.w;
+    if (len > 3u) q[3] = g1.x;
+    if (len > 4u) q[4] = g1.y;
+    if (len > 5u) q[5] = g1.z;
+    if (len > 6u) q[6] = g1.w;
+    for (uint32_t k = 7; k < len; k += 4) {
+        const uint4 g = e[(k + 1) >> 2];
+        q[k] = g.x;
+        if (k + 1 < len) q[k + 1] = g.y;
+        if (k + 2 < len) q[k + 2] = g.z;
+        if (k + 3 < len) q[k + 3] = g.w;
+    }
     counts[i] = table[2 * (uint64_t)cls_slot[c] + 1];
     if (hashes) hashes[i] = cls_hash[c];
 }
@@ -835,13 +852,14 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
         hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
                            eq->arena.p, keys_in.p, vals_in.p);
         SF_CHECK_LAUNCH();
-        if ((rc = sort_pairs_u64_u32(keys_in.p, keys_out.p, vals_in.p, eq->order.p, n, st))) return rc;
+        // (no host wait inside the sort and the scan: everything they touch lives until the synchronisation below)
+        if ((rc = sort_pairs_u64_u32(keys_in.p, keys_out.p, vals_in.p, eq->order.p, n, st, 64, false))) return rc;
         hipLaunchKernelGGL(k_tie_fix, dim3(grid_for(n)), dim3(kBlock), 0, st, n, keys_out.p, eq->order.p, eq->cls_hash.p,
                            eq->cls_off.p, eq->cls_len.p, eq->arena.p);
         SF_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_sorted_lens, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, n, eq->order.p, eq->cls_len.p, lens.p);
         SF_CHECK_LAUNCH();
-        if ((rc = exclusive_scan_u32(lens.p, eq->rowptr64.p, n, st))) return rc;
+        if ((rc = exclusive_scan_u32(lens.p, eq->rowptr64.p, n, st, false))) return rc;
         SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(n) < 512 ? grid_for(n) : 512), dim3(kBlock), 0, st, n, eq->table.p, eq->cls_slot.p,
                            eq->d_ctr + 3);
