@@ -112,7 +112,8 @@ class EquivalenceClassBuilder:
         st = _lib.EqStats()
         _lib.check(self._L.sfgpu_eq_get_stats(self._h, C.byref(st)))
         return dict(insert_ms=st.insert_ms, insert_launches=st.insert_launches, table_grows=st.table_grows,
-                    deferred_reads=st.deferred_reads, table_slots=st.table_slots)
+                    deferred_reads=st.deferred_reads, table_slots=st.table_slots,
+                    hot_reads=st.hot_reads, spilled_reads=st.spilled_reads)
 
     def finish(self):
         """finish() (:64-80): returns True; n_classes / total_reads are what the reference logs."""

@@ -160,6 +160,62 @@ def test_builder_partitioned_path_edge_cases(sf, gpu):
     _assert_same_classes(eq, ob, *oc)
 
 
+@pytest.mark.parametrize("sub_batch", ["65536", None])
+def test_builder_skewed_stream_hot_classes(sf, gpu, monkeypatch, sub_batch):
+    """real RNA-seq is skewed: a few labels hold a large part of the reads.  From the second sub-batch on such classes are
+    counted in the route pass itself (k_hot_select / the hot table of k_part_route) instead of overflowing their region's bins
+    into the generic kernel; what does spill is added once per wavefront (k_insert).  Hot labels of 1, 3, 4, 8, 40 and 123 ids
+    (one, two and many granules), more hot labels than hot-table slots can hold without collisions, near misses of the hottest labels (one id more, another last id), table growth between sub-batches (slots move: the hot table is rebuilt), two add_batch calls.
+    sub_batch=65536: ~30 sub-batches; None: one 5 M-read batch, which takes the small scout sub-batch first."""
+    import torch
+    if sub_batch:
+        monkeypatch.setenv("SFGPU_EQ_SUBBATCH", sub_batch)
+    rng = np.random.default_rng(5)
+    n_reads = 2_000_000 if sub_batch else 5_000_000
+    M = 60_000
+    hot = [np.sort(rng.choice(M, n, replace=False)).astype(np.uint32) for n in (1, 3, 4, 8, 40, 123)]
+    hot += [np.sort(rng.choice(M, int(rng.integers(1, 12)), replace=False)).astype(np.uint32) for _ in range(300)]
+    for h in hot[:6]:                                    # near misses of the hottest labels: same head, one id more / another last id
+        hot.append(np.concatenate([h, [M + 5]]).astype(np.uint32))
+        v = h.copy(); v[-1] = M + 9; hot.append(v)
+    cold_n = 400_000
+    k = np.minimum(1 + rng.geometric(0.3, cold_n), 60)
+    base = rng.integers(0, M, cold_n)
+    # cold label i = {base + 7 j}; some of them extend a hot label by one id (same head, different label)
+    pick = rng.integers(0, cold_n, n_reads)
+    u = rng.random(n_reads)
+    hot_pick = np.where(u < 0.45, rng.integers(0, 6, n_reads), rng.integers(0, len(hot), n_reads))
+    is_hot = u < 0.6
+    lens = np.where(is_hot, np.array([len(h) for h in hot])[hot_pick], k[pick]).astype(np.int64)
+    off = np.zeros(n_reads + 1, np.int64); np.cumsum(lens, out=off[1:])
+    ids = np.empty(off[-1], np.uint32)
+    rr = np.repeat(np.arange(n_reads), lens); j = np.arange(off[-1]) - off[:-1][rr]
+    ids[:] = ((base[pick][rr] + 7 * j) % M).astype(np.uint32)
+    hot_flat = np.concatenate(hot); hot_off = np.zeros(len(hot) + 1, np.int64); np.cumsum([len(h) for h in hot], out=hot_off[1:])
+    hm = is_hot[rr]
+    ids[hm] = hot_flat[hot_off[hot_pick[rr[hm]]] + j[hm]]
+    # cold labels that wrap around M are not sorted: sort every cold label (the builder wants sorted labels like the mapper's)
+    key = rr.astype(np.int64) * (1 << 32) + ids
+    cold_rows = ~hm
+    order = np.argsort(key[cold_rows], kind="stable")
+    ids[cold_rows] = ids[cold_rows][order]
+    off32 = off.astype(np.uint32)
+    ob, *oc = _oracle_classes([(ids, off32)])
+    cut = n_reads // 3 if sub_batch else n_reads - 300_000                      # (None: the first batch is big enough for the scout)
+    eq = sf.EquivalenceClassBuilder(device=gpu, expected_classes=1000)          # small table: it grows while the reads arrive
+    eq.start()
+    eq.add_batch(torch.from_numpy(ids[:off[cut]].view(np.int32)).to(gpu), torch.from_numpy(off32[:cut + 1].view(np.int32)).to(gpu))
+    eq.add_batch(torch.from_numpy(ids[off[cut]:].view(np.int32)).to(gpu),
+                 torch.from_numpy((off[cut:] - off[cut]).astype(np.uint32).view(np.int32)).to(gpu))
+    eq.finish()
+    _assert_same_classes(eq, ob, *oc)
+    st = eq.stats()
+    assert st["insert_launches"] >= (20 if sub_batch else 3)
+    # the hot classes hold 60 % of the reads: most of those are counted by the route pass; what spills to the generic kernel is
+    # bounded by the sub-batches that ran before the hot classes were known (the first one; the 1 M-read scout)
+    assert st["hot_reads"] > 0.3 * n_reads and st["spilled_reads"] < 0.15 * n_reads, st
+
+
 def test_builder_host_batches_from_threads(sf, gpu):
     """the reference-side adaptor's call pattern: several mapper threads hand over
     ~1000-read HOST batches concurrently; the library accumulates them in pinned memory and builds
