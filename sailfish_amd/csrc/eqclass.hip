@@ -373,6 +373,7 @@ struct sfgpu_eq {
     // radix-partitioned path (eqclass_part.h)
     bool use_part = true; uint32_t part_sub_batch = 1u << 24;
     DevBuf<uint32_t> part_words, part_hist, part_cursor, part_long, def_lens, def_ids, def_off;
+    DevBuf<uint64_t> def_w;                 // run lengths of the deferred labels (weights of their replay)
     DevBuf<unsigned long long> hot_buf;     // hot classes for k_part_route: kHotSlots hashes, kHotSlots (arena granule, slot) pairs, the count
     uint64_t reads_seen = 0;                // reads added since start()
     uint64_t hot_cap = 0, hot_reads = 0;    // table size and reads_seen when the hot table was last rebuilt
@@ -658,12 +659,13 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         SF_HIP(hipMemcpyAsync(&tot, eq->def_off64.p + n_def, 8, hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));
         if ((rc = eq->def_ids.reserve(tot + 1, st, false))) return rc;
+        if ((rc = eq->def_w.reserve(n_def + 1, st, false))) return rc;
         hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p,
-                           reinterpret_cast<const uint4*>(eq->part_words.p), eq->def_off64.p, eq->def_ids.p, eq->def_off.p);
+                           reinterpret_cast<const uint4*>(eq->part_words.p), eq->def_off64.p, eq->def_ids.p, eq->def_off.p, eq->def_w.p);
         SF_CHECK_LAUNCH();
         if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
         // deferred_a is reused by eq_generic: the copies above are complete (eq_grow synchronised)
-        if ((rc = eq_generic(eq, eq->def_ids.p, eq->def_off.p, 0, (uint32_t)n_def, nullptr, nullptr))) return rc;
+        if ((rc = eq_generic(eq, eq->def_ids.p, eq->def_off.p, 0, (uint32_t)n_def, nullptr, eq->def_w.p))) return rc;
     }
     if (n_long) {        // labels too long for an LDS tile
         if ((rc = eq_generic(eq, d_ids, d_offsets, 0, (uint32_t)n_long, eq->part_long.p, nullptr))) return rc;

@@ -84,6 +84,7 @@ struct RouteArgs {
     unsigned long long* n_hot_reads;               // statistics: reads counted here
 };
 
+constexpr uint32_t kCountedBit = 0x80000000u;          // in H: the label is followed by a granule [count, 0, 0, 0]
 constexpr uint32_t kHotSlots = 1024;
 constexpr uint32_t kHotProbes = 4;
 __device__ __forceinline__ uint32_t hot_index(uint64_t h) { return (uint32_t)(h >> 40) & (kHotSlots - 1); }   // (bits the region / slot / tag do not use alone)
@@ -215,8 +216,26 @@ k_part_route(RouteArgs a) {
         bool generic = unfit || (mx & kHeadBit);
         const uint32_t rg = ((uint32_t)h >> kRegionBits) & a.region_mask;
         const uint32_t H = (len << 24) | ((uint32_t)(h >> (64 - kTagBits)) << kRegionBits) | ((uint32_t)h & (kRegionSlots - 1));
+        // ---- runs: a read whose label is the previous read's (the lane below, same step) rides with it.  Reads that arrive
+        //      clustered (a position-sorted file: 64 consecutive reads hold one or two labels) would otherwise pile into a few
+        //      bins per block and overflow them (measured: 50 M sorted reads 22.8 ms against 2.6 ms shuffled).  The first read
+        //      of a run carries the run's length: one more granule [count, 0, 0, 0] behind its label, announced by bit 31 of H.
+        bool dup = false;
+        {
+            const uint64_t hp = __shfl_up(h, 1, kWave);
+            const uint32_t lp = __shfl_up(len, 1, kWave), bp = __shfl_up(b, 1, kWave);
+            const bool genp = __shfl_up((int)generic, 1, kWave) != 0;
+            if (lane != 0u && len != 0u && !generic && !genp && staged && h == hp && len == lp) {
+                const uint32_t* prev_s = stage + mis + (bp - w_lo);
+                dup = true;
+                for (uint32_t q = 0; dup && q < len; ++q) dup = lab_s[q] == prev_s[q];
+            }
+        }
+        const unsigned long long dm = __ballot(dup);
+        uint32_t mult = 1;
+        if (dm && !dup) { const unsigned long long after = lane == 63u ? 0ull : (dm >> (lane + 1u)); mult = 1u + (uint32_t)__builtin_ctzll(~after); }
         bool counted = false;
-        if (have_hot && len != 0 && !generic) {
+        if (have_hot && len != 0 && !generic && !dup) {
             uint32_t hi = hot_index(h);
             unsigned long long hv = hot_hl[hi];
             for (uint32_t p = 1; p < kHotProbes && hv != 0ull && hv != h; ++p) { hi = (hi + 1) & (kHotSlots - 1); hv = hot_hl[hi]; }
@@ -235,14 +254,16 @@ k_part_route(RouteArgs a) {
                     const uint4 eg = e[g];
                     same = eg.x == v0 && eg.y == (q + 1 < len ? v1 : 0u) && eg.z == (q + 2 < len ? v2 : 0u) && eg.w == (q + 3 < len ? v3 : 0u);
                 }
-                if (same) { atomicAdd(&hot_cnt[hi], 1u); counted = true; }
+                if (same) { atomicAdd(&hot_cnt[hi], mult); counted = true; }
             }
         }
-        if (len != 0 && !generic && !counted) {
-            const uint32_t at = atomicAdd(&cur[rg], ng);                                // my granules in the bin (rg, blk)
-            if (at + ng <= cap) {
+        if (len != 0 && !generic && !counted && !dup) {
+            const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
+            const uint32_t at = atomicAdd(&cur[rg], ngx);                               // my granules in the bin (rg, blk)
+            if (at + ngx <= cap) {
                 uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
-                dst[0] = make_uint4(w[0] | kHeadBit, H, w[1], w[2]);
+                dst[0] = make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]);
+                if (mult > 1u) dst[ng] = make_uint4(mult, 0u, 0u, 0u);
                 if (len > 3u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
                 for (uint32_t g = 2; g < ng; ++g) {
                     const uint32_t q = 4u * g - 1u;
@@ -260,7 +281,13 @@ k_part_route(RouteArgs a) {
             // one cursor update per wavefront, not per read: a label that holds a large part of the reads (a highly expressed
             // gene) overflows its bins read after read, and millions of returning atomics on ONE address serialise
             // (measured: 10 % of 50 M reads on one label, 76 ms for a 2.4 ms build)
-            const bool spill = len != 0 && generic;
+            bool spill = len != 0 && generic;
+            if (dm) {                                                                   // the reads of a run follow its first read
+                const unsigned long long lead = ~dm & ((2ull << lane) - 1ull);           // (lane 63: 2 << 63 wraps to 0, - 1 = all ones)
+                const int ll = 63 - __builtin_clzll(lead | 1ull);
+                const bool sl = __shfl((int)spill, ll, kWave) != 0;
+                if (dup) spill = sl;
+            }
             const unsigned long long sm = __ballot(spill);
             if (sm) {
                 unsigned long long base_l = 0;
@@ -375,11 +402,12 @@ k_part_insert(PartArgs a) {
         const uint32_t cnt = (n_gr - pos < 64u) ? (n_gr - pos) : 64u;
         const bool is_head = lane < cnt && (g.x & kHeadBit);
         const uint32_t H = g.y;
-        const uint32_t len = H >> 24;
+        const uint32_t len = (H >> 24) & 0x7Fu;
         const uint32_t ng = label_granules(len);
+        const uint32_t multi = H >> 31;                        // a run of identical reads: one more granule holds its length
         // labels whose granules are not all in this step wait for the next one, which starts at the first of them (a label
-        // is <= 31 granules, so the label at lane 0 is always whole; the last step of a bin holds whole labels only)
-        const unsigned long long inc = __ballot(is_head && lane + ng > cnt);
+        // is <= 32 granules, so the label at lane 0 is always whole; the last step of a bin holds whole labels only)
+        const unsigned long long inc = __ballot(is_head && lane + ng + multi > cnt);
         uint32_t adv = inc ? (uint32_t)__builtin_ctzll(inc) : cnt;
         if (adv == 0u) adv = cnt;                            // (cannot happen with well-formed bins: never spin on a corrupt one)
         tile[lane] = g;
@@ -401,7 +429,8 @@ k_part_insert(PartArgs a) {
         const uint32_t key = (((H >> kRegionBits) & 0xFFFu) << 20) | (len << 13);
         const uint32_t here = base + pos + lane;             // where this lane's granule sits in the bins (granule index)
         uint32_t s = H & (kRegionSlots - 1), probes = 0, c_idx = 0, c_rep = 0;
-        auto defer = [&]() { const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull); a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len; };
+        const uint32_t mult = (is_head && multi) ? tile[lane + ng].x : 1u;       // reads this label stands for
+        auto defer = [&]() { const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull); a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len | (multi << 31); };
         // -> true if the label is left with a candidate to verify (only when !serial: the serial form compares the further
         //    granules itself, one dependent load after the other -- the rare path after a failed verification)
         auto probe = [&](const bool serial) -> bool {
@@ -421,7 +450,7 @@ k_part_insert(PartArgs a) {
                     chead[idx] = make_uint4(here, w0, w1, w2);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     const uint32_t old = atomicCAS(&slot32[s], kSlotEmpty, key | idx);
-                    if (old == kSlotEmpty) { atomicAdd(&ccnt[idx], 1u); atomicAdd(&s_nnew, 1u); return false; }
+                    if (old == kSlotEmpty) { atomicAdd(&ccnt[idx], mult); atomicAdd(&s_nnew, 1u); return false; }
                     chead[idx].x = kDeadRep;                 // lost the race: this index stays unused
                     atomicSub(&s_occ, 1u);
                     e = old;
@@ -439,7 +468,7 @@ k_part_insert(PartArgs a) {
                         same = ej.x == tj.x && ej.y == tj.y && ej.z == tj.z && ej.w == tj.w;
                     }
                 }
-                if (same) { atomicAdd(&ccnt[idx], 1u); return false; }
+                if (same) { atomicAdd(&ccnt[idx], mult); return false; }
                 s = (s + 1) & (kRegionSlots - 1); ++probes;
             }
             return false;
@@ -459,8 +488,9 @@ k_part_insert(PartArgs a) {
             const int hl = below ? 63 - (int)__builtin_clzll(below) : 0;     // the lane of this granule's head (lane 0 starts a label)
             const uint32_t rep_h = __shfl(c_rep, hl, kWave);
             const bool pend_h = __shfl((int)pending, hl, kWave) != 0;
+            const uint32_t ng_h = __shfl(ng, hl, kWave);                     // (a run's count granule sits behind the label: not compared)
             bool bad = false;
-            if (pend_h && !is_head && lane < cnt) {
+            if (pend_h && !is_head && lane < cnt && lane - (uint32_t)hl < ng_h) {
                 const uint4* r = (rep_h & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (rep_h & ~kArenaBit) : a.bins + rep_h;
                 const uint4 ej = r[lane - (uint32_t)hl];
                 bad = ej.x != g.x || ej.y != g.y || ej.z != g.z || ej.w != g.w;
@@ -468,7 +498,7 @@ k_part_insert(PartArgs a) {
             const unsigned long long badm = __ballot(bad);
             if (pending) {
                 const unsigned long long mine = (badm >> lane) & ((2ull << (ng - 1)) - 2ull);     // bits 1 .. ng - 1: this label's lanes
-                if (!mine) atomicAdd(&ccnt[c_idx], 1u);
+                if (!mine) atomicAdd(&ccnt[c_idx], mult);
                 else { s = (s + 1) & (kRegionSlots - 1); ++probes; probe(true); }        // another label with this tag, length and head
             }
         }
@@ -523,19 +553,22 @@ k_part_insert(PartArgs a) {
 }
 
 // deferred labels (region full): copy them out of the bins into a small CSR batch that the generic path can insert
-// after the table has grown.  deferred[2 i] = granule index of the label in the bins, deferred[2 i + 1] = its length.
+// after the table has grown.  deferred[2 i] = granule index of the label in the bins, deferred[2 i + 1] = its length
+// (| bit 31: it stands for a run of reads); the generic path takes the run lengths as weights.
 __global__ void k_deferred_lens(uint64_t n, const uint32_t* __restrict__ deferred, uint32_t* lens) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    lens[i] = (i == n) ? 0u : deferred[2 * i + 1];
+    lens[i] = (i == n) ? 0u : (deferred[2 * i + 1] & 0x7Fu);
 }
 __global__ void k_deferred_copy(uint64_t n, const uint32_t* __restrict__ deferred, const uint4* __restrict__ bins,
-                                const uint64_t* __restrict__ off64, uint32_t* ids_out, uint32_t* off_out) {
+                                const uint64_t* __restrict__ off64, uint32_t* ids_out, uint32_t* off_out, uint64_t* weights_out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     off_out[i] = (uint32_t)off64[i];
     if (i == n) return;
     uint32_t len = (uint32_t)(off64[i + 1] - off64[i]);
+    // a run of identical reads carries its length in the granule behind the label (bit 31 of the deferred length word)
+    weights_out[i] = (deferred[2 * i + 1] >> 31) ? (uint64_t)bins[deferred[2 * i] + label_granules(len)].x : 1ull;
     const uint32_t* p = reinterpret_cast<const uint32_t*>(bins + deferred[2 * i]);
     uint32_t* q = ids_out + off64[i];
     q[0] = p[0] & ~kHeadBit;

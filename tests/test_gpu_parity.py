@@ -216,6 +216,77 @@ def test_builder_skewed_stream_hot_classes(sf, gpu, monkeypatch, sub_batch):
     assert st["hot_reads"] > 0.3 * n_reads and st["spilled_reads"] < 0.15 * n_reads, st
 
 
+@pytest.mark.parametrize("sub_batch,expected", [("65536", 1000), (None, 1000), (None, 0)])
+def test_builder_clustered_stream_runs(sf, gpu, monkeypatch, sub_batch, expected):
+    """reads that arrive CLUSTERED (a position-sorted input: the reads of one label come together).  The route pass folds a
+    run of identical labels inside a 64-read step into its first read, which carries the run length in one more granule; the
+    insert pass adds that length; a deferred run is replayed with its length as the weight; a spilled run goes to the generic
+    kernel read by read.  Runs of 1 ... 300 reads, of labels of 1 ... 130 ids (one, two, many granules; > 123 ids take the
+    generic kernel), empty reads inside runs, a fully sorted stretch, a shuffled stretch, runs crossing sub-batch and
+    add_batch boundaries; expected=1000 starts from a smaller table (test_builder_deferred_runs_keep_their_length forces the
+    deferral of runs)."""
+    import torch
+    if sub_batch:
+        monkeypatch.setenv("SFGPU_EQ_SUBBATCH", sub_batch)
+    rng = np.random.default_rng(17)
+    M = 70_000
+    n_labels = 150_000
+    lens = np.minimum(1 + rng.geometric(0.22, n_labels), 130)
+    lens[:40] = [1, 2, 3, 4, 7, 8, 9, 11, 12, 15, 16, 31, 64, 100, 123, 124, 125, 130, 5, 6] * 2
+    labels = [np.sort(rng.choice(M, int(n), replace=False)).astype(np.uint32) for n in lens[:3000]]
+    # the bulk of the labels: arithmetic progressions (cheap to build), sorted by construction
+    base = rng.integers(0, M - 130 * 3, n_labels)
+    reads = []
+    def lab(i):
+        return labels[i] if i < 3000 else (base[i] + 3 * np.arange(lens[i])).astype(np.uint32)
+    # part 1: runs (run length law: mostly short, some > 64 and > 256)
+    i = 0
+    while len(reads) < 700_000:
+        rl = int(min(300, rng.geometric(0.05))) if rng.random() < 0.9 else int(rng.integers(65, 300))
+        l = lab(i % n_labels); i += 1
+        for q in range(rl):
+            reads.append(l)
+            if rng.random() < 0.002: reads.append(np.zeros(0, np.uint32))       # an empty read inside the run
+    # part 2: a sorted stretch over few labels (long runs), then a shuffled stretch over the same labels
+    pick = np.sort(rng.integers(0, 2000, 400_000))
+    reads += [lab(int(k)) for k in pick]
+    pick = rng.integers(0, n_labels, 500_000)
+    reads += [lab(int(k)) for k in pick]
+    ids, off = _pack(reads)
+    ob, *oc = _oracle_classes([(ids, off)])
+    cut = 333_333
+    kw = dict(expected_classes=expected) if expected else {}
+    eq = sf.EquivalenceClassBuilder(device=gpu, **kw)
+    eq.start()
+    eq.add_batch(torch.from_numpy(ids[:off[cut]].view(np.int32)).to(gpu), torch.from_numpy(off[:cut + 1].view(np.int32)).to(gpu))
+    eq.add_batch(torch.from_numpy(ids[off[cut]:].view(np.int32)).to(gpu),
+                 torch.from_numpy((off[cut:] - off[cut]).astype(np.uint32).view(np.int32)).to(gpu))
+    eq.finish()
+    _assert_same_classes(eq, ob, *oc)
+
+
+def test_builder_deferred_runs_keep_their_length(sf, gpu):
+    """2.7 M distinct labels, each read three times in a row, into the smallest table (2^22 slots): the sub-batch after the
+    scout brings more new classes than its regions hold (2400 of 4096 slots), so labels are deferred -- as runs of three -- and
+    replayed after growth with the run length as their weight.  Known answer: every class counts exactly 3."""
+    import torch
+    n = 2_700_000
+    g = torch.Generator(device=gpu); g.manual_seed(4)
+    a = torch.randperm(n, generator=g, device=gpu, dtype=torch.int64)
+    lab = torch.stack([a, (a * 5 + 1) % 977 + n], 1)                      # all-distinct sorted 2-id labels
+    ids = lab.repeat_interleave(3, dim=0).reshape(-1).to(torch.int32)
+    off = (torch.arange(3 * n + 1, device=gpu, dtype=torch.int64) * 2).to(torch.int32)
+    eq = sf.EquivalenceClassBuilder(device=gpu, expected_classes=1000)
+    eq.start(); eq.add_batch(ids, off); eq.finish()
+    st = eq.stats()
+    assert st["deferred_reads"] > 0 and st["table_grows"] >= 1, st
+    v = eq.eqVec()
+    assert eq.n_classes == n and eq.total_reads == 3 * n
+    assert bool((v.counts == 3).all())
+    first = v.ids.view(-1, 2)[:, 0].to(torch.int64)
+    assert bool(torch.equal(torch.sort(first).values, torch.arange(n, device=gpu)))
+
+
 def test_builder_host_batches_from_threads(sf, gpu):
     """the reference-side adaptor's call pattern: several mapper threads hand over
     ~1000-read HOST batches concurrently; the library accumulates them in pinned memory and builds
