@@ -584,7 +584,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
     // every block of pass 1 owns one contiguous tile of reads and one bin per region
     static const uint32_t max_blocks = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long v = e ? atol(e) : 512; return (uint32_t)(v >= 1 && v <= 1024 ? v : 512); }();
-    uint32_t n_blocks = (cnt + 32767u) / 32768u; if (n_blocks > max_blocks) n_blocks = max_blocks; if (n_blocks == 0) n_blocks = 1;
+    uint32_t n_blocks = (cnt + 2047u) / 2048u; if (n_blocks > max_blocks) n_blocks = max_blocks; if (n_blocks == 0) n_blocks = 1;     // (>= 2 steps per wavefront)
     const uint32_t tile = (uint32_t)((((uint64_t)cnt + n_blocks - 1) / n_blocks + 63) & ~63ull);     // whole wavefront steps
     // Bin capacity in 16-byte granules.  A label of n ids takes ceil((n + 1) / 4) <= (n + 4) / 4 granules, so
     // (ids + 4 reads) / 4 bounds the stream from above; a bin gets its share of that bound plus 25 % and a constant --
@@ -631,7 +631,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen;
     }
     RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, eq->part_hist.p,
-                 eq->d_ctr + 3, eq->part_long.p, hot_h, hot_meta, n_hot, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT};
+                 eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT};
     const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
     hipLaunchKernelGGL(k_part_route, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
     SF_CHECK_LAUNCH();
@@ -678,6 +678,8 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     return SFGPU_OK;
 }
 
+constexpr uint32_t kScoutReads = 1u << 19;      // the first sub-batch of a builder: enough reads to see which classes are hot
+
 // caller holds eq->mu
 static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads,
                          const uint64_t* d_weights = nullptr) {
@@ -699,8 +701,8 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     const bool adaptive = part && getenv("SFGPU_EQ_SUBBATCH") == nullptr;
     // the very first sub-batch of a builder is small: it shows which classes are hot (eq_partitioned) at the price of one launch
     const uint32_t usual_step = step;
-    bool scout = adaptive && eq->reads_seen == 0 && n_reads > (1u << 22) && step > (1u << 20);
-    if (scout) step = 1u << 20;
+    bool scout = adaptive && eq->reads_seen == 0 && n_reads > (1u << 22) && step > kScoutReads;
+    if (scout) step = kScoutReads;
     uint32_t ends[3];
     const uint64_t first_end = (n_reads < step) ? n_reads : step;
     SF_HIP(hipMemcpyAsync(&ends[0], d_offsets, 4, hipMemcpyDeviceToHost, st));

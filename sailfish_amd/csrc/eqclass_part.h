@@ -77,9 +77,9 @@ struct RouteArgs {
     unsigned long long* n_long; uint32_t* long_list;     // reads for the generic kernel
     // HOT classes (k_hot_select): labels that already hold so many reads that they would overflow their region's bins.  A read
     // with such a label is counted in LDS and never enters the stream; the counts go to the table when the block ends.
-    const unsigned long long* hot_h;               // kHotSlots bucket hashes (0 = empty), indexed by hot_index(h)
-    const uint2* hot_meta;                         // (arena granule of the label, table slot)
-    const unsigned int* n_hot;                     // number of hot classes (0: the block skips all of this)
+    const unsigned long long* hot;                 // one block: kHotSlots bucket hashes (0 = empty; indexed by hot_index(h) + short
+                                                   // probing), kHotSlots x (arena granule of the label, table slot), the number of
+                                                   // hot classes (0: the block skips all of this)
     const uint32_t* arena; uint64_t* table;
     unsigned long long* n_hot_reads;               // statistics: reads counted here
 };
@@ -130,8 +130,8 @@ k_part_route(RouteArgs a) {
     // hot classes: their bucket hashes and a counter each, behind the staging buffers
     unsigned long long* hot_hl = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint4*>(cut + NR) + kPartWaves * (kStageWords / 4 + 4));
     unsigned int* hot_cnt = reinterpret_cast<unsigned int*>(hot_hl + kHotSlots);
-    const bool have_hot = *a.n_hot != 0u;                                            // (uniform)
-    if (have_hot) for (uint32_t q = tid; q < kHotSlots; q += kPartBlock) { hot_hl[q] = a.hot_h[q]; hot_cnt[q] = 0u; }
+    const bool have_hot = *reinterpret_cast<const unsigned int*>(a.hot + 2 * kHotSlots) != 0u;      // (uniform)
+    if (have_hot) for (uint32_t q = tid; q < kHotSlots; q += kPartBlock) { hot_hl[q] = a.hot[q]; hot_cnt[q] = 0u; }
     const uint32_t t0 = blk * a.tile;
     const uint32_t t1 = (t0 + a.tile < a.n && t0 + a.tile > t0) ? t0 + a.tile : a.n;
     const uint32_t* __restrict__ off = a.off;
@@ -219,13 +219,14 @@ k_part_route(RouteArgs a) {
         // ---- runs: a read whose label is the previous read's (the lane below, same step) rides with it.  Reads that arrive
         //      clustered (a position-sorted file: 64 consecutive reads hold one or two labels) would otherwise pile into a few
         //      bins per block and overflow them (measured: 50 M sorted reads 22.8 ms against 2.6 ms shuffled).  The first read
-        //      of a run carries the run's length: one more granule [count, 0, 0, 0] behind its label, announced by bit 31 of H.
+        //      of a run carries the run's length: one more granule [count, bit 31, 0, 0] behind its label, announced by bit 31 of H.
         bool dup = false;
         {
-            const uint64_t hp = __shfl_up(h, 1, kWave);
+            // filter: 32 bits of the bucket hash and the length (the labels themselves decide); `generic` is a property of the
+            // label here (too long, bit 31), so the previous read's need not be looked at
+            const uint32_t hp = __shfl_up((uint32_t)(h >> 32), 1, kWave);
             const uint32_t lp = __shfl_up(len, 1, kWave), bp = __shfl_up(b, 1, kWave);
-            const bool genp = __shfl_up((int)generic, 1, kWave) != 0;
-            if (lane != 0u && len != 0u && !generic && !genp && staged && h == hp && len == lp) {
+            if (lane != 0u && len != 0u && !generic && staged && (uint32_t)(h >> 32) == hp && len == lp) {
                 const uint32_t* prev_s = stage + mis + (bp - w_lo);
                 dup = true;
                 for (uint32_t q = 0; dup && q < len; ++q) dup = lab_s[q] == prev_s[q];
@@ -242,7 +243,7 @@ k_part_route(RouteArgs a) {
             if (hv == h) {
                 // same bucket hash: the label itself decides (arena entry [n, id0, id1, id2][id3 .. id6] ...; a label in
                 // granule form is the same from the second granule on)
-                const uint4* e = reinterpret_cast<const uint4*>(a.arena) + a.hot_meta[hi].x;
+                const uint4* e = reinterpret_cast<const uint4*>(a.arena) + reinterpret_cast<const uint2*>(a.hot + kHotSlots)[hi].x;
                 const uint4 e0 = e[0];
                 bool same = e0.x == len && e0.y == w[0] && e0.z == w[1] && e0.w == w[2];
                 if (same && len > 3u) { const uint4 e1 = e[1]; same = e1.x == w[3] && e1.y == w[4] && e1.z == w[5] && e1.w == w[6]; }
@@ -263,7 +264,7 @@ k_part_route(RouteArgs a) {
             if (at + ngx <= cap) {
                 uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
                 dst[0] = make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]);
-                if (mult > 1u) dst[ng] = make_uint4(mult, 0u, 0u, 0u);
+                if (mult > 1u) dst[ng] = make_uint4(mult, kCountedBit, 0u, 0u);      // (bit 31 of .y: no id has it -- such labels take the generic kernel)
                 if (len > 3u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
                 for (uint32_t g = 2; g < ng; ++g) {
                     const uint32_t q = 4u * g - 1u;
@@ -305,7 +306,7 @@ k_part_route(RouteArgs a) {
     if (have_hot) {
         static_assert(kHotSlots == kPartBlock, "one hot slot per thread");
         const unsigned int c = hot_cnt[tid];
-        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2ull * a.hot_meta[tid].y + 1]), (unsigned long long)c);
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2ull * reinterpret_cast<const uint2*>(a.hot + kHotSlots)[tid].y + 1]), (unsigned long long)c);
         unsigned int tot = c;
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
         if (lane == 0 && tot) atomicAdd(a.n_hot_reads, (unsigned long long)tot);
@@ -429,7 +430,8 @@ k_part_insert(PartArgs a) {
         const uint32_t key = (((H >> kRegionBits) & 0xFFFu) << 20) | (len << 13);
         const uint32_t here = base + pos + lane;             // where this lane's granule sits in the bins (granule index)
         uint32_t s = H & (kRegionSlots - 1), probes = 0, c_idx = 0, c_rep = 0;
-        const uint32_t mult = (is_head && multi) ? tile[lane + ng].x : 1u;       // reads this label stands for
+        uint32_t mult = 1u;                                                       // reads this label stands for
+        if (__ballot(is_head && multi)) { if (is_head && multi) mult = tile[lane + ng].x; }   // (no run in most steps: a uniform branch)
         auto defer = [&]() { const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull); a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len | (multi << 31); };
         // -> true if the label is left with a candidate to verify (only when !serial: the serial form compares the further
         //    granules itself, one dependent load after the other -- the rare path after a failed verification)
@@ -488,9 +490,8 @@ k_part_insert(PartArgs a) {
             const int hl = below ? 63 - (int)__builtin_clzll(below) : 0;     // the lane of this granule's head (lane 0 starts a label)
             const uint32_t rep_h = __shfl(c_rep, hl, kWave);
             const bool pend_h = __shfl((int)pending, hl, kWave) != 0;
-            const uint32_t ng_h = __shfl(ng, hl, kWave);                     // (a run's count granule sits behind the label: not compared)
             bool bad = false;
-            if (pend_h && !is_head && lane < cnt && lane - (uint32_t)hl < ng_h) {
+            if (pend_h && !is_head && lane < cnt && !(g.y & kCountedBit)) {  // (a run's count granule sits behind its label: not compared)
                 const uint4* r = (rep_h & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (rep_h & ~kArenaBit) : a.bins + rep_h;
                 const uint4 ej = r[lane - (uint32_t)hl];
                 bad = ej.x != g.x || ej.y != g.y || ej.z != g.z || ej.w != g.w;
