@@ -333,6 +333,39 @@ def main():
         out["value_host_pinned"] = host_leg.get("value")
         out["host_pinned"] = host_leg
 
+    # ---- N > 1 only, outside the timed region: what the EM-mode decision rests on, measured on THIS node (the sharded
+    # EM pays one all-reduce of M doubles per iteration; `auto` keeps the EM replicated while that costs more than a whole sweep)
+    if dist:
+        mg = {"em_mode_of_the_timed_steps": info["em_mode"]}
+        try:
+            buf = torch.zeros(M, dtype=torch.float64, device=dev)
+            for _ in range(10):
+                dist.all_reduce(buf)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            mg["allreduce_f64_M_us"] = (time.perf_counter() - t1) / 100 * 1e6
+            mg["allreduce_bytes"] = M * 8
+            mg["sweep_us_whole_problem"] = sweep_ms * 1e3
+            other = "sharded" if info["em_mode"] == "replicated" else "replicated"
+            q2 = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=other)
+            q2.run(ids, off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))
+            barrier()
+            t1 = time.perf_counter()
+            i2 = q2.run(ids, off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))
+            barrier()
+            t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            mg["other_em_mode"] = {"em_mode": i2["em_mode"], "ms_per_step": float(t2.item()) * 1e3, "em_ms": i2["t_em_ms"],
+                                   "em_iters": i2["em_stats"]["iters"], "same_classes": bool(i2["n_classes"] == info["n_classes"])}
+            mg["em_ms_of_the_timed_steps"] = em_ms
+            del q2
+        except Exception as e:                    # never take the headline line down
+            mg["error"] = repr(e)
+        out["multi_gpu"] = mg
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(ref_len_np, ids, off, a.cpu_seconds, use_vbem)
         # CPU seconds for the full step = build at the sampled rate + EM iterations at the sampled
