@@ -11,7 +11,7 @@ n_ok = 0
 while time.time() < t_end:
     M = int(rng.choice([50, 5000, 200_000, 3_000_000]))
     P = int(rng.choice([10, 1000, 100_000, 1_500_000]))
-    R = int(rng.choice([70_000, 300_000, 1_200_000, 3_000_000]))
+    R = int(rng.choice([70_000, 300_000, 1_200_000, 3_000_000, 5_000_000]))
     kind = rng.integers(0, 3)
     # label pool with a random length law
     if kind == 0: lens = rng.geometric(0.3, P)
@@ -21,6 +21,22 @@ while time.time() < t_end:
     poff = np.zeros(P + 1, np.int64); poff[1:] = np.cumsum(lens)
     pids = rng.integers(0, M, poff[-1]).astype(np.uint32)
     pick = np.minimum(rng.integers(0, P, R), rng.integers(0, P, R)) if rng.random() < 0.5 else rng.integers(0, P, R)
+    # the order / skew of the stream (round 2: hot classes counted in the route pass, runs folded into one label with a count)
+    shape = int(rng.integers(0, 6))
+    if shape == 1:                                                 # a few hot labels hold a large part of the reads
+        n_hot = int(rng.choice([1, 3, 40, 700, 3000])); frac = float(rng.choice([0.05, 0.3, 0.8]))
+        hot = rng.integers(0, P, n_hot)
+        m = rng.random(R) < frac
+        pick[m] = hot[rng.integers(0, n_hot, int(m.sum()))]
+    elif shape == 2:                                               # fully sorted by label
+        pick.sort()
+    elif shape == 3:                                               # runs of random length (1 .. 400)
+        runs = rng.geometric(float(rng.choice([0.5, 0.05, 0.008])), R); runs = np.minimum(runs, 400)
+        pick = np.repeat(pick[:R], runs)[:R]
+    elif shape == 4:                                               # sorted chunks + hot labels
+        c = int(rng.choice([1000, 64, 100_000]))
+        for a0 in range(0, R, c): pick[a0:a0 + c].sort()
+        m = rng.random(R) < 0.2; pick[m] = pick[0]
     rl = lens[pick].copy()
     rl[rng.random(R) < 0.01] = 0                                  # empty reads
     off = np.zeros(R + 1, np.int64); off[1:] = np.cumsum(rl)
@@ -45,7 +61,7 @@ while time.time() < t_end:
     rp, ii, cc, hh = eq.eqVec().to_numpy()
     ok = (eq.n_classes == ob.n_classes and np.array_equal(rp, orp.astype(np.uint32)) and np.array_equal(ii, oi)
           and np.array_equal(cc, oc) and np.array_equal(hh, oh))
-    print(f"M={M} P={P} R={R} kind={kind} sb={sb} host={host} cuts={len(cuts)-1}: classes {eq.n_classes} {'ok' if ok else 'MISMATCH'} {eq.stats()}", flush=True)
+    print(f"M={M} P={P} R={R} kind={kind} shape={shape} sb={sb} host={host} cuts={len(cuts)-1}: classes {eq.n_classes} {'ok' if ok else 'MISMATCH'} {eq.stats()}", flush=True)
     if not ok: sys.exit(1)
     n_ok += 1
 print("all ok:", n_ok)
