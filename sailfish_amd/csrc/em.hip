@@ -472,6 +472,9 @@ k_sweep_lds(SweepArgs a) {
     {
 #pragma unroll
         for (int c = 0; c < kRegChunks; ++c) {
+            // (a lane past the end of the tile holds eight null words: it stays out -- hundreds of lanes adding zeros to the ONE
+            //  null class serialise in the LDS atomic unit: cfg2's 5 300-nonzero tiles went from 8.5 to 16.5 us before this test)
+            if (g0 + (uint32_t)c * kSweepBlock * kPerLane >= n8) break;
             uint32_t cur = kTileNnz; double run = 0.0;
             den_words(w[c], N8{}, xv[c], cur, run);
             atomicAdd(&den[cur], run);
@@ -505,6 +508,7 @@ k_sweep_lds(SweepArgs a) {
     {
 #pragma unroll
         for (int c = 0; c < kRegChunks; ++c) {
+            if (g0 + (uint32_t)c * kSweepBlock * kPerLane >= n8) break;
             uint32_t cur = kTileNnz; double f = 0.0;
             acc_words(w[c], N8{}, xv[c], cur, f);
         }
