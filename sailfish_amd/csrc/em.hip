@@ -225,12 +225,13 @@ __global__ void k_vb_prepare(uint64_t M, const double* __restrict__ alpha, doubl
 //   D  publish the window with plain coalesced stores; the update folds the windows per transcript
 // HBM sees 4 bytes per nonzero + 8 per class per iteration and the common path has no global atomic.
 #ifndef SFGPU_TILE_NNZ
-#define SFGPU_TILE_NNZ 8000
+#define SFGPU_TILE_NNZ 7800
 #endif
 constexpr int kTileNnzMax = 1 << 17;         // nonzeros a tile may hold when its class count allows (see the plan in sfgpu_em_create)
 constexpr int kTileNnz = SFGPU_TILE_NNZ;     // largest CSR bucket that defines a tile (<= 8191 classes per tile);
                                              // the bucket actually used is sized per problem so that the tiles fill
                                              // the chip in whole rounds (tile_nnz_for)
+constexpr int kEscSlots = 128;              // LDS accumulator for escaped members (per tile)
 constexpr int kWin = 1024;                   // LDS window (transcripts): 2 x 8 KB
 #ifndef SFGPU_SWEEP_BLOCK
 #define SFGPU_SWEEP_BLOCK 1024
@@ -254,6 +255,7 @@ constexpr uint32_t kNullBit = 0x80000000u, kSingle = 0x20000000u;
 constexpr uint32_t kNull = kNullBit | ((uint32_t)kTileNnz << 16) | (uint32_t)kWin;
 static_assert(kTileNnz < (1 << 13) && kWin < (1 << 16), "stream word: 13-bit class, 16-bit window slot");
 static_assert(kTileNnz <= 8191, "class index field is 13 bits");
+static_assert(kEscSlots == 128, "the escape accumulator's hash takes 7 bits");
 
 // tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*tile_nnz, (i+1)*tile_nnz)
 __global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, uint32_t tile_nnz, const uint32_t* __restrict__ rowptr,
@@ -390,6 +392,12 @@ k_sweep_lds(SweepArgs a) {
     __shared__ double xs[kWin + 1];                        // (+ the slot of the null words: x = 0)
     __shared__ double acc[kWin + 1];
     __shared__ double den[kTileNnz + 1];                   // denominators, then count/denom, per class of the tile (+ the null class)
+    // escaped members: a small accumulator keyed by transcript -- a tile's escapes go to FEW far transcripts again and again (the
+    // pseudogene / paralog every read of this gene also hits), and thousands of f64 atomics on one alphaOut address serialise in
+    // the L2 (measured: 700 k escapes onto ~50 transcripts 162 us per sweep, 9 us without them).  kTileNnz is 7800, not 8000,
+    // to make room for it next to two resident blocks.
+    __shared__ unsigned int esc_key[kEscSlots];            // transcript + 1 (0 = free)
+    __shared__ double esc_val[kEscSlots];
     const double* __restrict__ x = a.x;
     if (nc == 0) return;
     const uint4* __restrict__ words = reinterpret_cast<const uint4*>(a.stream + s0);
@@ -466,6 +474,7 @@ k_sweep_lds(SweepArgs a) {
     for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
     if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
+    if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
     __syncthreads();
 
     // ---- A: denominators
@@ -517,13 +526,24 @@ k_sweep_lds(SweepArgs a) {
             uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
             double f = den[(tag >> 16) & 0x1FFFu];
             double contrib = (tag & kSingle) ? f : x[t] * f;
-            if (contrib != 0.0) { atomicAdd(&a.alpha_out[t], contrib); esc_sum += contrib; }
+            if (contrib != 0.0) {
+                esc_sum += contrib;
+                uint32_t q = (t * 2654435761u) >> (32 - 7);                      // kEscSlots = 2^7
+                bool placed = false;
+                for (int pr = 0; pr < 4 && !placed; ++pr, q = (q + 1) & (kEscSlots - 1)) {
+                    unsigned int k = esc_key[q];
+                    if (k == 0u) k = atomicCAS(&esc_key[q], 0u, t + 1u);
+                    if (k == 0u || k == t + 1u) { atomicAdd(&esc_val[q], contrib); placed = true; }
+                }
+                if (!placed) atomicAdd(&a.alpha_out[t], contrib);               // accumulator full around q: straight to memory
+            }
         }
     }
     __syncthreads();
     // ---- D: publish the window into the transcript-major partial array (plain stores): the update
     //         then folds each transcript's entries with contiguous, coalesced loads
     double mine = esc_sum;
+    if (threadIdx.x < kEscSlots && esc_key[threadIdx.x]) atomicAdd(&a.alpha_out[esc_key[threadIdx.x] - 1u], esc_val[threadIdx.x]);
     for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { const double v = acc[i]; a.partial[a.pub_pos[off + i]] = v; mine += v; }
     if (VB && a.tsum) {
         // everything this tile added to alphaOut, in a fixed order: the update derives sum(alpha) -- the

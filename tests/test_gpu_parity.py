@@ -430,6 +430,50 @@ def test_em_fixed_iterations(sf, gpu, midsize, vb, n_iter):
 
 
 @pytest.mark.parametrize("vb", [False, True])
+def test_em_far_members_shared_by_a_neighbourhood(sf, gpu, vb):
+    """members far from their class's window ("escapes": a pseudogene / paralog that every read of a gene also hits).  A tile
+    adds them up in a small LDS accumulator keyed by transcript and hands each far transcript ONE sum; more distinct far
+    transcripts than the accumulator holds go straight to alphaOut.  Classes here: 2..5 local members + (a) one far transcript
+    shared by ~1000 neighbouring classes, (b) one of ~600 far transcripts per neighbourhood (more than the 128 slots),
+    (c) far singletons; against the oracle after 1, 2 and 40 iterations."""
+    rng = np.random.default_rng(31)
+    M, C = 60_000, 120_000
+    first = np.sort(rng.integers(0, 40_000, C))
+    labels, counts = [], []
+    for c in range(C):
+        k = int(rng.integers(1, 5))
+        loc = first[c] + np.sort(rng.choice(200, k, replace=False))
+        kind = c % 4
+        if kind == 0: far = [M - 1 - first[c] // 1000]                                  # (a) shared by the neighbourhood
+        elif kind == 1: far = [45_000 + (first[c] // 1000) * 7 + int(rng.integers(0, 600))]  # (b) many distinct far targets per tile
+        elif kind == 2: far = []
+        else: far = [50_000 + int(rng.integers(0, 9_000)), 59_500 + int(rng.integers(0, 400))]
+        lab = np.unique(np.concatenate([loc, far]).astype(np.uint32))
+        labels.append(lab); counts.append(int(rng.integers(1, 50)))
+    # far singletons: a class that is ONE far transcript only, in the middle of the sorted class list, cannot exist (a class is
+    # sorted by its first id) -- but a singleton class can be the escape target of others; add a few plain singletons
+    for t in (M - 1, M - 2, 45_003):
+        labels.append(np.array([t], np.uint32)); counts.append(1000)
+    key = sorted(range(len(labels)), key=lambda i: (int(labels[i][0]), len(labels[i]), labels[i].tobytes()))
+    seen, L2, C2 = set(), [], []
+    for i in key:                                               # distinct labels only (a class table has each label once)
+        b = labels[i].tobytes()
+        if b in seen: continue
+        seen.add(b); L2.append(labels[i]); C2.append(counts[i])
+    rp = np.zeros(len(L2) + 1, np.uint64); rp[1:] = np.cumsum([len(l) for l in L2])
+    ii = np.concatenate(L2).astype(np.uint32); cc = np.asarray(C2, np.uint64)
+    R = int(cc.sum())
+    eff = np.maximum(rng.lognormal(7.0, 0.7, M), 50.0)
+    p = _gpu_em(sf, gpu, eff, rp, ii, cc, R)
+    for n_iter in (1, 2, 40):
+        rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, R, use_vbem=vb, tol=0.0, min_iter=0, max_iter=n_iter)
+        grc, st = p.optimize(use_vbem=vb, tol=0.0, min_iter=0, max_iter=n_iter, iters_per_launch=5)
+        assert rc == 0 and grc == 0 and st["iters"] == ost["iters"] == n_iter
+        assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+        assert abs(st["alpha_sum"] - ost["alpha_sum"]) <= 1e-9 * ost["alpha_sum"]
+
+
+@pytest.mark.parametrize("vb", [False, True])
 def test_em_to_convergence_matches_stop_iteration(sf, gpu, midsize, vb):
     m = midsize
     rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"], use_vbem=vb)
