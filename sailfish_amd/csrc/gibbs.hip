@@ -37,6 +37,7 @@
 #include "rng.h"
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 namespace sfgpu {
@@ -45,6 +46,8 @@ constexpr int kGibbsBlock = 64;            // one wavefront of chains per block
 constexpr int kGibbsTile = 64;             // classes per tile
 constexpr uint32_t kWideSpan = 2048;       // classes spanning more transcripts than this are "wide"
 constexpr uint32_t kMaxPhases = 1024;      // more phases than this: fall back to one sequential scan
+constexpr uint32_t kWideSerial = 64;       // up to this many wide classes are visited one after another by one launch
+constexpr uint32_t kMaxColours = 1u << 16; // more colours than this: visit the wide classes one after another after all
 constexpr double kGibbsPrior = 1e-8;       // priorAlpha (:215)
 constexpr double kGibbsTiny = 4.9406564584124654e-324;
 
@@ -159,6 +162,21 @@ k_gibbs_wide(GibbsArgs a) {
     }
 }
 
+// one COLOUR of the wide classes (no two classes of a colour share a transcript): blockIdx.x -> kListChunk classes of the
+// list, blockIdx.y -> group of 64 chains
+constexpr uint32_t kListChunk = 8;
+template <bool INIT>
+__global__ void __launch_bounds__(kGibbsBlock)
+k_gibbs_list(GibbsArgs a, const uint32_t* __restrict__ list, uint32_t n) {
+    const uint32_t ch = blockIdx.y * kGibbsBlock + threadIdx.x;
+    if (ch >= a.n_chains) return;
+    const uint32_t i0 = blockIdx.x * kListChunk, i1 = (i0 + kListChunk < n) ? i0 + kListChunk : n;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint64_t c = list[i];
+        if (INIT) gibbs_init_class(a, c, ch); else gibbs_round_class(a, c, ch);
+    }
+}
+
 // plan: per class wide flag; per tile the band [lo, hi] of its non-wide classes
 __global__ void k_gibbs_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
                              uint8_t* wide, uint32_t* tile_lo, uint32_t* tile_hi, uint32_t* wide_list, unsigned int* n_wide) {
@@ -221,6 +239,62 @@ static uint32_t gibbs_phase_count(const std::vector<uint32_t>& lo, const std::ve
     return K;
 }
 
+// First-fit colouring of the wide classes, in class order: colour(c) = the smallest colour that no earlier class sharing a
+// transcript with c has.  Classes of one colour share no transcript, so a colour is one launch of independent blocks, and
+// two classes that do share one are in different launches: visiting the colours in order is a sequential scan of the wide
+// classes in SOME order -- all a systematic scan needs (the reference's own order is its hash table's).
+// Per transcript: a 64-bit mask of the colours 0..63 its classes hold, overflow
+// words for the colours beyond (allocated for the few transcripts that need them), and the lowest colour that may still be
+// free -- a transcript shared by thousands of classes hands out its colours in O(1) each.
+struct ColourState {
+    std::vector<uint64_t> small;                 // colours 0..63 per transcript
+    std::vector<uint32_t> hint;                  // all colours < hint[t] are taken at t
+    std::vector<int32_t> ovf_at;                 // index into ovf, or -1
+    std::vector<std::vector<uint64_t>> ovf;      // colours 64.. per transcript that needs them
+    explicit ColourState(uint64_t M) : small(M, 0), hint(M, 0), ovf_at(M, -1) {}
+    uint64_t word(uint32_t t, uint32_t w) const {
+        if (w == 0) return small[t];
+        const int32_t o = ovf_at[t];
+        if (o < 0 || w - 1 >= ovf[(size_t)o].size()) return 0;
+        return ovf[(size_t)o][w - 1];
+    }
+    void set(uint32_t t, uint32_t colour) {
+        const uint32_t w = colour >> 6; const uint64_t bit = 1ull << (colour & 63);
+        if (w == 0) small[t] |= bit;
+        else {
+            if (ovf_at[t] < 0) { ovf_at[t] = (int32_t)ovf.size(); ovf.emplace_back(); }
+            auto& v = ovf[(size_t)ovf_at[t]];
+            if (v.size() < w) v.resize(w, 0);
+            v[w - 1] |= bit;
+        }
+        uint32_t h = hint[t];
+        while ((word(t, h >> 6) >> (h & 63)) & 1ull) ++h;
+        hint[t] = h;
+    }
+};
+static uint32_t colour_wide_classes(const std::vector<uint32_t>& wl, const std::vector<uint32_t>& rowptr, const std::vector<uint32_t>& ids,
+                                    uint64_t M, std::vector<uint32_t>& colour_of) {
+    ColourState cs(M);
+    colour_of.resize(wl.size());
+    uint32_t n_colours = 0;
+    for (size_t i = 0; i < wl.size(); ++i) {
+        const uint32_t b = rowptr[wl[i]], e = rowptr[wl[i] + 1];
+        uint32_t start = 0;
+        for (uint32_t j = b; j < e; ++j) start = std::max(start, cs.hint[ids[j]]);
+        uint32_t colour = start;
+        for (uint32_t w = start >> 6;; ++w) {
+            uint64_t used = 0;
+            for (uint32_t j = b; j < e; ++j) used |= cs.word(ids[j], w);
+            if (w == (start >> 6)) used |= (1ull << (start & 63)) - 1ull;          // colours below `start` are taken somewhere
+            if (~used) { colour = (w << 6) + (uint32_t)__builtin_ctzll(~used); break; }
+        }
+        colour_of[i] = colour;
+        for (uint32_t j = b; j < e; ++j) cs.set(ids[j], colour);
+        if (colour + 1 > n_colours) n_colours = colour + 1;
+    }
+    return n_colours;
+}
+
 extern "C" {
 
 int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t n_samples, uint32_t n_chains,
@@ -256,6 +330,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     {
         // ---- plan: bands, wide classes, number of phases
         uint32_t K = 1; unsigned int n_wide = 0;
+        std::vector<uint32_t> colour_off;                  // wide classes by colour (empty: visited one after another)
         if (n_tiles) {
             hipLaunchKernelGGL(k_gibbs_plan, dim3((n_tiles + 255) / 256), dim3(256), 0, st, C, n_tiles, prob->d_rowptr, prob->d_ids,
                                wide, tile_lo, tile_hi, wide_list, d_nwide);
@@ -275,11 +350,29 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                 G_TRY(hipMemcpyAsync(wl.data(), wide_list, (size_t)n_wide * 4, hipMemcpyDeviceToHost, st));
                 G_TRY(hipStreamSynchronize(st));
                 std::sort(wl.begin(), wl.end());
+                if (n_wide > kWideSerial) {
+                    // many wide classes (every class of a gene also names a far pseudogene / paralog): one after another they
+                    // took 108 ms per round for 722 k of them (measured).  Colour them and visit a colour per launch.
+                    std::vector<uint32_t> h_rowptr(C + 1), h_ids(L), colour_of;
+                    G_TRY(hipMemcpyAsync(h_rowptr.data(), prob->d_rowptr, (C + 1) * 4, hipMemcpyDeviceToHost, st));
+                    G_TRY(hipMemcpyAsync(h_ids.data(), prob->d_ids, (size_t)L * 4, hipMemcpyDeviceToHost, st));
+                    G_TRY(hipStreamSynchronize(st));
+                    const uint32_t n_colours = colour_wide_classes(wl, h_rowptr, h_ids, M, colour_of);
+                    if (n_colours <= kMaxColours) {
+                        colour_off.assign(n_colours + 1, 0);
+                        for (uint32_t c : colour_of) ++colour_off[c + 1];
+                        for (uint32_t c = 0; c < n_colours; ++c) colour_off[c + 1] += colour_off[c];
+                        std::vector<uint32_t> by_colour(n_wide), cur(colour_off.begin(), colour_off.end() - 1);
+                        for (size_t i = 0; i < wl.size(); ++i) by_colour[cur[colour_of[i]]++] = wl[i];       // class order inside a colour
+                        wl.swap(by_colour);
+                    }
+                }
                 G_TRY(hipMemcpyAsync(wide_list, wl.data(), (size_t)n_wide * 4, hipMemcpyHostToDevice, st));
                 G_TRY(hipStreamSynchronize(st));
             }
         }
-        log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes", n_chains, n_tiles, K, n_wide);
+        log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes%s", n_chains, n_tiles, K, n_wide,
+                colour_off.empty() ? "" : (" in " + std::to_string(colour_off.size() - 1) + " colours").c_str());
         GibbsArgs a{n_chains, C, prob->d_rowptr, prob->d_ids, prob->d_counts, inv_len, w_mass, count_map, txp_count,
                     wide, wide_list, n_wide, seed, 0};
         const unsigned groups = (n_chains + kGibbsBlock - 1) / kGibbsBlock;
@@ -289,9 +382,16 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                 if (init) hipLaunchKernelGGL(k_gibbs_phase<true>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
                 else hipLaunchKernelGGL(k_gibbs_phase<false>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
             }
-            if (n_wide) {
+            if (n_wide && colour_off.empty()) {
                 if (init) hipLaunchKernelGGL(k_gibbs_wide<true>, dim3(groups), dim3(kGibbsBlock), 0, st, a);
                 else hipLaunchKernelGGL(k_gibbs_wide<false>, dim3(groups), dim3(kGibbsBlock), 0, st, a);
+            } else if (n_wide) {
+                for (size_t c = 0; c + 1 < colour_off.size(); ++c) {
+                    const uint32_t n = colour_off[c + 1] - colour_off[c];
+                    dim3 g((n + kListChunk - 1) / kListChunk, groups);
+                    if (init) hipLaunchKernelGGL(k_gibbs_list<true>, g, dim3(kGibbsBlock), 0, st, a, wide_list + colour_off[c], n);
+                    else hipLaunchKernelGGL(k_gibbs_list<false>, g, dim3(kGibbsBlock), 0, st, a, wide_list + colour_off[c], n);
+                }
             }
             return hipGetLastError();
         };

@@ -153,21 +153,33 @@ def test_cfg5_thousand_draws_over_cfg3_classes(gpu):
         p.close()
 
 
-def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu):
+@pytest.mark.parametrize("n_wide_labels", [3, 150])
+def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labels):
     """per-transcript mean and spread of the phase-parallel sampler vs the oracle's sequential sampleRound_
-    (src/CollapsedGibbsSampler.cpp:113-184) on a problem with thousands of classes, a multi-phase round and wide classes"""
+    (src/CollapsedGibbsSampler.cpp:113-184) on a problem with thousands of classes, a multi-phase round and wide classes.
+    3 wide labels: visited one after another by one launch; 150 wide labels in groups of 30 that share a far transcript (the
+    pseudogene every read of a gene also hits) and overlap otherwise: coloured on the host, one launch per colour."""
     import sailfish_amd as sf
     from sailfish_amd import _lib, synth
     M, P, R = 3000, 6000, 120_000
     ref_len, ids, off = synth.workload(M, P, R)
-    # a few labels spanning the whole transcript range ("wide" classes: visited one after another after the phases)
+    # labels spanning the whole transcript range ("wide" classes: visited after the phases)
     rng = np.random.default_rng(5)
-    wide = [np.sort(rng.choice(M, 6, replace=False)).astype(np.int32) for _ in range(3)]
-    extra_ids = np.concatenate([np.tile(w, 400) for w in wide])
-    extra_off = int(off[-1]) + 6 * np.arange(1, 1201)
+    if n_wide_labels == 3:
+        wide = [np.sort(rng.choice(M, 6, replace=False)).astype(np.int32) for _ in range(3)]
+        reps = 400
+    else:
+        wide = []
+        for i in range(n_wide_labels):
+            loc = rng.choice(400, 5, replace=False) + 13 * (i // 30)                 # neighbours overlap locally, too
+            wide.append(np.unique(np.concatenate([loc, [M - 1 - i // 30]])).astype(np.int32))
+        reps = 40
+    extra_ids = np.concatenate([np.tile(w, reps) for w in wide])
+    extra_len = np.concatenate([np.full(reps, len(w)) for w in wide])
+    extra_off = int(off[-1]) + np.cumsum(extra_len)
     ids = torch.cat([ids, torch.from_numpy(extra_ids)])
     off = torch.cat([off, torch.from_numpy(extra_off.astype(np.int32))])
-    R += 1200
+    R += reps * len(wide)
     eq = sf.EquivalenceClassBuilder(device=gpu); eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); eq.finish(); v = eq.eqVec()
     assert eq.total_reads == R and eq.n_classes > 2000
     eff = O.efflen_smoothed(ref_len.numpy().view(np.uint32), O.cf_gaussian())
@@ -186,6 +198,9 @@ def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu):
     plan = [m for m in logs if "gibbs:" in m][-1]
     K = int(plan.split(" tiles in ")[1].split()[0]); n_wide = int(plan.split(" phases, ")[1].split()[0])
     assert K >= 2 and n_wide >= 3, plan
+    assert ("colours" in plan) == (n_wide_labels > 64), plan
+    if n_wide_labels > 64:
+        assert int(plan.split(" in ")[-1].split()[0]) >= 30, plan      # a far transcript shared by 30 classes: >= 30 colours
     # Chains are sticky: with priorAlpha = 1e-8 a transcript whose count reaches 0 practically never gets a read back, so
     # chains settle into different supports and ONE sequential chain is not comparable with an average over chains.
     # Both samplers are therefore run as many independent chains from the same start (initCountMap_ from the EM's mass)
