@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-host-pinned", action="store_true", help="skip the leg that re-runs the step with the hit lists in pinned host memory")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--one-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--compare-em-modes", action="store_true",
+                    help="N > 1: after the timed steps also run one step in the OTHER EM mode (sharded <-> replicated) and report it")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -349,6 +351,8 @@ def main():
             mg["allreduce_f64_M_us"] = (time.perf_counter() - t1) / 100 * 1e6
             mg["allreduce_bytes"] = M * 8
             mg["sweep_us_whole_problem"] = sweep_ms * 1e3
+            if not a.compare_em_modes:
+                raise StopIteration
             other = "sharded" if info["em_mode"] == "replicated" else "replicated"
             q2 = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=other)
             q2.run(ids, off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))
@@ -362,6 +366,8 @@ def main():
                                    "em_iters": i2["em_stats"]["iters"], "same_classes": bool(i2["n_classes"] == info["n_classes"])}
             mg["em_ms_of_the_timed_steps"] = em_ms
             del q2
+        except StopIteration:
+            pass
         except Exception as e:                    # never take the headline line down
             mg["error"] = repr(e)
         out["multi_gpu"] = mg
