@@ -239,7 +239,7 @@ def main():
     # buffers (copy of chunk k + 1 on its own stream while chunk k is built), so the step costs its PCIe transfer plus
     # the build of the last chunk plus EM.  PCIe-inclusive: reported next to `value`, never as `value`.
     host_leg = None
-    if not a.no_host_pinned:
+    if not a.no_host_pinned and world == 1:       # (an N = 1 figure; at N > 1 a rank that failed here would leave the others in a collective)
         try:
             h_ids = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True); h_ids.copy_(ids)
             h_off = torch.empty(off.shape, dtype=off.dtype, pin_memory=True); h_off.copy_(off)
