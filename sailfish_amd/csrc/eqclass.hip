@@ -827,9 +827,9 @@ static int eq_dacc_append_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint
     }
     if (eq->dacc_n_reads + (uint64_t)n_reads > kDevAccReads || eq->dacc_n_ids + n_ids > kDevAccIds)
         if ((rc = eq_flush_dacc_locked(eq))) return rc;
-    if (!eq->dacc_ids.p) {
-        if ((rc = eq->dacc_ids.reserve(kDevAccIds + 8, st, false)) || (rc = eq->dacc_off.reserve((uint64_t)kDevAccReads + 2, st, false))) return rc;
-    }
+    // (the buffers grow with what is gathered, doubling: a 10 000-read job does not pin half a gigabyte)
+    if ((rc = eq->dacc_ids.reserve(std::max<uint64_t>(eq->dacc_n_ids + n_ids + 8, 1u << 20), st, true, eq->dacc_n_ids)) ||
+        (rc = eq->dacc_off.reserve(std::max<uint64_t>((uint64_t)eq->dacc_n_reads + n_reads + 2, 1u << 18), st, true, (uint64_t)eq->dacc_n_reads + 1))) return rc;
     if (n_ids) SF_HIP(hipMemcpyAsync(eq->dacc_ids.p + eq->dacc_n_ids, d_ids + ends[0], n_ids * 4, hipMemcpyDeviceToDevice, st));
     const uint32_t shift = (uint32_t)eq->dacc_n_ids - ends[0];
     hipLaunchKernelGGL(k_rebase_offsets, dim3((n_reads + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_offsets, n_reads, shift,
