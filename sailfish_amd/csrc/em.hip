@@ -138,11 +138,12 @@ __global__ void k_alpha_partials(uint64_t M, const double* __restrict__ alpha, d
 }
 
 // device-private copy of the counts: 31 bits of count, bit 31 = the class is a singleton
+// (cperm: the plan's own class order, see em_renumber -- class c of the plan is the caller's class cperm[c]; rowptr is the plan's)
 __global__ void k_narrow_counts(uint64_t C, const uint64_t* __restrict__ c64, const uint32_t* __restrict__ rowptr,
-                                uint32_t* __restrict__ c32, unsigned int* overflow) {
+                                uint32_t* __restrict__ c32, unsigned int* overflow, const uint32_t* __restrict__ cperm) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    uint64_t v = c64[c];
+    uint64_t v = c64[cperm ? cperm[c] : c];
     if (v >= 0x80000000ull) atomicOr(overflow, 1u);
     // a class without members never comes out of the builder (addGroup is only called with hits); the tile plan
     // bounds classes per tile through nonzeros, so an empty class in a caller-made CSR is refused, not planned
@@ -231,6 +232,8 @@ constexpr int kTileNnzMax = 1 << 17;         // nonzeros a tile may hold when it
 constexpr int kTileNnz = SFGPU_TILE_NNZ;     // largest CSR bucket that defines a tile (<= 8191 classes per tile);
                                              // the bucket actually used is sized per problem so that the tiles fill
                                              // the chip in whole rounds (tile_nnz_for)
+constexpr uint64_t kRenumberMinClasses = 4096;   // smaller problems are not worth a second plan
+constexpr int kRenumberHops = 5;           // class hops of the label propagation behind the plan's own transcript order (em_renumber)
 constexpr int kEscSlots = 128;              // LDS accumulator for escaped members (per tile)
 constexpr int kWin = 1024;                   // LDS window (transcripts): 2 x 8 KB
 #ifndef SFGPU_SWEEP_BLOCK
@@ -309,7 +312,8 @@ k_tile_window(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
 __global__ void __launch_bounds__(kEmBlock)
 k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
               const uint32_t* __restrict__ tile_lo, const uint64_t* __restrict__ tile_s0,
-              const uint64_t* __restrict__ tile_esc0, uint32_t* stream, uint32_t* esc_id, uint32_t* esc_cls) {
+              const uint64_t* __restrict__ tile_esc0, uint32_t* stream, uint32_t* esc_id, uint32_t* esc_cls,
+              const uint32_t* __restrict__ inv) {          // inv: `ids` are positions of the plan's transcript order; escapes name transcripts
     __shared__ unsigned int esc_cursor;
     if (threadIdx.x == 0) esc_cursor = 0;
     __syncthreads();
@@ -325,7 +329,7 @@ k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
             if (d < (uint32_t)kWin) w = tag | d;
             else {
                 unsigned int idx = atomicAdd(&esc_cursor, 1u);
-                esc_id[e0 + idx] = t; esc_cls[e0 + idx] = tag;      // tag = class index << 16 | single flag
+                esc_id[e0 + idx] = inv ? inv[t] : t; esc_cls[e0 + idx] = tag;      // tag = class index << 16 | single flag
                 w = kNull;
             }
             stream[s0 + (b - j0) + m] = w;
@@ -338,10 +342,10 @@ k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
 // per-transcript update walks to fold the tiles' partial sums in a fixed order
 __global__ void __launch_bounds__(kEmBlock)
 k_cover_pairs(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span,
-              const uint64_t* __restrict__ tile_off, uint64_t* keys, uint32_t* vals) {
+              const uint64_t* __restrict__ tile_off, uint64_t* keys, uint32_t* vals, const uint32_t* __restrict__ inv) {
     uint32_t lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
     uint64_t off = tile_off[blockIdx.x];
-    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) { keys[off + d] = (uint64_t)lo + d; vals[off + d] = (uint32_t)(off + d); }
+    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) { keys[off + d] = inv ? (uint64_t)inv[lo + d] : (uint64_t)lo + d; vals[off + d] = (uint32_t)(off + d); }
 }
 
 // cov_pos[k] = window slot that sorts to position k  ->  pub_pos[slot] = k
@@ -358,6 +362,57 @@ __global__ void k_cover_ptr(uint64_t M, uint64_t P, const uint64_t* __restrict__
     cov_ptr[t] = (uint32_t)lo;
 }
 
+// ---- transcripts renumbered by co-occurrence (em_renumber) -------------------------------------------------------------------
+// The window form wants a class's members within kWin transcript ids of each other.  A transcriptome whose isoforms are not
+// adjacent in the index (accession order, a shuffled FASTA) makes every member but the first an escape -- correct, ~10x
+// slower.  When a first plan finds many escapes, the PLAN (not the caller's vectors) gets a transcript order of its own:
+// key_t = the smallest transcript id reachable from t over a few class hops (label propagation), transcripts sorted by
+// (key, id) -- a gene family becomes one contiguous run -- and classes sorted by their smallest new position.  The sweep
+// stages its window through `inv` (position -> transcript); x, alpha and everything the caller sees keep the caller's order.
+__global__ void k_renum_iota(uint64_t n, uint32_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+__global__ void k_lp_min(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, uint32_t* key) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const uint32_t b = rowptr[c], e = rowptr[c + 1];
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t j = b; j < e; ++j) { const uint32_t k = key[ids[j]]; m = k < m ? k : m; }
+    for (uint32_t j = b; j < e; ++j) atomicMin(&key[ids[j]], m);
+}
+__global__ void k_renum_pair_keys(uint64_t n, const uint32_t* __restrict__ hi, uint64_t* keys, uint32_t* vals) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = ((uint64_t)hi[i] << 32) | (uint64_t)i; vals[i] = (uint32_t)i; }
+}
+__global__ void k_class_min_pos(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                                const uint32_t* __restrict__ perm, uint32_t* ckey) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t j = rowptr[c]; j < rowptr[c + 1]; ++j) { const uint32_t v = perm[ids[j]]; m = v < m ? v : m; }
+    ckey[c] = m;
+}
+__global__ void k_renum_lens(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ cperm, uint32_t* lens) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) lens[c] = rowptr[cperm[c] + 1] - rowptr[cperm[c]]; else if (c == C) lens[c] = 0;
+}
+__global__ void k_renum_csr(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                           const uint32_t* __restrict__ cperm, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ off64,
+                           uint32_t* rowptr2, uint32_t* vids) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > C) return;
+    rowptr2[c] = (uint32_t)off64[c];
+    if (c == C) return;
+    const uint32_t src = rowptr[cperm[c]], k = rowptr[cperm[c] + 1] - src;
+    uint32_t* dst = vids + off64[c];
+    for (uint32_t m = 0; m < k; ++m) dst[m] = perm[ids[src + m]];
+}
+__global__ void k_renum_scatter(uint64_t n, const uint32_t* __restrict__ src, const uint32_t* __restrict__ where, uint32_t* dst) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[where[i]] = src[i];
+}
+
 struct SweepArgs {
     const uint32_t* rowptr; const uint32_t* counts;                      // caller CSR (class sizes, counts)
     const uint32_t* stream; const uint32_t* esc_id; const uint32_t* esc_cls;
@@ -367,6 +422,7 @@ struct SweepArgs {
     const double* x; double* alpha_out; double* partial;
     EmState* st; uint32_t min_iter, max_iter;
     double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
+    const uint32_t* inv;                                                 // window position -> transcript (null: the caller's order)
 };
 
 template <bool VB>
@@ -471,7 +527,8 @@ k_sweep_lds(SweepArgs a) {
         if (g < n8) { w0 = words[g / 4]; w1 = words[g / 4 + 1]; }
         w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
     }
-    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
+    if (a.inv) for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[a.inv[(uint64_t)lo + i]]; acc[i] = 0.0; }
+    else for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
     if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
     if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
@@ -693,6 +750,7 @@ struct sfgpu_em {
     double *alpha = nullptr, *alpha_out = nullptr, *x = nullptr, *lenc = nullptr;
     double *partials = nullptr, *sum_partials = nullptr, *scratch = nullptr;
     uint32_t* counts32 = nullptr;
+    uint32_t* inv = nullptr; uint32_t* cperm = nullptr;      // the plan's own transcript / class order (em_renumber), or null
     uint32_t* tile_lo = nullptr; uint32_t* tile_c0 = nullptr; uint32_t* tile_span = nullptr; uint32_t n_tiles = 0;
     uint64_t* tile_off = nullptr; uint64_t P = 0;          // window slots over all tiles
     double* partial = nullptr;                              // [P] per-tile window sums of one sweep
@@ -725,7 +783,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
-                    em->blkmax, em->tsum};
+                    em->blkmax, em->tsum, em->inv, em->cperm};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -770,7 +828,7 @@ static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     if (p.C == 0) return SFGPU_OK;
     SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr};
+                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr, em->inv};
     void* args[] = {&a};
     const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true>)
                                       : reinterpret_cast<const void*>(&k_sweep_lds<false>);
@@ -837,6 +895,61 @@ static void em_stats_from_state(sfgpu_em* em, sfgpu_em_stats* s) {
 
 extern "C" {
 
+// Build the plan's own transcript and class order (see the kernels above): em->inv, em->cperm, the class table in that order
+// (rowptr2 / vids: members as POSITIONS; freed by the caller once the stream is written) and counts32 in the new class order.
+static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint32_t** rowptr2_out, uint32_t** vids_out) {
+    const uint64_t M = prob->M, C = prob->C;
+    hipStream_t st = em->cur;
+    uint32_t *key = nullptr, *perm = nullptr, *inv = nullptr, *ckey = nullptr, *cperm = nullptr, *lens = nullptr, *vals = nullptr;
+    uint32_t *rowptr2 = nullptr, *vids = nullptr;
+    uint64_t *k_in = nullptr, *k_out = nullptr, *off64 = nullptr;
+    int rc = SFGPU_OK;
+    const uint64_t N = std::max(M, C) + 1;
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        for (void* q : {(void*)key, (void*)perm, (void*)inv, (void*)ckey, (void*)cperm, (void*)lens, (void*)vals, (void*)rowptr2, (void*)vids,
+                        (void*)k_in, (void*)k_out, (void*)off64}) if (q) pool_free(q);
+        return code;
+    };
+#define RN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return fail(SFGPU_ERR_HIP); } } while (0)
+    RN_TRY(pool_malloc(&key, M * 4)); RN_TRY(pool_malloc(&perm, M * 4)); RN_TRY(pool_malloc(&inv, M * 4));
+    RN_TRY(pool_malloc(&ckey, (C ? C : 1) * 4)); RN_TRY(pool_malloc(&cperm, (C ? C : 1) * 4)); RN_TRY(pool_malloc(&lens, (C + 1) * 4));
+    RN_TRY(pool_malloc(&vals, N * 4)); RN_TRY(pool_malloc(&k_in, N * 8)); RN_TRY(pool_malloc(&k_out, N * 8)); RN_TRY(pool_malloc(&off64, (C + 2) * 8));
+    RN_TRY(pool_malloc(&rowptr2, (C + 1) * 4)); RN_TRY(pool_malloc(&vids, ((uint64_t)L + 1) * 4));
+    // key_t = smallest transcript id within a few class hops of t
+    hipLaunchKernelGGL(k_renum_iota, dim3(blocks_for(M)), dim3(kEmBlock), 0, st, M, key);
+    int hops = kRenumberHops;
+    if (const char* e = getenv("SFGPU_EM_RENUMBER_HOPS")) { int v = atoi(e); if (v >= 1 && v <= 64) hops = v; }      // tuning
+    for (int hop = 0; hop < hops; ++hop)
+        hipLaunchKernelGGL(k_lp_min, dim3(blocks_for(C)), dim3(kEmBlock), 0, st, C, prob->d_rowptr, prob->d_ids, key);
+    // transcripts by (key, id): inv[position] = transcript, perm[transcript] = position
+    hipLaunchKernelGGL(k_renum_pair_keys, dim3(blocks_for(M)), dim3(kEmBlock), 0, st, M, key, k_in, vals);
+    RN_TRY(hipGetLastError());
+    if ((rc = sort_pairs_u64_u32(k_in, k_out, vals, inv, M, st, 64, false))) return fail(rc);
+    hipLaunchKernelGGL(k_invert_perm, dim3(blocks_for(M)), dim3(kEmBlock), 0, st, M, inv, perm);
+    // classes by their smallest position
+    hipLaunchKernelGGL(k_class_min_pos, dim3(blocks_for(C)), dim3(kEmBlock), 0, st, C, prob->d_rowptr, prob->d_ids, perm, ckey);
+    hipLaunchKernelGGL(k_renum_pair_keys, dim3(blocks_for(C)), dim3(kEmBlock), 0, st, C, ckey, k_in, vals);
+    RN_TRY(hipGetLastError());
+    if ((rc = sort_pairs_u64_u32(k_in, k_out, vals, cperm, C, st, 64, false))) return fail(rc);
+    hipLaunchKernelGGL(k_renum_lens, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, st, C, prob->d_rowptr, cperm, lens);
+    RN_TRY(hipGetLastError());
+    if ((rc = exclusive_scan_u32(lens, off64, C, st, false))) return fail(rc);
+    hipLaunchKernelGGL(k_renum_csr, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, st, C, prob->d_rowptr, prob->d_ids, cperm, perm, off64, rowptr2, vids);
+    {
+        unsigned int* ovf = reinterpret_cast<unsigned int*>(em->partials);
+        RN_TRY(hipMemsetAsync(ovf, 0, 4, st));
+        hipLaunchKernelGGL(k_narrow_counts, dim3(blocks_for(C)), dim3(kEmBlock), 0, st, C, prob->d_counts, rowptr2, em->counts32, ovf, cperm);
+    }
+    RN_TRY(hipGetLastError());
+    RN_TRY(hipStreamSynchronize(st));
+#undef RN_TRY
+    for (void* q : {(void*)key, (void*)perm, (void*)ckey, (void*)lens, (void*)vals, (void*)k_in, (void*)k_out, (void*)off64}) pool_free(q);
+    em->inv = inv; em->cperm = cperm;
+    *rowptr2_out = rowptr2; *vids_out = vids;
+    return SFGPU_OK;
+}
+
 int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stream) {
     SF_REQUIRE(out && prob, SFGPU_ERR_INVALID, "sfgpu_em_create: null pointer");
     SF_REQUIRE(prob->M > 0 && prob->d_len, SFGPU_ERR_INVALID, "sfgpu_em_create: need M > 0 and d_len");
@@ -875,7 +988,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         unsigned int* ovf = reinterpret_cast<unsigned int*>(em->partials);
         EM_TRY(hipMemsetAsync(ovf, 0, 4, em->cur));
         hipLaunchKernelGGL(k_narrow_counts, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_counts,
-                           prob->d_rowptr, em->counts32, ovf);
+                           prob->d_rowptr, em->counts32, ovf, (const uint32_t*)nullptr);
         unsigned int h_ovf = 0;
         EM_TRY(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipMemcpyAsync(&rp_end, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
@@ -912,6 +1025,13 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         const uint32_t nt_cap = std::max(em->n_tiles, nt_small);
         uint32_t nt = em->n_tiles;
         uint32_t *t_len8 = nullptr, *t_nesc = nullptr;
+        // the class table the plan is made from: the caller's, or (plan_state 1) the renumbered copy of em_renumber
+        const uint32_t* p_rowptr = prob->d_rowptr; const uint32_t* p_ids = prob->d_ids;
+        uint32_t *rowptr2 = nullptr, *vids = nullptr;
+        int plan_state = 0;                  // 0: caller's order, 1: renumbered (trial), 2: caller's order after a trial that did not pay
+        uint64_t E_first = 0;
+        const uint64_t rounds0 = rounds; const uint32_t tile_nnz0 = tile_nnz, nt0 = nt;
+        uint64_t P = 0, S = 0, E = 0;
         pool_free(em->tile_lo); em->tile_lo = nullptr;
         EM_TRY(pool_malloc(&em->tile_lo, (size_t)nt_cap * 4));
         EM_TRY(pool_malloc(&em->tile_span, ((size_t)nt_cap + 1) * 4));
@@ -919,12 +1039,14 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&em->tile_off, ((size_t)nt_cap + 1) * 8));
         EM_TRY(pool_malloc(&em->tile_s0, ((size_t)nt_cap + 1) * 8));
         EM_TRY(pool_malloc(&em->tile_esc0, ((size_t)nt_cap + 1) * 8));
-        EM_TRY(pool_malloc(&t_len8, ((size_t)nt_cap + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt_cap + 1) * 4));
         EM_TRY(pool_malloc(&em->cov_ptr, ((size_t)M + 1) * 4));
         EM_TRY(pool_malloc(&em->tsum, (size_t)nt_cap * 8));
         EM_TRY(hipMemsetAsync(em->tsum, 0, (size_t)nt_cap * 8, em->cur));      // empty tiles never write theirs
+      for (;;) {                             // (the plan; twice or three times when the transcripts are renumbered)
+        rounds = rounds0; tile_nnz = tile_nnz0; nt = nt0; em->n_tiles = nt0;
+        EM_TRY(pool_malloc(&t_len8, ((size_t)nt_cap + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt_cap + 1) * 4));
         hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
-                           prob->d_rowptr, em->tile_c0);
+                           p_rowptr, em->tile_c0);
         while (tile_nnz > (uint32_t)kTileNnz) {
             std::vector<uint32_t> c0(nt + 1);
             EM_TRY(hipMemcpyAsync(c0.data(), em->tile_c0, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, em->cur));
@@ -939,9 +1061,9 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             if (nt > nt_cap) { nt = nt_small; tile_nnz = kTileNnz; }
             em->n_tiles = nt;
             hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
-                               prob->d_rowptr, em->tile_c0);
+                               p_rowptr, em->tile_c0);
         }
-        hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
+        hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
                            em->tile_lo, em->tile_span, t_len8, t_nesc);
         EM_TRY(hipGetLastError());
         // (no host wait inside the scans: the totals are read back with one synchronisation below)
@@ -950,11 +1072,30 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur, false);
         pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur);
         if (sr) { em_free(em); return sr; }
-        uint64_t P = 0, S = 0, E = 0;
         EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipMemcpyAsync(&S, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipMemcpyAsync(&E, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
+        // Many members outside their tile's window (an index whose isoforms are not adjacent): let the plan order the transcripts
+        // itself, and keep that order if it removes at least 40 % of the escapes.
+        if (plan_state == 0 && C >= kRenumberMinClasses && E * 8 > (uint64_t)rp_end && getenv("SFGPU_EM_NO_RENUMBER") == nullptr) {
+            E_first = E;
+            if (em_renumber(em, prob, rp_end, &rowptr2, &vids) == SFGPU_OK) { p_rowptr = rowptr2; p_ids = vids; plan_state = 1; continue; }
+            (void)hipGetLastError();
+        } else if (plan_state == 1 && E * 10 > E_first * 6) {
+            (void)hipStreamSynchronize(em->cur);
+            pool_free(rowptr2); pool_free(vids); pool_free(em->inv); pool_free(em->cperm);
+            rowptr2 = vids = nullptr; em->inv = em->cperm = nullptr;
+            unsigned int* ovf = reinterpret_cast<unsigned int*>(em->partials);
+            hipLaunchKernelGGL(k_narrow_counts, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_counts, prob->d_rowptr, em->counts32, ovf,
+                               (const uint32_t*)nullptr);
+            p_rowptr = prob->d_rowptr; p_ids = prob->d_ids; plan_state = 2;
+            continue;
+        }
+        break;
+      }
+        if (plan_state == 1) log_msg(0, "EM plan: transcripts renumbered by co-occurrence, %llu -> %llu of %u members outside their window",
+                                     (unsigned long long)E_first, (unsigned long long)E, rp_end);
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
         em->P = P;
         if (getenv("SFGPU_TIMING")) fprintf(stderr, "em plan: %u tiles (%u nnz each), P = %llu window slots (%.2f per transcript), %llu escapes of %llu nonzeros\n",
@@ -962,9 +1103,10 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
         EM_TRY(pool_malloc(&em->esc_id, (E ? E : 1) * 4));
         EM_TRY(pool_malloc(&em->esc_cls, (E ? E : 1) * 4));
-        hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, prob->d_rowptr, prob->d_ids, em->tile_c0,
-                           em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls);
+        hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
+                           em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls, em->inv);
         EM_TRY(hipGetLastError());
+        if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }
         EM_TRY(pool_malloc(&em->partial, (P ? P : 1) * 8));
         EM_TRY(pool_malloc(&em->cov_pos, (P ? P : 1) * 4));
         EM_TRY(pool_malloc(&em->pub_pos, (P ? P : 1) * 4));
@@ -973,7 +1115,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             uint64_t *k_in = nullptr, *k_out = nullptr; uint32_t* v_in = nullptr;
             EM_TRY(pool_malloc(&k_in, P * 8)); EM_TRY(pool_malloc(&k_out, P * 8)); EM_TRY(pool_malloc(&v_in, P * 4));
             hipLaunchKernelGGL(k_cover_pairs, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off,
-                               k_in, v_in);
+                               k_in, v_in, em->inv);
             int bits = 1; while (bits < 32 && (1ull << bits) <= M) ++bits;
             int src = sort_pairs_u64_u32(k_in, k_out, v_in, em->cov_pos, P, em->cur, bits, false);     // (synchronised below, before the frees)
             if (!src) {
@@ -1370,10 +1512,17 @@ int sfgpu_bootstrap_counts(sfgpu_em* em, uint64_t seed, uint64_t draw, uint32_t*
     if ((rc = em_join_user(em))) return rc;
     if ((rc = em_bootstrap_prepare(em))) return rc;
     // n is a uint32_t in MultinomialSampler::operator() (MultinomialSampler.hpp:15): totals wrap
-    rc = multinomial_tree(em->bs_prefix, em->prob.C, (uint32_t)em->bs_total, seed, draw, nullptr, d_counts_out,
+    uint32_t* dst = d_counts_out;
+    if (em->cperm) SF_HIP(pool_malloc(&dst, (em->prob.C ? em->prob.C : 1) * 4));       // the plan's class order -> the caller's
+    rc = multinomial_tree(em->bs_prefix, em->prob.C, (uint32_t)em->bs_total, seed, draw, nullptr, dst,
                           em->bs_scratch_a, em->bs_scratch_b, em->stream);
+    if (!rc && em->cperm) {
+        hipLaunchKernelGGL(k_renum_scatter, dim3(blocks_for(em->prob.C)), dim3(kEmBlock), 0, em->stream, em->prob.C, dst, em->cperm, d_counts_out);
+    }
+    hipError_t e = hipStreamSynchronize(em->stream);
+    if (em->cperm) pool_free(dst);
     if (rc) return rc;
-    SF_HIP(hipStreamSynchronize(em->stream));
+    SF_HIP(e);
     return SFGPU_OK;
 }
 

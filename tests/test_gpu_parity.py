@@ -473,6 +473,51 @@ def test_em_far_members_shared_by_a_neighbourhood(sf, gpu, vb):
         assert abs(st["alpha_sum"] - ost["alpha_sum"]) <= 1e-9 * ost["alpha_sum"]
 
 
+def test_em_with_shuffled_transcript_ids_renumbers_its_plan(sf, gpu):
+    """an index whose isoforms are not adjacent (accession order, a shuffled FASTA): every member of a class but the first is
+    outside its tile's window.  The plan then orders the transcripts itself (label propagation over the classes) and windows
+    its own order; x, alpha and everything the caller sees stay in the caller's order.  Same classes as the midsize problem
+    with the transcript ids shuffled: EM / VBEM against the oracle after 1, 2 and 60 iterations and at convergence, the
+    renumbering really ran (logger), bootstrap counts come back in the caller's class order."""
+    from sailfish_amd import synth, _lib
+    M = 30_000
+    ref_len, ids, off = synth.workload(M, 120_000, 1_500_000)
+    rng = np.random.default_rng(8)
+    sigma = rng.permutation(M).astype(np.uint32)
+    ids_np, off_np = ids.numpy().view(np.uint32), off.numpy().view(np.uint32)
+    sh = sigma[ids_np]
+    # members of a label sorted again (a label is a sorted id list)
+    rr = np.repeat(np.arange(len(off_np) - 1), np.diff(off_np.astype(np.int64)))
+    order = np.lexsort((sh, rr))
+    sh = sh[order]
+    ob, rp, ii, cc, hh = _oracle_classes([(sh, off_np)])
+    eff = O.efflen_smoothed(ref_len.numpy().view(np.uint32), O.cf_gaussian())
+    R = 1_500_000
+    logs = []
+    _lib.set_logger(lambda lvl, msg: logs.append(msg))
+    try:
+        p = _gpu_em(sf, gpu, eff, rp, ii, cc, R)
+    finally:
+        _lib.set_logger(None)
+    assert any("renumbered by co-occurrence" in m for m in logs), logs
+    for vb in (False, True):
+        for n_iter in (1, 2, 60):
+            rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, R, use_vbem=vb, tol=0.0, min_iter=0, max_iter=n_iter)
+            grc, st = p.optimize(use_vbem=vb, tol=0.0, min_iter=0, max_iter=n_iter, iters_per_launch=9)
+            assert rc == 0 and grc == 0 and st["iters"] == ost["iters"] == n_iter
+            assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT and _rel(p.mass.cpu().numpy(), om) < TIGHT
+        rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, R, use_vbem=vb)
+        grc, st = p.optimize(use_vbem=vb)
+        assert rc == 0 and grc == 0 and st["iters"] == ost["iters"]
+        assert _rel(p.alpha.cpu().numpy(), oa) < 1e-7
+    # resampled counts are reported per class of the CALLER's table: their mean over draws follows the caller's counts
+    D = 60
+    draws = np.stack([p.bootstrap_counts(5, d).cpu().numpy() for d in range(D)]).astype(np.float64)
+    assert np.all(draws.sum(1) == R)
+    r = float(np.corrcoef(draws.mean(0), cc.astype(np.float64))[0, 1])
+    assert r > 0.97, r                                     # (a class order mix-up would give ~0)
+
+
 @pytest.mark.parametrize("vb", [False, True])
 def test_em_to_convergence_matches_stop_iteration(sf, gpu, midsize, vb):
     m = midsize
