@@ -24,7 +24,9 @@ pytestmark = pytest.mark.gpu
 
 CFG3 = (200_000, 4_000_000, 400_000_000)
 # the loop is cut at 80 iterations on both sides (cfg3 converges after 212): every one of them costs the eight ranks a gloo
-# all-reduce through the host, and the iterations past 80 show nothing the first 80 do not (min_iter is 50: the stop logic ran)
+# all-reduce through the host, and the iterations past 80 show nothing the first 80 do not (min_iter is 50: the stop logic ran).
+# (Nine processes on one device: on its own this test takes ~20 s, after other GPU tests in the same session 6-8 minutes --
+# the device's queues are oversubscribed; fewer queues per rank, trimmed caches, a fresh parent process were tried and do not help.)
 CFG4_MAX_ITER = 80
 
 
