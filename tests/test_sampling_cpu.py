@@ -111,3 +111,44 @@ def test_multinomial_tree_draws_are_independent(H):
             tot += out
         ps.append(stats.chisquare(tot, q * tot.sum()).pvalue)
     assert stats.kstest(ps, "uniform").pvalue > 1e-3 and min(ps) > 1e-5, (min(ps),)
+
+
+def test_gibbs_colouring_of_classes_that_share_transcripts(tmp_path):
+    """sailfish_amd/csrc/colour.h (host side of the Gibbs plan): first-fit colouring of classes over their transcripts.  No two
+    classes of a colour share a transcript; a transcript shared by k classes forces >= k colours and first fit needs no more
+    than (largest number of classes conflicting with one class) + 1; colours beyond 63 (the overflow words) work; the result
+    is a function of the input alone."""
+    import ctypes, subprocess
+    so = tmp_path / "colour_harness.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), os.path.join(os.path.dirname(__file__), "colour_harness.cpp")])
+    lib = ctypes.CDLL(str(so))
+    lib.colour_classes.restype = ctypes.c_uint32
+    P = ctypes.c_void_p
+    lib.colour_classes.argtypes = [P, ctypes.c_uint64, P, ctypes.c_uint64, P, ctypes.c_uint64, ctypes.c_uint64, P]
+    rng = np.random.default_rng(12)
+    M = 5000
+    labels = []
+    for c in range(6000):
+        k = int(rng.integers(1, 7))
+        lab = set((int(rng.integers(0, 3000)) + 3 * np.arange(k)).tolist())
+        if c % 3 == 0: lab.add(4000 + c // 900)            # a far transcript shared by ~300 classes: > 64 colours
+        if c % 50 == 0: lab.add(4999)                      # ... and one shared by 120 classes spread over the whole list
+        labels.append(np.array(sorted(lab), np.uint32))
+    rowptr = np.zeros(len(labels) + 1, np.uint32); rowptr[1:] = np.cumsum([len(l) for l in labels])
+    ids = np.concatenate(labels)
+    wl = np.sort(rng.choice(len(labels), 4500, replace=False)).astype(np.uint32)     # the "wide" subset, in class order
+    col = np.zeros(len(wl), np.uint32)
+    ptr = lambda a: a.ctypes.data_as(P)
+    k = lib.colour_classes(ptr(wl), len(wl), ptr(rowptr), len(labels), ptr(ids), len(ids), M, ptr(col))
+    assert k == int(col.max()) + 1 and k > 64
+    # no two classes of a colour share a transcript
+    for c in range(k):
+        members = np.concatenate([labels[i] for i in wl[col == c]])
+        assert len(members) == len(np.unique(members)), c
+    # lower bound: the most shared transcript; upper bound of first fit: max conflict degree + 1
+    per_t = np.bincount(np.concatenate([labels[i] for i in wl]), minlength=M)
+    assert k >= int(per_t.max())
+    deg = max(int(sum(per_t[t] - 1 for t in labels[i])) for i in wl)
+    assert k <= deg + 1
+    col2 = np.zeros_like(col)
+    assert lib.colour_classes(ptr(wl), len(wl), ptr(rowptr), len(labels), ptr(ids), len(ids), M, ptr(col2)) == k and np.array_equal(col, col2)
