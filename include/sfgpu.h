@@ -316,6 +316,11 @@ struct sfgpu_hit;
 SFGPU_API int sfgpu_index_build(sfgpu_index** out, const char* d_seq, const uint64_t* d_seq_off, const uint32_t* d_ref_len, uint64_t M,
                                 uint32_t k, uint32_t max_occ, sfgpu_stream stream);
 SFGPU_API int sfgpu_index_destroy(sfgpu_index* idx);
+/* Seeds per strand (default 2: offsets 0 and len - k, every (transcript, strand) either seed hits is kept).  With S > 2 the
+ * seeds sit at offsets floor(j (len - k) / (S - 1)), j = 0 .. S-1, and a mate keeps only the (transcript, strand) pairs that the
+ * most seeds hit: more sensitive on reads with errors (one clean k-mer is enough) without keeping what a single repeat k-mer
+ * drags in.  2 <= S <= 8. */
+SFGPU_API int sfgpu_index_set_seeds(sfgpu_index* x, uint32_t seeds_per_strand);
 SFGPU_API int sfgpu_index_info(const sfgpu_index* idx, uint32_t* k, uint64_t* n_positions, uint64_t* n_kmers);
 SFGPU_API int sfgpu_map_reads(const sfgpu_index* idx, const char* d_seq1, const uint64_t* d_off1, const char* d_seq2, const uint64_t* d_off2,
                               uint32_t n_reads, struct sfgpu_hit* d_hits, uint64_t hit_capacity, uint32_t* d_hit_offsets, uint64_t* n_hits,

@@ -55,33 +55,51 @@ def _key(codes):
     return key
 
 
-def map_read(index, read: bytes, k=31):
+def seed_offsets(n, k, seeds):
+    """offsets of the `seeds` seeds of a read of n bases: floor(j (n - k) / (seeds - 1)); a seed whose offset equals the
+    previous one's (a read barely longer than k) is dropped"""
+    out = []
+    for j in range(seeds):
+        o = (j * (n - k)) // (seeds - 1)
+        if j == 0 or o != (((j - 1) * (n - k)) // (seeds - 1)):
+            out.append((j, o))
+    return out
+
+
+def map_read(index, read: bytes, k=31, seeds=2):
+    """seeds = 2: the contract above.  seeds > 2: seeds spread evenly between offsets 0 and len - k; a (transcript, strand) is
+    positioned by the first seed (lowest index, fwd strand before rc) that hits it, and only the pairs that the MOST seeds hit
+    are kept."""
     c = _codes(read)
     n = len(c)
     if n < k:
         return []
     rc = (3 - c[::-1]).astype(np.uint8); rc[c[::-1] > 3] = 4
-    found = {}
+    found, votes = {}, {}
     for fwd, q in ((1, c), (0, rc)):
-        for o in (0, n - k):
+        for j, o in seed_offsets(n, k, seeds):
             key = _key(q[o:o + k])
             if key is None:
                 continue
             for t, p in index.get(key, ()):
                 found.setdefault((t, fwd), p - o)
+                votes.setdefault((t, fwd), set()).add(j)
+    if seeds > 2 and len(found) > 1:
+        best = max(len(v) for v in votes.values())
+        found = {key: p for key, p in found.items() if len(votes[key]) == best}
     return sorted((t, fwd, p) for (t, fwd), p in found.items())
 
 
-def map_reads(index, reads1, reads2=None, k=31):
+def map_reads(index, reads1, reads2=None, k=31, seeds=2):
     """-> (hits HIT_DTYPE[n], offsets uint32[R + 1])"""
     recs, off = [], [0]
     for i, r1 in enumerate(reads1):
-        left = map_read(index, r1, k)
+        left = map_read(index, r1, k, seeds)
         if reads2 is None:
             recs += [(t, p, 0, 0, len(r1), 0, f, 0, 0, 0) for t, f, p in left]
         else:
             r2 = reads2[i]
-            right = map_read(index, r2, k)
+            right = map_read(index, r2, k, seeds)
             paired = [(t, f, p, f2, p2) for t, f, p in left for t2, f2, p2 in right if t2 == t and f2 != f]
             if paired:
                 for t, f, p, f2, p2 in paired:

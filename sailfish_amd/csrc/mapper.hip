@@ -89,7 +89,13 @@ __global__ void k_count_valid(uint64_t n, const uint64_t* __restrict__ keys, uns
 
 struct IndexView {
     const uint64_t* keys; const uint32_t* tid; const uint32_t* tpos; const uint32_t* bucket; uint64_t n; uint32_t k, shift, max_occ;
+    uint32_t n_seeds;                      // seeds per strand (2: offsets 0 and len - k; more: spread evenly between them)
 };
+constexpr uint32_t kMaxSeeds = 8;
+// offset of seed j of S in a read of `len` bases (S = 2: 0 and len - k)
+__device__ __host__ __forceinline__ uint32_t seed_offset(uint32_t j, uint32_t S, uint32_t len, uint32_t k) {
+    return S <= 1 ? 0u : (uint32_t)(((uint64_t)j * (len - k)) / (S - 1));
+}
 // occurrences of `key`: [lo, lo + cnt)
 __device__ __forceinline__ void index_lookup(const IndexView& x, uint64_t key, uint32_t& lo_out, uint32_t& cnt_out) {
     const uint64_t b = key >> x.shift;
@@ -102,47 +108,45 @@ __device__ __forceinline__ void index_lookup(const IndexView& x, uint64_t key, u
 }
 
 // ---- mapping -----------------------------------------------------------------------------------------------------
-// the four seed k-mers of a read: [fwd seed0, fwd seed1, rc seed0, rc seed1]; valid[i] false if a base is not A/C/G/T
-__device__ __forceinline__ void seed_keys(const char* r, uint32_t len, uint32_t k, uint64_t (&key)[4], bool (&valid)[4]) {
+// seed k-mer j of the read on one strand: fwd -> the window at offset o_j; rc -> the read's reverse complement at offset o_j,
+// i.e. the complement of r[len - 1 - o_j .. len - o_j - k], reversed.  valid false if a base is not A/C/G/T.
+__device__ __forceinline__ uint64_t seed_key(const char* r, uint32_t len, uint32_t k, uint32_t o, bool rc, bool& valid) {
     const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
-    const uint32_t o1 = len - k;
-    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0; bool vf0 = true, vf1 = true, vr0 = true, vr1 = true;
+    uint64_t key = 0; bool ok = true;
     for (uint32_t i = 0; i < k; ++i) {
-        const uint32_t a = base_code((unsigned char)r[i]), b = base_code((unsigned char)r[o1 + i]);
-        vf0 = vf0 && a < 4u; vf1 = vf1 && b < 4u;
-        f0 = (f0 << 2) | (a & 3u); f1 = (f1 << 2) | (b & 3u);
-        // reverse complement of the read: its seed at offset 0 is the complement of r[len-1 .. len-k] (the read's LAST k
-        // bases, i.e. the window at o1, reversed); its seed at offset len - k is that of r[k-1 .. 0]
-        const uint32_t c = base_code((unsigned char)r[len - 1 - i]), d = base_code((unsigned char)r[k - 1 - i]);
-        vr0 = vr0 && c < 4u; vr1 = vr1 && d < 4u;
-        r0 = (r0 << 2) | ((3u - c) & 3u); r1 = (r1 << 2) | ((3u - d) & 3u);
+        const uint32_t c = base_code((unsigned char)(rc ? r[len - 1 - o - i] : r[o + i]));
+        ok = ok && c < 4u;
+        key = (key << 2) | ((rc ? 3u - c : c) & 3u);
     }
-    key[0] = f0 & mask; key[1] = f1 & mask; key[2] = r0 & mask; key[3] = r1 & mask;
-    valid[0] = vf0; valid[1] = vf1; valid[2] = vr0; valid[3] = vr1;
+    valid = ok;
+    return key & mask;
 }
 
-// pass A: the four lookups of every mate; ranges[4 m + i] = lo | cnt << 32; cand_cnt[m] = sum of the counts
+// pass A: the 2 S lookups of every mate (fwd seeds 0 .. S-1, then rc seeds 0 .. S-1); ranges[2 S m + i] = lo | cnt << 32;
+// cand_cnt[m] = sum of the counts.  A seed whose offset equals the previous seed's (a read barely longer than k) is skipped.
 __global__ void __launch_bounds__(kMapBlock)
 k_map_lookup(IndexView x, const char* __restrict__ seq, const uint64_t* __restrict__ off, uint64_t n_mates, uint64_t* ranges, uint32_t* cand_cnt) {
     const uint64_t m = (uint64_t)blockIdx.x * kMapBlock + threadIdx.x;
     if (m > n_mates) return;
     if (m == n_mates) { cand_cnt[m] = 0; return; }
     const uint64_t b = off[m]; const uint32_t len = (uint32_t)(off[m + 1] - b);
+    const uint32_t S = x.n_seeds;
     uint32_t total = 0;
-    uint64_t rg[4] = {0, 0, 0, 0};
-    if (len >= x.k) {
-        uint64_t key[4]; bool valid[4];
-        seed_keys(seq + b, len, x.k, key, valid);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t lo = 0, cnt = 0;
-            if (valid[i]) index_lookup(x, key[i], lo, cnt);
-            rg[i] = (uint64_t)lo | ((uint64_t)cnt << 32);
-            total += cnt;
+    for (uint32_t i = 0; i < 2 * S; ++i) {
+        uint64_t rg = 0;
+        if (len >= x.k) {
+            const uint32_t j = i < S ? i : i - S;
+            const uint32_t o = seed_offset(j, S, len, x.k);
+            if (j == 0 || o != seed_offset(j - 1, S, len, x.k)) {
+                bool valid; const uint64_t key = seed_key(seq + b, len, x.k, o, i >= S, valid);
+                uint32_t lo = 0, cnt = 0;
+                if (valid) index_lookup(x, key, lo, cnt);
+                rg = (uint64_t)lo | ((uint64_t)cnt << 32);
+                total += cnt;
+            }
         }
+        ranges[2ull * S * m + i] = rg;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ranges[4 * m + i] = rg[i];
     cand_cnt[m] = total;
 }
 
@@ -152,28 +156,38 @@ __device__ __forceinline__ uint32_t cand_tid(uint64_t c) { return (uint32_t)(c >
 __device__ __forceinline__ uint32_t cand_fwd(uint64_t c) { return (uint32_t)(c >> 31) & 1u; }
 __device__ __forceinline__ int32_t cand_pos(uint64_t c) { return (int32_t)((uint32_t)c & 0x7FFFFFFFu) - (1 << 30); }
 
-// pass B: expand the ranges in the contract's order, keep the first occurrence per (transcript, strand), sort by
-// (transcript, strand).  Lists are short (a few entries); the dedupe and the insertion sort work in place in global memory.
+// pass B: expand the ranges in the contract's order, keep the first occurrence per (transcript, strand) -- with S > 2 seeds
+// also WHICH seeds hit it, and then only the (transcript, strand) pairs that the most seeds agree on --, sort by (transcript,
+// strand).  Lists are short (a few entries); the dedupe and the insertion sort work in place in global memory.
 __global__ void __launch_bounds__(kMapBlock)
 k_map_hits(IndexView x, const uint64_t* __restrict__ off, uint64_t n_mates, const uint64_t* __restrict__ ranges,
-           const uint64_t* __restrict__ cand_off, uint64_t* cand, uint32_t* n_hits) {
+           const uint64_t* __restrict__ cand_off, uint64_t* cand, uint8_t* votes, uint32_t* n_hits) {
     const uint64_t m = (uint64_t)blockIdx.x * kMapBlock + threadIdx.x;
     if (m >= n_mates) return;
     const uint32_t len = (uint32_t)(off[m + 1] - off[m]);
+    const uint32_t S = x.n_seeds;
     uint64_t* out = cand + cand_off[m];
+    uint8_t* vt = votes + cand_off[m];
     uint32_t n = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint64_t rg = ranges[4 * m + i];
+    for (uint32_t i = 0; i < 2 * S; ++i) {
+        const uint64_t rg = ranges[2ull * S * m + i];
         const uint32_t lo = (uint32_t)rg, cnt = (uint32_t)(rg >> 32);
-        const uint32_t fwd = i < 2 ? 1u : 0u;
-        const int32_t o = (i & 1) ? (int32_t)(len - x.k) : 0;
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t t = x.tid[lo + j];
-            bool seen = false;
-            for (uint32_t q = 0; q < n && !seen; ++q) seen = cand_tid(out[q]) == t && cand_fwd(out[q]) == fwd;
-            if (!seen) out[n++] = cand_pack(t, fwd, (int32_t)x.tpos[lo + j] - o);
+        const uint32_t fwd = i < S ? 1u : 0u, j = i < S ? i : i - S;
+        const int32_t o = cnt ? (int32_t)seed_offset(j, S, len, x.k) : 0;
+        for (uint32_t q0 = 0; q0 < cnt; ++q0) {
+            const uint32_t t = x.tid[lo + q0];
+            uint32_t at = n;
+            for (uint32_t q = 0; q < n && at == n; ++q) if (cand_tid(out[q]) == t && cand_fwd(out[q]) == fwd) at = q;
+            if (at == n) { out[n] = cand_pack(t, fwd, (int32_t)x.tpos[lo + q0] - o); vt[n] = (uint8_t)(1u << j); ++n; }
+            else vt[at] |= (uint8_t)(1u << j);
         }
+    }
+    if (S > 2 && n > 1) {                                   // the pairs the most seeds agree on
+        uint32_t best = 0;
+        for (uint32_t q = 0; q < n; ++q) { const uint32_t v = (uint32_t)__popc((unsigned)vt[q]); best = v > best ? v : best; }
+        uint32_t w = 0;
+        for (uint32_t q = 0; q < n; ++q) if ((uint32_t)__popc((unsigned)vt[q]) == best) out[w++] = out[q];
+        n = w;
     }
     for (uint32_t a = 1; a < n; ++a) {                      // (transcript, strand) ascending: the key is the word's top 33 bits
         const uint64_t v = out[a]; uint32_t b = a;
@@ -233,13 +247,12 @@ __global__ void k_mate_lens(uint64_t n_reads, const uint64_t* __restrict__ o1, c
     else if (r == n_reads) lens[2 * r] = 0;
 }
 // side s of a pair: ranges / counts of read r -> mate 2 r + s
-__global__ void k_interleave(uint64_t n_reads, int side, const uint64_t* __restrict__ s_ranges, const uint32_t* __restrict__ s_cnt,
+__global__ void k_interleave(uint64_t n_reads, int side, uint32_t per_mate, const uint64_t* __restrict__ s_ranges, const uint32_t* __restrict__ s_cnt,
                              uint64_t* ranges, uint32_t* cand_cnt) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint64_t m = 2 * r + side;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ranges[4 * m + i] = s_ranges[4 * r + i];
+    for (uint32_t i = 0; i < per_mate; ++i) ranges[(uint64_t)per_mate * m + i] = s_ranges[(uint64_t)per_mate * r + i];
     cand_cnt[m] = s_cnt[r];
 }
 __global__ void k_narrow_off(uint64_t n, const uint64_t* __restrict__ in, uint32_t* out) {
@@ -252,7 +265,7 @@ __global__ void k_narrow_off(uint64_t n, const uint64_t* __restrict__ in, uint32
 using namespace sfgpu;
 
 struct sfgpu_index {
-    uint32_t k = 31, shift = 0, max_occ = 1000;
+    uint32_t k = 31, shift = 0, max_occ = 1000, n_seeds = 2;
     uint64_t n_valid = 0, n_slots = 0, M = 0, n_buckets = 0;
     DevBuf<uint64_t> keys; DevBuf<uint32_t> tid, tpos, bucket;
 };
@@ -308,6 +321,13 @@ int sfgpu_index_build(sfgpu_index** out, const char* d_seq, const uint64_t* d_se
 
 int sfgpu_index_destroy(sfgpu_index* x) { delete x; return SFGPU_OK; }
 
+int sfgpu_index_set_seeds(sfgpu_index* x, uint32_t seeds_per_strand) {
+    SF_REQUIRE(x, SFGPU_ERR_INVALID, "sfgpu_index_set_seeds: null handle");
+    SF_REQUIRE(seeds_per_strand >= 2 && seeds_per_strand <= kMaxSeeds, SFGPU_ERR_INVALID, "sfgpu_index_set_seeds: 2 .. 8 seeds per strand");
+    x->n_seeds = seeds_per_strand;
+    return SFGPU_OK;
+}
+
 int sfgpu_index_info(const sfgpu_index* x, uint32_t* k, uint64_t* n_positions, uint64_t* n_kmers) {
     SF_REQUIRE(x, SFGPU_ERR_INVALID, "sfgpu_index_info: null handle");
     if (k) *k = x->k;
@@ -326,12 +346,13 @@ int sfgpu_map_reads(const sfgpu_index* x, const char* d_seq1, const uint64_t* d_
     SF_REQUIRE(d_seq1 && d_off1 && (!d_seq2 || d_off2), SFGPU_ERR_INVALID, "sfgpu_map_reads: null reads");
     const int paired = d_seq2 != nullptr;
     const uint64_t n_mates = paired ? 2ull * n_reads : n_reads;
-    IndexView v{x->keys.p, x->tid.p, x->tpos.p, x->bucket.p, x->n_valid, x->k, x->shift, x->max_occ};
+    IndexView v{x->keys.p, x->tid.p, x->tpos.p, x->bucket.p, x->n_valid, x->k, x->shift, x->max_occ, x->n_seeds};
+    const uint64_t per_mate = 2ull * x->n_seeds;                     // lookups per mate
     int rc;
     // Mates are numbered 2 r (left) and 2 r + 1 (right).  The two files are looked up side by side (each with its own
     // sequence buffer and offsets) and interleaved; from then on only the mates' LENGTHS are needed, as offsets `moff`.
-    DevBuf<uint64_t> ranges, cand_off, cand, rec_off, moff, s_ranges; DevBuf<uint32_t> cand_cnt, n_hits, rec_cnt, s_cnt, lens;
-    if ((rc = ranges.reserve(4 * n_mates, st, false)) || (rc = cand_cnt.reserve(n_mates + 1, st, false)) || (rc = cand_off.reserve(n_mates + 2, st, false)) ||
+    DevBuf<uint64_t> ranges, cand_off, cand, rec_off, moff, s_ranges; DevBuf<uint32_t> cand_cnt, n_hits, rec_cnt, s_cnt, lens; DevBuf<uint8_t> votes;
+    if ((rc = ranges.reserve(per_mate * n_mates, st, false)) || (rc = cand_cnt.reserve(n_mates + 1, st, false)) || (rc = cand_off.reserve(n_mates + 2, st, false)) ||
         (rc = n_hits.reserve(n_mates, st, false)) || (rc = rec_cnt.reserve((uint64_t)n_reads + 1, st, false)) ||
         (rc = rec_off.reserve((uint64_t)n_reads + 2, st, false)) || (rc = moff.reserve(n_mates + 2, st, false))) return rc;
     if (!paired) {
@@ -339,11 +360,11 @@ int sfgpu_map_reads(const sfgpu_index* x, const char* d_seq1, const uint64_t* d_
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(moff.p, d_off1, ((uint64_t)n_reads + 1) * 8, hipMemcpyDeviceToDevice, st));
     } else {
-        if ((rc = s_ranges.reserve(4ull * n_reads, st, false)) || (rc = s_cnt.reserve((uint64_t)n_reads + 1, st, false)) || (rc = lens.reserve(n_mates + 1, st, false))) return rc;
+        if ((rc = s_ranges.reserve(per_mate * n_reads, st, false)) || (rc = s_cnt.reserve((uint64_t)n_reads + 1, st, false)) || (rc = lens.reserve(n_mates + 1, st, false))) return rc;
         for (int side = 0; side < 2; ++side) {
             hipLaunchKernelGGL(k_map_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, side ? d_seq2 : d_seq1, side ? d_off2 : d_off1,
                                (uint64_t)n_reads, s_ranges.p, s_cnt.p);
-            hipLaunchKernelGGL(k_interleave, dim3(mpgrid(n_reads)), dim3(kMapBlock), 0, st, (uint64_t)n_reads, side, s_ranges.p, s_cnt.p, ranges.p, cand_cnt.p);
+            hipLaunchKernelGGL(k_interleave, dim3(mpgrid(n_reads)), dim3(kMapBlock), 0, st, (uint64_t)n_reads, side, (uint32_t)per_mate, s_ranges.p, s_cnt.p, ranges.p, cand_cnt.p);
             SF_CHECK_LAUNCH();
         }
         SF_HIP(hipMemsetAsync(cand_cnt.p + n_mates, 0, 4, st));
@@ -355,8 +376,8 @@ int sfgpu_map_reads(const sfgpu_index* x, const char* d_seq1, const uint64_t* d_
     uint64_t n_cand = 0;
     SF_HIP(hipMemcpyAsync(&n_cand, cand_off.p + n_mates, 8, hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
-    if ((rc = cand.reserve(n_cand + 1, st, false))) return rc;
-    hipLaunchKernelGGL(k_map_hits, dim3(mpgrid(n_mates)), dim3(kMapBlock), 0, st, v, moff.p, n_mates, ranges.p, cand_off.p, cand.p, n_hits.p);
+    if ((rc = cand.reserve(n_cand + 1, st, false)) || (rc = votes.reserve(n_cand + 1, st, false))) return rc;
+    hipLaunchKernelGGL(k_map_hits, dim3(mpgrid(n_mates)), dim3(kMapBlock), 0, st, v, moff.p, n_mates, ranges.p, cand_off.p, cand.p, votes.p, n_hits.p);
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_map_records<false>, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, (uint64_t)n_reads, paired, moff.p, cand_off.p, cand.p,
                        n_hits.p, rec_cnt.p, (const uint64_t*)nullptr, (sfgpu_hit*)nullptr);

@@ -25,7 +25,7 @@ def pack_sequences(seqs, device="cpu"):
 class QuasiIndex:
     """k-mer index of a transcriptome on the device (sfgpu_index_build)."""
 
-    def __init__(self, sequences, k=31, max_occ=1000, device="cuda"):
+    def __init__(self, sequences, k=31, max_occ=1000, device="cuda", seeds=2):
         self.device = torch.device(device)
         self._L = _lib.lib()
         seq, off = pack_sequences(sequences, self.device)
@@ -40,6 +40,15 @@ class QuasiIndex:
         kk, npos, nk = C.c_uint32(), C.c_uint64(), C.c_uint64()
         _lib.check(self._L.sfgpu_index_info(self._h, C.byref(kk), C.byref(npos), C.byref(nk)))
         self.k, self.n_positions, self.n_kmers = kk.value, npos.value, nk.value
+        self.seeds = 2
+        if seeds != 2:
+            self.set_seeds(seeds)
+
+    def set_seeds(self, seeds):
+        """seeds per strand (sfgpu_index_set_seeds): 2 = offsets 0 and len - k, every hit kept; 3 .. 8 = seeds spread evenly over
+        the read, only the (transcript, strand) pairs that the most seeds hit are kept (more sensitive on reads with errors)"""
+        _lib.check(self._L.sfgpu_index_set_seeds(self._h, int(seeds)))
+        self.seeds = int(seeds)
 
     def map_reads(self, reads1, reads2=None):
         """reads1 / reads2: lists of str / bytes, or (uint8 tensor, int64 offsets) pairs already packed.

@@ -88,6 +88,61 @@ def test_device_mapper_matches_its_contract(gpu, paired):
     assert np.array_equal(o2, eo) and np.array_equal(h2, eh)
 
 
+def _with_errors(rng, reads, rate):
+    """substitutions at `rate` per base (A/C/G/T only; other characters stay)"""
+    sub = {65: b"CGT", 67: b"AGT", 71: b"ACT", 84: b"ACG", 97: b"cgt", 99: b"agt", 103: b"act", 116: b"acg"}
+    out = []
+    for r in reads:
+        b = bytearray(r)
+        for i in np.nonzero(rng.random(len(b)) < rate)[0]:
+            if b[i] in sub:
+                b[i] = sub[b[i]][int(rng.integers(0, 3))]
+        out.append(bytes(b))
+    return out
+
+
+def test_more_seeds_map_more_reads_with_errors(built):
+    """the contract with S > 2 seeds per strand (CPU restatement): on the bundled reads with 2 % substitutions, eight seeds per
+    strand place the simulated transcript among the hits of more reads than the two end seeds do (a read maps if ANY of its
+    seeds is error free; with k = 31 and 70-base reads the gain is a few percent), and S = 2 is the old contract"""
+    names, seqs, r1, r2, truth = _sample_reads()
+    rng = np.random.default_rng(3)
+    n = 400
+    e1 = _with_errors(rng, r1[:n], 0.02)
+    index = MO.build_index(seqs)
+    found = {}
+    for S in (2, 8):
+        ok = 0
+        for r in range(n):
+            ok += int(truth[r] in [t for t, f, p in MO.map_read(index, e1[r], seeds=S)])
+        found[S] = ok
+    assert found[8] > found[2], found
+    assert all(MO.map_read(index, r1[r], seeds=2) == MO.map_read(index, r1[r]) for r in range(50))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seeds", [3, 5, 8])
+def test_device_mapper_with_more_seeds_matches_its_contract(gpu, seeds):
+    """S > 2 seeds per strand on the device = the restated contract, record for record: random isoform-like transcriptome (shared
+    segments, N, lower case, ragged and short reads), reads with 3 % substitutions, paired and single end; setting the seeds
+    back to 2 gives the two-seed records again"""
+    import sailfish_amd as sf
+    rng = np.random.default_rng(40 + seeds)
+    seqs, r1, r2 = _random_case(rng, n_reads=2000, read_len=70)
+    r1, r2 = _with_errors(rng, r1, 0.03), _with_errors(rng, r2, 0.03)
+    idx = sf.mapper.QuasiIndex(seqs, k=31, max_occ=1000, device=gpu, seeds=seeds)
+    oi = MO.build_index(seqs, 31, 1000)
+    for paired in (True, False):
+        gh, go = sf.mapper.hits_to_numpy(*idx.map_reads(r1, r2 if paired else None))
+        oh, oo = MO.map_reads(oi, r1, r2 if paired else None, seeds=seeds)
+        assert np.array_equal(go, oo) and np.array_equal(gh, oh)
+        assert len(oh) > len(r1) // 3
+    idx.set_seeds(2)
+    gh, go = sf.mapper.hits_to_numpy(*idx.map_reads(r1, r2))
+    oh, oo = MO.map_reads(oi, r1, r2)
+    assert np.array_equal(go, oo) and np.array_equal(gh, oh)
+
+
 @pytest.mark.gpu
 def test_bundled_sample_data_from_the_reads(gpu, tmp_path):
     """BASELINE config 1 from the READS on: index the 15 transcripts, map the 10 000 pairs on the device -- the records are
