@@ -122,6 +122,25 @@ __device__ __forceinline__ uint64_t seed_key(const char* r, uint32_t len, uint32
     return key & mask;
 }
 
+// S = 2 (the default), all four keys in one pass over the read: [fwd seed0, fwd seed1, rc seed0, rc seed1]; valid[i] false if a base is not A/C/G/T
+__device__ __forceinline__ void seed_keys(const char* r, uint32_t len, uint32_t k, uint64_t (&key)[4], bool (&valid)[4]) {
+    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t o1 = len - k;
+    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0; bool vf0 = true, vf1 = true, vr0 = true, vr1 = true;
+    for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t a = base_code((unsigned char)r[i]), b = base_code((unsigned char)r[o1 + i]);
+        vf0 = vf0 && a < 4u; vf1 = vf1 && b < 4u;
+        f0 = (f0 << 2) | (a & 3u); f1 = (f1 << 2) | (b & 3u);
+        // reverse complement of the read: its seed at offset 0 is the complement of r[len-1 .. len-k] (the read's LAST k
+        // bases, i.e. the window at o1, reversed); its seed at offset len - k is that of r[k-1 .. 0]
+        const uint32_t c = base_code((unsigned char)r[len - 1 - i]), d = base_code((unsigned char)r[k - 1 - i]);
+        vr0 = vr0 && c < 4u; vr1 = vr1 && d < 4u;
+        r0 = (r0 << 2) | ((3u - c) & 3u); r1 = (r1 << 2) | ((3u - d) & 3u);
+    }
+    key[0] = f0 & mask; key[1] = f1 & mask; key[2] = r0 & mask; key[3] = r1 & mask;
+    valid[0] = vf0; valid[1] = vf1; valid[2] = vr0; valid[3] = vr1;
+}
+
 // pass A: the 2 S lookups of every mate (fwd seeds 0 .. S-1, then rc seeds 0 .. S-1); ranges[2 S m + i] = lo | cnt << 32;
 // cand_cnt[m] = sum of the counts.  A seed whose offset equals the previous seed's (a read barely longer than k) is skipped.
 __global__ void __launch_bounds__(kMapBlock)
@@ -132,6 +151,24 @@ k_map_lookup(IndexView x, const char* __restrict__ seq, const uint64_t* __restri
     const uint64_t b = off[m]; const uint32_t len = (uint32_t)(off[m + 1] - b);
     const uint32_t S = x.n_seeds;
     uint32_t total = 0;
+    if (S == 2u) {                                          // the default: one fused pass computes the four keys
+        uint64_t rg4[4] = {0, 0, 0, 0};
+        if (len >= x.k) {
+            uint64_t key[4]; bool valid[4];
+            seed_keys(seq + b, len, x.k, key, valid);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t lo = 0, cnt = 0;
+                if (valid[i] && !(i & 1 && len == x.k)) index_lookup(x, key[i], lo, cnt);     // (len == k: seed 1 is seed 0 again)
+                rg4[i] = (uint64_t)lo | ((uint64_t)cnt << 32);
+                total += cnt;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ranges[4 * m + i] = rg4[i];
+        cand_cnt[m] = total;
+        return;
+    }
     for (uint32_t i = 0; i < 2 * S; ++i) {
         uint64_t rg = 0;
         if (len >= x.k) {
