@@ -373,13 +373,18 @@ __global__ void k_renum_iota(uint64_t n, uint32_t* out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t)i;
 }
-__global__ void k_lp_min(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, uint32_t* key) {
+// one hop of the label propagation, Jacobi style: the keys of the previous hop are only READ (key_in), the minima go to
+// key_out (a copy of key_in before the launch), so a hop's result is a pure function of its input -- not of which lanes ran
+// first (reading and atomicMin-ing one array made the plan's transcript order, and with it the summation order and the
+// bootstrap's class order, depend on the schedule)
+__global__ void k_lp_min(uint64_t C, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                         const uint32_t* __restrict__ key_in, uint32_t* key_out) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const uint32_t b = rowptr[c], e = rowptr[c + 1];
     uint32_t m = 0xFFFFFFFFu;
-    for (uint32_t j = b; j < e; ++j) { const uint32_t k = key[ids[j]]; m = k < m ? k : m; }
-    for (uint32_t j = b; j < e; ++j) atomicMin(&key[ids[j]], m);
+    for (uint32_t j = b; j < e; ++j) { const uint32_t k = key_in[ids[j]]; m = k < m ? k : m; }
+    for (uint32_t j = b; j < e; ++j) if (m < key_in[ids[j]]) atomicMin(&key_out[ids[j]], m);
 }
 __global__ void k_renum_pair_keys(uint64_t n, const uint32_t* __restrict__ hi, uint64_t* keys, uint32_t* vals) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,7 +499,7 @@ k_sweep_lds(SweepArgs a) {
     auto den_chunk = [&](const uint4& w0, const uint4& w1) {
         const uint32_t a4[4] = {w0.x, w0.y, w0.z, w0.w}, b4[4] = {w1.x, w1.y, w1.z, w1.w};
         double v[4];
-        uint32_t cur = kTileNnz; double run = 0.0;                           // (starts on the null class: adds 0 to it)
+        uint32_t cur = (w0.x >> 16) & 0x1FFFu; double run = 0.0;             // (starts on its first word's class with an empty run: no add to den[null])
         den_words(a4, N4{}, v, cur, run);
         den_words(b4, N4{}, v, cur, run);
         atomicAdd(&den[cur], run);
@@ -541,7 +546,7 @@ k_sweep_lds(SweepArgs a) {
             // (a lane past the end of the tile holds eight null words: it stays out -- hundreds of lanes adding zeros to the ONE
             //  null class serialise in the LDS atomic unit: cfg2's 5 300-nonzero tiles went from 8.5 to 16.5 us before this test)
             if (g0 + (uint32_t)c * kSweepBlock * kPerLane >= n8) break;
-            uint32_t cur = kTileNnz; double run = 0.0;
+            uint32_t cur = (w[c][0] >> 16) & 0x1FFFu; double run = 0.0;
             den_words(w[c], N8{}, xv[c], cur, run);
             atomicAdd(&den[cur], run);
         }
@@ -920,8 +925,15 @@ static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint
     hipLaunchKernelGGL(k_renum_iota, dim3(blocks_for(M)), dim3(kEmBlock), 0, st, M, key);
     int hops = kRenumberHops;
     if (const char* e = getenv("SFGPU_EM_RENUMBER_HOPS")) { int v = atoi(e); if (v >= 1 && v <= 64) hops = v; }      // tuning
-    for (int hop = 0; hop < hops; ++hop)
-        hipLaunchKernelGGL(k_lp_min, dim3(blocks_for(C)), dim3(kEmBlock), 0, st, C, prob->d_rowptr, prob->d_ids, key);
+    {
+        uint32_t *kin = key, *kout = perm;                  // (perm is filled further down: free until then)
+        for (int hop = 0; hop < hops; ++hop) {
+            RN_TRY(hipMemcpyAsync(kout, kin, M * 4, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_lp_min, dim3(blocks_for(C)), dim3(kEmBlock), 0, st, C, prob->d_rowptr, prob->d_ids, kin, kout);
+            std::swap(kin, kout);
+        }
+        if (kin != key) RN_TRY(hipMemcpyAsync(key, kin, M * 4, hipMemcpyDeviceToDevice, st));
+    }
     // transcripts by (key, id): inv[position] = transcript, perm[transcript] = position
     hipLaunchKernelGGL(k_renum_pair_keys, dim3(blocks_for(M)), dim3(kEmBlock), 0, st, M, key, k_in, vals);
     RN_TRY(hipGetLastError());

@@ -381,6 +381,7 @@ struct sfgpu_eq {
     DevBuf<unsigned long long> hot_buf;     // hot classes for k_part_route: kHotSlots hashes, kHotSlots (arena granule, slot) pairs, the count
     uint64_t reads_seen = 0;                // reads added since start()
     uint64_t hot_cap = 0, hot_reads = 0;    // table size and reads_seen when the hot table was last rebuilt
+    uint32_t hot_slots = 0;                 // ... and the number of slots it was laid out for
     DevBuf<uint64_t> part_off, def_off64;
 };
 
@@ -556,6 +557,15 @@ __global__ void k_sub_batch_begin(unsigned long long* ctr, const uint32_t* __res
     if (threadIdx.x == 3) ctr[CTR_PEEK + 2] = offsets[p2];
 }
 
+static int device_cus() {
+    static const int n = []() {
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        return n_cu > 0 ? n_cu : 256;
+    }();
+    return n;
+}
+
 // radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.  peek[3] = positions in
 // d_offsets whose values are returned in eq->h_ctr[CTR_PEEK..]
 static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t cnt,
@@ -586,24 +596,38 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
-    // every block of pass 1 owns one contiguous tile of reads and one bin per region
+    // every block of pass 1 owns one contiguous tile of reads and one bin per region.  The RING form of the pass (bins written
+    // through LDS rings, eqclass_part.h) wants one block per CU and fits up to 1024 regions (a table of <= 4 M slots).  It is
+    // OFF by default: measured on cfg3 it writes whole 64-byte units (no partial lines) but takes 10.8 ms per build against
+    // 9.8 ms -- one block per CU is 4 wavefronts per SIMD, and the pass is instruction-bound (profiles/r3_class_build_notes.md)
+    static const int ring_mode = []() { const char* e = getenv("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();
     static const uint32_t max_blocks = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long v = e ? atol(e) : 512; return (uint32_t)(v >= 1 && v <= 1024 ? v : 512); }();
-    uint32_t n_blocks = (cnt + 2047u) / 2048u; if (n_blocks > max_blocks) n_blocks = max_blocks; if (n_blocks == 0) n_blocks = 1;     // (>= 2 steps per wavefront)
-    const uint32_t tile = (uint32_t)((((uint64_t)cnt + n_blocks - 1) / n_blocks + 63) & ~63ull);     // whole wavefront steps
+    static const uint32_t ring_blocks = []() { const char* e = getenv("SFGPU_EQ_RING_BLOCKS"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 0); }();
+    bool ring = ring_mode != 0 && n_regions >= 2 && n_regions <= kRingMaxRegions;
+    uint32_t n_blocks, tile;
+    uint64_t cap, n_bins;
+    for (;;) {
+        uint32_t mb = ring ? (ring_blocks ? ring_blocks : (uint32_t)device_cus()) : max_blocks;
+        if (mb > 1024u) mb = 1024u;
+        n_blocks = (cnt + 2047u) / 2048u; if (n_blocks > mb) n_blocks = mb; if (n_blocks == 0) n_blocks = 1;     // (>= 2 steps per wavefront)
+        tile = (uint32_t)((((uint64_t)cnt + n_blocks - 1) / n_blocks + 63) & ~63ull);     // whole wavefront steps
     // Bin capacity in 16-byte granules.  A label of n ids takes ceil((n + 1) / 4) <= (n + 4) / 4 granules, so
     // (ids + 4 reads) / 4 bounds the stream from above; a bin gets its share of that bound plus 25 % and a constant --
     // the share is a sum of ~mean / 1.6 independent labels, so this is > 6 standard deviations for hashed labels.  A
     // region far above its share (one label holding a large part of the reads) overflows into the generic kernel's
     // list.  Rounded to whole 128-byte lines.
-    const uint64_t n_bins = (uint64_t)n_regions * n_blocks;
-    const uint64_t stream_gr = (n_words + 4ull * cnt) / 4 + 1;
-    uint64_t cap = (stream_gr + n_bins - 1) / n_bins;
-    cap = cap + cap / 4 + 48;
-    cap = (cap + 7) & ~7ull;
+        n_bins = (uint64_t)n_regions * n_blocks;
+        const uint64_t stream_gr = (n_words + 4ull * cnt) / 4 + 1;
+        cap = (stream_gr + n_bins - 1) / n_bins;
+        cap = cap + cap / 4 + 48;
+        cap = (cap + 7) & ~7ull;
+        if (ring && cap > kRingMaxCap) { ring = false; continue; }       // (16-bit cursors: few regions and a huge sub-batch take the direct form)
+        break;
+    }
     // positions inside the bins are 31-bit granule indices (bit 31 of a slot's rep marks arena entries)
     SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 granules");
     if ((rc = eq->part_words.reserve(n_bins * cap * 4 + 8, st, false))) return rc;
-    if ((rc = eq->part_hist.reserve(n_bins + 1, st, false))) return rc;          // fill of every bin
+    if ((rc = eq->part_hist.reserve(4 * n_bins + 1, st, false))) return rc;      // fill of every bin (front, back) + the ring form's cut marks
     if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
     if ((rc = eq->deferred_a.reserve(2ull * cnt, st, false))) return rc;
     hipLaunchKernelGGL(k_sub_batch_begin, dim3(1), dim3(64), 0, st, eq->d_ctr, d_offsets, peek[0], peek[1], peek[2]);   // CTR_NEW, CTR_DEFER, long-label counter
@@ -621,27 +645,40 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
         eq->hot_cap = 0; eq->hot_reads = 0;
     }
+    // (the ring form's LDS leaves room for kRingHotSlots entries: the table is laid out for the form this sub-batch takes)
+    const uint32_t hs = ring ? kRingHotSlots : kHotSlots;
     unsigned long long* hot_h = eq->hot_buf.p;
-    uint2* hot_meta = reinterpret_cast<uint2*>(hot_h + kHotSlots);
-    unsigned int* n_hot = reinterpret_cast<unsigned int*>(hot_h + 2ull * kHotSlots);
-    if (eq->n_classes && eq->reads_seen && (eq->hot_cap != eq->cap || eq->reads_seen >= 4 * eq->hot_reads)) {
+    uint2* hot_meta = reinterpret_cast<uint2*>(hot_h + hs);
+    unsigned int* n_hot = reinterpret_cast<unsigned int*>(hot_h + 2ull * hs);
+    if (eq->n_classes && eq->reads_seen && (eq->hot_cap != eq->cap || eq->hot_slots != hs || eq->reads_seen >= 4 * eq->hot_reads)) {
         const unsigned long long thr = std::max<unsigned long long>(64ull, eq->reads_seen / (8ull * n_regions));
         SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
-        hipLaunchKernelGGL(k_hot_select, dim3(grid_for(eq->cap)), dim3(kBlock), 0, st, eq->table.p, eq->cap, thr, eq->arena.p, hot_h, hot_meta, n_hot);
+        hipLaunchKernelGGL(k_hot_select, dim3(grid_for(eq->cap)), dim3(kBlock), 0, st, eq->table.p, eq->cap, thr, eq->arena.p, hot_h, hot_meta, n_hot, hs);
         SF_CHECK_LAUNCH();
-        eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen;
-    } else if (eq->hot_cap != eq->cap) {                 // (an empty table: nothing is hot)
+        eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen; eq->hot_slots = hs;
+    } else if (eq->hot_cap != eq->cap || eq->hot_slots != hs) {                 // (an empty table: nothing is hot)
         SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
-        eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen;
+        eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen; eq->hot_slots = hs;
     }
-    RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, eq->part_hist.p,
+    uint32_t* fill_f = eq->part_hist.p, *fill_b = fill_f + n_bins, *cutmarks = fill_b + n_bins;
+    RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
                  eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT};
-    const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
-    hipLaunchKernelGGL(k_part_route, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+    if (ring) {
+        const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 12;
+        static const bool attr_ok = []() {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_route<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        }();
+        (void)attr_ok;
+        hipLaunchKernelGGL(k_part_route<true>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+    } else {
+        const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
+        hipLaunchKernelGGL(k_part_route<false>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+    }
     SF_CHECK_LAUNCH();
-    PartArgs pa{eq->table.p, bins, eq->part_hist.p, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+    PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
                 eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes};
-    hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
+    static const bool skip_insert = getenv("SFGPU_X_SKIP_INSERT") != nullptr;      // (dev: timing experiments on pass 1 whose bins are not valid)
+    if (!skip_insert) hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev1, st));
     SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -946,12 +983,17 @@ int sfgpu_eq_add_weighted_device(sfgpu_eq* eq, const uint32_t* d_ids, const uint
                                  const uint64_t* d_counts, uint32_t n_groups) {
     SF_REQUIRE(eq && d_offsets && d_counts, SFGPU_ERR_INVALID, "sfgpu_eq_add_weighted: null pointer");
     std::lock_guard<std::mutex> lk(eq->mu);
-    return eq_add_locked(eq, d_ids, d_offsets, n_groups, d_counts);
+    int rc = eq_flush_dacc_locked(eq);                      // small device batches gathered earlier are built first (errors surface here, in order)
+    return rc ? rc : eq_add_locked(eq, d_ids, d_offsets, n_groups, d_counts);
 }
 
 int sfgpu_eq_get_stats(sfgpu_eq* eq, sfgpu_eq_stats* out) {
     SF_REQUIRE(eq && out, SFGPU_ERR_INVALID, "sfgpu_eq_get_stats: null pointer");
     std::lock_guard<std::mutex> lk(eq->mu);
+    // small batches are gathered before they are built (host: acc, device: dacc): build them so that the statistics -- and the
+    // class count a caller may be watching -- cover every read handed over so far
+    int rc;
+    if (!eq->finished) { if ((rc = eq_flush_acc_locked(eq))) return rc; if ((rc = eq_flush_dacc_locked(eq))) return rc; }
     *out = eq->stats;
     out->table_slots = eq->cap;
     return SFGPU_OK;

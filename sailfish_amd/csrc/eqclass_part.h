@@ -64,6 +64,32 @@ __device__ __forceinline__ uint32_t label_granules(uint32_t n) { return (n + 4u)
 // confined to 1 MB -- the rest is partial lines leaving the L2 (64 K open lines per XCD).
 constexpr int kStageWords = 512;                             // ids a wavefront stages per step (64 consecutive reads): 2 KB
 
+// ---- the RING form of pass 1 (round 3) ---------------------------------------------------------------------------------
+// What bounded the pass above was measured in round 2: 1.6 scattered 16-byte stores per label, each to a different bin, whose
+// 128-byte lines leave the L2 half full (512 blocks x 1024 bins = 64 K open lines per XCD): WRITE_SIZE 1.8x the payload, the
+// texture addresser busy 12.2 of 12.5 cycles per read.  The ring form keeps the tail of every bin of the block in LDS -- a
+// ring of two 64-byte UNITS (4 granules each) per region, 128 KB for 1024 regions, ONE block per CU -- and only whole units
+// leave the CU, four lanes per unit, 16 units per store instruction: every 64-byte segment of the stream is written once, whole.
+//   * cbst[r].x = front cursor (low 16 bits) | back cursor (high 16 bits), in granules.  Labels of <= 4 granules (98.7 % of
+//     the benchmark's) grow the bin from its front through the ring; longer ones are stored directly, as before, from the
+//     bin's BACK downwards (they are runs of >= 80 contiguous bytes anyway): pass 2 streams both segments.  One returning LDS
+//     atomic gives a lane both cursors, so "does it fit" is exact.
+//   * cbst[r].y = per unit parity q (16 bits each): granules written into the open unit of that parity (3 bits) | units of
+//     that parity flushed so far (12 bits).  Granule p lives in unit v = p / 4, ring slot p % 8; unit v may be written when
+//     v / 2 units of its parity have been flushed (the ring slot is free).  A writer adds its granules to the counts AFTER
+//     writing them; the add that brings a count to 4 makes its lane the unit's COMPLETER: the wavefront flushes the completed
+//     units of the step together, then the completers add 4 -- count back to 0, carry into the flushed field -- which opens
+//     the slot for unit v + 2.  A lane that finds its unit closed (the ring is two units deep; it needs 3+ labels of a region
+//     in flight at once) retries after the flush; no lane ever holds a completed unit while it waits, so this cannot deadlock.
+//   * LDS executes a wavefront's instructions in order, which is what orders granule write -> count add -> (completer) unit
+//     read -> release add between wavefronts; the fences below are for the compiler.
+// What is left in the ring when the block ends (the last, partial unit of every bin) is written by one thread per region.
+constexpr int kRingStageWords = 304;                          // staging per wavefront: (304 / 4 + 4) x 16 B = 1280 B (mean step: 256 ids; beyond: labels from global memory)
+constexpr uint32_t kRingHotSlots = 256;                       // what 160 KB leave for the hot table
+constexpr uint32_t kRingMaxRegions = 1024;                    // 128 B of ring per region
+constexpr uint32_t kRingMaxCap = 32000;                       // 16-bit cursors with room for the reservations of every lane in flight
+constexpr uint32_t kRingFrontGranules = 4;                    // labels of more granules take the back of the bin
+
 struct RouteArgs {
     const uint32_t* ids; const uint32_t* off;      // off is already advanced to the sub-batch's first read
     uint32_t first;                                // index of that read in the caller's batch (for the generic kernel's list)
@@ -73,7 +99,9 @@ struct RouteArgs {
     uint32_t cap;                                  // granules per bin
     uint4* out;                                    // bins: bin (r, b) starts at granule (b * n_regions + r) * cap -- a block's bins are one window
                                                    // of memory (region-major, every store of a block hit a different 2 MB page)
-    uint32_t* fill;                                // fill[r * n_blocks + b] = granules written to bin (r, b)
+    uint32_t* fill;                                // fill[r * n_blocks + b] = granules written to bin (r, b) (from its front)
+    uint32_t* fill_back;                           // ... and from its back (ring form; 0 otherwise)
+    uint32_t* cut;                                 // ring form: cut[(b * n_regions + r) * 2 + side] = first granule that did not fit
     unsigned long long* n_long; uint32_t* long_list;     // reads for the generic kernel
     // HOT classes (k_hot_select): labels that already hold so many reads that they would overflow their region's bins.  A read
     // with such a label is counted in LDS and never enters the stream; the counts go to the table when the block ends.
@@ -87,12 +115,12 @@ struct RouteArgs {
 constexpr uint32_t kCountedBit = 0x80000000u;          // in H: the label is followed by a granule [count, 0, 0, 0]
 constexpr uint32_t kHotSlots = 1024;
 constexpr uint32_t kHotProbes = 4;
-__device__ __forceinline__ uint32_t hot_index(uint64_t h) { return (uint32_t)(h >> 40) & (kHotSlots - 1); }   // (bits the region / slot / tag do not use alone)
+__device__ __forceinline__ uint32_t hot_index(uint64_t h, uint32_t slots) { return (uint32_t)(h >> 40) & (slots - 1u); }   // (bits the region / slot / tag do not use alone)
 
-// classes of the table that hold >= thr reads -> hot table (first come per slot; the table is rebuilt before every route pass:
-// growth moves the slots).  One thread per table slot.
+// classes of the table that hold >= thr reads -> hot table of `slots` entries (a power of two; first come per slot; the table
+// is rebuilt before every route pass: growth moves the slots).  One thread per table slot.
 __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slots, unsigned long long thr, const uint32_t* __restrict__ arena,
-                             unsigned long long* hot_h, uint2* hot_meta, unsigned int* n_hot) {
+                             unsigned long long* hot_h, uint2* hot_meta, unsigned int* n_hot, uint32_t slots) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const uint64_t w = table[2 * s];
@@ -106,7 +134,7 @@ __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slot
     const uint64_t h = label_mix64([&](uint32_t k) { return e[1 + k]; }, len, tmp);
     if (h == 0) return;
     for (uint32_t p = 0; p < kHotProbes; ++p) {                        // short linear probing; a class that finds no place is not hot
-        const uint32_t idx = (hot_index(h) + p) & (kHotSlots - 1);
+        const uint32_t idx = (hot_index(h, slots) + p) & (slots - 1u);
         if (atomicCAS(&hot_h[idx], 0ull, (unsigned long long)h) == 0ull) { hot_meta[idx] = make_uint2(rep & ~kArenaBit, (uint32_t)s); atomicAdd(n_hot, 1u); break; }
     }
 }
@@ -116,22 +144,35 @@ __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slot
 // buffer with coalesced, 16-byte-aligned loads (lane-per-label loads from global memory cost the texture addresser one
 // cycle per lane and dword: measured TA-bound, profiles/r2_class_build_notes.md); the lanes then pick their labels out
 // of LDS.  The next step's offsets and ids are requested before this step's labels are hashed.
-__global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// RING = false: the form of round 2 (any number of regions, two blocks per CU); RING = true: bins written through LDS rings.
+template <bool RING>
+__global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(RING ? 4 : 8, RING ? 4 : 8)))
 k_part_route(RouteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SW = RING ? kRingStageWords : kStageWords;
+    constexpr uint32_t HS = RING ? kRingHotSlots : kHotSlots;
     const uint32_t NR = a.region_mask + 1u;
-    unsigned int* cur = reinterpret_cast<unsigned int*>(smem);                        // NR: granules taken from my bin of region r
-    unsigned int* cut = cur + NR;                                                     // NR: first granule of a label that did not fit
+    // LDS: [ring: NR x 8 granules] | per region 2 words (RING: {cursors, unit state}; else {cursor, cut}) | staging | hot table
+    uint4* ring4 = reinterpret_cast<uint4*>(smem);
+    unsigned int* cur = reinterpret_cast<unsigned int*>(smem + (RING ? (size_t)NR * 128u : 0u));      // !RING: NR: granules taken from my bin of region r
+    unsigned int* cut = cur + NR;                                                     // !RING: NR: first granule of a label that did not fit
+    uint2* cbst = reinterpret_cast<uint2*>(cur);                                      // RING: NR x {cursors, unit state}
     const uint32_t B1 = gridDim.x, blk = blockIdx.x, cap = a.cap, tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
-    uint4* stage4 = reinterpret_cast<uint4*>(cut + NR) + wave * (kStageWords / 4 + 4);   // this wavefront's staging buffer (+ slack)
+    uint4* stage4 = reinterpret_cast<uint4*>(cut + NR) + wave * (SW / 4 + 4);   // this wavefront's staging buffer (+ slack)
     const uint32_t* stage = reinterpret_cast<const uint32_t*>(stage4);
-    for (uint32_t r = tid; r < NR; r += kPartBlock) { cur[r] = 0; cut[r] = 0xFFFFFFFFu; }
+    if constexpr (RING) {
+        for (uint32_t r = tid; r < NR; r += kPartBlock) cbst[r] = make_uint2(0u, 0u);
+        for (uint32_t r = tid; r < 2u * NR; r += kPartBlock) a.cut[(size_t)blk * NR * 2u + r] = 0xFFFFFFFFu;
+        __threadfence();                                                              // (a later atomicMin of another wavefront finds it)
+    } else {
+        for (uint32_t r = tid; r < NR; r += kPartBlock) { cur[r] = 0; cut[r] = 0xFFFFFFFFu; }
+    }
     // hot classes: their bucket hashes and a counter each, behind the staging buffers
-    unsigned long long* hot_hl = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint4*>(cut + NR) + kPartWaves * (kStageWords / 4 + 4));
-    unsigned int* hot_cnt = reinterpret_cast<unsigned int*>(hot_hl + kHotSlots);
-    const bool have_hot = *reinterpret_cast<const unsigned int*>(a.hot + 2 * kHotSlots) != 0u;      // (uniform)
-    if (have_hot) for (uint32_t q = tid; q < kHotSlots; q += kPartBlock) { hot_hl[q] = a.hot[q]; hot_cnt[q] = 0u; }
+    unsigned long long* hot_hl = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint4*>(cut + NR) + kPartWaves * (SW / 4 + 4));
+    unsigned int* hot_cnt = reinterpret_cast<unsigned int*>(hot_hl + HS);
+    const bool have_hot = *reinterpret_cast<const unsigned int*>(a.hot + 2 * HS) != 0u;      // (uniform)
+    if (have_hot) for (uint32_t q = tid; q < HS; q += kPartBlock) { hot_hl[q] = a.hot[q]; hot_cnt[q] = 0u; }
     const uint32_t t0 = blk * a.tile;
     const uint32_t t1 = (t0 + a.tile < a.n && t0 + a.tile > t0) ? t0 + a.tile : a.n;
     const uint32_t* __restrict__ off = a.off;
@@ -150,24 +191,29 @@ k_part_route(RouteArgs a) {
         const uint32_t n4 = (w_hi - w_lo + mis + 3u) >> 2;
         const uint4* src = reinterpret_cast<const uint4*>(ids + w_lo - mis);
         x0 = make_uint4(0u, 0u, 0u, 0u); x1 = x0;
-        if (lane < n4 && n4 <= (uint32_t)kStageWords / 4) x0 = src[lane];
-        if (lane + 64u < n4 && n4 <= (uint32_t)kStageWords / 4) x1 = src[lane + 64u];
+        if (lane < n4 && n4 <= (uint32_t)SW / 4) x0 = src[lane];
+        if (lane + 64u < n4 && n4 <= (uint32_t)SW / 4) x1 = src[lane + 64u];
     };
     uint32_t r0 = t0 + 64u * wave;
-    uint32_t o = 0, oe = 0, no = 0, noe = 0;
+    uint32_t o = 0, oe = 0, no = 0, noe = 0, nno = 0, nnoe = 0;
     uint4 x0 = make_uint4(0u, 0u, 0u, 0u), x1 = x0;
     if (r0 < t1) {
         offsets(r0, o, oe);
+        if (RING && r0 + 64u * kPartWaves < t1) offsets(r0 + 64u * kPartWaves, no, noe);
         fetch(__shfl(o, 0, kWave), oe, x0, x1);
     }
     for (; r0 < t1; r0 += 64u * kPartWaves) {
         const uint32_t nr0 = r0 + 64u * kPartWaves;
-        if (nr0 < t1) offsets(nr0, no, noe);                                            // the next step's offsets travel now
+        // the next step's offsets travel now (ring form, one block per CU: the offsets of the step after it -- the ids of the
+        // next step are then requested with offsets that arrived a whole step ago)
+        if constexpr (RING) { if (nr0 + 64u * kPartWaves < t1) offsets(nr0 + 64u * kPartWaves, nno, nnoe); }
+        else { if (nr0 < t1) offsets(nr0, no, noe); }
         const uint32_t re = (r0 + 64u < t1) ? r0 + 64u : t1;
         const uint32_t w_lo = __shfl(o, 0, kWave), w_hi = oe;
         const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(ids + w_lo) >> 2) & 3u);
-        const bool staged = ((w_hi - w_lo + mis + 3u) >> 2) <= (uint32_t)kStageWords / 4;
-        stage4[lane] = x0; stage4[lane + 64u] = x1;
+        const bool staged = ((w_hi - w_lo + mis + 3u) >> 2) <= (uint32_t)SW / 4;
+        stage4[lane] = x0;
+        if (SW / 4 > 64 && lane + 64u < (uint32_t)SW / 4 + 4u) stage4[lane + 64u] = x1;
         // my label: [b, e)
         const uint32_t nxt = __shfl_down(o, 1, kWave);
         const uint32_t b = o, e = (lane == 63u || r0 + lane + 1u >= re) ? oe : nxt;
@@ -189,26 +235,35 @@ k_part_route(RouteArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < kHead; ++q) { w[q] = ((uint32_t)q < len) ? w[q] : 0u; mx = mx > w[q] ? mx : w[q]; }
+#ifdef SFGPU_X_SHORT_ONLY
+        const bool unfit = len > 7u;                        // (experiment: what do the long-label loops cost)
+#else
         const bool unfit = len > kMaxPartLabel;
+#endif
         // bucket hash: 8 rounds over the (zero padded) head, then one round per further id (label_mix64_words' chain)
         uint32_t ha = MP1 + len, hb = 0x27D4EB2Fu ^ (len * MP3);
 #pragma unroll
         for (int q = 0; q < kHead; ++q) mix_round(ha, hb, w[q]);
         const uint32_t ng = label_granules(len);
+        // granule g >= 2 of my label (ids 4g-1 .. 4g+2, zero padded)
+        auto granule = [&](uint32_t g) -> uint4 {
+            const uint32_t q = 4u * g - 1u;
+            uint32_t v0, v1, v2, v3;
+            if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
+            else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
+            return make_uint4(v0, q + 1 < len ? v1 : 0u, q + 2 < len ? v2 : 0u, q + 3 < len ? v3 : 0u);
+        };
         // ids 7.. come one granule (ids 4g-1 .. 4g+2) at a time; labels of > 7 ids are 13 % of the reads, so this path is
         // taken by some lane of nearly every wavefront and must not be a chain of dependent global loads
         if (len > (uint32_t)kHead && !unfit) {
             for (uint32_t g = 2; g < ng; ++g) {
                 const uint32_t q = 4u * g - 1u;
-                uint32_t v0, v1, v2, v3;
-                if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
-                else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
-                v1 = q + 1 < len ? v1 : 0u; v2 = q + 2 < len ? v2 : 0u; v3 = q + 3 < len ? v3 : 0u;
-                if (q >= (uint32_t)kHead) mix_round(ha, hb, v0);
-                if (q + 1 < len) mix_round(ha, hb, v1);
-                if (q + 2 < len) mix_round(ha, hb, v2);
-                if (q + 3 < len) mix_round(ha, hb, v3);
-                mx = mx > v0 ? mx : v0; mx = mx > v1 ? mx : v1; mx = mx > v2 ? mx : v2; mx = mx > v3 ? mx : v3;
+                const uint4 v = granule(g);
+                if (q >= (uint32_t)kHead) mix_round(ha, hb, v.x);
+                if (q + 1 < len) mix_round(ha, hb, v.y);
+                if (q + 2 < len) mix_round(ha, hb, v.z);
+                if (q + 3 < len) mix_round(ha, hb, v.w);
+                mx = mx > v.x ? mx : v.x; mx = mx > v.y ? mx : v.y; mx = mx > v.z ? mx : v.z; mx = mx > v.w ? mx : v.w;
             }
         }
         const uint64_t h = ((uint64_t)mix_fin(ha ^ hb) << 32) | mix_fin(hb + (ha >> 3));
@@ -237,45 +292,166 @@ k_part_route(RouteArgs a) {
         if (dm && !dup) { const unsigned long long after = lane == 63u ? 0ull : (dm >> (lane + 1u)); mult = 1u + (uint32_t)__builtin_ctzll(~after); }
         bool counted = false;
         if (have_hot && len != 0 && !generic && !dup) {
-            uint32_t hi = hot_index(h);
+            uint32_t hi = hot_index(h, HS);
             unsigned long long hv = hot_hl[hi];
-            for (uint32_t p = 1; p < kHotProbes && hv != 0ull && hv != h; ++p) { hi = (hi + 1) & (kHotSlots - 1); hv = hot_hl[hi]; }
+            for (uint32_t p = 1; p < kHotProbes && hv != 0ull && hv != h; ++p) { hi = (hi + 1) & (HS - 1); hv = hot_hl[hi]; }
             if (hv == h) {
                 // same bucket hash: the label itself decides (arena entry [n, id0, id1, id2][id3 .. id6] ...; a label in
                 // granule form is the same from the second granule on)
-                const uint4* e = reinterpret_cast<const uint4*>(a.arena) + reinterpret_cast<const uint2*>(a.hot + kHotSlots)[hi].x;
+                const uint4* e = reinterpret_cast<const uint4*>(a.arena) + reinterpret_cast<const uint2*>(a.hot + HS)[hi].x;
                 const uint4 e0 = e[0];
                 bool same = e0.x == len && e0.y == w[0] && e0.z == w[1] && e0.w == w[2];
                 if (same && len > 3u) { const uint4 e1 = e[1]; same = e1.x == w[3] && e1.y == w[4] && e1.z == w[5] && e1.w == w[6]; }
                 for (uint32_t g = 2; same && g < ng; ++g) {
-                    const uint32_t q = 4u * g - 1u;
-                    uint32_t v0, v1, v2, v3;
-                    if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
-                    else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
-                    const uint4 eg = e[g];
-                    same = eg.x == v0 && eg.y == (q + 1 < len ? v1 : 0u) && eg.z == (q + 2 < len ? v2 : 0u) && eg.w == (q + 3 < len ? v3 : 0u);
+                    const uint4 v = granule(g), eg = e[g];
+                    same = eg.x == v.x && eg.y == v.y && eg.z == v.z && eg.w == v.w;
                 }
                 if (same) { atomicAdd(&hot_cnt[hi], mult); counted = true; }
             }
         }
-        if (len != 0 && !generic && !counted && !dup) {
-            const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
-            const uint32_t at = atomicAdd(&cur[rg], ngx);                               // my granules in the bin (rg, blk)
-            if (at + ngx <= cap) {
-                uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
-                dst[0] = make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]);
-                if (mult > 1u) dst[ng] = make_uint4(mult, kCountedBit, 0u, 0u);      // (bit 31 of .y: no id has it -- such labels take the generic kernel)
-                if (len > 3u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
-                for (uint32_t g = 2; g < ng; ++g) {
-                    const uint32_t q = 4u * g - 1u;
-                    uint32_t v0, v1, v2, v3;
-                    if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
-                    else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
-                    dst[g] = make_uint4(v0, q + 1 < len ? v1 : 0u, q + 2 < len ? v2 : 0u, q + 3 < len ? v3 : 0u);
+        const bool place = len != 0 && !generic && !counted && !dup;
+        const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
+        auto head_granule = [&]() { return make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]); };
+        auto count_granule = [&]() { return make_uint4(mult, kCountedBit, 0u, 0u); };       // (bit 31 of .y: no id has it -- such labels take the generic kernel)
+        if constexpr (!RING) {
+            if (place) {
+                const uint32_t at = atomicAdd(&cur[rg], ngx);                               // my granules in the bin (rg, blk)
+                if (at + ngx <= cap) {
+                    uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
+                    dst[0] = head_granule();
+                    if (mult > 1u) dst[ng] = count_granule();
+                    if (len > 3u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                    for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
+                } else {
+                    atomicMin(&cut[rg], at);                                                // the bin ends before this label
+                    generic = true;
                 }
-            } else {
-                atomicMin(&cut[rg], at);                                                // the bin ends before this label
-                generic = true;
+            }
+        } else {
+            // ---- reservation: front (through the ring) or back (direct stores) of the bin (rg, blk)
+            bool front = false;
+            uint32_t at = 0;
+            uint32_t stv = 0;
+            uint4 G[kRingFrontGranules];
+#pragma unroll
+            for (int j = 0; j < (int)kRingFrontGranules; ++j) G[j] = count_granule();
+            if (place) {
+                const uint2 cs = cbst[rg];                                                   // (a stale unit state is safe: it can only say "closed")
+                stv = cs.y;
+                if ((cs.x & 0xFFFFu) + (cs.x >> 16) + ngx > cap) generic = true;             // does not fit, and never will: nothing reserved
+                else if (ngx <= kRingFrontGranules) {
+                    const uint32_t old = atomicAdd(&cbst[rg].x, ngx);
+                    at = old & 0xFFFFu;
+                    if (at + ngx + (old >> 16) <= cap) {
+                        front = true;
+                        G[0] = head_granule();
+                        if (len > 3u) G[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                        if (ng > 2u) G[2] = granule(2);
+                        if (ng > 3u) G[3] = granule(3);
+                    } else {                                                                 // lost a race for the last room: the front ends before this label
+                        atomicMin(&a.cut[((size_t)blk * NR + rg) * 2u], at); __threadfence();
+                        generic = true;
+                    }
+                } else {
+                    const uint32_t old = atomicAdd(&cbst[rg].x, ngx << 16);
+                    const uint32_t bk = old >> 16;
+                    if ((old & 0xFFFFu) + bk + ngx <= cap) {
+                        uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + (cap - bk - ngx);
+                        dst[0] = head_granule();
+                        if (mult > 1u) dst[ng] = count_granule();
+                        dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                        for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
+                    } else {
+                        atomicMin(&a.cut[((size_t)blk * NR + rg) * 2u + 1u], bk); __threadfence();
+                        generic = true;
+                    }
+                }
+            }
+            // ---- the ring: every lane is done with the staged ids (G is in registers), the staging buffer now holds the flush list
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // a label touches at most two units: u0 (its first n0 granules) and u0 + 1 (the other n1)
+            const uint32_t u0 = at >> 2, q0 = u0 & 1u;
+            const uint32_t n0 = (4u - (at & 3u)) < ngx ? (4u - (at & 3u)) : ngx, n1 = ngx - n0;
+            auto is_open = [&](uint32_t v, uint32_t sv) { return ((v >> 1) & 0xFFFu) == ((sv >> (16u * (v & 1u) + 3u)) & 0xFFFu); };
+            uint32_t* flist = reinterpret_cast<uint32_t*>(stage4);
+            bool c0 = false, c1 = false;                                                      // completed: unit u0 / unit u0 + 1
+            // the usual step: every unit a lane needs is open -- write, count, flush once
+            bool more = front;
+            const bool fast = front && is_open(u0, stv) && (n1 == 0u || is_open(u0 + 1u, stv));
+            if (fast) {
+#pragma unroll
+                for (uint32_t j = 0; j < kRingFrontGranules; ++j) if (j < ngx) ring4[rg * 8u + ((at + j) & 7u)] = G[j];
+                const uint32_t add = (n0 << (16u * q0)) | (n1 << (16u * (q0 ^ 1u)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef SFGPU_X_NORING
+                const uint32_t nw = cap == 0xFFFFFFFFu ? atomicAdd(&cbst[rg].y, add) + add : 0u;
+#else
+                const uint32_t nw = atomicAdd(&cbst[rg].y, add) + add;
+#endif
+                c0 = ((nw >> (16u * q0)) & 7u) == 4u;
+                c1 = n1 != 0u && ((nw >> (16u * (q0 ^ 1u))) & 7u) == 4u;
+                more = false;
+            }
+            // flush the units this step completed: four lanes per unit, 16 units per store instruction; then the completers
+            // release the ring slots (count back to 0, one more unit of that parity flushed)
+            auto flush = [&]() {
+                const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+                if (m0 | m1) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const uint32_t k_n0 = (uint32_t)__builtin_popcountll(m0), K = k_n0 + (uint32_t)__builtin_popcountll(m1);
+                    if (c0) flist[__builtin_popcountll(m0 & below)] = rg | (u0 << 10);
+                    if (c1) flist[k_n0 + __builtin_popcountll(m1 & below)] = rg | ((u0 + 1u) << 10);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (uint32_t k0 = 0; k0 < K; k0 += 16u) {
+                        const uint32_t k = k0 + (lane >> 2);
+#ifdef SFGPU_X_NOFLUSH
+                        if (k < K && cap == 0xFFFFFFFFu) {
+#else
+                        if (k < K) {
+#endif
+                            const uint32_t e = flist[k], r = e & 1023u, v = e >> 10;
+                            a.out[(size_t)(blk * NR + r) * cap + 4u * v + (lane & 3u)] = ring4[r * 8u + ((v & 1u) << 2) + (lane & 3u)];
+                        }
+                    }
+                    // the units' granules have been read (LDS is in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (c0 | c1) atomicAdd(&cbst[rg].y, (c0 ? (4u << (16u * q0)) : 0u) | (c1 ? (4u << (16u * (q0 ^ 1u))) : 0u));
+                }
+            };
+            flush();
+            // the rare step: some lane found a unit closed (the ring is two units deep: it takes three labels of one region in
+            // flight at once, or a slow completer in another wavefront).  Granule by granule, until every lane is through; a lane
+            // never holds a completed unit while it waits, so the completers it waits for always get to flush.
+            uint32_t wr = 0;
+            while (__ballot(more)) {
+                c0 = false; c1 = false;
+                if (more) {
+                    __builtin_amdgcn_s_sleep(1);
+                    stv = __hip_atomic_load(&cbst[rg].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t add = 0;
+                    bool open = true;
+                    for (uint32_t j = wr; open && j < ngx; ++j) {
+                        const uint32_t p = at + j, v = p >> 2;
+                        if (is_open(v, stv)) {
+                            uint4 gj = G[0];
+                            if (j == 1u) gj = G[1]; else if (j == 2u) gj = G[2]; else if (j == 3u) gj = G[3];
+                            ring4[rg * 8u + (p & 7u)] = gj; add += 1u << (16u * (v & 1u)); wr = j + 1u;
+                        } else open = false;
+                    }
+                    if (add) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        const uint32_t nw = atomicAdd(&cbst[rg].y, add) + add;
+                        const uint32_t a0 = (add >> (16u * q0)) & 7u, a1 = (add >> (16u * (q0 ^ 1u))) & 7u;
+                        c0 = a0 != 0u && ((nw >> (16u * q0)) & 7u) == 4u;
+                        c1 = a1 != 0u && ((nw >> (16u * (q0 ^ 1u))) & 7u) == 4u;
+                    }
+                    more = wr < ngx;
+                }
+                flush();
             }
         }
         {
@@ -300,14 +476,29 @@ k_part_route(RouteArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                      // every lane is done with the staged ids before they are replaced
         o = no; oe = noe;
+        if constexpr (RING) { no = nno; noe = nnoe; }
     }
     __syncthreads();
-    for (uint32_t r = tid; r < NR; r += kPartBlock) { const unsigned int c = cur[r], x = cut[r]; a.fill[r * B1 + blk] = c < x ? c : x; }
+    if constexpr (!RING) {
+        for (uint32_t r = tid; r < NR; r += kPartBlock) { const unsigned int c = cur[r], x = cut[r]; a.fill[r * B1 + blk] = c < x ? c : x; a.fill_back[r * B1 + blk] = 0u; }
+    } else {
+        // what the rings still hold: the last, partial unit of every bin
+        for (uint32_t r = tid; r < NR; r += kPartBlock) {
+            const uint32_t c = cbst[r].x;
+            const uint32_t xf = a.cut[((size_t)blk * NR + r) * 2u], xb = a.cut[((size_t)blk * NR + r) * 2u + 1u];
+            const uint32_t f = (c & 0xFFFFu) < xf ? (c & 0xFFFFu) : xf, bk = (c >> 16) < xb ? (c >> 16) : xb;
+            const uint32_t v = f >> 2;
+            for (uint32_t j = 0; j < (f & 3u); ++j) a.out[(size_t)(blk * NR + r) * cap + 4u * v + j] = ring4[r * 8u + ((v & 1u) << 2) + j];
+            a.fill[r * B1 + blk] = f; a.fill_back[r * B1 + blk] = bk;
+        }
+    }
     if (have_hot) {
-        static_assert(kHotSlots == kPartBlock, "one hot slot per thread");
-        const unsigned int c = hot_cnt[tid];
-        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2ull * reinterpret_cast<const uint2*>(a.hot + kHotSlots)[tid].y + 1]), (unsigned long long)c);
-        unsigned int tot = c;
+        unsigned int tot = 0;
+        for (uint32_t q = tid; q < HS; q += kPartBlock) {
+            const unsigned int c = hot_cnt[q];
+            if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2ull * reinterpret_cast<const uint2*>(a.hot + HS)[q].y + 1]), (unsigned long long)c);
+            tot += c;
+        }
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, kWave);
         if (lane == 0 && tot) atomicAdd(a.n_hot_reads, (unsigned long long)tot);
     }
@@ -316,7 +507,8 @@ k_part_route(RouteArgs a) {
 struct PartArgs {
     uint64_t* table;                       // {word, count} pairs
     const uint4* bins;                     // granules
-    const uint32_t* fill; uint32_t n_blocks; uint32_t cap;     // region r: bins (r, 0 .. n_blocks), fill granules of cap each
+    const uint32_t* fill; const uint32_t* fill_back; uint32_t n_blocks; uint32_t cap;     // region r: bins (r, 0 .. n_blocks) of cap granules each: fill from the
+                                                               // front, fill_back from the back (the ring form of pass 1 puts long labels there)
     uint64_t* cls_hash; uint64_t* cls_off; uint32_t* cls_len; uint32_t* cls_slot; uint32_t* arena;
     unsigned long long* ctr;               // CTR_* counters (classes / arena cursor / deferred)
     uint32_t* deferred;                    // (granule index of the label in the bins, length) of labels that found their region full
@@ -355,9 +547,11 @@ k_part_insert(PartArgs a) {
     const uint32_t region = blockIdx.x;
     const uint64_t rb = (uint64_t)region * kRegionSlots;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // this wavefront's bins: lane t holds the fill of bin wave + 16 t
+    // this wavefront's bins: lane t holds the fills of bin wave + 16 t.  A bin is two SEGMENTS of whole labels: [0, fill) and
+    // [cap - fill_back, cap); segment t < 64 is the front of bin t, segment 64 + t its back
     const uint32_t my_bin = wave + kPartWaves * lane;
     const uint32_t my_fill = (my_bin < a.n_blocks) ? a.fill[region * a.n_blocks + my_bin] : 0u;
+    const uint32_t my_back = (my_bin < a.n_blocks) ? a.fill_back[region * a.n_blocks + my_bin] : 0u;
 
     if (threadIdx.x == 0) { s_occ = 0; s_ncls = 0; s_nnew = 0; s_newwords = 0; }
     for (uint32_t c = threadIdx.x; c < kMaxRegionClasses; c += kPartBlock) ccnt[c] = 0;
@@ -385,17 +579,27 @@ k_part_insert(PartArgs a) {
     const uint32_t n_old = s_nold;
 
     uint4* tile = wtile[wave];
-    const unsigned long long have = __ballot(my_fill != 0u);
-    auto next_bin = [&](int after) -> int {             // first bin t > after with granules in it, -1 if none
-        const unsigned long long m = (after >= 63) ? 0ull : (have & (~0ull << (after + 1)));
-        return m ? (int)__builtin_ctzll(m) : -1;
+    const unsigned long long have_f = __ballot(my_fill != 0u), have_b = __ballot(my_back != 0u);
+    auto next_bin = [&](int after) -> int {             // first segment t > after with granules in it, -1 if none
+        if (after < 63) {
+            const unsigned long long m = have_f & (~0ull << (after + 1));
+            if (m) return (int)__builtin_ctzll(m);
+            return have_b ? 64 + (int)__builtin_ctzll(have_b) : -1;
+        }
+        const unsigned long long m = (after >= 127) ? 0ull : (have_b & (~0ull << (after - 63)));
+        return m ? 64 + (int)__builtin_ctzll(m) : -1;
+    };
+    // first granule (index into a.bins) and length of segment t
+    auto segment = [&](int t, uint32_t& sb, uint32_t& sn) {
+        const uint32_t bin0 = ((wave + kPartWaves * (uint32_t)(t & 63)) * gridDim.x + region) * a.cap;
+        if (t < 64) { sb = bin0; sn = __shfl(my_fill, t, kWave); }
+        else { sn = __shfl(my_back, t - 64, kWave); sb = bin0 + a.cap - sn; }
     };
     int t = next_bin(-1);
-    uint32_t base = 0, n_gr = 0, pos = 0;                // current bin: first granule (index into a.bins), granules, position
+    uint32_t base = 0, n_gr = 0, pos = 0;                // current segment: first granule (index into a.bins), granules, position
     uint4 g = make_uint4(0u, 0u, 0u, 0u);
     if (t >= 0) {
-        base = ((wave + kPartWaves * (uint32_t)t) * gridDim.x + region) * a.cap;
-        n_gr = __shfl(my_fill, t, kWave);
+        segment(t, base, n_gr);
         if (lane < n_gr) g = a.bins[base + lane];
     }
     if (lane < 2u) tile[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -417,7 +621,7 @@ k_part_insert(PartArgs a) {
         int nt = t; uint32_t nbase = base, nn_gr = n_gr, npos = pos + adv;
         if (npos >= n_gr) {
             nt = next_bin(t);
-            if (nt >= 0) { nbase = ((wave + kPartWaves * (uint32_t)nt) * gridDim.x + region) * a.cap; nn_gr = __shfl(my_fill, nt, kWave); npos = 0; }
+            if (nt >= 0) { segment(nt, nbase, nn_gr); npos = 0; }
         }
         uint4 gn = make_uint4(0u, 0u, 0u, 0u);
         if (nt >= 0 && npos + lane < nn_gr) gn = a.bins[nbase + npos + lane];

@@ -105,7 +105,7 @@ class HipEngine:
         from .eqclass import EqVec
         w = len(blocks)
         n = sum(c for c, _ in sizes); l = sum(x for _, x in sizes)
-        if l >= 2 ** 32 or n >= 2 ** 32:
+        if l >= 2 ** 32 or n >= 2 ** 32 or w > 64:        # (sfgpu_eqvec_merge_disjoint takes <= 64 partitions: the caller folds instead)
             return None
         dev = self.device
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev); ids = torch.empty(l, dtype=torch.int32, device=dev)

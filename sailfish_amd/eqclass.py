@@ -81,14 +81,16 @@ class EquivalenceClassBuilder:
         n = int(offsets.shape[0]) - 1
         if n <= 0:
             return
-        on_dev = isinstance(ids, torch.Tensor) and ids.is_cuda
+        # device path only when BOTH arrays already live on a device; a mixed pair is taken through the host path
+        on_dev = (isinstance(ids, torch.Tensor) and ids.is_cuda) and (isinstance(offsets, torch.Tensor) and offsets.is_cuda)
         if on_dev:
             ids_t = _as_dev_u32(ids, self.device); off_t = _as_dev_u32(offsets, self.device)
             torch.cuda.current_stream().synchronize()   # the builder works on its creation stream
             _lib.check(self._L.sfgpu_eq_add_batch_device(self._h, _lib.ptr(ids_t), _lib.ptr(off_t), n))
         else:
-            def _host_u32(a):          # no copy for 32-bit integer arrays (a pinned 8 GB batch must stay where it is)
-                a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+            def _host_u32(a):          # no copy for 32-bit integer HOST arrays (a pinned 8 GB batch must stay where it is); other
+                                       # integer types are narrowed with one copy, device tensors of a mixed pair come to the host
+                a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
                 a = np.ascontiguousarray(a)
                 return a.view(np.uint32) if a.dtype in (np.int32, np.uint32) else a.astype(np.uint32)
             ids_h, off_h = _host_u32(ids), _host_u32(offsets)
