@@ -53,8 +53,11 @@ def parse():
     ap.add_argument("--no-host-pinned", action="store_true", help="skip the leg that re-runs the step with the hit lists in pinned host memory")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--one-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--compare-em-modes", action="store_true",
-                    help="N > 1: after the timed steps also run one step in the OTHER EM mode (sharded <-> replicated) and report it")
+    ap.add_argument("--no-compare-em-modes", action="store_true",
+                    help="N > 1: skip the step in the OTHER EM mode (sharded <-> replicated) that is run and reported after the timed steps")
+    ap.add_argument("--no-sampling", action="store_true", help="N = 1: skip the bootstrap / Gibbs (BASELINE config 5) legs after the timed steps")
+    ap.add_argument("--gibbs-draws", type=int, default=1000)
+    ap.add_argument("--bootstrap-draws", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -162,6 +165,10 @@ def cpu_baseline(ref_len_np, ids_t, off_t, target_s, use_vbem):
                 sample_classes=int(b.n_classes), sample_nnz=int(b.nnz), sample_em_iters=n_it, parity=parity, all_cores=mt)
 
 
+def info_total_reads(info, quant):
+    return int(quant.last_vec.total_reads)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -239,11 +246,24 @@ def main():
     # buffers (copy of chunk k + 1 on its own stream while chunk k is built), so the step costs its PCIe transfer plus
     # the build of the last chunk plus EM.  PCIe-inclusive: reported next to `value`, never as `value`.
     host_leg = None
-    if not a.no_host_pinned and world == 1:       # (an N = 1 figure; at N > 1 a rank that failed here would leave the others in a collective)
+    if not a.no_host_pinned:
+        # every rank pins ITS shard (its own PCIe link); a rank that cannot (pinned allocation) must not leave the others in a
+        # collective: the ok flag is agreed on first, then all ranks run the leg or none does
+        h_ids = h_off = None
+        ok = 1
         try:
             h_ids = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True); h_ids.copy_(ids)
             h_off = torch.empty(off.shape, dtype=off.dtype, pin_memory=True); h_off.copy_(off)
             torch.cuda.synchronize()
+        except Exception as e:
+            ok = 0; host_leg = dict(error=repr(e))
+        if dist:
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if ok and int(t.item()) == 0:
+                host_leg = dict(error="another rank could not pin its shard")
+            ok = int(t.item())
+        if ok:
             hsteps = max(1, min(a.steps, 3))
             infoh = quant.run(h_ids, h_off, fl_counts=fl_counts, remaining_fl_ops=(0 if paired else 1))      # warm-up (staging buffers)
             barrier()
@@ -254,18 +274,16 @@ def main():
             barrier()
             dth = time.perf_counter() - th0
             if dist:
-                t = torch.tensor([dth], dtype=torch.float64, device=dev)
+                t = torch.tensor([dth, tb], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dth = float(t.item())
+                dth, tb = float(t[0]), float(t[1])
             same = bool(infoh["n_classes"] == info["n_classes"] and infoh["nnz"] == info["nnz"] and
                         infoh["em_stats"]["iters"] == info["em_stats"]["iters"])
             nbytes = (ids.numel() + off.numel()) * 4
             host_leg = dict(value=R_total * hsteps / dth, unit="reads/s", steps=hsteps, ms_per_step=dth / hsteps * 1e3,
                             class_build_ms=tb / hsteps, h2d_bytes_per_gpu=nbytes, pcie_gbps_per_gpu=nbytes / (tb / hsteps * 1e-3) / 1e9,
-                            same_result_as_hbm_resident_step=same)
-            del h_ids, h_off
-        except Exception as e:                    # never take the headline line down
-            host_leg = dict(error=repr(e))
+                            em_mode=infoh["em_mode"], same_result_as_hbm_resident_step=same)
+        del h_ids, h_off
     st = info["em_stats"]
     C, L = info["n_classes"], info["nnz"]
 
@@ -350,8 +368,11 @@ def main():
             torch.cuda.synchronize()
             mg["allreduce_f64_M_us"] = (time.perf_counter() - t1) / 100 * 1e6
             mg["allreduce_bytes"] = M * 8
-            mg["sweep_us_whole_problem"] = sweep_ms * 1e3
-            if not a.compare_em_modes:
+            mg["sweep_us_of_the_timed_problem"] = sweep_ms * 1e3
+            if getattr(quant, "auto_measurement", None):
+                mg["auto_decision"] = quant.auto_measurement       # what `auto` measured on its first run (libsfgpu's own RCCL communicator)
+            mg["em_ms_of_the_timed_steps"] = em_ms
+            if a.no_compare_em_modes:
                 raise StopIteration
             other = "sharded" if info["em_mode"] == "replicated" else "replicated"
             q2 = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode=other)
@@ -364,13 +385,54 @@ def main():
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             mg["other_em_mode"] = {"em_mode": i2["em_mode"], "ms_per_step": float(t2.item()) * 1e3, "em_ms": i2["t_em_ms"],
                                    "em_iters": i2["em_stats"]["iters"], "same_classes": bool(i2["n_classes"] == info["n_classes"])}
-            mg["em_ms_of_the_timed_steps"] = em_ms
+            mg["em_ms"] = {info["em_mode"]: em_ms, i2["em_mode"]: i2["t_em_ms"]}
             del q2
         except StopIteration:
             pass
         except Exception as e:                    # never take the headline line down
             mg["error"] = repr(e)
         out["multi_gpu"] = mg
+
+    # ---- N = 1 only, outside the timed region: the posterior-sampling paths over the job's converged classes.  BASELINE
+    # config 5 = CollapsedGibbsSampler, 1000 draws; the bootstrap is its sibling (doBootstrap).  SURVEY 8d's byte counts:
+    #   Gibbs round, per sample and chain: B_round = 28 L + 8 C;   bootstrap draw: 8 C + iters x B_iter'
+    if world == 1 and not a.no_sampling:
+        samp = {}
+        try:
+            p = quant.problem
+            nb = max(1, a.bootstrap_draws)
+            p.bootstrap(1, seed=3, use_vbem=use_vbem)                               # warm-up (the lanes' clones are planned once)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            rc_b, outb, itb = p.bootstrap(nb, seed=1, use_vbem=use_vbem)
+            torch.cuda.synchronize(); dtb = time.perf_counter() - t1
+            b_bytes = float(sum(8 * C + int(k) * b_iter for k in itb))
+            samp["bootstrap"] = dict(draws=nb, rc=int(rc_b), ms_per_replicate=dtb / nb * 1e3, em_iters_mean=float(np.mean(itb)),
+                                     roofline=dict(bound="hbm", achieved=b_bytes / dtb / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                                   frac=b_bytes / dtb / 1e9 / HBM_PEAK_GBS, bytes_per_draw=b_bytes / nb,
+                                                   formula="8 C + iters x B_iter' per draw (SURVEY 8d)"))
+            del outb
+            out["bootstrap_ms_per_replicate"] = samp["bootstrap"]["ms_per_replicate"]
+        except Exception as e:                    # never take the headline line down
+            samp["bootstrap"] = dict(error=repr(e))
+        try:
+            n_draws, n_chains = a.gibbs_draws, 1024
+            quant.gibbs(8, seed=5, n_chains=n_chains)                                # warm-up: the first call of a process pays ~2 s for mapping the
+                                                                                     # 4 x nnz x chains bytes of chain state (38 GB here) for the first time
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            g = quant.gibbs(n_draws, seed=1, n_chains=n_chains)
+            torch.cuda.synchronize(); dtg = time.perf_counter() - t1
+            rounds = (n_draws + n_chains - 1) // n_chains
+            g_bytes = float(28 * L + 8 * C) * rounds * min(n_chains, n_draws)        # every chain runs `rounds` rounds
+            sums_ok = bool((g.sum(1) == info_total_reads(info, quant)).all())
+            samp["gibbs"] = dict(draws=n_draws, chains=n_chains, rounds_per_chain=rounds, seconds=dtg, sums_ok=sums_ok,
+                                 roofline=dict(bound="hbm", achieved=g_bytes / dtg / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                               frac=g_bytes / dtg / 1e9 / HBM_PEAK_GBS, bytes=g_bytes,
+                                               formula="B_round = 28 L + 8 C per sample and chain (SURVEY 8d)"))
+            del g
+            out["gibbs_1000_draws_s"] = dtg * (1000.0 / n_draws)
+        except Exception as e:
+            samp["gibbs"] = dict(error=repr(e))
+        out["sampling"] = samp
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(ref_len_np, ids, off, a.cpu_seconds, use_vbem)

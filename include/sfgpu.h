@@ -249,6 +249,27 @@ SFGPU_API int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts,
                                         uint32_t poll_every, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats);
 /* the stream the handle's kernels run on (what to pass to a collective that must be ordered with them) */
 SFGPU_API sfgpu_stream sfgpu_em_stream(sfgpu_em* em);
+
+/* ---------------------------------------------------------------------------------------------
+ * (e) multi-GPU transport: RCCL over xGMI, bound at run time (csrc/comm.hip).  No counterpart in the reference (a
+ * shared-memory program: the atomic adds of src/CollapsedEMOptimizer.cpp:224-281 are what the all-reduce replaces).
+ * libsfgpu.so does not link librccl: it is dlopen'ed on first use (the copy the process already holds, else /opt/rocm/lib).
+ * A communicator is made the NCCL way: one rank calls sfgpu_comm_unique_id and hands the SFGPU_COMM_ID_BYTES bytes to the
+ * others by any channel (MPI_Bcast, a torch.distributed broadcast, a file); every rank then calls sfgpu_comm_create with
+ * its own device current.  sfgpu_comm_allreduce_fn() is the callback for sfgpu_em_optimize_sharded (user = the
+ * communicator): ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, stream), enqueued on the loop's stream, so that
+ * no host code runs between two EM iterations. */
+#define SFGPU_COMM_ID_BYTES 128
+typedef struct sfgpu_comm sfgpu_comm;
+SFGPU_API int sfgpu_comm_available(void);                                   /* 1 if librccl.so could be loaded */
+SFGPU_API int sfgpu_comm_unique_id(void* id_out /* SFGPU_COMM_ID_BYTES */);
+SFGPU_API int sfgpu_comm_create(sfgpu_comm** out, const void* id /* SFGPU_COMM_ID_BYTES */, int world, int rank);
+SFGPU_API int sfgpu_comm_destroy(sfgpu_comm* c);
+SFGPU_API int sfgpu_comm_allreduce_sum_f64(sfgpu_comm* c, double* d_buf, uint64_t n, sfgpu_stream stream);   /* in place, on `stream` */
+SFGPU_API sfgpu_allreduce_fn sfgpu_comm_allreduce_fn(void);
+/* average duration (us) of one such all-reduce, `reps` back to back on `stream` (HIP events): what a host's choice between
+ * the replicated and the sharded EM rests on */
+SFGPU_API int sfgpu_comm_time_allreduce(sfgpu_comm* c, double* d_buf, uint64_t n, uint32_t reps, sfgpu_stream stream, double* avg_us);
 /* Launch the E-step sweep kernel `n` times back to back (state untouched afterwards) and
  * return its average duration from HIP events on the stream: the live roofline measurement. */
 SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n, double* avg_ms);
@@ -321,6 +342,17 @@ SFGPU_API int sfgpu_index_destroy(sfgpu_index* idx);
  * most seeds hit: more sensitive on reads with errors (one clean k-mer is enough) without keeping what a single repeat k-mer
  * drags in.  2 <= S <= 8. */
 SFGPU_API int sfgpu_index_set_seeds(sfgpu_index* x, uint32_t seeds_per_strand);
+/* The mapping mode.  seed_len != 0 (the DEFAULT after sfgpu_index_build: min(19, k)): SCAN mode, modelled on RapMap's maximal
+ * mappable prefixes -- the sorted k-mer table is used as a suffix array of depth k, a seed of seed_len <= k bases is a prefix
+ * range of it.  A mate is walked once per strand (forward first; the reverse complement is skipped when a forward match
+ * covered the whole read): window at i -> prefix range; no occurrence, more than max_occ, or a non-ACGT base -> i += 1;
+ * otherwise every occurrence is extended base by base on the transcripts' text (the index keeps a copy), L = the longest
+ * extension, the occurrences that reach L form a group, i += L - seed_len + 1 (at most 8 groups per mate).  A (transcript,
+ * strand) is positioned by the first group that holds it and gets a vote per group; with several candidates only those with
+ * the most votes are kept.  A read with substitutions maps as long as seed_len clean bases remain somewhere.
+ * seed_len == 0: the END-SEED contract above (exact k-mers at offsets 0 and len - k, or sfgpu_index_set_seeds' S seeds) -- the
+ * baseline of rounds 1-2.  8 <= seed_len <= k.  Parity with RapMap is unpinned in both modes. */
+SFGPU_API int sfgpu_index_set_scan(sfgpu_index* x, uint32_t seed_len);
 SFGPU_API int sfgpu_index_info(const sfgpu_index* idx, uint32_t* k, uint64_t* n_positions, uint64_t* n_kmers);
 SFGPU_API int sfgpu_map_reads(const sfgpu_index* idx, const char* d_seq1, const uint64_t* d_off1, const char* d_seq2, const uint64_t* d_off2,
                               uint32_t n_reads, struct sfgpu_hit* d_hits, uint64_t hit_capacity, uint32_t* d_hit_offsets, uint64_t* n_hits,

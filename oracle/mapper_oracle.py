@@ -109,3 +109,117 @@ def map_reads(index, reads1, reads2=None, k=31, seeds=2):
                 recs += [(t, p, 0, 0, len(r2), len(r1), f, 0, 2, 0) for t, f, p in right]
         off.append(len(recs))
     return np.array(recs, dtype=HIT_DTYPE), np.array(off, np.uint32)
+
+
+# ---- the SCAN contract (round 3): RapMap-style maximal-match extension instead of two fixed end seeds ----------------
+# PARITY WITH RAPMAP STAYS UNPINNED (see the header).  What follows restates csrc/mapper.hip's scan mode, modelled on what the
+# quasi-mapping paper describes (walk the read; look the next seed up; extend the match as far as any occurrence allows --
+# the maximal mappable prefix --; jump to its end; the transcripts that the most matches agree on are the hits):
+#   * the index is the sorted table of k-mers (k = 31) with their (transcript, position); a seed of s <= k bases is looked up
+#     as a PREFIX range of that table (so a seed can only be found at positions that start a whole k-mer: the last k - 1
+#     bases of a transcript and k-mers holding a non-ACGT base are not seed starts);
+#   * the forward strand (fwd = 1) and the reverse complement are walked in LOCKSTEP: one step on the forward strand, one on
+#     the reverse complement, and so on; a match that covers the whole read ends both walks;
+#   * a step on a strand: windows q[i:i+s] that hold a non-ACGT base are skipped; the next window is looked up; no occurrence or
+#     more than max_occ occurrences -> i += 1; else every occurrence is extended base by base against the transcript (A/C/G/T,
+#     case folded) up to the end of the read / transcript; L = the longest extension; the occurrences that reach L, in table
+#     order, form a GROUP (i, L), groups numbered in the order they are found; i += L - s + 1; at most 8 groups per mate;
+#   * a (transcript, strand) is positioned by the first group that holds it (p - i) and gets one vote per group that holds
+#     it; with more than one (transcript, strand) only those with the most votes are kept; hits sorted by (transcript, strand).
+MAX_GROUPS = 8
+
+
+def build_scan_index(transcripts, k=31):
+    """-> (sorted list of (kmer key, t, p), transcripts' code arrays): the table the device sorts (key, then (t, p))"""
+    codes = [_codes(s) for s in transcripts]
+    table = []
+    for t, c in enumerate(codes):
+        for p in range(len(c) - k + 1):
+            w = c[p:p + k]
+            if (w > 3).any():
+                continue
+            key = 0
+            for x in w:
+                key = (key << 2) | int(x)
+            table.append((key, t, p))
+    table.sort()
+    return table, codes, k
+
+
+def _prefix_range(table, k, prefix, s):
+    import bisect
+    lo = bisect.bisect_left(table, (prefix << (2 * (k - s)), -1, -1))
+    hi = bisect.bisect_left(table, ((prefix + 1) << (2 * (k - s)), -1, -1))
+    return lo, hi
+
+
+def scan_read(sindex, read: bytes, s=19, max_occ=1000):
+    table, tcodes, k = sindex
+    c = _codes(read)
+    n = len(c)
+    if n < s:
+        return []
+    rc = (3 - c[::-1]).astype(np.uint8); rc[c[::-1] > 3] = 4
+    strands = [(1, c), (0, rc)]
+    pos = [0, 0]; live = [True, True]
+    groups, whole = [], False
+    while (live[0] or live[1]) and not whole and len(groups) < MAX_GROUPS:
+        for w in (0, 1):                                   # lockstep: one lookup on the forward strand, one on the reverse complement
+            if not live[w] or whole or len(groups) >= MAX_GROUPS:
+                continue
+            fwd, q = strands[w]
+            i = pos[w]
+            while i + s <= n and (q[i:i + s] > 3).any():   # windows that hold a non-ACGT base are skipped (not a step)
+                i += 1
+            if i + s > n:
+                live[w] = False; continue
+            key = _key(q[i:i + s])
+            lo, hi = _prefix_range(table, k, key, s)
+            if hi == lo or hi - lo > max_occ:
+                i += 1
+            else:
+                ext = []
+                for _, t, p in table[lo:hi]:
+                    tc = tcodes[t]
+                    e = s
+                    while i + e < n and p + e < len(tc) and q[i + e] < 4 and tc[p + e] == q[i + e]:
+                        e += 1
+                    ext.append(e)
+                L = max(ext)
+                groups.append((fwd, i, L, [(t, p) for (_, t, p), e in zip(table[lo:hi], ext) if e == L]))
+                if L == n:
+                    whole = True                           # the whole read matched: both walks end
+                i += L - s + 1
+            if i + s > n:
+                live[w] = False
+            pos[w] = i
+    found, votes = {}, {}
+    for g, (fwd, i, L, occ) in enumerate(groups):
+        for t, p in occ:
+            found.setdefault((t, fwd), p - i)
+            votes.setdefault((t, fwd), set()).add(g)
+    if len(found) > 1:
+        best = max(len(v) for v in votes.values())
+        found = {key: p for key, p in found.items() if len(votes[key]) == best}
+    return sorted((t, fwd, p) for (t, fwd), p in found.items())
+
+
+def scan_reads(sindex, reads1, reads2=None, s=19, max_occ=1000):
+    """map_reads with the scan contract -> (hits HIT_DTYPE[n], offsets uint32[R + 1])"""
+    recs, off = [], [0]
+    for i, r1 in enumerate(reads1):
+        left = scan_read(sindex, r1, s, max_occ)
+        if reads2 is None:
+            recs += [(t, p, 0, 0, len(r1), 0, f, 0, 0, 0) for t, f, p in left]
+        else:
+            r2 = reads2[i]
+            right = scan_read(sindex, r2, s, max_occ)
+            paired = [(t, f, p, f2, p2) for t, f, p in left for t2, f2, p2 in right if t2 == t and f2 != f]
+            if paired:
+                for t, f, p, f2, p2 in paired:
+                    recs.append((t, p, p2, max(p + len(r1), p2 + len(r2)) - min(p, p2), len(r1), len(r2), f, f2, 3, 0))
+            else:
+                recs += [(t, p, 0, 0, len(r1), len(r2), f, 0, 1, 0) for t, f, p in left]
+                recs += [(t, p, 0, 0, len(r2), len(r1), f, 0, 2, 0) for t, f, p in right]
+        off.append(len(recs))
+    return np.array(recs, dtype=HIT_DTYPE), np.array(off, np.uint32)

@@ -97,6 +97,7 @@ _SIGS = {
     "sfgpu_set_logger": (None, [_LOG_CB]),
     "sfgpu_pool_trim": (C.c_int, []),
     "sfgpu_index_set_seeds": (C.c_int, [_P, C.c_uint32]),
+    "sfgpu_index_set_scan": (C.c_int, [_P, C.c_uint32]),
     "sfgpu_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "sfgpu_xxh64_labels": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
     "sfgpu_eq_create": (C.c_int, [C.POINTER(_P), C.c_uint64, _P]),
@@ -137,6 +138,13 @@ _SIGS = {
     "sfgpu_em_finish": (C.c_int, [_P, _P, _P, C.POINTER(EmStats)]),
     "sfgpu_em_optimize_sharded": (C.c_int, [_P, C.POINTER(EmOpts), ALLREDUCE_CB, _P, C.c_uint32, _P, _P, C.POINTER(EmStats)]),
     "sfgpu_em_stream": (_P, [_P]),
+    "sfgpu_comm_available": (C.c_int, []),
+    "sfgpu_comm_unique_id": (C.c_int, [_P]),
+    "sfgpu_comm_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),
+    "sfgpu_comm_destroy": (C.c_int, [_P]),
+    "sfgpu_comm_allreduce_sum_f64": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "sfgpu_comm_allreduce_fn": (_P, []),
+    "sfgpu_comm_time_allreduce": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P, C.POINTER(C.c_double)]),
     "sfgpu_eqvec_owner_sizes": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P, _P, _P]),
     "sfgpu_eqvec_pack_by_owner": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P]),
     "sfgpu_eq_add_block_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),

@@ -90,7 +90,10 @@ __global__ void k_count_valid(uint64_t n, const uint64_t* __restrict__ keys, uns
 struct IndexView {
     const uint64_t* keys; const uint32_t* tid; const uint32_t* tpos; const uint32_t* bucket; uint64_t n; uint32_t k, shift, max_occ;
     uint32_t n_seeds;                      // seeds per strand (2: offsets 0 and len - k; more: spread evenly between them)
+    // scan mode (seed_len != 0): the transcripts' text (the index's own copy) for the extension of a match past the seed
+    uint32_t seed_len; const char* tseq; const uint64_t* tseq_off; const uint32_t* tlen;
 };
+constexpr uint32_t kScanGroups = 8;       // maximal matches kept per mate (both strands together)
 constexpr uint32_t kMaxSeeds = 8;
 // offset of seed j of S in a read of `len` bases (S = 2: 0 and len - k)
 __device__ __host__ __forceinline__ uint32_t seed_offset(uint32_t j, uint32_t S, uint32_t len, uint32_t k) {
@@ -234,6 +237,149 @@ k_map_hits(IndexView x, const uint64_t* __restrict__ off, uint64_t n_mates, cons
     n_hits[m] = n;
 }
 
+// ---- scan mode: maximal-match extension (RapMap-style; parity with RapMap itself is unpinned -- it is not in the reference tree) ----
+// The sorted k-mer table doubles as a suffix array of depth k: a seed of s <= k bases is a PREFIX range of it.  A mate is walked
+// on both strands in lockstep: window at i -> prefix range; none, or more than max_occ -> i += 1; else every occurrence is extended
+// base by base against the transcript's text; L = the longest extension, the occurrences that reach it form a GROUP (i, L);
+// i += L - s + 1; a match that covers the whole read ends both walks.  Reads with substitutions map as long as s error-free bases remain somewhere (the fixed 31-mer end seeds of the first
+// contract lose a 50-base read to a single substitution in its middle).  The contract is restated on the CPU for the tests.
+// first sorted index whose key is >= key (key < 4^k; key == 4^k: the end)
+__device__ __forceinline__ uint32_t index_lower_bound(const IndexView& x, uint64_t key) {
+    if (x.k < 32u && (key >> (2u * x.k)) != 0ull) return (uint32_t)x.n;
+    const uint64_t b = key >> x.shift;
+    uint32_t lo = x.bucket[b], hi = x.bucket[b + 1];
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (x.keys[mid] >= key) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+// base j of the mate on a strand: fwd -> r[j]; rc -> complement of r[n - 1 - j]; 4 = not A/C/G/T
+__device__ __forceinline__ uint32_t strand_code(const char* r, uint32_t n, bool rc, uint32_t j) {
+    const uint32_t c = base_code((unsigned char)(rc ? r[n - 1u - j] : r[j]));
+    return c > 3u ? 4u : (rc ? 3u - c : c);
+}
+// how far q[i ...] and transcript t from p on agree, given that the first s bases do
+__device__ __forceinline__ uint32_t scan_extend(const IndexView& x, const char* r, uint32_t n, bool rc, uint32_t i, uint32_t t, uint32_t p) {
+    const char* ts = x.tseq + x.tseq_off[t];
+    const uint32_t tl = x.tlen[t];
+    uint32_t e = x.seed_len;
+    while (i + e < n && p + e < tl) {
+        const uint32_t cq = strand_code(r, n, rc, i + e);
+        if (cq > 3u || base_code((unsigned char)ts[p + e]) != cq) break;
+        ++e;
+    }
+    return e;
+}
+// group words: w0 = first sorted index | occurrences << 32;  w1 = i | L << 16 | fwd << 32 | 1 << 33 (present)
+// pass A: walk the mate; groups[2 G m + 2 g ..], cand_cnt[m] = occurrences that reach L, summed over the groups.
+// The two strands are walked in LOCKSTEP -- one lookup on the forward strand, one on the reverse complement, and so on -- and
+// a match that covers the whole read ends both walks: an error-free read costs one or two lookups whichever strand it came
+// from (walking the forward strand to its end first cost a reverse-strand read ~80 missed lookups: 188 ms instead of 35 ms per
+// 10 M pairs of 2 x 100 bases).
+__global__ void __launch_bounds__(kMapBlock)
+k_scan_lookup(IndexView x, const char* __restrict__ seq, const uint64_t* __restrict__ off, uint64_t n_mates, uint64_t* groups, uint32_t* cand_cnt) {
+    const uint64_t m = (uint64_t)blockIdx.x * kMapBlock + threadIdx.x;
+    if (m > n_mates) return;
+    if (m == n_mates) { cand_cnt[m] = 0; return; }
+    const uint64_t b = off[m]; const uint32_t n = (uint32_t)(off[m + 1] - b);
+    const char* r = seq + b;
+    const uint32_t s = x.seed_len;
+    uint64_t* out = groups + 2ull * kScanGroups * m;
+    uint32_t ng = 0, total = 0;
+    const uint64_t smask = (s == 32u) ? ~0ull : ((1ull << (2u * s)) - 1ull);
+    const uint32_t sh = 2u * (x.k - s);
+    // per strand: i = start of the window, key / have = the rolling window (have valid bases collected), live = still walking
+    uint32_t wi[2] = {0u, 0u}, whave[2] = {0u, 0u};
+    uint64_t wkey[2] = {0ull, 0ull};
+    bool live[2] = {n >= s, n >= s};
+    bool whole = false;
+    while ((live[0] || live[1]) && !whole && ng < kScanGroups) {
+#pragma unroll
+        for (int strand = 0; strand < 2; ++strand) {
+            if (!live[strand] || whole || ng >= kScanGroups) continue;
+            const bool rc = strand == 1;
+            uint32_t i = wi[strand], have = whave[strand];
+            uint64_t key = wkey[strand];
+            // bring the next window without a non-ACGT base into key (skipping such windows is not a step)
+            while (have < s && i + s <= n) {
+                const uint32_t c = strand_code(r, n, rc, i + have);
+                if (c > 3u) { i += have + 1u; have = 0; key = 0; continue; }
+                key = ((key << 2) | c) & smask; ++have;
+            }
+            if (have < s) { live[strand] = false; continue; }
+            // ONE step: look the window up
+            const uint32_t lo = index_lower_bound(x, key << sh);
+            uint32_t hi = lo;
+            while (hi < (uint32_t)x.n && hi - lo <= x.max_occ && (x.keys[hi] >> sh) == key) ++hi;      // (runs are short; max_occ bounds the walk)
+            const uint32_t cnt = hi - lo;
+            if (cnt == 0u || cnt > x.max_occ) { ++i; --have; }                        // a miss: slide by one (the oldest base leaves through smask)
+            else {
+                uint32_t L = 0, reach = 0;
+                for (uint32_t q = lo; q < hi; ++q) {
+                    const uint32_t e = scan_extend(x, r, n, rc, i, x.tid[q], x.tpos[q]);
+                    if (e > L) { L = e; reach = 1; } else if (e == L) ++reach;
+                }
+                out[2u * ng] = (uint64_t)lo | ((uint64_t)cnt << 32);
+                out[2u * ng + 1u] = (uint64_t)i | ((uint64_t)L << 16) | ((uint64_t)(rc ? 0u : 1u) << 32) | (1ull << 33);
+                ++ng; total += reach;
+                if (L == n) whole = true;                                               // the whole read matched: both walks end
+                i += L - s + 1u; have = 0; key = 0;
+            }
+            if (i + s > n) live[strand] = false;
+            wi[strand] = i; whave[strand] = have; wkey[strand] = key;
+        }
+    }
+    for (uint32_t g = ng; g < kScanGroups; ++g) { out[2u * g] = 0; out[2u * g + 1u] = 0; }
+    cand_cnt[m] = total;
+}
+// pass B: the occurrences that reach their group's L, in group order -> first position per (transcript, strand), one vote per
+// group; the pairs with the most votes; sorted by (transcript, strand)
+__global__ void __launch_bounds__(kMapBlock)
+k_scan_hits(IndexView x, const char* __restrict__ seq1, const uint64_t* __restrict__ off1, const char* __restrict__ seq2, const uint64_t* __restrict__ off2,
+            int paired, uint64_t n_mates, const uint64_t* __restrict__ groups, const uint64_t* __restrict__ cand_off, uint64_t* cand, uint8_t* votes, uint32_t* n_hits) {
+    const uint64_t m = (uint64_t)blockIdx.x * kMapBlock + threadIdx.x;
+    if (m >= n_mates) return;
+    const uint64_t rd = paired ? (m >> 1) : m;
+    const bool second = paired && (m & 1ull);
+    const uint64_t* off = second ? off2 : off1;
+    const char* r = (second ? seq2 : seq1) + off[rd];
+    const uint32_t n = (uint32_t)(off[rd + 1] - off[rd]);
+    uint64_t* out = cand + cand_off[m];
+    uint8_t* vt = votes + cand_off[m];
+    const uint64_t* gw = groups + 2ull * kScanGroups * m;
+    uint32_t nc = 0;
+    for (uint32_t g = 0; g < kScanGroups; ++g) {
+        const uint64_t w0 = gw[2u * g], w1 = gw[2u * g + 1u];
+        if (!(w1 >> 33)) break;
+        const uint32_t lo = (uint32_t)w0, cnt = (uint32_t)(w0 >> 32);
+        const uint32_t i = (uint32_t)(w1 & 0xFFFFu), L = (uint32_t)((w1 >> 16) & 0xFFFFu), fwd = (uint32_t)(w1 >> 32) & 1u;
+        for (uint32_t q = lo; q < lo + cnt; ++q) {
+            const uint32_t t = x.tid[q], p = x.tpos[q];
+            if (scan_extend(x, r, n, fwd == 0u, i, t, p) != L) continue;
+            uint32_t at = nc;
+            for (uint32_t c = 0; c < nc && at == nc; ++c) if (cand_tid(out[c]) == t && cand_fwd(out[c]) == fwd) at = c;
+            if (at == nc) { out[nc] = cand_pack(t, fwd, (int32_t)p - (int32_t)i); vt[nc] = (uint8_t)(1u << g); ++nc; }
+            else vt[at] |= (uint8_t)(1u << g);
+        }
+    }
+    if (nc > 1) {                                            // the pairs the most groups agree on
+        uint32_t best = 0;
+        for (uint32_t c = 0; c < nc; ++c) { const uint32_t v = (uint32_t)__popc((unsigned)vt[c]); best = v > best ? v : best; }
+        uint32_t w = 0;
+        for (uint32_t c = 0; c < nc; ++c) if ((uint32_t)__popc((unsigned)vt[c]) == best) out[w++] = out[c];
+        nc = w;
+    }
+    for (uint32_t a = 1; a < nc; ++a) {
+        const uint64_t v = out[a]; uint32_t bpos = a;
+        while (bpos > 0 && (out[bpos - 1] >> 31) > (v >> 31)) { out[bpos] = out[bpos - 1]; --bpos; }
+        out[bpos] = v;
+    }
+    n_hits[m] = nc;
+}
+// where the transcripts' text ends (max over t of seq_off[t] + ref_len[t]): the index copies that much
+__global__ void k_seq_extent(uint64_t M, const uint64_t* __restrict__ seq_off, const uint32_t* __restrict__ ref_len, unsigned long long* out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) atomicMax(out, (unsigned long long)(seq_off[t] + ref_len[t]));
+}
+
 // pass C / D: records per read, then the records.  Paired: mates 2r (left) and 2r + 1 (right).
 template <bool FILL>
 __global__ void __launch_bounds__(kMapBlock)
@@ -301,11 +447,17 @@ __global__ void k_narrow_off(uint64_t n, const uint64_t* __restrict__ in, uint32
 
 using namespace sfgpu;
 
+// waits for the stream when it goes out of scope
+struct StreamSyncOnExit { hipStream_t s; ~StreamSyncOnExit() { (void)hipStreamSynchronize(s); } };
+
 struct sfgpu_index {
     uint32_t k = 31, shift = 0, max_occ = 1000, n_seeds = 2;
+    uint32_t seed_len = 0;                 // != 0: scan mode with seeds of this many bases (the default: min(19, k)); 0: end seeds
     uint64_t n_valid = 0, n_slots = 0, M = 0, n_buckets = 0;
     DevBuf<uint64_t> keys; DevBuf<uint32_t> tid, tpos, bucket;
+    DevBuf<char> tseq; DevBuf<uint64_t> tseq_off; DevBuf<uint32_t> tlen;      // the transcripts' text (scan mode extends matches on it)
 };
+constexpr uint32_t kDefaultSeedLen = 19;
 
 extern "C" {
 
@@ -320,6 +472,7 @@ int sfgpu_index_build(sfgpu_index** out, const char* d_seq, const uint64_t* d_se
     int rc;
 #define IDX_TRY(expr) do { if ((rc = (expr))) { delete x; return rc; } } while (0)
     DevBuf<uint32_t> n_kmers, vals_in, vals; DevBuf<uint64_t> kmer_off, keys_in; DevBuf<unsigned long long> ctr;
+    StreamSyncOnExit sync_first{st};         // (destroyed before the scratch buffers above: see sfgpu_map_reads)
     IDX_TRY(n_kmers.reserve(M + 1, st, false)); IDX_TRY(kmer_off.reserve(M + 2, st, false)); IDX_TRY(ctr.reserve(1, st, false));
     hipLaunchKernelGGL(k_index_lens, dim3(mpgrid(M + 1)), dim3(kMapBlock), 0, st, M, d_ref_len, k, n_kmers.p);
     IDX_TRY(exclusive_scan_u32(n_kmers.p, kmer_off.p, M, st));
@@ -343,6 +496,18 @@ int sfgpu_index_build(sfgpu_index** out, const char* d_seq, const uint64_t* d_se
         if (hipMemcpyAsync(&nv, ctr.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { delete x; set_error("sfgpu_index_build: copy failed"); return SFGPU_ERR_HIP; }
         x->n_valid = nv;
     }
+    // the index's own copy of the text: the scan mode extends matches past the seed on it
+    {
+        (void)hipMemsetAsync(ctr.p, 0, 8, st);
+        hipLaunchKernelGGL(k_seq_extent, dim3(mpgrid(M)), dim3(kMapBlock), 0, st, M, d_seq_off, d_ref_len, ctr.p);
+        unsigned long long ext = 0;
+        if (hipMemcpyAsync(&ext, ctr.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { delete x; set_error("sfgpu_index_build: copy failed"); return SFGPU_ERR_HIP; }
+        IDX_TRY(x->tseq.reserve(ext + 1, st, false)); IDX_TRY(x->tseq_off.reserve(M, st, false)); IDX_TRY(x->tlen.reserve(M, st, false));
+        if (hipMemcpyAsync(x->tseq.p, d_seq, ext, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(x->tseq_off.p, d_seq_off, M * 8, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(x->tlen.p, d_ref_len, M * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { delete x; set_error("sfgpu_index_build: copy failed"); return SFGPU_ERR_HIP; }
+        x->seed_len = k < kDefaultSeedLen ? k : kDefaultSeedLen;
+    }
     // bucket table over the top bits: ~8 k-mers per bucket, between 2^8 and 2^26 buckets
     uint32_t bits = 8; while (bits < 26 && bits < 2 * k && (1ull << bits) * 8 < x->n_valid) ++bits;
     x->shift = 2 * k - bits; x->n_buckets = 1ull << bits;
@@ -365,6 +530,13 @@ int sfgpu_index_set_seeds(sfgpu_index* x, uint32_t seeds_per_strand) {
     return SFGPU_OK;
 }
 
+int sfgpu_index_set_scan(sfgpu_index* x, uint32_t seed_len) {
+    SF_REQUIRE(x, SFGPU_ERR_INVALID, "sfgpu_index_set_scan: null handle");
+    SF_REQUIRE(seed_len == 0 || (seed_len >= 8 && seed_len <= x->k), SFGPU_ERR_INVALID, "sfgpu_index_set_scan: seed length 0 (end seeds) or 8 .. k");
+    x->seed_len = seed_len;
+    return SFGPU_OK;
+}
+
 int sfgpu_index_info(const sfgpu_index* x, uint32_t* k, uint64_t* n_positions, uint64_t* n_kmers) {
     SF_REQUIRE(x, SFGPU_ERR_INVALID, "sfgpu_index_info: null handle");
     if (k) *k = x->k;
@@ -383,23 +555,30 @@ int sfgpu_map_reads(const sfgpu_index* x, const char* d_seq1, const uint64_t* d_
     SF_REQUIRE(d_seq1 && d_off1 && (!d_seq2 || d_off2), SFGPU_ERR_INVALID, "sfgpu_map_reads: null reads");
     const int paired = d_seq2 != nullptr;
     const uint64_t n_mates = paired ? 2ull * n_reads : n_reads;
-    IndexView v{x->keys.p, x->tid.p, x->tpos.p, x->bucket.p, x->n_valid, x->k, x->shift, x->max_occ, x->n_seeds};
-    const uint64_t per_mate = 2ull * x->n_seeds;                     // lookups per mate
+    IndexView v{x->keys.p, x->tid.p, x->tpos.p, x->bucket.p, x->n_valid, x->k, x->shift, x->max_occ, x->n_seeds,
+                x->seed_len, x->tseq.p, x->tseq_off.p, x->tlen.p};
+    const bool scan = x->seed_len != 0;
+    const uint64_t per_mate = scan ? 2ull * kScanGroups : 2ull * x->n_seeds;       // words per mate: group descriptors / lookups
     int rc;
     // Mates are numbered 2 r (left) and 2 r + 1 (right).  The two files are looked up side by side (each with its own
     // sequence buffer and offsets) and interleaved; from then on only the mates' LENGTHS are needed, as offsets `moff`.
     DevBuf<uint64_t> ranges, cand_off, cand, rec_off, moff, s_ranges; DevBuf<uint32_t> cand_cnt, n_hits, rec_cnt, s_cnt, lens; DevBuf<uint8_t> votes;
+    StreamSyncOnExit sync_first{st};         // (declared after the buffers: destroyed before them -- an early error return must not hand
+                                             //  scratch back to the pool while a kernel enqueued above may still be writing it)
     if ((rc = ranges.reserve(per_mate * n_mates, st, false)) || (rc = cand_cnt.reserve(n_mates + 1, st, false)) || (rc = cand_off.reserve(n_mates + 2, st, false)) ||
         (rc = n_hits.reserve(n_mates, st, false)) || (rc = rec_cnt.reserve((uint64_t)n_reads + 1, st, false)) ||
         (rc = rec_off.reserve((uint64_t)n_reads + 2, st, false)) || (rc = moff.reserve(n_mates + 2, st, false))) return rc;
     if (!paired) {
-        hipLaunchKernelGGL(k_map_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, d_seq1, d_off1, (uint64_t)n_reads, ranges.p, cand_cnt.p);
+        if (scan) hipLaunchKernelGGL(k_scan_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, d_seq1, d_off1, (uint64_t)n_reads, ranges.p, cand_cnt.p);
+        else hipLaunchKernelGGL(k_map_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, d_seq1, d_off1, (uint64_t)n_reads, ranges.p, cand_cnt.p);
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(moff.p, d_off1, ((uint64_t)n_reads + 1) * 8, hipMemcpyDeviceToDevice, st));
     } else {
         if ((rc = s_ranges.reserve(per_mate * n_reads, st, false)) || (rc = s_cnt.reserve((uint64_t)n_reads + 1, st, false)) || (rc = lens.reserve(n_mates + 1, st, false))) return rc;
         for (int side = 0; side < 2; ++side) {
-            hipLaunchKernelGGL(k_map_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, side ? d_seq2 : d_seq1, side ? d_off2 : d_off1,
+            if (scan) hipLaunchKernelGGL(k_scan_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, side ? d_seq2 : d_seq1, side ? d_off2 : d_off1,
+                                         (uint64_t)n_reads, s_ranges.p, s_cnt.p);
+            else hipLaunchKernelGGL(k_map_lookup, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, v, side ? d_seq2 : d_seq1, side ? d_off2 : d_off1,
                                (uint64_t)n_reads, s_ranges.p, s_cnt.p);
             hipLaunchKernelGGL(k_interleave, dim3(mpgrid(n_reads)), dim3(kMapBlock), 0, st, (uint64_t)n_reads, side, (uint32_t)per_mate, s_ranges.p, s_cnt.p, ranges.p, cand_cnt.p);
             SF_CHECK_LAUNCH();
@@ -414,7 +593,9 @@ int sfgpu_map_reads(const sfgpu_index* x, const char* d_seq1, const uint64_t* d_
     SF_HIP(hipMemcpyAsync(&n_cand, cand_off.p + n_mates, 8, hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
     if ((rc = cand.reserve(n_cand + 1, st, false)) || (rc = votes.reserve(n_cand + 1, st, false))) return rc;
-    hipLaunchKernelGGL(k_map_hits, dim3(mpgrid(n_mates)), dim3(kMapBlock), 0, st, v, moff.p, n_mates, ranges.p, cand_off.p, cand.p, votes.p, n_hits.p);
+    if (scan) hipLaunchKernelGGL(k_scan_hits, dim3(mpgrid(n_mates)), dim3(kMapBlock), 0, st, v, d_seq1, d_off1, d_seq2, d_off2, paired, n_mates, ranges.p, cand_off.p,
+                                 cand.p, votes.p, n_hits.p);
+    else hipLaunchKernelGGL(k_map_hits, dim3(mpgrid(n_mates)), dim3(kMapBlock), 0, st, v, moff.p, n_mates, ranges.p, cand_off.p, cand.p, votes.p, n_hits.p);
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_map_records<false>, dim3(mpgrid((uint64_t)n_reads + 1)), dim3(kMapBlock), 0, st, (uint64_t)n_reads, paired, moff.p, cand_off.p, cand.p,
                        n_hits.p, rec_cnt.p, (const uint64_t*)nullptr, (sfgpu_hit*)nullptr);

@@ -16,9 +16,11 @@ Data flow for N ranks:
                      the north-star layout; the all-reduce is latency bound (M = 200k -> 1.6 MB).
        "replicated": every rank runs the whole EM on the merged classes with the on-device loop --
                      no per-iteration collective.
-     "auto" picks "sharded" only when a local sweep is expected to outlast an all-reduce
-     (nnz/N >= kShardNnz); at BASELINE's sizes (nnz <= ~2e7, sweep ~10 us) the per-iteration
-     all-reduce (tens of us over xGMI) costs more than it saves.
+     "auto" MEASURES on the first run: the all-reduce of M doubles on this node's fabric (the communicator of the
+     sharded loop) against the sweep of the whole problem; it shards when sweep/N (not below the ~8 us a round of
+     tiles costs) plus the all-reduce is shorter than the whole sweep, and keeps the decision for later runs.
+     In the sharded mode the loop itself runs in C (sfgpu_em_optimize_sharded) with ncclAllReduce enqueued on
+     its stream by libsfgpu's own RCCL communicator (sailfish_amd/comm.py): no Python between two iterations.
 
 The compute engine is injected so that the control flow is covered on CPU (gloo, world_size 2) by
 tests that supply their own CPU checker engine; the product engine is HipEngine (libsfgpu only)."""
@@ -33,7 +35,7 @@ from .eqclass import EquivalenceClassBuilder
 from .experiment import ReadExperiment, SailfishOpts
 from .optimizer import EMProblem
 
-kShardNnz = 1 << 27
+kSweepFloorUs = 8.0                    # what one round of tiles costs however small they are
 RECOMPUTE_ITERS = (50, 500, 1000)      # recomputeIt, src/CollapsedEMOptimizer.cpp:814
 
 
@@ -315,7 +317,48 @@ class DistributedQuant:
             return "single"
         if self.em_mode != "auto":
             return self.em_mode
-        return "sharded" if nnz // self.world >= kShardNnz else "replicated"
+        return getattr(self, "_auto_mode", None) or "replicated"           # (decided by _measure_auto on the first run)
+
+    def _allreduce(self):
+        """what sums alphaOut over the ranks: libsfgpu's RCCL communicator on the nccl backend (made once, collectively),
+        a torch.distributed call otherwise (gloo: CPU tests, several ranks sharing one device)"""
+        import torch.distributed as dist
+        if getattr(self, "_ar", None) is None:
+            self._ar = None
+            if isinstance(self.engine, HipEngine) and dist.get_backend(self.group) == "nccl":
+                from . import comm as _comm
+                if _comm.available():
+                    self._ar = _comm.Comm.from_group(self.group, self.engine.device)
+            if self._ar is None:
+                group = self.group
+                self._ar = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return self._ar
+
+    def _measure_auto(self, p_full, M):
+        """auto: time the two things the modes differ in, on this node, once; every rank takes the slowest rank's numbers"""
+        import torch.distributed as dist
+        if getattr(self, "_auto_mode", None) is not None or self.em_mode != "auto" or self.world == 1:
+            return
+        self._auto_mode = "replicated"
+        if not hasattr(p_full, "time_sweep"):
+            return
+        ar = self._allreduce()
+        sweep_us = p_full.time_sweep(20, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter) * 1e3
+        if hasattr(ar, "time_all_reduce"):
+            ar_us = ar.time_all_reduce(M, 30)
+        else:
+            buf = torch.zeros(M, dtype=torch.float64, device=self.engine.device)
+            ar(buf); self.engine.sync(); t0 = time.perf_counter()
+            for _ in range(10):
+                ar(buf)
+            self.engine.sync(); ar_us = (time.perf_counter() - t0) / 10 * 1e6
+        t = torch.tensor([sweep_us, ar_us], dtype=torch.float64, device=self.engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        sweep_us, ar_us = float(t[0]), float(t[1])
+        local_us = max(kSweepFloorUs, sweep_us / self.world)
+        self._auto_mode = "sharded" if local_us + ar_us < sweep_us else "replicated"
+        self.auto_measurement = dict(sweep_us_whole_problem=sweep_us, allreduce_us=ar_us, sweep_us_local_estimate=local_us,
+                                     chosen=self._auto_mode)
 
     def _em(self, vec):
         exp, sopt = self.exp, self.sopt
@@ -329,8 +372,17 @@ class DistributedQuant:
         bias = self.engine.bias_model(exp, sopt) if (sopt.biasCorrect or sopt.gcBiasCorrect) else None
         eff = None
         self.recomputes = 0
-        if mode in ("single", "replicated"):
+        if mode == "replicated" and self.em_mode == "auto" and getattr(self, "_auto_mode", None) is None:
             p = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
+            self._measure_auto(p, length.numel())
+            mode = self._pick_mode(vec.nnz)
+            if mode != "replicated":
+                p.close(); p = None
+        else:
+            p = None
+        if mode in ("single", "replicated"):
+            if p is None:
+                p = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
             if bias is not None:
                 rc, st, eff, self.recomputes = p.optimize_bias(bias, **kw)
             else:
@@ -343,36 +395,40 @@ class DistributedQuant:
             j0, j1 = int(rp_cpu[c0]), int(rp_cpu[c1])
             rp_loc = ((vec.rowptr[c0:c1 + 1].to(torch.int64) & 0xFFFFFFFF) - j0).to(torch.int32)
             p = self.engine.em_problem(length, rp_loc, vec.ids[j0:j1], vec.counts[c0:c1], exp.numMappedFragments())
-            p.begin(**kw)
-            ao = p.alpha_out_view()
-            dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)     # union of the active sets
-            p.init()
-            # The loop runs in segments that end at the recompute iterations (one segment without bias): the stop
-            # bounds are lowered to the next hook, and at a hook the reference would reach (its while condition
-            # still true, :820) every rank recomputes the lengths from the replicated alpha; rank 0's result is
-            # broadcast so that the ranks stay bit-identical (the 4096-bin expectation is summed with atomics).
-            user_min, user_max = kw["min_iter"], kw["max_iter"]
-            it, conv = 0, False
-            while not (it >= user_min and (it >= user_max or conv)):
-                if bias is not None and it in RECOMPUTE_ITERS:
-                    new_len, _ = bias.update(p.length_view(), p.alpha_view())
-                    dist.broadcast(new_len, src=dist.get_global_rank(self.group, 0), group=self.group)
-                    p.rebase(new_len)
-                    self.recomputes += 1
-                bound = max(user_min, user_max)                            # the loop cannot end before either
-                nxt = min([h for h in RECOMPUTE_ITERS if h > it] + [bound]) if bias is not None else bound
-                p.set_bounds(min(user_min, nxt), nxt)
-                done = False
-                while not done:
-                    for _ in range(self.poll_every):
-                        p.sweep()
-                        dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)
-                        p.update()
-                    done, seg = p.poll()
-                it, conv = int(seg["iters"]), bool(seg["converged"])
-            if bias is not None:
+            if bias is None:
+                # the whole loop in C: begin -> all-reduce (union of the active sets) -> init -> { sweep, all-reduce,
+                # update } with the stop latch polled every poll_every iterations -> finish
+                rc, st = p.optimize_sharded(self._allreduce(), poll_every=self.poll_every, **kw)
+            else:
+                # doBiasCorrect: the loop runs in segments that end at the recompute iterations: the stop bounds are lowered
+                # to the next hook, and at a hook the reference would reach (its while condition still true, :820) every
+                # rank recomputes the lengths from the replicated alpha; rank 0's result is broadcast so that the ranks
+                # stay bit-identical (the 4096-bin expectation is summed with atomics).  Piecewise API, driven from here.
+                p.begin(**kw)
+                ao = p.alpha_out_view()
+                dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)     # union of the active sets
+                p.init()
+                user_min, user_max = kw["min_iter"], kw["max_iter"]
+                it, conv = 0, False
+                while not (it >= user_min and (it >= user_max or conv)):
+                    if it in RECOMPUTE_ITERS:
+                        new_len, _ = bias.update(p.length_view(), p.alpha_view())
+                        dist.broadcast(new_len, src=dist.get_global_rank(self.group, 0), group=self.group)
+                        p.rebase(new_len)
+                        self.recomputes += 1
+                    bound = max(user_min, user_max)                            # the loop cannot end before either
+                    nxt = min([h for h in RECOMPUTE_ITERS if h > it] + [bound])
+                    p.set_bounds(min(user_min, nxt), nxt)
+                    done = False
+                    while not done:
+                        for _ in range(self.poll_every):
+                            p.sweep()
+                            dist.all_reduce(ao, op=dist.ReduceOp.SUM, group=self.group)
+                            p.update()
+                        done, seg = p.poll()
+                    it, conv = int(seg["iters"]), bool(seg["converged"])
                 eff = p.length_view().clone()
-            rc, st = p.finish()
+                rc, st = p.finish()
         self.problem = p
         self.problem_mode = mode                          # "sharded": self.problem holds this rank's class slice only
         ok = rc == 0

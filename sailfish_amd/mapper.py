@@ -25,7 +25,9 @@ def pack_sequences(seqs, device="cpu"):
 class QuasiIndex:
     """k-mer index of a transcriptome on the device (sfgpu_index_build)."""
 
-    def __init__(self, sequences, k=31, max_occ=1000, device="cuda", seeds=2):
+    def __init__(self, sequences, k=31, max_occ=1000, device="cuda", seeds=2, seed_len=None):
+        """seed_len: None = the library's default (scan mode, seeds of min(19, k) bases, matches extended to maximal length);
+        0 = the end-seed contract (`seeds` exact k-mers per strand); 8 .. k = scan mode with seeds of that length"""
         self.device = torch.device(device)
         self._L = _lib.lib()
         seq, off = pack_sequences(sequences, self.device)
@@ -41,8 +43,18 @@ class QuasiIndex:
         _lib.check(self._L.sfgpu_index_info(self._h, C.byref(kk), C.byref(npos), C.byref(nk)))
         self.k, self.n_positions, self.n_kmers = kk.value, npos.value, nk.value
         self.seeds = 2
+        self.seed_len = min(19, self.k)
+        if seed_len is not None:
+            self.set_scan(seed_len)
         if seeds != 2:
             self.set_seeds(seeds)
+            if seed_len is None:
+                self.set_scan(0)                           # asking for S end seeds selects the end-seed contract
+
+    def set_scan(self, seed_len):
+        """sfgpu_index_set_scan: 0 = end seeds; 8 .. k = scan mode (maximal-match extension) with seeds of that length"""
+        _lib.check(self._L.sfgpu_index_set_scan(self._h, int(seed_len)))
+        self.seed_len = int(seed_len)
 
     def set_seeds(self, seeds):
         """seeds per strand (sfgpu_index_set_seeds): 2 = offsets 0 and len - k, every hit kept; 3 .. 8 = seeds spread evenly over

@@ -50,6 +50,32 @@ class EMProblem:
                                             _lib.ptr(eff), C.byref(nr), C.byref(st))
         return rc, st.as_dict(), eff, nr.value
 
+    def optimize_sharded(self, allreduce, poll_every=16, **kw):
+        """The sharded loop as ONE call (sfgpu_em_optimize_sharded): this handle holds one rank's slice of the classes,
+        `allreduce` leaves the sum of alphaOut over the ranks on every rank -- a sailfish_amd.comm.Comm (ncclAllReduce on
+        the loop's stream: no host code between two iterations) or a Python callable(tensor) (dry runs over gloo).
+        Returns (rc, stats dict) like optimize()."""
+        o = self.opts(**kw)
+        st = _lib.EmStats()
+        if hasattr(allreduce, "callback"):
+            fn, user = allreduce.callback()
+        else:
+            dev, err = self.device, []
+
+            def _cb(p, n, _u, _s):
+                try:
+                    allreduce(_tensor_from_ptr(p, n, dev))
+                    return 0
+                except Exception as e:      # an exception must not unwind through the C frame
+                    err.append(e)
+                    return 1
+            fn, user = _lib.ALLREDUCE_CB(_cb), None
+        rc = self._L.sfgpu_em_optimize_sharded(self._h, C.byref(o), fn, user, int(poll_every), _lib.ptr(self.alpha),
+                                               _lib.ptr(self.mass), C.byref(st))
+        if not hasattr(allreduce, "callback") and err:
+            raise err[0]
+        return rc, st.as_dict()
+
     # piecewise API (multi-GPU driver, tests)
     def begin(self, **kw):
         self._o = self.opts(**kw)

@@ -103,6 +103,26 @@ static int two_ranks_on_one_gpu() {
         DeviceBuf<double> a(M), ms(M);
         check(sfgpu_em_optimize(em, &opts, a.get(), ms.get(), &want_st), "optimize");
         want_alpha = a.download();
+        // the RCCL callback of the library itself (sfgpu_comm_*: librccl bound at run time), a communicator of one rank: the
+        // sharded loop with ncclAllReduce enqueued on its stream must give what optimize() gives
+        if (sfgpu_comm_available()) {
+            unsigned char id[SFGPU_COMM_ID_BYTES];
+            sfgpu_comm* comm = nullptr;
+            check(sfgpu_comm_unique_id(id), "comm_unique_id");
+            check(sfgpu_comm_create(&comm, id, 1, 0), "comm_create");
+            double us = 0.0;
+            DeviceBuf<double> buf(M);
+            check(sfgpu_comm_time_allreduce(comm, buf.get(), M, 20, nullptr, &us), "comm_time_allreduce");
+            sfgpu_em_stats st1{};
+            DeviceBuf<double> a1(M), ms1(M);
+            check(sfgpu_em_optimize_sharded(em, &opts, sfgpu_comm_allreduce_fn(), comm, 8, a1.get(), ms1.get(), &st1), "optimize_sharded(rccl)");
+            const std::vector<double> got = a1.download();
+            bool ok = st1.iters == want_st.iters;
+            for (uint32_t t = 0; ok && t < M; ++t) ok = (want_alpha[t] > 0) == (got[t] > 0) && close_to(got[t], want_alpha[t], 1e-9);
+            EXPECT(ok);
+            std::printf("rccl callback: world 1, all-reduce of %u doubles %.1f us, stop iteration %u\n", M, us, st1.iters);
+            sfgpu_comm_destroy(comm);
+        } else std::printf("rccl callback: librccl.so not loadable, skipped\n");
         sfgpu_em_destroy(em); sfgpu_eq_destroy(eq);
     }
     Shared sh;

@@ -23,7 +23,7 @@ K, READ = 31, 50
 COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
 
 
-def main(src="/root/reference/sample_data.tgz"):
+def main(src="/root/reference/sample_data.tgz", scan=False):
     tf = tarfile.open(src)
     get = lambda n: tf.extractfile("sample_data/" + n).read().decode()
     names, seqs = [], []
@@ -45,6 +45,12 @@ def main(src="/root/reference/sample_data.tgz"):
 
     r1 = get("reads_1.fastq").split("\n"); r2 = get("reads_2.fastq").split("\n")
     n = len(r1) // 4
+    if scan:
+        # the SCAN contract (the mapper's default since round 3: maximal-match extension, seeds of 19 bases), restated in
+        # oracle/mapper_oracle.py -- same record layout, written to sample_data_hits_scan.npz
+        from oracle import mapper_oracle as MO
+        sindex = MO.build_scan_index([x.encode() for x in seqs])
+        map_read = lambda r: MO.scan_read(sindex, r.encode(), s=19)
     recs, off, truth = [], [0], []
     for i in range(n):
         truth.append(names.index(r1[4 * i].split(":")[1]))
@@ -58,7 +64,7 @@ def main(src="/root/reference/sample_data.tgz"):
             recs += [(t, p, 0, 0, READ, READ, f, 0, 2, 0) for t, f, p in right]
         off.append(len(recs))
     hits = np.array(recs, dtype=HIT_DTYPE)
-    out = os.path.join(HERE, "sample_data_hits.npz")
+    out = os.path.join(HERE, "sample_data_hits_scan.npz" if scan else "sample_data_hits.npz")
     np.savez_compressed(out, names=np.array(names), ref_len=np.array([len(s) for s in seqs], np.uint32),
                         hits=hits.view(np.uint8), offsets=np.array(off, np.uint32), truth=np.array(truth, np.uint32))
     mapped = int((np.diff(off) > 0).sum())
@@ -67,4 +73,5 @@ def main(src="/root/reference/sample_data.tgz"):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    args = [a for a in sys.argv[1:] if a != "--scan"]
+    main(*args, scan="--scan" in sys.argv[1:])

@@ -141,6 +141,19 @@ class _EM:
     def poll(self):
         return self._stop(), dict(iters=self.it, converged=self.conv, n_active=self.n_active)
 
+    def optimize_sharded(self, allreduce, poll_every=16, **kw):
+        """sfgpu_em_optimize_sharded's control flow (csrc/em.hip) over the numpy pieces: begin -> all-reduce -> init ->
+        { sweep, all-reduce, update } polled every poll_every iterations -> finish"""
+        self.begin(**kw)
+        allreduce(self.ao)
+        self.init()
+        done = self._stop()
+        while not done:
+            for _ in range(poll_every):
+                self.sweep(); allreduce(self.ao); self.update()
+            done, _ = self.poll()
+        return self.finish()
+
     # the piecewise loop with the bias hook
     def set_bounds(self, min_iter, max_iter):
         self.min_iter, self.max_iter = min_iter, max_iter

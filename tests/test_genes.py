@@ -48,3 +48,42 @@ def test_gene_map_from_gtf(tmp_path):
     out = genes.generate_gene_level_estimates(str(tmp_path / "map.gtf"), str(tmp_path))      # the .gtf extension selects the reader (:1050-1053)
     lines = open(out).read().split("\n")
     assert lines[1] == "G1\t714.286\t600\t40\t100" and lines[2] == "G2\t500\t300\t2\t3"
+
+
+def _tgm_vectors():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tgm_vectors.json")))["cases"]
+
+
+def test_gene_lookup_matches_the_reference_header():
+    """genes.TranscriptGeneMap.gene_name against TranscriptGeneMap::geneName of the reference's own header
+    (include/TranscriptGeneMap.hpp:94-135, compiled unmodified into oracle/_ref/libtgm_ref.so; vectors committed by
+    tests/golden/make_ref_tgm_vectors.py): names in the map, absent names that land on the next entry, names past the end"""
+    from sailfish_amd import genes
+    n = 0
+    for case in _tgm_vectors():
+        tgm = genes.TranscriptGeneMap.__new__(genes.TranscriptGeneMap)
+        tgm.transcript_names, tgm.gene_names, tgm.t2g = case["transcripts"], case["genes"], case["t2g"]
+        for q, want in zip(case["queries"], case["gene_of_query"]):
+            assert tgm.gene_name(q) == want, (q, want)
+            n += 1
+    assert n > 300
+
+
+def test_reference_header_still_gives_the_committed_vectors():
+    """where oracle/_ref was built (this container; it travels to the GPU box): the live library reproduces the fixture"""
+    import ctypes as C
+    import pytest
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libtgm_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libtgm_ref.so not built (no /root/reference here)")
+    L = C.CDLL(so)
+    L.ref_tgm_gene_names.restype = C.c_size_t
+    L.ref_tgm_gene_names.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_char_p), C.c_size_t, C.c_char_p, C.c_size_t]
+    arr = lambda strs: (C.c_char_p * len(strs))(*[s.encode() for s in strs])
+    for case in _tgm_vectors():
+        out = C.create_string_buffer(1 << 20)
+        L.ref_tgm_gene_names(arr(case["transcripts"]), len(case["transcripts"]), arr(case["genes"]), len(case["genes"]),
+                             (C.c_size_t * len(case["t2g"]))(*case["t2g"]), arr(case["queries"]), len(case["queries"]), out, len(out))
+        assert out.value.decode().split("\n") == case["gene_of_query"]

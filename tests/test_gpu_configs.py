@@ -27,7 +27,9 @@ CFG3 = (200_000, 4_000_000, 400_000_000)
 # all-reduce through the host, and the iterations past 80 show nothing the first 80 do not (min_iter is 50: the stop logic ran).
 # (Nine processes on one device: on its own this test takes ~20 s, after other GPU tests in the same session 6-8 minutes --
 # the device's queues are oversubscribed; fewer queues per rank, trimmed caches, a fresh parent process were tried and do not help.)
-CFG4_MAX_ITER = 80
+# SFGPU_CFG4_FULL=1 lifts the cut: both sides then run to convergence and the sharded loop must stop at the single-GPU loop's
+# iteration (212 on this read stream) -- run on its own, outside the default suite (profiles/r3_cfg4_full.txt).
+CFG4_MAX_ITER = 10000 if os.environ.get("SFGPU_CFG4_FULL") else 80
 
 
 def _fl_counts():
@@ -101,7 +103,9 @@ def test_cfg4_eight_ranks_share_the_gpu(gpu):
     assert np.array_equal(tab["counts"], v1.counts.cpu().numpy())
     # sharded EM: each rank swept ~1/8 of the classes, and the loop stopped where the single-GPU loop stops
     assert sharded == 1 and 0 < c_local < n_classes // 4
-    assert iters == info1["em_stats"]["iters"] == CFG4_MAX_ITER and conv == int(info1["em_stats"]["converged"]), (iters, info1["em_stats"])
+    assert iters == info1["em_stats"]["iters"] and conv == int(info1["em_stats"]["converged"]), (iters, info1["em_stats"])
+    assert iters == CFG4_MAX_ITER or (CFG4_MAX_ITER == 10000 and conv == 1 and iters > 80), (iters, conv)
+    print(f"cfg4: {world} ranks, sharded EM stopped at iteration {iters} (single GPU: {info1['em_stats']['iters']}), converged={conv}")
     alphas = [np.load(os.path.join(outdir, f"alpha{r}.npy")) for r in range(world)]
     for a in alphas[1:]:
         assert np.array_equal(a, alphas[0])                        # the all-reduce leaves every rank with the same bits

@@ -176,3 +176,40 @@ def test_rccl_all_to_all_single_takes_byte_blocks(gpu):
     assert out.get(timeout=240) is True
     p.join(60)
     assert p.exitcode == 0
+
+
+def test_rccl_comm_drives_the_sharded_loop(gpu):
+    """libsfgpu's own RCCL communicator (sailfish_amd/comm.py, csrc/comm.hip: librccl bound at run time) as the all-reduce
+    of sfgpu_em_optimize_sharded.  One GPU allows a communicator of ONE rank only (RCCL refuses two ranks on a device): the
+    sum over one rank is the identity, so the sharded loop -- piecewise kernels, ncclAllReduce enqueued on the loop's stream
+    between sweep and update, no Python between iterations -- must stop where optimize() stops, with its alpha."""
+    import sailfish_amd as sf
+    from sailfish_amd import comm, synth
+    if not comm.available():
+        pytest.fail("librccl.so could not be loaded on a GPU box")
+    M = 5000
+    ref_len, ids, off = synth.workload(M, 20000, 400_000)
+    eq = sf.EquivalenceClassBuilder(device=gpu); eq.start(); eq.add_batch(ids.to(gpu), off.to(gpu)); eq.finish(); v = eq.eqVec()
+    length = ref_len.to(gpu).to(torch.float64)
+    c = comm.Comm(1, 0, comm.Comm.unique_id(), gpu)
+    try:
+        t = torch.arange(1000, dtype=torch.float64, device=gpu)
+        c.all_reduce(t); torch.cuda.synchronize()
+        assert torch.equal(t, torch.arange(1000, dtype=torch.float64, device=gpu))
+        assert c.time_all_reduce(M, 20) > 0.0
+        for vb in (False, True):
+            p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads)
+            rc, st = p.optimize(use_vbem=vb)
+            want = p.alpha.clone()
+            rc2, st2 = p.optimize_sharded(c, poll_every=7, use_vbem=vb)
+            assert rc == 0 and rc2 == 0 and st2["iters"] == st["iters"] and st2["converged"] == st["converged"]
+            nz = want > 0
+            assert torch.equal(p.alpha > 0, nz)
+            assert float(((p.alpha[nz] - want[nz]).abs() / want[nz]).max()) < 1e-9
+            # and with a Python callable in the callback's place (what the gloo dry runs use)
+            calls = []
+            rc3, st3 = p.optimize_sharded(lambda buf: calls.append(buf.numel()), poll_every=7, use_vbem=vb)
+            assert rc3 == 0 and st3["iters"] == st["iters"] and len(calls) >= st["iters"] + 1 and set(calls) == {M}
+            p.close()
+    finally:
+        c.close()

@@ -72,7 +72,7 @@ def test_device_mapper_matches_its_contract(gpu, paired):
     import sailfish_amd as sf
     rng = np.random.default_rng(17 + paired)
     seqs, r1, r2 = _random_case(rng)
-    idx = sf.mapper.QuasiIndex(seqs, k=31, max_occ=1000, device=gpu)
+    idx = sf.mapper.QuasiIndex(seqs, k=31, max_occ=1000, device=gpu, seed_len=0)          # the end-seed contract (default: scan mode)
     assert idx.n_positions == sum(max(len(s) - 30, 0) for s in seqs)
     hits, off = idx.map_reads(r1, r2 if paired else None)
     gh, go = sf.mapper.hits_to_numpy(hits, off)
@@ -82,7 +82,7 @@ def test_device_mapper_matches_its_contract(gpu, paired):
     assert len(oh) > len(r1) // 2 and (not paired or int((oh["mate_status"] == 3).sum()) > len(r1) // 4)
     # a repeat that exceeds max_occ: the same cut on both sides
     rep = [b"ACGT" * 40] * 6 + seqs[:5]
-    idx2 = sf.mapper.QuasiIndex(rep, k=31, max_occ=3, device=gpu)
+    idx2 = sf.mapper.QuasiIndex(rep, k=31, max_occ=3, device=gpu, seed_len=0)
     h2, o2 = sf.mapper.hits_to_numpy(*idx2.map_reads([b"ACGT" * 15, b"TTTT" * 15, b"AC"]))
     eh, eo = MO.map_reads(MO.build_index(rep, 31, 3), [b"ACGT" * 15, b"TTTT" * 15, b"AC"])
     assert np.array_equal(o2, eo) and np.array_equal(h2, eh)
@@ -150,11 +150,14 @@ def test_bundled_sample_data_from_the_reads(gpu, tmp_path):
     recovers the simulated abundances"""
     import sailfish_amd as sf
     names, seqs, r1, r2, truth = _sample_reads()
-    gold = np.load(os.path.join(GOLD, "sample_data_hits.npz"))
     idx = sf.mapper.QuasiIndex(seqs, device=gpu)
-    hits, off = sf.mapper.hits_to_numpy(*idx.map_reads(r1, r2))
-    assert np.array_equal(off, gold["offsets"]) and np.array_equal(hits, gold["hits"].view(O.HIT_DTYPE))
-    assert all(truth[r] in hits["tid"][off[r]:off[r + 1]] for r in range(len(truth)))
+    for seed_len, fixture in ((None, "sample_data_hits_scan.npz"), (0, "sample_data_hits.npz")):     # default = scan mode; 0 = end seeds
+        gold = np.load(os.path.join(GOLD, fixture))
+        if seed_len is not None:
+            idx.set_scan(seed_len)
+        hits, off = sf.mapper.hits_to_numpy(*idx.map_reads(r1, r2))
+        assert np.array_equal(off, gold["offsets"]) and np.array_equal(hits, gold["hits"].view(O.HIT_DTYPE)), fixture
+        assert all(truth[r] in hits["tid"][off[r]:off[r + 1]] for r in range(len(truth)))
     out = str(tmp_path / "out")
     rc, exp = sf.mapper.quantify_reads(names, seqs, r1, r2, "IU", out, sf.SailfishOpts(numFragSamples=5000), batch_reads=3000,
                                        cmd_options={"libType": "IU"}, device=gpu)
@@ -164,3 +167,78 @@ def test_bundled_sample_data_from_the_reads(gpu, tmp_path):
     num_reads = np.array([float(r[4]) for r in rows])
     want = np.bincount(truth, minlength=15).astype(np.float64)
     assert abs(num_reads.sum() - 10000) < 1e-2 and np.abs(num_reads - want).sum() / 10000 < 0.1
+    print("sample_data from the reads (scan mode): L1 error of NumReads vs the simulator's truth", np.abs(num_reads - want).sum() / 10000)
+
+
+# ---- scan mode (maximal-match extension; the default since round 3) ---------------------------------------------------------
+
+def test_scan_contract_reproduces_its_committed_hit_records(built):
+    """the CPU restatement of the scan contract on the bundled reads gives the committed scan fixture (first 800 pairs)"""
+    names, seqs, r1, r2, truth = _sample_reads()
+    gold = np.load(os.path.join(GOLD, "sample_data_hits_scan.npz"))
+    gh = gold["hits"].view(O.HIT_DTYPE); go = gold["offsets"]
+    n = 800
+    hits, off = MO.scan_reads(MO.build_scan_index(seqs), r1[:n], r2[:n], s=19)
+    assert np.array_equal(off, go[: n + 1]) and np.array_equal(hits, gh[: go[n]])
+
+
+def test_scan_contract_maps_reads_with_substitutions(built):
+    """on the bundled reads (2 x 50 bases) with 2 % substitutions the end-seed contract places the simulated
+    transcript among the hits of 274 of 400 reads (287 with eight 31-mer seeds: a single substitution in the middle of a 50-base
+    read leaves no clean 31-mer); the scan contract with 19-base seeds and maximal-match extension must reach 380"""
+    names, seqs, r1, r2, truth = _sample_reads()
+    rng = np.random.default_rng(3)
+    n = 400
+    e1 = _with_errors(rng, r1[:n], 0.02)
+    si = MO.build_scan_index(seqs)
+    got = {s: sum(int(truth[r] in [t for t, f, p in MO.scan_read(si, e1[r], s=s)]) for r in range(n)) for s in (31, 19, 15)}
+    assert got[19] >= 380 and got[15] >= got[19] >= got[31], got
+    # error-free reads: every read carries its transcript, and a whole-read forward match never walks the other strand
+    assert all(truth[r] in [t for t, f, p in MO.scan_read(si, r1[r], s=19)] for r in range(n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed_len,rate", [(19, 0.03), (15, 0.05), (31, 0.0), (8, 0.02)])
+def test_device_scan_mapper_matches_its_contract(gpu, seed_len, rate):
+    """scan mode on the device = the restated contract, record for record: random isoform-like transcriptome (shared segments, N,
+    lower case, transcripts shorter than k, ragged and short reads, reads with N), substitutions, paired and single end, several
+    seed lengths (31 = whole k-mers, 8 = shorter than the bucket prefix: the range spans buckets), a repeat beyond max_occ"""
+    import sailfish_amd as sf
+    rng = np.random.default_rng(90 + seed_len)
+    seqs, r1, r2 = _random_case(rng, n_reads=1500, read_len=70)
+    if rate:
+        r1, r2 = _with_errors(rng, r1, rate), _with_errors(rng, r2, rate)
+    max_occ = 50 if seed_len == 8 else 1000
+    idx = sf.mapper.QuasiIndex(seqs, k=31, max_occ=max_occ, device=gpu, seed_len=seed_len)
+    si = MO.build_scan_index(seqs)
+    for paired in (True, False):
+        gh, go = sf.mapper.hits_to_numpy(*idx.map_reads(r1, r2 if paired else None))
+        oh, oo = MO.scan_reads(si, r1, r2 if paired else None, s=seed_len, max_occ=max_occ)
+        assert np.array_equal(go, oo) and np.array_equal(gh, oh)
+        assert len(oh) > len(r1) // 3
+    # a repeat that exceeds max_occ is a miss in scan mode (dropped, not truncated), on both sides
+    rep = [b"ACGT" * 40, b"ACGT" * 30 + b"GATTACAGATTACAGATTACAGATTACAGATTACA"]
+    idx2 = sf.mapper.QuasiIndex(rep, k=31, max_occ=3, device=gpu, seed_len=19)
+    q = [b"ACGT" * 15, b"TACAGATTACAGATTACAGATTACA", b"AC"]
+    h2, o2 = sf.mapper.hits_to_numpy(*idx2.map_reads(q))
+    eh, eo = MO.scan_reads(MO.build_scan_index(rep), q, s=19, max_occ=3)
+    assert np.array_equal(o2, eo) and np.array_equal(h2, eh) and o2[1] == 0 and o2[2] > o2[1]
+
+
+@pytest.mark.gpu
+def test_device_scan_mapper_recovers_reads_with_errors(gpu):
+    """the device's default mode on the 400 bundled reads with 2 % substitutions: >= 380 carry their true transcript"""
+    import sailfish_amd as sf
+    names, seqs, r1, r2, truth = _sample_reads()
+    rng = np.random.default_rng(3)
+    n = 400
+    e1 = _with_errors(rng, r1[:n], 0.02)
+    idx = sf.mapper.QuasiIndex(seqs, device=gpu)
+    assert idx.seed_len == 19
+    hits, off = sf.mapper.hits_to_numpy(*idx.map_reads(e1))
+    ok = sum(int(truth[r] in hits["tid"][off[r]:off[r + 1]]) for r in range(n))
+    idx.set_scan(0)
+    hits0, off0 = sf.mapper.hits_to_numpy(*idx.map_reads(e1))
+    ok0 = sum(int(truth[r] in hits0["tid"][off0[r]:off0[r + 1]]) for r in range(n))
+    print(f"reads with 2 % substitutions carrying their transcript: scan mode {ok} / {n}, end seeds {ok0} / {n}")
+    assert ok >= 380 > ok0

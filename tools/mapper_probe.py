@@ -29,6 +29,13 @@ rl32 = ref_len.to(torch.int32).contiguous(); o0 = off[:-1].contiguous()
 _lib.check(Lb.sfgpu_index_build(C.byref(h), _lib.ptr(seq), _lib.ptr(o0), _lib.ptr(rl32), M, 31, 1000, None))
 torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"index: {M} transcripts, {N/1e6:.1f} M bases: {1e3*(t1-t0):.1f} ms")
+if os.environ.get("MAP_SEED_LEN") is not None:
+    _lib.check(Lb.sfgpu_index_set_scan(h, int(os.environ["MAP_SEED_LEN"])))       # 0 = end seeds; default: scan mode, 19-base seeds
+if float(os.environ.get("MAP_ERR", 0)) > 0:                                        # substitutions at this rate per base
+    er = float(os.environ["MAP_ERR"])
+    for m in (m1, m2):
+        hit = torch.rand(m.shape, generator=g, device=dev) < er
+        m[hit] = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (int(hit.sum()),), generator=g, device=dev)]
 hoff = torch.empty(R + 1, dtype=torch.int32, device=dev); nh = C.c_uint64(0)
 hits = torch.empty(2 * R * 24, dtype=torch.uint8, device=dev)
 for it in range(3):
