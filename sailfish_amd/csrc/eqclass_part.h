@@ -85,7 +85,8 @@ constexpr int kStageWords = 512;                             // ids a wavefront 
 //     read -> release add between wavefronts; the fences below are for the compiler.
 // What is left in the ring when the block ends (the last, partial unit of every bin) is written by one thread per region.
 constexpr int kRingStageWords = 304;                          // staging per wavefront: (304 / 4 + 4) x 16 B = 1280 B (mean step: 256 ids; beyond: labels from global memory)
-constexpr uint32_t kRingHotSlots = 256;                       // what 160 KB leave for the hot table
+constexpr uint32_t kRingHotSlots = 256;                       // what 160 KB leave for the hot table (32-bit tags + counters: 2 KB)
+constexpr uint32_t kRingFlushList = 32;                       // completed units a wavefront lists per flush round (128 B per wavefront)
 constexpr uint32_t kRingMaxRegions = 1024;                    // 128 B of ring per region
 constexpr uint32_t kRingMaxCap = 32000;                       // 16-bit cursors with room for the reservations of every lane in flight
 constexpr uint32_t kRingFrontGranules = 4;                    // labels of more granules take the back of the bin
@@ -169,10 +170,14 @@ k_part_route(RouteArgs a) {
         for (uint32_t r = tid; r < NR; r += kPartBlock) { cur[r] = 0; cut[r] = 0xFFFFFFFFu; }
     }
     // hot classes: their bucket hashes and a counter each, behind the staging buffers
-    unsigned long long* hot_hl = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint4*>(cut + NR) + kPartWaves * (SW / 4 + 4));
+    // (the ring form has LDS for 32 bits of every hot hash -- a filter; the label compare below decides either way -- and for a
+    //  list of 32 completed units per wavefront, kRingFlushList)
+    using HotTag = typename std::conditional<RING, unsigned int, unsigned long long>::type;
+    HotTag* hot_hl = reinterpret_cast<HotTag*>(reinterpret_cast<uint4*>(cut + NR) + kPartWaves * (SW / 4 + 4));
     unsigned int* hot_cnt = reinterpret_cast<unsigned int*>(hot_hl + HS);
+    uint32_t* flist = hot_cnt + HS + wave * kRingFlushList;                                  // RING only
     const bool have_hot = *reinterpret_cast<const unsigned int*>(a.hot + 2 * HS) != 0u;      // (uniform)
-    if (have_hot) for (uint32_t q = tid; q < HS; q += kPartBlock) { hot_hl[q] = a.hot[q]; hot_cnt[q] = 0u; }
+    if (have_hot) for (uint32_t q = tid; q < HS; q += kPartBlock) { hot_hl[q] = RING ? (HotTag)(a.hot[q] >> 32) : (HotTag)a.hot[q]; hot_cnt[q] = 0u; }
     const uint32_t t0 = blk * a.tile;
     const uint32_t t1 = (t0 + a.tile < a.n && t0 + a.tile > t0) ? t0 + a.tile : a.n;
     const uint32_t* __restrict__ off = a.off;
@@ -214,6 +219,7 @@ k_part_route(RouteArgs a) {
         const bool staged = ((w_hi - w_lo + mis + 3u) >> 2) <= (uint32_t)SW / 4;
         stage4[lane] = x0;
         if (SW / 4 > 64 && lane + 64u < (uint32_t)SW / 4 + 4u) stage4[lane + 64u] = x1;
+        const uint32_t bit31_here = (x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w) & kHeadBit;      // (the step's ids as fetched: a superset of its labels' ids)
         // my label: [b, e)
         const uint32_t nxt = __shfl_down(o, 1, kWave);
         const uint32_t b = o, e = (lane == 63u || r0 + lane + 1u >= re) ? oe : nxt;
@@ -240,33 +246,41 @@ k_part_route(RouteArgs a) {
 #else
         const bool unfit = len > kMaxPartLabel;
 #endif
-        // bucket hash: 8 rounds over the (zero padded) head, then one round per further id (label_mix64_words' chain)
-        uint32_t ha = MP1 + len, hb = 0x27D4EB2Fu ^ (len * MP3);
-#pragma unroll
-        for (int q = 0; q < kHead; ++q) mix_round(ha, hb, w[q]);
+        // ---- bucket hash (xxh64_device.h): length, the first 8 ids, and for longer labels the last and the middle id -- no walk
+        //      over the tail (13 % of the labels have one: a lane walking its tail while the others wait cost this pass half of
+        //      its vector instructions)
+        uint32_t ha, hb;
+        label_mix_head(w, len, ha, hb);
+#ifdef SFGPU_X_NOTAIL
+        const uint32_t ng = label_granules(len) < 2u ? label_granules(len) : 2u;        // (experiment: no tail granules -- wrong bins, timing only)
+#else
         const uint32_t ng = label_granules(len);
-        // granule g >= 2 of my label (ids 4g-1 .. 4g+2, zero padded)
-        auto granule = [&](uint32_t g) -> uint4 {
+#endif
+        // granule g >= 2 (ids 4g-1 .. 4g+2, zero padded) of the label that starts at id `lb` and holds `ll` ids
+        auto granule_at = [&](uint32_t lb, uint32_t ll, uint32_t g) -> uint4 {
             const uint32_t q = 4u * g - 1u;
             uint32_t v0, v1, v2, v3;
-            if (staged) { v0 = lab_s[q]; v1 = lab_s[q + 1]; v2 = lab_s[q + 2]; v3 = lab_s[q + 3]; }
-            else { v0 = lab_g[q]; v1 = q + 1 < len ? lab_g[q + 1] : 0u; v2 = q + 2 < len ? lab_g[q + 2] : 0u; v3 = q + 3 < len ? lab_g[q + 3] : 0u; }
-            return make_uint4(v0, q + 1 < len ? v1 : 0u, q + 2 < len ? v2 : 0u, q + 3 < len ? v3 : 0u);
+            if (staged) { const uint32_t* ls = stage + mis + (lb - w_lo); v0 = ls[q]; v1 = ls[q + 1]; v2 = ls[q + 2]; v3 = ls[q + 3]; }
+            else { const uint32_t* lg = ids + lb; v0 = lg[q]; v1 = q + 1 < ll ? lg[q + 1] : 0u; v2 = q + 2 < ll ? lg[q + 2] : 0u; v3 = q + 3 < ll ? lg[q + 3] : 0u; }
+            return make_uint4(v0, q + 1 < ll ? v1 : 0u, q + 2 < ll ? v2 : 0u, q + 3 < ll ? v3 : 0u);
         };
-        // ids 7.. come one granule (ids 4g-1 .. 4g+2) at a time; labels of > 7 ids are 13 % of the reads, so this path is
-        // taken by some lane of nearly every wavefront and must not be a chain of dependent global loads
+        auto granule = [&](uint32_t g) -> uint4 { return granule_at(b, len, g); };
+#ifndef SFGPU_X_NOFAR
         if (len > (uint32_t)kHead && !unfit) {
-            for (uint32_t g = 2; g < ng; ++g) {
-                const uint32_t q = 4u * g - 1u;
-                const uint4 v = granule(g);
-                if (q >= (uint32_t)kHead) mix_round(ha, hb, v.x);
-                if (q + 1 < len) mix_round(ha, hb, v.y);
-                if (q + 2 < len) mix_round(ha, hb, v.z);
-                if (q + 3 < len) mix_round(ha, hb, v.w);
-                mx = mx > v.x ? mx : v.x; mx = mx > v.y ? mx : v.y; mx = mx > v.z ? mx : v.z; mx = mx > v.w ? mx : v.w;
-            }
+#else
+        if (len > (uint32_t)kHead && !unfit && cap == 0xFFFFFFFFu) {
+#endif
+            const uint32_t last = staged ? lab_s[len - 1u] : lab_g[len - 1u], mid = staged ? lab_s[len >> 1] : lab_g[len >> 1];
+            label_mix_far(ha, hb, last, mid);
         }
-        const uint64_t h = ((uint64_t)mix_fin(ha ^ hb) << 32) | mix_fin(hb + (ha >> 3));
+        // ids >= 2^31 in a tail: the staged words of the whole step are checked at once (they never occur in a real index: such a
+        // step -- or, unstaged, such a label -- takes the generic kernel)
+        if (staged) {
+            if (__ballot(bit31_here != 0u)) mx |= kHeadBit;
+        } else if (len > (uint32_t)kHead && !unfit) {
+            for (uint32_t q = kHead; q < len; ++q) mx |= lab_g[q];
+        }
+        const uint64_t h = label_mix_final(ha, hb);
         // an id >= 2^31 would collide with the label marker of the partition stream (no real transcriptome has one)
         bool generic = unfit || (mx & kHeadBit);
         const uint32_t rg = ((uint32_t)h >> kRegionBits) & a.region_mask;
@@ -293,9 +307,10 @@ k_part_route(RouteArgs a) {
         bool counted = false;
         if (have_hot && len != 0 && !generic && !dup) {
             uint32_t hi = hot_index(h, HS);
-            unsigned long long hv = hot_hl[hi];
-            for (uint32_t p = 1; p < kHotProbes && hv != 0ull && hv != h; ++p) { hi = (hi + 1) & (HS - 1); hv = hot_hl[hi]; }
-            if (hv == h) {
+            const HotTag hk = RING ? (HotTag)(h >> 32) : (HotTag)h;
+            HotTag hv = hot_hl[hi];
+            for (uint32_t p = 1; p < kHotProbes && hv != 0 && hv != hk; ++p) { hi = (hi + 1) & (HS - 1); hv = hot_hl[hi]; }
+            if (hv == hk && hv != 0) {
                 // same bucket hash: the label itself decides (arena entry [n, id0, id1, id2][id3 .. id6] ...; a label in
                 // granule form is the same from the second granule on)
                 const uint4* e = reinterpret_cast<const uint4*>(a.arena) + reinterpret_cast<const uint2*>(a.hot + HS)[hi].x;
@@ -309,10 +324,21 @@ k_part_route(RouteArgs a) {
                 if (same) { atomicAdd(&hot_cnt[hi], mult); counted = true; }
             }
         }
+#ifdef SFGPU_X_DROPLONG
+        const bool place = len != 0 && !generic && !counted && !dup && ng <= 2u;       // (experiment: what would a pass over the regular labels alone cost)
+#else
         const bool place = len != 0 && !generic && !counted && !dup;
+#endif
         const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
         auto head_granule = [&]() { return make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]); };
         auto count_granule = [&]() { return make_uint4(mult, kCountedBit, 0u, 0u); };       // (bit 31 of .y: no id has it -- such labels take the generic kernel)
+        // granule j of what my label puts into the stream: head, ids 3..6, tail granules, the run's count
+        auto stream_granule = [&](uint32_t j) -> uint4 {
+            if (j == 0u) return head_granule();
+            if (j >= ng) return count_granule();
+            if (j == 1u) return make_uint4(w[3], w[4], w[5], w[6]);
+            return granule(j);
+        };
         if constexpr (!RING) {
             if (place) {
                 const uint32_t at = atomicAdd(&cur[rg], ngx);                               // my granules in the bin (rg, blk)
@@ -328,119 +354,178 @@ k_part_route(RouteArgs a) {
                 }
             }
         } else {
-            // ---- reservation: front (through the ring) or back (direct stores) of the bin (rg, blk)
+            // ---- reservation: front (through the ring) or back (direct stores) of the bin (rg, blk).  The back takes the labels of
+            //      more than 4 granules and the labels that would have to WAIT for a ring slot: a unit that is complete but not yet
+            //      released by its completer (a window of a thousand cycles or so) is closed to the lane that needs its slot, and
+            //      1.8 % of the labels met one -- every other wavefront step then went through the retry loop below.  The lane looks
+            //      before it reserves: if the units it would get at the cursor's present position are not open it stores its label
+            //      at the back instead (scattered 16-byte stores, for those few labels).  Only a lane that loses a race between the
+            //      look and the reservation still has to wait.
             bool front = false;
             uint32_t at = 0;
             uint32_t stv = 0;
-            uint4 G[kRingFrontGranules];
-#pragma unroll
-            for (int j = 0; j < (int)kRingFrontGranules; ++j) G[j] = count_granule();
+            auto is_open = [&](uint32_t v, uint32_t sv) { return ((v >> 1) & 0xFFFu) == ((sv >> (16u * (v & 1u) + 3u)) & 0xFFFu); };
+            bool back_ok = false;
+            uint32_t back_at = 0;                                                             // granule index of my label in a.out
             if (place) {
                 const uint2 cs = cbst[rg];                                                   // (a stale unit state is safe: it can only say "closed")
                 stv = cs.y;
-                if ((cs.x & 0xFFFFu) + (cs.x >> 16) + ngx > cap) generic = true;             // does not fit, and never will: nothing reserved
+                const uint32_t pf = cs.x & 0xFFFFu;
+                if (pf + (cs.x >> 16) + ngx > cap) generic = true;                           // does not fit, and never will: nothing reserved
+#ifdef SFGPU_X_NOSLOW
                 else if (ngx <= kRingFrontGranules) {
+#else
+                else if (ngx <= kRingFrontGranules && is_open(pf >> 2, stv) && is_open((pf + ngx - 1u) >> 2, stv)) {
+#endif
                     const uint32_t old = atomicAdd(&cbst[rg].x, ngx);
                     at = old & 0xFFFFu;
-                    if (at + ngx + (old >> 16) <= cap) {
-                        front = true;
-                        G[0] = head_granule();
-                        if (len > 3u) G[1] = make_uint4(w[3], w[4], w[5], w[6]);
-                        if (ng > 2u) G[2] = granule(2);
-                        if (ng > 3u) G[3] = granule(3);
-                    } else {                                                                 // lost a race for the last room: the front ends before this label
+                    if (at + ngx + (old >> 16) <= cap) front = true;
+                    else {                                                                   // lost a race for the last room: the front ends before this label
                         atomicMin(&a.cut[((size_t)blk * NR + rg) * 2u], at); __threadfence();
                         generic = true;
                     }
-                } else {
+                }
+#ifdef SFGPU_X_NOBACK
+                else if (cap == 0xFFFFFFFFu) {
+#else
+                else {
+#endif
                     const uint32_t old = atomicAdd(&cbst[rg].x, ngx << 16);
                     const uint32_t bk = old >> 16;
                     if ((old & 0xFFFFu) + bk + ngx <= cap) {
-                        uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + (cap - bk - ngx);
+                        back_ok = true; back_at = (blk * NR + rg) * cap + (cap - bk - ngx);
+                        uint4* dst = a.out + (size_t)back_at;
                         dst[0] = head_granule();
                         if (mult > 1u) dst[ng] = count_granule();
-                        dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
-                        for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
+                        if (ng > 1u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
                     } else {
                         atomicMin(&a.cut[((size_t)blk * NR + rg) * 2u + 1u], bk); __threadfence();
                         generic = true;
                     }
                 }
             }
-            // ---- the ring: every lane is done with the staged ids (G is in registers), the staging buffer now holds the flush list
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // a label touches at most two units: u0 (its first n0 granules) and u0 + 1 (the other n1)
+            // the tail granules of the labels at the back: the wavefront copies them together, label by label -- lane i takes granule
+            // 2 + i (a lane walking its own label's tail kept the other 63 waiting: 72 of this kernel's 535 vector instructions per step)
+            for (unsigned long long bm = __ballot(back_ok && ng > 2u); bm; bm &= bm - 1ull) {
+                const int src = __builtin_ctzll(bm);
+                const uint32_t o_at = __shfl(back_at, src, kWave), o_b = __shfl(b, src, kWave), o_len = __shfl(len, src, kWave);
+                const uint32_t o_ng = label_granules(o_len);
+                for (uint32_t g = 2u + lane; g < o_ng; g += 64u) a.out[(size_t)o_at + g] = granule_at(o_b, o_len, g);
+            }
+            // ---- the ring.  A label touches at most two units: u0 (its first n0 granules) and u0 + 1 (the other n1)
             const uint32_t u0 = at >> 2, q0 = u0 & 1u;
             const uint32_t n0 = (4u - (at & 3u)) < ngx ? (4u - (at & 3u)) : ngx, n1 = ngx - n0;
-            auto is_open = [&](uint32_t v, uint32_t sv) { return ((v >> 1) & 0xFFFu) == ((sv >> (16u * (v & 1u) + 3u)) & 0xFFFu); };
-            uint32_t* flist = reinterpret_cast<uint32_t*>(stage4);
             bool c0 = false, c1 = false;                                                      // completed: unit u0 / unit u0 + 1
-            // the usual step: every unit a lane needs is open -- write, count, flush once
-            bool more = front;
-            const bool fast = front && is_open(u0, stv) && (n1 == 0u || is_open(u0 + 1u, stv));
-            if (fast) {
-#pragma unroll
-                for (uint32_t j = 0; j < kRingFrontGranules; ++j) if (j < ngx) ring4[rg * 8u + ((at + j) & 7u)] = G[j];
-                const uint32_t add = (n0 << (16u * q0)) | (n1 << (16u * (q0 ^ 1u)));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#ifdef SFGPU_X_NORING
-                const uint32_t nw = cap == 0xFFFFFFFFu ? atomicAdd(&cbst[rg].y, add) + add : 0u;
-#else
-                const uint32_t nw = atomicAdd(&cbst[rg].y, add) + add;
-#endif
-                c0 = ((nw >> (16u * q0)) & 7u) == 4u;
-                c1 = n1 != 0u && ((nw >> (16u * (q0 ^ 1u))) & 7u) == 4u;
-                more = false;
-            }
-            // flush the units this step completed: four lanes per unit, 16 units per store instruction; then the completers
-            // release the ring slots (count back to 0, one more unit of that parity flushed)
+            // The units a step completed are written out by the wavefront together: four lanes per unit -- one whole 64-byte segment
+            // per four lanes -- 16 units per store instruction, listed kRingFlushList at a time; then the completers release the ring
+            // slots: count back to 0, one more unit of that parity flushed.  (A completer storing its own unit's four granules one
+            // after the other was measured: 10.2 instead of 7.9 ms per build -- 1.6 scattered 16-byte requests per label again.  LDS
+            // executes a wavefront's instructions in order: the granules have been read when the release is performed.)
             auto flush = [&]() {
                 const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
-                if (m0 | m1) {
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    const uint32_t k_n0 = (uint32_t)__builtin_popcountll(m0), K = k_n0 + (uint32_t)__builtin_popcountll(m1);
-                    if (c0) flist[__builtin_popcountll(m0 & below)] = rg | (u0 << 10);
-                    if (c1) flist[k_n0 + __builtin_popcountll(m1 & below)] = rg | ((u0 + 1u) << 10);
+                if (!(m0 | m1)) return;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t k_n0 = (uint32_t)__builtin_popcountll(m0), K = k_n0 + (uint32_t)__builtin_popcountll(m1);
+                const uint32_t r0 = (uint32_t)__builtin_popcountll(m0 & below), r1 = k_n0 + (uint32_t)__builtin_popcountll(m1 & below);
+                for (uint32_t base = 0; base < K; base += kRingFlushList) {
+                    if (c0 && r0 - base < kRingFlushList) flist[r0 - base] = rg | (u0 << 10);
+                    if (c1 && r1 - base < kRingFlushList) flist[r1 - base] = rg | ((u0 + 1u) << 10);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (uint32_t k0 = 0; k0 < K; k0 += 16u) {
-                        const uint32_t k = k0 + (lane >> 2);
-#ifdef SFGPU_X_NOFLUSH
-                        if (k < K && cap == 0xFFFFFFFFu) {
-#else
-                        if (k < K) {
-#endif
-                            const uint32_t e = flist[k], r = e & 1023u, v = e >> 10;
-                            a.out[(size_t)(blk * NR + r) * cap + 4u * v + (lane & 3u)] = ring4[r * 8u + ((v & 1u) << 2) + (lane & 3u)];
-                        }
+                    const uint32_t n_here = (K - base < kRingFlushList) ? (K - base) : kRingFlushList;
+                    // the units' granules go to registers first; as soon as the last round's reads are in the LDS queue the ring
+                    // slots are released (in order behind them) -- the stores to memory follow: a unit that is complete but not
+                    // yet released keeps every lane that needs its slot waiting
+                    static_assert(kRingFlushList == 32, "two store rounds of 16 units per list");
+                    const uint32_t ka = lane >> 2, kb = 16u + (lane >> 2);
+                    uint4 da = make_uint4(0u, 0u, 0u, 0u), db = da;
+                    uint32_t wa = 0xFFFFFFFFu, wb = 0xFFFFFFFFu;
+                    if (ka < n_here) {
+                        const uint32_t e = flist[ka], r = e & 1023u, v = e >> 10;
+                        da = ring4[r * 8u + ((v & 1u) << 2) + (lane & 3u)];
+                        wa = (blk * NR + r) * cap + 4u * v + (lane & 3u);
                     }
-                    // the units' granules have been read (LDS is in order)
+                    if (kb < n_here) {
+                        const uint32_t e = flist[kb], r = e & 1023u, v = e >> 10;
+                        db = ring4[r * 8u + ((v & 1u) << 2) + (lane & 3u)];
+                        wb = (blk * NR + r) * cap + 4u * v + (lane & 3u);
+                    }
+                    if (base + kRingFlushList >= K) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        if (c0 | c1) atomicAdd(&cbst[rg].y, (c0 ? (4u << (16u * q0)) : 0u) | (c1 ? (4u << (16u * (q0 ^ 1u))) : 0u));
+                    }
+#ifdef SFGPU_X_NOFLUSH
+                    if (cap == 0xFFFFFFFFu) {
+#else
+                    {
+#endif
+                        if (wa != 0xFFFFFFFFu) a.out[(size_t)wa] = da;
+                        if (wb != 0xFFFFFFFFu) a.out[(size_t)wb] = db;
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    if (c0 | c1) atomicAdd(&cbst[rg].y, (c0 ? (4u << (16u * q0)) : 0u) | (c1 ? (4u << (16u * (q0 ^ 1u))) : 0u));
                 }
             };
+            // the usual step: every unit a lane needs is open -- write, count, flush
+            bool more = front;
+#ifdef SFGPU_X_NOSLOW
+            const bool fast = front;
+#else
+            const bool fast = front && is_open(u0, stv) && (n1 == 0u || is_open(u0 + 1u, stv));
+#endif
+            if (fast) {
+                ring4[rg * 8u + (at & 7u)] = head_granule();
+                if (ngx > 1u) ring4[rg * 8u + ((at + 1u) & 7u)] = (ng > 1u) ? make_uint4(w[3], w[4], w[5], w[6]) : count_granule();
+                if (mult > 1u && ng > 1u) ring4[rg * 8u + ((at + ng) & 7u)] = count_granule();
+                more = false;
+            }
+#ifdef SFGPU_X_NORT
+            if (__ballot(fast && ng > 2u) && cap == 0xFFFFFFFFu) {
+#else
+            if (__ballot(fast && ng > 2u)) {
+#endif                                                  // (front labels are <= 4 granules: tail granules 2 and 3)
+                if (fast && ng > 2u) ring4[rg * 8u + ((at + 2u) & 7u)] = granule(2);
+                if (fast && ng > 3u) ring4[rg * 8u + ((at + 3u) & 7u)] = granule(3);
+            }
+            if (fast) {
+                const uint32_t add = (n0 << (16u * q0)) | (n1 << (16u * (q0 ^ 1u)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const uint32_t nw = atomicAdd(&cbst[rg].y, add) + add;
+                c0 = ((nw >> (16u * q0)) & 7u) == 4u;
+                c1 = n1 != 0u && ((nw >> (16u * (q0 ^ 1u))) & 7u) == 4u;
+            }
             flush();
-            // the rare step: some lane found a unit closed (the ring is two units deep: it takes three labels of one region in
-            // flight at once, or a slow completer in another wavefront).  Granule by granule, until every lane is through; a lane
-            // never holds a completed unit while it waits, so the completers it waits for always get to flush.
+            // the rare lane: a unit it needs is closed (the ring is two units deep; a completer of another wavefront is between its
+            // count and its release, or three labels of one region are in flight at once).  Granule by granule until it is through;
+            // a lane never holds a completed unit while it waits, so the completers it waits for always get to flush.
             uint32_t wr = 0;
+#if defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 2
+            { const unsigned long long sm = __ballot(more); if (sm && lane == 0) atomicAdd(a.n_hot_reads, (unsigned long long)__builtin_popcountll(sm)); }   // slow LANES
+#elif defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 3
+            { const unsigned long long sm = __ballot(more); if (sm && lane == 0) atomicAdd(a.n_hot_reads, 1ull); }                                          // steps with a slow lane
+#elif defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 4
+            { const unsigned long long sm = __ballot(more && !is_open(u0, stv)); if (sm && lane == 0) atomicAdd(a.n_hot_reads, (unsigned long long)__builtin_popcountll(sm)); }   // slow lanes whose FIRST unit is closed
+#endif
             while (__ballot(more)) {
+#if defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 1
+                if (lane == 0) atomicAdd(a.n_hot_reads, 1ull);           // (experiment: slow-loop iterations, reported as stats.hot_reads)
+#endif
                 c0 = false; c1 = false;
+                // wait (cheaply: a read and a test per poll) until the next granule of SOME waiting lane can be written
+                for (;;) {
+                    bool can = false;
+                    if (more) { stv = __hip_atomic_load(&cbst[rg].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); can = is_open((at + wr) >> 2, stv); }
+                    if (__ballot(can)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
                 if (more) {
-                    __builtin_amdgcn_s_sleep(1);
-                    stv = __hip_atomic_load(&cbst[rg].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     uint32_t add = 0;
                     bool open = true;
                     for (uint32_t j = wr; open && j < ngx; ++j) {
                         const uint32_t p = at + j, v = p >> 2;
-                        if (is_open(v, stv)) {
-                            uint4 gj = G[0];
-                            if (j == 1u) gj = G[1]; else if (j == 2u) gj = G[2]; else if (j == 3u) gj = G[3];
-                            ring4[rg * 8u + (p & 7u)] = gj; add += 1u << (16u * (v & 1u)); wr = j + 1u;
-                        } else open = false;
+                        if (is_open(v, stv)) { ring4[rg * 8u + (p & 7u)] = stream_granule(j); add += 1u << (16u * (v & 1u)); wr = j + 1u; }
+                        else open = false;
                     }
                     if (add) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

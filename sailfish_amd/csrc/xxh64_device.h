@@ -114,30 +114,33 @@ __device__ __forceinline__ void mix_round(uint32_t& a, uint32_t& b, uint32_t w) 
     b = mix_rotl(b, 11) + (w ^ a);
     b += b << 2;
 }
-template <typename WordFn>
-__device__ __forceinline__ uint64_t label_mix64_words(WordFn word, uint32_t n) {
-    uint32_t a = MP1 + n, b = 0x27D4EB2Fu ^ (n * MP3);
-    const uint32_t rounds = n < (uint32_t)kHead ? (uint32_t)kHead : n;     // zero-padded to >= 8 rounds
-    for (uint32_t i = 0; i < rounds; ++i) {
-        uint32_t w = (i < n) ? word(i) : 0u;
-        mix_round(a, b, w);
-    }
-    return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
-}
-// n <= 8 words in w[] (words past n are zero): all 8 rounds run unconditionally -- the length is in
-// the seeds, so zero padding cannot alias a shorter label -- which keeps the code branch-free.
-// Must agree with label_mix64_words for n <= 8: that loop is padded to 8 rounds the same way.
-__device__ __forceinline__ uint64_t label_mix64_head(const uint32_t (&w)[kHead], uint32_t n) {
-    uint32_t a = MP1 + n, b = 0x27D4EB2Fu ^ (n * MP3);
+// the head: 8 rounds over the first 8 ids, zero padded -- the length is in the seeds, so zero padding cannot alias a shorter
+// label -- which keeps the code branch-free
+__device__ __forceinline__ void label_mix_head(const uint32_t (&w)[kHead], uint32_t n, uint32_t& a, uint32_t& b) {
+    a = MP1 + n; b = 0x27D4EB2Fu ^ (n * MP3);
 #pragma unroll
     for (int i = 0; i < kHead; ++i) mix_round(a, b, w[i]);
+}
+// Labels of more than 8 ids: the bucket hash does NOT walk the tail.  It takes the length, the first 8 ids, the LAST id and the
+// MIDDLE one (two more rounds, no loop): a label is an ordered id list, so labels that agree in all of these and still differ
+// are rare, and when they do they only share a slot neighbourhood -- class identity is decided by the full label compare, never
+// by this value.  (Round 3: walking the tail cost the route pass half of its vector instructions -- 13 % of the labels have one,
+// so some lane of nearly every wavefront walked while the others waited: 9.6 instead of 6.4 ms per build in the ring form; hashing
+// the tail granules by lanes of their own cost as much in bookkeeping: profiles/r3_class_build_notes.md.)
+__device__ __forceinline__ void label_mix_far(uint32_t& a, uint32_t& b, uint32_t last, uint32_t middle) {
+    mix_round(a, b, last); mix_round(a, b, middle);
+}
+__device__ __forceinline__ uint64_t label_mix_final(uint32_t a, uint32_t b) {
     return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
 }
-// bucket hash of any label: registers for n <= 8, the loop otherwise
+// bucket hash of any label (w[] receives the zero-padded head)
 template <typename WordFn>
 __device__ __forceinline__ uint64_t label_mix64(WordFn word, uint32_t n, uint32_t (&w)[kHead]) {
     label_head(word, n, w);
-    return (n <= (uint32_t)kHead) ? label_mix64_head(w, n) : label_mix64_words(word, n);
+    uint32_t a, b;
+    label_mix_head(w, n, a, b);
+    if (n > (uint32_t)kHead) label_mix_far(a, b, word(n - 1u), word(n >> 1));
+    return label_mix_final(a, b);
 }
 
 // hash of any label: registers for n <= 8, the generic loop otherwise

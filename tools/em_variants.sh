@@ -10,6 +10,6 @@ for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   hipcc $FLAGS $defs -c em.hip -o variants/em_$name.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libsfgpu_$name.so build/core.o build/eqclass.o variants/em_$name.o build/misc.o build/primitives.o \
-        build/sampling.o build/gibbs.o build/filter.o build/bias.o build/merge.o build/mapper.o -Wl,-rpath,/opt/rocm/lib
+        build/sampling.o build/gibbs.o build/filter.o build/bias.o build/merge.o build/mapper.o build/comm.o -Wl,-rpath,/opt/rocm/lib
   echo built $name "($defs)"
 done
