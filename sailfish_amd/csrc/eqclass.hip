@@ -598,9 +598,10 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
     // every block of pass 1 owns one contiguous tile of reads and one bin per region.  The RING form of the pass (bins written
     // through LDS rings, eqclass_part.h) wants one block per CU and fits up to 1024 regions (a table of <= 4 M slots).  It is
-    // OFF by default: measured on cfg3 it writes whole 64-byte units (no partial lines) but takes 10.8 ms per build against
-    // 9.8 ms -- one block per CU is 4 wavefronts per SIMD, and the pass is instruction-bound (profiles/r3_class_build_notes.md)
-    static const int ring_mode = []() { const char* e = getenv("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();
+    // OFF by default (SFGPU_EQ_RING=1 selects it): it writes whole 64-byte units -- no partial lines -- but one block per CU is
+    // 4 wavefronts per SIMD and the pass is bound by instruction issue there: cfg3 9.4 ms per build against 9.7 under rocprofv3,
+    // no difference in the bench step, and skewed / sorted streams and cfg2 are 10-80 % slower (profiles/r3_class_build_notes.md)
+    const int ring_mode = []() { const char* e = getenv("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();      // (read per sub-batch: tests switch it)
     static const uint32_t max_blocks = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long v = e ? atol(e) : 512; return (uint32_t)(v >= 1 && v <= 1024 ? v : 512); }();
     static const uint32_t ring_blocks = []() { const char* e = getenv("SFGPU_EQ_RING_BLOCKS"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 0); }();
     bool ring = ring_mode != 0 && n_regions >= 2 && n_regions <= kRingMaxRegions;

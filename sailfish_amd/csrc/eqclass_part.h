@@ -241,21 +241,13 @@ k_part_route(RouteArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < kHead; ++q) { w[q] = ((uint32_t)q < len) ? w[q] : 0u; mx = mx > w[q] ? mx : w[q]; }
-#ifdef SFGPU_X_SHORT_ONLY
-        const bool unfit = len > 7u;                        // (experiment: what do the long-label loops cost)
-#else
         const bool unfit = len > kMaxPartLabel;
-#endif
         // ---- bucket hash (xxh64_device.h): length, the first 8 ids, and for longer labels the last and the middle id -- no walk
         //      over the tail (13 % of the labels have one: a lane walking its tail while the others wait cost this pass half of
         //      its vector instructions)
         uint32_t ha, hb;
         label_mix_head(w, len, ha, hb);
-#ifdef SFGPU_X_NOTAIL
-        const uint32_t ng = label_granules(len) < 2u ? label_granules(len) : 2u;        // (experiment: no tail granules -- wrong bins, timing only)
-#else
         const uint32_t ng = label_granules(len);
-#endif
         // granule g >= 2 (ids 4g-1 .. 4g+2, zero padded) of the label that starts at id `lb` and holds `ll` ids
         auto granule_at = [&](uint32_t lb, uint32_t ll, uint32_t g) -> uint4 {
             const uint32_t q = 4u * g - 1u;
@@ -265,11 +257,7 @@ k_part_route(RouteArgs a) {
             return make_uint4(v0, q + 1 < ll ? v1 : 0u, q + 2 < ll ? v2 : 0u, q + 3 < ll ? v3 : 0u);
         };
         auto granule = [&](uint32_t g) -> uint4 { return granule_at(b, len, g); };
-#ifndef SFGPU_X_NOFAR
         if (len > (uint32_t)kHead && !unfit) {
-#else
-        if (len > (uint32_t)kHead && !unfit && cap == 0xFFFFFFFFu) {
-#endif
             const uint32_t last = staged ? lab_s[len - 1u] : lab_g[len - 1u], mid = staged ? lab_s[len >> 1] : lab_g[len >> 1];
             label_mix_far(ha, hb, last, mid);
         }
@@ -324,11 +312,7 @@ k_part_route(RouteArgs a) {
                 if (same) { atomicAdd(&hot_cnt[hi], mult); counted = true; }
             }
         }
-#ifdef SFGPU_X_DROPLONG
-        const bool place = len != 0 && !generic && !counted && !dup && ng <= 2u;       // (experiment: what would a pass over the regular labels alone cost)
-#else
         const bool place = len != 0 && !generic && !counted && !dup;
-#endif
         const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
         auto head_granule = [&]() { return make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]); };
         auto count_granule = [&]() { return make_uint4(mult, kCountedBit, 0u, 0u); };       // (bit 31 of .y: no id has it -- such labels take the generic kernel)
@@ -372,11 +356,7 @@ k_part_route(RouteArgs a) {
                 stv = cs.y;
                 const uint32_t pf = cs.x & 0xFFFFu;
                 if (pf + (cs.x >> 16) + ngx > cap) generic = true;                           // does not fit, and never will: nothing reserved
-#ifdef SFGPU_X_NOSLOW
-                else if (ngx <= kRingFrontGranules) {
-#else
                 else if (ngx <= kRingFrontGranules && is_open(pf >> 2, stv) && is_open((pf + ngx - 1u) >> 2, stv)) {
-#endif
                     const uint32_t old = atomicAdd(&cbst[rg].x, ngx);
                     at = old & 0xFFFFu;
                     if (at + ngx + (old >> 16) <= cap) front = true;
@@ -385,11 +365,7 @@ k_part_route(RouteArgs a) {
                         generic = true;
                     }
                 }
-#ifdef SFGPU_X_NOBACK
-                else if (cap == 0xFFFFFFFFu) {
-#else
                 else {
-#endif
                     const uint32_t old = atomicAdd(&cbst[rg].x, ngx << 16);
                     const uint32_t bk = old >> 16;
                     if ((old & 0xFFFFu) + bk + ngx <= cap) {
@@ -455,11 +431,7 @@ k_part_route(RouteArgs a) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         if (c0 | c1) atomicAdd(&cbst[rg].y, (c0 ? (4u << (16u * q0)) : 0u) | (c1 ? (4u << (16u * (q0 ^ 1u))) : 0u));
                     }
-#ifdef SFGPU_X_NOFLUSH
-                    if (cap == 0xFFFFFFFFu) {
-#else
                     {
-#endif
                         if (wa != 0xFFFFFFFFu) a.out[(size_t)wa] = da;
                         if (wb != 0xFFFFFFFFu) a.out[(size_t)wb] = db;
                     }
@@ -469,22 +441,14 @@ k_part_route(RouteArgs a) {
             };
             // the usual step: every unit a lane needs is open -- write, count, flush
             bool more = front;
-#ifdef SFGPU_X_NOSLOW
-            const bool fast = front;
-#else
             const bool fast = front && is_open(u0, stv) && (n1 == 0u || is_open(u0 + 1u, stv));
-#endif
             if (fast) {
                 ring4[rg * 8u + (at & 7u)] = head_granule();
                 if (ngx > 1u) ring4[rg * 8u + ((at + 1u) & 7u)] = (ng > 1u) ? make_uint4(w[3], w[4], w[5], w[6]) : count_granule();
                 if (mult > 1u && ng > 1u) ring4[rg * 8u + ((at + ng) & 7u)] = count_granule();
                 more = false;
             }
-#ifdef SFGPU_X_NORT
-            if (__ballot(fast && ng > 2u) && cap == 0xFFFFFFFFu) {
-#else
             if (__ballot(fast && ng > 2u)) {
-#endif                                                  // (front labels are <= 4 granules: tail granules 2 and 3)
                 if (fast && ng > 2u) ring4[rg * 8u + ((at + 2u) & 7u)] = granule(2);
                 if (fast && ng > 3u) ring4[rg * 8u + ((at + 3u) & 7u)] = granule(3);
             }
@@ -500,17 +464,7 @@ k_part_route(RouteArgs a) {
             // count and its release, or three labels of one region are in flight at once).  Granule by granule until it is through;
             // a lane never holds a completed unit while it waits, so the completers it waits for always get to flush.
             uint32_t wr = 0;
-#if defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 2
-            { const unsigned long long sm = __ballot(more); if (sm && lane == 0) atomicAdd(a.n_hot_reads, (unsigned long long)__builtin_popcountll(sm)); }   // slow LANES
-#elif defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 3
-            { const unsigned long long sm = __ballot(more); if (sm && lane == 0) atomicAdd(a.n_hot_reads, 1ull); }                                          // steps with a slow lane
-#elif defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 4
-            { const unsigned long long sm = __ballot(more && !is_open(u0, stv)); if (sm && lane == 0) atomicAdd(a.n_hot_reads, (unsigned long long)__builtin_popcountll(sm)); }   // slow lanes whose FIRST unit is closed
-#endif
             while (__ballot(more)) {
-#if defined(SFGPU_X_COUNT) && SFGPU_X_COUNT == 1
-                if (lane == 0) atomicAdd(a.n_hot_reads, 1ull);           // (experiment: slow-loop iterations, reported as stats.hot_reads)
-#endif
                 c0 = false; c1 = false;
                 // wait (cheaply: a read and a test per poll) until the next granule of SOME waiting lane can be written
                 for (;;) {

@@ -335,6 +335,36 @@ def test_builder_large_host_batch_is_streamed_in_chunks(sf, gpu, monkeypatch, ch
     _assert_same_classes(eq, ob, *oc)
 
 
+def test_builder_ring_form_of_the_route_pass(sf, gpu, monkeypatch):
+    """SFGPU_EQ_RING=1: pass 1 writes its bins through LDS rings (whole 64-byte units from the front of a bin, long labels and
+    labels that would have to wait for a ring slot directly at its back; eqclass_part.h) -- off by default, measured no faster;
+    the classes must be the oracle's whichever form ran: the benchmark's law, a skewed stream with hot labels, runs of identical
+    reads, and labels of up to 123 ids"""
+    import torch
+    from sailfish_amd import synth
+    monkeypatch.setenv("SFGPU_EQ_RING", "1")
+    rng = np.random.default_rng(12)
+    ref_len, ids, off = synth.workload(20000, 150_000, 2_500_000)
+    ids_np, off_np = ids.numpy().view(np.uint32), off.numpy().view(np.uint32)
+    lens = np.diff(off_np.astype(np.int64))
+    # a skewed copy: 30 % of the reads carry one of 5 labels; and every label 1 .. 4 times in a row
+    picks = np.arange(len(lens)); hot = rng.random(len(lens)) < 0.3; picks[hot] = rng.integers(0, 5, int(hot.sum())) * 1013
+    picks = np.repeat(picks[: len(picks) // 2], rng.integers(1, 5, len(picks) // 2))[: len(lens)]
+    starts = off_np[:-1].astype(np.int64)[picks]; l2 = lens[picks]
+    off2 = np.zeros(len(picks) + 1, np.int64); np.cumsum(l2, out=off2[1:])
+    ids2 = ids_np[np.repeat(starts, l2) + (np.arange(off2[-1]) - np.repeat(off2[:-1], l2))]
+    # long labels: 1 .. 123 ids
+    n_long = 100_000                                          # (>= 65 536 reads: the partitioned path)
+    ll = rng.integers(1, 124, n_long); base = rng.integers(0, 500, n_long)
+    off3 = np.zeros(n_long + 1, np.int64); np.cumsum(ll, out=off3[1:])
+    ids3 = (np.repeat(base, ll) + 3 * (np.arange(off3[-1]) - np.repeat(off3[:-1], ll))).astype(np.uint32)
+    for ii, oo in ((ids_np, off_np.astype(np.int64)), (ids2, off2), (ids3, off3)):
+        ob, *oc = _oracle_classes([(ii, oo.astype(np.uint32))])
+        eq = sf.EquivalenceClassBuilder(device=gpu)
+        eq.start(); eq.add_batch(torch.from_numpy(ii.view(np.int32)).to(gpu), torch.from_numpy(oo.astype(np.uint32).view(np.int32)).to(gpu)); eq.finish()
+        _assert_same_classes(eq, ob, *oc)
+
+
 @pytest.mark.parametrize("sub_batch", ["65536", None])
 def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
     """more distinct classes than the table budget: deferred reads are replayed after growth.
