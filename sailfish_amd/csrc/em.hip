@@ -418,6 +418,76 @@ __global__ void k_renum_scatter(uint64_t n, const uint32_t* __restrict__ src, co
     if (i < n) dst[where[i]] = src[i];
 }
 
+// ---- the TRANSCRIPT-major copy of a tile's nonzeros (round 3): phase C as a gather ------------------------------------------
+// Phase C of the sweep adds x_t * (count / denom)_class into the window slot of every nonzero: 9.3 M random f64 LDS atomics
+// per sweep on cfg3, and the LDS atomic unit is what bounds the phase (0.29 - 0.37 cycles per lane and CU at random addresses,
+// 10.8 of the sweep's 21 us).  A random f64 LDS READ costs 0.085 cycles (tools/probes/lds_atomic_probe.hip).  So the tile's
+// nonzeros are kept a second time, sorted by window slot: 16 bits per nonzero -- class index in the tile (13 bits) | singleton
+// flag (bit 13) -- with a marker entry (bit 15 | slot) in front of every slot's run, in chunks of 8 entries (one 16-byte load)
+// that carry the slot their first entry belongs to (csc_slot0).  A thread then reads count / denom of its 8 entries' classes,
+// adds them up in registers and hands acc[slot] ONE sum per run: ~2 700 atomics per tile instead of 18 000.  Within a slot the
+// entries are in class order (stable sort), so the sums are formed in the same order on every rank and in every plan.
+// Costs 2 more bytes per nonzero and iteration, and a sort of the nonzeros when the plan is made.
+constexpr uint32_t kCscSingle = 0x2000u, kCscMarker = 0x8000u;
+// key = tile << 11 | window offset (escaped members: n_tiles << 11 -> sorted to the end), val = class in tile | singleton flag
+__global__ void __launch_bounds__(kEmBlock)
+k_csc_keys(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
+           const uint32_t* __restrict__ tile_lo, uint32_t* keys, uint32_t* vals) {
+    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
+    const uint32_t lo = tile_lo[blockIdx.x];
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
+        const uint32_t v = (c - c0) | (k == 1 ? kCscSingle : 0u);
+        for (uint32_t m = 0; m < k; ++m) {
+            const uint32_t d = ids[b + m] - lo;
+            keys[b + m] = d < (uint32_t)kWin ? ((blockIdx.x << 11) | d) : (gridDim.x << 11);      // (escaped members: behind every tile)
+            vals[b + m] = v;
+        }
+    }
+}
+__global__ void k_csc_flags(uint64_t V, const uint32_t* __restrict__ keys, uint32_t* flag) {      // 1: first entry of a (tile, slot) run
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; else if (i == V) flag[i] = 0u;
+}
+// tile t: first sorted element, entries incl. markers padded to whole chunks (chunk8[t], scanned by the caller)
+__global__ void k_csc_tiles(uint64_t V, uint32_t n_tiles, const uint32_t* __restrict__ keys, const uint64_t* __restrict__ mx,
+                            uint32_t* idx, uint32_t* entries, uint32_t* padded) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    auto lower = [&](uint32_t tile) -> uint64_t {             // first i < V with keys[i] >= tile << 11
+        const uint32_t target = tile << 11;
+        uint64_t lo = 0, hi = V;
+        while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (keys[mid] >= target) hi = mid; else lo = mid + 1; }
+        return lo;
+    };
+    const uint64_t a = (t == n_tiles) ? V : lower(t);
+    idx[t] = (uint32_t)a;
+    if (t == n_tiles) { entries[t] = 0; padded[t] = 0; return; }
+    const uint64_t b = (t + 1 == n_tiles) ? V : lower(t + 1);
+    const uint32_t e = (uint32_t)((b - a) + (mx[b] - mx[a]));
+    entries[t] = e; padded[t] = (e + 7u) & ~7u;
+}
+__global__ void k_csc_fill(uint64_t n, uint16_t* csc) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) csc[i] = (uint16_t)kTileNnz;                  // the null class: count / denom = 0
+}
+__global__ void k_csc_scatter(uint64_t V, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ flag,
+                              const uint64_t* __restrict__ mx, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ q0,
+                              uint16_t* csc, uint16_t* slot0) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const uint32_t key = keys[i], t = key >> 11, slot = key & 0x7FFu;
+    const uint64_t a = idx[t];
+    uint64_t p = q0[t] + (i - a) + (mx[i] - mx[a]);
+    if (flag[i]) {
+        csc[p] = (uint16_t)(kCscMarker | slot);
+        if ((p & 7u) == 0) slot0[p >> 3] = (uint16_t)slot;
+        ++p;
+    }
+    csc[p] = (uint16_t)vals[i];
+    if ((p & 7u) == 0) slot0[p >> 3] = (uint16_t)slot;
+}
+
 struct SweepArgs {
     const uint32_t* rowptr; const uint32_t* counts;                      // caller CSR (class sizes, counts)
     const uint32_t* stream; const uint32_t* esc_id; const uint32_t* esc_cls;
@@ -428,6 +498,7 @@ struct SweepArgs {
     EmState* st; uint32_t min_iter, max_iter;
     double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
     const uint32_t* inv;                                                 // window position -> transcript (null: the caller's order)
+    const uint16_t* csc; const uint16_t* csc_slot0; const uint64_t* tile_q0;     // transcript-major copy (null: phase C scatters with atomics)
 };
 
 template <bool VB>
@@ -574,9 +645,36 @@ k_sweep_lds(SweepArgs a) {
     for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = threadIdx.x + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
     for (uint32_t c = threadIdx.x + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, a.counts[c0 + c]);
     __syncthreads();
-    // ---- C: scatter-add into the window
+    // ---- C: the window.  With the transcript-major copy: a GATHER -- a thread takes chunks of 8 entries sorted by window slot,
+    //      reads count / denom of their classes (random LDS reads: 0.085 cycles per lane and CU against 0.29 - 0.37 for a random
+    //      f64 atomic), sums per slot in registers (singletons add their count, the others x_t times the sum) and hands the window
+    //      one sum per run.  Without it: one atomic per nonzero.
     double esc_sum = 0.0;
     {
+        if (a.csc) {
+            const uint64_t q0 = a.tile_q0[blockIdx.x];
+            const uint32_t n_chunks = (uint32_t)((a.tile_q0[blockIdx.x + 1] - q0) >> 3);
+            const uint4* __restrict__ chunks = reinterpret_cast<const uint4*>(a.csc + q0);
+            const uint16_t* __restrict__ s0 = a.csc_slot0 + (q0 >> 3);
+            for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += kSweepBlock) {
+                const uint4 e4 = chunks[ch];
+                uint32_t slot = s0[ch];
+                double sn = 0.0, ss = 0.0;                     // sums of count / denom: classes of several members / singletons
+                auto flush_run = [&]() {
+                    const double v = xs[slot] * sn + ss;
+                    if (v != 0.0) atomicAdd(&acc[slot], v);
+                };
+                // (one path for every chunk: a separate branch for the 85 % of the chunks without a marker was measured slower --
+                //  some lane of every wavefront has one, so both branches ran: 20.5 instead of 18.8 us per sweep)
+                auto entry = [&](uint32_t e) {
+                    if (e & kCscMarker) { flush_run(); slot = e & 0x7FFu; sn = 0.0; ss = 0.0; }
+                    else { const double f = den[e & 0x1FFFu]; if (e & kCscSingle) ss += f; else sn += f; }
+                };
+                entry(e4.x & 0xFFFFu); entry(e4.x >> 16); entry(e4.y & 0xFFFFu); entry(e4.y >> 16);
+                entry(e4.z & 0xFFFFu); entry(e4.z >> 16); entry(e4.w & 0xFFFFu); entry(e4.w >> 16);
+                flush_run();
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < kRegChunks; ++c) {
             if (g0 + (uint32_t)c * kSweepBlock * kPerLane >= n8) break;
@@ -584,6 +682,7 @@ k_sweep_lds(SweepArgs a) {
             acc_words(w[c], N8{}, xv[c], cur, f);
         }
         for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) acc_chunk(words[g / 4], words[g / 4 + 1]);
+        }
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global atomics
             uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
             double f = den[(tag >> 16) & 0x1FFFu];
@@ -763,6 +862,7 @@ struct sfgpu_em {
     uint32_t* pub_pos = nullptr;                                // window slot -> its entry of `partial`
     uint32_t* lstream = nullptr; uint32_t* esc_id = nullptr; uint32_t* esc_cls = nullptr;   // re-packed labels (k_sweep_lds)
     uint64_t* tile_s0 = nullptr; uint64_t* tile_esc0 = nullptr;
+    uint16_t* csc = nullptr; uint16_t* csc_slot0 = nullptr; uint64_t* tile_q0 = nullptr;      // transcript-major copy of the tiles (phase C as a gather)
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
     double* tsum = nullptr;                                 // [n_tiles] what each tile added in the last sweep (VBEM, optimize())
     bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
@@ -787,7 +887,7 @@ static void em_free(sfgpu_em* em) {
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
-                    em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0,
+                    em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->csc, em->csc_slot0, em->tile_q0,
                     em->blkmax, em->tsum, em->inv, em->cperm};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
@@ -833,7 +933,8 @@ static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     if (p.C == 0) return SFGPU_OK;
     SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr, em->inv};
+                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr, em->inv,
+                em->csc, em->csc_slot0, em->tile_q0};
     void* args[] = {&a};
     const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true>)
                                       : reinterpret_cast<const void*>(&k_sweep_lds<false>);
@@ -1118,6 +1219,45 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
                            em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls, em->inv);
         EM_TRY(hipGetLastError());
+        // the transcript-major copy for phase C (see k_csc_keys): sort the nonzeros by (tile, window slot), lay them out in
+        // chunks of 8 sixteen-bit entries with a marker in front of every slot's run.  SFGPU_EM_GATHER=0 keeps the scatter form.
+        {
+            const char* eg = getenv("SFGPU_EM_GATHER");
+            const uint64_t Lnz = rp_end;
+            if ((!eg || atoi(eg) != 0) && Lnz > E && nt < (1u << 21)) {
+                const uint64_t V = Lnz - E;
+                uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *flag = nullptr, *idx = nullptr, *ent = nullptr, *pad = nullptr;
+                uint64_t* mx = nullptr;
+                EM_TRY(pool_malloc(&k_in, Lnz * 4)); EM_TRY(pool_malloc(&k_out, Lnz * 4)); EM_TRY(pool_malloc(&v_in, Lnz * 4)); EM_TRY(pool_malloc(&v_out, Lnz * 4));
+                EM_TRY(pool_malloc(&flag, (V + 1) * 4)); EM_TRY(pool_malloc(&mx, (V + 2) * 8));
+                EM_TRY(pool_malloc(&idx, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&ent, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&pad, ((size_t)nt + 2) * 4));
+                EM_TRY(pool_malloc(&em->tile_q0, ((size_t)nt + 2) * 8));
+                hipLaunchKernelGGL(k_csc_keys, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo, k_in, v_in);
+                int bits = 11; while (bits < 32 && (1ull << bits) <= ((uint64_t)nt << 11)) ++bits;      // (the largest key is nt << 11)
+                int cr = sort_pairs_u32_u32(k_in, k_out, v_in, v_out, Lnz, em->cur, bits, false);
+                if (!cr) {
+                    hipLaunchKernelGGL(k_csc_flags, dim3(blocks_for(V + 1)), dim3(kEmBlock), 0, em->cur, V, k_out, flag);
+                    cr = exclusive_scan_u32(flag, mx, V, em->cur, false);
+                }
+                uint64_t Q = 0;
+                if (!cr) {
+                    hipLaunchKernelGGL(k_csc_tiles, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, V, nt, k_out, mx, idx, ent, pad);
+                    cr = exclusive_scan_u32(pad, em->tile_q0, nt, em->cur, false);
+                }
+                if (!cr) {
+                    EM_TRY(hipMemcpyAsync(&Q, em->tile_q0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+                    EM_TRY(hipStreamSynchronize(em->cur));
+                    EM_TRY(pool_malloc(&em->csc, (Q ? Q : 8) * 2 + 16));
+                    EM_TRY(pool_malloc(&em->csc_slot0, (Q / 8 + 1) * 2));
+                    EM_TRY(hipMemsetAsync(em->csc_slot0, 0, (Q / 8 + 1) * 2, em->cur));
+                    hipLaunchKernelGGL(k_csc_fill, dim3(blocks_for(Q ? Q : 1)), dim3(kEmBlock), 0, em->cur, Q, em->csc);
+                    hipLaunchKernelGGL(k_csc_scatter, dim3(blocks_for(V)), dim3(kEmBlock), 0, em->cur, V, k_out, v_out, flag, mx, idx, em->tile_q0, em->csc, em->csc_slot0);
+                    EM_TRY(hipGetLastError());
+                }
+                for (void* q : {(void*)k_in, (void*)k_out, (void*)v_in, (void*)v_out, (void*)flag, (void*)mx, (void*)idx, (void*)ent, (void*)pad}) pool_free_on(q, em->cur);
+                if (cr) { em_free(em); return cr; }
+            }
+        }
         if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }
         EM_TRY(pool_malloc(&em->partial, (P ? P : 1) * 8));
         EM_TRY(pool_malloc(&em->cov_pos, (P ? P : 1) * 4));
