@@ -309,11 +309,15 @@ def main():
         if pmc.get("workload") == a.workload and world == 1:
             k = pmc["kernels"]
             bytes_of = lambda e: ((2 if e.get("fetch_x2") else 1) * e["fetch_kib_per_launch"] + e["write_kib_per_launch"]) * 1024
-            e = k.get("k_sweep_lds<true>" if use_vbem else "k_sweep_lds<false>")
+            # (kernel names carry their template arguments: k_sweep_lds<VB, GATHER>, k_part_route<RING>; the instance with the
+            #  most launches is the one the step ran)
+            pick = lambda prefix: max((v for n, v in k.items() if n == prefix or (n.startswith(prefix) and n[len(prefix)] in "<,>")),
+                                      key=lambda v: v.get("launches", 0), default=None)
+            e = pick("k_sweep_lds<true" if use_vbem else "k_sweep_lds<false")
             if e:
                 traffic_em = bytes_of(e)
             # class build = the partition kernels of one sub-batch (k_insert on the generic path)
-            parts = [k[n] for n in ("k_part_route", "k_part_insert") if n in k] or [k[n] for n in ("k_insert",) if n in k]
+            parts = [v for v in (pick("k_part_route"), pick("k_part_insert")) if v] or [v for v in (pick("k_insert"),) if v]
             if parts:
                 traffic_ins = sum(bytes_of(e) for e in parts)
             # not re-measured by this run: it comes from the committed PMC passes of the same command

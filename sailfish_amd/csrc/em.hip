@@ -338,6 +338,37 @@ k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
     for (uint64_t p = s0 + n + threadIdx.x; p < s1; p += kEmBlock) stream[p] = kNull;
 }
 
+// the COMPACT form of the class-major stream (k_sweep_lds<., true>): slot16[s0 + p] = window slot of nonzero p of the tile (kWin:
+// a member outside the window -- its x reads as 0), chdr[(s0 + p) / 8] = class of the chunk's first nonzero | bit 16 + k for every
+// nonzero k >= 1 of the chunk that starts the next class.  chdr is zero before the launch.
+__global__ void __launch_bounds__(kEmBlock)
+k_fill_stream_compact(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
+                      const uint32_t* __restrict__ tile_lo, const uint64_t* __restrict__ tile_s0, const uint64_t* __restrict__ tile_esc0,
+                      uint16_t* slot16, uint32_t* chdr, uint32_t* esc_id, uint32_t* esc_cls, const uint32_t* __restrict__ inv) {
+    __shared__ unsigned int esc_cursor;
+    if (threadIdx.x == 0) esc_cursor = 0;
+    __syncthreads();
+    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
+    const uint32_t lo = tile_lo[blockIdx.x];
+    const uint64_t s0 = tile_s0[blockIdx.x], s1 = tile_s0[blockIdx.x + 1], e0 = tile_esc0[blockIdx.x];
+    const uint32_t j0 = rowptr[c0], n = rowptr[c1] - j0;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
+        for (uint32_t m = 0; m < k; ++m) {
+            const uint32_t t = ids[b + m], d = t - lo;
+            const uint64_t p = s0 + (b - j0) + m;
+            if (d >= (uint32_t)kWin) {
+                const unsigned int idx = atomicAdd(&esc_cursor, 1u);
+                esc_id[e0 + idx] = inv ? inv[t] : t; esc_cls[e0 + idx] = ((c - c0) << 16) | (k == 1 ? kSingle : 0u);
+            }
+            slot16[p] = (uint16_t)(d < (uint32_t)kWin ? d : (uint32_t)kWin);
+            if ((p & 7u) == 0) atomicOr(&chdr[p >> 3], c - c0);
+            else if (m == 0) atomicOr(&chdr[p >> 3], 1u << (16u + (uint32_t)(p & 7u)));
+        }
+    }
+    for (uint64_t p = s0 + n + threadIdx.x; p < s1; p += kEmBlock) slot16[p] = (uint16_t)kWin;
+}
+
 // one (transcript, slot) pair per window entry; sorted by transcript this is the cover list that the
 // per-transcript update walks to fold the tiles' partial sums in a fixed order
 __global__ void __launch_bounds__(kEmBlock)
@@ -422,14 +453,16 @@ __global__ void k_renum_scatter(uint64_t n, const uint32_t* __restrict__ src, co
 // Phase C of the sweep adds x_t * (count / denom)_class into the window slot of every nonzero: 9.3 M random f64 LDS atomics
 // per sweep on cfg3, and the LDS atomic unit is what bounds the phase (0.29 - 0.37 cycles per lane and CU at random addresses,
 // 10.8 of the sweep's 21 us).  A random f64 LDS READ costs 0.085 cycles (tools/probes/lds_atomic_probe.hip).  So the tile's
-// nonzeros are kept a second time, sorted by window slot: 16 bits per nonzero -- class index in the tile (13 bits) | singleton
-// flag (bit 13) -- with a marker entry (bit 15 | slot) in front of every slot's run, in chunks of 8 entries (one 16-byte load)
-// that carry the slot their first entry belongs to (csc_slot0).  A thread then reads count / denom of its 8 entries' classes,
-// adds them up in registers and hands acc[slot] ONE sum per run: ~2 700 atomics per tile instead of 18 000.  Within a slot the
-// entries are in class order (stable sort), so the sums are formed in the same order on every rank and in every plan.
-// Costs 2 more bytes per nonzero and iteration, and a sort of the nonzeros when the plan is made.
-constexpr uint32_t kCscSingle = 0x2000u, kCscMarker = 0x8000u;
-// key = tile << 11 | window offset (escaped members: n_tiles << 11 -> sorted to the end), val = class in tile | singleton flag
+// nonzeros are kept a second time, sorted by (singleton class or not, window slot), 16 bits per nonzero -- the class index in
+// the tile -- in CHUNKS of 8 (one 16-byte load).  A run of one slot is ~47 entries long, so 85 % of the chunks are PURE (one
+// slot): such a chunk is 8 class indices plus, in a separate array, its slot (| bit 15: its classes are singletons, which add
+// their count, not x_t times it); the thread reads count / denom of the 8 classes, adds them up in a tree and hands acc[slot]
+// ONE sum.  The chunks that straddle slots are MIXED: 8 class indices + 8 slots, combined run by run.  Pure chunks come first
+// in a tile, mixed ones behind them, so that a wavefront runs one of the two loops, not both.  ~2 700 atomics per tile instead
+// of 18 000; within a slot the entries are in class order (stable sort), so the sums are formed in the same order on every rank
+// and in every plan.  Costs ~2.3 more bytes per nonzero and iteration, and a sort of the nonzeros when the plan is made.
+constexpr uint32_t kCscSingleBit = 0x8000u;
+// key = tile << 12 | singleton << 11 | window offset (escaped members: n_tiles << 12 -> sorted to the end), val = class in tile
 __global__ void __launch_bounds__(kEmBlock)
 k_csc_keys(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
            const uint32_t* __restrict__ tile_lo, uint32_t* keys, uint32_t* vals) {
@@ -437,55 +470,78 @@ k_csc_keys(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids
     const uint32_t lo = tile_lo[blockIdx.x];
     for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
         const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
-        const uint32_t v = (c - c0) | (k == 1 ? kCscSingle : 0u);
+        const uint32_t hi = (blockIdx.x << 12) | (k == 1 ? 0x800u : 0u);
         for (uint32_t m = 0; m < k; ++m) {
             const uint32_t d = ids[b + m] - lo;
-            keys[b + m] = d < (uint32_t)kWin ? ((blockIdx.x << 11) | d) : (gridDim.x << 11);      // (escaped members: behind every tile)
-            vals[b + m] = v;
+            keys[b + m] = d < (uint32_t)kWin ? (hi | d) : (gridDim.x << 12);
+            vals[b + m] = c - c0;
         }
     }
 }
-__global__ void k_csc_flags(uint64_t V, const uint32_t* __restrict__ keys, uint32_t* flag) {      // 1: first entry of a (tile, slot) run
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < V) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; else if (i == V) flag[i] = 0u;
-}
-// tile t: first sorted element, entries incl. markers padded to whole chunks (chunk8[t], scanned by the caller)
-__global__ void k_csc_tiles(uint64_t V, uint32_t n_tiles, const uint32_t* __restrict__ keys, const uint64_t* __restrict__ mx,
-                            uint32_t* idx, uint32_t* entries, uint32_t* padded) {
+// tile t: its first sorted element idx[t] (t == n_tiles: the number of entries at all) and its number of chunks
+__global__ void k_csc_tiles(uint64_t L, uint32_t n_tiles, const uint32_t* __restrict__ keys, uint32_t* idx, uint32_t* chunks) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
-    auto lower = [&](uint32_t tile) -> uint64_t {             // first i < V with keys[i] >= tile << 11
-        const uint32_t target = tile << 11;
-        uint64_t lo = 0, hi = V;
+    auto lower = [&](uint32_t tile) -> uint64_t {             // first i with keys[i] >= tile << 12
+        const uint32_t target = tile << 12;
+        uint64_t lo = 0, hi = L;
         while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (keys[mid] >= target) hi = mid; else lo = mid + 1; }
         return lo;
     };
-    const uint64_t a = (t == n_tiles) ? V : lower(t);
+    const uint64_t a = lower(t);
     idx[t] = (uint32_t)a;
-    if (t == n_tiles) { entries[t] = 0; padded[t] = 0; return; }
-    const uint64_t b = (t + 1 == n_tiles) ? V : lower(t + 1);
-    const uint32_t e = (uint32_t)((b - a) + (mx[b] - mx[a]));
-    entries[t] = e; padded[t] = (e + 7u) & ~7u;
+    chunks[t] = (t == n_tiles) ? 0u : (uint32_t)((lower(t + 1) - a + 7) >> 3);
 }
-__global__ void k_csc_fill(uint64_t n, uint16_t* csc) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) csc[i] = (uint16_t)kTileNnz;                  // the null class: count / denom = 0
-}
-__global__ void k_csc_scatter(uint64_t V, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ flag,
-                              const uint64_t* __restrict__ mx, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ q0,
-                              uint16_t* csc, uint16_t* slot0) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    const uint32_t key = keys[i], t = key >> 11, slot = key & 0x7FFu;
-    const uint64_t a = idx[t];
-    uint64_t p = q0[t] + (i - a) + (mx[i] - mx[a]);
-    if (flag[i]) {
-        csc[p] = (uint16_t)(kCscMarker | slot);
-        if ((p & 7u) == 0) slot0[p >> 3] = (uint16_t)slot;
-        ++p;
+__global__ void __launch_bounds__(kEmBlock)
+k_csc_pure(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ cb, uint32_t* pure) {
+    const uint32_t t = blockIdx.x, a = idx[t], e = idx[t + 1];
+    const uint64_t g0 = cb[t];
+    const uint32_t n = (uint32_t)(cb[t + 1] - g0);
+    for (uint32_t j = threadIdx.x; j < n; j += kEmBlock) {
+        const uint32_t first = a + 8u * j, last = (first + 7u < e) ? first + 7u : e - 1u;
+        pure[g0 + j] = keys[first] == keys[last] ? 1u : 0u;
     }
-    csc[p] = (uint16_t)vals[i];
-    if ((p & 7u) == 0) slot0[p >> 3] = (uint16_t)slot;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) pure[cb[t + 1]] = 0u;       // the scan's sentinel
+}
+// byte offset of tile t's chunks in the copy (pure chunks 16 B, mixed 32 B), its pure chunks and the rank of its first pure chunk
+__global__ void k_csc_offsets(uint32_t n_tiles, const uint64_t* __restrict__ cb, const uint64_t* __restrict__ ps,
+                              uint64_t* tile_qb, uint32_t* tile_np, uint32_t* tile_pr) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const uint64_t g = cb[t], p = ps[g];
+    tile_qb[t] = 16ull * p + 32ull * (g - p);
+    tile_pr[t] = (uint32_t)p;
+    tile_np[t] = (t == n_tiles) ? 0u : (uint32_t)(ps[cb[t + 1]] - p);
+}
+__global__ void __launch_bounds__(kEmBlock)
+k_csc_write(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ cb,
+            const uint64_t* __restrict__ ps, const uint64_t* __restrict__ tile_qb, const uint32_t* __restrict__ tile_np,
+            unsigned char* csc, uint16_t* slot0) {
+    const uint32_t t = blockIdx.x, a = idx[t], e = idx[t + 1];
+    const uint64_t g0 = cb[t], p0 = ps[g0];
+    const uint32_t n = (uint32_t)(cb[t + 1] - g0), np = tile_np[t];
+    unsigned char* base = csc + tile_qb[t];
+    for (uint32_t j = threadIdx.x; j < n; j += kEmBlock) {
+        const uint32_t first = a + 8u * j, last = (first + 7u < e) ? first + 7u : e - 1u;
+        uint32_t cl[8], sl[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const uint32_t i = first + k;
+            const uint32_t key = keys[i <= last ? i : last];
+            cl[k] = i <= last ? vals[i] : (uint32_t)kTileNnz;                 // padding: the null class (count / denom = 0)
+            sl[k] = (key & 0x7FFu) | ((key & 0x800u) ? kCscSingleBit : 0u);
+        }
+        const uint64_t g = g0 + j, pr = ps[g];
+        const uint4 cls4 = make_uint4(cl[0] | (cl[1] << 16), cl[2] | (cl[3] << 16), cl[4] | (cl[5] << 16), cl[6] | (cl[7] << 16));
+        if (keys[first] == keys[last]) {
+            reinterpret_cast<uint4*>(base)[pr - p0] = cls4;
+            slot0[pr] = (uint16_t)sl[0];
+        } else {
+            uint4* m = reinterpret_cast<uint4*>(base + 16ull * np) + 2ull * ((g - pr) - (g0 - p0));
+            m[0] = cls4;
+            m[1] = make_uint4(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), sl[4] | (sl[5] << 16), sl[6] | (sl[7] << 16));
+        }
+    }
 }
 
 struct SweepArgs {
@@ -498,10 +554,17 @@ struct SweepArgs {
     EmState* st; uint32_t min_iter, max_iter;
     double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
     const uint32_t* inv;                                                 // window position -> transcript (null: the caller's order)
-    const uint16_t* csc; const uint16_t* csc_slot0; const uint64_t* tile_q0;     // transcript-major copy (null: phase C scatters with atomics)
+    const uint32_t* chdr;                                                // GATHER: the class-major stream is 16-bit window slots, 8 per chunk, + one header word per chunk
+    const unsigned char* csc; const uint16_t* csc_slot0;                  // transcript-major copy (null: phase C scatters with atomics)
+    const uint64_t* tile_qb; const uint32_t* tile_np; const uint32_t* tile_pr;
 };
 
-template <bool VB>
+// GATHER (the default since round 3): phase C reads the transcript-major copy (above) and phase A a COMPACT class-major stream --
+// the classes of a tile follow each other, so a nonzero only has to name its window slot (16 bits); a header word per chunk of 8
+// holds the class of the chunk's first nonzero and a bit for every nonzero that starts the next class.  Half the bytes of the
+// 32-bit words, and half the instructions per nonzero in phase A (no class field to extract and compare: 6.4 -> ~4 us on cfg3).
+// !GATHER: the 32-bit stream words [null | single | class | slot] and one LDS atomic per nonzero in phase C (rounds 1 - 2).
+template <bool VB, bool GATHER>
 __global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two 1024-thread blocks per CU: 64 VGPRs
 k_sweep_lds(SweepArgs a) {
     // the tile descriptors do not depend on the loop state: request them first so that the state test
@@ -594,14 +657,22 @@ k_sweep_lds(SweepArgs a) {
     // one-round tiles hold ~18 000 nonzeros = 2.2 chunks of 8192: 1 chunk in registers 21.9 us per sweep, 2 chunks 23.8,
     // 3 chunks 25.1 -- the re-fetch of the other chunks hits the L2 and costs less than the registers do.)
     const uint32_t g0 = threadIdx.x * kPerLane;
-    uint32_t w[kRegChunks][kPerLane];
-    double xv[kRegChunks][kPerLane];                      // x of the register chunks' words, phase A -> phase C
+    uint32_t w[GATHER ? 1 : kRegChunks][kPerLane];
+    double xv[GATHER ? 1 : kRegChunks][kPerLane];         // x of the register chunks' words, phase A -> phase C (scatter form)
+    // GATHER: chunk q of the tile = 8 sixteen-bit slots (one 16-byte load) + its header
+    const uint4* __restrict__ slots8 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.stream) + s0);
+    const uint32_t* __restrict__ hdrs = GATHER ? a.chdr + (s0 >> 3) : nullptr;
+    uint4 sl_first = make_uint4(0u, 0u, 0u, 0u); uint32_t hdr_first = 0;
+    if constexpr (GATHER) {
+        if (g0 < n8) { sl_first = slots8[threadIdx.x]; hdr_first = hdrs[threadIdx.x]; }
+    } else {
 #pragma unroll
     for (int c = 0; c < kRegChunks; ++c) {
         const uint32_t g = g0 + (uint32_t)c * kSweepBlock * kPerLane;
         uint4 w0 = make_uint4(kNull, kNull, kNull, kNull), w1 = w0;
         if (g < n8) { w0 = words[g / 4]; w1 = words[g / 4 + 1]; }
         w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
+    }
     }
     if (a.inv) for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[a.inv[(uint64_t)lo + i]]; acc[i] = 0.0; }
     else for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
@@ -612,6 +683,23 @@ k_sweep_lds(SweepArgs a) {
 
     // ---- A: denominators
     {
+        if constexpr (GATHER) {
+            // a chunk: the class of its first nonzero, a bit per nonzero that starts the next class; classes are consecutive
+            auto den_slots = [&](const uint4& s4, uint32_t hdr) {
+                uint32_t cur = hdr & 0x1FFFu;
+                const uint32_t mask = hdr >> 16;
+                double run = xs[s4.x & 0xFFFFu];
+                auto step = [&](uint32_t k, uint32_t slot) {
+                    const double v = xs[slot];
+                    if (mask & (1u << k)) { atomicAdd(&den[cur], run); ++cur; run = v; } else run += v;
+                };
+                step(1, s4.x >> 16); step(2, s4.y & 0xFFFFu); step(3, s4.y >> 16); step(4, s4.z & 0xFFFFu);
+                step(5, s4.z >> 16); step(6, s4.w & 0xFFFFu); step(7, s4.w >> 16);
+                atomicAdd(&den[cur], run);
+            };
+            if (g0 < n8) den_slots(sl_first, hdr_first);
+            for (uint32_t q = threadIdx.x + kSweepBlock; q * kPerLane < n8; q += kSweepBlock) den_slots(slots8[q], hdrs[q]);
+        } else {
 #pragma unroll
         for (int c = 0; c < kRegChunks; ++c) {
             // (a lane past the end of the tile holds eight null words: it stays out -- hundreds of lanes adding zeros to the ONE
@@ -622,6 +710,7 @@ k_sweep_lds(SweepArgs a) {
             atomicAdd(&den[cur], run);
         }
         for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) den_chunk(words[g / 4], words[g / 4 + 1]);
+        }
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global gather
             uint32_t tag = a.esc_cls[e0 + i];
             if (tag & kSingle) continue;
@@ -651,27 +740,37 @@ k_sweep_lds(SweepArgs a) {
     //      one sum per run.  Without it: one atomic per nonzero.
     double esc_sum = 0.0;
     {
-        if (a.csc) {
-            const uint64_t q0 = a.tile_q0[blockIdx.x];
-            const uint32_t n_chunks = (uint32_t)((a.tile_q0[blockIdx.x + 1] - q0) >> 3);
-            const uint4* __restrict__ chunks = reinterpret_cast<const uint4*>(a.csc + q0);
-            const uint16_t* __restrict__ s0 = a.csc_slot0 + (q0 >> 3);
-            for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += kSweepBlock) {
-                const uint4 e4 = chunks[ch];
-                uint32_t slot = s0[ch];
-                double sn = 0.0, ss = 0.0;                     // sums of count / denom: classes of several members / singletons
+        if constexpr (GATHER) {
+            const uint64_t qb = a.tile_qb[blockIdx.x];
+            const uint32_t np = a.tile_np[blockIdx.x], nm = (uint32_t)((a.tile_qb[blockIdx.x + 1] - qb - 16ull * np) >> 5);
+            const uint4* __restrict__ pure = reinterpret_cast<const uint4*>(a.csc + qb);
+            const uint16_t* __restrict__ s0 = a.csc_slot0 + a.tile_pr[blockIdx.x];
+            for (uint32_t ch = threadIdx.x; ch < np; ch += kSweepBlock) {            // one slot per chunk: 8 reads, a tree of adds, one hand-over
+                const uint4 e4 = pure[ch];
+                const uint32_t sf = s0[ch];
+                const double f0 = den[e4.x & 0x1FFFu], f1 = den[(e4.x >> 16) & 0x1FFFu], f2 = den[e4.y & 0x1FFFu], f3 = den[(e4.y >> 16) & 0x1FFFu];
+                const double f4 = den[e4.z & 0x1FFFu], f5 = den[(e4.z >> 16) & 0x1FFFu], f6 = den[e4.w & 0x1FFFu], f7 = den[(e4.w >> 16) & 0x1FFFu];
+                const double sum = ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7));
+                const uint32_t slot = sf & 0x7FFFu;
+                const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;           // singletons add their count (:275 / :364)
+                if (v != 0.0) atomicAdd(&acc[slot], v);
+            }
+            const uint4* __restrict__ mixed = pure + np;
+            for (uint32_t ch = threadIdx.x; ch < nm; ch += kSweepBlock) {            // chunks that straddle slots: run by run
+                const uint4 e4 = mixed[2u * ch], s4 = mixed[2u * ch + 1u];
+                uint32_t cur = s4.x & 0xFFFFu;
+                double sum = 0.0;
                 auto flush_run = [&]() {
-                    const double v = xs[slot] * sn + ss;
+                    const uint32_t slot = cur & 0x7FFFu;
+                    const double v = (cur & kCscSingleBit) ? sum : xs[slot] * sum;
                     if (v != 0.0) atomicAdd(&acc[slot], v);
                 };
-                // (one path for every chunk: a separate branch for the 85 % of the chunks without a marker was measured slower --
-                //  some lane of every wavefront has one, so both branches ran: 20.5 instead of 18.8 us per sweep)
-                auto entry = [&](uint32_t e) {
-                    if (e & kCscMarker) { flush_run(); slot = e & 0x7FFu; sn = 0.0; ss = 0.0; }
-                    else { const double f = den[e & 0x1FFFu]; if (e & kCscSingle) ss += f; else sn += f; }
+                auto entry = [&](uint32_t cls, uint32_t sfk) {
+                    if (sfk != cur) { flush_run(); cur = sfk; sum = 0.0; }
+                    sum += den[cls & 0x1FFFu];
                 };
-                entry(e4.x & 0xFFFFu); entry(e4.x >> 16); entry(e4.y & 0xFFFFu); entry(e4.y >> 16);
-                entry(e4.z & 0xFFFFu); entry(e4.z >> 16); entry(e4.w & 0xFFFFu); entry(e4.w >> 16);
+                entry(e4.x & 0xFFFFu, s4.x & 0xFFFFu); entry(e4.x >> 16, s4.x >> 16); entry(e4.y & 0xFFFFu, s4.y & 0xFFFFu); entry(e4.y >> 16, s4.y >> 16);
+                entry(e4.z & 0xFFFFu, s4.z & 0xFFFFu); entry(e4.z >> 16, s4.z >> 16); entry(e4.w & 0xFFFFu, s4.w & 0xFFFFu); entry(e4.w >> 16, s4.w >> 16);
                 flush_run();
             }
         } else {
@@ -862,7 +961,10 @@ struct sfgpu_em {
     uint32_t* pub_pos = nullptr;                                // window slot -> its entry of `partial`
     uint32_t* lstream = nullptr; uint32_t* esc_id = nullptr; uint32_t* esc_cls = nullptr;   // re-packed labels (k_sweep_lds)
     uint64_t* tile_s0 = nullptr; uint64_t* tile_esc0 = nullptr;
-    uint16_t* csc = nullptr; uint16_t* csc_slot0 = nullptr; uint64_t* tile_q0 = nullptr;      // transcript-major copy of the tiles (phase C as a gather)
+    bool gather = false;                        // the sweep runs in its GATHER form (compact class-major stream + transcript-major copy)
+    uint32_t* chdr = nullptr;                   // ... the compact stream's chunk headers (lstream then holds 16-bit slots)
+    unsigned char* csc = nullptr; uint16_t* csc_slot0 = nullptr;                              // transcript-major copy of the tiles (phase C as a gather)
+    uint64_t* tile_qb = nullptr; uint32_t* tile_np = nullptr; uint32_t* tile_pr = nullptr;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
     double* tsum = nullptr;                                 // [n_tiles] what each tile added in the last sweep (VBEM, optimize())
     bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
@@ -887,7 +989,7 @@ static void em_free(sfgpu_em* em) {
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
-                    em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->csc, em->csc_slot0, em->tile_q0,
+                    em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
                     em->blkmax, em->tsum, em->inv, em->cperm};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
@@ -934,10 +1036,12 @@ static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
                 em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr, em->inv,
-                em->csc, em->csc_slot0, em->tile_q0};
+                em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr};
     void* args[] = {&a};
-    const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true>)
-                                      : reinterpret_cast<const void*>(&k_sweep_lds<false>);
+    const void* f = em->gather ? (em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true>)
+                                                    : reinterpret_cast<const void*>(&k_sweep_lds<false, true>))
+                               : (em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, false>)
+                                                    : reinterpret_cast<const void*>(&k_sweep_lds<false, false>));
     SF_HIP(L.launch(f, dim3(em->n_tiles), dim3(kSweepBlock), args));
     return SFGPU_OK;
 }
@@ -1216,45 +1320,53 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
         EM_TRY(pool_malloc(&em->esc_id, (E ? E : 1) * 4));
         EM_TRY(pool_malloc(&em->esc_cls, (E ? E : 1) * 4));
+        {
+            const char* eg = getenv("SFGPU_EM_GATHER");
+            em->gather = (!eg || atoi(eg) != 0) && (uint64_t)rp_end > E && nt < (1u << 20);
+        }
+        if (em->gather) {
+            EM_TRY(pool_malloc(&em->chdr, (S / 8 + 1) * 4));
+            EM_TRY(hipMemsetAsync(em->chdr, 0, (S / 8 + 1) * 4, em->cur));
+            hipLaunchKernelGGL(k_fill_stream_compact, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo,
+                               em->tile_s0, em->tile_esc0, reinterpret_cast<uint16_t*>(em->lstream), em->chdr, em->esc_id, em->esc_cls, em->inv);
+        } else
         hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
                            em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls, em->inv);
         EM_TRY(hipGetLastError());
         // the transcript-major copy for phase C (see k_csc_keys): sort the nonzeros by (tile, window slot), lay them out in
         // chunks of 8 sixteen-bit entries with a marker in front of every slot's run.  SFGPU_EM_GATHER=0 keeps the scatter form.
         {
-            const char* eg = getenv("SFGPU_EM_GATHER");
             const uint64_t Lnz = rp_end;
-            if ((!eg || atoi(eg) != 0) && Lnz > E && nt < (1u << 21)) {
-                const uint64_t V = Lnz - E;
-                uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *flag = nullptr, *idx = nullptr, *ent = nullptr, *pad = nullptr;
-                uint64_t* mx = nullptr;
+            if (em->gather) {
+                uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *idx = nullptr, *chunks = nullptr, *pure = nullptr;
+                uint64_t *cb = nullptr, *ps = nullptr;
                 EM_TRY(pool_malloc(&k_in, Lnz * 4)); EM_TRY(pool_malloc(&k_out, Lnz * 4)); EM_TRY(pool_malloc(&v_in, Lnz * 4)); EM_TRY(pool_malloc(&v_out, Lnz * 4));
-                EM_TRY(pool_malloc(&flag, (V + 1) * 4)); EM_TRY(pool_malloc(&mx, (V + 2) * 8));
-                EM_TRY(pool_malloc(&idx, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&ent, ((size_t)nt + 1) * 4)); EM_TRY(pool_malloc(&pad, ((size_t)nt + 2) * 4));
-                EM_TRY(pool_malloc(&em->tile_q0, ((size_t)nt + 2) * 8));
+                EM_TRY(pool_malloc(&idx, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&chunks, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&cb, ((size_t)nt + 3) * 8));
+                EM_TRY(pool_malloc(&em->tile_qb, ((size_t)nt + 2) * 8)); EM_TRY(pool_malloc(&em->tile_np, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&em->tile_pr, ((size_t)nt + 2) * 4));
                 hipLaunchKernelGGL(k_csc_keys, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo, k_in, v_in);
-                int bits = 11; while (bits < 32 && (1ull << bits) <= ((uint64_t)nt << 11)) ++bits;      // (the largest key is nt << 11)
+                int bits = 12; while (bits < 32 && (1ull << bits) <= ((uint64_t)nt << 12)) ++bits;      // (the largest key is nt << 12)
                 int cr = sort_pairs_u32_u32(k_in, k_out, v_in, v_out, Lnz, em->cur, bits, false);
+                // G: the number of chunks is only known on the device (cb[nt]); its bound -- every tile ends in a partial chunk --
+                // sizes the arrays, and the flags behind the last real chunk stay 0, so no readback holds the plan up
+                const uint64_t G = Lnz / 8 + nt + 1;
                 if (!cr) {
-                    hipLaunchKernelGGL(k_csc_flags, dim3(blocks_for(V + 1)), dim3(kEmBlock), 0, em->cur, V, k_out, flag);
-                    cr = exclusive_scan_u32(flag, mx, V, em->cur, false);
-                }
-                uint64_t Q = 0;
-                if (!cr) {
-                    hipLaunchKernelGGL(k_csc_tiles, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, V, nt, k_out, mx, idx, ent, pad);
-                    cr = exclusive_scan_u32(pad, em->tile_q0, nt, em->cur, false);
+                    hipLaunchKernelGGL(k_csc_tiles, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, Lnz, nt, k_out, idx, chunks);
+                    cr = exclusive_scan_u32(chunks, cb, nt, em->cur, false);
                 }
                 if (!cr) {
-                    EM_TRY(hipMemcpyAsync(&Q, em->tile_q0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-                    EM_TRY(hipStreamSynchronize(em->cur));
-                    EM_TRY(pool_malloc(&em->csc, (Q ? Q : 8) * 2 + 16));
-                    EM_TRY(pool_malloc(&em->csc_slot0, (Q / 8 + 1) * 2));
-                    EM_TRY(hipMemsetAsync(em->csc_slot0, 0, (Q / 8 + 1) * 2, em->cur));
-                    hipLaunchKernelGGL(k_csc_fill, dim3(blocks_for(Q ? Q : 1)), dim3(kEmBlock), 0, em->cur, Q, em->csc);
-                    hipLaunchKernelGGL(k_csc_scatter, dim3(blocks_for(V)), dim3(kEmBlock), 0, em->cur, V, k_out, v_out, flag, mx, idx, em->tile_q0, em->csc, em->csc_slot0);
+                    EM_TRY(pool_malloc(&pure, (G + 2) * 4)); EM_TRY(pool_malloc(&ps, (G + 3) * 8));
+                    EM_TRY(hipMemsetAsync(pure, 0, (G + 2) * 4, em->cur));
+                    hipLaunchKernelGGL(k_csc_pure, dim3(nt), dim3(kEmBlock), 0, em->cur, k_out, idx, cb, pure);
+                    cr = exclusive_scan_u32(pure, ps, G, em->cur, false);
+                }
+                if (!cr) {
+                    hipLaunchKernelGGL(k_csc_offsets, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, cb, ps, em->tile_qb, em->tile_np, em->tile_pr);
+                    EM_TRY(pool_malloc(&em->csc, 32 * (G ? G : 1) + 32));                  // (every chunk mixed: the upper bound)
+                    EM_TRY(pool_malloc(&em->csc_slot0, (G + 1) * 2));
+                    hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, k_out, v_out, idx, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0);
                     EM_TRY(hipGetLastError());
                 }
-                for (void* q : {(void*)k_in, (void*)k_out, (void*)v_in, (void*)v_out, (void*)flag, (void*)mx, (void*)idx, (void*)ent, (void*)pad}) pool_free_on(q, em->cur);
+                for (void* q : {(void*)k_in, (void*)k_out, (void*)v_in, (void*)v_out, (void*)idx, (void*)chunks, (void*)pure, (void*)cb, (void*)ps}) if (q) pool_free_on(q, em->cur);
                 if (cr) { em_free(em); return cr; }
             }
         }
