@@ -57,6 +57,13 @@ __device__ __forceinline__ bool em_stop(uint32_t it, const EmState* s, uint32_t 
     return it > 0 && s->notconv[(it - 1) & 1] == 0;
 }
 
+// the stop test of the host loop, posted where the host can read it without a copy command: `mirror` is pinned host memory
+// (see em_poll_start).  low word: iterations completed, high word: 1 = the loop has ended.
+__global__ void k_post_state(const EmState* st, uint32_t min_iter, uint32_t max_iter, unsigned long long* mirror) {
+    const uint32_t it = st->it_a;
+    *mirror = (unsigned long long)it | ((unsigned long long)(em_stop(it, st, min_iter, max_iter) ? 1u : 0u) << 32);
+}
+
 // psi(x), x > 0: the recurrence psi(x) = psi(x + 10) - sum_{k<10} 1/(x + k) for x < 10, then the asymptotic
 // series through B_14 (boost::math::digamma at :303, :314 in the reference; |err| ~ 1e-15).
 // The ten reciprocals are added as ONE fraction (pairwise n/d merges: every term is positive, so nothing
@@ -338,35 +345,127 @@ k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
     for (uint64_t p = s0 + n + threadIdx.x; p < s1; p += kEmBlock) stream[p] = kNull;
 }
 
-// the COMPACT form of the class-major stream (k_sweep_lds<., true>): slot16[s0 + p] = window slot of nonzero p of the tile (kWin:
-// a member outside the window -- its x reads as 0), chdr[(s0 + p) / 8] = class of the chunk's first nonzero | bit 16 + k for every
-// nonzero k >= 1 of the chunk that starts the next class.  chdr is zero before the launch.
-__global__ void __launch_bounds__(kEmBlock)
-k_fill_stream_compact(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
-                      const uint32_t* __restrict__ tile_lo, const uint64_t* __restrict__ tile_s0, const uint64_t* __restrict__ tile_esc0,
-                      uint16_t* slot16, uint32_t* chdr, uint32_t* esc_id, uint32_t* esc_cls, const uint32_t* __restrict__ inv) {
+// ---- GATHER form: one kernel per tile makes the COMPACT class-major stream and sorts the tile's nonzeros by window slot ----------
+// slot16[s0 + p] = window slot of nonzero p of the tile (kWin: a member outside the window, or padding -- its x reads as 0),
+// chdr[(s0 + p) / 8] = class of the chunk's first nonzero | bit 16 + k for every nonzero k >= 1 of the chunk that starts the next
+// class; escapes go to the tile's side list as in k_fill_stream.  The same pass classifies every nonzero for the
+// transcript-major copy: key = singleton class << 11 | window slot (kEscBin: an escape), and the tile's nonzeros are sorted by
+// that key with a STABLE counting sort -- wavefront w owns the w-th contiguous piece of the tile and a histogram row of its own,
+// the column scan of the rows gives every wavefront its first position per key, and lanes of one step that share a key are
+// ranked by lane (ballots over the 12 key bits) -- so entries of one slot stay in class order whatever the schedule, and the
+// sums of phase C are formed in the same order on every rank and in every plan.  A nonzero finds its class without a walk
+// per class: a step's 64 consecutive positions meet at most 64 class starts, which the lanes load side by side and search with
+// shuffles.  One pass of ~30 us on cfg3 in place of a key pass, a 3-pass radix sort of all nonzeros and a search per tile (0.4 ms).
+constexpr int kBuildBlock = 512, kBuildWaves = kBuildBlock / kWave, kBuildPerThread = 7;
+constexpr uint32_t kEscBin = 0xC00u, kBuildBins = kEscBin + 1u;          // keys 0..0x3FF, 0x800..0xBFF and the escape bin
+static_assert(kBuildBlock * kBuildPerThread >= (int)kBuildBins, "bins per thread in the column scan");
+static_assert(kWin <= 0x400, "key: 10 bits of window slot under the singleton bit");
+__global__ void __launch_bounds__(kBuildBlock)
+k_tile_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
+             const uint32_t* __restrict__ tile_lo, const uint64_t* __restrict__ tile_s0, const uint64_t* __restrict__ tile_esc0,
+             uint16_t* slot16, uint32_t* chdr, uint32_t* esc_id, uint32_t* esc_cls, const uint32_t* __restrict__ inv,
+             uint32_t* tmp, uint32_t* kv, uint32_t* idx, uint32_t* tile_in, uint32_t* chunks) {
+    extern __shared__ uint32_t hist[];                          // [kBuildWaves][kBuildBins]
     __shared__ unsigned int esc_cursor;
-    if (threadIdx.x == 0) esc_cursor = 0;
-    __syncthreads();
-    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
-    const uint32_t lo = tile_lo[blockIdx.x];
-    const uint64_t s0 = tile_s0[blockIdx.x], s1 = tile_s0[blockIdx.x + 1], e0 = tile_esc0[blockIdx.x];
+    __shared__ uint32_t wsum[kBuildWaves];
+    const uint32_t t = blockIdx.x, c0 = tile_c0[t], c1 = tile_c0[t + 1], lo = tile_lo[t];
+    const uint64_t s0 = tile_s0[t], e0 = tile_esc0[t];
+    const uint32_t len = (uint32_t)(tile_s0[t + 1] - s0);       // padded to whole chunks
     const uint32_t j0 = rowptr[c0], n = rowptr[c1] - j0;
-    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
-        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
-        for (uint32_t m = 0; m < k; ++m) {
-            const uint32_t t = ids[b + m], d = t - lo;
-            const uint64_t p = s0 + (b - j0) + m;
-            if (d >= (uint32_t)kWin) {
-                const unsigned int idx = atomicAdd(&esc_cursor, 1u);
-                esc_id[e0 + idx] = inv ? inv[t] : t; esc_cls[e0 + idx] = ((c - c0) << 16) | (k == 1 ? kSingle : 0u);
+    for (uint32_t i = threadIdx.x; i < kBuildWaves * kBuildBins; i += kBuildBlock) hist[i] = 0u;
+    if (threadIdx.x == 0) esc_cursor = 0u;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const uint32_t seg = ((len + kBuildWaves - 1) / kBuildWaves + (kWave - 1)) & ~(uint32_t)(kWave - 1);
+    const uint32_t p_begin = wave * seg < len ? wave * seg : len, p_end = p_begin + seg < len ? p_begin + seg : len;
+    uint32_t* h = hist + wave * kBuildBins;
+
+    // ---- a: classify, write the compact stream, count
+    uint32_t cfirst = c0;                                       // class of position p0 (wave-uniform)
+    if (p_begin < n) {
+        uint32_t a = c0, b = c1;                                // last class with rowptr[c] <= j0 + p_begin
+        while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if (rowptr[mid] <= j0 + p_begin) a = mid; else b = mid; }
+        cfirst = a;
+    }
+    for (uint32_t p0 = p_begin; p0 < p_end; p0 += kWave) {
+        if (p0 < n && cfirst + 1u < c1 && rowptr[cfirst + 1u] <= j0 + p0) ++cfirst;
+        const uint32_t p = p0 + lane, pos = j0 + p;
+        const uint32_t ia = cfirst + lane;
+        const uint32_t A = ia <= c1 ? rowptr[ia] : 0xFFFFFFFFu;             // start of class cfirst + lane ...
+        const uint32_t B = ia + 1u <= c1 ? rowptr[ia + 1u] : 0xFFFFFFFFu;   // ... and of the one behind it
+        uint32_t r = 0;                                         // how many of B_0 <= B_1 <= ... are <= pos (at most 63: see above)
+#pragma unroll
+        for (uint32_t step = kWave / 2; step; step >>= 1) { const uint32_t probe = __shfl(B, (int)(r + step - 1u), kWave); if (probe <= pos) r += step; }
+        const uint32_t a_r = __shfl(A, (int)r, kWave), b_r = __shfl(B, (int)r, kWave);
+        const bool valid = p < n;
+        const uint32_t crel = cfirst + r - c0;
+        const bool single = b_r - a_r == 1u;
+        uint32_t slot = (uint32_t)kWin;
+        if (valid) {
+            const uint32_t tr = ids[pos], d = tr - lo;
+            uint32_t key = kEscBin;
+            if (d < (uint32_t)kWin) { slot = d; key = (single ? 0x800u : 0u) | d; }
+            else {
+                const unsigned int q = atomicAdd(&esc_cursor, 1u);
+                esc_id[e0 + q] = inv ? inv[tr] : tr; esc_cls[e0 + q] = (crel << 16) | (single ? kSingle : 0u);
             }
-            slot16[p] = (uint16_t)(d < (uint32_t)kWin ? d : (uint32_t)kWin);
-            if ((p & 7u) == 0) atomicOr(&chdr[p >> 3], c - c0);
-            else if (m == 0) atomicOr(&chdr[p >> 3], 1u << (16u + (uint32_t)(p & 7u)));
+            tmp[pos] = (key << 16) | crel;
+            atomicAdd(&h[key], 1u);
+        }
+        const uint64_t starts = __ballot(valid && a_r == pos);
+        if (p < len) {
+            slot16[s0 + p] = (uint16_t)slot;
+            if ((lane & 7u) == 0u) chdr[(s0 + p) >> 3] = (valid ? crel : 0u) | ((uint32_t)((starts >> (lane + 1u)) & 0x7Full) << 17);
+        }
+        cfirst = __shfl(cfirst + r, kWave - 1, kWave);
+        if (cfirst > c1) cfirst = c1;
+    }
+    __syncthreads();
+
+    // ---- b: first position of every (wavefront, key): column scan of the rows, then a scan over the keys
+    uint32_t tot[kBuildPerThread], sum = 0u;
+#pragma unroll
+    for (int k = 0; k < kBuildPerThread; ++k) {
+        const uint32_t b = threadIdx.x * kBuildPerThread + k;
+        uint32_t run = 0u;
+        if (b < kBuildBins) for (int w = 0; w < kBuildWaves; ++w) { const uint32_t c = hist[w * kBuildBins + b]; hist[w * kBuildBins + b] = run; run += c; }
+        tot[k] = run; sum += run;
+    }
+    uint32_t inc = sum;
+    for (int o = 1; o < kWave; o <<= 1) { const uint32_t v = __shfl_up(inc, o, kWave); if ((int)lane >= o) inc += v; }
+    if (lane == kWave - 1) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - sum;
+    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < kBuildPerThread; ++k) {
+        const uint32_t b = threadIdx.x * kBuildPerThread + k;
+        if (b < kBuildBins) {
+            for (int w = 0; w < kBuildWaves; ++w) hist[w * kBuildBins + b] += base;
+            if (b == kEscBin) {                                 // everything in front of the escape bin lies in the window
+                tile_in[t] = base; idx[t] = j0; chunks[t] = (base + 7u) >> 3;
+                if (t == gridDim.x - 1) chunks[gridDim.x] = 0u;                    // the scan's sentinel
+            }
+        }
+        base += tot[k];
+    }
+    __syncthreads();
+
+    // ---- c: place (stable: wavefronts in order of their pieces, steps in order, lanes in order)
+    for (uint32_t p0 = p_begin; p0 < p_end; p0 += kWave) {
+        const uint32_t p = p0 + lane;
+        const uint32_t v = p < n ? tmp[j0 + p] : (kEscBin << 16);
+        const uint32_t key = v >> 16;
+        const bool in = key != kEscBin;
+        uint64_t peers = __ballot(in);
+#pragma unroll
+        for (uint32_t b = 0; b < 12u; ++b) { const bool bit = (key >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
+        if (in) {
+            const uint32_t first = h[key];
+            kv[j0 + first + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull))] = v;
+            if ((peers >> lane) == 1ull) h[key] = first + (uint32_t)__popcll(peers);    // the last lane of the group moves the cursor
         }
     }
-    for (uint64_t p = s0 + n + threadIdx.x; p < s1; p += kEmBlock) slot16[p] = (uint16_t)kWin;
 }
 
 // one (transcript, slot) pair per window entry; sorted by transcript this is the cover list that the
@@ -462,44 +561,15 @@ __global__ void k_renum_scatter(uint64_t n, const uint32_t* __restrict__ src, co
 // of 18 000; within a slot the entries are in class order (stable sort), so the sums are formed in the same order on every rank
 // and in every plan.  Costs ~2.3 more bytes per nonzero and iteration, and a sort of the nonzeros when the plan is made.
 constexpr uint32_t kCscSingleBit = 0x8000u;
-// key = tile << 12 | singleton << 11 | window offset (escaped members: n_tiles << 12 -> sorted to the end), val = class in tile
+// the sorted nonzeros of tile t: kv[idx[t] .. idx[t] + tile_in[t]), key << 16 | class in the tile (k_tile_build)
 __global__ void __launch_bounds__(kEmBlock)
-k_csc_keys(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ tile_c0,
-           const uint32_t* __restrict__ tile_lo, uint32_t* keys, uint32_t* vals) {
-    const uint32_t c0 = tile_c0[blockIdx.x], c1 = tile_c0[blockIdx.x + 1];
-    const uint32_t lo = tile_lo[blockIdx.x];
-    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
-        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
-        const uint32_t hi = (blockIdx.x << 12) | (k == 1 ? 0x800u : 0u);
-        for (uint32_t m = 0; m < k; ++m) {
-            const uint32_t d = ids[b + m] - lo;
-            keys[b + m] = d < (uint32_t)kWin ? (hi | d) : (gridDim.x << 12);
-            vals[b + m] = c - c0;
-        }
-    }
-}
-// tile t: its first sorted element idx[t] (t == n_tiles: the number of entries at all) and its number of chunks
-__global__ void k_csc_tiles(uint64_t L, uint32_t n_tiles, const uint32_t* __restrict__ keys, uint32_t* idx, uint32_t* chunks) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    auto lower = [&](uint32_t tile) -> uint64_t {             // first i with keys[i] >= tile << 12
-        const uint32_t target = tile << 12;
-        uint64_t lo = 0, hi = L;
-        while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (keys[mid] >= target) hi = mid; else lo = mid + 1; }
-        return lo;
-    };
-    const uint64_t a = lower(t);
-    idx[t] = (uint32_t)a;
-    chunks[t] = (t == n_tiles) ? 0u : (uint32_t)((lower(t + 1) - a + 7) >> 3);
-}
-__global__ void __launch_bounds__(kEmBlock)
-k_csc_pure(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ cb, uint32_t* pure) {
-    const uint32_t t = blockIdx.x, a = idx[t], e = idx[t + 1];
+k_csc_pure(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tile_in, const uint64_t* __restrict__ cb, uint32_t* pure) {
+    const uint32_t t = blockIdx.x, a = idx[t], e = a + tile_in[t];
     const uint64_t g0 = cb[t];
     const uint32_t n = (uint32_t)(cb[t + 1] - g0);
     for (uint32_t j = threadIdx.x; j < n; j += kEmBlock) {
         const uint32_t first = a + 8u * j, last = (first + 7u < e) ? first + 7u : e - 1u;
-        pure[g0 + j] = keys[first] == keys[last] ? 1u : 0u;
+        pure[g0 + j] = (kv[first] >> 16) == (kv[last] >> 16) ? 1u : 0u;
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) pure[cb[t + 1]] = 0u;       // the scan's sentinel
 }
@@ -514,10 +584,10 @@ __global__ void k_csc_offsets(uint32_t n_tiles, const uint64_t* __restrict__ cb,
     tile_np[t] = (t == n_tiles) ? 0u : (uint32_t)(ps[cb[t + 1]] - p);
 }
 __global__ void __launch_bounds__(kEmBlock)
-k_csc_write(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ cb,
+k_csc_write(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tile_in, const uint64_t* __restrict__ cb,
             const uint64_t* __restrict__ ps, const uint64_t* __restrict__ tile_qb, const uint32_t* __restrict__ tile_np,
             unsigned char* csc, uint16_t* slot0) {
-    const uint32_t t = blockIdx.x, a = idx[t], e = idx[t + 1];
+    const uint32_t t = blockIdx.x, a = idx[t], e = a + tile_in[t];
     const uint64_t g0 = cb[t], p0 = ps[g0];
     const uint32_t n = (uint32_t)(cb[t + 1] - g0), np = tile_np[t];
     unsigned char* base = csc + tile_qb[t];
@@ -527,13 +597,13 @@ k_csc_write(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k) {
             const uint32_t i = first + k;
-            const uint32_t key = keys[i <= last ? i : last];
-            cl[k] = i <= last ? vals[i] : (uint32_t)kTileNnz;                 // padding: the null class (count / denom = 0)
+            const uint32_t v = kv[i <= last ? i : last], key = v >> 16;
+            cl[k] = i <= last ? (v & 0xFFFFu) : (uint32_t)kTileNnz;           // padding: the null class (count / denom = 0)
             sl[k] = (key & 0x7FFu) | ((key & 0x800u) ? kCscSingleBit : 0u);
         }
         const uint64_t g = g0 + j, pr = ps[g];
         const uint4 cls4 = make_uint4(cl[0] | (cl[1] << 16), cl[2] | (cl[3] << 16), cl[4] | (cl[5] << 16), cl[6] | (cl[7] << 16));
-        if (keys[first] == keys[last]) {
+        if ((kv[first] >> 16) == (kv[last] >> 16)) {
             reinterpret_cast<uint4*>(base)[pr - p0] = cls4;
             slot0[pr] = (uint16_t)sl[0];
         } else {
@@ -947,6 +1017,8 @@ struct sfgpu_em {
     hipStream_t stream = nullptr;          // own stream: graph capture is illegal on the null stream
     hipStream_t cur = nullptr;             // where work goes: `stream` inside optimize(), the caller's stream for the piecewise API
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_join = nullptr;
+    hipEvent_t ev_poll[2] = {nullptr, nullptr};   // pipelined stop test of the loop (em_poll_start / em_poll_wait)
+    unsigned long long* h_mirror = nullptr;       // pinned: what k_post_state wrote last
     sfgpu_problem prob{};
     uint64_t L = 0;
     int nb = 1;                            // blocks of the per-transcript kernels
@@ -997,6 +1069,8 @@ static void em_free(sfgpu_em* em) {
     if (em->ev_a) (void)hipEventDestroy(em->ev_a);
     if (em->ev_b) (void)hipEventDestroy(em->ev_b);
     if (em->ev_join) (void)hipEventDestroy(em->ev_join);
+    for (hipEvent_t e : em->ev_poll) if (e) (void)hipEventDestroy(e);
+    if (em->h_mirror) pinned_free(em->h_mirror);
     if (em->stream) stream_release(em->stream);    // synchronised above
     delete em;
 }
@@ -1186,6 +1260,9 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     em->cur = em->stream;
     EM_TRY(hipEventCreate(&em->ev_a)); EM_TRY(hipEventCreate(&em->ev_b));
     EM_TRY(hipEventCreateWithFlags(&em->ev_join, hipEventDisableTiming));
+    for (hipEvent_t& e : em->ev_poll) EM_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    EM_TRY(pinned_malloc(&em->h_mirror, 128));
+    memset(em->h_mirror, 0, 128);
     EM_TRY(pool_malloc(&em->alpha, M * 8)); EM_TRY(pool_malloc(&em->alpha_out, M * 8));
     EM_TRY(pool_malloc(&em->x, M * 8)); EM_TRY(pool_malloc(&em->lenc, M * 8)); EM_TRY(pool_malloc(&em->scratch, M * 8));
     EM_TRY(pool_malloc(&em->partials, kMaxPartials * 8)); EM_TRY(pool_malloc(&em->sum_partials, kMaxPartials * 8));
@@ -1322,53 +1399,48 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&em->esc_cls, (E ? E : 1) * 4));
         {
             const char* eg = getenv("SFGPU_EM_GATHER");
-            em->gather = (!eg || atoi(eg) != 0) && (uint64_t)rp_end > E && nt < (1u << 20);
+            em->gather = (!eg || atoi(eg) != 0) && (uint64_t)rp_end > E;
         }
-        if (em->gather) {
-            EM_TRY(pool_malloc(&em->chdr, (S / 8 + 1) * 4));
-            EM_TRY(hipMemsetAsync(em->chdr, 0, (S / 8 + 1) * 4, em->cur));
-            hipLaunchKernelGGL(k_fill_stream_compact, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo,
-                               em->tile_s0, em->tile_esc0, reinterpret_cast<uint16_t*>(em->lstream), em->chdr, em->esc_id, em->esc_cls, em->inv);
-        } else
-        hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
-                           em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls, em->inv);
-        EM_TRY(hipGetLastError());
-        // the transcript-major copy for phase C (see k_csc_keys): sort the nonzeros by (tile, window slot), lay them out in
-        // chunks of 8 sixteen-bit entries with a marker in front of every slot's run.  SFGPU_EM_GATHER=0 keeps the scatter form.
-        {
+        if (!em->gather) {
+            hipLaunchKernelGGL(k_fill_stream, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
+                               em->tile_lo, em->tile_s0, em->tile_esc0, em->lstream, em->esc_id, em->esc_cls, em->inv);
+            EM_TRY(hipGetLastError());
+        } else {
+            // the compact class-major stream and the transcript-major copy for phase C: k_tile_build sorts every tile's nonzeros
+            // by window slot, the rest lays them out in chunks of 8 sixteen-bit entries, pure chunks first.  SFGPU_EM_GATHER=0
+            // keeps the scatter form.
             const uint64_t Lnz = rp_end;
-            if (em->gather) {
-                uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *idx = nullptr, *chunks = nullptr, *pure = nullptr;
-                uint64_t *cb = nullptr, *ps = nullptr;
-                EM_TRY(pool_malloc(&k_in, Lnz * 4)); EM_TRY(pool_malloc(&k_out, Lnz * 4)); EM_TRY(pool_malloc(&v_in, Lnz * 4)); EM_TRY(pool_malloc(&v_out, Lnz * 4));
-                EM_TRY(pool_malloc(&idx, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&chunks, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&cb, ((size_t)nt + 3) * 8));
-                EM_TRY(pool_malloc(&em->tile_qb, ((size_t)nt + 2) * 8)); EM_TRY(pool_malloc(&em->tile_np, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&em->tile_pr, ((size_t)nt + 2) * 4));
-                hipLaunchKernelGGL(k_csc_keys, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo, k_in, v_in);
-                int bits = 12; while (bits < 32 && (1ull << bits) <= ((uint64_t)nt << 12)) ++bits;      // (the largest key is nt << 12)
-                int cr = sort_pairs_u32_u32(k_in, k_out, v_in, v_out, Lnz, em->cur, bits, false);
-                // G: the number of chunks is only known on the device (cb[nt]); its bound -- every tile ends in a partial chunk --
-                // sizes the arrays, and the flags behind the last real chunk stay 0, so no readback holds the plan up
-                const uint64_t G = Lnz / 8 + nt + 1;
-                if (!cr) {
-                    hipLaunchKernelGGL(k_csc_tiles, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, Lnz, nt, k_out, idx, chunks);
-                    cr = exclusive_scan_u32(chunks, cb, nt, em->cur, false);
-                }
-                if (!cr) {
-                    EM_TRY(pool_malloc(&pure, (G + 2) * 4)); EM_TRY(pool_malloc(&ps, (G + 3) * 8));
-                    EM_TRY(hipMemsetAsync(pure, 0, (G + 2) * 4, em->cur));
-                    hipLaunchKernelGGL(k_csc_pure, dim3(nt), dim3(kEmBlock), 0, em->cur, k_out, idx, cb, pure);
-                    cr = exclusive_scan_u32(pure, ps, G, em->cur, false);
-                }
-                if (!cr) {
-                    hipLaunchKernelGGL(k_csc_offsets, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, cb, ps, em->tile_qb, em->tile_np, em->tile_pr);
-                    EM_TRY(pool_malloc(&em->csc, 32 * (G ? G : 1) + 32));                  // (every chunk mixed: the upper bound)
-                    EM_TRY(pool_malloc(&em->csc_slot0, (G + 1) * 2));
-                    hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, k_out, v_out, idx, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0);
-                    EM_TRY(hipGetLastError());
-                }
-                for (void* q : {(void*)k_in, (void*)k_out, (void*)v_in, (void*)v_out, (void*)idx, (void*)chunks, (void*)pure, (void*)cb, (void*)ps}) if (q) pool_free_on(q, em->cur);
-                if (cr) { em_free(em); return cr; }
+            uint32_t *tmp = nullptr, *kv = nullptr, *idx = nullptr, *tin = nullptr, *chunks = nullptr, *pure = nullptr;
+            uint64_t *cb = nullptr, *ps = nullptr;
+            EM_TRY(pool_malloc(&em->chdr, (S / 8 + 1) * 4));
+            // G: the number of chunks is only known on the device (cb[nt]); its bound -- every tile ends in a partial chunk --
+            // sizes the arrays, and the flags behind the last real chunk stay 0, so no readback holds the plan up
+            const uint64_t G = Lnz / 8 + nt + 1;
+            EM_TRY(pool_malloc(&tmp, Lnz * 4)); EM_TRY(pool_malloc(&kv, Lnz * 4));
+            EM_TRY(pool_malloc(&idx, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&tin, ((size_t)nt + 2) * 4));
+            EM_TRY(pool_malloc(&chunks, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&cb, ((size_t)nt + 3) * 8));
+            EM_TRY(pool_malloc(&em->tile_qb, ((size_t)nt + 2) * 8)); EM_TRY(pool_malloc(&em->tile_np, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&em->tile_pr, ((size_t)nt + 2) * 4));
+            constexpr size_t kBuildLds = (size_t)kBuildWaves * kBuildBins * 4;
+            EM_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLds));
+            hipLaunchKernelGGL(k_tile_build, dim3(nt), dim3(kBuildBlock), kBuildLds, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo, em->tile_s0, em->tile_esc0,
+                               reinterpret_cast<uint16_t*>(em->lstream), em->chdr, em->esc_id, em->esc_cls, em->inv, tmp, kv, idx, tin, chunks);
+            EM_TRY(hipGetLastError());
+            int cr = exclusive_scan_u32(chunks, cb, nt, em->cur, false);
+            if (!cr) {
+                EM_TRY(pool_malloc(&pure, (G + 2) * 4)); EM_TRY(pool_malloc(&ps, (G + 3) * 8));
+                EM_TRY(hipMemsetAsync(pure, 0, (G + 2) * 4, em->cur));
+                hipLaunchKernelGGL(k_csc_pure, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, pure);
+                cr = exclusive_scan_u32(pure, ps, G, em->cur, false);
             }
+            if (!cr) {
+                hipLaunchKernelGGL(k_csc_offsets, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, cb, ps, em->tile_qb, em->tile_np, em->tile_pr);
+                EM_TRY(pool_malloc(&em->csc, 32 * (G ? G : 1) + 32));                  // (every chunk mixed: the upper bound)
+                EM_TRY(pool_malloc(&em->csc_slot0, (G + 1) * 2));
+                hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0);
+                EM_TRY(hipGetLastError());
+            }
+            for (void* q : {(void*)tmp, (void*)kv, (void*)idx, (void*)tin, (void*)chunks, (void*)pure, (void*)cb, (void*)ps}) if (q) pool_free_on(q, em->cur);
+            if (cr) { em_free(em); return cr; }
         }
         if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }
         EM_TRY(pool_malloc(&em->partial, (P ? P : 1) * 8));
@@ -1511,6 +1583,35 @@ int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
     return em_poll_impl(em, done, stats, true);
 }
 
+// The stop test of optimize()'s loop costs the device no idle time: a one-thread kernel behind chunk k (part of the chunk's
+// graph) posts "iterations done | ended" into pinned host memory, an event marks the end of the chunk, and the host looks at
+// chunk k's word only once chunk k + 1 is on the stream.  A device-to-host copy command per chunk plus a host that waits for
+// it before launching again left the device idle ~22 us per chunk of 16 iterations (0.3 ms of cfg3's 232 iterations, 1.1 ms of
+// cfg2's 818).  The chunk that is already enqueued when the end is seen consists of no-ops (the latch lives in device
+// memory): ~80 us, once.
+// Two words, one per event: the word of chunk k is only rewritten by chunk k + 2, which is enqueued after the host has read
+// it -- every rank of a sharded run reads the same value at the same point of the loop, whatever its timing (a single word
+// could already hold the next chunk's state on one rank and not on the other: they would leave the loop at different chunks,
+// one of them inside an all-reduce).  The graph of em_run bakes its arguments and always posts into word 0: there a newer
+// value only means the end is seen a chunk earlier.
+static int em_enqueue_post(sfgpu_em* em, Launcher& L, int slot) {
+    const EmState* st = em->d_state; uint32_t mn = em->opts.min_iter, mx = em->opts.max_iter; unsigned long long* m = em->h_mirror + 8 * slot;
+    void* args[] = {&st, &mn, &mx, &m};
+    SF_HIP(L.launch(reinterpret_cast<const void*>(&k_post_state), dim3(1), dim3(1), args));
+    return SFGPU_OK;
+}
+static int em_poll_start(sfgpu_em* em, int slot, bool post) {
+    if (post) { Launcher L; L.stream = em->cur; int rc = em_enqueue_post(em, L, slot); if (rc) return rc; }
+    SF_HIP(hipEventRecord(em->ev_poll[slot], em->cur));
+    return SFGPU_OK;
+}
+static int em_poll_wait(sfgpu_em* em, int slot, bool posted_by_graph, int* done) {
+    SF_HIP(hipEventSynchronize(em->ev_poll[slot]));
+    const unsigned long long v = *reinterpret_cast<volatile unsigned long long*>(em->h_mirror + (posted_by_graph ? 0 : 8 * slot));
+    *done = (int)((v >> 32) & 1ull);
+    return SFGPU_OK;
+}
+
 int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats) {
     SF_REQUIRE(em && d_alpha_out, SFGPU_ERR_INVALID, "sfgpu_em_finish: null pointer");
     const sfgpu_problem& p = em->prob;
@@ -1557,11 +1658,13 @@ int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_all
         return SFGPU_ERR_NO_ACTIVE;
     }
     if (poll_every == 0) poll_every = 16;
-    while (!done) {
-        for (uint32_t i = 0; i < poll_every; ++i) {                              // iterations past the stop are no-ops on every rank alike
+    em->h_mirror[0] = em->h_mirror[8] = 0ull;
+    for (uint32_t k = 0; !done; ++k) {                                           // (stop test pipelined as in em_run: every rank sees
+        for (uint32_t i = 0; i < poll_every; ++i) {                              //  the same state, iterations past the stop are no-ops)
             if ((rc = sfgpu_em_sweep(em)) || (rc = reduce()) || (rc = sfgpu_em_update(em))) return rc;
         }
-        if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+        if ((rc = em_poll_start(em, (int)(k & 1u), true))) return rc;
+        if (k > 0 && (rc = em_poll_wait(em, (int)((k - 1u) & 1u), false, &done))) return rc;
     }
     return sfgpu_em_finish(em, d_alpha_out, d_mass_out, stats);
 }
@@ -1585,6 +1688,7 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
         rc = em_enqueue_sweep(em, L);
         if (rc == SFGPU_OK) rc = em_enqueue_update(em, true, L);
     }
+    if (rc == SFGPU_OK) rc = em_enqueue_post(em, L, 0);
     if (rc) { (void)hipGraphDestroy(L.graph); return rc; }
     hipError_t ei = hipGraphInstantiate(&em->graph, L.graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(L.graph);
@@ -1621,7 +1725,8 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         }
     }
     if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
-    while (!done) {
+    em->h_mirror[0] = em->h_mirror[8] = 0ull;                // (nothing of an earlier run is in flight: finish() waited for it)
+    for (uint32_t k = 0; !done; ++k) {
         if (use_graph) {
             SF_HIP(hipGraphLaunch(em->graph, em->cur));
         } else {
@@ -1630,7 +1735,8 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
                 if ((rc = em_enqueue_update(em, true))) return rc;
             }
         }
-        if ((rc = em_poll_impl(em, &done, &st, false))) return rc;
+        if ((rc = em_poll_start(em, (int)(k & 1u), !use_graph))) return rc;
+        if (k > 0 && (rc = em_poll_wait(em, (int)((k - 1u) & 1u), use_graph, &done))) return rc;       // the chunk before this one
     }
     SF_HIP(hipEventRecord(em->ev_b, em->cur));
     rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);

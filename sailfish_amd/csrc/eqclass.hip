@@ -248,12 +248,21 @@ __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table
 }
 
 // ---- finish(): canonical order ---------------------------------------------------------------
+// sort key = first id << 14 | the top 14 bits of XXH64: with the ids of a transcriptome (< 2^18) that is a 32-bit key -- four
+// radix passes instead of the eight of (first id << 32 | hash >> 32); classes that share a key (same first id, same 14 bits:
+// a few per thousand) are put into (hash, length, label) order by k_tie_fix.  max_first: the largest first id (sizes the sort).
+constexpr int kSortHashBits = 14;
 __global__ void k_sort_keys(uint64_t n, const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
-                            const uint32_t* __restrict__ arena, uint64_t* keys, uint32_t* vals) {
+                            const uint32_t* __restrict__ arena, uint64_t* keys, uint32_t* vals, unsigned long long* max_first) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    keys[c] = ((uint64_t)arena[cls_off[c]] << 32) | (cls_hash[c] >> 32);
-    vals[c] = (uint32_t)c;
+    uint32_t first = 0;
+    if (c < n) {
+        first = arena[cls_off[c]];
+        keys[c] = ((uint64_t)first << kSortHashBits) | (cls_hash[c] >> (64 - kSortHashBits));
+        vals[c] = (uint32_t)c;
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t v = __shfl_down(first, o, kWave); first = v > first ? v : first; }
+    if ((threadIdx.x & (kWave - 1)) == 0 && first) atomicMax(max_first, (unsigned long long)first);
 }
 
 __device__ bool class_less(uint32_t a, uint32_t b, const uint64_t* cls_hash, const uint64_t* cls_off,
@@ -266,8 +275,8 @@ __device__ bool class_less(uint32_t a, uint32_t b, const uint64_t* cls_hash, con
     return false;
 }
 
-// runs of equal (first id, hash>>32) keys are ordered by (hash, len, label); such runs are rare
-// and short, so the thread at the head of a run insertion-sorts it.
+// runs of equal sort keys (first id, top bits of the hash) are ordered by (hash, len, label); such runs are
+// short, so the thread at the head of a run insertion-sorts it.
 __global__ void k_tie_fix(uint64_t n, const uint64_t* __restrict__ keys, uint32_t* order,
                           const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
                           const uint32_t* __restrict__ cls_len, const uint32_t* __restrict__ arena) {
@@ -300,39 +309,53 @@ __global__ void k_sum_counts(uint64_t n, const uint64_t* __restrict__ table, con
     if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(total, v);
 }
 
-__global__ void k_export(uint64_t n, const uint32_t* __restrict__ order, const uint64_t* __restrict__ rowptr64,
-                         const uint64_t* __restrict__ table, const uint32_t* __restrict__ cls_slot,
-                         const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
-                         const uint32_t* __restrict__ cls_len, const uint32_t* __restrict__ arena,
-                         uint32_t* rowptr, uint32_t* ids, uint64_t* counts, uint64_t* hashes) {
+// export, per class: rowptr, count, hash in the canonical order
+__global__ void k_export_classes(uint64_t n, const uint32_t* __restrict__ order, const uint64_t* __restrict__ rowptr64,
+                                 const uint64_t* __restrict__ table, const uint32_t* __restrict__ cls_slot,
+                                 const uint64_t* __restrict__ cls_hash, uint32_t* rowptr, uint64_t* counts, uint64_t* hashes) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     rowptr[i] = (uint32_t)rowptr64[i];
     if (i == n) return;
-    uint32_t c = order[i];
-    // an arena entry is 16-byte aligned: [n, id0, id1, id2][id3 .. id6] ...; read by granules, not by words
-    const uint4* e = reinterpret_cast<const uint4*>(arena + cls_off[c] - 1);
-    uint32_t* q = ids + rowptr64[i];
-    const uint32_t len = cls_len[c];
-    const uint4 g0 = e[0];
-    uint4 g1 = make_uint4(0u, 0u, 0u, 0u);
-    if (len > 3u) g1 = e[1];
-    if (len > 0u) q[0] = g0.y;
-    if (len > 1u) q[1] = g0.z;
-    if (len > 2u) q[2] = g0.w;
-    if (len > 3u) q[3] = g1.x;
-    if (len > 4u) q[4] = g1.y;
-    if (len > 5u) q[5] = g1.z;
-    if (len > 6u) q[6] = g1.w;
-    for (uint32_t k = 7; k < len; k += 4) {
-        const uint4 g = e[(k + 1) >> 2];
-        q[k] = g.x;
-        if (k + 1 < len) q[k + 1] = g.y;
-        if (k + 2 < len) q[k + 2] = g.z;
-        if (k + 3 < len) q[k + 3] = g.w;
-    }
+    const uint32_t c = order[i];
     counts[i] = table[2 * (uint64_t)cls_slot[c] + 1];
     if (hashes) hashes[i] = cls_hash[c];
+}
+// export, per ID: a wavefront writes kExportPerWave consecutive positions of `ids`, 64 per step, coalesced; the class of a
+// position comes from the class starts the lanes hold side by side (64 consecutive positions meet at most 64 of them: searched
+// with shuffles), its label from the arena (consecutive lanes of a class read consecutive words).  A lane per class that copies
+// its whole label wrote 4 bytes here and 4 bytes there: 240 us on cfg3, this form ~60.
+constexpr uint32_t kExportPerWave = 1024;
+__global__ void __launch_bounds__(kBlock)
+k_export_ids(uint64_t n, uint64_t nnz, const uint32_t* __restrict__ order, const uint64_t* __restrict__ rowptr64,
+             const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ arena, uint32_t* ids) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t p_begin = wave * kExportPerWave, p_end = p_begin + kExportPerWave < nnz ? p_begin + kExportPerWave : nnz;
+    if (p_begin >= nnz) return;
+    uint64_t cf;                                                // class of position p0: the last one with rowptr64[c] <= p0
+    { uint64_t a = 0, b = n; while (b - a > 1) { const uint64_t mid = (a + b) >> 1; if (rowptr64[mid] <= p_begin) a = mid; else b = mid; } cf = a; }
+    for (uint64_t p0 = p_begin; p0 < p_end; p0 += kWave) {
+        if (cf + 1 < n && rowptr64[cf + 1] <= p0) ++cf;         // (position p0 - 1 was of class cf or cf - 1 ... see below)
+        const uint64_t pos = p0 + lane;
+        const uint64_t ia = cf + lane;
+        const uint64_t A = ia <= n ? rowptr64[ia] : ~0ull, B = ia + 1 <= n ? rowptr64[ia + 1] : ~0ull;
+        uint32_t r = 0;                                         // how many of the starts B_0 <= B_1 <= ... are <= pos (at most 63)
+#pragma unroll
+        for (uint32_t step = kWave / 2; step; step >>= 1) {
+            const uint32_t q = r + step - 1u;
+            const uint64_t probe = ((uint64_t)__shfl((uint32_t)(B >> 32), (int)q, kWave) << 32) | __shfl((uint32_t)B, (int)q, kWave);
+            if (probe <= pos) r += step;
+        }
+        const uint64_t a_r = ((uint64_t)__shfl((uint32_t)(A >> 32), (int)r, kWave) << 32) | __shfl((uint32_t)A, (int)r, kWave);
+        if (pos < p_end) {
+            const uint32_t c = order[cf + r];
+            ids[pos] = arena[cls_off[c] + (pos - a_r)];
+        }
+        const uint32_t r_last = __shfl(r, kWave - 1, kWave);    // lane 63's class becomes the next step's first guess
+        cf += r_last;
+        if (cf >= n) cf = n - 1;
+    }
 }
 
 static inline unsigned grid_for(uint64_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
@@ -679,8 +702,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     SF_CHECK_LAUNCH();
     PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
                 eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes};
-    static const bool skip_insert = getenv("SFGPU_X_SKIP_INSERT") != nullptr;      // (dev: timing experiments on pass 1 whose bins are not valid)
-    if (!skip_insert) hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
+    hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev1, st));
     SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1016,11 +1038,16 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
         DevBuf<uint64_t> keys_in, keys_out; DevBuf<uint32_t> vals_in, lens;
         if ((rc = keys_in.reserve(n, st, false)) || (rc = keys_out.reserve(n, st, false)) ||
             (rc = vals_in.reserve(n, st, false)) || (rc = lens.reserve(n + 1, st, false))) return rc;
+        SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
-                           eq->arena.p, keys_in.p, vals_in.p);
+                           eq->arena.p, keys_in.p, vals_in.p, eq->d_ctr + 3);
         SF_CHECK_LAUNCH();
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));                       // (~15 us; each radix pass it saves costs ~35)
+        int key_bits = kSortHashBits + 1;
+        while (key_bits < 64 && (eq->h_ctr[3] >> (key_bits - kSortHashBits)) != 0) ++key_bits;
         // (no host wait inside the sort and the scan: everything they touch lives until the synchronisation below)
-        if ((rc = sort_pairs_u64_u32(keys_in.p, keys_out.p, vals_in.p, eq->order.p, n, st, 64, false))) return rc;
+        if ((rc = sort_pairs_u64_u32(keys_in.p, keys_out.p, vals_in.p, eq->order.p, n, st, key_bits, false))) return rc;
         hipLaunchKernelGGL(k_tie_fix, dim3(grid_for(n)), dim3(kBlock), 0, st, n, keys_out.p, eq->order.p, eq->cls_hash.p,
                            eq->cls_off.p, eq->cls_len.p, eq->arena.p);
         SF_CHECK_LAUNCH();
@@ -1055,10 +1082,15 @@ int sfgpu_eq_export_device(sfgpu_eq* eq, uint32_t* d_rowptr, uint32_t* d_ids, ui
     uint64_t n = eq->n_classes;
     if (n == 0) { SF_HIP(hipMemsetAsync(d_rowptr, 0, 4, eq->stream)); return SFGPU_OK; }
     SF_REQUIRE(d_ids && d_counts, SFGPU_ERR_INVALID, "sfgpu_eq_export: null pointer");
-    hipLaunchKernelGGL(k_export, dim3(grid_for(n + 1)), dim3(kBlock), 0, eq->stream, n, eq->order.p, eq->rowptr64.p,
-                       eq->table.p, eq->cls_slot.p, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->arena.p,
-                       d_rowptr, d_ids, d_counts, d_hashes);
+    hipLaunchKernelGGL(k_export_classes, dim3(grid_for(n + 1)), dim3(kBlock), 0, eq->stream, n, eq->order.p, eq->rowptr64.p,
+                       eq->table.p, eq->cls_slot.p, eq->cls_hash.p, d_rowptr, d_counts, d_hashes);
     SF_CHECK_LAUNCH();
+    if (eq->nnz) {
+        const uint64_t waves = (eq->nnz + kExportPerWave - 1) / kExportPerWave;
+        hipLaunchKernelGGL(k_export_ids, dim3(grid_for(waves * kWave)), dim3(kBlock), 0, eq->stream, n, eq->nnz, eq->order.p, eq->rowptr64.p,
+                           eq->cls_off.p, eq->arena.p, d_ids);
+        SF_CHECK_LAUNCH();
+    }
     return SFGPU_OK;
 }
 

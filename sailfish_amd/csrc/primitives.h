@@ -13,10 +13,6 @@ namespace sfgpu {
 int sort_pairs_u64_u32(const uint64_t* d_keys_in, uint64_t* d_keys_out, const uint32_t* d_vals_in,
                        uint32_t* d_vals_out, uint64_t n, hipStream_t s, int end_bit = 64, bool sync = true);
 
-// the same for (key u32, value u32) pairs
-int sort_pairs_u32_u32(const uint32_t* d_keys_in, uint32_t* d_keys_out, const uint32_t* d_vals_in,
-                       uint32_t* d_vals_out, uint64_t n, hipStream_t s, int end_bit = 32, bool sync = true);
-
 // out[i] = sum_{j<i} in[j] for i in [0, n]; out has n+1 entries (out[n] = total).  sync as above.
 int exclusive_scan_u32(const uint32_t* d_in, uint64_t* d_out, uint64_t n, hipStream_t s, bool sync = true);
 
