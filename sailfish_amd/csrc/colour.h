@@ -63,4 +63,31 @@ inline uint32_t colour_wide_classes(const std::vector<uint32_t>& wl, const std::
     return n_colours;
 }
 
+// Connected components of the wide classes (two classes are connected when they share a transcript, directly or through
+// other wide classes): comp_of[i] = component of wl[i], numbered in order of first appearance.  Classes of different
+// components commute, so components can be visited concurrently whatever happens inside them.
+inline uint32_t components_of_wide_classes(const std::vector<uint32_t>& wl, const std::vector<uint32_t>& rowptr, const std::vector<uint32_t>& ids,
+                                           uint64_t M, std::vector<uint32_t>& comp_of) {
+    std::vector<uint32_t> parent(M);
+    for (uint64_t t = 0; t < M; ++t) parent[t] = (uint32_t)t;
+    auto find = [&](uint32_t t) { while (parent[t] != t) { parent[t] = parent[parent[t]]; t = parent[t]; } return t; };
+    for (size_t i = 0; i < wl.size(); ++i) {
+        const uint32_t b = rowptr[wl[i]], e = rowptr[wl[i] + 1];
+        if (e == b) continue;
+        const uint32_t r0 = find(ids[b]);
+        for (uint32_t j = b + 1; j < e; ++j) { const uint32_t r = find(ids[j]); if (r != r0) parent[r] = r0; }
+    }
+    std::vector<uint32_t> label(M, 0xFFFFFFFFu);
+    comp_of.resize(wl.size());
+    uint32_t n = 0;
+    for (size_t i = 0; i < wl.size(); ++i) {
+        const uint32_t b = rowptr[wl[i]], e = rowptr[wl[i] + 1];
+        if (e == b) { comp_of[i] = n++; continue; }
+        const uint32_t r = find(ids[b]);
+        if (label[r] == 0xFFFFFFFFu) label[r] = n++;
+        comp_of[i] = label[r];
+    }
+    return n;
+}
+
 }  // namespace sfgpu

@@ -39,7 +39,16 @@ std::unordered_map<Key, std::vector<void*>, KeyHash> g_pool_free;   // (device, 
 std::unordered_map<void*, Key> g_pool_key;                           // live or cached block -> its key
 std::unordered_map<int, std::vector<hipStream_t>> g_streams;         // device -> idle non-blocking streams
 enum { kDeviceMem = 0, kPinnedMem = 1 };
-size_t round_up_pow2(size_t n) { size_t r = 256; while (r < n) r <<= 1; return r; }
+// size classes: powers of two up to 1 GiB; above that eight steps per octave (a 38 GB block is 40 GB, not 64: mapping a block
+// for the first time costs ~15 ms per GB) -- still few distinct keys, so freed blocks keep finding takers
+size_t round_up_pow2(size_t n) {
+    size_t r = 256;
+    while (r < n && r < ((size_t)1 << 30)) r <<= 1;
+    if (r >= n) return r;
+    while ((r << 1) < n) r <<= 1;                 // r < n <= 2 r
+    const size_t step = r >> 3;
+    return r + (n - r + step - 1) / step * step;
+}
 int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
 struct Pending { void* p; hipEvent_t ev; };

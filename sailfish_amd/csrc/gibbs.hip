@@ -38,6 +38,7 @@
 #include "rng.h"
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,7 @@ constexpr uint32_t kWideSpan = 2048;       // classes spanning more transcripts 
 constexpr uint32_t kMaxPhases = 1024;      // more phases than this: fall back to one sequential scan
 constexpr uint32_t kWideSerial = 64;       // up to this many wide classes are visited one after another by one launch
 constexpr uint32_t kMaxColours = 1u << 16; // more colours than this: visit the wide classes one after another after all
+constexpr uint32_t kThinWidth = 12;        // a component of wide classes with fewer classes per colour than this is visited serially
 constexpr double kGibbsPrior = 1e-8;       // priorAlpha (:215)
 constexpr double kGibbsTiny = 4.9406564584124654e-324;
 
@@ -137,8 +139,10 @@ __device__ __forceinline__ void gibbs_round_class(const GibbsArgs& a, uint64_t c
 }
 
 // one phase: blockIdx.x -> tile (phase + K * x), blockIdx.y -> group of 64 chains
+// (4 wavefronts per SIMD, 128 VGPRs: the compiler's own choice is 142 registers and 3 wavefronts -- the sampler is long chains of
+//  dependent f64 operations, a fourth wavefront to switch to is worth 9 %; at 5 it spills)
 template <bool INIT>
-__global__ void __launch_bounds__(kGibbsBlock)
+__global__ void __launch_bounds__(kGibbsBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_gibbs_phase(GibbsArgs a, uint32_t phase, uint32_t K, uint32_t n_tiles) {
     const uint32_t tile = phase + K * blockIdx.x;
     const uint32_t ch = blockIdx.y * kGibbsBlock + threadIdx.x;
@@ -165,14 +169,29 @@ k_gibbs_wide(GibbsArgs a) {
 
 // one COLOUR of the wide classes (no two classes of a colour share a transcript): blockIdx.x -> kListChunk classes of the
 // list, blockIdx.y -> group of 64 chains
+// `chunk` classes per block: 8 when the colour is large (fewer, longer blocks), down to 1 when it is small -- a colour of 49
+// classes at 8 per block was 7 blocks of 8 visits one after another (~100 us per launch); at 1 per block it is ~20.
 constexpr uint32_t kListChunk = 8;
 template <bool INIT>
 __global__ void __launch_bounds__(kGibbsBlock)
-k_gibbs_list(GibbsArgs a, const uint32_t* __restrict__ list, uint32_t n) {
+k_gibbs_list(GibbsArgs a, const uint32_t* __restrict__ list, uint32_t n, uint32_t chunk) {
     const uint32_t ch = blockIdx.y * kGibbsBlock + threadIdx.x;
     if (ch >= a.n_chains) return;
-    const uint32_t i0 = blockIdx.x * kListChunk, i1 = (i0 + kListChunk < n) ? i0 + kListChunk : n;
+    const uint32_t i0 = blockIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
     for (uint32_t i = i0; i < i1; ++i) {
+        const uint64_t c = list[i];
+        if (INIT) gibbs_init_class(a, c, ch); else gibbs_round_class(a, c, ch);
+    }
+}
+
+// the THIN components of the wide classes (see the plan): blockIdx.x -> component, whose classes are visited one after another,
+// in class order; blockIdx.y -> group of 64 chains
+template <bool INIT>
+__global__ void __launch_bounds__(kGibbsBlock)
+k_gibbs_components(GibbsArgs a, const uint32_t* __restrict__ list, const uint32_t* __restrict__ comp_off) {
+    const uint32_t ch = blockIdx.y * kGibbsBlock + threadIdx.x;
+    if (ch >= a.n_chains) return;
+    for (uint32_t i = comp_off[blockIdx.x]; i < comp_off[blockIdx.x + 1]; ++i) {
         const uint64_t c = list[i];
         if (INIT) gibbs_init_class(a, c, ch); else gibbs_round_class(a, c, ch);
     }
@@ -258,8 +277,18 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     const uint32_t n_tiles = (uint32_t)((C + kGibbsTile - 1) / kGibbsTile);
     uint32_t* count_map = nullptr; int32_t* txp_count = nullptr; double *inv_len = nullptr, *w_mass = nullptr;
     uint8_t* wide = nullptr; uint32_t *tile_lo = nullptr, *tile_hi = nullptr, *wide_list = nullptr; unsigned int* d_nwide = nullptr;
-    int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr;
+    int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr; uint32_t* d_thin_off = nullptr;
     int rc = SFGPU_OK;
+    const bool timing = getenv("SFGPU_TIMING") != nullptr;                 // where a call's time goes (stderr)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t_mark = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        if (atoi(getenv("SFGPU_TIMING")) != 2) (void)hipStreamSynchronize(st);       // (2: host-side times only)
+        fprintf(stderr, "gibbs timing: %-12s %9.2f ms\n", what, ms_since(t_mark));
+        t_mark = now();
+    };
 #define G_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); rc = SFGPU_ERR_HIP; goto done; } } while (0)
     G_TRY(pool_malloc(&count_map, ((uint64_t)L * n_chains + 1) * 4));
     G_TRY(pool_malloc(&txp_count, (uint64_t)M * n_chains * 4));
@@ -270,12 +299,15 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     if (cb) G_TRY(pinned_malloc(&h_tmp, (uint64_t)n_chains * M * 4));
     G_TRY(hipMemsetAsync(txp_count, 0, (uint64_t)M * n_chains * 4, st));
     G_TRY(hipMemsetAsync(d_nwide, 0, 4, st));
+    lap("allocate");
     hipLaunchKernelGGL(k_gibbs_weights, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, prob->d_len, d_mass,
                        (double)prob->num_mapped, inv_len, w_mass);
     {
         // ---- plan: bands, wide classes, number of phases
         uint32_t K = 1; unsigned int n_wide = 0;
         std::vector<uint32_t> colour_off;                  // wide classes by colour (empty: visited one after another)
+        std::vector<uint32_t> thin_off, thin_list;         // ... and those of thin components, by component
+        unsigned int n_rest = 0;                           // wide classes outside the thin components: wide_list[0, n_rest)
         if (n_tiles) {
             hipLaunchKernelGGL(k_gibbs_plan, dim3((n_tiles + 255) / 256), dim3(256), 0, st, C, n_tiles, prob->d_rowptr, prob->d_ids,
                                wide, tile_lo, tile_hi, wide_list, d_nwide);
@@ -287,6 +319,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
             G_TRY(hipStreamSynchronize(st));
             K = gibbs_phase_count(lo, hi);
             if (K > kMaxPhases) K = n_tiles;             // no locality to exploit: one tile per launch == a sequential scan
+            n_rest = n_wide;
             if (n_wide > 1) {
                 // the plan appends wide classes with an atomic cursor: put them into class order, so that the wide
                 // phase visits them in the same order on every run (they may share transcripts -> order matters
@@ -302,24 +335,59 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                     G_TRY(hipMemcpyAsync(h_rowptr.data(), prob->d_rowptr, (C + 1) * 4, hipMemcpyDeviceToHost, st));
                     G_TRY(hipMemcpyAsync(h_ids.data(), prob->d_ids, (size_t)L * 4, hipMemcpyDeviceToHost, st));
                     G_TRY(hipStreamSynchronize(st));
-                    const uint32_t n_colours = colour_wide_classes(wl, h_rowptr, h_ids, M, colour_of);
+                    uint32_t n_colours = colour_wide_classes(wl, h_rowptr, h_ids, M, colour_of);
+                    // THIN components first.  A colour is a launch (~100 us of latency however few classes it holds), and classes that
+                    // all share one transcript need a colour each: 14.7 k launches per round when one far transcript is shared by
+                    // the classes of 4096 ids.  But such a chain is only sequential INSIDE its connected component; a component whose
+                    // colours hold < kThinWidth classes on average is cheaper as one wavefront (per 64 chains) walking its classes in
+                    // order (~8 us per class), all thin components side by side in one launch.  What is left is coloured again.
+                    std::vector<uint32_t> comp_of;
+                    const uint32_t n_comp = components_of_wide_classes(wl, h_rowptr, h_ids, M, comp_of);
+                    std::vector<uint32_t> comp_n(n_comp, 0), comp_colours(n_comp, 0);
+                    for (size_t i = 0; i < wl.size(); ++i) { ++comp_n[comp_of[i]]; comp_colours[comp_of[i]] = std::max(comp_colours[comp_of[i]], colour_of[i] + 1); }
+                    std::vector<uint32_t> thin_id(n_comp, 0xFFFFFFFFu);
+                    uint32_t n_thin = 0;
+                    for (uint32_t c = 0; c < n_comp; ++c)
+                        if ((uint64_t)comp_n[c] < (uint64_t)kThinWidth * comp_colours[c]) thin_id[c] = n_thin++;
+                    std::vector<uint32_t> rest;
+                    if (n_thin) {
+                        thin_off.assign(n_thin + 1, 0);
+                        for (size_t i = 0; i < wl.size(); ++i) if (thin_id[comp_of[i]] != 0xFFFFFFFFu) ++thin_off[thin_id[comp_of[i]] + 1];
+                        for (uint32_t c = 0; c < n_thin; ++c) thin_off[c + 1] += thin_off[c];
+                        thin_list.resize(thin_off[n_thin]);
+                        std::vector<uint32_t> cur(thin_off.begin(), thin_off.end() - 1);
+                        for (size_t i = 0; i < wl.size(); ++i) {
+                            const uint32_t t = thin_id[comp_of[i]];
+                            if (t != 0xFFFFFFFFu) thin_list[cur[t]++] = wl[i]; else rest.push_back(wl[i]);      // class order inside a component
+                        }
+                        wl.swap(rest);
+                        colour_of.clear();
+                        n_colours = wl.empty() ? 0 : colour_wide_classes(wl, h_rowptr, h_ids, M, colour_of);
+                    }
                     if (n_colours <= kMaxColours) {
                         colour_off.assign(n_colours + 1, 0);
                         for (uint32_t c : colour_of) ++colour_off[c + 1];
                         for (uint32_t c = 0; c < n_colours; ++c) colour_off[c + 1] += colour_off[c];
-                        std::vector<uint32_t> by_colour(n_wide), cur(colour_off.begin(), colour_off.end() - 1);
+                        std::vector<uint32_t> by_colour(wl.size()), cur(colour_off.begin(), colour_off.end() - 1);
                         for (size_t i = 0; i < wl.size(); ++i) by_colour[cur[colour_of[i]]++] = wl[i];       // class order inside a colour
                         wl.swap(by_colour);
                     }
+                    n_rest = (unsigned int)wl.size();
+                    wl.insert(wl.end(), thin_list.begin(), thin_list.end());       // device list: [coloured (or serial) rest | thin components]
                 }
                 G_TRY(hipMemcpyAsync(wide_list, wl.data(), (size_t)n_wide * 4, hipMemcpyHostToDevice, st));
+                if (!thin_off.empty()) {
+                    G_TRY(pool_malloc(&d_thin_off, thin_off.size() * 4));
+                    G_TRY(hipMemcpyAsync(d_thin_off, thin_off.data(), thin_off.size() * 4, hipMemcpyHostToDevice, st));
+                }
                 G_TRY(hipStreamSynchronize(st));
             }
         }
-        log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes%s", n_chains, n_tiles, K, n_wide,
-                colour_off.empty() ? "" : (" in " + std::to_string(colour_off.size() - 1) + " colours").c_str());
+        log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes%s%s", n_chains, n_tiles, K, n_wide,
+                colour_off.empty() ? "" : (": " + std::to_string(n_rest) + " in " + std::to_string(colour_off.size() - 1) + " colours").c_str(),
+                thin_off.empty() ? "" : (", " + std::to_string(thin_list.size()) + " in " + std::to_string(thin_off.size() - 1) + " thin components").c_str());
         GibbsArgs a{n_chains, C, prob->d_rowptr, prob->d_ids, prob->d_counts, inv_len, w_mass, count_map, txp_count,
-                    wide, wide_list, n_wide, seed, 0};
+                    wide, wide_list, n_rest, seed, 0};
         const unsigned groups = (n_chains + kGibbsBlock - 1) / kGibbsBlock;
         auto sweep = [&](bool init) -> hipError_t {
             for (uint32_t p = 0; p < K && p < n_tiles; ++p) {
@@ -327,20 +395,29 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                 if (init) hipLaunchKernelGGL(k_gibbs_phase<true>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
                 else hipLaunchKernelGGL(k_gibbs_phase<false>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
             }
-            if (n_wide && colour_off.empty()) {
+            if (!thin_off.empty()) {
+                dim3 g((unsigned)(thin_off.size() - 1), groups);
+                if (init) hipLaunchKernelGGL(k_gibbs_components<true>, g, dim3(kGibbsBlock), 0, st, a, wide_list + n_rest, d_thin_off);
+                else hipLaunchKernelGGL(k_gibbs_components<false>, g, dim3(kGibbsBlock), 0, st, a, wide_list + n_rest, d_thin_off);
+            }
+            if (n_rest && colour_off.empty()) {
                 if (init) hipLaunchKernelGGL(k_gibbs_wide<true>, dim3(groups), dim3(kGibbsBlock), 0, st, a);
                 else hipLaunchKernelGGL(k_gibbs_wide<false>, dim3(groups), dim3(kGibbsBlock), 0, st, a);
-            } else if (n_wide) {
+            } else if (n_rest) {
                 for (size_t c = 0; c + 1 < colour_off.size(); ++c) {
                     const uint32_t n = colour_off[c + 1] - colour_off[c];
-                    dim3 g((n + kListChunk - 1) / kListChunk, groups);
-                    if (init) hipLaunchKernelGGL(k_gibbs_list<true>, g, dim3(kGibbsBlock), 0, st, a, wide_list + colour_off[c], n);
-                    else hipLaunchKernelGGL(k_gibbs_list<false>, g, dim3(kGibbsBlock), 0, st, a, wide_list + colour_off[c], n);
+                    uint32_t chunk = (uint32_t)(((uint64_t)n * groups + 4095) / 4096);        // ~4 k wavefronts fill the chip
+                    chunk = chunk < 1u ? 1u : (chunk > kListChunk ? kListChunk : chunk);
+                    dim3 g((n + chunk - 1) / chunk, groups);
+                    if (init) hipLaunchKernelGGL(k_gibbs_list<true>, g, dim3(kGibbsBlock), 0, st, a, wide_list + colour_off[c], n, chunk);
+                    else hipLaunchKernelGGL(k_gibbs_list<false>, g, dim3(kGibbsBlock), 0, st, a, wide_list + colour_off[c], n, chunk);
                 }
             }
             return hipGetLastError();
         };
+        lap("plan");
         G_TRY(sweep(true));                                                           // initCountMap_
+        lap("init");
         uint32_t done = 0;
         while (done < n_samples) {
             G_TRY(sweep(false));                                                      // one sampleRound_ per sample
@@ -359,15 +436,20 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
             done += n_emit; ++a.round;
         }
         G_TRY(hipStreamSynchronize(st));
+        lap("rounds");
     }
 #undef G_TRY
 done:
     (void)hipStreamSynchronize(st);
+    lap("drain");
     for (void* p : {(void*)count_map, (void*)txp_count, (void*)inv_len, (void*)w_mass, (void*)wide, (void*)wide_list,
-                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp})
+                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp, (void*)d_thin_off})
         if (p) pool_free(p);
     if (h_tmp) pinned_free(h_tmp);
-    pool_trim();          // the chain state is large (4 * nnz * n_chains bytes): do not keep it cached
+    // The chain state (4 * nnz * n_chains bytes, 38 GB for cfg3's classes and 1024 chains) stays in the allocator's cache: giving
+    // it back to the driver and mapping it again cost the next call 1 - 4 s (measured), ten times what the sampling itself takes.
+    // sfgpu_pool_trim() releases it (the allocator also does when an allocation fails).
+    lap("release");
     return rc;
 }
 

@@ -62,6 +62,20 @@ struct Philox {
     }
 };
 
+// The BINV walk below, f_x = f_(x-1) * (a / x - s) against u_x = u_(x-1) - f_(x-1), costs an f64 division per step.  Both
+// sides scaled by x! need none:  F_x = x! f_x = F_(x-1) * (a - s x),  U_x = x! u_x = x * (U_(x-1) - F_(x-1)),  and
+// u_x > f_x  <=>  U_x > F_x.  127! is the last factorial a double holds comfortably: from step kBinvSwitch on the walk
+// continues unscaled.  BINV is used up to a mean of kBinvMaxMean = 60 (the customary 30 dates from scalar machines: in a
+// wavefront of 64 chains BTPE costs every lane the slowest lane's rejection path, the walk costs mean + ~3 sd cheap steps;
+// measured on the Gibbs sampler over cfg3's classes: 30 -> 60 is -14 %, beyond 60 nothing).
+constexpr double kBinvMaxMean = 60.0;
+#if !defined(SFGPU_BINV_SWITCH)
+#define SFGPU_BINV_SWITCH 128          // (tests/test_sampling_cpu.py builds the header with 8 as well, to walk through the switch)
+#endif
+constexpr uint32_t kBinvSwitch = SFGPU_BINV_SWITCH;
+constexpr double binv_unscale(uint32_t n) { double f = 1.0; for (uint32_t i = 2; i <= n; ++i) f *= (double)i; return 1.0 / f; }
+constexpr double kBinvUnscale = binv_unscale(kBinvSwitch - 1u);      // ~ 1 / 127! = 3.3e-214 (U and F get the same factor: its last bits do not matter)
+
 // Binomial(n, p), exact: inversion (BINV) for small means, BTPE (Kachitvichyanukul & Schmeiser, 1988)
 // otherwise.  n < 2^32.
 SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
@@ -72,18 +86,23 @@ SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
     const double q = 1.0 - r;
     const double dn = (double)n;
     double y;
-    if (dn * r < 30.0) {
+    if (dn * r < kBinvMaxMean) {
         // ---- BINV: walk the CDF from 0
         const double s = r / q, a = (dn + 1.0) * s;
-        const double f0 = exp(dn * log1p(-r));   // q^n >= e^-30 / ... : no underflow
+        const double f0 = exp(dn * log1p(-r));   // q^n >= e^(-2 ln 2 * 60): no underflow
         for (;;) {
-            double f = f0, u = g.uniform();
+            double F = f0, U = g.uniform();                  // x! f_x and x! u_x
             uint32_t x = 0;
             bool ok = true;
-            while (u > f) {
-                u -= f; ++x;
-                if (x > n) { ok = false; break; }      // rounding ran off the end: redraw
-                f *= (a / (double)x - s);
+            while (U > F && x < kBinvSwitch - 1u) {           // scaled by x!: no division
+                ++x;
+                if (x > n) { ok = false; break; }              // rounding ran off the end: redraw
+                const double dx = (double)x;
+                U = dx * (U - F); F *= (a - s * dx);
+            }
+            if (ok && x == kBinvSwitch - 1u && U > F) {        // (probability < 1e-40 for the means BINV is used for)
+                U *= kBinvUnscale; F *= kBinvUnscale;
+                while (U > F) { U -= F; ++x; if (x > n) { ok = false; break; } F *= (a / (double)x - s); }
             }
             if (ok) { y = (double)x; break; }
         }
@@ -122,7 +141,17 @@ SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
             if (k <= 20.0 || k >= nrq / 2.0 - 1.0) {
                 // explicit evaluation of f(y)/f(m) by the recurrence
                 const double s = r / q, a = s * (dn + 1.0);
-                double F = 1.0;
+                if (k <= 20.0) {
+                    // f(y)/f(m) = prod (a - s i) / prod i over the <= 20 steps between y and m: ONE comparison of products instead
+                    // of a division per step (every factor is <= n + 1 < 2^32.1, so 20 of them stay below 1e193).  In a
+                    // wavefront of 64 chains some lane takes this path in nearly every trial: -18 % on the Gibbs sampler.
+                    double num = 1.0, den = 1.0;
+                    const double i0 = (m < y ? m : y) + 1.0, i1 = m < y ? y : m;
+                    for (double i = i0; i <= i1; i += 1.0) { num *= (a - s * i); den *= i; }
+                    if (m < y ? (v * den > num) : (v * num > den)) continue;
+                    break;
+                }
+                double F = 1.0;                      // far from the mode (only when n r q is small): the factors decay, F may underflow to 0
                 if (m < y) { for (double i = m + 1.0; i <= y; i += 1.0) F *= (a / i - s); }
                 else if (m > y) { for (double i = y + 1.0; i <= m; i += 1.0) F /= (a / i - s); }
                 if (v > F) continue;

@@ -46,5 +46,6 @@ class CollapsedGibbsSampler:
         rc, out = gibbs_sample(length, txps.mass, vec.rowptr, vec.ids, vec.counts, readExp.numMappedFragments(),
                                numSamples, n_chains=n_chains, seed=seed, callback=writeSample)
         self.last_samples = out
+        _lib.lib().sfgpu_pool_trim()        # the chain state (4 * nnz * chains bytes) is not needed again: sample() ends a quantification
         _lib.check(rc)
         return True

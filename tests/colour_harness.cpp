@@ -7,3 +7,10 @@ extern "C" uint32_t colour_classes(const uint32_t* list, uint64_t n, const uint3
     for (uint64_t i = 0; i < n; ++i) colour_out[i] = col[i];
     return k;
 }
+extern "C" uint32_t class_components(const uint32_t* list, uint64_t n, const uint32_t* rowptr, uint64_t C, const uint32_t* ids, uint64_t L,
+                                     uint64_t M, uint32_t* comp_out) {
+    std::vector<uint32_t> wl(list, list + n), rp(rowptr, rowptr + C + 1), id(ids, ids + L), comp;
+    const uint32_t k = sfgpu::components_of_wide_classes(wl, rp, id, M, comp);
+    for (uint64_t i = 0; i < n; ++i) comp_out[i] = comp[i];
+    return k;
+}

@@ -162,12 +162,14 @@ def test_cfg5_thousand_draws_over_cfg3_classes(gpu):
         p.close()
 
 
-@pytest.mark.parametrize("n_wide_labels", [3, 150])
+@pytest.mark.parametrize("n_wide_labels", [3, 150, 600])
 def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labels):
     """per-transcript mean and spread of the phase-parallel sampler vs the oracle's sequential sampleRound_
     (src/CollapsedGibbsSampler.cpp:113-184) on a problem with thousands of classes, a multi-phase round and wide classes.
     3 wide labels: visited one after another by one launch; 150 wide labels in groups of 30 that share a far transcript (the
-    pseudogene every read of a gene also hits) and overlap otherwise: coloured on the host, one launch per colour."""
+    pseudogene every read of a gene also hits) and overlap otherwise: five THIN components (30 classes need 30 colours), each
+    walked by one wavefront per 64 chains; 600 wide labels linked into one long chain (label i shares a transcript with label
+    i + 1, and a far one with two others): one component, a few colours of ~200 classes, one launch per colour."""
     import sailfish_amd as sf
     from sailfish_amd import _lib, synth
     M, P, R = 3000, 6000, 120_000
@@ -177,12 +179,15 @@ def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labe
     if n_wide_labels == 3:
         wide = [np.sort(rng.choice(M, 6, replace=False)).astype(np.int32) for _ in range(3)]
         reps = 400
-    else:
+    elif n_wide_labels == 150:
         wide = []
         for i in range(n_wide_labels):
             loc = rng.choice(400, 5, replace=False) + 13 * (i // 30)                 # neighbours overlap locally, too
             wide.append(np.unique(np.concatenate([loc, [M - 1 - i // 30]])).astype(np.int32))
         reps = 40
+    else:
+        wide = [np.array([i, i + 1, 2800 + i % 190], np.int32) for i in range(n_wide_labels)]       # (span > 2048: wide)
+        reps = 20
     extra_ids = np.concatenate([np.tile(w, reps) for w in wide])
     extra_len = np.concatenate([np.full(reps, len(w)) for w in wide])
     extra_off = int(off[-1]) + np.cumsum(extra_len)
@@ -207,9 +212,17 @@ def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labe
     plan = [m for m in logs if "gibbs:" in m][-1]
     K = int(plan.split(" tiles in ")[1].split()[0]); n_wide = int(plan.split(" phases, ")[1].split()[0])
     assert K >= 2 and n_wide >= 3, plan
+    # "... W wide classes: A in B colours, C in D thin components"
     assert ("colours" in plan) == (n_wide_labels > 64), plan
     if n_wide_labels > 64:
-        assert int(plan.split(" in ")[-1].split()[0]) >= 30, plan      # a far transcript shared by 30 classes: >= 30 colours
+        tail = plan.split(": ")[-1]
+        n_col, n_colours = int(tail.split(" in ")[0]), int(tail.split(" in ")[1].split()[0])
+        n_thin = int(tail.split(", ")[1].split(" in ")[0]) if "thin" in tail else 0
+        assert n_col + n_thin == n_wide, plan
+        if n_wide_labels == 150:
+            assert n_thin >= 150, plan                                  # 30 classes that need 30 colours: walked, not coloured
+        else:
+            assert n_col >= 600 and 2 <= n_colours <= 12, plan          # a path with a few far links: a handful of colours
     # Chains are sticky: with priorAlpha = 1e-8 a transcript whose count reaches 0 practically never gets a read back, so
     # chains settle into different supports and ONE sequential chain is not comparable with an average over chains.
     # Both samplers are therefore run as many independent chains from the same start (initCountMap_ from the EM's mass)

@@ -12,15 +12,25 @@ from scipy import stats
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def H(tmp_path_factory):
+def _harness(tmp_path_factory, *defs):
     so = tmp_path_factory.mktemp("h") / "libharness.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), os.path.join(HERE, "sampling_harness.cpp")])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", *defs, "-o", str(so), os.path.join(HERE, "sampling_harness.cpp")])
     L = C.CDLL(str(so))
     L.draw_binomial.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p]
     L.draw_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
     L.philox_block.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
     return L
+
+
+@pytest.fixture(scope="module")
+def H(tmp_path_factory):
+    return _harness(tmp_path_factory)
+
+
+@pytest.fixture(scope="module")
+def H8(tmp_path_factory):
+    """the same header with the BINV walk leaving its factorial-scaled form after 7 steps instead of 127"""
+    return _harness(tmp_path_factory, "-DSFGPU_BINV_SWITCH=8")
 
 
 def test_philox_known_answers(H):
@@ -43,9 +53,24 @@ def test_uniform_open_interval_and_flat(H):
     assert not np.array_equal(u[:1000], v)              # streams differ
 
 
+def test_binv_switch_point_is_invisible(H, H8):
+    """both forms of the walk (scaled by x!, and unscaled behind the switch) follow the same recurrence: the same seed gives
+    the same draws wherever the switch lies -- up to the last bits of the running products, which move a draw that falls
+    on a boundary of the CDF by one (rare)"""
+    N = 20000
+    for n, p in ((100, 0.2), (1000, 0.05), (59, 0.5), (130, 0.45), (100000, 0.0004)):
+        a = np.zeros(N, np.uint32); b = np.zeros(N, np.uint32)
+        H.draw_binomial(99, n, p, N, a.ctypes.data); H8.draw_binomial(99, n, p, N, b.ctypes.data)
+        assert b.max() > 8                                      # the walk did pass the switch
+        d = a.astype(np.int64) - b.astype(np.int64)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() < 1e-3, (n, p, (d != 0).mean())
+
+
 @pytest.mark.parametrize("n,p", [(1, 0.3), (10, 0.5), (100, 0.01), (1000, 0.02), (50, 0.9), (200, 0.16), (1000, 0.5),
                                  (100000, 0.001), (100000, 0.3), (3000000, 0.7), (4000000000, 1e-9), (4000000000, 0.25),
-                                 (59, 0.5), (61, 0.5), (400, 0.075)])
+                                 (59, 0.5), (61, 0.5), (400, 0.075),
+                                 # around the BINV / BTPE boundary (mean 60) and BTPE's explicit-product path
+                                 (119, 0.5), (121, 0.5), (1000, 0.055), (600000, 0.0001), (130, 0.45), (250, 0.45), (700, 0.1)])
 def test_binomial_matches_scipy(H, n, p):
     N = 60000
     x = np.zeros(N, np.uint32)
@@ -152,3 +177,45 @@ def test_gibbs_colouring_of_classes_that_share_transcripts(tmp_path):
     assert k <= deg + 1
     col2 = np.zeros_like(col)
     assert lib.colour_classes(ptr(wl), len(wl), ptr(rowptr), len(labels), ptr(ids), len(ids), M, ptr(col2)) == k and np.array_equal(col, col2)
+
+
+def test_gibbs_components_of_classes_that_share_transcripts(tmp_path):
+    """colour.h, components_of_wide_classes: classes that share a transcript -- directly or through other listed classes -- get
+    one component number, classes of different components share nothing; numbered in order of first appearance.  Checked
+    against scipy's connected components of the class/transcript bipartite graph."""
+    import ctypes, subprocess
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    so = tmp_path / "colour_harness.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), os.path.join(os.path.dirname(__file__), "colour_harness.cpp")])
+    lib = ctypes.CDLL(str(so))
+    lib.class_components.restype = ctypes.c_uint32
+    P = ctypes.c_void_p
+    lib.class_components.argtypes = [P, ctypes.c_uint64, P, ctypes.c_uint64, P, ctypes.c_uint64, ctypes.c_uint64, P]
+    rng = np.random.default_rng(5)
+    M = 4000
+    labels = []
+    for c in range(3000):
+        base = int(rng.integers(0, 3500))
+        lab = set((base + np.arange(int(rng.integers(1, 4)))).tolist())
+        if c % 4 == 0: lab.add(3600 + (base // 500))           # a far transcript per neighbourhood of 500 ids
+        labels.append(np.array(sorted(lab), np.uint32))
+    rowptr = np.zeros(len(labels) + 1, np.uint32); rowptr[1:] = np.cumsum([len(l) for l in labels])
+    ids = np.concatenate(labels)
+    wl = np.sort(rng.choice(len(labels), 2000, replace=False)).astype(np.uint32)
+    comp = np.zeros(len(wl), np.uint32)
+    ptr = lambda a: a.ctypes.data_as(P)
+    k = lib.class_components(ptr(wl), len(wl), ptr(rowptr), len(labels), ptr(ids), len(ids), M, ptr(comp))
+    rows = np.concatenate([np.full(len(labels[c]), i) for i, c in enumerate(wl)])
+    cols = np.concatenate([labels[c] for c in wl]).astype(np.int64) + len(wl)
+    n = len(wl) + M
+    g = coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    _, ref = connected_components(g, directed=False)
+    ref = ref[:len(wl)]
+    assert k == len(np.unique(ref)) == int(comp.max()) + 1 and 1 < k < len(wl)
+    # the same partition ...
+    pairs = set(zip(comp.tolist(), ref.tolist()))
+    assert len(pairs) == k
+    # ... numbered in order of first appearance
+    first = [int(np.argmax(comp == c)) for c in range(k)]
+    assert first == sorted(first)
