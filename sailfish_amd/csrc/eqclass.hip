@@ -254,15 +254,18 @@ __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table
 constexpr int kSortHashBits = 14;
 __global__ void k_sort_keys(uint64_t n, const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
                             const uint32_t* __restrict__ arena, uint64_t* keys, uint32_t* vals, unsigned long long* max_first) {
-    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t first = 0;
-    if (c < n) {
-        first = arena[cls_off[c]];
+    // grid-stride over a capped grid: at most one atomic per wavefront of a few thousand blocks, not one per 64 classes (25 k atomics
+    // on one address took 250 us)
+    uint32_t mx = 0;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t first = arena[cls_off[c]];
         keys[c] = ((uint64_t)first << kSortHashBits) | (cls_hash[c] >> (64 - kSortHashBits));
         vals[c] = (uint32_t)c;
+        mx = first > mx ? first : mx;
     }
-    for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t v = __shfl_down(first, o, kWave); first = v > first ? v : first; }
-    if ((threadIdx.x & (kWave - 1)) == 0 && first) atomicMax(max_first, (unsigned long long)first);
+    for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t v = __shfl_down(mx, o, kWave); mx = v > mx ? v : mx; }
+    if ((threadIdx.x & (kWave - 1)) == 0 && (unsigned long long)mx > __hip_atomic_load(max_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(max_first, (unsigned long long)mx);       // (looks first: the running maximum is soon above most wavefronts')
 }
 
 __device__ bool class_less(uint32_t a, uint32_t b, const uint64_t* cls_hash, const uint64_t* cls_off,
@@ -1039,7 +1042,7 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
         if ((rc = keys_in.reserve(n, st, false)) || (rc = keys_out.reserve(n, st, false)) ||
             (rc = vals_in.reserve(n, st, false)) || (rc = lens.reserve(n + 1, st, false))) return rc;
         SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
+        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n) < 4096 ? grid_for(n) : 4096), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
                            eq->arena.p, keys_in.p, vals_in.p, eq->d_ctr + 3);
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));

@@ -8,7 +8,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${TAG}prof
 rm -rf $O; mkdir -p $O
 cd /tmp
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-pinned"
+# (the sampling legs run concurrent EM lanes and a second of Gibbs kernels: they get a kernel-stats pass of their own below, so that
+#  the averages of the step's kernels are those of the timed region)
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-pinned --no-sampling"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/bench_under_rocprof.json 2> $O/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMD > $O/fetch.out 2> $O/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMD > $O/write.out 2> $O/write.err
@@ -46,6 +48,8 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1]["TA_TA_BUSY_sum"]):
     c = max(n[k], 1)
     print("%-24s %6d %16.0f %16.0f %16.0f %16.0f" % (k[:24], n[k], v["TA_TA_BUSY_sum"] / c, v["TCP_TCC_READ_REQ_sum"] / c, v["TCP_TCC_WRITE_REQ_sum"] / c, v["GRBM_GUI_ACTIVE"] / c))
 PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sampling -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-pinned --no-compare-em-modes > $O/sampling.out 2> $O/sampling.err
+find $O/sampling -name '*kernel_trace.csv' -delete
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-600
