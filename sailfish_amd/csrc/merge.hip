@@ -152,7 +152,7 @@ k_union_ties(uint64_t n, uint32_t n_parts, PartTables t, const uint64_t* __restr
 }
 // rare: runs of equal (first id, hash >> 32) keys are put into full-hash order by the thread at the head of the run
 __global__ void __launch_bounds__(kMergeBlock)
-k_union_tie_fix(uint64_t n, uint32_t n_parts, PartTables t, const uint64_t* __restrict__ sorted_keys, uint32_t* order) {
+k_union_tie_fix(uint64_t n, uint32_t n_parts, PartTables t, const uint64_t* __restrict__ sorted_keys, uint32_t* order, unsigned int* flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || (i > 0 && sorted_keys[i - 1] == sorted_keys[i])) return;
     uint64_t e = i + 1;
@@ -164,6 +164,9 @@ k_union_tie_fix(uint64_t n, uint32_t n_parts, PartTables t, const uint64_t* __re
         while (b > i && hv < hash_of(order[b - 1])) { order[b] = order[b - 1]; --b; }
         order[b] = v;
     }
+    // two members of a run of three or more may share their FULL hash without having been neighbours before the run was put
+    // into order (k_union_ties only saw sorted-adjacent pairs): they are neighbours now
+    for (uint64_t a = i + 1; a < e; ++a) if (hash_of(order[a]) == hash_of(order[a - 1])) atomicOr(flag, 1u);
 }
 __global__ void __launch_bounds__(kMergeBlock)
 k_union_gather(uint64_t n, uint32_t n_parts, PartTables t, const uint32_t* __restrict__ order, const uint64_t* __restrict__ src_off,
@@ -331,8 +334,11 @@ int sfgpu_eqvec_merge_disjoint(const void* const* d_blocks, const uint64_t* n_cl
         return SFGPU_OK;
     }
     if (h_flag & 2u) {
-        hipLaunchKernelGGL(k_union_tie_fix, dim3(mgrid(n)), dim3(kMergeBlock), 0, st, n, n_parts, t, keys_out.p, order.p);
+        hipLaunchKernelGGL(k_union_tie_fix, dim3(mgrid(n)), dim3(kMergeBlock), 0, st, n, n_parts, t, keys_out.p, order.p, flag.p);
         SF_CHECK_LAUNCH();
+        SF_HIP(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, st));   // (rare path: the extra round trip does not matter)
+        SF_HIP(hipStreamSynchronize(st));
+        if (h_flag & 1u) { if (same_key_twice) *same_key_twice = 1; return SFGPU_OK; }
     }
     hipLaunchKernelGGL(k_sorted_union_lens, dim3(mgrid(n + 1)), dim3(kMergeBlock), 0, st, n, order.p, lens.p, lens_sorted.p);
     SF_CHECK_LAUNCH();
