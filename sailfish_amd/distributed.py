@@ -328,7 +328,22 @@ class DistributedQuant:
             if isinstance(self.engine, HipEngine) and dist.get_backend(self.group) == "nccl":
                 from . import comm as _comm
                 if _comm.available():
-                    self._ar = _comm.Comm.from_group(self.group, self.engine.device)
+                    # made collectively and checked collectively: a communicator that does not come up, or does not add, on ANY
+                    # rank sends every rank to the torch.distributed call (a split decision would hang the first all-reduce)
+                    comm, ok = None, 1
+                    try:
+                        comm = _comm.Comm.from_group(self.group, self.engine.device)
+                        probe = torch.ones(4, dtype=torch.float64, device=self.engine.device)
+                        comm.all_reduce(probe); self.engine.sync()
+                        ok = int(bool((probe == float(self.world)).all()))
+                    except Exception:
+                        ok = 0
+                    flag = torch.tensor([ok], dtype=torch.int32, device=self.engine.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                    if int(flag.item()) == 1:
+                        self._ar = comm
+                    elif comm is not None:
+                        comm.close()
             if self._ar is None:
                 group = self.group
                 self._ar = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
