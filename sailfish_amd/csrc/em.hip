@@ -1412,6 +1412,10 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             const uint64_t Lnz = rp_end;
             uint32_t *tmp = nullptr, *kv = nullptr, *idx = nullptr, *tin = nullptr, *chunks = nullptr, *pure = nullptr;
             uint64_t *cb = nullptr, *ps = nullptr;
+            struct Scratch {                                  // the plan's temporaries go back to the pool on every way out
+                void** slots[8]; hipStream_t st;
+                ~Scratch() { for (void** q : slots) if (*q) pool_free_on(*q, st); }
+            } scratch{{(void**)&tmp, (void**)&kv, (void**)&idx, (void**)&tin, (void**)&chunks, (void**)&pure, (void**)&cb, (void**)&ps}, em->cur};
             EM_TRY(pool_malloc(&em->chdr, (S / 8 + 1) * 4));
             // G: the number of chunks is only known on the device (cb[nt]); its bound -- every tile ends in a partial chunk --
             // sizes the arrays, and the flags behind the last real chunk stay 0, so no readback holds the plan up
@@ -1439,7 +1443,6 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0);
                 EM_TRY(hipGetLastError());
             }
-            for (void* q : {(void*)tmp, (void*)kv, (void*)idx, (void*)tin, (void*)chunks, (void*)pure, (void*)cb, (void*)ps}) if (q) pool_free_on(q, em->cur);
             if (cr) { em_free(em); return cr; }
         }
         if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }
