@@ -217,6 +217,19 @@ __global__ void k_gibbs_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __res
     tile_lo[tile] = lo; tile_hi[tile] = hi;                  // lo > hi: the tile has no banded class
 }
 
+// the labels of the listed classes as a compact CSR (the host colours the wide classes: it needs their labels, not all 9 M nonzeros)
+__global__ void k_gibbs_list_lens(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ rowptr, uint32_t* lens) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lens[i] = rowptr[list[i] + 1] - rowptr[list[i]];
+}
+__global__ void k_gibbs_list_rows(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                                  const uint32_t* __restrict__ out_off, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = rowptr[list[i]], k = rowptr[list[i] + 1] - b;
+    for (uint32_t j = 0; j < k; ++j) out[out_off[i] + j] = ids[b + j];
+}
+
 __global__ void k_gibbs_weights(uint64_t M, const double* __restrict__ len, const double* __restrict__ mass, double num_mapped,
                                 double* __restrict__ inv_len, double* __restrict__ w_mass) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +291,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     uint32_t* count_map = nullptr; int32_t* txp_count = nullptr; double *inv_len = nullptr, *w_mass = nullptr;
     uint8_t* wide = nullptr; uint32_t *tile_lo = nullptr, *tile_hi = nullptr, *wide_list = nullptr; unsigned int* d_nwide = nullptr;
     int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr; uint32_t* d_thin_off = nullptr;
+    uint32_t *d_lens = nullptr, *d_off = nullptr, *d_rows = nullptr;          // plan scratch: the wide classes' labels
     int rc = SFGPU_OK;
     const bool timing = getenv("SFGPU_TIMING") != nullptr;                 // where a call's time goes (stderr)
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -331,25 +345,40 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                 if (n_wide > kWideSerial) {
                     // many wide classes (every class of a gene also names a far pseudogene / paralog): one after another they
                     // took 108 ms per round for 722 k of them (measured).  Colour them and visit a colour per launch.
-                    std::vector<uint32_t> h_rowptr(C + 1), h_ids(L), colour_of;
-                    G_TRY(hipMemcpyAsync(h_rowptr.data(), prob->d_rowptr, (C + 1) * 4, hipMemcpyDeviceToHost, st));
-                    G_TRY(hipMemcpyAsync(h_ids.data(), prob->d_ids, (size_t)L * 4, hipMemcpyDeviceToHost, st));
-                    G_TRY(hipStreamSynchronize(st));
-                    uint32_t n_colours = colour_wide_classes(wl, h_rowptr, h_ids, M, colour_of);
+                    // the wide classes' labels as a compact CSR on the host (class wl[i] = row i): gathered on the device, two small
+                    // copies instead of the whole class table (43 MB through pageable memory cost 10 ms per call on cfg3)
+                    std::vector<uint32_t> h_rowptr(n_wide + 1, 0), h_ids, colour_of, rows(n_wide);
+                    {
+                        G_TRY(hipMemcpyAsync(wide_list, wl.data(), (size_t)n_wide * 4, hipMemcpyHostToDevice, st));     // (sorted)
+                        G_TRY(pool_malloc(&d_lens, (size_t)n_wide * 4)); G_TRY(pool_malloc(&d_off, (size_t)n_wide * 4));
+                        hipLaunchKernelGGL(k_gibbs_list_lens, dim3((n_wide + 255) / 256), dim3(256), 0, st, n_wide, wide_list, prob->d_rowptr, d_lens);
+                        G_TRY(hipMemcpyAsync(h_rowptr.data() + 1, d_lens, (size_t)n_wide * 4, hipMemcpyDeviceToHost, st));
+                        G_TRY(hipStreamSynchronize(st));
+                        for (uint32_t i = 0; i < n_wide; ++i) h_rowptr[i + 1] += h_rowptr[i];
+                        const uint32_t total = h_rowptr[n_wide];
+                        h_ids.resize(total ? total : 1);
+                        G_TRY(pool_malloc(&d_rows, (size_t)(total ? total : 1) * 4));
+                        G_TRY(hipMemcpyAsync(d_off, h_rowptr.data(), (size_t)n_wide * 4, hipMemcpyHostToDevice, st));
+                        hipLaunchKernelGGL(k_gibbs_list_rows, dim3((n_wide + 255) / 256), dim3(256), 0, st, n_wide, wide_list, prob->d_rowptr, prob->d_ids, d_off, d_rows);
+                        G_TRY(hipMemcpyAsync(h_ids.data(), d_rows, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+                        G_TRY(hipStreamSynchronize(st));
+                    }
+                    for (uint32_t i = 0; i < n_wide; ++i) rows[i] = i;                  // row numbers of the classes still to be coloured
+                    uint32_t n_colours = colour_wide_classes(rows, h_rowptr, h_ids, M, colour_of);
                     // THIN components first.  A colour is a launch (~100 us of latency however few classes it holds), and classes that
                     // all share one transcript need a colour each: 14.7 k launches per round when one far transcript is shared by
                     // the classes of 4096 ids.  But such a chain is only sequential INSIDE its connected component; a component whose
                     // colours hold < kThinWidth classes on average is cheaper as one wavefront (per 64 chains) walking its classes in
                     // order (~8 us per class), all thin components side by side in one launch.  What is left is coloured again.
                     std::vector<uint32_t> comp_of;
-                    const uint32_t n_comp = components_of_wide_classes(wl, h_rowptr, h_ids, M, comp_of);
+                    const uint32_t n_comp = components_of_wide_classes(rows, h_rowptr, h_ids, M, comp_of);
                     std::vector<uint32_t> comp_n(n_comp, 0), comp_colours(n_comp, 0);
                     for (size_t i = 0; i < wl.size(); ++i) { ++comp_n[comp_of[i]]; comp_colours[comp_of[i]] = std::max(comp_colours[comp_of[i]], colour_of[i] + 1); }
                     std::vector<uint32_t> thin_id(n_comp, 0xFFFFFFFFu);
                     uint32_t n_thin = 0;
                     for (uint32_t c = 0; c < n_comp; ++c)
                         if ((uint64_t)comp_n[c] < (uint64_t)kThinWidth * comp_colours[c]) thin_id[c] = n_thin++;
-                    std::vector<uint32_t> rest;
+                    std::vector<uint32_t> rest, rest_rows;
                     if (n_thin) {
                         thin_off.assign(n_thin + 1, 0);
                         for (size_t i = 0; i < wl.size(); ++i) if (thin_id[comp_of[i]] != 0xFFFFFFFFu) ++thin_off[thin_id[comp_of[i]] + 1];
@@ -358,11 +387,11 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                         std::vector<uint32_t> cur(thin_off.begin(), thin_off.end() - 1);
                         for (size_t i = 0; i < wl.size(); ++i) {
                             const uint32_t t = thin_id[comp_of[i]];
-                            if (t != 0xFFFFFFFFu) thin_list[cur[t]++] = wl[i]; else rest.push_back(wl[i]);      // class order inside a component
+                            if (t != 0xFFFFFFFFu) thin_list[cur[t]++] = wl[i]; else { rest.push_back(wl[i]); rest_rows.push_back((uint32_t)i); }   // class order inside a component
                         }
                         wl.swap(rest);
                         colour_of.clear();
-                        n_colours = wl.empty() ? 0 : colour_wide_classes(wl, h_rowptr, h_ids, M, colour_of);
+                        n_colours = wl.empty() ? 0 : colour_wide_classes(rest_rows, h_rowptr, h_ids, M, colour_of);
                     }
                     if (n_colours <= kMaxColours) {
                         colour_off.assign(n_colours + 1, 0);
@@ -443,7 +472,7 @@ done:
     (void)hipStreamSynchronize(st);
     lap("drain");
     for (void* p : {(void*)count_map, (void*)txp_count, (void*)inv_len, (void*)w_mass, (void*)wide, (void*)wide_list,
-                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp, (void*)d_thin_off})
+                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp, (void*)d_thin_off, (void*)d_lens, (void*)d_off, (void*)d_rows})
         if (p) pool_free(p);
     if (h_tmp) pinned_free(h_tmp);
     // The chain state (4 * nnz * n_chains bytes, 38 GB for cfg3's classes and 1024 chains) stays in the allocator's cache: giving
