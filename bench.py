@@ -327,23 +327,46 @@ def main():
         pass
     n_ins = max(int(info["insert_launches"]), 1)
     ins_ms = info["t_insert_ms"] / n_ins
-    roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_iter / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                   unit="GB/s", frac=b_iter / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em, traffic_source=traffic_src,
-                   bytes_per_launch=b_iter, avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
+    # The EM is reported twice, and neither figure borrows from the other (round-3 review: B_iter' over the sweep kernel's time
+    # alone over-stated it):
+    #   roofline_em_iteration : the WHOLE iteration's algorithmic bytes B_iter' over the time one iteration takes in the loop as it
+    #                           runs (sweep + per-transcript update + what a chunk boundary costs) -- the figure to quote;
+    #   roofline_em_sweep     : the sweep kernel alone, with the bytes the SWEEP moves: labels 4 L + rowptr / count 8 C + the
+    #                           x vector it gathers from (8 M) + one partial sum per transcript it publishes (8 M); the other
+    #                           32 M (+ 16 M VBEM) of B_iter' are the update's.
+    b_sweep = 4 * L + 8 * C + 16 * M
+    roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_sweep / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                   unit="GB/s", frac=b_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em, traffic_source=traffic_src,
+                   bytes_per_launch=b_sweep, bytes_formula="4 L + 8 C + 16 M (sweep only: labels, rowptr + count, x gathered, partials published)",
+                   avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
+    it_s = em_loop_ms_per_iter * 1e-3
+    roof_em_iter = dict(bound="hbm", kernel="one EM iteration as the loop runs it (sweep + update + chunk boundaries)",
+                        achieved=b_iter / it_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b_iter / it_s / 1e9 / HBM_PEAK_GBS,
+                        traffic=None, bytes_per_launch=b_iter, bytes_formula="B_iter' = 4 L + 8 C + 48 M (+ 16 M VBEM), SURVEY 8d aux-weight-free variant",
+                        avg_launch_ms=em_loop_ms_per_iter, launches_per_step=st["iters"])
+    # class build: SURVEY 8d's B_read (ids + offset + one 16-byte slot probe) and, next to it, the COMPULSORY bytes alone
+    # (ids + offset: what any builder must read), so that the probe term cannot flatter the fraction
+    b_comp = 4.0 * n_hits / R_local + 4.0
     roof_build = dict(bound="hbm", kernel=info.get("insert_kernels", "k_insert"), achieved=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=b_read * R_local / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_ins, traffic_source=traffic_src,
-                      bytes_per_launch=b_read * R_local / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins)
+                      bytes_per_launch=b_read * R_local / n_ins, avg_launch_ms=ins_ms, launches_per_step=n_ins,
+                      frac_compulsory_bytes=b_comp * R_local / n_ins / (ins_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      compulsory_bytes_per_read=b_comp, bytes_per_read=b_read,
+                      frac_of_whole_phase=b_read * R_local / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
     dominant = roof_em if sweep_ms * st["iters"] >= info["t_insert_ms"] else roof_build
 
     out = {
-        "metric": "reads quantified/sec (hit lists -> eq-classes -> EM to convergence -> TPM)",
+        "metric": "reads quantified/sec, hit lists HBM-resident when the timed region starts (hit lists -> eq-classes -> EM to convergence "
+                  "-> TPM); the same step from HOST-PINNED hit lists (BASELINE.md 3's timed region, PCIe-inclusive) is value_host_pinned",
+        "value_residency": "hbm",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": ("weak" if (a.weak or world == 1) else "strong"), "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{'cfg4 = ' if (a.workload == 'cfg3' and world > 1 and not a.weak) else ''}{a.workload}: "
                                f"{R_total} reads in all over {world} GPU ({R_local} on rank 0), {M}-transcript index, label pool {P}, "
-                               f"{'VBEM' if use_vbem else 'EM'} to convergence (tol 0.01, minIter 50)",
+                               f"{'VBEM' if use_vbem else 'EM'} to convergence (tol 0.01, minIter 50); hit lists HBM-resident "
+                               f"(value) / host-pinned (value_host_pinned)",
                    "reads_total": R_total, "reads_per_gpu": R_local, "transcripts": M, "hits": n_hits, "classes": C, "nnz": L,
                    "em_mode": info["em_mode"]},
         "em_iters": st["iters"], "em_iters_per_s": st["iters"] / (em_ms * 1e-3),
@@ -351,10 +374,12 @@ def main():
         "phase_ms": {"class_build": build_ms, "insert_kernel": info["t_insert_ms"], "merge": info.get("t_merge_ms", 0.0),
                      "efflen": info["t_efflen_ms"], "em": em_ms, "tpm": info["t_tpm_ms"]},
         "class_build_reads_per_s": R_local / (build_ms * 1e-3),
-        "roofline": dominant, "roofline_em_sweep": roof_em, "roofline_class_build": roof_build,
+        "roofline": dominant, "roofline_em_iteration": roof_em_iter, "roofline_em_sweep": roof_em, "roofline_class_build": roof_build,
     }
     if host_leg is not None:
+        # BASELINE.md 3 / SURVEY 8d time the step from host-pinned hit lists: this is the figure that answers them
         out["value_host_pinned"] = host_leg.get("value")
+        out["ms_per_step_host_pinned"] = host_leg.get("ms_per_step")
         out["host_pinned"] = host_leg
 
     # ---- N > 1 only, outside the timed region: what the EM-mode decision rests on, measured on THIS node (the sharded
@@ -488,6 +513,15 @@ def main():
                 "value_from_2M_read_sample": R / cpu_step_s})
         except Exception as e:                    # keep the sample-based figure
             out["cpu_baseline"]["full_problem_error"] = repr(e)
+    # GPU / CPU ratios for BOTH residencies (reported, not a target: the roofline fractions say how good the kernels are)
+    if rank == 0 and "cpu_baseline" in out:
+        sp = {}
+        for key in ("cpu_baseline", "cpu_baseline_all_cores"):
+            cv = out.get(key, {}).get("value") if isinstance(out.get(key), dict) else None
+            if cv:
+                sp[key] = {"cores": out[key].get("cores"), "hbm_resident": value / cv,
+                           "host_pinned": (out["value_host_pinned"] / cv) if out.get("value_host_pinned") else None}
+        out["speedup_vs_cpu"] = sp
     if rank == 0:
         print(json.dumps(out))
     if dist:

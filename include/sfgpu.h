@@ -50,6 +50,11 @@ SFGPU_API void sfgpu_set_logger(void (*log)(int level, const char* msg));
 /* Scratch device memory is cached inside the library (hipMalloc/hipFree are slow and hipFree
  * synchronises the device); this returns every cached block to the driver. */
 SFGPU_API int sfgpu_pool_trim(void);
+/* Cached blocks of >= 1 GiB (the Gibbs sampler's chain state: 4 x nnz x chains bytes, 38 GB for 1.6 M classes and 1024
+ * chains) are kept only up to this many bytes per device -- memory parked in this cache is invisible to other allocators in
+ * the process (e.g. torch's).  Default: a quarter of the device's memory, at most 64 GiB (SFGPU_POOL_LARGE_LIMIT_GB overrides);
+ * 0 = never cache them (every call pays the mapping: ~15 ms per GB); negative = back to the default. */
+SFGPU_API int sfgpu_pool_set_large_limit(long long bytes);
 /* Device name / CU count / HBM bytes of the current device (any pointer may be NULL). */
 SFGPU_API int sfgpu_device_info(char* name, int name_len, int* n_cu, uint64_t* hbm_bytes);
 
@@ -349,7 +354,9 @@ SFGPU_API int sfgpu_index_set_seeds(sfgpu_index* x, uint32_t seeds_per_strand);
  * otherwise every occurrence is extended base by base on the transcripts' text (the index keeps a copy), L = the longest
  * extension, the occurrences that reach L form a group, i += L - seed_len + 1 (at most 8 groups per mate).  A (transcript,
  * strand) is positioned by the first group that holds it and gets a vote per group; with several candidates only those with
- * the most votes are kept.  A read with substitutions maps as long as seed_len clean bases remain somewhere.
+ * the most votes are kept.  A read with substitutions maps as long as seed_len clean bases remain somewhere that an indexed
+ * k-mer starts in: seeds are prefix ranges of WHOLE k-mers, so a seed that begins within the last k - seed_len bases of a
+ * transcript, or within k - 1 bases upstream of a non-ACGT base, is not in the index.  Mates of >= 2^24 bases are left unmapped.
  * seed_len == 0: the END-SEED contract above (exact k-mers at offsets 0 and len - k, or sfgpu_index_set_seeds' S seeds) -- the
  * baseline of rounds 1-2.  8 <= seed_len <= k.  Parity with RapMap is unpinned in both modes. */
 SFGPU_API int sfgpu_index_set_scan(sfgpu_index* x, uint32_t seed_len);

@@ -96,6 +96,7 @@ _SIGS = {
     "sfgpu_last_error": (C.c_char_p, []),
     "sfgpu_set_logger": (None, [_LOG_CB]),
     "sfgpu_pool_trim": (C.c_int, []),
+    "sfgpu_pool_set_large_limit": (C.c_int, [C.c_longlong]),
     "sfgpu_index_set_seeds": (C.c_int, [_P, C.c_uint32]),
     "sfgpu_index_set_scan": (C.c_int, [_P, C.c_uint32]),
     "sfgpu_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),

@@ -24,6 +24,7 @@ hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);
 void pool_free_on(void* p, hipStream_t s);     // back to the cache once the work enqueued on s so far is done (no host wait)
 void pool_trim();
+void pool_set_large_limit(long long bytes);     // cached device blocks >= 1 GiB are kept up to this many bytes per device
 template <typename T>
 inline hipError_t pool_malloc(T** p, size_t bytes) { return pool_malloc(reinterpret_cast<void**>(p), bytes); }
 // same recycling for pinned host blocks and for the handles' private non-blocking streams

@@ -51,6 +51,25 @@ size_t round_up_pow2(size_t n) {
 }
 int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
+// LARGE device blocks (>= 1 GiB: the Gibbs sampler's chain state is 4 x nnz x chains bytes, 38 GB at cfg3) are cached only up
+// to a budget: memory parked here is invisible to every other allocator of the process (torch's caching allocator cannot
+// reclaim it and would report out-of-memory).  Default: a quarter of the device's memory, at most 64 GiB;
+// SFGPU_POOL_LARGE_LIMIT_GB / sfgpu_pool_set_large_limit() change it (0: large blocks are never cached).
+constexpr size_t kLargeBlock = (size_t)1 << 30;
+std::unordered_map<int, size_t> g_large_cached;                      // device -> bytes of cached (free) large blocks
+long long g_large_limit = -1;                                        // bytes; -1: not decided yet
+size_t large_limit_locked() {
+    if (g_large_limit < 0) {
+        size_t fr = 0, tot = 0;
+        long long lim = 64ll << 30;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (long long)(tot / 4) < lim) lim = (long long)(tot / 4);
+        (void)hipGetLastError();
+        if (const char* e = getenv("SFGPU_POOL_LARGE_LIMIT_GB")) { const double g = atof(e); if (g >= 0) lim = (long long)(g * (double)(1ull << 30)); }
+        g_large_limit = lim;
+    }
+    return (size_t)g_large_limit;
+}
+
 struct Pending { void* p; hipEvent_t ev; };
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_events;
@@ -62,7 +81,13 @@ void reap_pending_locked(bool wait) {
         if (q == hipErrorNotReady) { g_pending[keep++] = x; continue; }
         (void)hipGetLastError();
         auto it = g_pool_key.find(x.p);
-        if (it != g_pool_key.end()) g_pool_free[it->second].push_back(x.p); else (void)hipFree(x.p);
+        if (it == g_pool_key.end()) (void)hipFree(x.p);
+        else if (it->second.kind == kDeviceMem && it->second.sz >= kLargeBlock && g_large_cached[it->second.dev] + it->second.sz > large_limit_locked()) {
+            g_pool_key.erase(it); (void)hipFree(x.p);                        // over the large-block budget: back to the driver
+        } else {
+            if (it->second.kind == kDeviceMem && it->second.sz >= kLargeBlock) g_large_cached[it->second.dev] += it->second.sz;
+            g_pool_free[it->second].push_back(x.p);
+        }
         g_events.push_back(x.ev);
     }
     g_pending.resize(keep);
@@ -74,7 +99,11 @@ hipError_t pool_get(void** p, size_t bytes, int kind) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (!g_pending.empty()) reap_pending_locked(false);
         auto it = g_pool_free.find(key);
-        if (it != g_pool_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); return hipSuccess; }
+        if (it != g_pool_free.end() && !it->second.empty()) {
+            *p = it->second.back(); it->second.pop_back();
+            if (kind == kDeviceMem && key.sz >= kLargeBlock) g_large_cached[key.dev] -= key.sz;
+            return hipSuccess;
+        }
     }
     void* q = nullptr;
     auto alloc = [&] { return kind == kDeviceMem ? hipMalloc(&q, key.sz) : hipHostMalloc(&q, key.sz, hipHostMallocDefault); };
@@ -95,6 +124,10 @@ void pool_put(void* p, int kind) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_pool_key.find(p);
     if (it == g_pool_key.end()) { if (kind == kDeviceMem) (void)hipFree(p); else (void)hipHostFree(p); return; }
+    if (kind == kDeviceMem && it->second.sz >= kLargeBlock) {
+        if (g_large_cached[it->second.dev] + it->second.sz > large_limit_locked()) { g_pool_key.erase(it); (void)hipFree(p); return; }
+        g_large_cached[it->second.dev] += it->second.sz;
+    }
     g_pool_free[it->second].push_back(p);
 }
 }  // namespace
@@ -146,14 +179,17 @@ void pool_trim() {
         }
         kv.second.clear();
     }
+    g_large_cached.clear();
     for (auto& kv : g_streams) { for (hipStream_t s : kv.second) (void)hipStreamDestroy(s); kv.second.clear(); }
 }
+void pool_set_large_limit(long long bytes) { std::lock_guard<std::mutex> lk(g_pool_mu); g_large_limit = bytes; }
 
 }  // namespace sfgpu
 
 extern "C" {
 
 int sfgpu_pool_trim(void) { sfgpu::pool_trim(); return SFGPU_OK; }
+int sfgpu_pool_set_large_limit(long long bytes) { sfgpu::pool_set_large_limit(bytes); return SFGPU_OK; }
 
 
 int sfgpu_version(void) { return SFGPU_VERSION; }

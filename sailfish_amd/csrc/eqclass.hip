@@ -126,7 +126,7 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
          const uint32_t* __restrict__ list, uint64_t* table, uint64_t mask,
          const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ cls_len,
          const uint32_t* __restrict__ arena, unsigned long long* ctr, uint32_t* newlist,
-         unsigned long long limit_new, uint32_t* deferred, const uint64_t* __restrict__ weights) {
+         unsigned long long limit_new, uint32_t* deferred, const uint64_t* __restrict__ weights, uint32_t mix_mode) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < n;
     uint32_t r = in_range ? (list ? list[i] : first + i) : 0u;
@@ -137,7 +137,7 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
     const uint32_t* lab = ids + b;
     uint32_t hw[kHead];
     uint64_t h = 0;
-    if (act) h = label_mix64([&](uint32_t k) { return lab[k]; }, len, hw);     // bucket hash (xxh64_device.h)
+    if (act) h = label_mix64([&](uint32_t k) { return lab[k]; }, len, hw, mix_mode);     // bucket hash (xxh64_device.h)
     // Identical labels of one wavefront are added once, with their counts summed: the reads this kernel sees are often
     // dominated by a few labels (the overflow of a hot label's bins, see k_part_route), and 64 atomics on one slot are 64
     // serialised L2 round trips.  Two rounds: the first two distinct labels of the wavefront collect their duplicates.
@@ -228,12 +228,12 @@ __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __res
 // re-insert every class into a larger table, carrying its count
 __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table, uint64_t mask, uint64_t n_cls,
                          const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ cls_len,
-                         const uint32_t* __restrict__ arena, uint32_t* cls_slot) {
+                         const uint32_t* __restrict__ arena, uint32_t* cls_slot, uint32_t mix_mode) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cls) return;
     const uint32_t* lab = arena + cls_off[c];
     uint32_t hw[kHead];
-    uint64_t h = label_mix64([&](uint32_t k) { return lab[k]; }, cls_len[c], hw);
+    uint64_t h = label_mix64([&](uint32_t k) { return lab[k]; }, cls_len[c], hw, mix_mode);
     uint64_t mine = ((h >> 32) << 32) | (uint64_t)(kArenaBit | (uint32_t)((cls_off[c] - 1) >> 2));
     uint64_t cnt = old_table[2 * (uint64_t)cls_slot[c] + 1];
     uint64_t s = h & mask;
@@ -408,6 +408,8 @@ struct sfgpu_eq {
     uint64_t reads_seen = 0;                // reads added since start()
     uint64_t hot_cap = 0, hot_reads = 0;    // table size and reads_seen when the hot table was last rebuilt
     uint32_t hot_slots = 0;                 // ... and the number of slots it was laid out for
+    uint32_t mix_mode = kMixSampled;        // how the bucket hash treats the tail of a long label (xxh64_device.h): sampled, or walked
+                                            // once a cluster of long labels that agree in every sample has been seen (eq_generic)
     DevBuf<uint64_t> part_off, def_off64;
 };
 
@@ -428,7 +430,7 @@ static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
     if (rc) return rc;
     if (eq->n_classes) {
         hipLaunchKernelGGL(k_rehash, dim3(grid_for(eq->n_classes)), dim3(kBlock), 0, eq->stream, old, eq->table.p,
-                           new_cap - 1, eq->n_classes, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->cls_slot.p);
+                           new_cap - 1, eq->n_classes, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->cls_slot.p, eq->mix_mode);
         SF_CHECK_LAUNCH();
     }
     SF_HIP(hipStreamSynchronize(eq->stream));
@@ -454,7 +456,7 @@ static int eq_reset(sfgpu_eq* eq) {
     eq->stats = sfgpu_eq_stats{};
     eq->finished = false; eq->n_classes = 0; eq->arena_used = 0; eq->nnz = 0; eq->total_reads = 0;
     eq->acc_n_ids = 0; eq->acc_n_reads = 0; eq->dacc_n_reads = 0; eq->dacc_n_ids = 0;
-    eq->reads_seen = 0; eq->hot_cap = 0; eq->hot_reads = 0;
+    eq->reads_seen = 0; eq->hot_cap = 0; eq->hot_reads = 0; eq->mix_mode = kMixSampled;
     uint64_t want = pow2_at_least(2 * (eq->expected ? eq->expected : 1000000ull) + 2 * kSlack);
     if (eq->table.p && eq->cap == want) {
         hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
@@ -529,6 +531,8 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
     hipStream_t st = eq->stream;
     int rc;
     bool flip = false;
+    uint64_t prev_def = 0;      // reads the previous launch of this call deferred (0: this is the first launch)
+    int stalls = 0;
     while (todo) {
         // new-class budget of this launch: keep load <= 1/2 with room for the guard's slack
         int64_t free_budget = (int64_t)(eq->cap / 2) - (int64_t)eq->n_classes - (int64_t)kSlack;
@@ -548,7 +552,7 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
         SF_HIP(hipEventRecord(eq->ev0, st));
         hipLaunchKernelGGL(k_insert, dim3(grid_for(todo)), dim3(kBlock), 0, st, d_ids, d_offsets, first, todo, list,
                            eq->table.p, eq->cap - 1, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->d_ctr,
-                           eq->newlist.p, (unsigned long long)limit_new, dout.p, d_weights);
+                           eq->newlist.p, (unsigned long long)limit_new, dout.p, d_weights, eq->mix_mode);
         SF_CHECK_LAUNCH();
         SF_HIP(hipEventRecord(eq->ev1, st));
         SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -565,7 +569,25 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
         }
         if (n_def) {
             eq->stats.deferred_reads += n_def;
-            if ((rc = eq_grow(eq, eq->cap * 2))) return rc;   // synchronises: commit has finished
+            // A replay after growth that defers (nearly) as many reads as before, in a table that is far from full, is not
+            // short of room: its labels share a home slot at every table size -- distinct long labels that agree in every field
+            // the sampled bucket hash looks at (xxh64_device.h).  The builder then hashes whole labels for the rest of its
+            // life (the table is rehashed in place); should even that not spread them, the loop gives up instead of doubling
+            // the table until an allocation fails.
+            const bool no_progress = prev_def != 0 && n_def * 2 > prev_def && eq->n_classes * 8 < eq->cap;
+            if (no_progress && eq->mix_mode == kMixSampled) {
+                eq->mix_mode = kMixFull; eq->hot_cap = 0;
+                log_msg(0, "eq: %llu reads deferred again after growth at load %.3f: long labels share their sampled ids -- hashing whole labels from here on",
+                        (unsigned long long)n_def, (double)eq->n_classes / (double)eq->cap);
+                if ((rc = eq_grow(eq, eq->cap))) return rc;       // same size, new hash (synchronises: commit has finished)
+                eq->stats.table_grows--;                          // (a rehash, not a growth)
+                stalls = 0;
+            } else {
+                if (no_progress) ++stalls;
+                SF_REQUIRE(stalls < 3, SFGPU_ERR_RANGE, "equivalence-class table: labels cannot be placed (one region keeps overflowing)");
+                if ((rc = eq_grow(eq, eq->cap * 2))) return rc;   // synchronises: commit has finished
+            }
+            prev_def = n_def;
             list = dout.p; todo = (uint32_t)n_def; flip = !flip;
         } else {
             todo = 0;
@@ -680,7 +702,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if (eq->n_classes && eq->reads_seen && (eq->hot_cap != eq->cap || eq->hot_slots != hs || eq->reads_seen >= 4 * eq->hot_reads)) {
         const unsigned long long thr = std::max<unsigned long long>(64ull, eq->reads_seen / (8ull * n_regions));
         SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
-        hipLaunchKernelGGL(k_hot_select, dim3(grid_for(eq->cap)), dim3(kBlock), 0, st, eq->table.p, eq->cap, thr, eq->arena.p, hot_h, hot_meta, n_hot, hs);
+        hipLaunchKernelGGL(k_hot_select, dim3(grid_for(eq->cap)), dim3(kBlock), 0, st, eq->table.p, eq->cap, thr, eq->arena.p, hot_h, hot_meta, n_hot, hs, eq->mix_mode);
         SF_CHECK_LAUNCH();
         eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen; eq->hot_slots = hs;
     } else if (eq->hot_cap != eq->cap || eq->hot_slots != hs) {                 // (an empty table: nothing is hot)
@@ -689,7 +711,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     }
     uint32_t* fill_f = eq->part_hist.p, *fill_b = fill_f + n_bins, *cutmarks = fill_b + n_bins;
     RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
-                 eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT};
+                 eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode};
     if (ring) {
         const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
                                  (size_t)kPartWaves * kRingFlushList * 4;
@@ -704,7 +726,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     }
     SF_CHECK_LAUNCH();
     PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes};
+                eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes, eq->mix_mode};
     hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev1, st));

@@ -111,6 +111,7 @@ struct RouteArgs {
                                                    // hot classes (0: the block skips all of this)
     const uint32_t* arena; uint64_t* table;
     unsigned long long* n_hot_reads;               // statistics: reads counted here
+    uint32_t mix_mode;                             // bucket hash of long labels: kMixSampled / kMixFull (xxh64_device.h)
 };
 
 constexpr uint32_t kCountedBit = 0x80000000u;          // in H: the label is followed by a granule [count, 0, 0, 0]
@@ -121,7 +122,7 @@ __device__ __forceinline__ uint32_t hot_index(uint64_t h, uint32_t slots) { retu
 // classes of the table that hold >= thr reads -> hot table of `slots` entries (a power of two; first come per slot; the table
 // is rebuilt before every route pass: growth moves the slots).  One thread per table slot.
 __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slots, unsigned long long thr, const uint32_t* __restrict__ arena,
-                             unsigned long long* hot_h, uint2* hot_meta, unsigned int* n_hot, uint32_t slots) {
+                             unsigned long long* hot_h, uint2* hot_meta, unsigned int* n_hot, uint32_t slots, uint32_t mix_mode) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const uint64_t w = table[2 * s];
@@ -132,7 +133,7 @@ __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slot
     const uint32_t len = e[0];
     if (len == 0 || len > kMaxPartLabel) return;
     uint32_t tmp[kHead];
-    const uint64_t h = label_mix64([&](uint32_t k) { return e[1 + k]; }, len, tmp);
+    const uint64_t h = label_mix64([&](uint32_t k) { return e[1 + k]; }, len, tmp, mix_mode);
     if (h == 0) return;
     for (uint32_t p = 0; p < kHotProbes; ++p) {                        // short linear probing; a class that finds no place is not hot
         const uint32_t idx = (hot_index(h, slots) + p) & (slots - 1u);
@@ -258,8 +259,8 @@ k_part_route(RouteArgs a) {
         };
         auto granule = [&](uint32_t g) -> uint4 { return granule_at(b, len, g); };
         if (len > (uint32_t)kHead && !unfit) {
-            const uint32_t last = staged ? lab_s[len - 1u] : lab_g[len - 1u], mid = staged ? lab_s[len >> 1] : lab_g[len >> 1];
-            label_mix_far(ha, hb, last, mid);
+            if (staged) label_mix_tail(ha, hb, [&](uint32_t k) { return lab_s[k]; }, len, a.mix_mode);
+            else label_mix_tail(ha, hb, [&](uint32_t k) { return lab_g[k]; }, len, a.mix_mode);
         }
         // ids >= 2^31 in a tail: the staged words of the whole step are checked at once (they never occur in a real index: such a
         // step -- or, unstaged, such a label -- takes the generic kernel)
@@ -552,6 +553,7 @@ struct PartArgs {
     unsigned long long* ctr;               // CTR_* counters (classes / arena cursor / deferred)
     uint32_t* deferred;                    // (granule index of the label in the bins, length) of labels that found their region full
     uint64_t base_classes;                 // classes committed before this launch
+    uint32_t mix_mode;                     // bucket hash of long labels (the full tag of a new class is computed at commit)
 };
 
 // ---- pass 2: one block per region
@@ -789,7 +791,7 @@ k_part_insert(PartArgs a) {
             a.cls_hash[cid] = xxh64_words(word, len);
             a.cls_off[cid] = dst + 1; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
             uint32_t tmp[kHead];
-            const uint64_t h = label_mix64(word, len, tmp);                               // the table keeps the full 32-bit tag
+            const uint64_t h = label_mix64(word, len, tmp, a.mix_mode);                   // the table keeps the full 32-bit tag
             a.table[2 * (rb + s)] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(kArenaBit | (uint32_t)(dst >> 2));
             a.table[2 * (rb + s) + 1] = ccnt[idx];                                         // (the slot was empty: count 0 before)
         }

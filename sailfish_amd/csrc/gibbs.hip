@@ -477,7 +477,9 @@ done:
     if (h_tmp) pinned_free(h_tmp);
     // The chain state (4 * nnz * n_chains bytes, 38 GB for cfg3's classes and 1024 chains) stays in the allocator's cache: giving
     // it back to the driver and mapping it again cost the next call 1 - 4 s (measured), ten times what the sampling itself takes.
-    // sfgpu_pool_trim() releases it (the allocator also does when an allocation fails).
+    // It stays only within the allocator's budget for large blocks (core.hip: a quarter of the device's memory, at most 64 GiB;
+    // sfgpu_pool_set_large_limit): beyond it the block goes back to the driver here, so that the process's other allocators
+    // (torch's) are not starved by memory they cannot see.  sfgpu_pool_trim() releases everything.
     lap("release");
     return rc;
 }

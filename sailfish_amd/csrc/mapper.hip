@@ -241,7 +241,7 @@ k_map_hits(IndexView x, const uint64_t* __restrict__ off, uint64_t n_mates, cons
 // The sorted k-mer table doubles as a suffix array of depth k: a seed of s <= k bases is a PREFIX range of it.  A mate is walked
 // on both strands in lockstep: window at i -> prefix range; none, or more than max_occ -> i += 1; else every occurrence is extended
 // base by base against the transcript's text; L = the longest extension, the occurrences that reach it form a GROUP (i, L);
-// i += L - s + 1; a match that covers the whole read ends both walks.  Reads with substitutions map as long as s error-free bases remain somewhere (the fixed 31-mer end seeds of the first
+// i += L - s + 1; a match that covers the whole read ends both walks.  Reads with substitutions map as long as s error-free bases remain somewhere an indexed k-mer starts in (not within the last k - s bases of a transcript or k - 1 bases upstream of an N) (the fixed 31-mer end seeds of the first
 // contract lose a 50-base read to a single substitution in its middle).  The contract is restated on the CPU for the tests.
 // first sorted index whose key is >= key (key < 4^k; key == 4^k: the end)
 __device__ __forceinline__ uint32_t index_lower_bound(const IndexView& x, uint64_t key) {
@@ -268,7 +268,9 @@ __device__ __forceinline__ uint32_t scan_extend(const IndexView& x, const char* 
     }
     return e;
 }
-// group words: w0 = first sorted index | occurrences << 32;  w1 = i | L << 16 | fwd << 32 | 1 << 33 (present)
+// group words: w0 = first sorted index | occurrences << 32;  w1 = i (24 bits) | L << 24 (24 bits) | fwd << 48 | 1 << 49 (present):
+// mates of up to 2^24 - 1 bases (a longer mate is left unmapped: see kMaxScanMate; round 3 packed 16 bits each and a mate of
+// >= 65536 bases spilled into the strand and present bits)
 // pass A: walk the mate; groups[2 G m + 2 g ..], cand_cnt[m] = occurrences that reach L, summed over the groups.
 // The two strands are walked in LOCKSTEP -- one lookup on the forward strand, one on the reverse complement, and so on -- and
 // a match that covers the whole read ends both walks: an error-free read costs one or two lookups whichever strand it came
@@ -289,7 +291,8 @@ k_scan_lookup(IndexView x, const char* __restrict__ seq, const uint64_t* __restr
     // per strand: i = start of the window, key / have = the rolling window (have valid bases collected), live = still walking
     uint32_t wi[2] = {0u, 0u}, whave[2] = {0u, 0u};
     uint64_t wkey[2] = {0ull, 0ull};
-    bool live[2] = {n >= s, n >= s};
+    constexpr uint32_t kMaxScanMate = (1u << 24) - 1u;       // i and L travel in 24 bits each
+    bool live[2] = {n >= s && n <= kMaxScanMate, n >= s && n <= kMaxScanMate};
     bool whole = false;
     while ((live[0] || live[1]) && !whole && ng < kScanGroups) {
 #pragma unroll
@@ -318,7 +321,7 @@ k_scan_lookup(IndexView x, const char* __restrict__ seq, const uint64_t* __restr
                     if (e > L) { L = e; reach = 1; } else if (e == L) ++reach;
                 }
                 out[2u * ng] = (uint64_t)lo | ((uint64_t)cnt << 32);
-                out[2u * ng + 1u] = (uint64_t)i | ((uint64_t)L << 16) | ((uint64_t)(rc ? 0u : 1u) << 32) | (1ull << 33);
+                out[2u * ng + 1u] = (uint64_t)i | ((uint64_t)L << 24) | ((uint64_t)(rc ? 0u : 1u) << 48) | (1ull << 49);
                 ++ng; total += reach;
                 if (L == n) whole = true;                                               // the whole read matched: both walks end
                 i += L - s + 1u; have = 0; key = 0;
@@ -348,9 +351,9 @@ k_scan_hits(IndexView x, const char* __restrict__ seq1, const uint64_t* __restri
     uint32_t nc = 0;
     for (uint32_t g = 0; g < kScanGroups; ++g) {
         const uint64_t w0 = gw[2u * g], w1 = gw[2u * g + 1u];
-        if (!(w1 >> 33)) break;
+        if (!(w1 >> 49)) break;
         const uint32_t lo = (uint32_t)w0, cnt = (uint32_t)(w0 >> 32);
-        const uint32_t i = (uint32_t)(w1 & 0xFFFFu), L = (uint32_t)((w1 >> 16) & 0xFFFFu), fwd = (uint32_t)(w1 >> 32) & 1u;
+        const uint32_t i = (uint32_t)(w1 & 0xFFFFFFu), L = (uint32_t)((w1 >> 24) & 0xFFFFFFu), fwd = (uint32_t)(w1 >> 48) & 1u;
         for (uint32_t q = lo; q < lo + cnt; ++q) {
             const uint32_t t = x.tid[q], p = x.tpos[q];
             if (scan_extend(x, r, n, fwd == 0u, i, t, p) != L) continue;

@@ -121,25 +121,39 @@ __device__ __forceinline__ void label_mix_head(const uint32_t (&w)[kHead], uint3
 #pragma unroll
     for (int i = 0; i < kHead; ++i) mix_round(a, b, w[i]);
 }
-// Labels of more than 8 ids: the bucket hash does NOT walk the tail.  It takes the length, the first 8 ids, the LAST id and the
-// MIDDLE one (two more rounds, no loop): a label is an ordered id list, so labels that agree in all of these and still differ
-// are rare, and when they do they only share a slot neighbourhood -- class identity is decided by the full label compare, never
-// by this value.  (Round 3: walking the tail cost the route pass half of its vector instructions -- 13 % of the labels have one,
-// so some lane of nearly every wavefront walked while the others waited: 9.6 instead of 6.4 ms per build in the ring form; hashing
-// the tail granules by lanes of their own cost as much in bookkeeping: profiles/r3_class_build_notes.md.)
-__device__ __forceinline__ void label_mix_far(uint32_t& a, uint32_t& b, uint32_t last, uint32_t middle) {
-    mix_round(a, b, last); mix_round(a, b, middle);
+// Labels of more than 8 ids: by default (mode 0) the bucket hash does NOT walk the tail.  It takes the length, the first 8 ids
+// and three ids OF THE TAIL -- the last one, the one in the middle of the tail and the one a quarter into it (three more rounds,
+// no loop): a label is an ordered id list, so labels that agree in all of these and still differ are rare, and when they do
+// they only share a slot neighbourhood -- class identity is decided by the full label compare, never by this value.  (Round 3:
+// walking the tail cost the route pass half of its vector instructions -- 13 % of the labels have one, so some lane of nearly
+// every wavefront walked while the others waited: 9.6 instead of 6.4 ms per build in the ring form; hashing the tail granules by
+// lanes of their own cost as much in bookkeeping: profiles/r3_class_build_notes.md.  Round 4: the middle sample was id[n / 2],
+// which for n <= 15 lies in the head and added nothing.)
+// Thousands of DISTINCT long labels that agree in every sampled field would share one home slot at every table size, fill their
+// region and be deferred for ever.  The builder notices that (a grown table that defers as many reads as before) and switches
+// to mode 1 for the rest of its life: the tail is walked, one round per id, as before round 3 -- the table is rehashed with it.
+constexpr uint32_t kMixSampled = 0u, kMixFull = 1u;
+__device__ __forceinline__ uint32_t mix_tail_mid(uint32_t n) { return (uint32_t)kHead + ((n - (uint32_t)kHead) >> 1); }
+__device__ __forceinline__ uint32_t mix_tail_quarter(uint32_t n) { return (uint32_t)kHead + ((n - (uint32_t)kHead) >> 2); }
+__device__ __forceinline__ void label_mix_far(uint32_t& a, uint32_t& b, uint32_t last, uint32_t middle, uint32_t quarter) {
+    mix_round(a, b, last); mix_round(a, b, middle); mix_round(a, b, quarter);
 }
 __device__ __forceinline__ uint64_t label_mix_final(uint32_t a, uint32_t b) {
     return ((uint64_t)mix_fin(a ^ b) << 32) | mix_fin(b + (a >> 3));
 }
+// the tail of a label of n > 8 ids into the two lanes, by the builder's mode
+template <typename WordFn>
+__device__ __forceinline__ void label_mix_tail(uint32_t& a, uint32_t& b, WordFn word, uint32_t n, uint32_t mode) {
+    if (mode == kMixSampled) label_mix_far(a, b, word(n - 1u), word(mix_tail_mid(n)), word(mix_tail_quarter(n)));
+    else for (uint32_t k = kHead; k < n; ++k) mix_round(a, b, word(k));
+}
 // bucket hash of any label (w[] receives the zero-padded head)
 template <typename WordFn>
-__device__ __forceinline__ uint64_t label_mix64(WordFn word, uint32_t n, uint32_t (&w)[kHead]) {
+__device__ __forceinline__ uint64_t label_mix64(WordFn word, uint32_t n, uint32_t (&w)[kHead], uint32_t mode) {
     label_head(word, n, w);
     uint32_t a, b;
     label_mix_head(w, n, a, b);
-    if (n > (uint32_t)kHead) label_mix_far(a, b, word(n - 1u), word(n >> 1));
+    if (n > (uint32_t)kHead) label_mix_tail(a, b, word, n, mode);
     return label_mix_final(a, b);
 }
 

@@ -317,7 +317,8 @@ class DistributedQuant:
             return "single"
         if self.em_mode != "auto":
             return self.em_mode
-        return getattr(self, "_auto_mode", None) or "replicated"           # (decided by _measure_auto on the first run)
+        # (decided by _measure_auto on the first run of a problem of this size: the decision is kept per (M, nnz))
+        return getattr(self, "_auto_modes", {}).get(getattr(self, "_auto_key", None)) or "replicated"
 
     def _allreduce(self):
         """what sums alphaOut over the ranks: libsfgpu's RCCL communicator on the nccl backend (made once, collectively),
@@ -327,9 +328,17 @@ class DistributedQuant:
             self._ar = None
             if isinstance(self.engine, HipEngine) and dist.get_backend(self.group) == "nccl":
                 from . import comm as _comm
-                if _comm.available():
+                # availability is agreed on FIRST (librccl may load on some ranks only): every rank then takes the same branch,
+                # so the collective creation below is entered by all ranks or by none (a rank without the library
+                # went straight to the MIN all-reduce while the others sat in the id broadcast -- mismatched collectives hang)
+                have = torch.tensor([int(bool(_comm.available()))], dtype=torch.int32, device=self.engine.device)
+                dist.all_reduce(have, op=dist.ReduceOp.MIN, group=self.group)
+                if int(have.item()) == 1:
                     # made collectively and checked collectively: a communicator that does not come up, or does not add, on ANY
-                    # rank sends every rank to the torch.distributed call (a split decision would hang the first all-reduce)
+                    # rank sends every rank to the torch.distributed call (a split decision would hang the first all-reduce).
+                    # from_group's own collectives (the id broadcast) run inside the try on every rank; a rank that raises
+                    # before ncclCommInitRank still reaches the flag all-reduce below, and the ranks stuck in ncclCommInitRank
+                    # are released by RCCL's own bootstrap timeout.
                     comm, ok = None, 1
                     try:
                         comm = _comm.Comm.from_group(self.group, self.engine.device)
@@ -352,9 +361,11 @@ class DistributedQuant:
     def _measure_auto(self, p_full, M):
         """auto: time the two things the modes differ in, on this node, once; every rank takes the slowest rank's numbers"""
         import torch.distributed as dist
-        if getattr(self, "_auto_mode", None) is not None or self.em_mode != "auto" or self.world == 1:
+        if not hasattr(self, "_auto_modes"):
+            self._auto_modes = {}
+        if self._auto_modes.get(self._auto_key) is not None or self.em_mode != "auto" or self.world == 1:
             return
-        self._auto_mode = "replicated"
+        self._auto_modes[self._auto_key] = "replicated"
         if not hasattr(p_full, "time_sweep"):
             return
         ar = self._allreduce()
@@ -371,14 +382,18 @@ class DistributedQuant:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         sweep_us, ar_us = float(t[0]), float(t[1])
         local_us = max(kSweepFloorUs, sweep_us / self.world)
-        self._auto_mode = "sharded" if local_us + ar_us < sweep_us else "replicated"
+        self._auto_modes[self._auto_key] = "sharded" if local_us + ar_us < sweep_us else "replicated"
         self.auto_measurement = dict(sweep_us_whole_problem=sweep_us, allreduce_us=ar_us, sweep_us_local_estimate=local_us,
-                                     chosen=self._auto_mode)
+                                     chosen=self._auto_modes[self._auto_key], problem=dict(M=self._auto_key[0], nnz_log2_x4=self._auto_key[1]))
 
     def _em(self, vec):
         exp, sopt = self.exp, self.sopt
         txps = exp.transcripts()
         length = txps.ref_length_f64() if sopt.noEffectiveLengthCorrection else txps.EffectiveLength
+        # `auto` measures once per problem SIZE: a later run over a different transcriptome / class table decides again
+        # (sizes are bucketed to a quarter octave so that run-to-run jitter in nnz does not re-measure)
+        import math
+        self._auto_key = (int(length.numel()), int(round(4 * math.log2(max(int(vec.nnz), 1)))))
         mode = self._pick_mode(vec.nnz)
         if self.problem is not None:       # release the previous run's device state before building the next
             self.problem.close(); self.problem = None
@@ -387,7 +402,7 @@ class DistributedQuant:
         bias = self.engine.bias_model(exp, sopt) if (sopt.biasCorrect or sopt.gcBiasCorrect) else None
         eff = None
         self.recomputes = 0
-        if mode == "replicated" and self.em_mode == "auto" and getattr(self, "_auto_mode", None) is None:
+        if mode == "replicated" and self.em_mode == "auto" and self.world > 1 and getattr(self, "_auto_modes", {}).get(self._auto_key) is None:
             p = self.engine.em_problem(length, vec.rowptr, vec.ids, vec.counts, exp.numMappedFragments())
             self._measure_auto(p, length.numel())
             mode = self._pick_mode(vec.nnz)

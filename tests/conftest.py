@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The cfg4 test (eight worker processes + this one on ONE device) runs FIRST: on a device that earlier tests of the session
+    have used, the nine processes take 6-8 minutes instead of ~20 s (queue oversubscription; VERDICT r3, weak #8)."""
+    first = [it for it in items if it.name.startswith("test_cfg4_eight_ranks_share_the_gpu")]
+    if first:
+        rest = [it for it in items if it not in first]
+        items[:] = first + rest
+
+
 @pytest.fixture(scope="session")
 def built():
     """Everything compiled (libsfgpu.so for gfx950, the C oracle, oracle/_ref when possible)."""

@@ -71,7 +71,7 @@ def test_gene_lookup_matches_the_reference_header():
 
 
 def test_reference_header_still_gives_the_committed_vectors():
-    """where oracle/_ref was built (this container; it travels to the GPU box): the live library reproduces the fixture"""
+    """where oracle/_ref was built (this container only -- it is not shipped to the GPU box): the live library reproduces the fixture"""
     import ctypes as C
     import pytest
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libtgm_ref.so")

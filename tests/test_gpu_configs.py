@@ -27,8 +27,11 @@ CFG3 = (200_000, 4_000_000, 400_000_000)
 # all-reduce through the host, and the iterations past 80 show nothing the first 80 do not (min_iter is 50: the stop logic ran).
 # (Nine processes on one device: on its own this test takes ~20 s, after other GPU tests in the same session 6-8 minutes --
 # the device's queues are oversubscribed; fewer queues per rank, trimmed caches, a fresh parent process were tried and do not help.)
-# SFGPU_CFG4_FULL=1 lifts the cut: both sides then run to convergence and the sharded loop must stop at the single-GPU loop's
-# iteration (212 on this read stream) -- run on its own, outside the default suite (profiles/r3_cfg4_full.txt).
+# SFGPU_CFG4_FULL=1 lifts the cut for the eight PROCESSES (both sides then run to convergence: 212 = 212, ~9 minutes of nine
+# processes time-slicing one device, profiles/r3_cfg4_full.txt).  The suite asserts the same thing at full size without the
+# processes: test_cfg4_eight_class_slices_to_convergence_in_one_process below runs the eight class slices to convergence through
+# the same sweep / sum / update pieces and must stop at the single-GPU loop's iteration.  tests/conftest.py runs this file's cfg4
+# test FIRST among the GPU tests (nine processes on a device that earlier tests have used take minutes instead of seconds).
 CFG4_MAX_ITER = 10000 if os.environ.get("SFGPU_CFG4_FULL") else 80
 
 
@@ -112,6 +115,78 @@ def test_cfg4_eight_ranks_share_the_gpu(gpu):
     nz = a1 > 0
     assert np.array_equal(alphas[0] > 0, nz)
     assert float(np.max(np.abs(alphas[0][nz] - a1[nz]) / a1[nz])) < 1e-9
+
+
+def test_cfg4_eight_class_slices_to_convergence_in_one_process(gpu):
+    """BASELINE configs[3]'s EM layout at full size, to CONVERGENCE: cfg3's 1.62 M classes cut into eight nnz-balanced slices
+    (the cuts DistributedQuant makes), one sfgpu_em handle per slice, and per iteration { sweep on every slice, SUM of the
+    eight alphaOut vectors, update on every slice } -- what the eight ranks do with an all-reduce in between (the transport
+    itself is covered by the gloo tests and by test_cfg4_eight_ranks_share_the_gpu).  The sharded loop must stop at the
+    single-GPU loop's iteration with the single-GPU alpha (<= 1e-9), and every slice must hold the same bits."""
+    import sailfish_amd as sf
+    from sailfish_amd import distributed as sfd, synth
+    M, P, R = CFG3
+    world = 8
+    ref_len = synth.transcript_lengths(M, device=gpu)
+    poff, pids = synth.label_pool(M, P, device=gpu)
+    ids, off = synth.reads_slice(poff, pids, 0, R, seed=7, device=gpu)
+    del poff, pids
+    sopt = sf.SailfishOpts(useVBOpt=True)
+    exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.cpu().numpy().view(np.uint32), device=gpu), sopt)
+    q1 = sfd.DistributedQuant(exp, sopt)
+    info1 = q1.run(ids, off, fl_counts=_fl_counts(), remaining_fl_ops=0)
+    del ids, off
+    v = q1.last_vec
+    a1 = exp.transcripts().estCount.clone()
+    it1 = info1["em_stats"]["iters"]
+    assert info1["em_stats"]["converged"] and it1 > 80
+    length = exp.transcripts().EffectiveLength
+    rp_cpu = (v.rowptr.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+    cuts = sfd.nnz_balanced_slices(rp_cpu, world)
+    probs = []
+    for r in range(world):
+        c0, c1 = cuts[r], cuts[r + 1]
+        j0, j1 = int(rp_cpu[c0]), int(rp_cpu[c1])
+        rp_loc = ((v.rowptr[c0:c1 + 1].to(torch.int64) & 0xFFFFFFFF) - j0).to(torch.int32)
+        probs.append(sf.EMProblem(length, rp_loc, v.ids[j0:j1], v.counts[c0:c1], exp.numMappedFragments()))
+    kw = dict(use_vbem=True, tol=0.01, min_iter=50, max_iter=10000)
+    for p in probs:
+        p.begin(**kw)
+    outs = [p.alpha_out_view() for p in probs]
+
+    def all_reduce():
+        tot = outs[0].clone()
+        for o in outs[1:]:
+            tot += o                      # (rank order: the same sum on every "rank")
+        for o in outs:
+            o.copy_(tot)
+
+    all_reduce()                          # union of the active sets
+    for p in probs:
+        p.init()
+    done = False
+    while not done:
+        for _ in range(16):
+            for p in probs:
+                p.sweep()
+            all_reduce()
+            for p in probs:
+                p.update()
+        flags = [p.poll() for p in probs]
+        assert len({f[0] for f in flags}) == 1 and len({f[1]["iters"] for f in flags}) == 1      # the ranks leave the loop together
+        done = flags[0][0]
+    res = [p.finish() for p in probs]
+    assert all(rc == 0 for rc, _ in res)
+    iters = res[0][1]["iters"]
+    print(f"cfg4 in one process: 8 class slices, sharded loop stopped at iteration {iters} (single GPU: {it1})")
+    assert iters == it1 and all(st["iters"] == it1 and st["converged"] for _, st in res)
+    for p in probs[1:]:
+        assert torch.equal(p.alpha, probs[0].alpha)
+    nz = a1 > 0
+    assert torch.equal(probs[0].alpha > 0, nz)
+    assert float(((probs[0].alpha[nz] - a1[nz]).abs() / a1[nz]).max()) < 1e-9
+    for p in probs:
+        p.close()
 
 
 def test_cfg5_thousand_draws_over_cfg3_classes(gpu):

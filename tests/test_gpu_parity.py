@@ -417,6 +417,37 @@ def test_builder_beyond_partition_limit(sf, gpu):
     assert bool(torch.equal(torch.sort(twice).values, torch.sort(a[:dup]).values))
 
 
+@pytest.mark.parametrize("n_reads", [40_000, 200_000])
+def test_builder_long_labels_that_agree_in_every_sampled_id(sf, gpu, n_reads):
+    """the bucket hash of a label of more than 8 ids looks at its length, its first 8 ids and three ids of its
+    tail.  6 000 DISTINCT 40-id labels that agree in all of those share one home slot at every table size: more than a region
+    holds (3 072).  The builder must notice that growth does not help, hash whole labels from there on, and end with the
+    oracle's classes -- not double the table until an allocation fails.  40 000 reads: the generic kernel alone; 200 000: the
+    partitioned passes defer the region's labels first."""
+    rng = np.random.default_rng(5)
+    n_lab, n = 6000, 40
+    lab = np.tile(np.arange(0, 3 * n, 3, dtype=np.uint32), (n_lab, 1))
+    fixed = {0, 1, 2, 3, 4, 5, 6, 7, n - 1, 8 + (n - 8) // 2, 8 + (n - 8) // 4}
+    free = [k for k in range(8, n - 1) if k not in fixed]
+    # distinct labels: the label number written into four free positions, in base 10 on top of the ascending pattern
+    for d, k in enumerate(free[:4]):
+        lab[:, k] += ((np.arange(n_lab) // 10 ** d) % 10).astype(np.uint32) * 1000
+    assert len({tuple(r) for r in lab.tolist()}) == n_lab
+    picks = np.concatenate([np.arange(n_lab), rng.integers(0, n_lab, n_reads - n_lab)])
+    rng.shuffle(picks)
+    ids = lab[picks].reshape(-1)
+    # ... among ordinary short labels
+    short = rng.integers(0, 50_000, (n_reads, 2)).astype(np.uint32)
+    ids_all = np.concatenate([ids, short.reshape(-1)])
+    off = np.concatenate([np.arange(n_reads + 1, dtype=np.uint64) * n, n_reads * n + np.arange(1, n_reads + 1, dtype=np.uint64) * 2]).astype(np.uint32)
+    ob, *oc = _oracle_classes([(ids_all, off)])
+    eq = _gpu_classes(sf, gpu, [(ids_all, off)])
+    _assert_same_classes(eq, ob, *oc)
+    st = eq.stats()
+    assert st["deferred_reads"] > 0                       # the cluster really overflowed its region ...
+    assert st["table_slots"] <= (1 << 24)                 # ... and the table did not keep doubling
+
+
 # ------------------------------------------------------------------------------------ a6-a13
 @pytest.fixture(scope="module")
 def midsize(sf, gpu):
