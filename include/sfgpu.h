@@ -140,6 +140,7 @@ typedef struct {
     uint64_t table_slots;
     uint64_t hot_reads;       /* reads whose class was already hot and that the route pass counted itself */
     uint64_t spilled_reads;   /* reads of the partitioned passes that went to the generic kernel (bin overflow, long labels) */
+    uint64_t pipeline_drains; /* times the pipelined partition passes had to run dry (table growth, deferred reads, reallocation) */
 } sfgpu_eq_stats;
 SFGPU_API int sfgpu_eq_get_stats(sfgpu_eq* eq, sfgpu_eq_stats* out);
 /* finish() :64-80: snapshot into the canonical class order (first id, XXH64, length, label --

@@ -42,7 +42,7 @@ class EmStats(C.Structure):
 class EqStats(C.Structure):
     _fields_ = [("insert_ms", C.c_double), ("insert_launches", C.c_uint64), ("table_grows", C.c_uint64),
                 ("deferred_reads", C.c_uint64), ("table_slots", C.c_uint64),
-                ("hot_reads", C.c_uint64), ("spilled_reads", C.c_uint64)]
+                ("hot_reads", C.c_uint64), ("spilled_reads", C.c_uint64), ("pipeline_drains", C.c_uint64)]
 
 
 _LOG_CB = C.CFUNCTYPE(None, C.c_int, C.c_char_p)

@@ -45,7 +45,7 @@ constexpr int kBlock = 256;
 
 // ctr[0] = classes created by this launch, ctr[1] = deferred reads, ctr[2] = arena cursor (words),
 // ctr[3] = scratch (long-label count / read total), ctr[4] = nnz read back at finish
-enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_TMP = 3, CTR_NNZ = 4, CTR_PEEK = 5, CTR_HOT = 8, CTR_N = 12 };     // CTR_PEEK..+2: offsets read ahead for the host
+enum { CTR_NEW = 0, CTR_DEFER = 1, CTR_ARENA = 2, CTR_TMP = 3, CTR_NNZ = 4, CTR_PEEK = 5, CTR_HOT = 8, CTR_GCLS = 9, CTR_N = 12 };     // CTR_PEEK..+2: offsets read ahead for the host; CTR_GCLS: classes committed (the partition passes number new classes from it)
 
 // ---- label arena ------------------------------------------------------------------------------
 // A committed class keeps its label in the arena as one ENTRY: [len, id0, id1, ...], zero-padded to a
@@ -198,7 +198,11 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
         s = region_next(s);
     }
     // deferred reads are replayed one by one with their own weights: a deferred leader takes the reads it absorbed along
-    const bool follow = absorbed && __shfl((int)was_deferred, leader_of, kWave) != 0;
+    // (the shuffle runs in EVERY lane, before the test: inside `absorbed && shfl(...)` it would execute with the leader's lane
+    //  masked off -- leaders are never absorbed -- and read 0 from it: the followers of a deferred leader were then dropped.
+    //  Found in round 4 by test_builder_long_labels_that_agree_in_every_sampled_id: 11 of 40 000 reads lost.)
+    const bool leader_deferred = __shfl((int)was_deferred, leader_of, kWave) != 0;
+    const bool follow = absorbed && leader_deferred;
     if (was_deferred || follow) {
         unsigned long long d = atomicAdd(&ctr[CTR_DEFER], 1ull);
         deferred[d] = r;
@@ -404,7 +408,23 @@ struct sfgpu_eq {
     // its size: 100 M reads in 1 M-read batches took 34 ms instead of 5 ms)
     DevBuf<uint32_t> dacc_ids, dacc_off;
     uint32_t dacc_n_reads = 0; uint64_t dacc_n_ids = 0;
-    DevBuf<unsigned long long> hot_buf;     // hot classes for k_part_route: kHotSlots hashes, kHotSlots (arena granule, slot) pairs, the count
+    // hot classes for k_part_route: kHotSlots hashes, kHotSlots (arena granule, slot) pairs, the count.  Two copies: the pipelined
+    // path (eq_pipeline) rebuilds the table for sub-batch k + 1 while the route pass of sub-batch k still reads the other one
+    DevBuf<unsigned long long> hot_bufs[2]; int hot_cur = 0;
+    // ---- pipelined partition passes (eq_pipeline): route(k + 1) runs next to insert(k) on a second stream; two sets of bins
+    struct PartSet {
+        DevBuf<uint32_t> words, hist, longl, deferred;
+        unsigned long long* d_ctr = nullptr;                  // CTR_N counters of the sub-batch in this set
+        unsigned long long* h_ctr = nullptr;                  // pinned: [0, CTR_N) this set's counters, [CTR_N, 2 CTR_N) the builder's (arena cursor, classes)
+        hipEvent_t ev_route = nullptr, ev_ins = nullptr;
+        uint32_t first = 0, cnt = 0, n_blocks = 0; uint64_t n_words = 0, cap = 0;
+        bool in_flight = false, fix = false;                  // launched and not yet collected / has deferred or spilled reads to replay
+        uint64_t n_def = 0, n_long = 0;
+    } pset[2];
+    hipStream_t ins_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_hot = nullptr, ev_join = nullptr;
+    DevBuf<uint32_t> grid_dev; uint32_t* grid_host = nullptr; uint64_t grid_cap = 0;     // offsets at the sub-batch grid (pinned copy)
+    bool use_pipe = false;      // SFGPU_EQ_PIPE=1: measured no faster than the serial form (profiles/r4_class_build_notes.md), so not the default
     uint64_t reads_seen = 0;                // reads added since start()
     uint64_t hot_cap = 0, hot_reads = 0;    // table size and reads_seen when the hot table was last rebuilt
     uint32_t hot_slots = 0;                 // ... and the number of slots it was laid out for
@@ -457,6 +477,7 @@ static int eq_reset(sfgpu_eq* eq) {
     eq->finished = false; eq->n_classes = 0; eq->arena_used = 0; eq->nnz = 0; eq->total_reads = 0;
     eq->acc_n_ids = 0; eq->acc_n_reads = 0; eq->dacc_n_reads = 0; eq->dacc_n_ids = 0;
     eq->reads_seen = 0; eq->hot_cap = 0; eq->hot_reads = 0; eq->mix_mode = kMixSampled;
+    for (auto& S : eq->pset) { S.in_flight = false; S.fix = false; }
     uint64_t want = pow2_at_least(2 * (eq->expected ? eq->expected : 1000000ull) + 2 * kSlack);
     if (eq->table.p && eq->cap == want) {
         hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
@@ -489,6 +510,7 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     eq->expected = expected_classes;
     if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) { eq->sub_batch = (uint32_t)v; eq->part_sub_batch = (uint32_t)v; } }
     if (const char* e = getenv("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
+    if (const char* e = getenv("SFGPU_EQ_PIPE")) eq->use_pipe = atoi(e) != 0;
     hipError_t e1 = pool_malloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
     hipError_t e2 = pinned_malloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long));
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
@@ -514,6 +536,15 @@ int sfgpu_eq_destroy(sfgpu_eq* eq) {
     if (eq->ev1) (void)hipEventDestroy(eq->ev1);
     if (eq->copy_stream) { (void)hipStreamSynchronize(eq->copy_stream); stream_release(eq->copy_stream); }
     for (int i = 0; i < 2; ++i) if (eq->ev_copy[i]) (void)hipEventDestroy(eq->ev_copy[i]);
+    if (eq->ins_stream) { (void)hipStreamSynchronize(eq->ins_stream); stream_release(eq->ins_stream); }
+    for (hipEvent_t ev : {eq->ev_fork, eq->ev_hot, eq->ev_join}) if (ev) (void)hipEventDestroy(ev);
+    for (auto& S : eq->pset) {
+        if (S.d_ctr) pool_free(S.d_ctr);
+        if (S.h_ctr) pinned_free(S.h_ctr);
+        if (S.ev_route) (void)hipEventDestroy(S.ev_route);
+        if (S.ev_ins) (void)hipEventDestroy(S.ev_ins);
+    }
+    if (eq->grid_host) pinned_free(eq->grid_host);
     delete eq;
     return SFGPU_OK;
 }
@@ -596,10 +627,120 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
     return SFGPU_OK;
 }
 
+
+// geometry of one partitioned sub-batch (direct form of pass 1): blocks of pass 1, reads per block, granules per bin.
+// Bin capacity in 16-byte granules: a label of n ids takes ceil((n + 1) / 4) <= (n + 4) / 4 granules, so (ids + 4 reads) / 4 bounds
+// the stream from above; a bin gets its share of that bound plus 25 % and a constant -- the share is a sum of ~mean / 1.6
+// independent labels, so this is > 6 standard deviations for hashed labels.  A region far above its share (one label holding a
+// large part of the reads) overflows into the generic kernel's list.  Rounded to whole 128-byte lines.
+struct PartGeom { uint32_t n_blocks, tile; uint64_t cap, n_bins; };
+static PartGeom part_geometry(uint32_t cnt, uint64_t n_words, uint32_t n_regions, uint32_t mb) {
+    PartGeom g;
+    if (mb > 1024u) mb = 1024u;
+    g.n_blocks = (cnt + 2047u) / 2048u; if (g.n_blocks > mb) g.n_blocks = mb; if (g.n_blocks == 0) g.n_blocks = 1;     // (>= 2 steps per wavefront)
+    g.tile = (uint32_t)((((uint64_t)cnt + g.n_blocks - 1) / g.n_blocks + 63) & ~63ull);     // whole wavefront steps
+    g.n_bins = (uint64_t)n_regions * g.n_blocks;
+    const uint64_t stream_gr = (n_words + 4ull * cnt) / 4 + 1;
+    g.cap = (stream_gr + g.n_bins - 1) / g.n_bins;
+    g.cap = g.cap + g.cap / 4 + 48;
+    g.cap = (g.cap + 7) & ~7ull;
+    return g;
+}
+static uint32_t part_max_blocks() {
+    static const uint32_t v = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long x = e ? atol(e) : 512; return (uint32_t)(x >= 1 && x <= 1024 ? x : 512); }();
+    return v;
+}
+static uint64_t part_load_div() {
+    static const uint64_t v = []() { const char* e = getenv("SFGPU_EQ_LOAD_DIV"); long x = e ? atol(e) : 2; return (uint64_t)(x >= 2 && x <= 8 ? x : 2); }();
+    return v;
+}
+
+// Hot classes: a label that already holds more than 1/8 of a region's fair share of the reads (1.25x the share is what a
+// region's bins hold) is counted in the route pass itself.  Real RNA-seq is skewed like that -- a highly expressed gene
+// holds percents of the reads -- and without this its region overflows into the generic kernel read after read (measured
+// on 50 M reads: 10 % on one label 76 ms, 50 % on 100 labels 22 ms, for a 2.4 ms build).  The table is rebuilt when the
+// class table has grown (slots moved) and each time the reads seen have quadrupled; the first sub-batch of a builder is
+// kept small (see eq_add_locked) so that the hot classes are known before the bulk of the reads arrives.
+// `into`: which of the two buffers to (re)build when a rebuild is due; `reads`: reads the table holds when the kernel runs;
+// `have_classes`: the table may hold classes.  *rebuilt = true when `into` was written (the caller then makes it current).
+static int eq_hot_refresh(sfgpu_eq* eq, uint32_t n_regions, uint32_t hs, hipStream_t st, int into, uint64_t reads, bool have_classes, bool* rebuilt) {
+    int rc;
+    *rebuilt = false;
+    for (auto& b : eq->hot_bufs)
+        if (!b.p) {
+            if ((rc = b.reserve(2ull * kHotSlots + 2, st, false))) return rc;
+            SF_HIP(hipMemsetAsync(b.p, 0, (2ull * kHotSlots + 2) * 8, st));
+            eq->hot_cap = 0; eq->hot_reads = 0;
+        }
+    // (the ring form's LDS leaves room for kRingHotSlots entries: the table is laid out for the form the sub-batch takes)
+    unsigned long long* hot_h = eq->hot_bufs[into].p;
+    uint2* hot_meta = reinterpret_cast<uint2*>(hot_h + hs);
+    unsigned int* n_hot = reinterpret_cast<unsigned int*>(hot_h + 2ull * hs);
+    if (have_classes && reads && (eq->hot_cap != eq->cap || eq->hot_slots != hs || reads >= 4 * eq->hot_reads)) {
+        const unsigned long long thr = std::max<unsigned long long>(64ull, reads / (8ull * n_regions));
+        SF_HIP(hipMemsetAsync(hot_h, 0, (2ull * kHotSlots + 2) * 8, st));
+        hipLaunchKernelGGL(k_hot_select, dim3(grid_for(eq->cap)), dim3(kBlock), 0, st, eq->table.p, eq->cap, thr, eq->arena.p, hot_h, hot_meta, n_hot, hs, eq->mix_mode);
+        SF_CHECK_LAUNCH();
+        eq->hot_cap = eq->cap; eq->hot_reads = reads; eq->hot_slots = hs;
+        *rebuilt = true;
+    } else if (eq->hot_cap != eq->cap || eq->hot_slots != hs) {                 // (an empty table: nothing is hot)
+        SF_HIP(hipMemsetAsync(hot_h, 0, (2ull * kHotSlots + 2) * 8, st));
+        eq->hot_cap = eq->cap; eq->hot_reads = reads; eq->hot_slots = hs;
+        *rebuilt = true;
+    }
+    return SFGPU_OK;
+}
+
+static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t todo,
+                      const uint32_t* list, const uint64_t* d_weights);
+// what a partitioned sub-batch leaves for the generic kernel: labels whose home region was full (deferred: copied out of the
+// bins, the table grown, inserted the generic way) and reads that never entered the stream (bin overflow, over-long labels).
+// The table must be quiescent (no partition pass in flight); synchronises eq->stream.
+static int eq_part_fixups(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, const uint32_t* bins_words, const uint32_t* deferred,
+                          const uint32_t* long_list, uint64_t n_def, uint64_t n_long) {
+    hipStream_t st = eq->stream;
+    int rc;
+    eq->stats.spilled_reads += n_long;
+    if (n_def) {
+        eq->stats.deferred_reads += n_def;
+        if ((rc = eq->def_lens.reserve(n_def + 1, st, false)) || (rc = eq->def_off64.reserve(n_def + 2, st, false)) ||
+            (rc = eq->def_off.reserve(n_def + 1, st, false))) return rc;
+        hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, deferred, eq->def_lens.p);
+        SF_CHECK_LAUNCH();
+        if ((rc = exclusive_scan_u32(eq->def_lens.p, eq->def_off64.p, n_def, st))) return rc;
+        uint64_t tot = 0;
+        SF_HIP(hipMemcpyAsync(&tot, eq->def_off64.p + n_def, 8, hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        if ((rc = eq->def_ids.reserve(tot + 1, st, false))) return rc;
+        if ((rc = eq->def_w.reserve(n_def + 1, st, false))) return rc;
+        hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, deferred,
+                           reinterpret_cast<const uint4*>(bins_words), eq->def_off64.p, eq->def_ids.p, eq->def_off.p, eq->def_w.p);
+        SF_CHECK_LAUNCH();
+        // worst case every deferred label opens a class
+        {
+            const uint64_t need = eq->arena_used + tot + 4 * n_def + 4;
+            SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
+            if ((rc = eq->arena.reserve(need, st, true, eq->arena_used))) return rc;
+        }
+        if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
+        // (the deferred list may be eq->deferred_a, which eq_generic reuses: the copies above are complete -- eq_grow synchronised)
+        if ((rc = eq_generic(eq, eq->def_ids.p, eq->def_off.p, 0, (uint32_t)n_def, nullptr, eq->def_w.p))) return rc;
+    }
+    if (n_long) {        // labels too long for an LDS tile, reads that did not fit their bin
+        if ((rc = eq_generic(eq, d_ids, d_offsets, 0, (uint32_t)n_long, long_list, nullptr))) return rc;
+    }
+    if (n_def || n_long) {      // the generic kernel's commits moved the arena cursor
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        eq->arena_used = eq->h_ctr[CTR_ARENA];
+    }
+    return SFGPU_OK;
+}
+
 // start of a partitioned sub-batch: zero its counters and fetch the offsets the host will want for the NEXT sub-batch (its
 // possible ends), so that they come back with this sub-batch's counters instead of in a round trip of their own
-__global__ void k_sub_batch_begin(unsigned long long* ctr, const uint32_t* __restrict__ offsets, uint64_t p0, uint64_t p1, uint64_t p2) {
-    if (threadIdx.x == 0) { ctr[CTR_NEW] = 0; ctr[CTR_DEFER] = 0; ctr[CTR_TMP] = 0; ctr[CTR_HOT] = 0; }
+__global__ void k_sub_batch_begin(unsigned long long* ctr, const uint32_t* __restrict__ offsets, uint64_t p0, uint64_t p1, uint64_t p2, unsigned long long n_classes) {
+    if (threadIdx.x == 0) { ctr[CTR_NEW] = 0; ctr[CTR_DEFER] = 0; ctr[CTR_TMP] = 0; ctr[CTR_HOT] = 0; ctr[CTR_GCLS] = n_classes; }
     if (threadIdx.x == 1) ctr[CTR_PEEK + 0] = offsets[p0];
     if (threadIdx.x == 2) ctr[CTR_PEEK + 1] = offsets[p1];
     if (threadIdx.x == 3) ctr[CTR_PEEK + 2] = offsets[p2];
@@ -614,8 +755,9 @@ static int device_cus() {
     return n;
 }
 
-// radix-partitioned path for one sub-batch (see eqclass_part.h).  n_words = ids in the sub-batch.  peek[3] = positions in
-// d_offsets whose values are returned in eq->h_ctr[CTR_PEEK..]
+// radix-partitioned path for one sub-batch (see eqclass_part.h), SERIAL form: route, insert, one host round trip.  Small batches,
+// batches with a caller-chosen sub-batch size and the ring form of pass 1 come here; large batches take eq_pipeline below.
+// n_words = ids in the sub-batch.  peek[3] = positions in d_offsets whose values are returned in eq->h_ctr[CTR_PEEK..]
 static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t cnt,
                           uint64_t n_words, const uint64_t* peek) {
     hipStream_t st = eq->stream;
@@ -626,7 +768,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     // halves the number of regions: pass 2 is one block per region, two blocks per CU, and fewer, longer-lived
     // blocks amortise the region load / write-back and the per-block ramp (cfg3, 1.6 M classes: 2048 -> 1024
     // regions, class build 22.8 -> 21.5 ms; cfg2 unchanged).
-    static const uint64_t load_div = []() { const char* e = getenv("SFGPU_EQ_LOAD_DIV"); long v = e ? atol(e) : 2; return (uint64_t)(v >= 2 && v <= 8 ? v : 2); }();
+    const uint64_t load_div = part_load_div();
     while (eq->n_classes + kMinHeadroom > eq->cap / load_div) {
         if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
     }
@@ -650,65 +792,29 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     // 4 wavefronts per SIMD and the pass is bound by instruction issue there: cfg3 9.4 ms per build against 9.7 under rocprofv3,
     // no difference in the bench step, and skewed / sorted streams and cfg2 are 10-80 % slower (profiles/r3_class_build_notes.md)
     const int ring_mode = []() { const char* e = getenv("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();      // (read per sub-batch: tests switch it)
-    static const uint32_t max_blocks = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long v = e ? atol(e) : 512; return (uint32_t)(v >= 1 && v <= 1024 ? v : 512); }();
     static const uint32_t ring_blocks = []() { const char* e = getenv("SFGPU_EQ_RING_BLOCKS"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 0); }();
     bool ring = ring_mode != 0 && n_regions >= 2 && n_regions <= kRingMaxRegions;
-    uint32_t n_blocks, tile;
-    uint64_t cap, n_bins;
-    for (;;) {
-        uint32_t mb = ring ? (ring_blocks ? ring_blocks : (uint32_t)device_cus()) : max_blocks;
-        if (mb > 1024u) mb = 1024u;
-        n_blocks = (cnt + 2047u) / 2048u; if (n_blocks > mb) n_blocks = mb; if (n_blocks == 0) n_blocks = 1;     // (>= 2 steps per wavefront)
-        tile = (uint32_t)((((uint64_t)cnt + n_blocks - 1) / n_blocks + 63) & ~63ull);     // whole wavefront steps
-    // Bin capacity in 16-byte granules.  A label of n ids takes ceil((n + 1) / 4) <= (n + 4) / 4 granules, so
-    // (ids + 4 reads) / 4 bounds the stream from above; a bin gets its share of that bound plus 25 % and a constant --
-    // the share is a sum of ~mean / 1.6 independent labels, so this is > 6 standard deviations for hashed labels.  A
-    // region far above its share (one label holding a large part of the reads) overflows into the generic kernel's
-    // list.  Rounded to whole 128-byte lines.
-        n_bins = (uint64_t)n_regions * n_blocks;
-        const uint64_t stream_gr = (n_words + 4ull * cnt) / 4 + 1;
-        cap = (stream_gr + n_bins - 1) / n_bins;
-        cap = cap + cap / 4 + 48;
-        cap = (cap + 7) & ~7ull;
-        if (ring && cap > kRingMaxCap) { ring = false; continue; }       // (16-bit cursors: few regions and a huge sub-batch take the direct form)
-        break;
+    PartGeom gm = part_geometry(cnt, n_words, n_regions, ring ? (ring_blocks ? ring_blocks : (uint32_t)device_cus()) : part_max_blocks());
+    if (ring && gm.cap > kRingMaxCap) {       // (16-bit cursors: few regions and a huge sub-batch take the direct form)
+        ring = false;
+        gm = part_geometry(cnt, n_words, n_regions, part_max_blocks());
     }
+    const uint32_t n_blocks = gm.n_blocks, tile = gm.tile;
+    const uint64_t cap = gm.cap, n_bins = gm.n_bins;
     // positions inside the bins are 31-bit granule indices (bit 31 of a slot's rep marks arena entries)
     SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 granules");
     if ((rc = eq->part_words.reserve(n_bins * cap * 4 + 8, st, false))) return rc;
     if ((rc = eq->part_hist.reserve(4 * n_bins + 1, st, false))) return rc;      // fill of every bin (front, back) + the ring form's cut marks
     if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
     if ((rc = eq->deferred_a.reserve(2ull * cnt, st, false))) return rc;
-    hipLaunchKernelGGL(k_sub_batch_begin, dim3(1), dim3(64), 0, st, eq->d_ctr, d_offsets, peek[0], peek[1], peek[2]);   // CTR_NEW, CTR_DEFER, long-label counter
+    hipLaunchKernelGGL(k_sub_batch_begin, dim3(1), dim3(64), 0, st, eq->d_ctr, d_offsets, peek[0], peek[1], peek[2], (unsigned long long)eq->n_classes);   // CTR_NEW, CTR_DEFER, long-label counter
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev0, st));
     uint4* bins = reinterpret_cast<uint4*>(eq->part_words.p);
-    // Hot classes: a label that already holds more than 1/8 of a region's fair share of the reads (1.25x the share is what a
-    // region's bins hold) is counted in the route pass itself.  Real RNA-seq is skewed like that -- a highly expressed gene
-    // holds percents of the reads -- and without this its region overflows into the generic kernel read after read (measured
-    // on 50 M reads: 10 % on one label 76 ms, 50 % on 100 labels 22 ms, for a 2.4 ms build).  The table is rebuilt when the
-    // class table has grown (slots moved) and each time the reads seen have quadrupled; the first sub-batch of a builder is
-    // kept small (see eq_add_locked) so that the hot classes are known before the bulk of the reads arrives.
-    if (!eq->hot_buf.p) {
-        if ((rc = eq->hot_buf.reserve(2ull * kHotSlots + 2, st, false))) return rc;
-        SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
-        eq->hot_cap = 0; eq->hot_reads = 0;
-    }
-    // (the ring form's LDS leaves room for kRingHotSlots entries: the table is laid out for the form this sub-batch takes)
     const uint32_t hs = ring ? kRingHotSlots : kHotSlots;
-    unsigned long long* hot_h = eq->hot_buf.p;
-    uint2* hot_meta = reinterpret_cast<uint2*>(hot_h + hs);
-    unsigned int* n_hot = reinterpret_cast<unsigned int*>(hot_h + 2ull * hs);
-    if (eq->n_classes && eq->reads_seen && (eq->hot_cap != eq->cap || eq->hot_slots != hs || eq->reads_seen >= 4 * eq->hot_reads)) {
-        const unsigned long long thr = std::max<unsigned long long>(64ull, eq->reads_seen / (8ull * n_regions));
-        SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
-        hipLaunchKernelGGL(k_hot_select, dim3(grid_for(eq->cap)), dim3(kBlock), 0, st, eq->table.p, eq->cap, thr, eq->arena.p, hot_h, hot_meta, n_hot, hs, eq->mix_mode);
-        SF_CHECK_LAUNCH();
-        eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen; eq->hot_slots = hs;
-    } else if (eq->hot_cap != eq->cap || eq->hot_slots != hs) {                 // (an empty table: nothing is hot)
-        SF_HIP(hipMemsetAsync(eq->hot_buf.p, 0, (2ull * kHotSlots + 2) * 8, st));
-        eq->hot_cap = eq->cap; eq->hot_reads = eq->reads_seen; eq->hot_slots = hs;
-    }
+    bool rebuilt = false;
+    if ((rc = eq_hot_refresh(eq, n_regions, hs, st, eq->hot_cur, eq->reads_seen, eq->n_classes != 0, &rebuilt))) return rc;
+    unsigned long long* hot_h = eq->hot_bufs[eq->hot_cur].p;
     uint32_t* fill_f = eq->part_hist.p, *fill_b = fill_f + n_bins, *cutmarks = fill_b + n_bins;
     RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
                  eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode};
@@ -726,7 +832,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     }
     SF_CHECK_LAUNCH();
     PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                eq->arena.p, eq->d_ctr, eq->deferred_a.p, eq->n_classes, eq->mix_mode};
+                eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode};
     hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev1, st));
@@ -737,38 +843,265 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     eq->n_classes += eq->h_ctr[CTR_NEW];
     eq->arena_used = eq->h_ctr[CTR_ARENA];
     const uint64_t n_def = eq->h_ctr[CTR_DEFER], n_long = eq->h_ctr[3];
-    eq->stats.hot_reads += eq->h_ctr[CTR_HOT]; eq->stats.spilled_reads += n_long;
-    if (n_def) {         // labels whose home region was full: copy them out, grow, insert them the generic way
-        eq->stats.deferred_reads += n_def;
-        if ((rc = eq->def_lens.reserve(n_def + 1, st, false)) || (rc = eq->def_off64.reserve(n_def + 2, st, false)) ||
-            (rc = eq->def_off.reserve(n_def + 1, st, false))) return rc;
-        hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p, eq->def_lens.p);
-        SF_CHECK_LAUNCH();
-        if ((rc = exclusive_scan_u32(eq->def_lens.p, eq->def_off64.p, n_def, st))) return rc;
-        uint64_t tot = 0;
-        SF_HIP(hipMemcpyAsync(&tot, eq->def_off64.p + n_def, 8, hipMemcpyDeviceToHost, st));
-        SF_HIP(hipStreamSynchronize(st));
-        if ((rc = eq->def_ids.reserve(tot + 1, st, false))) return rc;
-        if ((rc = eq->def_w.reserve(n_def + 1, st, false))) return rc;
-        hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, eq->deferred_a.p,
-                           reinterpret_cast<const uint4*>(eq->part_words.p), eq->def_off64.p, eq->def_ids.p, eq->def_off.p, eq->def_w.p);
-        SF_CHECK_LAUNCH();
-        if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
-        // deferred_a is reused by eq_generic: the copies above are complete (eq_grow synchronised)
-        if ((rc = eq_generic(eq, eq->def_ids.p, eq->def_off.p, 0, (uint32_t)n_def, nullptr, eq->def_w.p))) return rc;
-    }
-    if (n_long) {        // labels too long for an LDS tile
-        if ((rc = eq_generic(eq, d_ids, d_offsets, 0, (uint32_t)n_long, eq->part_long.p, nullptr))) return rc;
-    }
-    if (n_def || n_long) {      // the generic kernel's commits moved the arena cursor
-        SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        SF_HIP(hipStreamSynchronize(st));
-        eq->arena_used = eq->h_ctr[CTR_ARENA];
-    }
-    return SFGPU_OK;
+    eq->stats.hot_reads += eq->h_ctr[CTR_HOT];
+    return eq_part_fixups(eq, d_ids, d_offsets, eq->part_words.p, eq->deferred_a.p, eq->part_long.p, n_def, n_long);
 }
 
 constexpr uint32_t kScoutReads = 1u << 19;      // the first sub-batch of a builder: enough reads to see which classes are hot
+
+// ---- the PIPELINED form of the partitioned path (round 4) ---------------------------------------------------------------
+// The serial form runs route(k), insert(k), a host round trip, route(k + 1), ...: the two passes never overlap although they lean
+// on different parts of a CU (route: scattered 16-byte stores, the memory path; insert: LDS probes and instruction issue), and
+// the device idles through every round trip.  Here the sub-batches of ONE large batch are laid out ahead of the device:
+//   * the offsets at every possible sub-batch boundary (a grid of kScoutReads reads) come back in one round trip per batch;
+//   * two sets of bins / counters: route(k + 1) fills one set on the builder's stream while insert(k) drains the other on a
+//     second stream (events order route(k) -> insert(k); the host has collected set k - 2 before it reuses it);
+//   * insert numbers its new classes from a device-side counter (PartArgs::gcls) and adds its counts with atomics (the route
+//     pass of the next sub-batch may be adding what it counted for hot classes), so neither needs what the host knows;
+//   * the host reads sub-batch k - 1's counters (pinned copy behind insert(k - 1)) AFTER enqueueing sub-batch k: it is one
+//     sub-batch behind the device, which always has the next route + insert queued;
+//   * everything that needs a quiescent table -- growth, the generic kernel for deferred / spilled reads, a reallocation of the
+//     arena or the class arrays -- DRAINS the pipeline first (both sets collected, both streams idle); the hot-class table is
+//     rebuilt on the insert stream into its second copy, one sub-batch behind, except around the scout (drained: the bulk
+//     must not start before the hot classes are known).
+// Returns in *consumed how many reads it took; the caller's serial loop continues from there (0: nothing suited the pipeline).
+__global__ void k_gather_offsets(const uint32_t* __restrict__ off, uint32_t n_reads, uint32_t g, uint32_t n_out, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    uint64_t pos = (uint64_t)i * g;
+    if (pos > n_reads) pos = n_reads;                 // (the last entry is the batch's end)
+    out[i] = off[pos];
+}
+__global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
+__global__ void k_zero_ctr(unsigned long long* ctr) { if (threadIdx.x < (unsigned)CTR_N) ctr[threadIdx.x] = 0ull; }
+
+static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads, uint32_t* consumed) {
+    *consumed = 0;
+    hipStream_t sr = eq->stream;
+    int rc;
+    if ((eq->cap >> kRegionBits) > (uint64_t)kMaxRegions) return SFGPU_OK;
+    if (!eq->ins_stream) {
+        SF_HIP(stream_acquire(&eq->ins_stream));
+        SF_HIP(hipEventCreateWithFlags(&eq->ev_fork, hipEventDisableTiming));
+        SF_HIP(hipEventCreateWithFlags(&eq->ev_hot, hipEventDisableTiming));
+        SF_HIP(hipEventCreateWithFlags(&eq->ev_join, hipEventDisableTiming));
+        for (auto& S : eq->pset) {
+            SF_HIP(pool_malloc(&S.d_ctr, CTR_N * sizeof(unsigned long long)));
+            SF_HIP(pinned_malloc(&S.h_ctr, 2 * CTR_N * sizeof(unsigned long long)));
+            SF_HIP(hipEventCreateWithFlags(&S.ev_route, hipEventDisableTiming));
+            SF_HIP(hipEventCreateWithFlags(&S.ev_ins, hipEventDisableTiming));
+        }
+    }
+    hipStream_t si = eq->ins_stream;
+    // ---- offsets at the grid of possible sub-batch boundaries: one round trip for the whole batch
+    const uint32_t g = kScoutReads;
+    const uint32_t n_grid = n_reads / g + 2;
+    if ((rc = eq->grid_dev.reserve(n_grid, sr, false))) return rc;
+    if (eq->grid_cap < n_grid) {
+        if (eq->grid_host) pinned_free(eq->grid_host);
+        eq->grid_host = nullptr; eq->grid_cap = 0;
+        uint64_t c = 1024; while (c < n_grid) c *= 2;
+        SF_HIP(pinned_malloc(&eq->grid_host, c * 4));
+        eq->grid_cap = c;
+    }
+    hipLaunchKernelGGL(k_gather_offsets, dim3(grid_for(n_grid)), dim3(kBlock), 0, sr, d_offsets, n_reads, g, n_grid, eq->grid_dev.p);
+    SF_CHECK_LAUNCH();
+    SF_HIP(hipMemcpyAsync(eq->grid_host, eq->grid_dev.p, (size_t)n_grid * 4, hipMemcpyDeviceToHost, sr));
+    SF_HIP(hipStreamSynchronize(sr));
+    const uint32_t* grid = eq->grid_host;
+    auto off_at = [&](uint64_t pos) -> uint32_t { return pos >= n_reads ? grid[n_grid - 1] : grid[pos / g]; };    // pos: a multiple of g, or the end
+    const uint64_t batch_words = (uint64_t)(uint32_t)(off_at(n_reads) - off_at(0));                           // (modulo 2^32 like the offsets themselves)
+
+    const uint64_t load_div = part_load_div();
+    int n_fly = 0;                                   // sets in flight (launched, not collected): 0, 1 or 2
+    int k = 0;                                       // sub-batches launched so far: sub-batch k uses set k & 1
+    uint64_t fly_reads = 0, fly_words = 0;           // what the sets in flight hold
+    double rate = 1.0;                               // new classes per read of the sub-batch collected last
+    bool timing = false;
+    int hot_next = -1;                               // copy of the hot table that becomes current with the next sub-batch (-1: none pending)
+    auto open_timing = [&]() -> int { if (!timing) { SF_HIP(hipEventRecord(eq->ev0, sr)); timing = true; } return SFGPU_OK; };
+
+    // collect the oldest set in flight: wait for its insert pass, take its counters
+    auto collect = [&](sfgpu_eq::PartSet& S) -> int {
+        SF_HIP(hipEventSynchronize(S.ev_ins));
+        const unsigned long long* h = S.h_ctr;
+        const uint64_t classes_before = eq->n_classes;
+        eq->n_classes = h[CTR_N + CTR_GCLS];
+        eq->arena_used = h[CTR_N + CTR_ARENA];
+        S.n_def = h[CTR_DEFER]; S.n_long = h[CTR_TMP];
+        S.fix = S.n_def != 0 || S.n_long != 0;
+        eq->stats.hot_reads += h[CTR_HOT];
+        eq->stats.insert_launches++;
+        rate = (double)(eq->n_classes - classes_before + 1) / (double)S.cnt;
+        fly_reads -= S.cnt; fly_words -= S.n_words;
+        eq->reads_seen += S.cnt;
+        S.in_flight = false; --n_fly;
+        return SFGPU_OK;
+    };
+    // drain: both sets collected, both streams idle, deferred / spilled reads replayed, the device's class counter in step
+    auto drain = [&]() -> int {
+        int r;
+        for (int j = 0; j < 2; ++j) {                // oldest first
+            sfgpu_eq::PartSet& S = eq->pset[(k + j) & 1];
+            if (S.in_flight && (r = collect(S))) return r;
+        }
+        SF_HIP(hipStreamSynchronize(si));
+        if (timing) {
+            SF_HIP(hipEventRecord(eq->ev1, sr));
+            SF_HIP(hipStreamSynchronize(sr));
+            float ms = 0.f; if (hipEventElapsedTime(&ms, eq->ev0, eq->ev1) == hipSuccess) eq->stats.insert_ms += ms;
+            timing = false;
+        } else SF_HIP(hipStreamSynchronize(sr));
+        bool fixed = false;
+        for (int j = 0; j < 2; ++j) {
+            sfgpu_eq::PartSet& S = eq->pset[(k + j) & 1];
+            if (!S.fix) continue;
+            S.fix = false; fixed = true;
+            if ((r = eq_part_fixups(eq, d_ids, d_offsets, S.words.p, S.deferred.p, S.longl.p, S.n_def, S.n_long))) return r;
+        }
+        if (fixed) {                                  // the generic kernel committed classes the device-side counter has not seen
+            hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, sr, eq->d_ctr + CTR_GCLS, (unsigned long long)eq->n_classes);
+            SF_CHECK_LAUNCH();
+        }
+        eq->stats.pipeline_drains++;
+        return SFGPU_OK;
+    };
+
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, sr, eq->d_ctr + CTR_GCLS, (unsigned long long)eq->n_classes);
+    SF_CHECK_LAUNCH();
+    SF_HIP(hipEventRecord(eq->ev_fork, sr));
+    SF_HIP(hipStreamWaitEvent(si, eq->ev_fork, 0));
+    // the arena and the class arrays hold what the sub-batches in flight can add in the worst case (every read a new class); they
+    // are sized once, for two sub-batches of the largest size, so that no reallocation (= drain) falls into the steady state
+    {
+        const uint64_t span = std::min<uint64_t>(n_reads, 2 * kMaxSubBatch);
+        const uint64_t words_span = std::min<uint64_t>(batch_words, (uint64_t)((double)batch_words / (double)n_reads * 1.25 * (double)span) + 1024);
+        const uint64_t need = eq->arena_used + words_span + 4 * span + 4;
+        SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
+        if ((rc = eq->arena.reserve(need, sr, true, eq->arena_used))) return rc;
+        const uint64_t cls_need = eq->n_classes + span + 1;
+        SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
+        if ((rc = eq->cls_hash.reserve(cls_need, sr, true, eq->n_classes)) || (rc = eq->cls_off.reserve(cls_need, sr, true, eq->n_classes)) ||
+            (rc = eq->cls_len.reserve(cls_need, sr, true, eq->n_classes)) || (rc = eq->cls_slot.reserve(cls_need, sr, true, eq->n_classes))) return rc;
+    }
+
+    uint32_t first = 0;
+    uint32_t step = eq->part_sub_batch;
+    const uint32_t usual_step = step;
+    bool scout = eq->reads_seen == 0 && n_reads > (1u << 22) && step > kScoutReads;
+    bool bail = false;
+    while (first < n_reads && !bail) {
+        uint32_t cnt = scout ? kScoutReads : ((n_reads - first < step) ? (n_reads - first) : step);
+        uint64_t n_words = (uint32_t)(off_at((uint64_t)first + cnt) - off_at(first));
+        while (n_words >= (1ull << 31) && cnt > (1u << 20)) {       // too many ids for 31-bit positions in the bins: halve
+            cnt = (cnt / 2 + g - 1) / g * g; step = cnt;
+            n_words = (uint32_t)(off_at((uint64_t)first + cnt) - off_at(first));
+        }
+        if (n_words >= (1ull << 31) || n_words < 64) { bail = true; break; }            // (the serial loop knows what to do with those)
+        // ---- table growth, from the classes the host knows of (one sub-batch behind; a region that overflows meanwhile only
+        //      defers its labels); capacity of the arena and the class arrays for the worst case of what is in flight + this
+        if (eq->n_classes + kMinHeadroom > eq->cap / load_div) {
+            if ((rc = drain())) return rc;
+            while (eq->n_classes + kMinHeadroom > eq->cap / load_div) if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
+        }
+        {
+            uint64_t need = eq->arena_used + fly_words + 4 * fly_reads + n_words + 4ull * cnt + 4;
+            uint64_t cls_need = eq->n_classes + fly_reads + cnt + 1;
+            if (need > eq->arena.cap || cls_need > eq->cls_hash.cap) {
+                if ((rc = drain())) return rc;
+                need = eq->arena_used + n_words + 4ull * cnt + 4; cls_need = eq->n_classes + cnt + 1;
+                SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
+                SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
+                if ((rc = eq->arena.reserve(need, sr, true, eq->arena_used))) return rc;
+                if ((rc = eq->cls_hash.reserve(cls_need, sr, true, eq->n_classes)) || (rc = eq->cls_off.reserve(cls_need, sr, true, eq->n_classes)) ||
+                    (rc = eq->cls_len.reserve(cls_need, sr, true, eq->n_classes)) || (rc = eq->cls_slot.reserve(cls_need, sr, true, eq->n_classes))) return rc;
+            }
+        }
+        if ((eq->cap >> kRegionBits) > (uint64_t)kMaxRegions) { bail = true; break; }
+        const uint32_t n_regions = (uint32_t)(eq->cap >> kRegionBits);
+        const PartGeom gm = part_geometry(cnt, n_words, n_regions, part_max_blocks());
+        if (gm.n_bins * gm.cap >= (1ull << 31)) { bail = true; break; }
+        sfgpu_eq::PartSet& S = eq->pset[k & 1];           // free: the host collected its previous sub-batch (k - 2) an iteration ago
+        if (S.in_flight && (rc = collect(S))) return rc;   // (cannot be: kept for safety)
+        if (S.fix) { if ((rc = drain())) return rc; }      // its bins still hold deferred labels: replay them before they are overwritten
+        // (reserve() may wait for the route stream when a buffer grows: first step only)
+        if ((rc = S.words.reserve(gm.n_bins * gm.cap * 4 + 8, sr, false)) || (rc = S.hist.reserve(4 * gm.n_bins + 1, sr, false)) ||
+            (rc = S.longl.reserve(cnt, sr, false)) || (rc = S.deferred.reserve(2ull * cnt, sr, false))) return rc;
+        // ---- hot classes.  (A) exactly, for THIS sub-batch, drained: the first table, a grown table, and the scout's boundary (the
+        //      bulk must not start before the hot classes are known).  (B) otherwise a rebuild that is due is made for the NEXT
+        //      sub-batch, on the insert stream AHEAD of insert(k) -- i.e. right behind insert(k - 1), next to route(k) -- into the
+        //      second copy (route(k) and perhaps route(k - 1) are reading the first); route(k + 1) waits for its event, which by
+        //      then fired long ago.  So in the steady state route(k + 1) knows the table as of insert(k - 1): one sub-batch staler
+        //      than the serial form, which only means that a class that has just become hot spills for one more sub-batch.
+        const uint64_t reads_tab = eq->reads_seen + fly_reads;             // reads the table holds once the queued insert passes are done
+        {
+            const bool have = eq->n_classes != 0 || k > 0;
+            const bool relaid = !eq->hot_bufs[0].p || eq->hot_cap != eq->cap || eq->hot_slots != kHotSlots;
+            const bool small_due = have && reads_tab && reads_tab < (1ull << 22) && reads_tab >= 4 * eq->hot_reads;
+            bool rebuilt = false;
+            if (relaid || small_due) {
+                if (n_fly && (rc = drain())) return rc;
+                hot_next = -1;
+                if ((rc = eq_hot_refresh(eq, n_regions, kHotSlots, sr, eq->hot_cur, eq->reads_seen, eq->n_classes != 0, &rebuilt))) return rc;
+            } else if (hot_next >= 0) {
+                SF_HIP(hipStreamWaitEvent(sr, eq->ev_hot, 0));
+                eq->hot_cur = hot_next; hot_next = -1;
+            }
+        }
+        // ---- route(k) on the builder's stream
+        if ((rc = open_timing())) return rc;
+        hipLaunchKernelGGL(k_zero_ctr, dim3(1), dim3(64), 0, sr, S.d_ctr);
+        SF_CHECK_LAUNCH();
+        uint4* bins = reinterpret_cast<uint4*>(S.words.p);
+        uint32_t* fill_f = S.hist.p, *fill_b = fill_f + gm.n_bins, *cutmarks = fill_b + gm.n_bins;
+        RouteArgs ra{d_ids, d_offsets + first, first, cnt, gm.tile, n_regions - 1u, (uint32_t)gm.cap, bins, fill_f, fill_b, cutmarks,
+                     S.d_ctr + CTR_TMP, S.longl.p, eq->hot_bufs[eq->hot_cur].p, eq->arena.p, eq->table.p, S.d_ctr + CTR_HOT, eq->mix_mode};
+        const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
+        hipLaunchKernelGGL(k_part_route<false>, dim3(gm.n_blocks), dim3(kPartBlock), route_lds, sr, ra);
+        SF_CHECK_LAUNCH();
+        SF_HIP(hipEventRecord(S.ev_route, sr));
+        // ---- (B) the hot table of the NEXT sub-batch, if due: behind insert(k - 1), ahead of insert(k)
+        if (reads_tab >= (1ull << 22) && reads_tab >= 4 * eq->hot_reads && eq->hot_cap == eq->cap) {
+            bool rebuilt = false;
+            const int into = eq->hot_cur ^ 1;
+            if ((rc = eq_hot_refresh(eq, n_regions, kHotSlots, si, into, reads_tab, true, &rebuilt))) return rc;
+            if (rebuilt) { SF_HIP(hipEventRecord(eq->ev_hot, si)); hot_next = into; }
+        }
+        // ---- insert(k) on the second stream, behind route(k) (and, in stream order, behind insert(k - 1))
+        SF_HIP(hipStreamWaitEvent(si, S.ev_route, 0));
+        PartArgs pa{eq->table.p, bins, fill_f, fill_b, gm.n_blocks, (uint32_t)gm.cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+                    eq->arena.p, S.d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, S.deferred.p, eq->mix_mode};
+        hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, si, pa);
+        SF_CHECK_LAUNCH();
+        SF_HIP(hipMemcpyAsync(S.h_ctr, S.d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, si));
+        SF_HIP(hipMemcpyAsync(S.h_ctr + CTR_N, eq->d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, si));
+        SF_HIP(hipEventRecord(S.ev_ins, si));
+        S.first = first; S.cnt = cnt; S.n_words = n_words; S.n_blocks = gm.n_blocks; S.cap = gm.cap; S.in_flight = true;
+        ++n_fly; fly_reads += cnt; fly_words += n_words;
+        first += cnt; ++k;
+        // ---- the host now looks at the sub-batch BEFORE the one it just queued
+        sfgpu_eq::PartSet& P = eq->pset[k & 1];            // (k was advanced: this is set (k - 2) & 1 = the older one in flight)
+        if (P.in_flight && (rc = collect(P))) return rc;
+        if (scout) {                                        // the scout is extra: drained, so that the bulk starts with its hot classes
+            scout = false; step = usual_step;
+            if ((rc = drain())) return rc;
+            continue;
+        }
+        // sub-batches grow (x4, x2) while, at the rate new classes appeared in the last collected one, the table stays under half full
+        for (uint32_t mult = 4; mult >= 2; mult /= 2) {
+            const uint64_t next = (uint64_t)step * mult;
+            if (next <= kMaxSubBatch && (double)eq->n_classes + rate * (double)(fly_reads + next) <= (double)(eq->cap / 2)) { step = (uint32_t)next; break; }
+        }
+    }
+    // the end of the batch: everything collected, deferred reads replayed, the builder's stream behind both passes
+    {
+        if ((rc = drain())) return rc;
+        eq->stats.pipeline_drains--;                        // (the final one is not an interruption)
+        if (hot_next >= 0) { eq->hot_cur = hot_next; hot_next = -1; }      // (rebuilt for a sub-batch that did not come: complete -- both streams are idle)
+    }
+    *consumed = first;
+    return SFGPU_OK;
+}
 
 // caller holds eq->mu
 static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads,
@@ -813,11 +1146,18 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     };
 
     if (!part && (rc = reserve_arena(batch_ids, n_reads))) return rc;
+    uint32_t first0 = 0;
+    const bool ring_wanted = []() { const char* e = getenv("SFGPU_EQ_RING"); return e && atoi(e) != 0; }();
+    if (part && adaptive && eq->use_pipe && !ring_wanted && n_reads >= (1u << 22)) {
+        // large batches: the sub-batches are pipelined (route(k + 1) next to insert(k), the host one sub-batch behind)
+        if ((rc = eq_pipeline(eq, d_ids, d_offsets, n_reads, &first0))) return rc;
+        if (first0) { scout = false; step = usual_step; }      // (whatever is left takes the serial loop at the usual size)
+    }
     // Sub-batches bound the partition buffer and let the table grow between them.  Each one shows how fast
     // new classes appear (the rate only falls as the table fills); the next sub-batch is made up to four
     // times larger (at most 2^26 reads) as long as, at that rate, the table would stay under half full:
     // fewer launches and longer region segments (400 M reads: 24 sub-batches -> 8).
-    for (uint32_t first = 0; first < n_reads; ) {
+    for (uint32_t first = first0; first < n_reads; ) {
         uint32_t cnt = (n_reads - first < step) ? (n_reads - first) : step;
         const uint64_t classes_before = eq->n_classes;
         bool done = false;

@@ -197,8 +197,12 @@ k_part_route(RouteArgs a) {
         const uint32_t n4 = (w_hi - w_lo + mis + 3u) >> 2;
         const uint4* src = reinterpret_cast<const uint4*>(ids + w_lo - mis);
         x0 = make_uint4(0u, 0u, 0u, 0u); x1 = x0;
-        if (lane < n4 && n4 <= (uint32_t)SW / 4) x0 = src[lane];
-        if (lane + 64u < n4 && n4 <= (uint32_t)SW / 4) x1 = src[lane + 64u];
+        // non-temporal loads: the ids are read once -- they need not displace the bins' open lines from the L2 (round 4: route
+        // 10.2 -> 9.6 ms per build under rocprofv3, profiles/r4_class_build_notes.md)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* srcv = reinterpret_cast<const u32x4*>(src);
+        if (lane < n4 && n4 <= (uint32_t)SW / 4) { const u32x4 v = __builtin_nontemporal_load(srcv + lane); x0 = make_uint4(v.x, v.y, v.z, v.w); }
+        if (lane + 64u < n4 && n4 <= (uint32_t)SW / 4) { const u32x4 v = __builtin_nontemporal_load(srcv + lane + 64u); x1 = make_uint4(v.x, v.y, v.z, v.w); }
     };
     uint32_t r0 = t0 + 64u * wave;
     uint32_t o = 0, oe = 0, no = 0, noe = 0, nno = 0, nnoe = 0;
@@ -550,9 +554,11 @@ struct PartArgs {
     const uint32_t* fill; const uint32_t* fill_back; uint32_t n_blocks; uint32_t cap;     // region r: bins (r, 0 .. n_blocks) of cap granules each: fill from the
                                                                // front, fill_back from the back (the ring form of pass 1 puts long labels there)
     uint64_t* cls_hash; uint64_t* cls_off; uint32_t* cls_len; uint32_t* cls_slot; uint32_t* arena;
-    unsigned long long* ctr;               // CTR_* counters (classes / arena cursor / deferred)
+    unsigned long long* ctr;               // this sub-batch's counters: CTR_NEW (classes it created), CTR_DEFER
+    unsigned long long* arena_ctr;         // the builder's arena cursor (words)
+    unsigned long long* gcls;              // the builder's class counter: class ids come from here, so a launch need not know how
+                                           // many classes the launch before it created (the host may still be a sub-batch behind)
     uint32_t* deferred;                    // (granule index of the label in the bins, length) of labels that found their region full
-    uint64_t base_classes;                 // classes committed before this launch
     uint32_t mix_mode;                     // bucket hash of long labels (the full tag of a new class is computed at commit)
 };
 
@@ -582,8 +588,8 @@ k_part_insert(PartArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 chead[kMaxRegionClasses];
     __shared__ unsigned int ccnt[kMaxRegionClasses];
     __shared__ __attribute__((aligned(16))) uint4 wtile[kPartWaves][64 + 2];
-    __shared__ unsigned int s_occ, s_ncls, s_nold, s_nnew, s_newwords, s_cid0;
-    __shared__ unsigned long long s_arena0;
+    __shared__ unsigned int s_occ, s_ncls, s_nold, s_nnew, s_newwords;
+    __shared__ unsigned long long s_arena0, s_cid0;
     static_assert(kRegionBits == 12, "slot32 packs a 12-bit tag, a 7-bit length and a 13-bit class index");
     const uint32_t region = blockIdx.x;
     const uint64_t rb = (uint64_t)region * kRegionSlots;
@@ -761,7 +767,9 @@ k_part_insert(PartArgs a) {
         const uint32_t e = slot32[s];
         if (e == kSlotEmpty) continue;
         const uint32_t idx = e & kSlotIdxMask;
-        if (idx < n_old) { const uint32_t c = ccnt[idx]; if (c) a.table[2 * (rb + s) + 1] += c; }
+        // (an atomic add: the route pass of the NEXT sub-batch may be running and adds what it counted for hot classes to the
+        //  same words)
+        if (idx < n_old) { const uint32_t c = ccnt[idx]; if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2 * (rb + s) + 1]), (unsigned long long)c); }
         else { new_slots[atomicAdd(&s_newwords, 1u)] = s; }                      // s_newwords doubles as the list cursor here
     }
     __syncthreads();
@@ -772,8 +780,9 @@ k_part_insert(PartArgs a) {
         for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, entry_words((slot32[new_slots[i]] >> 13) & 0x7Fu));
         __syncthreads();
         if (threadIdx.x == 0) {
-            s_cid0 = (unsigned int)atomicAdd(&a.ctr[CTR_NEW], (unsigned long long)n_new);
-            s_arena0 = atomicAdd(&a.ctr[CTR_ARENA], (unsigned long long)s_newwords);
+            s_cid0 = atomicAdd(a.gcls, (unsigned long long)n_new);
+            atomicAdd(&a.ctr[CTR_NEW], (unsigned long long)n_new);
+            s_arena0 = atomicAdd(a.arena_ctr, (unsigned long long)s_newwords);
             s_newwords = 0;
         }
         __syncthreads();
@@ -782,7 +791,7 @@ k_part_insert(PartArgs a) {
             const uint32_t e = slot32[s];
             const uint32_t idx = e & kSlotIdxMask, len = (e >> 13) & 0x7Fu;
             const uint32_t rep = chead[idx].x;
-            const uint64_t cid = a.base_classes + s_cid0 + i;
+            const uint64_t cid = s_cid0 + i;
             const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
             const uint32_t* p = reinterpret_cast<const uint32_t*>(a.bins + rep);
             const uint32_t w0 = p[0] & ~kHeadBit;

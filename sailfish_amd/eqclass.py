@@ -115,7 +115,7 @@ class EquivalenceClassBuilder:
         _lib.check(self._L.sfgpu_eq_get_stats(self._h, C.byref(st)))
         return dict(insert_ms=st.insert_ms, insert_launches=st.insert_launches, table_grows=st.table_grows,
                     deferred_reads=st.deferred_reads, table_slots=st.table_slots,
-                    hot_reads=st.hot_reads, spilled_reads=st.spilled_reads)
+                    hot_reads=st.hot_reads, spilled_reads=st.spilled_reads, pipeline_drains=st.pipeline_drains)
 
     def finish(self):
         """finish() (:64-80): returns True; n_classes / total_reads are what the reference logs."""

@@ -417,6 +417,63 @@ def test_builder_beyond_partition_limit(sf, gpu):
     assert bool(torch.equal(torch.sort(twice).values, torch.sort(a[:dup]).values))
 
 
+@pytest.mark.parametrize("shape", ["uniform", "hot", "sorted", "many_classes", "long_and_empty"])
+def test_builder_pipelined_partition_passes(sf, gpu, monkeypatch, shape):
+    """Batches of >= 4 M reads take the PIPELINED partition passes (round 4: route(k + 1) next to insert(k) on a second stream,
+    two sets of bins, class ids from a device-side counter, the host one sub-batch behind; eq_pipeline in eqclass.hip).  The
+    classes must be the oracle's, and the serial form's (SFGPU_EQ_PIPE=0), on: the benchmark's law; a stream with hot labels
+    (counted in the route pass; their table is rebuilt one sub-batch behind); a sorted stream (runs); far more classes than
+    the table was sized for (growth and deferral drain the pipeline); labels of up to 200 ids among empty reads (the generic
+    kernel's list).  A second batch goes into the same builder (the pipeline starts from a table that holds classes)."""
+    import torch
+    from sailfish_amd import synth
+    rng = np.random.default_rng(31)
+    R = 6_500_000
+    M, P = (3_000_000, 6_000_000) if shape == "many_classes" else (60_000, 700_000)
+    ref_len, ids, off = synth.workload(M, P, R)
+    ids_np, off_np = ids.numpy().view(np.uint32), off.numpy().view(np.uint32).astype(np.int64)
+    lens = np.diff(off_np)
+    picks = np.arange(R)
+    if shape == "hot":
+        m = rng.random(R) < 0.4; picks[m] = rng.integers(0, 40, int(m.sum())) * 977
+    elif shape == "sorted":
+        key = ids_np[off_np[:-1]].astype(np.int64) * 256 + np.minimum(lens, 255)
+        picks = np.argsort(key, kind="stable")
+    elif shape == "long_and_empty":
+        m = rng.random(R) < 0.02; picks[m] = -1
+    if shape != "uniform":
+        l2 = np.where(picks >= 0, lens[np.maximum(picks, 0)], 0)
+        o2 = np.zeros(R + 1, np.int64); np.cumsum(l2, out=o2[1:])
+        src = np.repeat(off_np[:-1][np.maximum(picks, 0)], l2) + (np.arange(o2[-1]) - np.repeat(o2[:-1], l2))
+        ids_np, off_np = ids_np[src], o2
+        if shape == "long_and_empty":             # ... and 30 000 labels of 124 .. 200 ids (beyond the partition stream's 123)
+            n_long = 30_000
+            ll = rng.integers(124, 201, n_long); base = rng.integers(0, 300, n_long)
+            o3 = np.zeros(n_long + 1, np.int64); np.cumsum(ll, out=o3[1:])
+            i3 = (np.repeat(base, ll) + 2 * (np.arange(o3[-1]) - np.repeat(o3[:-1], ll))).astype(np.uint32)
+            ids_np = np.concatenate([ids_np, i3]); off_np = np.concatenate([off_np, off_np[-1] + o3[1:]])
+    off32 = off_np.astype(np.uint32)
+    cut = len(off32) // 2
+    second = (ids_np[: off_np[cut]], off32[: cut + 1])                  # the first half again, as a second batch
+    ob, *oc = _oracle_classes([(ids_np, off32), second])
+    tables = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("SFGPU_EQ_PIPE", pipe)
+        eq = sf.EquivalenceClassBuilder(device=gpu, expected_classes=(1000 if shape == "many_classes" else 0))
+        eq.start()
+        for ii, oo in ((ids_np, off32), second):
+            eq.add_batch(torch.from_numpy(ii.view(np.int32)).to(gpu), torch.from_numpy(oo.view(np.int32)).to(gpu))
+        eq.finish()
+        _assert_same_classes(eq, ob, *oc)
+        st = eq.stats()
+        tables.append(st)
+        if shape == "hot":
+            assert st["hot_reads"] > R // 4
+        if shape == "many_classes":
+            assert st["table_grows"] >= 1
+    assert tables[0]["insert_launches"] >= 2, tables
+
+
 @pytest.mark.parametrize("n_reads", [40_000, 200_000])
 def test_builder_long_labels_that_agree_in_every_sampled_id(sf, gpu, n_reads):
     """the bucket hash of a label of more than 8 ids looks at its length, its first 8 ids and three ids of its

@@ -11,7 +11,7 @@ n_ok = 0
 while time.time() < t_end:
     M = int(rng.choice([50, 5000, 200_000, 3_000_000]))
     P = int(rng.choice([10, 1000, 100_000, 1_500_000]))
-    R = int(rng.choice([70_000, 300_000, 1_200_000, 3_000_000, 5_000_000]))
+    R = int(rng.choice([70_000, 300_000, 1_200_000, 3_000_000, 5_000_000, 9_000_000]))
     kind = rng.integers(0, 3)
     # label pool with a random length law
     if kind == 0: lens = rng.geometric(0.3, P)
@@ -49,6 +49,8 @@ while time.time() < t_end:
     sb = rng.choice([None, "65536", "262144", "1048576"])
     if sb: os.environ["SFGPU_EQ_SUBBATCH"] = sb
     else: os.environ.pop("SFGPU_EQ_SUBBATCH", None)
+    pipe = rng.choice(["1", "1", "0"])                             # batches of >= 4 M reads: pipelined partition passes (round 4) or the serial form
+    os.environ["SFGPU_EQ_PIPE"] = pipe
     eq = sf.EquivalenceClassBuilder(device=dev, expected_classes=int(rng.choice([0, 1000, 5_000_000])))
     eq.start()
     ncut = int(rng.integers(0, 4)); cuts = sorted(set([0, R] + rng.integers(0, R, ncut).tolist()))
@@ -61,7 +63,7 @@ while time.time() < t_end:
     rp, ii, cc, hh = eq.eqVec().to_numpy()
     ok = (eq.n_classes == ob.n_classes and np.array_equal(rp, orp.astype(np.uint32)) and np.array_equal(ii, oi)
           and np.array_equal(cc, oc) and np.array_equal(hh, oh))
-    print(f"M={M} P={P} R={R} kind={kind} shape={shape} sb={sb} host={host} cuts={len(cuts)-1}: classes {eq.n_classes} {'ok' if ok else 'MISMATCH'} {eq.stats()}", flush=True)
+    print(f"M={M} P={P} R={R} kind={kind} shape={shape} sb={sb} pipe={pipe} host={host} cuts={len(cuts)-1}: classes {eq.n_classes} {'ok' if ok else 'MISMATCH'} {eq.stats()}", flush=True)
     if not ok: sys.exit(1)
     n_ok += 1
 print("all ok:", n_ok)
