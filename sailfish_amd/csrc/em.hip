@@ -69,7 +69,7 @@ __global__ void k_post_state(const EmState* st, uint32_t min_iter, uint32_t max_
 // The ten reciprocals are added as ONE fraction (pairwise n/d merges: every term is positive, so nothing
 // cancels) -- a single f64 division instead of up to ten dependent ones (a wavefront always holds some
 // low-abundance transcript, so the old loop ran all ten rounds for everybody).
-__device__ __forceinline__ double digamma_pos(double x) {
+__host__ __device__ __forceinline__ double digamma_pos(double x) {
     double r = 0.0;
     if (x < 10.0) {
         const double a0 = x, a1 = x + 1.0, a2 = x + 2.0, a3 = x + 3.0, a4 = x + 4.0,
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(kEmBlock)
 k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* __restrict__ lenc,
          double tol, int check_mode, double* sum_partials_out, double* blkmax, EmState* st,
          const uint32_t* __restrict__ cov_ptr, const uint32_t* __restrict__ cov_pos,
-         const double* __restrict__ partial, const double* __restrict__ tsum, uint32_t n_tiles) {
+         const double* __restrict__ partial, const double* __restrict__ tsum, uint32_t n_tiles, double const_log_norm, int use_const_norm) {
     // request this thread's first operands before looking at the loop state (they do not depend on it):
     // the state test then costs no extra memory round trip
     const uint64_t t_first = (uint64_t)blockIdx.x * kEmBlock + threadIdx.x;
@@ -925,8 +925,16 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
         if (FOLD) { k0_first = cov_ptr[t_first]; k1_first = cov_ptr[t_first + 1]; }
     }
     double tsum_part = 0.0;
-    const bool fused_vb = VB && tsum != nullptr;      // x for the next sweep is produced here, no k_vb_prepare pass
-    if (fused_vb) for (uint32_t i = threadIdx.x; i < n_tiles; i += kEmBlock) tsum_part += tsum[i];
+    // x for the next sweep is produced here (no k_vb_prepare pass) when the normaliser psi(sum alpha) is at hand: from the sweep's
+    // per-tile sums (tsum), or -- round 4, the default inside optimize() -- as a CONSTANT of the run, psi(M prior + numMapped).
+    // expTheta's normaliser scales every x_t alike and cancels in x_t count / denom (:340-366), and in VBEM every class hands out
+    // its whole count (alpha >= prior > 0 keeps every denominator far above denorm_min), so sum(alpha') IS M prior + numMapped up
+    // to rounding: the constant differs from the reference's psi(sum of the floats) by ~1e-13 in a factor that cancels.  What it
+    // buys: no n_tiles-element reduction, no digamma of the sum and no block barrier in front of every update (SFGPU_EM_EXACT_NORM=1
+    // keeps the summed form).
+    const bool const_norm = VB && use_const_norm != 0;
+    const bool fused_vb = VB && (tsum != nullptr || const_norm);
+    if (fused_vb && !const_norm) for (uint32_t i = threadIdx.x; i < n_tiles; i += kEmBlock) tsum_part += tsum[i];
     uint32_t it = st->it_b;
     if (it == kDoneMark) return;
     __shared__ double lds[kEmBlock / kWave];
@@ -934,7 +942,8 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
     double local_sum = 0.0, local_max = -1.0;
     unsigned notconv = 0;
     double log_norm = 0.0;
-    if (fused_vb) {
+    if (const_norm) log_norm = const_log_norm;
+    else if (fused_vb) {
         // sum(alpha) of this update = M * prior + what the tiles added; same order in every block
         double sacc = block_sum(tsum_part, lds);
         __shared__ double bc;
@@ -1038,7 +1047,8 @@ struct sfgpu_em {
     unsigned char* csc = nullptr; uint16_t* csc_slot0 = nullptr;                              // transcript-major copy of the tiles (phase C as a gather)
     uint64_t* tile_qb = nullptr; uint32_t* tile_np = nullptr; uint32_t* tile_pr = nullptr;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
-    double* tsum = nullptr;                                 // [n_tiles] what each tile added in the last sweep (VBEM, optimize())
+    double* tsum = nullptr;                                 // [n_tiles] what each tile added in the last sweep (VBEM, optimize(), SFGPU_EM_EXACT_NORM=1)
+    bool const_norm = true; double vb_log_norm = 0.0;       // VBEM inside optimize(): psi(M prior + numMapped) as the run's normaliser (k_update)
     bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
@@ -1109,7 +1119,7 @@ static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     if (p.C == 0) return SFGPU_OK;
     SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize) ? em->tsum : nullptr, em->inv,
+                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize && !em->const_norm) ? em->tsum : nullptr, em->inv,
                 em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr};
     void* args[] = {&a};
     const void* f = em->gather ? (em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true>)
@@ -1129,15 +1139,18 @@ static int em_enqueue_update(sfgpu_em* em, bool fold, Launcher& L) {
     fold = fold && p.C != 0;
     // inside optimize() the VBEM update gets sum(alpha) from the sweep's per-tile sums and writes the next
     // x itself; the piecewise API (all-reduce between sweep and update) keeps the separate k_vb_prepare pass
-    const double* fused_tsum = (em->opts.use_vbem && fold && em->in_optimize) ? em->tsum : nullptr;
+    const bool fused = em->opts.use_vbem && fold && em->in_optimize;
+    const double* fused_tsum = (fused && !em->const_norm) ? em->tsum : nullptr;
+    int use_const = (fused && em->const_norm) ? 1 : 0;
+    double const_log_norm = em->vb_log_norm;
     uint64_t M = p.M; double tol = em->opts.tol; int check_mode = em->opts.check_mode; uint32_t n_tiles = em->n_tiles;
     void* args[] = {&M, &em->alpha, &em->alpha_out, &em->x, &em->lenc, &tol, &check_mode, &em->sum_partials,
-                    &em->blkmax, &em->d_state, &em->cov_ptr, &em->cov_pos, &em->partial, &fused_tsum, &n_tiles};
+                    &em->blkmax, &em->d_state, &em->cov_ptr, &em->cov_pos, &em->partial, &fused_tsum, &n_tiles, &const_log_norm, &use_const};
     const void* f;
     if (em->opts.use_vbem) f = fold ? reinterpret_cast<const void*>(&k_update<true, true>) : reinterpret_cast<const void*>(&k_update<true, false>);
     else f = fold ? reinterpret_cast<const void*>(&k_update<false, true>) : reinterpret_cast<const void*>(&k_update<false, false>);
     SF_HIP(L.launch(f, g, b, args));
-    if (em->opts.use_vbem && !fused_tsum) {
+    if (em->opts.use_vbem && !fused_tsum && !use_const) {
         int nb = em->nb, force = 0;
         void* vargs[] = {&M, &em->alpha, &em->x, &em->lenc, &em->sum_partials, &nb, &em->d_state, &force};
         SF_HIP(L.launch(reinterpret_cast<const void*>(&k_vb_prepare), g, b, vargs));
@@ -1484,6 +1497,8 @@ static int em_begin_on(sfgpu_em* em, const sfgpu_em_opts* opts, hipStream_t work
     int rc = em_fill_opts(em, opts);
     if (rc) return rc;
     em->cur = work;
+    em->const_norm = getenv("SFGPU_EM_EXACT_NORM") == nullptr;
+    em->vb_log_norm = digamma_pos((double)em->prob.M * kPriorAlpha + (double)em->prob.num_mapped);
     if (em->lenc_dirty) {
         hipLaunchKernelGGL(k_clamp_len, dim3(blocks_for(em->prob.M)), dim3(kEmBlock), 0, em->cur, em->prob.M, em->prob.d_len, em->lenc);
         SF_CHECK_LAUNCH();

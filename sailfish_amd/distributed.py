@@ -169,7 +169,7 @@ def nnz_balanced_slices(rowptr_cpu, world):
 
 class DistributedQuant:
     def __init__(self, exp: ReadExperiment, sopt: SailfishOpts, group=None, em_mode="auto", engine=None,
-                 tol=0.01, max_iter=10000, poll_every=16, merge_mode="auto"):
+                 tol=0.01, max_iter=10000, poll_every=16, merge_mode="auto", min_iter=50):
         self.exp, self.sopt, self.group = exp, sopt, group
         self.world = 1
         self.rank = 0
@@ -179,6 +179,7 @@ class DistributedQuant:
         self.engine = engine or HipEngine(exp.transcripts().device)
         self.em_mode = em_mode
         self.tol, self.max_iter, self.poll_every = tol, max_iter, poll_every
+        self.min_iter = min_iter            # optimize()'s minIter is 50 (src/CollapsedEMOptimizer.cpp:716); tests shorten the loop
         self.local = self.engine.new_builder()
         self.merged = self.engine.new_builder() if self.world > 1 else None
         # "owner": classes are first reduced at the rank that owns their hash (one all-to-all), then the disjoint
@@ -369,7 +370,7 @@ class DistributedQuant:
         if not hasattr(p_full, "time_sweep"):
             return
         ar = self._allreduce()
-        sweep_us = p_full.time_sweep(20, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter) * 1e3
+        sweep_us = p_full.time_sweep(20, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=self.min_iter, max_iter=self.max_iter) * 1e3
         if hasattr(ar, "time_all_reduce"):
             ar_us = ar.time_all_reduce(M, 30)
         else:
@@ -397,7 +398,7 @@ class DistributedQuant:
         mode = self._pick_mode(vec.nnz)
         if self.problem is not None:       # release the previous run's device state before building the next
             self.problem.close(); self.problem = None
-        kw = dict(use_vbem=sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)
+        kw = dict(use_vbem=sopt.useVBOpt, tol=self.tol, min_iter=self.min_iter, max_iter=self.max_iter)
         # doBiasCorrect (src/CollapsedEMOptimizer.cpp:717): lengths are recomputed at iterations 50 / 500 / 1000
         bias = self.engine.bias_model(exp, sopt) if (sopt.biasCorrect or sopt.gcBiasCorrect) else None
         eff = None
@@ -529,4 +530,4 @@ class DistributedQuant:
     def time_sweep(self, n=200):
         """average duration of one sweep launch of THIS rank's problem (its class slice in sharded mode)"""
         p = self.problem
-        return p.time_sweep(n, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=50, max_iter=self.max_iter)
+        return p.time_sweep(n, use_vbem=self.sopt.useVBOpt, tol=self.tol, min_iter=self.min_iter, max_iter=self.max_iter)

@@ -23,16 +23,19 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 CFG3 = (200_000, 4_000_000, 400_000_000)
-# the loop is cut at 80 iterations on both sides (cfg3 converges after 212): every one of them costs the eight ranks a gloo
-# all-reduce through the host, and the iterations past 80 show nothing the first 80 do not (min_iter is 50: the stop logic ran).
-# (Nine processes on one device: on its own this test takes ~20 s, after other GPU tests in the same session 6-8 minutes --
-# the device's queues are oversubscribed; fewer queues per rank, trimmed caches, a fresh parent process were tried and do not help.)
-# SFGPU_CFG4_FULL=1 lifts the cut for the eight PROCESSES (both sides then run to convergence: 212 = 212, ~9 minutes of nine
-# processes time-slicing one device, profiles/r3_cfg4_full.txt).  The suite asserts the same thing at full size without the
-# processes: test_cfg4_eight_class_slices_to_convergence_in_one_process below runs the eight class slices to convergence through
-# the same sweep / sum / update pieces and must stop at the single-GPU loop's iteration.  tests/conftest.py runs this file's cfg4
-# test FIRST among the GPU tests (nine processes on a device that earlier tests have used take minutes instead of seconds).
-CFG4_MAX_ITER = 10000 if os.environ.get("SFGPU_CFG4_FULL") else 80
+# The eight PROCESSES run only CFG4_ITERS iterations of the sharded loop (both sides: min_iter = max_iter): every iteration costs
+# the eight ranks a gloo all-reduce through the host, and nine processes time-slicing one device are erratic -- the same test took
+# 82 s on one box and 863 s on the next in round 4 (80 iterations; 20 s to 8 minutes in round 3), which alone would overrun the
+# suite's limit.  What the processes are here for is the transport: shards -> owner-partitioned merge over eight ranks -> the table
+# of the single-process run, then the all-reduce between sweep and update on eight ranks -> the single-GPU alpha.  That the sharded
+# loop stops where the single-GPU loop stops, at full size and run to CONVERGENCE, is asserted without the processes by
+# test_cfg4_eight_class_slices_to_convergence_in_one_process below (and on two / three ranks by tests/test_gpu_distributed.py).
+# SFGPU_CFG4_FULL=1 lifts the cut for the processes too (212 = 212, ~9 minutes, profiles/r3_cfg4_full.txt).
+# tests/conftest.py runs this file's cfg4 test FIRST among the GPU tests (a device that earlier tests have used makes it slower still).
+CFG4_FULL = bool(os.environ.get("SFGPU_CFG4_FULL"))
+CFG4_MAX_ITER = 10000 if CFG4_FULL else 6
+CFG4_MIN_ITER = 50 if CFG4_FULL else 6
+CFG4_POLL = 16 if CFG4_FULL else 2
 
 
 def _fl_counts():
@@ -55,7 +58,7 @@ def _cfg4_worker(rank, world, port, sizes, outdir):
         del poff, pids
         sopt = sf.SailfishOpts(useVBOpt=True)
         exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.cpu().numpy().view(np.uint32), device=dev), sopt)
-        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode="sharded", poll_every=16, max_iter=CFG4_MAX_ITER)
+        q = sfd.DistributedQuant(exp, sopt, group=dist.group.WORLD, em_mode="sharded", poll_every=CFG4_POLL, max_iter=CFG4_MAX_ITER, min_iter=CFG4_MIN_ITER)
         info = q.run(ids, off, fl_counts=_fl_counts(), remaining_fl_ops=0)
         v = q.last_vec
         np.save(os.path.join(outdir, f"alpha{rank}.npy"), exp.transcripts().estCount.cpu().numpy())
@@ -89,7 +92,7 @@ def test_cfg4_eight_ranks_share_the_gpu(gpu):
     del poff, pids
     sopt = sf.SailfishOpts(useVBOpt=True)
     exp = sf.ReadExperiment(sf.Transcripts([str(i) for i in range(M)], ref_len.cpu().numpy().view(np.uint32), device=gpu), sopt)
-    q1 = sfd.DistributedQuant(exp, sopt, max_iter=CFG4_MAX_ITER)
+    q1 = sfd.DistributedQuant(exp, sopt, max_iter=CFG4_MAX_ITER, min_iter=CFG4_MIN_ITER)
     info1 = q1.run(ids, off, fl_counts=_fl_counts(), remaining_fl_ops=0)
     v1 = q1.last_vec
     a1 = exp.transcripts().estCount.cpu().numpy()
@@ -107,7 +110,7 @@ def test_cfg4_eight_ranks_share_the_gpu(gpu):
     # sharded EM: each rank swept ~1/8 of the classes, and the loop stopped where the single-GPU loop stops
     assert sharded == 1 and 0 < c_local < n_classes // 4
     assert iters == info1["em_stats"]["iters"] and conv == int(info1["em_stats"]["converged"]), (iters, info1["em_stats"])
-    assert iters == CFG4_MAX_ITER or (CFG4_MAX_ITER == 10000 and conv == 1 and iters > 80), (iters, conv)
+    assert iters == CFG4_MAX_ITER or (CFG4_FULL and conv == 1 and iters > 80), (iters, conv)
     print(f"cfg4: {world} ranks, sharded EM stopped at iteration {iters} (single GPU: {info1['em_stats']['iters']}), converged={conv}")
     alphas = [np.load(os.path.join(outdir, f"alpha{r}.npy")) for r in range(world)]
     for a in alphas[1:]:
