@@ -88,6 +88,52 @@ __device__ __forceinline__ void entry_write(uint32_t* arena, uint64_t dst, WordF
     for (uint32_t k = len + 1; k < entry_words(len); ++k) arena[dst + k] = 0u;
 }
 
+// ---- the PROBE granule of a class (round 4) ------------------------------------------------------------------------------
+// The partition stream carries a label of 4 .. 9 ids in ONE 16-byte granule when it can: ids below 2^24 that ascend in steps of
+// 0 .. 255 (the isoforms of a gene in annotation order) travel as  [head | compact | id0][H][d1 d2 d3 d4][d5 d6 d7 d8]  -- the
+// first id and eight 8-bit steps.  92 % of the benchmark's labels are then one granule (58 % with <= 3 ids, which always were),
+// pass 1 writes one 16-byte store for them and pass 2 decides their identity in LDS without touching the arena: with every label
+// cut to 3 ids the two passes took 8.7 ms instead of 14.6 (profiles/r4_class_build_notes.md).  The encoding is a function of the
+// label alone and injective among labels of one length, so comparing encodings compares labels; everything else (more ids, wider
+// steps, unsorted ids, ids >= 2^24) keeps the multi-granule form [id0][H][id1][id2] [id3 ..] ...
+// Pass 2 keeps, per class, the three payload words of the label's FIRST stream granule.  For committed classes they sit in the
+// arena in a granule of their own right in front of the entry:  [len, p0, p1, p2] [len, id0, id1, id2] [id3 ..] ... ; the table's
+// rep still addresses the entry, so every other reader of the arena is unchanged.
+constexpr uint32_t kCompactBit = 0x40000000u;                 // in word 0 of a head granule (ids >= 2^30 take the generic kernel)
+constexpr uint32_t kMaxCompactLen = 9;
+constexpr uint32_t kProbeWords = 4;                           // arena words in front of an entry
+template <typename WordFn>
+__device__ __forceinline__ void label_probe(WordFn word, uint32_t n, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    const uint32_t id0 = word(0);
+    if (n >= 4u && n <= kMaxCompactLen && id0 < (1u << 24)) {
+        uint32_t prev = id0, lo = 0, hi = 0;
+        bool ok = true;
+        for (uint32_t k = 1; k < n; ++k) {
+            const uint32_t v = word(k), d = v - prev;
+            ok = ok && d <= 255u;
+            prev = v;
+            if (k <= 4u) lo |= (d & 255u) << (8u * (k - 1u)); else hi |= (d & 255u) << (8u * (k - 5u));
+        }
+        if (ok) { p0 = kCompactBit | id0; p1 = lo; p2 = hi; return; }
+    }
+    // (ids >= 2^30 never enter the stream -- such reads take the generic kernel -- and must not look like a compact granule here)
+    p0 = id0 < kCompactBit ? id0 : 0xFFFFFFFFu; p1 = n > 1u ? word(1) : 0u; p2 = n > 2u ? word(2) : 0u;
+}
+// id k of a label held as ONE compact granule (c0 = word 0 without the head bit, lo / hi = words 2 and 3)
+__device__ __forceinline__ uint32_t compact_id(uint32_t c0, uint32_t lo, uint32_t hi, uint32_t k) {
+    uint32_t v = c0 & 0xFFFFFFu;
+    for (uint32_t j = 1; j <= k; ++j) v += (j <= 4u ? (lo >> (8u * (j - 1u))) : (hi >> (8u * (j - 5u)))) & 255u;
+    return v;
+}
+// arena words a class takes: probe granule + entry
+__host__ __device__ __forceinline__ uint32_t class_words(uint32_t len) { return kProbeWords + entry_words(len); }
+template <typename WordFn>
+__device__ __forceinline__ void probe_write(uint32_t* arena, uint64_t dst, WordFn word, uint32_t len) {
+    uint32_t p0, p1, p2;
+    label_probe(word, len, p0, p1, p2);
+    arena[dst] = len; arena[dst + 1] = p0; arena[dst + 2] = p1; arena[dst + 3] = p2;
+}
+
 __global__ void k_table_init(uint64_t* table, uint64_t cap) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -221,7 +267,9 @@ __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __res
     uint32_t r = (uint32_t)w;
     uint32_t b = off[r], len = off[r + 1] - b;
     const uint32_t* lab = ids + b;
-    unsigned long long dst = atomicAdd(&ctr[CTR_ARENA], (unsigned long long)entry_words(len));
+    unsigned long long dst = atomicAdd(&ctr[CTR_ARENA], (unsigned long long)class_words(len));
+    probe_write(arena, dst, [&](uint32_t k) { return lab[k]; }, len);
+    dst += kProbeWords;
     entry_write(arena, dst, [&](uint32_t k) { return lab[k]; }, len);
     uint64_t cid = base_cid + i;
     cls_hash[cid] = xxh64_words([&](uint32_t k) { return lab[k]; }, len);
@@ -404,6 +452,7 @@ struct sfgpu_eq {
     bool use_part = true; uint32_t part_sub_batch = 1u << 24;
     DevBuf<uint32_t> part_words, part_hist, part_cursor, part_long, def_lens, def_ids, def_off;
     DevBuf<uint64_t> def_w;                 // run lengths of the deferred labels (weights of their replay)
+    uint64_t def_n = 0, def_words = 0;      // deferred labels saved out of the bins and not yet replayed (eq_deferred_save), their ids
     // small DEVICE batches are gathered here and built together (a sub-batch costs ~0.25 ms of launches and round trips whatever
     // its size: 100 M reads in 1 M-read batches took 34 ms instead of 5 ms)
     DevBuf<uint32_t> dacc_ids, dacc_off;
@@ -478,6 +527,7 @@ static int eq_reset(sfgpu_eq* eq) {
     eq->acc_n_ids = 0; eq->acc_n_reads = 0; eq->dacc_n_reads = 0; eq->dacc_n_ids = 0;
     eq->reads_seen = 0; eq->hot_cap = 0; eq->hot_reads = 0; eq->mix_mode = kMixSampled;
     for (auto& S : eq->pset) { S.in_flight = false; S.fix = false; }
+    eq->def_n = 0; eq->def_words = 0;
     uint64_t want = pow2_at_least(2 * (eq->expected ? eq->expected : 1000000ull) + 2 * kSlack);
     if (eq->table.p && eq->cap == want) {
         hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
@@ -693,37 +743,48 @@ static int eq_hot_refresh(sfgpu_eq* eq, uint32_t n_regions, uint32_t hs, hipStre
 
 static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t first, uint32_t todo,
                       const uint32_t* list, const uint64_t* d_weights);
-// what a partitioned sub-batch leaves for the generic kernel: labels whose home region was full (deferred: copied out of the
-// bins, the table grown, inserted the generic way) and reads that never entered the stream (bin overflow, over-long labels).
+// Labels whose home region was full stay in the bins as (granule index, length) pairs: before the bins are reused they are
+// copied out -- APPENDED to a small CSR batch (def_ids / def_off / def_w) that eq_part_fixups inserts the generic way once the
+// table may grow.  `deferred` = the n_new pairs to save.  Synchronises eq->stream (the size of the copy is read back).
+static int eq_deferred_save(sfgpu_eq* eq, const uint32_t* bins_words, const uint32_t* deferred, uint64_t n_new) {
+    if (!n_new) return SFGPU_OK;
+    hipStream_t st = eq->stream;
+    int rc;
+    if ((rc = eq->def_lens.reserve(n_new + 1, st, false)) || (rc = eq->def_off64.reserve(n_new + 2, st, false))) return rc;
+    hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_new + 1)), dim3(kBlock), 0, st, n_new, deferred, eq->def_lens.p);
+    SF_CHECK_LAUNCH();
+    if ((rc = exclusive_scan_u32(eq->def_lens.p, eq->def_off64.p, n_new, st))) return rc;
+    uint64_t tot = 0;
+    SF_HIP(hipMemcpyAsync(&tot, eq->def_off64.p + n_new, 8, hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    SF_REQUIRE(eq->def_words + tot < (1ull << 32), SFGPU_ERR_RANGE, "deferred labels exceed 2^32 ids");
+    if ((rc = eq->def_ids.reserve(eq->def_words + tot + 1, st, true, eq->def_words)) ||
+        (rc = eq->def_off.reserve(eq->def_n + n_new + 1, st, true, eq->def_n + 1)) ||
+        (rc = eq->def_w.reserve(eq->def_n + n_new + 1, st, true, eq->def_n))) return rc;
+    hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_new + 1)), dim3(kBlock), 0, st, n_new, deferred,
+                       reinterpret_cast<const uint4*>(bins_words), eq->def_off64.p, eq->def_ids.p + eq->def_words, eq->def_off.p + eq->def_n,
+                       eq->def_w.p + eq->def_n, eq->def_words);
+    SF_CHECK_LAUNCH();
+    eq->def_n += n_new; eq->def_words += tot;
+    eq->stats.deferred_reads += n_new;
+    return SFGPU_OK;
+}
+
+// what partitioned sub-batches leave for the generic kernel: the deferred labels saved by eq_deferred_save (the table is grown,
+// they are inserted the generic way) and reads that never entered the stream (bin overflow, over-long labels: `long_list`).
 // The table must be quiescent (no partition pass in flight); synchronises eq->stream.
-static int eq_part_fixups(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, const uint32_t* bins_words, const uint32_t* deferred,
-                          const uint32_t* long_list, uint64_t n_def, uint64_t n_long) {
+static int eq_part_fixups(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, const uint32_t* long_list, uint64_t n_long) {
     hipStream_t st = eq->stream;
     int rc;
     eq->stats.spilled_reads += n_long;
+    const uint64_t n_def = eq->def_n, tot = eq->def_words;
     if (n_def) {
-        eq->stats.deferred_reads += n_def;
-        if ((rc = eq->def_lens.reserve(n_def + 1, st, false)) || (rc = eq->def_off64.reserve(n_def + 2, st, false)) ||
-            (rc = eq->def_off.reserve(n_def + 1, st, false))) return rc;
-        hipLaunchKernelGGL(k_deferred_lens, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, deferred, eq->def_lens.p);
-        SF_CHECK_LAUNCH();
-        if ((rc = exclusive_scan_u32(eq->def_lens.p, eq->def_off64.p, n_def, st))) return rc;
-        uint64_t tot = 0;
-        SF_HIP(hipMemcpyAsync(&tot, eq->def_off64.p + n_def, 8, hipMemcpyDeviceToHost, st));
-        SF_HIP(hipStreamSynchronize(st));
-        if ((rc = eq->def_ids.reserve(tot + 1, st, false))) return rc;
-        if ((rc = eq->def_w.reserve(n_def + 1, st, false))) return rc;
-        hipLaunchKernelGGL(k_deferred_copy, dim3(grid_for(n_def + 1)), dim3(kBlock), 0, st, n_def, deferred,
-                           reinterpret_cast<const uint4*>(bins_words), eq->def_off64.p, eq->def_ids.p, eq->def_off.p, eq->def_w.p);
-        SF_CHECK_LAUNCH();
+        eq->def_n = 0; eq->def_words = 0;
         // worst case every deferred label opens a class
-        {
-            const uint64_t need = eq->arena_used + tot + 4 * n_def + 4;
-            SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
-            if ((rc = eq->arena.reserve(need, st, true, eq->arena_used))) return rc;
-        }
+        const uint64_t need = eq->arena_used + tot + 8 * n_def + 4;
+        SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
+        if ((rc = eq->arena.reserve(need, st, true, eq->arena_used))) return rc;
         if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
-        // (the deferred list may be eq->deferred_a, which eq_generic reuses: the copies above are complete -- eq_grow synchronised)
         if ((rc = eq_generic(eq, eq->def_ids.p, eq->def_off.p, 0, (uint32_t)n_def, nullptr, eq->def_w.p))) return rc;
     }
     if (n_long) {        // labels too long for an LDS tile, reads that did not fit their bin
@@ -786,6 +847,13 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq->cls_off.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_len.reserve(cls_need, st, true, eq->n_classes))) return rc;
     if ((rc = eq->cls_slot.reserve(cls_need, st, true, eq->n_classes))) return rc;
+    // A table of more than kGroupRegions regions (16 M slots: more than ~8 M classes) is built in GROUPS of kGroupRegions regions:
+    // one route + insert pass over the sub-batch per group, each skipping the reads whose label lives in another group.  The
+    // cursors of a group fit the route pass's LDS next to a second block (2 x 4096 x 4 B), its bins stay at 2 M lines; the price
+    // is reading and hashing the sub-batch once per group (round 4: before, such tables fell back to the generic kernel at
+    // ~6 G reads/s).
+    const uint32_t n_groups = (n_regions + kGroupRegions - 1) / kGroupRegions;
+    const uint32_t grp_n = n_regions / n_groups;                  // (both powers of two)
     // every block of pass 1 owns one contiguous tile of reads and one bin per region.  The RING form of the pass (bins written
     // through LDS rings, eqclass_part.h) wants one block per CU and fits up to 1024 regions (a table of <= 4 M slots).  It is
     // OFF by default (SFGPU_EQ_RING=1 selects it): it writes whole 64-byte units -- no partial lines -- but one block per CU is
@@ -794,13 +862,14 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     const int ring_mode = []() { const char* e = getenv("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();      // (read per sub-batch: tests switch it)
     static const uint32_t ring_blocks = []() { const char* e = getenv("SFGPU_EQ_RING_BLOCKS"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 0); }();
     bool ring = ring_mode != 0 && n_regions >= 2 && n_regions <= kRingMaxRegions;
+    // (a bin's share of the stream is computed over ALL regions -- a group's launch fills the bins of its regions only)
     PartGeom gm = part_geometry(cnt, n_words, n_regions, ring ? (ring_blocks ? ring_blocks : (uint32_t)device_cus()) : part_max_blocks());
     if (ring && gm.cap > kRingMaxCap) {       // (16-bit cursors: few regions and a huge sub-batch take the direct form)
         ring = false;
         gm = part_geometry(cnt, n_words, n_regions, part_max_blocks());
     }
     const uint32_t n_blocks = gm.n_blocks, tile = gm.tile;
-    const uint64_t cap = gm.cap, n_bins = gm.n_bins;
+    const uint64_t cap = gm.cap, n_bins = (uint64_t)grp_n * n_blocks;
     // positions inside the bins are 31-bit granule indices (bit 31 of a slot's rep marks arena entries)
     SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 granules");
     if ((rc = eq->part_words.reserve(n_bins * cap * 4 + 8, st, false))) return rc;
@@ -816,25 +885,39 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     if ((rc = eq_hot_refresh(eq, n_regions, hs, st, eq->hot_cur, eq->reads_seen, eq->n_classes != 0, &rebuilt))) return rc;
     unsigned long long* hot_h = eq->hot_bufs[eq->hot_cur].p;
     uint32_t* fill_f = eq->part_hist.p, *fill_b = fill_f + n_bins, *cutmarks = fill_b + n_bins;
-    RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
-                 eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode};
-    if (ring) {
-        const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
-                                 (size_t)kPartWaves * kRingFlushList * 4;
-        static const bool attr_ok = []() {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_route<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        }();
-        (void)attr_ok;
-        hipLaunchKernelGGL(k_part_route<true>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
-    } else {
-        const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
-        hipLaunchKernelGGL(k_part_route<false>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+    uint64_t saved_def = 0;                        // deferred pairs already copied out of the bins (groups)
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t grp_lo = g * grp_n;
+        RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
+                     eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode, grp_lo, grp_n};
+        if (ring) {
+            const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
+                                     (size_t)kPartWaves * kRingFlushList * 4;
+            static const bool attr_ok = []() {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_route<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            }();
+            (void)attr_ok;
+            hipLaunchKernelGGL(k_part_route<true>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+        } else {
+            const size_t route_lds = (size_t)2 * grp_n * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
+            hipLaunchKernelGGL(k_part_route<false>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+        }
+        SF_CHECK_LAUNCH();
+        PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+                    eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo};
+        hipLaunchKernelGGL(k_part_insert, dim3(grp_n), dim3(kPartBlock), 0, st, pa);
+        SF_CHECK_LAUNCH();
+        if (g + 1 < n_groups) {
+            // the next group reuses the bins: labels this group deferred (they are addressed by their position in the bins) leave now
+            SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_DEFER, eq->d_ctr + CTR_DEFER, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            SF_HIP(hipStreamSynchronize(st));
+            const uint64_t n_def_now = eq->h_ctr[CTR_DEFER];
+            if (n_def_now > saved_def) {
+                if ((rc = eq_deferred_save(eq, eq->part_words.p, eq->deferred_a.p + 2 * saved_def, n_def_now - saved_def))) return rc;
+                saved_def = n_def_now;
+            }
+        }
     }
-    SF_CHECK_LAUNCH();
-    PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode};
-    hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, st, pa);
-    SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev1, st));
     SF_HIP(hipMemcpyAsync(eq->h_ctr, eq->d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
@@ -844,7 +927,8 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     eq->arena_used = eq->h_ctr[CTR_ARENA];
     const uint64_t n_def = eq->h_ctr[CTR_DEFER], n_long = eq->h_ctr[3];
     eq->stats.hot_reads += eq->h_ctr[CTR_HOT];
-    return eq_part_fixups(eq, d_ids, d_offsets, eq->part_words.p, eq->deferred_a.p, eq->part_long.p, n_def, n_long);
+    if (n_def > saved_def && (rc = eq_deferred_save(eq, eq->part_words.p, eq->deferred_a.p + 2 * saved_def, n_def - saved_def))) return rc;
+    return eq_part_fixups(eq, d_ids, d_offsets, eq->part_long.p, n_long);
 }
 
 constexpr uint32_t kScoutReads = 1u << 19;      // the first sub-batch of a builder: enough reads to see which classes are hot
@@ -879,7 +963,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
     *consumed = 0;
     hipStream_t sr = eq->stream;
     int rc;
-    if ((eq->cap >> kRegionBits) > (uint64_t)kMaxRegions) return SFGPU_OK;
+    if ((eq->cap >> kRegionBits) > (uint64_t)kGroupRegions) return SFGPU_OK;       // (tables built in groups take the serial form)
     if (!eq->ins_stream) {
         SF_HIP(stream_acquire(&eq->ins_stream));
         SF_HIP(hipEventCreateWithFlags(&eq->ev_fork, hipEventDisableTiming));
@@ -957,7 +1041,8 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
             sfgpu_eq::PartSet& S = eq->pset[(k + j) & 1];
             if (!S.fix) continue;
             S.fix = false; fixed = true;
-            if ((r = eq_part_fixups(eq, d_ids, d_offsets, S.words.p, S.deferred.p, S.longl.p, S.n_def, S.n_long))) return r;
+            if ((r = eq_deferred_save(eq, S.words.p, S.deferred.p, S.n_def))) return r;
+            if ((r = eq_part_fixups(eq, d_ids, d_offsets, S.longl.p, S.n_long))) return r;
         }
         if (fixed) {                                  // the generic kernel committed classes the device-side counter has not seen
             hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, sr, eq->d_ctr + CTR_GCLS, (unsigned long long)eq->n_classes);
@@ -976,7 +1061,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
     {
         const uint64_t span = std::min<uint64_t>(n_reads, 2 * kMaxSubBatch);
         const uint64_t words_span = std::min<uint64_t>(batch_words, (uint64_t)((double)batch_words / (double)n_reads * 1.25 * (double)span) + 1024);
-        const uint64_t need = eq->arena_used + words_span + 4 * span + 4;
+        const uint64_t need = eq->arena_used + words_span + 8 * span + 4;
         SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
         if ((rc = eq->arena.reserve(need, sr, true, eq->arena_used))) return rc;
         const uint64_t cls_need = eq->n_classes + span + 1;
@@ -1005,11 +1090,11 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
             while (eq->n_classes + kMinHeadroom > eq->cap / load_div) if ((rc = eq_grow(eq, eq->cap * 2))) return rc;
         }
         {
-            uint64_t need = eq->arena_used + fly_words + 4 * fly_reads + n_words + 4ull * cnt + 4;
+            uint64_t need = eq->arena_used + fly_words + 8 * fly_reads + n_words + 8ull * cnt + 4;
             uint64_t cls_need = eq->n_classes + fly_reads + cnt + 1;
             if (need > eq->arena.cap || cls_need > eq->cls_hash.cap) {
                 if ((rc = drain())) return rc;
-                need = eq->arena_used + n_words + 4ull * cnt + 4; cls_need = eq->n_classes + cnt + 1;
+                need = eq->arena_used + n_words + 8ull * cnt + 4; cls_need = eq->n_classes + cnt + 1;
                 SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
                 SF_REQUIRE(cls_need < kArenaBit, SFGPU_ERR_RANGE, "more than 2^31 equivalence classes");
                 if ((rc = eq->arena.reserve(need, sr, true, eq->arena_used))) return rc;
@@ -1017,7 +1102,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
                     (rc = eq->cls_len.reserve(cls_need, sr, true, eq->n_classes)) || (rc = eq->cls_slot.reserve(cls_need, sr, true, eq->n_classes))) return rc;
             }
         }
-        if ((eq->cap >> kRegionBits) > (uint64_t)kMaxRegions) { bail = true; break; }
+        if ((eq->cap >> kRegionBits) > (uint64_t)kGroupRegions) { bail = true; break; }
         const uint32_t n_regions = (uint32_t)(eq->cap >> kRegionBits);
         const PartGeom gm = part_geometry(cnt, n_words, n_regions, part_max_blocks());
         if (gm.n_bins * gm.cap >= (1ull << 31)) { bail = true; break; }
@@ -1055,7 +1140,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
         uint4* bins = reinterpret_cast<uint4*>(S.words.p);
         uint32_t* fill_f = S.hist.p, *fill_b = fill_f + gm.n_bins, *cutmarks = fill_b + gm.n_bins;
         RouteArgs ra{d_ids, d_offsets + first, first, cnt, gm.tile, n_regions - 1u, (uint32_t)gm.cap, bins, fill_f, fill_b, cutmarks,
-                     S.d_ctr + CTR_TMP, S.longl.p, eq->hot_bufs[eq->hot_cur].p, eq->arena.p, eq->table.p, S.d_ctr + CTR_HOT, eq->mix_mode};
+                     S.d_ctr + CTR_TMP, S.longl.p, eq->hot_bufs[eq->hot_cur].p, eq->arena.p, eq->table.p, S.d_ctr + CTR_HOT, eq->mix_mode, 0u, n_regions};
         const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
         hipLaunchKernelGGL(k_part_route<false>, dim3(gm.n_blocks), dim3(kPartBlock), route_lds, sr, ra);
         SF_CHECK_LAUNCH();
@@ -1070,7 +1155,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
         // ---- insert(k) on the second stream, behind route(k) (and, in stream order, behind insert(k - 1))
         SF_HIP(hipStreamWaitEvent(si, S.ev_route, 0));
         PartArgs pa{eq->table.p, bins, fill_f, fill_b, gm.n_blocks, (uint32_t)gm.cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                    eq->arena.p, S.d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, S.deferred.p, eq->mix_mode};
+                    eq->arena.p, S.d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, S.deferred.p, eq->mix_mode, 0u};
         hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, si, pa);
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(S.h_ctr, S.d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, si));
@@ -1137,10 +1222,10 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     uint64_t batch_ids = (uint64_t)ends[1] - ends[0];
     int rc;
     // arena room for the reads about to be inserted -- worst case every read opens a class: its ids + the
-    // entry header and padding (<= 4 words).  Reserved per sub-batch on the partitioned path (a 400 M-read
+    // entry header and padding (<= 4 words) + the probe granule in front of the entry (4 words).  Reserved per sub-batch on the partitioned path (a 400 M-read
     // batch would otherwise pin 13 GB for ~30 MB of labels), once per batch on the generic one.
     auto reserve_arena = [&](uint64_t words, uint64_t reads) -> int {
-        const uint64_t need = eq->arena_used + words + 4 * reads + 4;
+        const uint64_t need = eq->arena_used + words + 8 * reads + 4;
         SF_REQUIRE((need >> 2) < kArenaBit, SFGPU_ERR_RANGE, "sfgpu_eq_add_batch: label arena would exceed 2^33 words");
         return eq->arena.reserve(need, st, true, eq->arena_used);
     };

@@ -34,7 +34,8 @@ constexpr uint32_t kRegionSlots = 1u << kRegionBits;          // 4096 slots: 32 
 constexpr uint32_t kRegionLimit = kRegionSlots / 4 * 3;       // inserts beyond this occupancy are deferred
 constexpr int kPartBlock = 1024;
 constexpr int kPartWaves = kPartBlock / 64;
-constexpr int kMaxRegions = 8192;
+constexpr int kMaxRegions = 1 << 19;                          // the whole range of the table (2^31 slots); the passes handle kGroupRegions at a time
+constexpr uint32_t kGroupRegions = 4096;                      // regions per launch pair: 2 x 4096 x 4 B of cursors next to a second block in LDS
 constexpr uint32_t kHeadBit = 0x80000000u;
 constexpr uint32_t kMaxPartLabel = 123;                       // ids: the length travels in 7 bits of H, a label is <= 31 granules
 constexpr int kTagBits = 24 - kRegionBits;                    // tag bits carried in H next to the slot (the table keeps 32)
@@ -112,6 +113,11 @@ struct RouteArgs {
     const uint32_t* arena; uint64_t* table;
     unsigned long long* n_hot_reads;               // statistics: reads counted here
     uint32_t mix_mode;                             // bucket hash of long labels: kMixSampled / kMixFull (xxh64_device.h)
+    // A launch handles the regions [grp_lo, grp_lo + grp_n) only: its LDS cursors and its bins are laid out for grp_n regions, and
+    // a read whose label lives elsewhere is skipped altogether (not stored, not counted hot, not spilled) -- another launch over the
+    // same reads takes it.  One group = the whole table up to kGroupRegions regions; larger tables (more than ~8 M classes) are
+    // built in several passes over the sub-batch instead of falling back to the generic kernel (round 4).
+    uint32_t grp_lo, grp_n;
 };
 
 constexpr uint32_t kCountedBit = 0x80000000u;          // in H: the label is followed by a granule [count, 0, 0, 0]
@@ -153,7 +159,7 @@ k_part_route(RouteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SW = RING ? kRingStageWords : kStageWords;
     constexpr uint32_t HS = RING ? kRingHotSlots : kHotSlots;
-    const uint32_t NR = a.region_mask + 1u;
+    const uint32_t NR = a.grp_n;                   // regions of this launch (= the whole table unless it is built in groups)
     // LDS: [ring: NR x 8 granules] | per region 2 words (RING: {cursors, unit state}; else {cursor, cut}) | staging | hot table
     uint4* ring4 = reinterpret_cast<uint4*>(smem);
     unsigned int* cur = reinterpret_cast<unsigned int*>(smem + (RING ? (size_t)NR * 128u : 0u));      // !RING: NR: granules taken from my bin of region r
@@ -224,7 +230,7 @@ k_part_route(RouteArgs a) {
         const bool staged = ((w_hi - w_lo + mis + 3u) >> 2) <= (uint32_t)SW / 4;
         stage4[lane] = x0;
         if (SW / 4 > 64 && lane + 64u < (uint32_t)SW / 4 + 4u) stage4[lane + 64u] = x1;
-        const uint32_t bit31_here = (x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w) & kHeadBit;      // (the step's ids as fetched: a superset of its labels' ids)
+        const uint32_t bit31_here = (x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w) & (kHeadBit | kCompactBit);      // (the step's ids as fetched: a superset of its labels' ids)
         // my label: [b, e)
         const uint32_t nxt = __shfl_down(o, 1, kWave);
         const uint32_t b = o, e = (lane == 63u || r0 + lane + 1u >= re) ? oe : nxt;
@@ -247,12 +253,26 @@ k_part_route(RouteArgs a) {
 #pragma unroll
         for (int q = 0; q < kHead; ++q) { w[q] = ((uint32_t)q < len) ? w[q] : 0u; mx = mx > w[q] ? mx : w[q]; }
         const bool unfit = len > kMaxPartLabel;
+        // ---- the COMPACT form (eqclass.hip, label_probe): 4 .. 9 ids below 2^24 ascending in steps of 0 .. 255 -> first id + eight
+        //      8-bit steps, one granule
+        const uint32_t w8 = staged ? lab_s[8] : ((len > 8u && !unfit) ? lab_g[8] : 0u);            // (the staging buffer has 16 words of slack)
+        bool compact = len >= 4u && len <= kMaxCompactLen && w[0] < (1u << 24);
+        uint32_t dlo = 0u, dhi = 0u;
+#pragma unroll
+        for (int k = 1; k <= 8; ++k) {
+            const uint32_t d = ((k < 8) ? w[k < 8 ? k : 7] : w8) - w[k - 1];
+            const bool live = (uint32_t)k < len;
+            compact = compact && (!live || d <= 255u);
+            const uint32_t dm = live ? (d & 255u) : 0u;
+            if (k <= 4) dlo |= dm << (8 * (k - 1)); else dhi |= dm << (8 * (k - 5));
+        }
         // ---- bucket hash (xxh64_device.h): length, the first 8 ids, and for longer labels the last and the middle id -- no walk
         //      over the tail (13 % of the labels have one: a lane walking its tail while the others wait cost this pass half of
         //      its vector instructions)
         uint32_t ha, hb;
         label_mix_head(w, len, ha, hb);
-        const uint32_t ng = label_granules(len);
+        const uint32_t ngl = label_granules(len);                 // granules of the label in the multi-granule form (compares)
+        const uint32_t ng = compact ? 1u : ngl;                   // ... and in the stream
         // granule g >= 2 (ids 4g-1 .. 4g+2, zero padded) of the label that starts at id `lb` and holds `ll` ids
         auto granule_at = [&](uint32_t lb, uint32_t ll, uint32_t g) -> uint4 {
             const uint32_t q = 4u * g - 1u;
@@ -275,8 +295,9 @@ k_part_route(RouteArgs a) {
         }
         const uint64_t h = label_mix_final(ha, hb);
         // an id >= 2^31 would collide with the label marker of the partition stream (no real transcriptome has one)
-        bool generic = unfit || (mx & kHeadBit);
-        const uint32_t rg = ((uint32_t)h >> kRegionBits) & a.region_mask;
+        bool generic = unfit || (mx & (kHeadBit | kCompactBit));
+        const uint32_t rg = (((uint32_t)h >> kRegionBits) & a.region_mask) - a.grp_lo;      // region inside this launch's group
+        const bool in_grp = rg < NR;
         const uint32_t H = (len << 24) | ((uint32_t)(h >> (64 - kTagBits)) << kRegionBits) | ((uint32_t)h & (kRegionSlots - 1));
         // ---- runs: a read whose label is the previous read's (the lane below, same step) rides with it.  Reads that arrive
         //      clustered (a position-sorted file: 64 consecutive reads hold one or two labels) would otherwise pile into a few
@@ -298,7 +319,7 @@ k_part_route(RouteArgs a) {
         uint32_t mult = 1;
         if (dm && !dup) { const unsigned long long after = lane == 63u ? 0ull : (dm >> (lane + 1u)); mult = 1u + (uint32_t)__builtin_ctzll(~after); }
         bool counted = false;
-        if (have_hot && len != 0 && !generic && !dup) {
+        if (have_hot && len != 0 && !generic && !dup && in_grp) {
             uint32_t hi = hot_index(h, HS);
             const HotTag hk = RING ? (HotTag)(h >> 32) : (HotTag)h;
             HotTag hv = hot_hl[hi];
@@ -310,16 +331,19 @@ k_part_route(RouteArgs a) {
                 const uint4 e0 = e[0];
                 bool same = e0.x == len && e0.y == w[0] && e0.z == w[1] && e0.w == w[2];
                 if (same && len > 3u) { const uint4 e1 = e[1]; same = e1.x == w[3] && e1.y == w[4] && e1.z == w[5] && e1.w == w[6]; }
-                for (uint32_t g = 2; same && g < ng; ++g) {
+                for (uint32_t g = 2; same && g < ngl; ++g) {
                     const uint4 v = granule(g), eg = e[g];
                     same = eg.x == v.x && eg.y == v.y && eg.z == v.z && eg.w == v.w;
                 }
                 if (same) { atomicAdd(&hot_cnt[hi], mult); counted = true; }
             }
         }
-        const bool place = len != 0 && !generic && !counted && !dup;
+        const bool place = len != 0 && !generic && !counted && !dup && in_grp;
         const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
-        auto head_granule = [&]() { return make_uint4(w[0] | kHeadBit, H | (mult > 1u ? kCountedBit : 0u), w[1], w[2]); };
+        auto head_granule = [&]() {
+            const uint32_t hx = H | (mult > 1u ? kCountedBit : 0u);
+            return compact ? make_uint4(w[0] | kHeadBit | kCompactBit, hx, dlo, dhi) : make_uint4(w[0] | kHeadBit, hx, w[1], w[2]);
+        };
         auto count_granule = [&]() { return make_uint4(mult, kCountedBit, 0u, 0u); };       // (bit 31 of .y: no id has it -- such labels take the generic kernel)
         // granule j of what my label puts into the stream: head, ids 3..6, tail granules, the run's count
         auto stream_granule = [&](uint32_t j) -> uint4 {
@@ -335,7 +359,7 @@ k_part_route(RouteArgs a) {
                     uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
                     dst[0] = head_granule();
                     if (mult > 1u) dst[ng] = count_granule();
-                    if (len > 3u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                    if (ng > 1u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
                     for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
                 } else {
                     atomicMin(&cut[rg], at);                                                // the bin ends before this label
@@ -502,7 +526,7 @@ k_part_route(RouteArgs a) {
             // one cursor update per wavefront, not per read: a label that holds a large part of the reads (a highly expressed
             // gene) overflows its bins read after read, and millions of returning atomics on ONE address serialise
             // (measured: 10 % of 50 M reads on one label, 76 ms for a 2.4 ms build)
-            bool spill = len != 0 && generic;
+            bool spill = len != 0 && generic && in_grp;
             if (dm) {                                                                   // the reads of a run follow its first read
                 const unsigned long long lead = ~dm & ((2ull << lane) - 1ull);           // (lane 63: 2 << 63 wraps to 0, - 1 = all ones)
                 const int ll = 63 - __builtin_clzll(lead | 1ull);
@@ -560,6 +584,7 @@ struct PartArgs {
                                            // many classes the launch before it created (the host may still be a sub-batch behind)
     uint32_t* deferred;                    // (granule index of the label in the bins, length) of labels that found their region full
     uint32_t mix_mode;                     // bucket hash of long labels (the full tag of a new class is computed at commit)
+    uint32_t grp_lo;                       // block b handles table region grp_lo + b; the bins are laid out for gridDim.x regions
 };
 
 // ---- pass 2: one block per region
@@ -591,8 +616,8 @@ k_part_insert(PartArgs a) {
     __shared__ unsigned int s_occ, s_ncls, s_nold, s_nnew, s_newwords;
     __shared__ unsigned long long s_arena0, s_cid0;
     static_assert(kRegionBits == 12, "slot32 packs a 12-bit tag, a 7-bit length and a 13-bit class index");
-    const uint32_t region = blockIdx.x;
-    const uint64_t rb = (uint64_t)region * kRegionSlots;
+    const uint32_t region = blockIdx.x;                                   // (inside the group: bins and fills are indexed by it)
+    const uint64_t rb = (uint64_t)(a.grp_lo + region) * kRegionSlots;       // the region's slots in the table
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // this wavefront's bins: lane t holds the fills of bin wave + 16 t.  A bin is two SEGMENTS of whole labels: [0, fill) and
     // [cap - fill_back, cap); segment t < 64 is the front of bin t, segment 64 + t its back
@@ -613,7 +638,7 @@ k_part_insert(PartArgs a) {
             const uint32_t idx = atomicAdd(&s_ncls, 1u);
             if (idx < kMaxRegionClasses) {
                 const uint32_t rep = (uint32_t)w;
-                const uint4 h = reinterpret_cast<const uint4*>(a.arena)[rep & ~kArenaBit];       // [n, id0, id1, id2]
+                const uint4 h = reinterpret_cast<const uint4*>(a.arena)[(rep & ~kArenaBit) - 1u];   // the class's probe granule [n, p0, p1, p2]
                 chead[idx] = make_uint4(rep, h.y, h.z, h.w);
                 e = ((uint32_t)(w >> 52) << 20) | ((h.x & 0x7Fu) << 13) | idx;
             } else overfull = true;                          // (a table loaded beyond 1/2 by the generic kernel: see below)
@@ -655,7 +680,8 @@ k_part_insert(PartArgs a) {
         const bool is_head = lane < cnt && (g.x & kHeadBit);
         const uint32_t H = g.y;
         const uint32_t len = (H >> 24) & 0x7Fu;
-        const uint32_t ng = label_granules(len);
+        const bool compact = (g.x & kCompactBit) != 0u;       // the whole label is in this granule (first id + 8-bit steps)
+        const uint32_t ng = compact ? 1u : label_granules(len);
         const uint32_t multi = H >> 31;                        // a run of identical reads: one more granule holds its length
         // labels whose granules are not all in this step wait for the next one, which starts at the first of them (a label
         // is <= 32 granules, so the label at lane 0 is always whole; the last step of a bin holds whole labels only)
@@ -713,7 +739,7 @@ k_part_insert(PartArgs a) {
                 const uint32_t idx = e & kSlotIdxMask;
                 const uint4 hd = chead[idx];
                 bool same = hd.y == w0 && hd.z == w1 && hd.w == w2;
-                if (same && len > 3u) {
+                if (same && len > 3u && !compact) {          // (a compact granule IS the label: equal words, equal labels)
                     if (!serial) { c_idx = idx; c_rep = hd.x; return true; }
                     const uint4* r = (hd.x & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (hd.x & ~kArenaBit) : a.bins + hd.x;
                     for (uint32_t j = 1; same && j < ng; ++j) {
@@ -777,7 +803,7 @@ k_part_insert(PartArgs a) {
         // (n_new == s_newwords: every class that won its slot is in the list once)
         if (threadIdx.x == 0) s_newwords = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, entry_words((slot32[new_slots[i]] >> 13) & 0x7Fu));
+        for (uint32_t i = threadIdx.x; i < n_new; i += kPartBlock) atomicAdd(&s_newwords, class_words((slot32[new_slots[i]] >> 13) & 0x7Fu));
         __syncthreads();
         if (threadIdx.x == 0) {
             s_cid0 = atomicAdd(a.gcls, (unsigned long long)n_new);
@@ -792,10 +818,13 @@ k_part_insert(PartArgs a) {
             const uint32_t idx = e & kSlotIdxMask, len = (e >> 13) & 0x7Fu;
             const uint32_t rep = chead[idx].x;
             const uint64_t cid = s_cid0 + i;
-            const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, entry_words(len));
+            const uint64_t dst = s_arena0 + atomicAdd(&s_newwords, class_words(len)) + kProbeWords;      // the entry; its probe granule in front
             const uint32_t* p = reinterpret_cast<const uint32_t*>(a.bins + rep);
             const uint32_t w0 = p[0] & ~kHeadBit;
-            auto word = [&](uint32_t k) { return k ? p[k + 1] : w0; };
+            const bool cpt = (w0 & kCompactBit) != 0u;
+            const uint32_t clo = p[2], chi = p[3];
+            auto word = [&](uint32_t k) { return cpt ? compact_id(w0, clo, chi, k) : (k ? p[k + 1] : w0); };
+            probe_write(a.arena, dst - kProbeWords, word, len);
             entry_write(a.arena, dst, word, len);
             a.cls_hash[cid] = xxh64_words(word, len);
             a.cls_off[cid] = dst + 1; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
@@ -815,18 +844,22 @@ __global__ void k_deferred_lens(uint64_t n, const uint32_t* __restrict__ deferre
     if (i > n) return;
     lens[i] = (i == n) ? 0u : (deferred[2 * i + 1] & 0x7Fu);
 }
+// (ids_out / off_out / weights_out point BEHIND what earlier calls saved; base_words = ids saved before: the offsets continue)
 __global__ void k_deferred_copy(uint64_t n, const uint32_t* __restrict__ deferred, const uint4* __restrict__ bins,
-                                const uint64_t* __restrict__ off64, uint32_t* ids_out, uint32_t* off_out, uint64_t* weights_out) {
+                                const uint64_t* __restrict__ off64, uint32_t* ids_out, uint32_t* off_out, uint64_t* weights_out, uint64_t base_words) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    off_out[i] = (uint32_t)off64[i];
+    off_out[i] = (uint32_t)(base_words + off64[i]);
     if (i == n) return;
     uint32_t len = (uint32_t)(off64[i + 1] - off64[i]);
-    // a run of identical reads carries its length in the granule behind the label (bit 31 of the deferred length word)
-    weights_out[i] = (deferred[2 * i + 1] >> 31) ? (uint64_t)bins[deferred[2 * i] + label_granules(len)].x : 1ull;
     const uint32_t* p = reinterpret_cast<const uint32_t*>(bins + deferred[2 * i]);
+    const uint32_t w0 = p[0] & ~kHeadBit;
+    const bool cpt = (w0 & kCompactBit) != 0u;                 // the label is one compact granule: first id + 8-bit steps
+    // a run of identical reads carries its length in the granule behind the label (bit 31 of the deferred length word)
+    weights_out[i] = (deferred[2 * i + 1] >> 31) ? (uint64_t)bins[deferred[2 * i] + (cpt ? 1u : label_granules(len))].x : 1ull;
     uint32_t* q = ids_out + off64[i];
-    q[0] = p[0] & ~kHeadBit;
+    if (cpt) { for (uint32_t k = 0; k < len; ++k) q[k] = compact_id(w0, p[2], p[3], k); return; }
+    q[0] = w0;
     for (uint32_t k = 1; k < len; ++k) q[k] = p[k + 1];
 }
 

@@ -395,11 +395,13 @@ def test_builder_growth_and_deferral(sf, gpu, monkeypatch, sub_batch):
     assert np.all(np.diff(first) >= 0)              # canonical order: first id ascending (then hash)
 
 
-def test_builder_beyond_partition_limit(sf, gpu):
-    """9 M distinct labels: the table passes 16 M slots, the size up to which the radix-partitioned kernels
-    run (load 1/2 there), and the generic kernel takes over -- counts and classes stay exact"""
+@pytest.mark.parametrize("n,dup,min_slots", [(9_000_000, 3_000_000, 1 << 24), (20_000_000, 4_000_000, 1 << 25)])
+def test_builder_beyond_partition_limit(sf, gpu, n, dup, min_slots):
+    """9 M / 20 M distinct labels: the table passes 16 M slots (4096 regions), the size up to which ONE route + insert pass
+    covers every region.  Rounds 1-3 handed larger tables to the generic kernel; since round 4 they are built in groups of 4096
+    regions (one route + insert pass over the sub-batch per group, eq_partitioned) -- counts and classes stay exact, and the
+    partitioned kernels keep running (the table grows through 2, 4 and 8 groups on the way)"""
     import torch
-    n, dup = 9_000_000, 3_000_000
     g = torch.Generator(device=gpu); g.manual_seed(1)
     a = torch.randperm(n, generator=g, device=gpu, dtype=torch.int64)
     ids = torch.stack([a, (a * 7 + 3) % 1000], 1).reshape(-1).to(torch.int32)
@@ -408,13 +410,15 @@ def test_builder_beyond_partition_limit(sf, gpu):
     eq = sf.EquivalenceClassBuilder(device=gpu)
     eq.start(); eq.add_batch(ids, off); eq.finish()
     v = eq.eqVec()
-    assert eq.n_classes == n and eq.total_reads == n + dup and eq.stats()["table_slots"] > (1 << 24)
+    st = eq.stats()
+    assert eq.n_classes == n and eq.total_reads == n + dup and st["table_slots"] > min_slots
     cc = v.counts
     assert int(cc.sum()) == n + dup and int((cc == 2).sum()) == dup and int((cc == 1).sum()) == n - dup
     first = v.ids.view(-1, 2)[:, 0].to(torch.int64)
     assert bool((first[1:] > first[:-1]).all())              # canonical order; every first id is distinct here
     twice = first[cc == 2]
     assert bool(torch.equal(torch.sort(twice).values, torch.sort(a[:dup]).values))
+    assert bool((sf.xxh64_labels(v.ids, v.rowptr, device=gpu) == v.hashes).all())
 
 
 @pytest.mark.parametrize("shape", ["uniform", "hot", "sorted", "many_classes", "long_and_empty"])

@@ -7,7 +7,7 @@ from sailfish_amd import synth
 dev = torch.device("cuda:0")
 M, P, R = 80_000, 1_000_000, 50_000_000
 if os.environ.get('EQ_CFG3'): M, P, R = 200_000, 4_000_000, 400_000_000
-poff, pids = synth.label_pool(M, P, device=dev)
+poff, pids = synth.label_pool(M, P, device=dev, max_k=int(os.environ.get('EQ_MAXK', '200')))     # EQ_MAXK=3: every label one granule
 ids, off = synth.reads_from_pool(poff, pids, R, device=dev)
 expected = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 eq = sf.EquivalenceClassBuilder(device=dev, expected_classes=expected)
