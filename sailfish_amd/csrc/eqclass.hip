@@ -868,6 +868,13 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         ring = false;
         gm = part_geometry(cnt, n_words, n_regions, part_max_blocks());
     }
+    // the QUAD form of pass 1 (single-granule labels written four at a time through LDS mailboxes, eqclass_part.h): tables of up
+    // to 1024 regions, bins the 16-bit cursors can address.  OFF by default (SFGPU_EQ_QUAD=1 selects it): it does write whole
+    // 64-byte units, but its per-region ticket couples the wavefronts of a block (a label waits for every label that reserved
+    // before it in its region, wherever that wavefront is) -- route 8.75 ms per build against the direct form's 8.0 on one box
+    // (profiles/r4_class_build_notes.md).
+    const int quad_mode = []() { const char* e = getenv("SFGPU_EQ_QUAD"); return e ? atoi(e) : 0; }();         // (read per sub-batch: tests switch it)
+    const bool quad = !ring && quad_mode != 0 && n_groups == 1 && n_regions >= 2 && n_regions <= kRingMaxRegions && gm.cap <= kRingMaxCap;
     const uint32_t n_blocks = gm.n_blocks, tile = gm.tile;
     const uint64_t cap = gm.cap, n_bins = (uint64_t)grp_n * n_blocks;
     // positions inside the bins are 31-bit granule indices (bit 31 of a slot's rep marks arena entries)
@@ -880,7 +887,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     SF_CHECK_LAUNCH();
     SF_HIP(hipEventRecord(eq->ev0, st));
     uint4* bins = reinterpret_cast<uint4*>(eq->part_words.p);
-    const uint32_t hs = ring ? kRingHotSlots : kHotSlots;
+    const uint32_t hs = (ring || quad) ? kRingHotSlots : kHotSlots;
     bool rebuilt = false;
     if ((rc = eq_hot_refresh(eq, n_regions, hs, st, eq->hot_cur, eq->reads_seen, eq->n_classes != 0, &rebuilt))) return rc;
     unsigned long long* hot_h = eq->hot_bufs[eq->hot_cur].p;
@@ -894,18 +901,26 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
             const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
                                      (size_t)kPartWaves * kRingFlushList * 4;
             static const bool attr_ok = []() {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_route<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_route<kFormRing>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             }();
             (void)attr_ok;
-            hipLaunchKernelGGL(k_part_route<true>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+            hipLaunchKernelGGL(k_part_route<kFormRing>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+        } else if (quad) {
+            const size_t route_lds = (size_t)n_regions * 48 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8;
+            static const bool attr_ok = []() {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_route<kFormQuad>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+            }();
+            (void)attr_ok;
+            hipLaunchKernelGGL(k_part_route<kFormQuad>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
         } else {
             const size_t route_lds = (size_t)2 * grp_n * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
-            hipLaunchKernelGGL(k_part_route<false>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+            hipLaunchKernelGGL(k_part_route<kFormDirect>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
         }
         SF_CHECK_LAUNCH();
         PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
                     eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo};
-        hipLaunchKernelGGL(k_part_insert, dim3(grp_n), dim3(kPartBlock), 0, st, pa);
+        static const bool route_only = getenv("SFGPU_X_ROUTE_ONLY") != nullptr;     // (dev: time pass 1 alone -- its experiment variants leave no valid bins)
+        if (!route_only) hipLaunchKernelGGL(k_part_insert, dim3(grp_n), dim3(kPartBlock), 0, st, pa);
         SF_CHECK_LAUNCH();
         if (g + 1 < n_groups) {
             // the next group reuses the bins: labels this group deferred (they are addressed by their position in the bins) leave now
@@ -1142,7 +1157,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
         RouteArgs ra{d_ids, d_offsets + first, first, cnt, gm.tile, n_regions - 1u, (uint32_t)gm.cap, bins, fill_f, fill_b, cutmarks,
                      S.d_ctr + CTR_TMP, S.longl.p, eq->hot_bufs[eq->hot_cur].p, eq->arena.p, eq->table.p, S.d_ctr + CTR_HOT, eq->mix_mode, 0u, n_regions};
         const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
-        hipLaunchKernelGGL(k_part_route<false>, dim3(gm.n_blocks), dim3(kPartBlock), route_lds, sr, ra);
+        hipLaunchKernelGGL(k_part_route<kFormDirect>, dim3(gm.n_blocks), dim3(kPartBlock), route_lds, sr, ra);
         SF_CHECK_LAUNCH();
         SF_HIP(hipEventRecord(S.ev_route, sr));
         // ---- (B) the hot table of the NEXT sub-batch, if due: behind insert(k - 1), ahead of insert(k)

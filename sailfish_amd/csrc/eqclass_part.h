@@ -152,24 +152,39 @@ __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slot
 // buffer with coalesced, 16-byte-aligned loads (lane-per-label loads from global memory cost the texture addresser one
 // cycle per lane and dword: measured TA-bound, profiles/r2_class_build_notes.md); the lanes then pick their labels out
 // of LDS.  The next step's offsets and ids are requested before this step's labels are hashed.
-// RING = false: the form of round 2 (any number of regions, two blocks per CU); RING = true: bins written through LDS rings.
-template <bool RING>
-__global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(RING ? 4 : 8, RING ? 4 : 8)))
+// FORM 0 (direct): the form of round 2 -- any number of regions, two blocks per CU, every granule stored where it belongs.
+// FORM 1 (ring, round 3): bins written through LDS rings of two 64-byte units per region; one block per CU; off by default.
+// FORM 2 (quad, round 4): since the compact stream format 92 % of the labels are ONE granule.  Those take the FRONT of their bin
+//   four at a time: a region has a three-granule mailbox in LDS and a ticket (the next front position allowed to act); the
+//   labels at positions 4u .. 4u + 2 leave their granule in the mailbox, the one at 4u + 3 takes all three out and writes the
+//   64-byte unit -- four stores of one lane to one aligned 64-byte segment, which the L2 hands on as ONE write.  What bounds the
+//   direct form is the number of partial writes leaving the L2 (3.5 of its 8.4 ms, profiles/r4_class_build_notes.md), and a
+//   64-byte write costs the memory side what a 16-byte one does (tools/probes/scatter_write_probe.hip).  Labels of several granules
+//   and runs are stored directly from the BACK of the bin (pass 2 streams both segments, as for the ring form).  48 KB of
+//   mailboxes for 1024 regions fit next to a second block with the ring form's smaller staging buffers and hot table.
+//   MEASURED SLOWER than the direct form (8.75 vs 8.0 ms per build): the ticket makes a label wait for every earlier label of its
+//   region, in whatever wavefront that is -- the wavefronts of a block no longer run independently.  Off by default, kept with its
+//   parity tests (builder_stress.py switches it) as the record of the attempt.
+constexpr int kFormDirect = 0, kFormRing = 1, kFormQuad = 2;
+template <int FORM>
+__global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(FORM == kFormRing ? 4 : 8, FORM == kFormRing ? 4 : 8)))
 k_part_route(RouteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int SW = RING ? kRingStageWords : kStageWords;
-    constexpr uint32_t HS = RING ? kRingHotSlots : kHotSlots;
+    constexpr bool RING = FORM == kFormRing, QUAD = FORM == kFormQuad, SMALL = FORM != kFormDirect;
+    constexpr int SW = SMALL ? kRingStageWords : kStageWords;
+    constexpr uint32_t HS = SMALL ? kRingHotSlots : kHotSlots;
     const uint32_t NR = a.grp_n;                   // regions of this launch (= the whole table unless it is built in groups)
     // LDS: [ring: NR x 8 granules] | per region 2 words (RING: {cursors, unit state}; else {cursor, cut}) | staging | hot table
     uint4* ring4 = reinterpret_cast<uint4*>(smem);
-    unsigned int* cur = reinterpret_cast<unsigned int*>(smem + (RING ? (size_t)NR * 128u : 0u));      // !RING: NR: granules taken from my bin of region r
+    unsigned int* cur = reinterpret_cast<unsigned int*>(smem + (RING ? (size_t)NR * 128u : (QUAD ? (size_t)NR * 48u : 0u)));      // direct: NR: granules taken from my bin of region r
     unsigned int* cut = cur + NR;                                                     // !RING: NR: first granule of a label that did not fit
-    uint2* cbst = reinterpret_cast<uint2*>(cur);                                      // RING: NR x {cursors, unit state}
+    uint2* cbst = reinterpret_cast<uint2*>(cur);                                      // RING: NR x {cursors, unit state}; QUAD: NR x {cursors, ticket}
+    uint4* mail = reinterpret_cast<uint4*>(smem);                                     // QUAD: NR x 3 granules
     const uint32_t B1 = gridDim.x, blk = blockIdx.x, cap = a.cap, tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     uint4* stage4 = reinterpret_cast<uint4*>(cut + NR) + wave * (SW / 4 + 4);   // this wavefront's staging buffer (+ slack)
     const uint32_t* stage = reinterpret_cast<const uint32_t*>(stage4);
-    if constexpr (RING) {
+    if constexpr (RING || QUAD) {
         for (uint32_t r = tid; r < NR; r += kPartBlock) cbst[r] = make_uint2(0u, 0u);
         for (uint32_t r = tid; r < 2u * NR; r += kPartBlock) a.cut[(size_t)blk * NR * 2u + r] = 0xFFFFFFFFu;
         __threadfence();                                                              // (a later atomicMin of another wavefront finds it)
@@ -179,12 +194,12 @@ k_part_route(RouteArgs a) {
     // hot classes: their bucket hashes and a counter each, behind the staging buffers
     // (the ring form has LDS for 32 bits of every hot hash -- a filter; the label compare below decides either way -- and for a
     //  list of 32 completed units per wavefront, kRingFlushList)
-    using HotTag = typename std::conditional<RING, unsigned int, unsigned long long>::type;
+    using HotTag = typename std::conditional<SMALL, unsigned int, unsigned long long>::type;
     HotTag* hot_hl = reinterpret_cast<HotTag*>(reinterpret_cast<uint4*>(cut + NR) + kPartWaves * (SW / 4 + 4));
     unsigned int* hot_cnt = reinterpret_cast<unsigned int*>(hot_hl + HS);
     uint32_t* flist = hot_cnt + HS + wave * kRingFlushList;                                  // RING only
     const bool have_hot = *reinterpret_cast<const unsigned int*>(a.hot + 2 * HS) != 0u;      // (uniform)
-    if (have_hot) for (uint32_t q = tid; q < HS; q += kPartBlock) { hot_hl[q] = RING ? (HotTag)(a.hot[q] >> 32) : (HotTag)a.hot[q]; hot_cnt[q] = 0u; }
+    if (have_hot) for (uint32_t q = tid; q < HS; q += kPartBlock) { hot_hl[q] = SMALL ? (HotTag)(a.hot[q] >> 32) : (HotTag)a.hot[q]; hot_cnt[q] = 0u; }
     const uint32_t t0 = blk * a.tile;
     const uint32_t t1 = (t0 + a.tile < a.n && t0 + a.tile > t0) ? t0 + a.tile : a.n;
     const uint32_t* __restrict__ off = a.off;
@@ -321,7 +336,7 @@ k_part_route(RouteArgs a) {
         bool counted = false;
         if (have_hot && len != 0 && !generic && !dup && in_grp) {
             uint32_t hi = hot_index(h, HS);
-            const HotTag hk = RING ? (HotTag)(h >> 32) : (HotTag)h;
+            const HotTag hk = SMALL ? (HotTag)(h >> 32) : (HotTag)h;
             HotTag hv = hot_hl[hi];
             for (uint32_t p = 1; p < kHotProbes && hv != 0 && hv != hk; ++p) { hi = (hi + 1) & (HS - 1); hv = hot_hl[hi]; }
             if (hv == hk && hv != 0) {
@@ -352,15 +367,74 @@ k_part_route(RouteArgs a) {
             if (j == 1u) return make_uint4(w[3], w[4], w[5], w[6]);
             return granule(j);
         };
-        if constexpr (!RING) {
+        if constexpr (QUAD) {
+            // ---- reservation: one granule -> the front of the bin (through the mailbox), several -> its back (direct stores).  Both
+            //      cursors share one LDS word, and a lane looks before it reserves (a bin that cannot take the label is left alone:
+            //      the 16-bit fields cannot run over)
+            bool front_ok = false;
+            uint32_t pos = 0;
+            if (place) {
+                const uint32_t cs = cbst[rg].x;
+                if ((cs & 0xFFFFu) + (cs >> 16) + ngx > cap) generic = true;
+                else if (ngx == 1u) {
+                    const uint32_t old = atomicAdd(&cbst[rg].x, 1u);
+                    pos = old & 0xFFFFu;
+                    if (pos + (old >> 16) + 1u <= cap) front_ok = true;
+                    else { atomicMin(&a.cut[((size_t)blk * NR + rg) * 2u], pos); __threadfence(); generic = true; }      // (lost a race for the last room)
+                } else {
+                    const uint32_t old = atomicAdd(&cbst[rg].x, ngx << 16);
+                    const uint32_t bk = old >> 16;
+                    if ((old & 0xFFFFu) + bk + ngx <= cap) {
+                        uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + (cap - bk - ngx);
+                        dst[0] = head_granule();
+                        if (mult > 1u) dst[ng] = count_granule();
+                        if (ng > 1u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                        for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
+                    } else { atomicMin(&a.cut[((size_t)blk * NR + rg) * 2u + 1u], bk); __threadfence(); generic = true; }
+                }
+            }
+            // ---- the front: cbst[rg].y is the region's TICKET, the next front position allowed to act.  Positions act strictly in
+            //      order: 4u, 4u + 1, 4u + 2 leave their granule in the mailbox, 4u + 3 takes the three out (into registers -- the
+            //      mailbox is free again the moment the ticket moves on) and writes the unit.  A lane only ever waits for labels
+            //      that reserved BEFORE it, in its own wavefront (they act in this very iteration) or another (it runs on its own):
+            //      no deadlock.  LDS executes a wavefront's instructions in order, which is what orders granule write -> ticket and
+            //      mailbox reads -> ticket; the fences are for the compiler.
+            bool pend = front_ok;
+            const uint4 mineg = head_granule();
+            while (__ballot(pend)) {
+                if (pend && __hip_atomic_load(&cbst[rg].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == pos) {
+                    const uint32_t sl = pos & 3u;
+                    if (sl != 3u) {
+                        mail[rg * 3u + sl] = mineg;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __hip_atomic_store(&cbst[rg].y, pos + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        const uint4 g0 = mail[rg * 3u], g1 = mail[rg * 3u + 1u], g2 = mail[rg * 3u + 2u];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __hip_atomic_store(&cbst[rg].y, pos + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + (pos - 3u);
+                        dst[0] = g0; dst[1] = g1; dst[2] = g2; dst[3] = mineg;
+                    }
+                    pend = false;
+                }
+            }
+        } else if constexpr (!RING) {
             if (place) {
                 const uint32_t at = atomicAdd(&cur[rg], ngx);                               // my granules in the bin (rg, blk)
                 if (at + ngx <= cap) {
+#if defined(SFGPU_X_FOLD)            // experiment: every store lands in 1 MB (L2-resident): what do the stores cost WITHOUT the memory behind the L2?
+                    uint4* dst = a.out + (((size_t)(blk * NR + rg) * cap + at) & 0xFFFFu);
+#else
                     uint4* dst = a.out + (size_t)(blk * NR + rg) * cap + at;
+#endif
+#if !defined(SFGPU_X_NOSTORE)        // experiment: no stores at all
                     dst[0] = head_granule();
                     if (mult > 1u) dst[ng] = count_granule();
                     if (ng > 1u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
                     for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
+#else
+                    if (at == 0xFFFFFFF0u) dst[0] = head_granule();
+#endif
                 } else {
                     atomicMin(&cut[rg], at);                                                // the bin ends before this label
                     generic = true;
@@ -547,7 +621,16 @@ k_part_route(RouteArgs a) {
         if constexpr (RING) { no = nno; noe = nnoe; }
     }
     __syncthreads();
-    if constexpr (!RING) {
+    if constexpr (QUAD) {
+        // what the mailboxes still hold: the last, partial unit of every bin (1 .. 3 granules)
+        for (uint32_t r = tid; r < NR; r += kPartBlock) {
+            const uint32_t c = cbst[r].x;
+            const uint32_t xf = a.cut[((size_t)blk * NR + r) * 2u], xb = a.cut[((size_t)blk * NR + r) * 2u + 1u];
+            const uint32_t f = (c & 0xFFFFu) < xf ? (c & 0xFFFFu) : xf, bk = (c >> 16) < xb ? (c >> 16) : xb;
+            for (uint32_t j = 0; j < (f & 3u); ++j) a.out[(size_t)(blk * NR + r) * cap + (f & ~3u) + j] = mail[r * 3u + j];
+            a.fill[r * B1 + blk] = f; a.fill_back[r * B1 + blk] = bk;
+        }
+    } else if constexpr (!RING) {
         for (uint32_t r = tid; r < NR; r += kPartBlock) { const unsigned int c = cur[r], x = cut[r]; a.fill[r * B1 + blk] = c < x ? c : x; a.fill_back[r * B1 + blk] = 0u; }
     } else {
         // what the rings still hold: the last, partial unit of every bin

@@ -335,14 +335,17 @@ def test_builder_large_host_batch_is_streamed_in_chunks(sf, gpu, monkeypatch, ch
     _assert_same_classes(eq, ob, *oc)
 
 
-def test_builder_ring_form_of_the_route_pass(sf, gpu, monkeypatch):
+@pytest.mark.parametrize("form", ["SFGPU_EQ_RING", "SFGPU_EQ_QUAD"])
+def test_builder_ring_form_of_the_route_pass(sf, gpu, monkeypatch, form):
     """SFGPU_EQ_RING=1: pass 1 writes its bins through LDS rings (whole 64-byte units from the front of a bin, long labels and
     labels that would have to wait for a ring slot directly at its back; eqclass_part.h) -- off by default, measured no faster;
     the classes must be the oracle's whichever form ran: the benchmark's law, a skewed stream with hot labels, runs of identical
     reads, and labels of up to 123 ids"""
     import torch
     from sailfish_amd import synth
-    monkeypatch.setenv("SFGPU_EQ_RING", "1")
+    # (round 4: the same streams through the QUAD form -- single-granule labels written four to a 64-byte unit through per-region
+    #  mailboxes and a ticket; measured slower than the direct form, off by default)
+    monkeypatch.setenv(form, "1")
     rng = np.random.default_rng(12)
     ref_len, ids, off = synth.workload(20000, 150_000, 2_500_000)
     ids_np, off_np = ids.numpy().view(np.uint32), off.numpy().view(np.uint32)
