@@ -1048,6 +1048,7 @@ struct sfgpu_em {
     uint64_t* tile_qb = nullptr; uint32_t* tile_np = nullptr; uint32_t* tile_pr = nullptr;
     double* blkmax = nullptr; double* h_blkmax = nullptr;   // [2][kMaxPartials]
     double* tsum = nullptr;                                 // [n_tiles] what each tile added in the last sweep (VBEM, optimize(), SFGPU_EM_EXACT_NORM=1)
+    unsigned long long* h_plan = nullptr;                   // pinned: what the plan reads back (a copy into pageable memory is a round trip of its own)
     bool const_norm = true; double vb_log_norm = 0.0;       // VBEM inside optimize(): psi(M prior + numMapped) as the run's normaliser (k_update)
     bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
@@ -1081,6 +1082,7 @@ static void em_free(sfgpu_em* em) {
     if (em->ev_join) (void)hipEventDestroy(em->ev_join);
     for (hipEvent_t e : em->ev_poll) if (e) (void)hipEventDestroy(e);
     if (em->h_mirror) pinned_free(em->h_mirror);
+    if (em->h_plan) pinned_free(em->h_plan);
     if (em->stream) stream_release(em->stream);    // synchronised above
     delete em;
 }
@@ -1276,6 +1278,8 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     for (hipEvent_t& e : em->ev_poll) EM_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     EM_TRY(pinned_malloc(&em->h_mirror, 128));
     memset(em->h_mirror, 0, 128);
+    EM_TRY(pinned_malloc(&em->h_plan, 64));
+    memset(em->h_plan, 0, 64);
     EM_TRY(pool_malloc(&em->alpha, M * 8)); EM_TRY(pool_malloc(&em->alpha_out, M * 8));
     EM_TRY(pool_malloc(&em->x, M * 8)); EM_TRY(pool_malloc(&em->lenc, M * 8)); EM_TRY(pool_malloc(&em->scratch, M * 8));
     EM_TRY(pool_malloc(&em->partials, kMaxPartials * 8)); EM_TRY(pool_malloc(&em->sum_partials, kMaxPartials * 8));
@@ -1296,10 +1300,13 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(hipMemsetAsync(ovf, 0, 4, em->cur));
         hipLaunchKernelGGL(k_narrow_counts, dim3(blocks_for(C)), dim3(kEmBlock), 0, em->cur, C, prob->d_counts,
                            prob->d_rowptr, em->counts32, ovf, (const uint32_t*)nullptr);
-        unsigned int h_ovf = 0;
-        EM_TRY(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, em->cur));
-        EM_TRY(hipMemcpyAsync(&rp_end, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
+        // (pinned destinations: the two copies are queued behind the kernel and cost ONE wait)
+        unsigned int* hp = reinterpret_cast<unsigned int*>(em->h_plan);
+        EM_TRY(hipMemcpyAsync(hp, ovf, 4, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(hp + 1, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
+        const unsigned int h_ovf = hp[0];
+        rp_end = hp[1];
         if (h_ovf & 2u) { set_error("sfgpu_em_create: rowptr not strictly ascending (a class without members)"); em_free(em); return SFGPU_ERR_INVALID; }
         if (h_ovf) { set_error("sfgpu_em_create: a class count >= 2^31"); em_free(em); return SFGPU_ERR_RANGE; }
     } else {
@@ -1355,11 +1362,14 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
                            p_rowptr, em->tile_c0);
         while (tile_nnz > (uint32_t)kTileNnz) {
-            std::vector<uint32_t> c0(nt + 1);
-            EM_TRY(hipMemcpyAsync(c0.data(), em->tile_c0, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, em->cur));
-            EM_TRY(hipStreamSynchronize(em->cur));
+            uint32_t* c0 = nullptr;                         // (pinned: a copy into pageable memory is staged by the runtime)
+            EM_TRY(pinned_malloc(&c0, ((size_t)nt + 1) * 4));
+            hipError_t ce = hipMemcpyAsync(c0, em->tile_c0, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, em->cur);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(em->cur);
             uint32_t most = 0;
-            for (uint32_t i = 0; i < nt; ++i) most = std::max(most, c0[i + 1] - c0[i]);
+            if (ce == hipSuccess) for (uint32_t i = 0; i < nt; ++i) most = std::max(most, c0[i + 1] - c0[i]);
+            pinned_free(c0);
+            EM_TRY(ce);
             if (most <= (uint32_t)kTileNnz) break;
             ++rounds;
             tile_nnz = tile_for(rounds);
@@ -1379,10 +1389,11 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur, false);
         pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur);
         if (sr) { em_free(em); return sr; }
-        EM_TRY(hipMemcpyAsync(&P, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
-        EM_TRY(hipMemcpyAsync(&S, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-        EM_TRY(hipMemcpyAsync(&E, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(em->h_plan + 1, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(em->h_plan + 2, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+        EM_TRY(hipMemcpyAsync(em->h_plan + 3, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
         EM_TRY(hipStreamSynchronize(em->cur));
+        P = em->h_plan[1]; S = em->h_plan[2]; E = em->h_plan[3];
         // Many members outside their tile's window (an index whose isoforms are not adjacent): let the plan order the transcripts
         // itself, and keep that order if it removes at least 40 % of the escapes.
         if (plan_state == 0 && C >= kRenumberMinClasses && E * 8 > (uint64_t)rp_end && getenv("SFGPU_EM_NO_RENUMBER") == nullptr) {
@@ -1473,10 +1484,9 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             if (!src) {
                 hipLaunchKernelGGL(k_invert_perm, dim3(blocks_for(P)), dim3(kEmBlock), 0, em->cur, P, em->cov_pos, em->pub_pos);
                 hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, em->cov_ptr);
-                (void)hipStreamSynchronize(em->cur);
             }
-            if (src) (void)hipStreamSynchronize(em->cur);
-            pool_free(k_in); pool_free(k_out); pool_free(v_in);
+            // (no host wait: the scratch goes back to the pool when the stream has passed this point)
+            pool_free_on(k_in, em->cur); pool_free_on(k_out, em->cur); pool_free_on(v_in, em->cur);
             if (src) { em_free(em); return src; }
         } else {
             EM_TRY(hipMemsetAsync(em->cov_ptr, 0, ((size_t)M + 1) * 4, em->cur));

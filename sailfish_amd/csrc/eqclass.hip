@@ -562,7 +562,7 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     if (const char* e = getenv("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
     if (const char* e = getenv("SFGPU_EQ_PIPE")) eq->use_pipe = atoi(e) != 0;
     hipError_t e1 = pool_malloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
-    hipError_t e2 = pinned_malloc(&eq->h_ctr, CTR_N * sizeof(unsigned long long));
+    hipError_t e2 = pinned_malloc(&eq->h_ctr, (CTR_N + 4) * sizeof(unsigned long long));      // (+ 4: scratch for small readbacks)
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev1);
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1226,7 +1226,9 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     const uint32_t usual_step = step;
     bool scout = adaptive && eq->reads_seen == 0 && n_reads > (1u << 22) && step > kScoutReads;
     if (scout) step = kScoutReads;
-    uint32_t ends[3];
+    // (read into the pinned counter block -- slots past the counters -- so that the three copies are queued and cost one wait:
+    //  a copy into pageable memory is a round trip of its own)
+    uint32_t* ends = reinterpret_cast<uint32_t*>(eq->h_ctr + CTR_N);
     const uint64_t first_end = (n_reads < step) ? n_reads : step;
     SF_HIP(hipMemcpyAsync(&ends[0], d_offsets, 4, hipMemcpyDeviceToHost, st));
     SF_HIP(hipMemcpyAsync(&ends[1], d_offsets + n_reads, 4, hipMemcpyDeviceToHost, st));
