@@ -13,8 +13,8 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """The cfg4 test (eight worker processes + this one on ONE device) runs FIRST: on a device that earlier tests of the session
-    have used, the nine processes take 6-8 minutes instead of ~20 s (queue oversubscription; VERDICT r3, weak #8)."""
+    """The eight-PROCESS cfg4 test (opt-in since round 4: SFGPU_CFG4_PROCS=1 -- nine processes on ONE device took 82, 460 and 863 s
+    on three boxes) runs FIRST when it runs: on a device that earlier tests of the session have used it is slower still."""
     first = [it for it in items if it.name.startswith("test_cfg4_eight_ranks_share_the_gpu")]
     if first:
         rest = [it for it in items if it not in first]
