@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md): 8 TB/s HBM3E
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--em-mode", default="auto", choices=["auto", "replicated", "sharded"])
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank gets its own R reads (weak scaling) instead of R/N")

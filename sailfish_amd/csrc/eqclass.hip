@@ -101,6 +101,12 @@ __device__ __forceinline__ void entry_write(uint32_t* arena, uint64_t dst, WordF
 // rep still addresses the entry, so every other reader of the arena is unchanged.
 constexpr uint32_t kCompactBit = 0x40000000u;                 // in word 0 of a head granule (ids >= 2^30 take the generic kernel)
 constexpr uint32_t kMaxCompactLen = 9;
+// ... and a second compact form for 10 .. 17 ids: sixteen 4-bit steps (0 .. 15).  With the first form alone 7.5 % of the
+// benchmark's labels kept their tails, and since some lane of nearly every 64-read step then holds one, they cost the two passes
+// 2.6 of 12.2 ms (profiles/r4_class_build_notes.md: labels cut to 9 ids).  Bit 29 of word 0 tells the forms apart (a compact
+// id0 is below 2^24).
+constexpr uint32_t kCompact4Bit = 0x20000000u;
+constexpr uint32_t kMaxCompact4Len = 17;
 constexpr uint32_t kProbeWords = 4;                           // arena words in front of an entry
 template <typename WordFn>
 __device__ __forceinline__ void label_probe(WordFn word, uint32_t n, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
@@ -115,6 +121,16 @@ __device__ __forceinline__ void label_probe(WordFn word, uint32_t n, uint32_t& p
             if (k <= 4u) lo |= (d & 255u) << (8u * (k - 1u)); else hi |= (d & 255u) << (8u * (k - 5u));
         }
         if (ok) { p0 = kCompactBit | id0; p1 = lo; p2 = hi; return; }
+    } else if (n > kMaxCompactLen && n <= kMaxCompact4Len && id0 < (1u << 24)) {
+        uint32_t prev = id0, lo = 0, hi = 0;
+        bool ok = true;
+        for (uint32_t k = 1; k < n; ++k) {
+            const uint32_t v = word(k), d = v - prev;
+            ok = ok && d <= 15u;
+            prev = v;
+            if (k <= 8u) lo |= (d & 15u) << (4u * (k - 1u)); else hi |= (d & 15u) << (4u * (k - 9u));
+        }
+        if (ok) { p0 = kCompactBit | kCompact4Bit | id0; p1 = lo; p2 = hi; return; }
     }
     // (ids >= 2^30 never enter the stream -- such reads take the generic kernel -- and must not look like a compact granule here)
     p0 = id0 < kCompactBit ? id0 : 0xFFFFFFFFu; p1 = n > 1u ? word(1) : 0u; p2 = n > 2u ? word(2) : 0u;
@@ -122,7 +138,8 @@ __device__ __forceinline__ void label_probe(WordFn word, uint32_t n, uint32_t& p
 // id k of a label held as ONE compact granule (c0 = word 0 without the head bit, lo / hi = words 2 and 3)
 __device__ __forceinline__ uint32_t compact_id(uint32_t c0, uint32_t lo, uint32_t hi, uint32_t k) {
     uint32_t v = c0 & 0xFFFFFFu;
-    for (uint32_t j = 1; j <= k; ++j) v += (j <= 4u ? (lo >> (8u * (j - 1u))) : (hi >> (8u * (j - 5u)))) & 255u;
+    if (c0 & kCompact4Bit) { for (uint32_t j = 1; j <= k; ++j) v += (j <= 8u ? (lo >> (4u * (j - 1u))) : (hi >> (4u * (j - 9u)))) & 15u; }
+    else for (uint32_t j = 1; j <= k; ++j) v += (j <= 4u ? (lo >> (8u * (j - 1u))) : (hi >> (8u * (j - 5u)))) & 255u;
     return v;
 }
 // arena words a class takes: probe granule + entry

@@ -271,16 +271,34 @@ k_part_route(RouteArgs a) {
         // ---- the COMPACT form (eqclass.hip, label_probe): 4 .. 9 ids below 2^24 ascending in steps of 0 .. 255 -> first id + eight
         //      8-bit steps, one granule
         const uint32_t w8 = staged ? lab_s[8] : ((len > 8u && !unfit) ? lab_g[8] : 0u);            // (the staging buffer has 16 words of slack)
-        bool compact = len >= 4u && len <= kMaxCompactLen && w[0] < (1u << 24);
+        bool ok8 = w[0] < (1u << 24);                           // every step among the first 9 ids is 0 .. 255
         uint32_t dlo = 0u, dhi = 0u;
 #pragma unroll
         for (int k = 1; k <= 8; ++k) {
             const uint32_t d = ((k < 8) ? w[k < 8 ? k : 7] : w8) - w[k - 1];
             const bool live = (uint32_t)k < len;
-            compact = compact && (!live || d <= 255u);
+            ok8 = ok8 && (!live || d <= 255u);
             const uint32_t dm = live ? (d & 255u) : 0u;
             if (k <= 4) dlo |= dm << (8 * (k - 1)); else dhi |= dm << (8 * (k - 5));
         }
+        bool compact = ok8 && len >= 4u && len <= kMaxCompactLen;
+        // the second compact form: 10 .. 17 ids in steps of 0 .. 15 (sixteen nibbles).  The first eight steps are at hand as bytes
+        // (squeezed into nibbles); the further ones are walked by the lanes that hold such a label (<= 8 short iterations)
+        bool compact4 = ok8 && len > kMaxCompactLen && len <= kMaxCompact4Len && !unfit && ((dlo | dhi) & 0xF0F0F0F0u) == 0u;
+        if (__ballot(compact4)) {
+            auto squeeze = [](uint32_t x) { x = (x | (x >> 4)) & 0x00FF00FFu; return (x | (x >> 8)) & 0xFFFFu; };
+            const uint32_t qlo = squeeze(dlo) | (squeeze(dhi) << 16);
+            uint32_t qhi = 0u, prev = w8;
+            for (uint32_t k = 9u; compact4 && k < len; ++k) {
+                const uint32_t cur = staged ? lab_s[k] : lab_g[k], d = cur - prev;
+                prev = cur;
+                compact4 = d <= 15u;
+                qhi |= (d & 15u) << (4u * (k - 9u));
+            }
+            if (compact4) { dlo = qlo; dhi = qhi; }
+        }
+        const uint32_t cflag = compact4 ? (kCompactBit | kCompact4Bit) : kCompactBit;
+        compact = compact || compact4;
         // ---- bucket hash (xxh64_device.h): length, the first 8 ids, and for longer labels the last and the middle id -- no walk
         //      over the tail (13 % of the labels have one: a lane walking its tail while the others wait cost this pass half of
         //      its vector instructions)
@@ -357,7 +375,7 @@ k_part_route(RouteArgs a) {
         const uint32_t ngx = ng + (mult > 1u ? 1u : 0u);
         auto head_granule = [&]() {
             const uint32_t hx = H | (mult > 1u ? kCountedBit : 0u);
-            return compact ? make_uint4(w[0] | kHeadBit | kCompactBit, hx, dlo, dhi) : make_uint4(w[0] | kHeadBit, hx, w[1], w[2]);
+            return compact ? make_uint4(w[0] | kHeadBit | cflag, hx, dlo, dhi) : make_uint4(w[0] | kHeadBit, hx, w[1], w[2]);
         };
         auto count_granule = [&]() { return make_uint4(mult, kCountedBit, 0u, 0u); };       // (bit 31 of .y: no id has it -- such labels take the generic kernel)
         // granule j of what my label puts into the stream: head, ids 3..6, tail granules, the run's count
