@@ -840,7 +840,11 @@ k_part_insert(PartArgs a) {
                 const uint32_t idx = e & kSlotIdxMask;
                 const uint4 hd = chead[idx];
                 bool same = hd.y == w0 && hd.z == w1 && hd.w == w2;
+#ifdef SFGPU_X_NOPHASE2            // experiment: the head granule decides (WRONG for long labels that share one: timing only)
+                if (false) {
+#else
                 if (same && len > 3u && !compact) {          // (a compact granule IS the label: equal words, equal labels)
+#endif
                     if (!serial) { c_idx = idx; c_rep = hd.x; return true; }
                     const uint4* r = (hd.x & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (hd.x & ~kArenaBit) : a.bins + hd.x;
                     for (uint32_t j = 1; same && j < ng; ++j) {
