@@ -713,7 +713,11 @@ k_part_insert(PartArgs a) {
     __shared__ unsigned int slot32[kRegionSlots];
     __shared__ __attribute__((aligned(16))) uint4 chead[kMaxRegionClasses];
     __shared__ unsigned int ccnt[kMaxRegionClasses];
-    __shared__ __attribute__((aligned(16))) uint4 wtile[kPartWaves][64 + 2];
+    // long labels waiting for their verification: (granule index in the bins, class | length | run), 64 per wavefront; after the
+    // stream the same words list the slots of the classes this launch created
+    __shared__ __attribute__((aligned(8))) uint32_t vq_words[kMaxRegionClasses];
+    static_assert(kMaxRegionClasses >= 2u * 64u * kPartWaves, "the verification queues fit the new-class list");
+    uint2 (*vq)[64] = reinterpret_cast<uint2 (*)[64]>(vq_words);
     __shared__ unsigned int s_occ, s_ncls, s_nold, s_nnew, s_newwords;
     __shared__ unsigned long long s_arena0, s_cid0;
     static_assert(kRegionBits == 12, "slot32 packs a 12-bit tag, a 7-bit length and a 13-bit class index");
@@ -751,7 +755,6 @@ k_part_insert(PartArgs a) {
     const bool region_overfull = __syncthreads_or(overfull);
     const uint32_t n_old = s_nold;
 
-    uint4* tile = wtile[wave];
     const unsigned long long have_f = __ballot(my_fill != 0u), have_b = __ballot(my_back != 0u);
     auto next_bin = [&](int after) -> int {             // first segment t > after with granules in it, -1 if none
         if (after < 63) {
@@ -768,6 +771,96 @@ k_part_insert(PartArgs a) {
         if (t < 64) { sb = bin0; sn = __shfl(my_fill, t, kWave); }
         else { sn = __shfl(my_back, t - 64, kWave); sb = bin0 + a.cap - sn; }
     };
+    // One label through the region's LDS image.  s = its home slot, key = tag | length, (w0, w1, w2) = the payload of its first
+    // granule, `here` = where that granule sits in the bins.  A label of <= 3 ids or in compact form is decided by those words.
+    // A longer one has further granules: with me == nullptr (the streaming loop) the first class whose key and head agree is
+    // returned as a CANDIDATE (-> true, cand = its index) and verified later, 64 labels at a time (verify_batch); with me != nullptr
+    // (a label whose candidate failed) every such class is compared granule by granule -- the label's granules from the bins
+    // (me), the class's from the arena or, for a class this launch created, from the bins.
+    auto probe = [&](uint32_t s, const uint32_t key, const uint32_t len, const uint32_t ng, const bool whole, const uint32_t w0, const uint32_t w1,
+                     const uint32_t w2, const uint32_t mult, const uint32_t here, const uint32_t multi, const uint4* me, uint32_t& cand) -> bool {
+        auto defer = [&]() { const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull); a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len | (multi << 31); };
+        if (region_overfull) { defer(); return false; }
+        uint32_t probes = 0;
+        while (probes <= kRegionSlots) {
+            uint32_t e = slot32[s];
+            while (e != kSlotEmpty && (e & kSlotKeyMask) != key && probes < kRegionSlots) {
+                s = (s + 1) & (kRegionSlots - 1); ++probes; e = slot32[s];
+            }
+            if (probes >= kRegionSlots) { defer(); return false; }                  // cannot place
+            if (e == kSlotEmpty) {
+                // claim: the class's head is written BEFORE the slot names it, so a prober that sees the slot reads a whole head
+                const uint32_t idx = atomicAdd(&s_ncls, 1u);
+                if (idx >= kMaxRegionClasses || atomicAdd(&s_occ, 1u) >= kRegionLimit) {      // region full: defer
+                    if (idx < kMaxRegionClasses) { atomicSub(&s_occ, 1u); chead[idx].x = kDeadRep; }
+                    defer(); return false;
+                }
+                chead[idx] = make_uint4(here, w0, w1, w2);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                const uint32_t old = atomicCAS(&slot32[s], kSlotEmpty, key | idx);
+                if (old == kSlotEmpty) { atomicAdd(&ccnt[idx], mult); atomicAdd(&s_nnew, 1u); return false; }
+                chead[idx].x = kDeadRep;                 // lost the race: this index stays unused
+                atomicSub(&s_occ, 1u);
+                e = old;
+                if ((e & kSlotKeyMask) != key) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t idx = e & kSlotIdxMask;
+            const uint4 hd = chead[idx];
+            bool same = hd.y == w0 && hd.z == w1 && hd.w == w2;
+#ifdef SFGPU_X_NOPHASE2            // experiment: the head granule decides (WRONG for long labels that share one: timing only)
+            if (false) {
+#else
+            if (same && !whole) {                        // (a compact granule, or <= 3 ids, IS the label: equal words, equal labels)
+#endif
+                if (!me) { cand = idx; return true; }
+                const uint4* r = (hd.x & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (hd.x & ~kArenaBit) : a.bins + hd.x;
+                for (uint32_t j = 1; same && j < ng; ++j) {
+                    const uint4 ej = r[j], tj = me[j];
+                    same = ej.x == tj.x && ej.y == tj.y && ej.z == tj.z && ej.w == tj.w;
+                }
+            }
+            if (same) { atomicAdd(&ccnt[idx], mult); return false; }
+            s = (s + 1) & (kRegionSlots - 1); ++probes;
+        }
+        return false;
+    };
+    // ---- long labels (more granules than one, not compact: 0.75 % of the benchmark's) are VERIFIED IN BATCHES.  Comparing a label's
+    //      further granules means loads from the arena, and when that happened inside the step (rounds 2 - 3: every lane compared the
+    //      granule it held) the whole wavefront sat through their round trip in every third step: 0.6 of the pass's 4.1 ms (round 4,
+    //      profiles/r4_class_build_notes.md).  Now a candidate (class whose tag, length and first granule agree) only puts the
+    //      label into the wavefront's queue; when 64 are waiting, lane i verifies label i -- its granules from the bins (just
+    //      streamed), the class's from the arena -- and the rare label whose candidate fails is probed again with full compares.
+    uint32_t qn = 0;                                       // labels waiting (wavefront-uniform)
+    auto verify_batch = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < qn) {
+            const uint2 e = vq[wave][lane];
+            const uint32_t here = e.x, idx = e.y & kSlotIdxMask, len = (e.y >> 13) & 0x7Fu, multi = (e.y >> 20) & 1u;
+            const uint32_t ng = label_granules(len);
+            const uint4* me = a.bins + here;
+            const uint32_t rep = chead[idx].x;
+            const uint4* r = (rep & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (rep & ~kArenaBit) : a.bins + rep;
+            bool same = true;
+            for (uint32_t j = 1; same && j < ng; ++j) {
+                const uint4 ej = r[j], tj = me[j];
+                same = ej.x == tj.x && ej.y == tj.y && ej.z == tj.z && ej.w == tj.w;
+            }
+            const uint32_t mult = multi ? me[ng].x : 1u;
+            if (same) atomicAdd(&ccnt[idx], mult);
+            else {                                          // another label with this tag, length and first granule: probe again, comparing whole labels
+                const uint4 g0 = me[0];
+                const uint32_t H = g0.y;
+                uint32_t dummy = 0;
+                probe(H & (kRegionSlots - 1), (((H >> kRegionBits) & 0xFFFu) << 20) | (len << 13), len, ng, false, g0.x & ~kHeadBit, g0.z, g0.w, mult, here, multi, me, dummy);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        qn = 0;
+    };
     int t = next_bin(-1);
     uint32_t base = 0, n_gr = 0, pos = 0;                // current segment: first granule (index into a.bins), granules, position
     uint4 g = make_uint4(0u, 0u, 0u, 0u);
@@ -775,13 +868,12 @@ k_part_insert(PartArgs a) {
         segment(t, base, n_gr);
         if (lane < n_gr) g = a.bins[base + lane];
     }
-    if (lane < 2u) tile[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     while (t >= 0) {
         const uint32_t cnt = (n_gr - pos < 64u) ? (n_gr - pos) : 64u;
         const bool is_head = lane < cnt && (g.x & kHeadBit);
         const uint32_t H = g.y;
         const uint32_t len = (H >> 24) & 0x7Fu;
-        const bool compact = (g.x & kCompactBit) != 0u;       // the whole label is in this granule (first id + 8-bit steps)
+        const bool compact = (g.x & kCompactBit) != 0u;       // the whole label is in this granule (first id + 8- or 4-bit steps)
         const uint32_t ng = compact ? 1u : label_granules(len);
         const uint32_t multi = H >> 31;                        // a run of identical reads: one more granule holds its length
         // labels whose granules are not all in this step wait for the next one, which starts at the first of them (a label
@@ -789,9 +881,8 @@ k_part_insert(PartArgs a) {
         const unsigned long long inc = __ballot(is_head && lane + ng + multi > cnt);
         uint32_t adv = inc ? (uint32_t)__builtin_ctzll(inc) : cnt;
         if (adv == 0u) adv = cnt;                            // (cannot happen with well-formed bins: never spin on a corrupt one)
-        tile[lane] = g;
         // the NEXT step's granule (of this bin or of the wavefront's next bin) is requested before this step's labels
-        // are probed and compared: its round trip hides behind theirs
+        // are probed: its round trip hides behind theirs
         int nt = t; uint32_t nbase = base, nn_gr = n_gr, npos = pos + adv;
         if (npos >= n_gr) {
             nt = next_bin(t);
@@ -799,101 +890,31 @@ k_part_insert(PartArgs a) {
         }
         uint4 gn = make_uint4(0u, 0u, 0u, 0u);
         if (nt >= 0 && npos + lane < nn_gr) gn = a.bins[nbase + npos + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- phase 1 (head lanes): probe the LDS slots, compare the first granule in LDS.  A label of <= 3 ids is finished
-        //      here; a longer one leaves phase 1 with a CANDIDATE class (tag, length and ids 0..2 agree)
-        const uint32_t w0 = g.x & ~kHeadBit, w1 = g.z, w2 = g.w;
-        const uint32_t key = (((H >> kRegionBits) & 0xFFFu) << 20) | (len << 13);
+        // a run's length sits in the granule behind its label: in the registers of the lane ng further on (the label is whole in
+        // this step)
+        uint32_t mult = 1u;
+        if (__ballot(is_head && multi)) { const uint32_t cx = __shfl(g.x, (int)((lane + ng) & 63u), kWave); if (is_head && multi) mult = cx; }
         const uint32_t here = base + pos + lane;             // where this lane's granule sits in the bins (granule index)
-        uint32_t s = H & (kRegionSlots - 1), probes = 0, c_idx = 0, c_rep = 0;
-        uint32_t mult = 1u;                                                       // reads this label stands for
-        if (__ballot(is_head && multi)) { if (is_head && multi) mult = tile[lane + ng].x; }   // (no run in most steps: a uniform branch)
-        auto defer = [&]() { const unsigned long long d = atomicAdd(&a.ctr[CTR_DEFER], 1ull); a.deferred[2 * d] = here; a.deferred[2 * d + 1] = len | (multi << 31); };
-        // -> true if the label is left with a candidate to verify (only when !serial: the serial form compares the further
-        //    granules itself, one dependent load after the other -- the rare path after a failed verification)
-        auto probe = [&](const bool serial) -> bool {
-            while (probes <= kRegionSlots) {
-                uint32_t e = slot32[s];
-                while (e != kSlotEmpty && (e & kSlotKeyMask) != key && probes < kRegionSlots) {
-                    s = (s + 1) & (kRegionSlots - 1); ++probes; e = slot32[s];
-                }
-                if (probes >= kRegionSlots) { defer(); return false; }                  // cannot place
-                if (e == kSlotEmpty) {
-                    // claim: the class's head is written BEFORE the slot names it, so a prober that sees the slot reads a whole head
-                    const uint32_t idx = atomicAdd(&s_ncls, 1u);
-                    if (idx >= kMaxRegionClasses || atomicAdd(&s_occ, 1u) >= kRegionLimit) {      // region full: defer
-                        if (idx < kMaxRegionClasses) { atomicSub(&s_occ, 1u); chead[idx].x = kDeadRep; }
-                        defer(); return false;
-                    }
-                    chead[idx] = make_uint4(here, w0, w1, w2);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    const uint32_t old = atomicCAS(&slot32[s], kSlotEmpty, key | idx);
-                    if (old == kSlotEmpty) { atomicAdd(&ccnt[idx], mult); atomicAdd(&s_nnew, 1u); return false; }
-                    chead[idx].x = kDeadRep;                 // lost the race: this index stays unused
-                    atomicSub(&s_occ, 1u);
-                    e = old;
-                    if ((e & kSlotKeyMask) != key) { s = (s + 1) & (kRegionSlots - 1); ++probes; continue; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t idx = e & kSlotIdxMask;
-                const uint4 hd = chead[idx];
-                bool same = hd.y == w0 && hd.z == w1 && hd.w == w2;
-#ifdef SFGPU_X_NOPHASE2            // experiment: the head granule decides (WRONG for long labels that share one: timing only)
-                if (false) {
-#else
-                if (same && len > 3u && !compact) {          // (a compact granule IS the label: equal words, equal labels)
-#endif
-                    if (!serial) { c_idx = idx; c_rep = hd.x; return true; }
-                    const uint4* r = (hd.x & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (hd.x & ~kArenaBit) : a.bins + hd.x;
-                    for (uint32_t j = 1; same && j < ng; ++j) {
-                        const uint4 ej = r[j], tj = tile[lane + j];
-                        same = ej.x == tj.x && ej.y == tj.y && ej.z == tj.z && ej.w == tj.w;
-                    }
-                }
-                if (same) { atomicAdd(&ccnt[idx], mult); return false; }
-                s = (s + 1) & (kRegionSlots - 1); ++probes;
-            }
-            return false;
-        };
-        bool pending = false;
-        if (is_head && lane < adv) {
-            if (region_overfull) defer();
-            else pending = probe(false);
+        uint32_t cand = 0;
+        bool queue = false;
+        if (is_head && lane < adv)
+            queue = probe(H & (kRegionSlots - 1), (((H >> kRegionBits) & 0xFFFu) << 20) | (len << 13), len, ng, compact || len <= 3u,
+                          g.x & ~kHeadBit, g.z, g.w, mult, here, multi, nullptr, cand);
+        const unsigned long long qm = __ballot(queue);
+        if (qm) {
+            const uint32_t nq = (uint32_t)__builtin_popcountll(qm);
+            if (qn + nq > 64u) verify_batch();
+            if (queue) vq[wave][qn + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull))] = make_uint2(here, cand | (len << 13) | (multi << 20));
+            qn += nq;
         }
-        // ---- phase 2 (the OTHER lanes): from the second granule on (ids 3..6, 7..10, ...) an arena entry and a label in the
-        //      bins are word for word the same, so the lane that holds granule j of a label compares it with granule j of the
-        //      candidate's representative: every further granule of every label of the step in ONE round of loads (a label's
-        //      own lane walking them one after the other cost 2.5 of this pass's 6 ms: some label of every step is long)
-        const unsigned long long heads = __ballot(is_head);
-        if (__ballot(pending)) {
-            const unsigned long long below = heads & (~0ull >> (63u - lane));
-            const int hl = below ? 63 - (int)__builtin_clzll(below) : 0;     // the lane of this granule's head (lane 0 starts a label)
-            const uint32_t rep_h = __shfl(c_rep, hl, kWave);
-            const bool pend_h = __shfl((int)pending, hl, kWave) != 0;
-            bool bad = false;
-            if (pend_h && !is_head && lane < cnt && !(g.y & kCountedBit)) {  // (a run's count granule sits behind its label: not compared)
-                const uint4* r = (rep_h & kArenaBit) ? reinterpret_cast<const uint4*>(a.arena) + (rep_h & ~kArenaBit) : a.bins + rep_h;
-                const uint4 ej = r[lane - (uint32_t)hl];
-                bad = ej.x != g.x || ej.y != g.y || ej.z != g.z || ej.w != g.w;
-            }
-            const unsigned long long badm = __ballot(bad);
-            if (pending) {
-                const unsigned long long mine = (badm >> lane) & ((2ull << (ng - 1)) - 2ull);     // bits 1 .. ng - 1: this label's lanes
-                if (!mine) atomicAdd(&ccnt[c_idx], mult);
-                else { s = (s + 1) & (kRegionSlots - 1); ++probes; probe(true); }        // another label with this tag, length and head
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                      // all lanes are done with the step before its LDS copy is replaced
         t = nt; base = nbase; n_gr = nn_gr; pos = npos; g = gn;
     }
+    if (qn) verify_batch();
     __syncthreads();
 
     // ---- counts of the committed classes, and the classes this block created: ids, arena space, labels, hashes, table words
     const uint32_t n_new = s_nnew;
-    uint32_t* new_slots = reinterpret_cast<uint32_t*>(&wtile[0][0]);            // (the tiles are free now: 4224 words)
+    uint32_t* new_slots = vq_words;                                               // (the queues are empty: every wavefront passed the barrier above)
     for (uint32_t s = threadIdx.x; s < kRegionSlots; s += kPartBlock) {
         const uint32_t e = slot32[s];
         if (e == kSlotEmpty) continue;
