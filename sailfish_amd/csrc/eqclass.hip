@@ -276,7 +276,7 @@ k_insert(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off, uin
 __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ off,
                          uint64_t* table, const uint32_t* __restrict__ newlist, uint64_t n_new, uint64_t base_cid,
                          uint64_t* cls_hash, uint64_t* cls_off, uint32_t* cls_len, uint32_t* cls_slot,
-                         uint32_t* arena, unsigned long long* ctr) {
+                         uint32_t* arena, unsigned long long* ctr, uint32_t* probe) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_new) return;
     uint32_t s = newlist[i];
@@ -286,6 +286,7 @@ __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __res
     const uint32_t* lab = ids + b;
     unsigned long long dst = atomicAdd(&ctr[CTR_ARENA], (unsigned long long)class_words(len));
     probe_write(arena, dst, [&](uint32_t k) { return lab[k]; }, len);
+    reinterpret_cast<uint4*>(probe)[s] = make_uint4(arena[dst], arena[dst + 1], arena[dst + 2], arena[dst + 3]);
     dst += kProbeWords;
     entry_write(arena, dst, [&](uint32_t k) { return lab[k]; }, len);
     uint64_t cid = base_cid + i;
@@ -297,7 +298,7 @@ __global__ void k_commit(const uint32_t* __restrict__ ids, const uint32_t* __res
 // re-insert every class into a larger table, carrying its count
 __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table, uint64_t mask, uint64_t n_cls,
                          const uint64_t* __restrict__ cls_off, const uint32_t* __restrict__ cls_len,
-                         const uint32_t* __restrict__ arena, uint32_t* cls_slot, uint32_t mix_mode) {
+                         const uint32_t* __restrict__ arena, uint32_t* cls_slot, uint32_t mix_mode, uint32_t* probe) {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cls) return;
     const uint32_t* lab = arena + cls_off[c];
@@ -314,6 +315,7 @@ __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table
     }
     table[2 * s + 1] = cnt;
     cls_slot[c] = (uint32_t)s;
+    reinterpret_cast<uint4*>(probe)[s] = *reinterpret_cast<const uint4*>(arena + cls_off[c] - 1 - kProbeWords);      // the class's probe granule moves with its slot
 }
 
 // ---- finish(): canonical order ---------------------------------------------------------------
@@ -443,6 +445,8 @@ struct sfgpu_eq {
     uint64_t expected = 0;
     uint64_t cap = 0;                     // slots (power of two)
     DevBuf<uint64_t> table;               // 2*cap
+    DevBuf<uint32_t> probe;               // 4*cap: the probe granule [len, p0, p1, p2] of the class in each occupied slot, slot-indexed, so that
+                                          // pass 2 loads a region's probes with coalesced reads (the arena keeps a copy in front of every entry)
     uint64_t n_classes = 0;
     DevBuf<uint64_t> cls_hash, cls_off;
     DevBuf<uint32_t> cls_len, cls_slot;
@@ -503,6 +507,8 @@ static int eq_alloc_table(sfgpu_eq* eq, uint64_t cap) {
     eq->table.p = nullptr; eq->table.cap = 0;
     int rc = eq->table.reserve(2 * cap, eq->stream, false);
     if (rc) return rc;
+    eq->probe.p = nullptr; eq->probe.cap = 0;
+    if ((rc = eq->probe.reserve(4 * cap, eq->stream, false))) return rc;
     hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, cap);
     SF_CHECK_LAUNCH();
     eq->cap = cap;
@@ -512,15 +518,17 @@ static int eq_alloc_table(sfgpu_eq* eq, uint64_t cap) {
 static int eq_grow(sfgpu_eq* eq, uint64_t new_cap) {
     SF_REQUIRE(new_cap <= (1ull << 31), SFGPU_ERR_RANGE, "equivalence-class table would exceed 2^31 slots");
     uint64_t* old = eq->table.p;
+    uint32_t* old_probe = eq->probe.p;
     int rc = eq_alloc_table(eq, new_cap);
     if (rc) return rc;
     if (eq->n_classes) {
         hipLaunchKernelGGL(k_rehash, dim3(grid_for(eq->n_classes)), dim3(kBlock), 0, eq->stream, old, eq->table.p,
-                           new_cap - 1, eq->n_classes, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->cls_slot.p, eq->mix_mode);
+                           new_cap - 1, eq->n_classes, eq->cls_off.p, eq->cls_len.p, eq->arena.p, eq->cls_slot.p, eq->mix_mode, eq->probe.p);
         SF_CHECK_LAUNCH();
     }
     SF_HIP(hipStreamSynchronize(eq->stream));
     if (old) pool_free(old);
+    if (old_probe) pool_free(old_probe);
     eq->stats.table_grows++;
     log_msg(0, "eq: table grown to %llu slots (%llu classes)", (unsigned long long)new_cap,
             (unsigned long long)eq->n_classes);
@@ -550,7 +558,7 @@ static int eq_reset(sfgpu_eq* eq) {
         hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(kBlock), 0, eq->stream, eq->table.p, eq->cap);
         SF_CHECK_LAUNCH();
     } else {
-        if (eq->table.p) { SF_HIP(hipStreamSynchronize(eq->stream)); pool_free(eq->table.p); }
+        if (eq->table.p) { SF_HIP(hipStreamSynchronize(eq->stream)); pool_free(eq->table.p); if (eq->probe.p) pool_free(eq->probe.p); }
         int rc = eq_alloc_table(eq, want);
         if (rc) return rc;
     }
@@ -661,7 +669,7 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
         if (n_new) {
             hipLaunchKernelGGL(k_commit, dim3(grid_for(n_new)), dim3(kBlock), 0, st, d_ids, d_offsets, eq->table.p,
                                eq->newlist.p, n_new, eq->n_classes, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p,
-                               eq->cls_slot.p, eq->arena.p, eq->d_ctr);
+                               eq->cls_slot.p, eq->arena.p, eq->d_ctr, eq->probe.p);
             SF_CHECK_LAUNCH();
             eq->n_classes += n_new;
         }
@@ -935,7 +943,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         }
         SF_CHECK_LAUNCH();
         PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                    eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo};
+                    eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo, 0u, eq->probe.p};
         static const bool route_only = getenv("SFGPU_X_ROUTE_ONLY") != nullptr;     // (dev: time pass 1 alone -- its experiment variants leave no valid bins)
         if (!route_only) hipLaunchKernelGGL(k_part_insert, dim3(grp_n), dim3(kPartBlock), 0, st, pa);
         SF_CHECK_LAUNCH();
@@ -1187,7 +1195,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
         // ---- insert(k) on the second stream, behind route(k) (and, in stream order, behind insert(k - 1))
         SF_HIP(hipStreamWaitEvent(si, S.ev_route, 0));
         PartArgs pa{eq->table.p, bins, fill_f, fill_b, gm.n_blocks, (uint32_t)gm.cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                    eq->arena.p, S.d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, S.deferred.p, eq->mix_mode, 0u};
+                    eq->arena.p, S.d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, S.deferred.p, eq->mix_mode, 0u, 1u, eq->probe.p};
         hipLaunchKernelGGL(k_part_insert, dim3(n_regions), dim3(kPartBlock), 0, si, pa);
         SF_CHECK_LAUNCH();
         SF_HIP(hipMemcpyAsync(S.h_ctr, S.d_ctr, CTR_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, si));

@@ -686,6 +686,10 @@ struct PartArgs {
     uint32_t* deferred;                    // (granule index of the label in the bins, length) of labels that found their region full
     uint32_t mix_mode;                     // bucket hash of long labels (the full tag of a new class is computed at commit)
     uint32_t grp_lo;                       // block b handles table region grp_lo + b; the bins are laid out for gridDim.x regions
+    uint32_t atomic_counts;                // 1: the counts go back with atomic adds (pipelined form: the next sub-batch's route pass may be adding
+                                           // what it counted for hot classes to the same words); 0: plain read-modify-write (nothing else runs)
+    uint32_t* probe;                       // slot-indexed copies of the classes' probe granules (4 words per table slot): a region's probes are
+                                           // one coalesced 64 KB read (the copies in the arena, found through rep, were 1.6 M scattered reads per launch)
 };
 
 // ---- pass 2: one block per region
@@ -743,7 +747,7 @@ k_part_insert(PartArgs a) {
             const uint32_t idx = atomicAdd(&s_ncls, 1u);
             if (idx < kMaxRegionClasses) {
                 const uint32_t rep = (uint32_t)w;
-                const uint4 h = reinterpret_cast<const uint4*>(a.arena)[(rep & ~kArenaBit) - 1u];   // the class's probe granule [n, p0, p1, p2]
+                const uint4 h = reinterpret_cast<const uint4*>(a.probe)[rb + s];                    // the class's probe granule [n, p0, p1, p2]
                 chead[idx] = make_uint4(rep, h.y, h.z, h.w);
                 e = ((uint32_t)(w >> 52) << 20) | ((h.x & 0x7Fu) << 13) | idx;
             } else overfull = true;                          // (a table loaded beyond 1/2 by the generic kernel: see below)
@@ -753,23 +757,42 @@ k_part_insert(PartArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) { s_nold = s_ncls < kMaxRegionClasses ? s_ncls : kMaxRegionClasses; s_occ = s_ncls; }
     const bool region_overfull = __syncthreads_or(overfull);
+#ifdef SFGPU_X_INS_PROLOGUE_ONLY       // experiment: what does a launch cost before it streams anything?
+    if (a.cap != 0xFFFFFFFFu) return;
+#endif
     const uint32_t n_old = s_nold;
 
-    const unsigned long long have_f = __ballot(my_fill != 0u), have_b = __ballot(my_back != 0u);
-    auto next_bin = [&](int after) -> int {             // first segment t > after with granules in it, -1 if none
-        if (after < 63) {
-            const unsigned long long m = have_f & (~0ull << (after + 1));
-            if (m) return (int)__builtin_ctzll(m);
-            return have_b ? 64 + (int)__builtin_ctzll(have_b) : -1;
-        }
-        const unsigned long long m = (after >= 127) ? 0ull : (have_b & (~0ull << (after - 63)));
-        return m ? 64 + (int)__builtin_ctzll(m) : -1;
+    // ---- the wavefront's bins as ONE flat stream of granules.  A wavefront owns the 128 segments {front, back} x {bin wave + 16 t}
+    //      of its region; streaming them one after the other in steps of 64 granules left the last step of every segment part
+    //      empty -- and a sub-batch of 67 M reads puts only ~130 granules into a segment, one of 4 M reads 8: the pass took 161 us
+    //      per LAUNCH whatever it held (profiles/r4_class_build_notes.md).  Now lane i of a step takes granule gpos + i of the
+    //      concatenation of all segments: the segments' exclusive prefix sums sit in the lanes (pf: fronts, pb: backs), a lane
+    //      finds its segment with a 6-step binary search over them by shuffle.  Labels never span segments, so everything
+    //      downstream (a label's granules in consecutive lanes, the label at lane 0 whole) holds as before.
+    uint32_t tot_f = 0, tot_b = 0;
+    auto excl_scan = [&](uint32_t v, uint32_t& total) -> uint32_t {
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, kWave); if ((int)lane >= o) x += y; }
+        total = __shfl(x, 63, kWave);
+        return x - v;
     };
-    // first granule (index into a.bins) and length of segment t
-    auto segment = [&](int t, uint32_t& sb, uint32_t& sn) {
-        const uint32_t bin0 = ((wave + kPartWaves * (uint32_t)(t & 63)) * gridDim.x + region) * a.cap;
-        if (t < 64) { sb = bin0; sn = __shfl(my_fill, t, kWave); }
-        else { sn = __shfl(my_back, t - 64, kWave); sb = bin0 + a.cap - sn; }
+    const uint32_t pf = excl_scan(my_fill, tot_f), pb = excl_scan(my_back, tot_b);
+    const uint32_t T = tot_f + tot_b;                      // granules this wavefront streams
+    // flat index q (clamped below T by the caller; every lane calls: shuffles inside) -> granule index in a.bins
+    auto locate = [&](uint32_t q) -> uint32_t {
+        const bool back = q >= tot_f;
+        const uint32_t qq = back ? q - tot_f : q;
+        uint32_t t = 0;
+#pragma unroll
+        for (uint32_t step = 32u; step; step >>= 1) {
+            const uint32_t c = t + step;                   // (<= 63)
+            const uint32_t vf = __shfl(pf, (int)c, kWave), vb = __shfl(pb, (int)c, kWave);
+            if ((back ? vb : vf) <= qq) t = c;
+        }
+        const uint32_t p0f = __shfl(pf, (int)t, kWave), p0b = __shfl(pb, (int)t, kWave), fb = __shfl(my_back, (int)t, kWave);
+        const uint32_t bin0 = ((wave + kPartWaves * t) * gridDim.x + region) * a.cap;
+        return back ? bin0 + a.cap - fb + (qq - p0b) : bin0 + (qq - p0f);
     };
     // One label through the region's LDS image.  s = its home slot, key = tag | length, (w0, w1, w2) = the payload of its first
     // granule, `here` = where that granule sits in the bins.  A label of <= 3 ids or in compact form is decided by those words.
@@ -861,15 +884,12 @@ k_part_insert(PartArgs a) {
         __builtin_amdgcn_wave_barrier();
         qn = 0;
     };
-    int t = next_bin(-1);
-    uint32_t base = 0, n_gr = 0, pos = 0;                // current segment: first granule (index into a.bins), granules, position
+    uint32_t gpos = 0;                                     // flat index of the step's first granule (wavefront-uniform)
+    uint32_t here = locate(lane < T ? lane : (T ? T - 1u : 0u));      // where this lane's granule sits in the bins (granule index)
     uint4 g = make_uint4(0u, 0u, 0u, 0u);
-    if (t >= 0) {
-        segment(t, base, n_gr);
-        if (lane < n_gr) g = a.bins[base + lane];
-    }
-    while (t >= 0) {
-        const uint32_t cnt = (n_gr - pos < 64u) ? (n_gr - pos) : 64u;
+    if (lane < T) g = a.bins[here];
+    while (gpos < T) {
+        const uint32_t cnt = (T - gpos < 64u) ? (T - gpos) : 64u;
         const bool is_head = lane < cnt && (g.x & kHeadBit);
         const uint32_t H = g.y;
         const uint32_t len = (H >> 24) & 0x7Fu;
@@ -877,24 +897,20 @@ k_part_insert(PartArgs a) {
         const uint32_t ng = compact ? 1u : label_granules(len);
         const uint32_t multi = H >> 31;                        // a run of identical reads: one more granule holds its length
         // labels whose granules are not all in this step wait for the next one, which starts at the first of them (a label
-        // is <= 32 granules, so the label at lane 0 is always whole; the last step of a bin holds whole labels only)
+        // is <= 32 granules, so the label at lane 0 is always whole; the last step holds whole labels only)
         const unsigned long long inc = __ballot(is_head && lane + ng + multi > cnt);
         uint32_t adv = inc ? (uint32_t)__builtin_ctzll(inc) : cnt;
         if (adv == 0u) adv = cnt;                            // (cannot happen with well-formed bins: never spin on a corrupt one)
-        // the NEXT step's granule (of this bin or of the wavefront's next bin) is requested before this step's labels
-        // are probed: its round trip hides behind theirs
-        int nt = t; uint32_t nbase = base, nn_gr = n_gr, npos = pos + adv;
-        if (npos >= n_gr) {
-            nt = next_bin(t);
-            if (nt >= 0) { segment(nt, nbase, nn_gr); npos = 0; }
-        }
+        // the NEXT step's granule is requested before this step's labels are probed: its round trip hides behind theirs
+        const uint32_t ngpos = gpos + adv;
+        const uint32_t nq = ngpos + lane;
+        const uint32_t nhere = locate(nq < T ? nq : T - 1u);
         uint4 gn = make_uint4(0u, 0u, 0u, 0u);
-        if (nt >= 0 && npos + lane < nn_gr) gn = a.bins[nbase + npos + lane];
+        if (nq < T) gn = a.bins[nhere];
         // a run's length sits in the granule behind its label: in the registers of the lane ng further on (the label is whole in
         // this step)
         uint32_t mult = 1u;
         if (__ballot(is_head && multi)) { const uint32_t cx = __shfl(g.x, (int)((lane + ng) & 63u), kWave); if (is_head && multi) mult = cx; }
-        const uint32_t here = base + pos + lane;             // where this lane's granule sits in the bins (granule index)
         uint32_t cand = 0;
         bool queue = false;
         if (is_head && lane < adv)
@@ -907,9 +923,12 @@ k_part_insert(PartArgs a) {
             if (queue) vq[wave][qn + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull))] = make_uint2(here, cand | (len << 13) | (multi << 20));
             qn += nq;
         }
-        t = nt; base = nbase; n_gr = nn_gr; pos = npos; g = gn;
+        gpos = ngpos; here = nhere; g = gn;
     }
     if (qn) verify_batch();
+#ifdef SFGPU_X_INS_NO_EPILOGUE        // experiment: ... and without writing anything back?
+    if (a.cap != 0xFFFFFFFFu) return;
+#endif
     __syncthreads();
 
     // ---- counts of the committed classes, and the classes this block created: ids, arena space, labels, hashes, table words
@@ -921,7 +940,10 @@ k_part_insert(PartArgs a) {
         const uint32_t idx = e & kSlotIdxMask;
         // (an atomic add: the route pass of the NEXT sub-batch may be running and adds what it counted for hot classes to the
         //  same words)
-        if (idx < n_old) { const uint32_t c = ccnt[idx]; if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2 * (rb + s) + 1]), (unsigned long long)c); }
+        if (idx < n_old) {
+            const uint32_t c = ccnt[idx];
+            if (c) { if (a.atomic_counts) atomicAdd(reinterpret_cast<unsigned long long*>(&a.table[2 * (rb + s) + 1]), (unsigned long long)c); else a.table[2 * (rb + s) + 1] += c; }
+        }
         else { new_slots[atomicAdd(&s_newwords, 1u)] = s; }                      // s_newwords doubles as the list cursor here
     }
     __syncthreads();
@@ -951,6 +973,7 @@ k_part_insert(PartArgs a) {
             const uint32_t clo = p[2], chi = p[3];
             auto word = [&](uint32_t k) { return cpt ? compact_id(w0, clo, chi, k) : (k ? p[k + 1] : w0); };
             probe_write(a.arena, dst - kProbeWords, word, len);
+            reinterpret_cast<uint4*>(a.probe)[rb + s] = make_uint4(a.arena[dst - 4], a.arena[dst - 3], a.arena[dst - 2], a.arena[dst - 1]);
             entry_write(a.arena, dst, word, len);
             a.cls_hash[cid] = xxh64_words(word, len);
             a.cls_off[cid] = dst + 1; a.cls_len[cid] = len; a.cls_slot[cid] = (uint32_t)(rb + s);
