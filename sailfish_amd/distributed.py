@@ -192,11 +192,17 @@ class DistributedQuant:
     def run(self, ids, off, fl_counts=None, remaining_fl_ops=1):
         eng, exp, sopt = self.engine, self.exp, self.sopt
         info = {}
+        # Phase times: the host waits only where the path itself does (finish() and optimize() return results to the host); in
+        # between, the phases are told apart by the host clock after those waits -- a device-wide synchronisation per phase
+        # boundary cost the step five idle gaps.
         eng.sync(); t0 = time.perf_counter()
         b = self.local
         b.start(); b.add_batch(ids, off); b.finish()
         vec = b.eqVec()
-        eng.sync(); t1 = time.perf_counter()
+        if self.world > 1:
+            eng.sync()
+        t1 = time.perf_counter()            # (finish() waited for the table; the export is queued on the builder's stream, ~0.2 ms of device time that the
+                                            #  next phase's clock takes)
         bst = b.stats()
         info["t_insert_ms"] = bst["insert_ms"]; info["insert_launches"] = bst.get("insert_launches", 1)
         # a "launch" of the class build is one sub-batch: pass 1 (route) + pass 2 (insert) of the radix-partitioned path
@@ -210,9 +216,9 @@ class DistributedQuant:
         self.last_vec = vec                               # the (merged) class table the EM ran on
         exp.setNumMappedFragments(vec.total_reads)        # every read with a non-empty hit list is mapped
         eng.set_effective_lengths(exp, sopt, fl_counts, remaining_fl_ops)
-        eng.sync(); t2 = time.perf_counter()
-        ok, st, mode = self._em(vec)
-        eng.sync(); t3 = time.perf_counter()
+        t2 = time.perf_counter()
+        ok, st, mode = self._em(vec)                      # (optimize() returns when alpha is final)
+        t3 = time.perf_counter()
         tpm = eng.tpm(exp, sopt)
         eng.sync(); t4 = time.perf_counter()
         info.update(ok=ok, em_stats=st, em_mode=mode, n_classes=vec.size(), nnz=vec.nnz, tpm=tpm,

@@ -51,7 +51,9 @@ class EquivalenceClassBuilder:
             _lib.set_logger(logger)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sfgpu_eq_create(C.byref(h), int(expected_classes), _lib.current_stream_ptr()))
+            sp = _lib.current_stream_ptr()
+            _lib.check(self._L.sfgpu_eq_create(C.byref(h), int(expected_classes), sp))
+        self._stream = sp.value or 0          # the builder works on its creation stream
         self._h = h
         self._pending = []          # single addGroup() calls buffered into one batch
         self._pending_n = 0
@@ -85,7 +87,9 @@ class EquivalenceClassBuilder:
         on_dev = (isinstance(ids, torch.Tensor) and ids.is_cuda) and (isinstance(offsets, torch.Tensor) and offsets.is_cuda)
         if on_dev:
             ids_t = _as_dev_u32(ids, self.device); off_t = _as_dev_u32(offsets, self.device)
-            torch.cuda.current_stream().synchronize()   # the builder works on its creation stream
+            with torch.cuda.device(self.device):
+                if (torch.cuda.current_stream().cuda_stream or 0) != self._stream:
+                    torch.cuda.current_stream().synchronize()   # the builder works on its creation stream
             _lib.check(self._L.sfgpu_eq_add_batch_device(self._h, _lib.ptr(ids_t), _lib.ptr(off_t), n))
         else:
             def _host_u32(a):          # no copy for 32-bit integer HOST arrays (a pinned 8 GB batch must stay where it is); other
@@ -135,10 +139,16 @@ class EquivalenceClassBuilder:
             ids = torch.empty(nnz, dtype=torch.int32, device=dev)
             counts = torch.empty(n, dtype=torch.int64, device=dev)
             hashes = torch.empty(n, dtype=torch.int64, device=dev)
-            torch.cuda.current_stream().synchronize()
+            # the export runs on the builder's creation stream: when that is still torch's current stream, the tensors above and
+            # whatever consumes them next are ordered by the stream itself (two host waits less per quantification)
+            with torch.cuda.device(dev):
+                same_stream = (torch.cuda.current_stream().cuda_stream or 0) == self._stream
+            if not same_stream:
+                torch.cuda.current_stream().synchronize()
             _lib.check(self._L.sfgpu_eq_export_device(self._h, _lib.ptr(rowptr), _lib.ptr(ids), _lib.ptr(counts),
                                                       _lib.ptr(hashes)))
-            torch.cuda.synchronize(dev)
+            if not same_stream:
+                torch.cuda.synchronize(dev)
             self._vec = EqVec(rowptr, ids, counts, hashes, self.total_reads)
         return self._vec
 
