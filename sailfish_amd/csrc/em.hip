@@ -48,6 +48,12 @@ struct EmState {
     uint32_t gated[2];             // per iteration parity: some transcript passed the gate
     unsigned long long n_active;
     double alpha_sum;
+    // the FUSED iteration (k_sweep_lds<.., .., true>: the update of iteration it - 1 runs at the head of sweep it, see there).  A launch
+    // reads itv[par] and writes itv[par ^ 1] (par: the launch's parity, a kernel argument), the update of iteration u sets
+    // notconv3[u % 3], the stop test of iteration it reads notconv3[(it - 1) % 3], the launch clears the slot of the NEXT update:
+    // no word is both read and written by the blocks of one launch.
+    uint32_t itv[2];
+    uint32_t notconv3[3];
 };
 
 // loop condition of :820, negated:  stop  <=>  it >= minIter && (it >= maxIter || converged)
@@ -57,11 +63,18 @@ __device__ __forceinline__ bool em_stop(uint32_t it, const EmState* s, uint32_t 
     return it > 0 && s->notconv[(it - 1) & 1] == 0;
 }
 
+__device__ __forceinline__ bool em_stop3(uint32_t it, const EmState* s, uint32_t min_iter, uint32_t max_iter) {
+    if (it < min_iter) return false;
+    if (it >= max_iter) return true;
+    return it > 0 && s->notconv3[(it - 1) % 3] == 0;
+}
+
 // the stop test of the host loop, posted where the host can read it without a copy command: `mirror` is pinned host memory
 // (see em_poll_start).  low word: iterations completed, high word: 1 = the loop has ended.
-__global__ void k_post_state(const EmState* st, uint32_t min_iter, uint32_t max_iter, unsigned long long* mirror) {
+__global__ void k_post_state(const EmState* st, uint32_t min_iter, uint32_t max_iter, unsigned long long* mirror, int fused) {
     const uint32_t it = st->it_a;
-    *mirror = (unsigned long long)it | ((unsigned long long)(em_stop(it, st, min_iter, max_iter) ? 1u : 0u) << 32);
+    const bool stop = fused ? em_stop3(it, st, min_iter, max_iter) : em_stop(it, st, min_iter, max_iter);
+    *mirror = (unsigned long long)it | ((unsigned long long)(stop ? 1u : 0u) << 32);
 }
 
 // psi(x), x > 0: the recurrence psi(x) = psi(x + 10) - sum_{k<10} 1/(x + k) for x < 10, then the asymptotic
@@ -87,6 +100,27 @@ __host__ __device__ __forceinline__ double digamma_pos(double x) {
     double s = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 * (1.0 / 240.0
              - inv2 * (1.0 / 132.0 - inv2 * (691.0 / 32760.0 - inv2 * (1.0 / 12.0)))))));
     return r + log(x) - 0.5 * inv - s;
+}
+
+// VBEM's x_t = exp(psi(a) - c) / effLen (:300-320) for the FUSED sweep, whose 64-register budget has no room for digamma_pos's
+// pairwise tree, a log and an exp.  Same recurrence and series as digamma_pos, but exp(log(y)) is y itself:
+//   exp(psi(a) - c) = y exp(-(1 / (2y) + s(y) + r + c)),   y = a (+ 10 below 10),   r = sum_{k<10} 1 / (a + k),
+// with r gathered as ONE fraction term by term (all terms positive: nothing cancels; ten numbers below 20 multiply to < 1e13).
+// One exp, no log, ~10 live doubles; agrees with exp(digamma_pos(a) - c) to a few ulp.
+__device__ __forceinline__ double vb_x_lean(double a, double c, double len) {
+    double y = a, q = c;
+    if (a < 10.0) {
+        double n = 1.0, d = a;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) { const double t = a + (double)k; n = n * t + d; d = d * t; }
+        q += n / d;
+        y = a + 10.0;
+    }
+    const double inv = 1.0 / y, inv2 = inv * inv;
+    const double s = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 * (1.0 / 240.0
+                   - inv2 * (1.0 / 132.0 - inv2 * (691.0 / 32760.0 - inv2 * (1.0 / 12.0)))))));
+    q += 0.5 * inv + s;
+    return y * exp(-q) / len;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -191,6 +225,7 @@ __global__ void k_init_alpha(uint64_t M, double* alpha, double* alpha_out, doubl
     if (VB) { double s = block_sum(local, lds); if (threadIdx.x == 0) sum_partials_out[blockIdx.x] = s; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->it_a = 0; st->it_b = 0; st->notconv[0] = st->notconv[1] = 0; st->gated[0] = st->gated[1] = 0;
+        st->itv[0] = st->itv[1] = 0; st->notconv3[0] = st->notconv3[1] = st->notconv3[2] = 0;
         st->n_active = (unsigned long long)n_act; st->alpha_sum = 0.0;
     }
 }
@@ -478,6 +513,23 @@ k_cover_pairs(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__
     for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) { keys[off + d] = inv ? (uint64_t)inv[lo + d] : (uint64_t)lo + d; vals[off + d] = (uint32_t)(off + d); }
 }
 
+// FUSED iteration: what a window slot's thread needs, in one 16-byte word: {transcript, its cover list [k0, k1), the slot's own entry}
+__global__ void __launch_bounds__(kEmBlock)
+k_win_desc(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span, const uint64_t* __restrict__ tile_off,
+           const uint32_t* __restrict__ inv, const uint32_t* __restrict__ cov_ptr, const uint32_t* __restrict__ pub_pos, uint4* wdesc) {
+    const uint32_t lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
+    const uint64_t off = tile_off[blockIdx.x];
+    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) {
+        const uint32_t t = inv ? inv[lo + d] : lo + d;
+        wdesc[off + d] = make_uint4(t, cov_ptr[t], cov_ptr[t + 1], pub_pos[off + d]);
+    }
+}
+// ... and the transcripts no window holds (inactive, or only ever a far member): the update reaches them through this list
+__global__ void k_uncovered(uint64_t M, const uint32_t* __restrict__ cov_ptr, uint32_t* list, uint32_t* n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M && cov_ptr[t] == cov_ptr[t + 1]) list[atomicAdd(n, 1u)] = (uint32_t)t;
+}
+
 // cov_pos[k] = window slot that sorts to position k  ->  pub_pos[slot] = k
 __global__ void k_invert_perm(uint64_t P, const uint32_t* __restrict__ cov_pos, uint32_t* pub_pos) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,14 +679,40 @@ struct SweepArgs {
     const uint32_t* chdr;                                                // GATHER: the class-major stream is 16-bit window slots, 8 per chunk, + one header word per chunk
     const unsigned char* csc; const uint16_t* csc_slot0;                  // transcript-major copy (null: phase C scatters with atomics)
     const uint64_t* tile_qb; const uint32_t* tile_np; const uint32_t* tile_pr;
+    // FUSED (see k_sweep_lds): the update's operands
+    double* alpha; const double* lenc; const uint32_t* cov_ptr;
+    double* part_a; double* part_b;                                      // the sweeps' window sums, by sweep parity
+    double* aout_a; double* aout_b; double* aout_c;                      // what the escapes add, by sweep mod 3
+    double* tmax;                                                        // [2][n_tiles][waves]: largest relative change a wavefront saw
+    double tol; double log_norm; uint64_t M; int check_mode; uint32_t par, first;
+    const uint4* wdesc; const uint32_t* unc; uint32_t n_unc;
+    unsigned long long* dbg;                                             // SFGPU_X_STAMP builds: [tile][16] phase time stamps (dev)
 };
+#ifdef SFGPU_X_STAMP
+#define SF_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define SF_STAMP(k) do { } while (0)
+#endif
 
 // GATHER (the default since round 3): phase C reads the transcript-major copy (above) and phase A a COMPACT class-major stream --
 // the classes of a tile follow each other, so a nonzero only has to name its window slot (16 bits); a header word per chunk of 8
 // holds the class of the chunk's first nonzero and a bit for every nonzero that starts the next class.  Half the bytes of the
 // 32-bit words, and half the instructions per nonzero in phase A (no class field to extract and compare: 6.4 -> ~4 us on cfg3).
 // !GATHER: the 32-bit stream words [null | single | class | slot] and one LDS atomic per nonzero in phase C (rounds 1 - 2).
-template <bool VB, bool GATHER>
+// FUSED (round 4; inside optimize(), GATHER plans, EM or VBEM with the constant normaliser): ONE kernel per iteration.  The launch
+// of sweep `it` first runs the per-transcript update of iteration it - 1 -- which the unfused loop runs as k_update between
+// the sweeps -- in two pieces:
+//   * every tile derives the x of ITS window straight from the previous sweep's window sums (the fold of k_update, the same
+//     additions in the same order: alphaOut[t] + its cover list + the prior; then psi / exp / 1 / effLen), and the x of its far
+//     members the same way: nothing has to travel through a global x vector, so nothing needs a grid-wide hand-over;
+//   * tile b also owns transcripts [b q, (b + 1) q), q = ceil(M / tiles): for those it does what is left of the update -- the
+//     gate and the relative change (:849-861), alpha <- alpha', and it zeroes the escape accumulator of the NEXT sweep.
+// The window sums ping-pong between two arrays (sweep `it` reads it - 1's while it writes its own); the escapes' accumulator
+// rotates through three (read it - 1's, add into it's, zero it + 1's).  The convergence flag of iteration it - 1 is complete
+// when this launch ends, so the loop ends one launch later than the unfused loop would notice: the stop test at the head of launch
+// it + 1 sees it, returns, and alpha holds exactly what the reference's loop leaves (the sweep `it` ran for nothing: ~17 us, once).
+// What it removes from every iteration: k_update's launch and its latency chain (6.2 us on cfg3) and one kernel boundary.
+template <bool VB, bool GATHER, bool FUSED = false>
 __global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two 1024-thread blocks per CU: 64 VGPRs
 k_sweep_lds(SweepArgs a) {
     // the tile descriptors do not depend on the loop state: request them first so that the state test
@@ -646,14 +724,27 @@ k_sweep_lds(SweepArgs a) {
     const uint64_t e0 = a.tile_esc0[blockIdx.x];
     const uint32_t n_esc = (uint32_t)(a.tile_esc0[blockIdx.x + 1] - e0);
     const uint64_t off = a.tile_off[blockIdx.x];
+#ifdef SFGPU_X_STAMP
+    const unsigned long long t_entry = wall_clock64();
+#endif
     EmState* st = a.st;
-    uint32_t it = st->it_a;
-    bool stop = em_stop(it, st, a.min_iter, a.max_iter);
+    uint32_t it = FUSED ? st->itv[a.par] : st->it_a;
+    bool stop = FUSED ? em_stop3(it, st, a.min_iter, a.max_iter) : em_stop(it, st, a.min_iter, a.max_iter);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->it_b = stop ? kDoneMark : it;
-        if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
+        if constexpr (FUSED) {
+            const uint32_t it_next = (stop || a.first) ? it : it + 1;       // updates done once this launch has ended
+            st->itv[a.par ^ 1u] = it_next; st->it_a = it_next;
+            if (!stop) st->notconv3[it_next % 3u] = 0;                        // (the slot of the update the NEXT launch runs)
+        } else {
+            st->it_b = stop ? kDoneMark : it;
+            if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
+        }
     }
     if (stop) return;
+#ifdef SFGPU_X_STAMP
+    if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 16] = t_entry;
+#endif
+    SF_STAMP(1);
     __shared__ double xs[kWin + 1];                        // (+ the slot of the null words: x = 0)
     __shared__ double acc[kWin + 1];
     __shared__ double den[kTileNnz + 1];                   // denominators, then count/denom, per class of the tile (+ the null class)
@@ -664,7 +755,32 @@ k_sweep_lds(SweepArgs a) {
     __shared__ unsigned int esc_key[kEscSlots];            // transcript + 1 (0 = free)
     __shared__ double esc_val[kEscSlots];
     const double* __restrict__ x = a.x;
-    if (nc == 0) return;
+    // FUSED: the arrays of this launch.  u = it: the update this launch runs (none in a `first` launch), fed by sweep u's sums.
+    const bool upd = FUSED && a.first == 0u;
+    const uint32_t sw = upd ? it + 1u : it;                                   // the sweep this launch runs
+    const double* __restrict__ rd_part = (it & 1u) ? a.part_b : a.part_a;
+    const uint32_t m3 = it % 3u;
+    const double* __restrict__ rd_aout = m3 == 0u ? a.aout_a : (m3 == 1u ? a.aout_b : a.aout_c);
+    double* __restrict__ wr_part = FUSED ? ((sw & 1u) ? a.part_b : a.part_a) : a.partial;
+    const uint32_t w3 = sw % 3u;
+    double* wr_aout = FUSED ? (w3 == 0u ? a.aout_a : (w3 == 1u ? a.aout_b : a.aout_c)) : a.alpha_out;
+    double* zr_aout = w3 == 0u ? a.aout_b : (w3 == 1u ? a.aout_c : a.aout_a);
+    // alpha' of transcript t as k_update<.., FOLD> forms it, and the x the sweep gathers for it
+    auto new_alpha = [&](uint32_t t) -> double {
+        double ap = rd_aout[t];
+        for (uint32_t k = a.cov_ptr[t], e = a.cov_ptr[t + 1]; k < e; ++k) ap += rd_part[k];
+        if (VB) ap += kPriorAlpha;
+        return ap;
+    };
+    auto x_of = [&](double ap, double len) -> double {
+#ifdef SFGPU_X_CHEAPX
+        return sweep_x<false>(ap / len);
+#endif
+        if (VB) return (ap > kTiny) ? sweep_x<true>(vb_x_lean(ap, a.log_norm, len)) : 0.0;       // :300-320
+        return sweep_x<false>(ap / len);
+    };
+    auto x_now = [&](uint32_t t) -> double { return upd ? x_of(new_alpha(t), a.lenc[t]) : x[t]; };      // (far members)
+    if (nc == 0 && !FUSED) return;
     const uint4* __restrict__ words = reinterpret_cast<const uint4*>(a.stream + s0);
 
     // The inner loops carry no test per word: x is clean (sweep_x), null words have a slot and a class of their own, a
@@ -744,12 +860,94 @@ k_sweep_lds(SweepArgs a) {
         w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
     }
     }
+    if constexpr (FUSED) {
+        // ---- U + staging.  Every thread holds at most ONE window slot (kWin == kSweepBlock) and, usually, at most one
+        //      transcript of the uncovered list (those no window holds: inactive, or only ever a far member).  The update
+        //      (:849-861) of transcript t is run by the thread that holds t's HOME slot -- the first entry of its cover list -- or
+        //      its entry of the uncovered list; that thread also zeroes t's word of the next sweep's escape accumulator.
+        //      Written as load / load / compute / store so that the two dependent round trips are the only ones.
+        static_assert(kWin <= kSweepBlock, "one window slot per thread");
+        const bool has = threadIdx.x < span;
+        const uint32_t ju = threadIdx.x * gridDim.x + blockIdx.x;
+        const bool has_u = ju < a.n_unc;
+        uint4 wd = make_uint4(0u, 0u, 0u, 1u);
+        if (has) wd = a.wdesc[off + threadIdx.x];                        // {t, k0, k1, this slot's entry}
+        uint32_t ut = 0;
+        if (has_u) ut = a.unc[ju];
+        // (the LDS accumulators are cleared while those words travel)
+        for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
+        if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
+        if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
+        const bool home = has && wd.w == wd.y;
+        SF_STAMP(2);
+        double ap = 0.0, len = 1.0, av = 0.0, uap = 0.0, uav = 0.0, xv = 0.0;
+        if (upd) {
+            if (has) {
+                ap = rd_aout[wd.x]; len = a.lenc[wd.x];
+                // (the first four entries of the cover list are requested together: a loop over them is one round trip per entry)
+                const uint32_t nk = wd.z - wd.y;
+                const double p0 = rd_part[wd.y];
+                const double p1 = nk > 1u ? rd_part[wd.y + 1u] : 0.0, p2 = nk > 2u ? rd_part[wd.y + 2u] : 0.0, p3 = nk > 3u ? rd_part[wd.y + 3u] : 0.0;
+                if (home) av = a.alpha[wd.x];
+                ap += p0;
+                if (nk > 1u) ap += p1;
+                if (nk > 2u) ap += p2;
+                if (nk > 3u) ap += p3;
+                for (uint32_t k = wd.y + 4u; k < wd.z; ++k) ap += rd_part[k];
+                if (VB) ap += kPriorAlpha;
+            }
+            if (has_u) { uap = rd_aout[ut] + (VB ? kPriorAlpha : 0.0); uav = a.alpha[ut]; }
+            SF_STAMP(3);
+            if (has) xv = x_of(ap, len);
+            SF_STAMP(4);
+        } else if (has) xv = x[wd.x];
+        double local_max = -1.0; unsigned notconv = 0;
+        auto judge = [&](double av_, double ap_) {
+            const double gate = a.check_mode ? av_ : ap_;           // :852 vs :499
+            if (gate > kCheckCutoff) {
+                const double rel = fabs(av_ - ap_) / ap_;
+                if (rel > local_max) local_max = rel;              // NaN never wins, as in the reference (:854)
+                if (rel > a.tol) notconv = 1;
+                if (local_max < 0.0) local_max = 0.0;              // gated at least once
+            }
+        };
+#ifndef SFGPU_X_NOUPD
+        if (upd) {
+            if (home) judge(av, ap);
+            if (has_u) judge(uav, uap);
+        }
+        if (home) { if (upd) a.alpha[wd.x] = ap; zr_aout[wd.x] = 0.0; }
+        if (has_u) { if (upd) a.alpha[ut] = uap; zr_aout[ut] = 0.0; }
+        for (uint32_t j = ju + kSweepBlock * gridDim.x; j < a.n_unc; j += kSweepBlock * gridDim.x) {      // (more uncovered transcripts than threads)
+            const uint32_t t = a.unc[j];
+            if (upd) { const double p = rd_aout[t] + (VB ? kPriorAlpha : 0.0); judge(a.alpha[t], p); a.alpha[t] = p; }
+            zr_aout[t] = 0.0;
+        }
+#endif
+        if (upd) {
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                const double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
+                notconv |= __shfl_down(notconv, o, kWave);
+            }
+            if ((threadIdx.x & (kWave - 1)) == 0) {
+                if (notconv) st->notconv3[it % 3u] = 1;
+                a.tmax[((uint64_t)(it & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + threadIdx.x / kWave] = local_max;
+            }
+        }
+        if (nc == 0) return;
+        SF_STAMP(5);
+        if (has) { xs[threadIdx.x] = xv; acc[threadIdx.x] = 0.0; }
+    } else {
     if (a.inv) for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[a.inv[(uint64_t)lo + i]]; acc[i] = 0.0; }
     else for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
+    }
+    if constexpr (!FUSED) {
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
     if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
     if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
+    }
     __syncthreads();
+    SF_STAMP(6);
 
     // ---- A: denominators
     {
@@ -784,7 +982,7 @@ k_sweep_lds(SweepArgs a) {
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global gather
             uint32_t tag = a.esc_cls[e0 + i];
             if (tag & kSingle) continue;
-            double v = x[a.esc_id[e0 + i]];
+            double v = FUSED ? x_now(a.esc_id[e0 + i]) : x[a.esc_id[e0 + i]];
             if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
         }
     }
@@ -794,6 +992,7 @@ k_sweep_lds(SweepArgs a) {
 #pragma unroll
     for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = threadIdx.x + i * kSweepBlock; cw[i] = (c < nc) ? a.counts[c0 + c] : 0u; }
     __syncthreads();
+    SF_STAMP(7);
     // ---- B: count / denom per class (in place); singletons carry the full count (:275 / :364)
     auto invert = [&](uint32_t c, uint32_t cwc) {
         double cnt = (double)(cwc & 0x7FFFFFFFu);
@@ -804,6 +1003,7 @@ k_sweep_lds(SweepArgs a) {
     for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = threadIdx.x + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
     for (uint32_t c = threadIdx.x + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, a.counts[c0 + c]);
     __syncthreads();
+    SF_STAMP(8);
     // ---- C: the window.  With the transcript-major copy: a GATHER -- a thread takes chunks of 8 entries sorted by window slot,
     //      reads count / denom of their classes (random LDS reads: 0.085 cycles per lane and CU against 0.29 - 0.37 for a random
     //      f64 atomic), sums per slot in registers (singletons add their count, the others x_t times the sum) and hands the window
@@ -855,7 +1055,7 @@ k_sweep_lds(SweepArgs a) {
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global atomics
             uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
             double f = den[(tag >> 16) & 0x1FFFu];
-            double contrib = (tag & kSingle) ? f : x[t] * f;
+            double contrib = (tag & kSingle) ? f : (FUSED ? x_now(t) : x[t]) * f;
             if (contrib != 0.0) {
                 esc_sum += contrib;
                 uint32_t q = (t * 2654435761u) >> (32 - 7);                      // kEscSlots = 2^7
@@ -865,17 +1065,19 @@ k_sweep_lds(SweepArgs a) {
                     if (k == 0u) k = atomicCAS(&esc_key[q], 0u, t + 1u);
                     if (k == 0u || k == t + 1u) { atomicAdd(&esc_val[q], contrib); placed = true; }
                 }
-                if (!placed) atomicAdd(&a.alpha_out[t], contrib);               // accumulator full around q: straight to memory
+                if (!placed) atomicAdd(&wr_aout[t], contrib);                   // accumulator full around q: straight to memory
             }
         }
     }
     __syncthreads();
+    SF_STAMP(9);
     // ---- D: publish the window into the transcript-major partial array (plain stores): the update
     //         then folds each transcript's entries with contiguous, coalesced loads
     double mine = esc_sum;
-    if (threadIdx.x < kEscSlots && esc_key[threadIdx.x]) atomicAdd(&a.alpha_out[esc_key[threadIdx.x] - 1u], esc_val[threadIdx.x]);
-    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { const double v = acc[i]; a.partial[a.pub_pos[off + i]] = v; mine += v; }
-    if (VB && a.tsum) {
+    if (threadIdx.x < kEscSlots && esc_key[threadIdx.x]) atomicAdd(&wr_aout[esc_key[threadIdx.x] - 1u], esc_val[threadIdx.x]);
+    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { const double v = acc[i]; wr_part[a.pub_pos[off + i]] = v; mine += v; }
+    SF_STAMP(10);
+    if (VB && !FUSED && a.tsum) {
         // everything this tile added to alphaOut, in a fixed order: the update derives sum(alpha) -- the
         // argument of psi(sum alpha) -- from these n_tiles numbers instead of a second pass over M
         __shared__ double red[kSweepBlock / kWave];
@@ -1051,6 +1253,14 @@ struct sfgpu_em {
     unsigned long long* h_plan = nullptr;                   // pinned: what the plan reads back (a copy into pageable memory is a round trip of its own)
     bool const_norm = true; double vb_log_norm = 0.0;       // VBEM inside optimize(): psi(M prior + numMapped) as the run's normaliser (k_update)
     bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
+    // the FUSED iteration (k_sweep_lds<.., true, true>): second array of window sums, two more escape accumulators, per-wavefront maxima
+    double *partial_b = nullptr, *aout_b = nullptr, *aout_c = nullptr, *tmax = nullptr;
+    uint4* wdesc = nullptr; uint32_t* unc = nullptr;        // window-slot descriptors; transcripts no window holds ([M] + the count behind them)
+    uint32_t n_unc = 0;
+    unsigned long long* dbg = nullptr;
+    bool fused = false;                                     // this optimize() runs fused launches
+    uint32_t par = 0;                                       // parity of the next fused launch
+    bool graph_fused = false;
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     EmState* d_state = nullptr;
@@ -1073,7 +1283,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->wdesc, em->unc};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -1123,6 +1333,7 @@ static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
                 em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
                 em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize && !em->const_norm) ? em->tsum : nullptr, em->inv,
                 em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr};
+    a.dbg = em->dbg;
     void* args[] = {&a};
     const void* f = em->gather ? (em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true>)
                                                     : reinterpret_cast<const void*>(&k_sweep_lds<false, true>))
@@ -1132,6 +1343,41 @@ static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     return SFGPU_OK;
 }
 static int em_enqueue_sweep(sfgpu_em* em) { Launcher L; L.stream = em->cur; return em_enqueue_sweep(em, L); }
+
+// one FUSED launch: the update of the iteration before + the sweep of this one (k_sweep_lds<.., true, true>).  `first`: nothing to
+// update yet -- x comes from the x vector that init made.  The launch's parity is a kernel argument (a graph bakes it: chunks hold
+// an even number of launches).
+static int em_enqueue_fused(sfgpu_em* em, Launcher& L, bool first) {
+    const sfgpu_problem& p = em->prob;
+    SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
+                em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
+                em->opts.min_iter, em->opts.max_iter, nullptr, em->inv,
+                em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
+                em->alpha, em->lenc, em->cov_ptr, em->partial, em->partial_b, em->alpha_out, em->aout_b, em->aout_c, em->tmax,
+                em->opts.tol, em->vb_log_norm, p.M, em->opts.check_mode, em->par, first ? 1u : 0u,
+                em->wdesc, em->unc, em->n_unc, em->dbg};
+    void* args[] = {&a};
+    const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true, true>)
+                                      : reinterpret_cast<const void*>(&k_sweep_lds<false, true, true>);
+    SF_HIP(L.launch(f, dim3(em->n_tiles), dim3(kSweepBlock), args));
+    em->par ^= 1u;
+    return SFGPU_OK;
+}
+static int em_enqueue_fused(sfgpu_em* em, bool first) { Launcher L; L.stream = em->cur; return em_enqueue_fused(em, L, first); }
+
+// per-wavefront maxima of the fused launches -> the per-block array finish() reads (slot 0 of each parity; the rest "nothing gated")
+__global__ void __launch_bounds__(kEmBlock)
+k_fused_max(uint64_t n, const double* __restrict__ tmax, double* blkmax, int nb) {
+    __shared__ double lmax[kEmBlock / kWave];
+    const int par = blockIdx.x;
+    double m = -1.0;
+    for (uint64_t i = threadIdx.x; i < n; i += kEmBlock) { const double v = tmax[(uint64_t)par * n + i]; if (v > m) m = v; }
+    for (int o = kWave / 2; o > 0; o >>= 1) { const double v = __shfl_down(m, o, kWave); if (v > m) m = v; }
+    if ((threadIdx.x & (kWave - 1)) == 0) lmax[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int i = 1; i < kEmBlock / kWave; ++i) if (lmax[i] > m) m = lmax[i]; blkmax[par * kMaxPartials] = m; }
+    for (int i = 1 + threadIdx.x; i < nb; i += kEmBlock) blkmax[par * kMaxPartials + i] = -1.0;
+}
 
 // `fold`: the sweep's per-tile window sums still have to be folded into alphaOut (true inside
 // optimize(); false in the piecewise API, where sfgpu_em_sweep folds before the caller's all-reduce)
@@ -1186,7 +1432,7 @@ static void em_stats_from_state(sfgpu_em* em, sfgpu_em_stats* s) {
     s->alpha_sum = h->alpha_sum;
     if (it == 0) { s->converged = 0; s->max_rel_diff = -DBL_MAX; return; }
     uint32_t par = (it - 1) & 1;
-    s->converged = h->notconv[par] == 0;
+    s->converged = em->fused ? (h->notconv3[(it - 1) % 3] == 0) : (h->notconv[par] == 0);
     double m = -1.0;
     for (int i = 0; i < em->nb; ++i) { double v = em->h_blkmax[par * kMaxPartials + i]; if (v > m) m = v; }
     s->max_rel_diff = (m >= 0.0) ? m : -DBL_MAX;      // the reference starts from -DBL_MAX (:850)
@@ -1507,6 +1753,7 @@ static int em_begin_on(sfgpu_em* em, const sfgpu_em_opts* opts, hipStream_t work
     int rc = em_fill_opts(em, opts);
     if (rc) return rc;
     em->cur = work;
+    em->fused = false;                                       // (em_run decides)
     em->const_norm = getenv("SFGPU_EM_EXACT_NORM") == nullptr;
     em->vb_log_norm = digamma_pos((double)em->prob.M * kPriorAlpha + (double)em->prob.num_mapped);
     if (em->lenc_dirty) {
@@ -1624,7 +1871,8 @@ int sfgpu_em_poll(sfgpu_em* em, int* done, sfgpu_em_stats* stats) {
 // value only means the end is seen a chunk earlier.
 static int em_enqueue_post(sfgpu_em* em, Launcher& L, int slot) {
     const EmState* st = em->d_state; uint32_t mn = em->opts.min_iter, mx = em->opts.max_iter; unsigned long long* m = em->h_mirror + 8 * slot;
-    void* args[] = {&st, &mn, &mx, &m};
+    int fused = em->fused ? 1 : 0;
+    void* args[] = {&st, &mn, &mx, &m, &fused};
     SF_HIP(L.launch(reinterpret_cast<const void*>(&k_post_state), dim3(1), dim3(1), args));
     return SFGPU_OK;
 }
@@ -1649,6 +1897,10 @@ int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_mass, g, b, 0, em->cur, p.M, d_alpha_out, d_mass_out, em->partials, em->nb, em->d_state);
     SF_CHECK_LAUNCH();
+    if (em->fused) {
+        hipLaunchKernelGGL(k_fused_max, dim3(2), dim3(kEmBlock), 0, em->cur, (uint64_t)em->n_tiles * (kSweepBlock / kWave), em->tmax, em->blkmax, em->nb);
+        SF_CHECK_LAUNCH();
+    }
     SF_HIP(hipMemcpyAsync(em->h_state, em->d_state, sizeof(EmState), hipMemcpyDeviceToHost, em->cur));
     SF_HIP(hipMemcpyAsync(em->h_blkmax, em->blkmax, 2 * kMaxPartials * 8, hipMemcpyDeviceToHost, em->cur));
     SF_HIP(hipStreamSynchronize(em->cur));
@@ -1706,22 +1958,29 @@ constexpr uint32_t kPreLaunched = 8;      // iterations enqueued directly while 
 
 // `n` iterations as an executable graph (kernel arguments are baked, the iteration index and the stop
 // latch live in device memory)
+static bool em_graph_ready(const sfgpu_em* em, uint32_t n) {
+    return em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == n && em->graph_fused == em->fused;
+}
 static int em_build_graph(sfgpu_em* em, uint32_t n) {
-    if (em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == n) return SFGPU_OK;
+    if (em_graph_ready(em, n)) return SFGPU_OK;
     if (em->graph) { (void)hipGraphExecDestroy(em->graph); em->graph = nullptr; }
     Launcher L;
     SF_HIP(hipGraphCreate(&L.graph, 0));
     int rc = SFGPU_OK;
+    const uint32_t par0 = em->par;                       // (fused: the graph starts on parity 0 and, n being even, ends on it)
+    em->par = 0;
     for (uint32_t i = 0; i < n && rc == SFGPU_OK; ++i) {
+        if (em->fused) { rc = em_enqueue_fused(em, L, false); continue; }
         rc = em_enqueue_sweep(em, L);
         if (rc == SFGPU_OK) rc = em_enqueue_update(em, true, L);
     }
+    em->par = par0;
     if (rc == SFGPU_OK) rc = em_enqueue_post(em, L, 0);
     if (rc) { (void)hipGraphDestroy(L.graph); return rc; }
     hipError_t ei = hipGraphInstantiate(&em->graph, L.graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(L.graph);
     SF_HIP(ei);
-    em->graph_opts = em->opts; em->graph_iters = n;
+    em->graph_opts = em->opts; em->graph_iters = n; em->graph_fused = em->fused;
     return SFGPU_OK;
 }
 
@@ -1731,26 +1990,65 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     int rc;
     em->in_optimize = true;
     if ((rc = em_begin_on(em, opts, em->stream))) return rc;
+    // the fused iteration: GATHER plans, EM or VBEM with the constant normaliser (SFGPU_EM_FUSED=0: sweep + k_update as before)
+    {
+        const char* fe = getenv("SFGPU_EM_FUSED");              // (read per run: tests switch it)
+        const bool fused_off = fe && atoi(fe) == 0;
+        em->fused = !fused_off && em->gather && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
+    }
+    bool fresh_fused = false;
+    if (em->fused && !em->partial_b) {
+        // its arrays, once per handle: second array of window sums, two more escape accumulators, the wavefronts' maxima, the window
+        // slots' descriptors and the list of transcripts no window holds (its length comes back with init's poll below)
+        const uint64_t M = em->prob.M, P = em->P ? em->P : 1;
+        SF_HIP(pool_malloc(&em->partial_b, P * 8)); SF_HIP(pool_malloc(&em->aout_b, M * 8)); SF_HIP(pool_malloc(&em->aout_c, M * 8));
+        SF_HIP(pool_malloc(&em->tmax, 2ull * em->n_tiles * (kSweepBlock / kWave) * 8));
+        SF_HIP(pool_malloc(&em->wdesc, P * 16)); SF_HIP(pool_malloc(&em->unc, (M + 1) * 4));
+        SF_HIP(hipMemsetAsync(em->unc + M, 0, 4, em->cur));
+        hipLaunchKernelGGL(k_win_desc, dim3(em->n_tiles), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off, em->inv,
+                           em->cov_ptr, em->pub_pos, em->wdesc);
+        SF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_uncovered, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->cov_ptr, em->unc, em->unc + M);
+        SF_CHECK_LAUNCH();
+        SF_HIP(hipMemcpyAsync(em->h_plan + 4, em->unc + M, 4, hipMemcpyDeviceToHost, em->cur));
+        fresh_fused = true;
+    }
     if ((rc = sfgpu_em_init_impl(em))) return rc;
     int done = 0;
     sfgpu_em_stats st{};
     if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+    if (fresh_fused) em->n_unc = *reinterpret_cast<const uint32_t*>(em->h_plan + 4);
     if (st.n_active == 0) {                                                      // :794-798
         set_error("It seems that no transcripts are expressed; something is likely wrong!");
         if (stats) *stats = st;
         return SFGPU_ERR_NO_ACTIVE;
     }
+    if (getenv("SFGPU_TIMING") && em->fused) fprintf(stderr, "em fused: %u transcripts outside every window\n", em->n_unc);
     if (!quiet) log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
     const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
-    const uint32_t chunk = em->opts.iters_per_launch;
+    uint32_t chunk = em->opts.iters_per_launch;
+    if (em->fused) {
+        chunk += chunk & 1u;                                  // (a graph bakes the launches' parities)
+        em->par = 0;
+    }
+#ifdef SFGPU_X_STAMP
+    if (!em->dbg) { SF_HIP(pool_malloc(&em->dbg, (size_t)em->n_tiles * 16 * 8)); }
+    SF_HIP(hipMemsetAsync(em->dbg, 0, (size_t)em->n_tiles * 16 * 8, em->cur));
+#endif
+    auto iteration = [&](bool first) -> int {
+        if (em->fused) return em_enqueue_fused(em, first);
+        int r = em_enqueue_sweep(em);
+        return r ? r : em_enqueue_update(em, true);
+    };
     SF_HIP(hipEventRecord(em->ev_a, em->cur));
-    if (use_graph && !(em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == chunk)) {
+    if (em->fused) {
+        // the first launch has nothing to update; a second one keeps the parity even for the graph
+        if ((rc = iteration(true)) || (rc = iteration(false))) return rc;
+    }
+    if (use_graph && !em_graph_ready(em, chunk)) {
         // building the graph takes the host ~170 us: the first iterations go straight onto the stream and run meanwhile
         // (iterations past the stop are no-ops, so it does not matter how many of them there are)
-        for (uint32_t i = 0; i < kPreLaunched; ++i) {
-            if ((rc = em_enqueue_sweep(em))) return rc;
-            if ((rc = em_enqueue_update(em, true))) return rc;
-        }
+        for (uint32_t i = 0; i < kPreLaunched; ++i) if ((rc = iteration(false))) return rc;
     }
     if (use_graph && (rc = em_build_graph(em, chunk))) return rc;
     em->h_mirror[0] = em->h_mirror[8] = 0ull;                // (nothing of an earlier run is in flight: finish() waited for it)
@@ -1758,16 +2056,28 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         if (use_graph) {
             SF_HIP(hipGraphLaunch(em->graph, em->cur));
         } else {
-            for (uint32_t i = 0; i < chunk; ++i) {
-                if ((rc = em_enqueue_sweep(em))) return rc;
-                if ((rc = em_enqueue_update(em, true))) return rc;
-            }
+            for (uint32_t i = 0; i < chunk; ++i) if ((rc = iteration(false))) return rc;
         }
         if ((rc = em_poll_start(em, (int)(k & 1u), !use_graph))) return rc;
         if (k > 0 && (rc = em_poll_wait(em, (int)((k - 1u) & 1u), use_graph, &done))) return rc;       // the chunk before this one
     }
     SF_HIP(hipEventRecord(em->ev_b, em->cur));
     rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
+#ifdef SFGPU_X_STAMP
+    if (em->dbg) {                                          // dev: phase stamps of the last launch that ran (100 MHz clock)
+        std::vector<unsigned long long> h((size_t)em->n_tiles * 16);
+        (void)hipMemcpy(h.data(), em->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0min = ~0ull, tend = 0; double sum[16] = {0}; double ramp = 0; uint32_t n = 0;
+        for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b * 16] && h[b * 16 + 10]) { t0min = std::min(t0min, h[b * 16]); tend = std::max(tend, h[b * 16 + 10]); }
+        for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b * 16] && h[b * 16 + 10]) {
+            ++n; ramp += (double)(h[b * 16] - t0min);
+            for (int k = 1; k <= 10; ++k) sum[k] += h[b * 16 + k] ? (double)(h[b * 16 + k] - h[b * 16]) : 0.0;
+        }
+        fprintf(stderr, "stamps (%s, %u tiles; us after the tile's entry): entry %.2f after the first |", em->fused ? "fused" : "unfused", n, ramp / n * 0.01);
+        for (int k = 1; k <= 10; ++k) fprintf(stderr, " s%d %.2f", k, sum[k] / n * 0.01);
+        fprintf(stderr, " | first entry -> last end %.2f us\n", (double)(tend - t0min) * 0.01);
+    }
+#endif
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, em->ev_a, em->ev_b);
     st.loop_ms = ms;
