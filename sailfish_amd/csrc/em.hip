@@ -513,16 +513,84 @@ k_cover_pairs(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__
     for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) { keys[off + d] = inv ? (uint64_t)inv[lo + d] : (uint64_t)lo + d; vals[off + d] = (uint32_t)(off + d); }
 }
 
-// FUSED iteration: what a window slot's thread needs, in one 16-byte word: {transcript, its cover list [k0, k1), the slot's own entry}
-__global__ void __launch_bounds__(kEmBlock)
-k_win_desc(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span, const uint64_t* __restrict__ tile_off,
-           const uint32_t* __restrict__ inv, const uint32_t* __restrict__ cov_ptr, const uint32_t* __restrict__ pub_pos, uint4* wdesc) {
-    const uint32_t lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
-    const uint64_t off = tile_off[blockIdx.x];
-    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) {
-        const uint32_t t = inv ? inv[lo + d] : lo + d;
-        wdesc[off + d] = make_uint4(t, cov_ptr[t], cov_ptr[t + 1], pub_pos[off + d]);
+// FUSED iteration: the tiles whose windows overlap a tile's own, in tile order.  A window is an interval of transcripts and the
+// tiles follow the classes' canonical order (first id ascending), so a tile's `lo` never decreases: the windows that overlap tile
+// T's belong to a few tiles around T.  With them in registers, the thread of window slot i finds every sum the previous sweep
+// published for its transcript -- partial[off' + (lo + i - lo')] for each overlapping tile -- without a cover list: ONE round trip
+// for everything the update needs (the cover-list form needed three).  Entry: {lo', span', off', tile'}; flags: 1 = more than kNbMax
+// overlapping tiles somewhere, 2 = `lo` decreases somewhere (a caller-made class table out of canonical order): such plans keep the
+// two-kernel iteration.
+constexpr int kNbMax = 6;
+// everything a sweep block needs to know about its tile, in ONE 192-byte record: three scalar loads issued together instead of a
+// dozen words from nine arrays (each array a pointer from the kernel arguments first, then the word: the compiler serialises them
+// into a chain of dependent scalar round trips at the head of every launch)
+struct alignas(64) TileDesc {
+    uint32_t c0, nc, lo, span;
+    uint64_t s0; uint32_t n8, n_esc;
+    uint64_t e0, off;
+    uint64_t qb; uint32_t np, nm;                          // GATHER: the transcript-major copy (pure chunks, mixed chunks)
+    uint32_t pr, nb_n, nb_before, pad0;                    // nb_*: FUSED, the overlapping tiles below
+    uint4 e[kNbMax];                                       // {lo', span', off', tile'}
+    uint4 pad1;
+};
+static_assert(sizeof(TileDesc) == 192, "three 64-byte scalar loads");
+__global__ void k_tile_desc(uint32_t n_tiles, const uint32_t* __restrict__ tile_c0, const uint32_t* __restrict__ tile_lo,
+                            const uint32_t* __restrict__ tile_span, const uint64_t* __restrict__ tile_s0, const uint64_t* __restrict__ tile_esc0,
+                            const uint64_t* __restrict__ tile_off, const uint64_t* __restrict__ tile_qb, const uint32_t* __restrict__ tile_np,
+                            const uint32_t* __restrict__ tile_pr, TileDesc* td) {
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= n_tiles) return;
+    TileDesc r{};
+    r.c0 = tile_c0[T]; r.nc = tile_c0[T + 1] - r.c0; r.lo = tile_lo[T]; r.span = tile_span[T];
+    r.s0 = tile_s0[T]; r.n8 = (uint32_t)(tile_s0[T + 1] - r.s0);
+    r.e0 = tile_esc0[T]; r.n_esc = (uint32_t)(tile_esc0[T + 1] - r.e0);
+    r.off = tile_off[T];
+    if (tile_qb) { r.qb = tile_qb[T]; r.np = tile_np[T]; r.nm = (uint32_t)((tile_qb[T + 1] - r.qb - 16ull * r.np) >> 5); r.pr = tile_pr[T]; }
+    td[T] = r;
+}
+__global__ void k_nb_table(uint32_t n_tiles, const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span,
+                           const uint64_t* __restrict__ tile_off, TileDesc* td, unsigned int* flags) {
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= n_tiles) return;
+    uint4 ent[kNbMax];
+    for (int j = 0; j < kNbMax; ++j) ent[j] = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t n = 0, n_before = 0;
+    const uint32_t lo = tile_lo[T], span = tile_span[T];
+    if (span) {
+        // below: walk down while a window that starts there could still reach lo (empty tiles -- no classes, span 0 -- are skipped)
+        uint32_t first = T;
+        for (uint32_t U = T; U-- > 0;) {
+            const uint32_t sl = tile_span[U], ll = tile_lo[U];
+            if (!sl) continue;
+            if (ll > lo) { atomicOr(flags, 2u); break; }
+            if ((uint64_t)ll + kWin <= lo) break;
+            if ((uint64_t)ll + sl > lo) first = U;
+        }
+        for (uint32_t U = first; U < n_tiles; ++U) {
+            if (U == T) { n_before = n; continue; }
+            const uint32_t sl = tile_span[U], ll = tile_lo[U];
+            if (!sl) continue;
+            if (U > T && ll < lo) { atomicOr(flags, 2u); break; }
+            if (U > T && (uint64_t)ll >= (uint64_t)lo + span) break;
+            if ((uint64_t)ll + sl > lo && (uint64_t)ll < (uint64_t)lo + span) {
+                if (n == (uint32_t)kNbMax) { atomicOr(flags, 1u); break; }
+                ent[n++] = make_uint4(ll, sl, (uint32_t)tile_off[U], U);
+            }
+        }
+        if (n_before > n) n_before = n;
     }
+    td[T].nb_n = n; td[T].nb_before = n_before;
+    for (int j = 0; j < kNbMax; ++j) td[T].e[j] = ent[j];
+}
+// FUSED: the first two entries of the cover list of every far member's transcript, inline (0xFFFFFFFF: none; more than two entries:
+// the rest comes through cov_ptr / cov_pos) -- a far member's alpha' then costs its thread one look-up less than two dependent ones
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+__global__ void k_esc_slots(uint64_t E, const uint32_t* __restrict__ esc_id, const uint32_t* __restrict__ cov_ptr,
+                            const uint32_t* __restrict__ cov_pos, uint2* esc_slots) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const uint32_t t = esc_id[i], k0 = cov_ptr[t], k1 = cov_ptr[t + 1];
+    esc_slots[i] = make_uint2(k1 > k0 ? cov_pos[k0] : kNoSlot, k1 > k0 + 1u ? cov_pos[k0 + 1u] : kNoSlot);
 }
 // ... and the transcripts no window holds (inactive, or only ever a far member): the update reaches them through this list
 __global__ void k_uncovered(uint64_t M, const uint32_t* __restrict__ cov_ptr, uint32_t* list, uint32_t* n) {
@@ -667,25 +735,22 @@ k_csc_write(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, c
 }
 
 struct SweepArgs {
-    const uint32_t* rowptr; const uint32_t* counts;                      // caller CSR (class sizes, counts)
-    const uint32_t* stream; const uint32_t* esc_id; const uint32_t* esc_cls;
-    const uint32_t* tile_c0; const uint32_t* tile_lo; const uint32_t* tile_span;
-    const uint64_t* tile_s0; const uint64_t* tile_esc0; const uint64_t* tile_off;
-    const uint32_t* pub_pos;                                             // window slot -> index in `partial`
-    const double* x; double* alpha_out; double* partial;
-    EmState* st; uint32_t min_iter, max_iter;
-    double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
+    // (what the head of the kernel needs comes first: the kernel arguments are fetched 64 bytes at a time)
+    const TileDesc* td; EmState* st; uint32_t min_iter, max_iter, par, first;
+    const uint32_t* stream; const uint32_t* chdr;                        // GATHER: 16-bit window slots, 8 per chunk, + one header word per chunk
+    const double* x; const uint32_t* counts;
+    double* part_a; double* part_b;                                      // FUSED: the sweeps' window sums, by sweep parity
+    double* aout_a; double* aout_b; double* aout_c;                      // FUSED: what the escapes add, by sweep mod 3
+    const double* lenc; double* alpha;
     const uint32_t* inv;                                                 // window position -> transcript (null: the caller's order)
-    const uint32_t* chdr;                                                // GATHER: the class-major stream is 16-bit window slots, 8 per chunk, + one header word per chunk
+    const uint32_t* esc_id; const uint32_t* esc_cls; const uint2* esc_slots;
     const unsigned char* csc; const uint16_t* csc_slot0;                  // transcript-major copy (null: phase C scatters with atomics)
-    const uint64_t* tile_qb; const uint32_t* tile_np; const uint32_t* tile_pr;
-    // FUSED (see k_sweep_lds): the update's operands
-    double* alpha; const double* lenc; const uint32_t* cov_ptr;
-    double* part_a; double* part_b;                                      // the sweeps' window sums, by sweep parity
-    double* aout_a; double* aout_b; double* aout_c;                      // what the escapes add, by sweep mod 3
+    const uint32_t* pub_pos;                                             // window slot -> index in `partial`
+    double* alpha_out; double* partial;
+    double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
+    const uint32_t* cov_ptr; const uint32_t* cov_pos; const uint32_t* unc; uint32_t n_unc; int check_mode;
     double* tmax;                                                        // [2][n_tiles][waves]: largest relative change a wavefront saw
-    double tol; double log_norm; uint64_t M; int check_mode; uint32_t par, first;
-    const uint4* wdesc; const uint32_t* unc; uint32_t n_unc;
+    double tol; double log_norm; uint64_t M;
     unsigned long long* dbg;                                             // SFGPU_X_STAMP builds: [tile][16] phase time stamps (dev)
 };
 #ifdef SFGPU_X_STAMP
@@ -703,10 +768,14 @@ struct SweepArgs {
 // of sweep `it` first runs the per-transcript update of iteration it - 1 -- which the unfused loop runs as k_update between
 // the sweeps -- in two pieces:
 //   * every tile derives the x of ITS window straight from the previous sweep's window sums (the fold of k_update, the same
-//     additions in the same order: alphaOut[t] + its cover list + the prior; then psi / exp / 1 / effLen), and the x of its far
-//     members the same way: nothing has to travel through a global x vector, so nothing needs a grid-wide hand-over;
-//   * tile b also owns transcripts [b q, (b + 1) q), q = ceil(M / tiles): for those it does what is left of the update -- the
-//     gate and the relative change (:849-861), alpha <- alpha', and it zeroes the escape accumulator of the NEXT sweep.
+//     additions in the same order: alphaOut[t] + the sums of the tiles whose windows hold t, in tile order, + the prior; then
+//     psi / exp / 1 / effLen), and the x of its far members the same way: nothing has to travel through a global x vector, so
+//     nothing needs a grid-wide hand-over.  The sums are published SLOT-major (tile's offset + slot: coalesced, no index), and
+//     the tiles that overlap a tile's window sit in its NbTable (k_nb_table), so the thread of a slot addresses all of them
+//     without a look-up: descriptors, then ONE round trip of operands;
+//   * the update itself (:849-861: the gate, the relative change, alpha <- alpha') and the zeroing of the NEXT sweep's escape
+//     accumulator are done for transcript t by the thread of t's HOME slot (the lowest tile whose window holds t); transcripts no
+//     window holds (inactive, or only ever far members) come from a list, at the END of the launch, off the critical path.
 // The window sums ping-pong between two arrays (sweep `it` reads it - 1's while it writes its own); the escapes' accumulator
 // rotates through three (read it - 1's, add into it's, zero it + 1's).  The convergence flag of iteration it - 1 is complete
 // when this launch ends, so the loop ends one launch later than the unfused loop would notice: the stop test at the head of launch
@@ -715,21 +784,36 @@ struct SweepArgs {
 template <bool VB, bool GATHER, bool FUSED = false>
 __global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two 1024-thread blocks per CU: 64 VGPRs
 k_sweep_lds(SweepArgs a) {
-    // the tile descriptors do not depend on the loop state: request them first so that the state test
-    // below costs no extra memory round trip
-    const uint32_t c0 = a.tile_c0[blockIdx.x], nc = a.tile_c0[blockIdx.x + 1] - c0;
-    const uint32_t lo = a.tile_lo[blockIdx.x], span = a.tile_span[blockIdx.x];
-    const uint64_t s0 = a.tile_s0[blockIdx.x];
-    const uint32_t n8 = (uint32_t)(a.tile_s0[blockIdx.x + 1] - s0);
-    const uint64_t e0 = a.tile_esc0[blockIdx.x];
-    const uint32_t n_esc = (uint32_t)(a.tile_esc0[blockIdx.x + 1] - e0);
-    const uint64_t off = a.tile_off[blockIdx.x];
+    // the tile's descriptor does not depend on the loop state: it is requested together with the state (pinned below)
+    const TileDesc td = a.td[blockIdx.x];
+    const uint32_t c0 = td.c0, nc = td.nc, lo = td.lo, span = td.span, n8 = td.n8, n_esc = td.n_esc;
+    const uint64_t s0 = td.s0, e0 = td.e0, off = td.off;
 #ifdef SFGPU_X_STAMP
     const unsigned long long t_entry = wall_clock64();
 #endif
+    // The loop state, read as ONE block of independent words (the flag the stop test needs is picked in registers: indexing memory with
+    // `it` would be a second, dependent round trip), and every descriptor above pinned in front of the early exit: left alone, the
+    // compiler sinks those loads below the branch and the kernel starts with seven dependent scalar round trips instead of two.
     EmState* st = a.st;
-    uint32_t it = FUSED ? st->itv[a.par] : st->it_a;
-    bool stop = FUSED ? em_stop3(it, st, a.min_iter, a.max_iter) : em_stop(it, st, a.min_iter, a.max_iter);
+    const uint32_t s_it_a = st->it_a, s_itv0 = st->itv[0], s_itv1 = st->itv[1];
+    const uint32_t s_nc0 = st->notconv[0], s_nc1 = st->notconv[1];
+    const uint32_t s_n30 = st->notconv3[0], s_n31 = st->notconv3[1], s_n32 = st->notconv3[2];
+    asm volatile("" :: "s"(c0), "s"(nc), "s"(lo), "s"(span), "s"(s0), "s"(n8), "s"(e0), "s"(n_esc), "s"(off));
+    if constexpr (GATHER) asm volatile("" :: "s"(td.qb), "s"(td.np), "s"(td.nm), "s"(td.pr));
+    if constexpr (FUSED) {
+        asm volatile("" :: "s"(td.nb_n), "s"(td.nb_before), "s"(td.e[0].x), "s"(td.e[0].y), "s"(td.e[0].z), "s"(td.e[1].x), "s"(td.e[1].y), "s"(td.e[1].z),
+                     "s"(td.e[2].x), "s"(td.e[2].y), "s"(td.e[2].z), "s"(td.e[3].x), "s"(td.e[3].y), "s"(td.e[3].z),
+                     "s"(td.e[4].x), "s"(td.e[4].y), "s"(td.e[4].z), "s"(td.e[5].x), "s"(td.e[5].y), "s"(td.e[5].z));
+        static_assert(kNbMax == 6, "the pin above names six entries");
+    }
+    asm volatile("" :: "s"(s_it_a), "s"(s_itv0), "s"(s_itv1), "s"(s_nc0), "s"(s_nc1), "s"(s_n30), "s"(s_n31), "s"(s_n32));
+    const uint32_t it = FUSED ? (a.par ? s_itv1 : s_itv0) : s_it_a;
+    bool stop;
+    {
+        const uint32_t k3 = (it + 2u) % 3u;                                   // (it - 1) mod 3
+        const uint32_t prev_notconv = FUSED ? (k3 == 0u ? s_n30 : (k3 == 1u ? s_n31 : s_n32)) : (((it - 1u) & 1u) ? s_nc1 : s_nc0);
+        stop = it >= a.min_iter && (it >= a.max_iter || (it > 0u && prev_notconv == 0u));      // em_stop / em_stop3
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if constexpr (FUSED) {
             const uint32_t it_next = (stop || a.first) ? it : it + 1;       // updates done once this launch has ended
@@ -765,10 +849,10 @@ k_sweep_lds(SweepArgs a) {
     const uint32_t w3 = sw % 3u;
     double* wr_aout = FUSED ? (w3 == 0u ? a.aout_a : (w3 == 1u ? a.aout_b : a.aout_c)) : a.alpha_out;
     double* zr_aout = w3 == 0u ? a.aout_b : (w3 == 1u ? a.aout_c : a.aout_a);
-    // alpha' of transcript t as k_update<.., FOLD> forms it, and the x the sweep gathers for it
+    // alpha' of a FAR transcript as k_update<.., FOLD> forms it (its sums through the cover list: cov_pos names the slots)
     auto new_alpha = [&](uint32_t t) -> double {
         double ap = rd_aout[t];
-        for (uint32_t k = a.cov_ptr[t], e = a.cov_ptr[t + 1]; k < e; ++k) ap += rd_part[k];
+        for (uint32_t k = a.cov_ptr[t], e = a.cov_ptr[t + 1]; k < e; ++k) ap += rd_part[a.cov_pos[k]];
         if (VB) ap += kPriorAlpha;
         return ap;
     };
@@ -780,7 +864,37 @@ k_sweep_lds(SweepArgs a) {
         return sweep_x<false>(ap / len);
     };
     auto x_now = [&](uint32_t t) -> double { return upd ? x_of(new_alpha(t), a.lenc[t]) : x[t]; };      // (far members)
-    if (nc == 0 && !FUSED) return;
+    double local_max = -1.0; unsigned notconv = 0;
+    auto judge = [&](double av_, double ap_) {
+        const double gate = a.check_mode ? av_ : ap_;               // :852 vs :499
+        if (gate > kCheckCutoff) {
+            const double rel = fabs(av_ - ap_) / ap_;
+            if (rel > local_max) local_max = rel;                  // NaN never wins, as in the reference (:854)
+            if (rel > a.tol) notconv = 1;
+            if (local_max < 0.0) local_max = 0.0;                  // gated at least once
+        }
+    };
+    // the end of a FUSED launch: the transcripts no window holds, then what the wavefront saw of the convergence test
+    auto fused_tail = [&]() {
+#ifndef SFGPU_X_NOUPD
+        for (uint32_t j = threadIdx.x * gridDim.x + blockIdx.x; j < a.n_unc; j += kSweepBlock * gridDim.x) {
+            const uint32_t t = a.unc[j];
+            if (upd) { const double p = rd_aout[t] + (VB ? kPriorAlpha : 0.0); judge(a.alpha[t], p); a.alpha[t] = p; }
+            zr_aout[t] = 0.0;
+        }
+#endif
+        if (upd) {
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                const double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
+                notconv |= __shfl_down(notconv, o, kWave);
+            }
+            if ((threadIdx.x & (kWave - 1)) == 0) {
+                if (notconv) st->notconv3[it % 3u] = 1;
+                a.tmax[((uint64_t)(it & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + threadIdx.x / kWave] = local_max;
+            }
+        }
+    };
+    if (nc == 0) { if constexpr (FUSED) fused_tail(); return; }
     const uint4* __restrict__ words = reinterpret_cast<const uint4*>(a.stream + s0);
 
     // The inner loops carry no test per word: x is clean (sweep_x), null words have a slot and a class of their own, a
@@ -860,81 +974,77 @@ k_sweep_lds(SweepArgs a) {
         w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
     }
     }
+    // The thread's FIRST far member (most tiles hold at most one per thread): its words are requested here, with everything else, and
+    // its x stays in a register through phases A and C.  A far member is a chain of dependent gathers, and inside the phases the
+    // whole block paid for that chain twice (cfg3's tile 0, which holds the benchmark's wrapped labels: + 3.5 us in A, + 4 us in C,
+    // and the launch lasts as long as its slowest tile).
+    const bool has_esc0 = threadIdx.x < n_esc;
+    uint32_t esc_tag0 = kSingle, esc_t0 = 0u; uint2 esc_sl0 = make_uint2(kNoSlot, kNoSlot);
+    double esc_x0 = 0.0;
+    if (has_esc0) {
+        esc_tag0 = a.esc_cls[e0 + threadIdx.x]; esc_t0 = a.esc_id[e0 + threadIdx.x];
+        if (FUSED && upd) esc_sl0 = a.esc_slots[e0 + threadIdx.x];
+    }
+    auto esc0_value = [&]() {                                            // (after the window's own requests have been issued)
+        if (!has_esc0 || (esc_tag0 & kSingle)) return;
+        if (FUSED && upd) {
+            double ap = rd_aout[esc_t0];
+            const double len = a.lenc[esc_t0];
+            const double q0 = esc_sl0.x != kNoSlot ? rd_part[esc_sl0.x] : 0.0, q1 = esc_sl0.y != kNoSlot ? rd_part[esc_sl0.y] : 0.0;
+            if (esc_sl0.x != kNoSlot) ap += q0;
+            if (esc_sl0.y != kNoSlot) {
+                ap += q1;
+                for (uint32_t k = a.cov_ptr[esc_t0] + 2u, e = a.cov_ptr[esc_t0 + 1]; k < e; ++k) ap += rd_part[a.cov_pos[k]];
+            }
+            if (VB) ap += kPriorAlpha;
+            esc_x0 = x_of(ap, len);
+        } else esc_x0 = x[esc_t0];
+    };
     if constexpr (FUSED) {
-        // ---- U + staging.  Every thread holds at most ONE window slot (kWin == kSweepBlock) and, usually, at most one
-        //      transcript of the uncovered list (those no window holds: inactive, or only ever a far member).  The update
-        //      (:849-861) of transcript t is run by the thread that holds t's HOME slot -- the first entry of its cover list -- or
-        //      its entry of the uncovered list; that thread also zeroes t's word of the next sweep's escape accumulator.
-        //      Written as load / load / compute / store so that the two dependent round trips are the only ones.
+        // ---- U + staging: descriptors (the tile's own and its NbTable), then ONE round trip of operands, the math, the stores.
+        //      A thread holds at most one window slot (kWin <= kSweepBlock); fused plans have no order of their own (inv == null),
+        //      so slot i is transcript lo + i.
         static_assert(kWin <= kSweepBlock, "one window slot per thread");
+        const uint32_t nb_n = td.nb_n, nb_before = td.nb_before;
         const bool has = threadIdx.x < span;
-        const uint32_t ju = threadIdx.x * gridDim.x + blockIdx.x;
-        const bool has_u = ju < a.n_unc;
-        uint4 wd = make_uint4(0u, 0u, 0u, 1u);
-        if (has) wd = a.wdesc[off + threadIdx.x];                        // {t, k0, k1, this slot's entry}
-        uint32_t ut = 0;
-        if (has_u) ut = a.unc[ju];
-        // (the LDS accumulators are cleared while those words travel)
+        const uint32_t pos = lo + threadIdx.x;
+        bool in[kNbMax]; double pj[kNbMax];
+        bool home = has;
+#pragma unroll
+        for (int j = 0; j < kNbMax; ++j) {
+            const uint4 e = td.e[j];                                     // {lo', span', off', tile'}
+            in[j] = has && (uint32_t)j < nb_n && (pos - e.x) < e.y;
+            pj[j] = (upd && in[j]) ? rd_part[(uint64_t)e.z + (pos - e.x)] : 0.0;
+            if (in[j] && (uint32_t)j < nb_before) home = false;
+        }
+        double ap = 0.0, len = 1.0, av = 0.0, xv = 0.0;
+        if (has) {
+            if (upd) {
+                ap = rd_aout[pos]; len = a.lenc[pos];
+                const double own = rd_part[off + threadIdx.x];
+                if (home) av = a.alpha[pos];
+                // (the LDS accumulators are cleared below, while these words travel)
+#pragma unroll
+                for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j < nb_before && in[j]) ap += pj[j];     // tile order, as the cover list
+                ap += own;
+#pragma unroll
+                for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j >= nb_before && in[j]) ap += pj[j];
+                if (VB) ap += kPriorAlpha;
+            } else xv = x[pos];
+        }
+        esc0_value();
         for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
         if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
         if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
-        const bool home = has && wd.w == wd.y;
-        SF_STAMP(2);
-        double ap = 0.0, len = 1.0, av = 0.0, uap = 0.0, uav = 0.0, xv = 0.0;
-        if (upd) {
-            if (has) {
-                ap = rd_aout[wd.x]; len = a.lenc[wd.x];
-                // (the first four entries of the cover list are requested together: a loop over them is one round trip per entry)
-                const uint32_t nk = wd.z - wd.y;
-                const double p0 = rd_part[wd.y];
-                const double p1 = nk > 1u ? rd_part[wd.y + 1u] : 0.0, p2 = nk > 2u ? rd_part[wd.y + 2u] : 0.0, p3 = nk > 3u ? rd_part[wd.y + 3u] : 0.0;
-                if (home) av = a.alpha[wd.x];
-                ap += p0;
-                if (nk > 1u) ap += p1;
-                if (nk > 2u) ap += p2;
-                if (nk > 3u) ap += p3;
-                for (uint32_t k = wd.y + 4u; k < wd.z; ++k) ap += rd_part[k];
-                if (VB) ap += kPriorAlpha;
-            }
-            if (has_u) { uap = rd_aout[ut] + (VB ? kPriorAlpha : 0.0); uav = a.alpha[ut]; }
-            SF_STAMP(3);
-            if (has) xv = x_of(ap, len);
-            SF_STAMP(4);
-        } else if (has) xv = x[wd.x];
-        double local_max = -1.0; unsigned notconv = 0;
-        auto judge = [&](double av_, double ap_) {
-            const double gate = a.check_mode ? av_ : ap_;           // :852 vs :499
-            if (gate > kCheckCutoff) {
-                const double rel = fabs(av_ - ap_) / ap_;
-                if (rel > local_max) local_max = rel;              // NaN never wins, as in the reference (:854)
-                if (rel > a.tol) notconv = 1;
-                if (local_max < 0.0) local_max = 0.0;              // gated at least once
-            }
-        };
+        SF_STAMP(3);
+        if (has && upd) xv = x_of(ap, len);
+        SF_STAMP(4);
 #ifndef SFGPU_X_NOUPD
-        if (upd) {
-            if (home) judge(av, ap);
-            if (has_u) judge(uav, uap);
-        }
-        if (home) { if (upd) a.alpha[wd.x] = ap; zr_aout[wd.x] = 0.0; }
-        if (has_u) { if (upd) a.alpha[ut] = uap; zr_aout[ut] = 0.0; }
-        for (uint32_t j = ju + kSweepBlock * gridDim.x; j < a.n_unc; j += kSweepBlock * gridDim.x) {      // (more uncovered transcripts than threads)
-            const uint32_t t = a.unc[j];
-            if (upd) { const double p = rd_aout[t] + (VB ? kPriorAlpha : 0.0); judge(a.alpha[t], p); a.alpha[t] = p; }
-            zr_aout[t] = 0.0;
+        if (home) {
+            if (upd) { judge(av, ap); a.alpha[pos] = ap; }
+            zr_aout[pos] = 0.0;
         }
 #endif
-        if (upd) {
-            for (int o = kWave / 2; o > 0; o >>= 1) {
-                const double m = __shfl_down(local_max, o, kWave); if (m > local_max) local_max = m;
-                notconv |= __shfl_down(notconv, o, kWave);
-            }
-            if ((threadIdx.x & (kWave - 1)) == 0) {
-                if (notconv) st->notconv3[it % 3u] = 1;
-                a.tmax[((uint64_t)(it & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + threadIdx.x / kWave] = local_max;
-            }
-        }
-        if (nc == 0) return;
         SF_STAMP(5);
         if (has) { xs[threadIdx.x] = xv; acc[threadIdx.x] = 0.0; }
     } else {
@@ -942,6 +1052,7 @@ k_sweep_lds(SweepArgs a) {
     else for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
     }
     if constexpr (!FUSED) {
+    esc0_value();
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
     if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
     if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
@@ -979,7 +1090,8 @@ k_sweep_lds(SweepArgs a) {
         }
         for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) den_chunk(words[g / 4], words[g / 4 + 1]);
         }
-        for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global gather
+        if (esc_x0 != 0.0) atomicAdd(&den[(esc_tag0 >> 16) & 0x1FFFu], esc_x0);       // far members: the first one from its register,
+        for (uint32_t i = threadIdx.x + kSweepBlock; i < n_esc; i += kSweepBlock) {      // the others by global gathers
             uint32_t tag = a.esc_cls[e0 + i];
             if (tag & kSingle) continue;
             double v = FUSED ? x_now(a.esc_id[e0 + i]) : x[a.esc_id[e0 + i]];
@@ -1011,10 +1123,10 @@ k_sweep_lds(SweepArgs a) {
     double esc_sum = 0.0;
     {
         if constexpr (GATHER) {
-            const uint64_t qb = a.tile_qb[blockIdx.x];
-            const uint32_t np = a.tile_np[blockIdx.x], nm = (uint32_t)((a.tile_qb[blockIdx.x + 1] - qb - 16ull * np) >> 5);
+            const uint64_t qb = td.qb;
+            const uint32_t np = td.np, nm = td.nm;
             const uint4* __restrict__ pure = reinterpret_cast<const uint4*>(a.csc + qb);
-            const uint16_t* __restrict__ s0 = a.csc_slot0 + a.tile_pr[blockIdx.x];
+            const uint16_t* __restrict__ s0 = a.csc_slot0 + td.pr;
             for (uint32_t ch = threadIdx.x; ch < np; ch += kSweepBlock) {            // one slot per chunk: 8 reads, a tree of adds, one hand-over
                 const uint4 e4 = pure[ch];
                 const uint32_t sf = s0[ch];
@@ -1053,9 +1165,10 @@ k_sweep_lds(SweepArgs a) {
         for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) acc_chunk(words[g / 4], words[g / 4 + 1]);
         }
         for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global atomics
-            uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
+            const bool first_esc = i == threadIdx.x;
+            uint32_t tag = first_esc ? esc_tag0 : a.esc_cls[e0 + i], t = first_esc ? esc_t0 : a.esc_id[e0 + i];
             double f = den[(tag >> 16) & 0x1FFFu];
-            double contrib = (tag & kSingle) ? f : (FUSED ? x_now(t) : x[t]) * f;
+            double contrib = (tag & kSingle) ? f : (first_esc ? esc_x0 : (FUSED ? x_now(t) : x[t])) * f;
             if (contrib != 0.0) {
                 esc_sum += contrib;
                 uint32_t q = (t * 2654435761u) >> (32 - 7);                      // kEscSlots = 2^7
@@ -1075,7 +1188,12 @@ k_sweep_lds(SweepArgs a) {
     //         then folds each transcript's entries with contiguous, coalesced loads
     double mine = esc_sum;
     if (threadIdx.x < kEscSlots && esc_key[threadIdx.x]) atomicAdd(&wr_aout[esc_key[threadIdx.x] - 1u], esc_val[threadIdx.x]);
-    for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { const double v = acc[i]; wr_part[a.pub_pos[off + i]] = v; mine += v; }
+    if constexpr (FUSED) {
+        for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) wr_part[off + i] = acc[i];        // slot-major
+        fused_tail();
+    } else {
+        for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { const double v = acc[i]; wr_part[a.pub_pos[off + i]] = v; mine += v; }
+    }
     SF_STAMP(10);
     if (VB && !FUSED && a.tsum) {
         // everything this tile added to alphaOut, in a fixed order: the update derives sum(alpha) -- the
@@ -1238,6 +1356,7 @@ struct sfgpu_em {
     uint32_t* counts32 = nullptr;
     uint32_t* inv = nullptr; uint32_t* cperm = nullptr;      // the plan's own transcript / class order (em_renumber), or null
     uint32_t* tile_lo = nullptr; uint32_t* tile_c0 = nullptr; uint32_t* tile_span = nullptr; uint32_t n_tiles = 0;
+    TileDesc* td = nullptr;                                 // the same, one record per tile (what the sweep reads)
     uint64_t* tile_off = nullptr; uint64_t P = 0;          // window slots over all tiles
     double* partial = nullptr;                              // [P] per-tile window sums of one sweep
     uint32_t* cov_ptr = nullptr; uint32_t* cov_pos = nullptr;   // transcript -> its entries of `partial`
@@ -1255,8 +1374,11 @@ struct sfgpu_em {
     bool in_optimize = false;                               // the on-device loop (vs the piecewise API) is driving the kernels
     // the FUSED iteration (k_sweep_lds<.., true, true>): second array of window sums, two more escape accumulators, per-wavefront maxima
     double *partial_b = nullptr, *aout_b = nullptr, *aout_c = nullptr, *tmax = nullptr;
-    uint4* wdesc = nullptr; uint32_t* unc = nullptr;        // window-slot descriptors; transcripts no window holds ([M] + the count behind them)
+    double* partial_a = nullptr;                            // (slot-major, like partial_b; `partial` stays the two-kernel loop's)
+    uint2* esc_slots = nullptr; uint64_t E = 0;             // the far members' inline cover slots (k_esc_slots)
+    uint32_t* unc = nullptr;                                // transcripts no window holds ([M] + count + the overlap tables' flags behind them)
     uint32_t n_unc = 0;
+    int fused_ok = -1;                                      // -1: not looked at yet; 0: this plan keeps the two-kernel iteration
     unsigned long long* dbg = nullptr;
     bool fused = false;                                     // this optimize() runs fused launches
     uint32_t par = 0;                                       // parity of the next fused launch
@@ -1283,7 +1405,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->wdesc, em->unc};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -1325,15 +1447,25 @@ struct Launcher {
     }
 };
 
+static SweepArgs em_sweep_args(sfgpu_em* em) {
+    const sfgpu_problem& p = em->prob;
+    SweepArgs a{};
+    a.td = em->td; a.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter;
+    a.stream = em->lstream; a.chdr = em->chdr; a.x = em->x; a.counts = em->counts32;
+    a.part_a = em->partial_a; a.part_b = em->partial_b; a.aout_a = em->alpha_out; a.aout_b = em->aout_b; a.aout_c = em->aout_c;
+    a.lenc = em->lenc; a.alpha = em->alpha; a.inv = em->inv; a.esc_id = em->esc_id; a.esc_cls = em->esc_cls; a.esc_slots = em->esc_slots;
+    a.csc = em->csc; a.csc_slot0 = em->csc_slot0; a.pub_pos = em->pub_pos; a.alpha_out = em->alpha_out; a.partial = em->partial;
+    a.cov_ptr = em->cov_ptr; a.cov_pos = em->cov_pos; a.unc = em->unc; a.n_unc = em->n_unc; a.check_mode = em->opts.check_mode;
+    a.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm; a.M = p.M; a.dbg = em->dbg;
+    return a;
+}
+
 // one sweep of the current iteration
 static int em_enqueue_sweep(sfgpu_em* em, Launcher& L) {
     const sfgpu_problem& p = em->prob;
     if (p.C == 0) return SFGPU_OK;
-    SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
-                em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                em->opts.min_iter, em->opts.max_iter, (em->opts.use_vbem && em->in_optimize && !em->const_norm) ? em->tsum : nullptr, em->inv,
-                em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr};
-    a.dbg = em->dbg;
+    SweepArgs a = em_sweep_args(em);
+    a.tsum = (em->opts.use_vbem && em->in_optimize && !em->const_norm) ? em->tsum : nullptr;
     void* args[] = {&a};
     const void* f = em->gather ? (em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true>)
                                                     : reinterpret_cast<const void*>(&k_sweep_lds<false, true>))
@@ -1348,14 +1480,8 @@ static int em_enqueue_sweep(sfgpu_em* em) { Launcher L; L.stream = em->cur; retu
 // update yet -- x comes from the x vector that init made.  The launch's parity is a kernel argument (a graph bakes it: chunks hold
 // an even number of launches).
 static int em_enqueue_fused(sfgpu_em* em, Launcher& L, bool first) {
-    const sfgpu_problem& p = em->prob;
-    SweepArgs a{p.d_rowptr, em->counts32, em->lstream, em->esc_id, em->esc_cls, em->tile_c0, em->tile_lo, em->tile_span,
-                em->tile_s0, em->tile_esc0, em->tile_off, em->pub_pos, em->x, em->alpha_out, em->partial, em->d_state,
-                em->opts.min_iter, em->opts.max_iter, nullptr, em->inv,
-                em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                em->alpha, em->lenc, em->cov_ptr, em->partial, em->partial_b, em->alpha_out, em->aout_b, em->aout_c, em->tmax,
-                em->opts.tol, em->vb_log_norm, p.M, em->opts.check_mode, em->par, first ? 1u : 0u,
-                em->wdesc, em->unc, em->n_unc, em->dbg};
+    SweepArgs a = em_sweep_args(em);
+    a.par = em->par; a.first = first ? 1u : 0u;
     void* args[] = {&a};
     const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true, true>)
                                       : reinterpret_cast<const void*>(&k_sweep_lds<false, true, true>);
@@ -1661,7 +1787,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         if (plan_state == 1) log_msg(0, "EM plan: transcripts renumbered by co-occurrence, %llu -> %llu of %u members outside their window",
                                      (unsigned long long)E_first, (unsigned long long)E, rp_end);
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
-        em->P = P;
+        em->P = P; em->E = E;
         if (getenv("SFGPU_TIMING")) fprintf(stderr, "em plan: %u tiles (%u nnz each), P = %llu window slots (%.2f per transcript), %llu escapes of %llu nonzeros\n",
                                             nt, tile_nnz, (unsigned long long)P, (double)P / (double)M, (unsigned long long)E, (unsigned long long)rp_end);
         EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
@@ -1737,6 +1863,9 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         } else {
             EM_TRY(hipMemsetAsync(em->cov_ptr, 0, ((size_t)M + 1) * 4, em->cur));
         }
+        EM_TRY(pool_malloc(&em->td, (size_t)nt * sizeof(TileDesc)));
+        hipLaunchKernelGGL(k_tile_desc, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, em->tile_lo, em->tile_span,
+                           em->tile_s0, em->tile_esc0, em->tile_off, em->gather ? em->tile_qb : nullptr, em->tile_np, em->tile_pr, em->td);
         EM_TRY(hipGetLastError());
     }
 #undef EM_TRY
@@ -1994,30 +2123,42 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     {
         const char* fe = getenv("SFGPU_EM_FUSED");              // (read per run: tests switch it)
         const bool fused_off = fe && atoi(fe) == 0;
-        em->fused = !fused_off && em->gather && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
+        em->fused = !fused_off && em->gather && !em->inv && em->fused_ok != 0 && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
     }
     bool fresh_fused = false;
-    if (em->fused && !em->partial_b) {
-        // its arrays, once per handle: second array of window sums, two more escape accumulators, the wavefronts' maxima, the window
-        // slots' descriptors and the list of transcripts no window holds (its length comes back with init's poll below)
+    if (em->fused && em->fused_ok < 0) {
+        // its arrays, once per handle: two slot-major arrays of window sums, two more escape accumulators, the wavefronts' maxima,
+        // the tiles' overlap tables and the list of transcripts no window holds (its length and the tables' flags come back with
+        // init's poll below)
         const uint64_t M = em->prob.M, P = em->P ? em->P : 1;
-        SF_HIP(pool_malloc(&em->partial_b, P * 8)); SF_HIP(pool_malloc(&em->aout_b, M * 8)); SF_HIP(pool_malloc(&em->aout_c, M * 8));
+        SF_HIP(pool_malloc(&em->partial_a, P * 8)); SF_HIP(pool_malloc(&em->partial_b, P * 8));
+        SF_HIP(pool_malloc(&em->aout_b, M * 8)); SF_HIP(pool_malloc(&em->aout_c, M * 8));
         SF_HIP(pool_malloc(&em->tmax, 2ull * em->n_tiles * (kSweepBlock / kWave) * 8));
-        SF_HIP(pool_malloc(&em->wdesc, P * 16)); SF_HIP(pool_malloc(&em->unc, (M + 1) * 4));
-        SF_HIP(hipMemsetAsync(em->unc + M, 0, 4, em->cur));
-        hipLaunchKernelGGL(k_win_desc, dim3(em->n_tiles), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off, em->inv,
-                           em->cov_ptr, em->pub_pos, em->wdesc);
+        SF_HIP(pool_malloc(&em->unc, (M + 2) * 4));
+        SF_HIP(hipMemsetAsync(em->unc + M, 0, 8, em->cur));
+        hipLaunchKernelGGL(k_nb_table, dim3((em->n_tiles + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, em->n_tiles, em->tile_lo, em->tile_span,
+                           em->tile_off, em->td, em->unc + M + 1);
         SF_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_uncovered, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->cov_ptr, em->unc, em->unc + M);
         SF_CHECK_LAUNCH();
-        SF_HIP(hipMemcpyAsync(em->h_plan + 4, em->unc + M, 4, hipMemcpyDeviceToHost, em->cur));
+        SF_HIP(pool_malloc(&em->esc_slots, (em->E ? em->E : 1) * 8));
+        if (em->E) {
+            hipLaunchKernelGGL(k_esc_slots, dim3(blocks_for(em->E)), dim3(kEmBlock), 0, em->cur, em->E, em->esc_id, em->cov_ptr, em->cov_pos, em->esc_slots);
+            SF_CHECK_LAUNCH();
+        }
+        SF_HIP(hipMemcpyAsync(em->h_plan + 4, em->unc + M, 8, hipMemcpyDeviceToHost, em->cur));
         fresh_fused = true;
     }
     if ((rc = sfgpu_em_init_impl(em))) return rc;
     int done = 0;
     sfgpu_em_stats st{};
     if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
-    if (fresh_fused) em->n_unc = *reinterpret_cast<const uint32_t*>(em->h_plan + 4);
+    if (fresh_fused) {
+        const uint32_t* hp = reinterpret_cast<const uint32_t*>(em->h_plan + 4);
+        em->n_unc = hp[0];
+        em->fused_ok = hp[1] == 0u ? 1 : 0;
+        if (!em->fused_ok) em->fused = false;                // (overlap tables too small, or the classes out of canonical order)
+    }
     if (st.n_active == 0) {                                                      // :794-798
         set_error("It seems that no transcripts are expressed; something is likely wrong!");
         if (stats) *stats = st;
@@ -2076,6 +2217,17 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         fprintf(stderr, "stamps (%s, %u tiles; us after the tile's entry): entry %.2f after the first |", em->fused ? "fused" : "unfused", n, ramp / n * 0.01);
         for (int k = 1; k <= 10; ++k) fprintf(stderr, " s%d %.2f", k, sum[k] / n * 0.01);
         fprintf(stderr, " | first entry -> last end %.2f us\n", (double)(tend - t0min) * 0.01);
+        // the slowest tiles: duration of each phase for the five tiles with the latest end
+        std::vector<uint32_t> order;
+        for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b * 16] && h[b * 16 + 10]) order.push_back(b);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h[x * 16 + 10] - h[x * 16] > h[y * 16 + 10] - h[y * 16]; });
+        for (size_t q = 0; q < order.size() && q < 5; ++q) {
+            const uint32_t b = order[q];
+            fprintf(stderr, "  slow tile %u (entry +%.2f):", b, (double)(h[b * 16] - t0min) * 0.01);
+            for (int k = 1; k <= 10; ++k) fprintf(stderr, " %.2f", h[b * 16 + k] ? (double)(h[b * 16 + k] - h[b * 16]) * 0.01 : 0.0);
+            fprintf(stderr, "\n");
+        }
+        if (order.size() > 5) { const uint32_t b = order[order.size() / 2]; fprintf(stderr, "  median tile %u: total %.2f\n", b, (double)(h[b * 16 + 10] - h[b * 16]) * 0.01); }
     }
 #endif
     float ms = 0.f;
