@@ -1076,8 +1076,17 @@ k_sweep_lds(SweepArgs a) {
                 step(5, s4.z >> 16); step(6, s4.w & 0xFFFFu); step(7, s4.w >> 16);
                 atomicAdd(&den[cur], run);
             };
+            // (the thread's second and third chunk are requested before the first is worked on: a chunk per round trip otherwise --
+            //  cfg3's tiles hold 2.2 chunks per thread)
+            const uint32_t q1 = threadIdx.x + kSweepBlock, q2 = threadIdx.x + 2u * kSweepBlock;
+            const bool in1 = q1 * kPerLane < n8, in2 = q2 * kPerLane < n8;
+            uint4 sl1 = make_uint4(0u, 0u, 0u, 0u), sl2 = sl1; uint32_t hd1 = 0u, hd2 = 0u;
+            if (in1) { sl1 = slots8[q1]; hd1 = hdrs[q1]; }
+            if (in2) { sl2 = slots8[q2]; hd2 = hdrs[q2]; }
             if (g0 < n8) den_slots(sl_first, hdr_first);
-            for (uint32_t q = threadIdx.x + kSweepBlock; q * kPerLane < n8; q += kSweepBlock) den_slots(slots8[q], hdrs[q]);
+            if (in1) den_slots(sl1, hd1);
+            if (in2) den_slots(sl2, hd2);
+            for (uint32_t q = threadIdx.x + 3u * kSweepBlock; q * kPerLane < n8; q += kSweepBlock) den_slots(slots8[q], hdrs[q]);
         } else {
 #pragma unroll
         for (int c = 0; c < kRegChunks; ++c) {
@@ -1114,6 +1123,15 @@ k_sweep_lds(SweepArgs a) {
 #pragma unroll
     for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = threadIdx.x + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
     for (uint32_t c = threadIdx.x + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, a.counts[c0 + c]);
+    // GATHER: the thread's first two pure chunks of phase C are requested here, ahead of the barrier
+    uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u; bool pc_in0 = false, pc_in1 = false;
+    if constexpr (GATHER) {
+        const uint4* __restrict__ pure_p = reinterpret_cast<const uint4*>(a.csc + td.qb);
+        const uint16_t* __restrict__ slot0_p = a.csc_slot0 + td.pr;
+        pc_in0 = threadIdx.x < td.np; pc_in1 = threadIdx.x + kSweepBlock < td.np;
+        if (pc_in0) { pc_e0 = pure_p[threadIdx.x]; pc_s0 = slot0_p[threadIdx.x]; }
+        if (pc_in1) { pc_e1 = pure_p[threadIdx.x + kSweepBlock]; pc_s1 = slot0_p[threadIdx.x + kSweepBlock]; }
+    }
     __syncthreads();
     SF_STAMP(8);
     // ---- C: the window.  With the transcript-major copy: a GATHER -- a thread takes chunks of 8 entries sorted by window slot,
@@ -1127,16 +1145,17 @@ k_sweep_lds(SweepArgs a) {
             const uint32_t np = td.np, nm = td.nm;
             const uint4* __restrict__ pure = reinterpret_cast<const uint4*>(a.csc + qb);
             const uint16_t* __restrict__ s0 = a.csc_slot0 + td.pr;
-            for (uint32_t ch = threadIdx.x; ch < np; ch += kSweepBlock) {            // one slot per chunk: 8 reads, a tree of adds, one hand-over
-                const uint4 e4 = pure[ch];
-                const uint32_t sf = s0[ch];
+            auto pure_chunk = [&](const uint4& e4, uint32_t sf) {                    // one slot per chunk: 8 reads, a tree of adds, one hand-over
                 const double f0 = den[e4.x & 0x1FFFu], f1 = den[(e4.x >> 16) & 0x1FFFu], f2 = den[e4.y & 0x1FFFu], f3 = den[(e4.y >> 16) & 0x1FFFu];
                 const double f4 = den[e4.z & 0x1FFFu], f5 = den[(e4.z >> 16) & 0x1FFFu], f6 = den[e4.w & 0x1FFFu], f7 = den[(e4.w >> 16) & 0x1FFFu];
                 const double sum = ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7));
                 const uint32_t slot = sf & 0x7FFFu;
                 const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;           // singletons add their count (:275 / :364)
                 if (v != 0.0) atomicAdd(&acc[slot], v);
-            }
+            };
+            if (pc_in0) pure_chunk(pc_e0, pc_s0);                                    // (requested ahead of the barrier, see phase B)
+            if (pc_in1) pure_chunk(pc_e1, pc_s1);
+            for (uint32_t ch = threadIdx.x + 2u * kSweepBlock; ch < np; ch += kSweepBlock) pure_chunk(pure[ch], s0[ch]);
             const uint4* __restrict__ mixed = pure + np;
             for (uint32_t ch = threadIdx.x; ch < nm; ch += kSweepBlock) {            // chunks that straddle slots: run by run
                 const uint4 e4 = mixed[2u * ch], s4 = mixed[2u * ch + 1u];
