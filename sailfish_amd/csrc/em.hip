@@ -974,32 +974,40 @@ k_sweep_lds(SweepArgs a) {
         w[c][0] = w0.x; w[c][1] = w0.y; w[c][2] = w0.z; w[c][3] = w0.w; w[c][4] = w1.x; w[c][5] = w1.y; w[c][6] = w1.z; w[c][7] = w1.w;
     }
     }
-    // The thread's FIRST far member (most tiles hold at most one per thread): its words are requested here, with everything else, and
-    // its x stays in a register through phases A and C.  A far member is a chain of dependent gathers, and inside the phases the
+    // The thread's first TWO far members (most tiles hold at most one per thread): their words are requested here, with everything else,
+    // and their x stays in registers through phases A and C.  A far member is a chain of dependent gathers, and inside the phases the
     // whole block paid for that chain twice (cfg3's tile 0, which holds the benchmark's wrapped labels: + 3.5 us in A, + 4 us in C,
     // and the launch lasts as long as its slowest tile).
-    const bool has_esc0 = threadIdx.x < n_esc;
-    uint32_t esc_tag0 = kSingle, esc_t0 = 0u; uint2 esc_sl0 = make_uint2(kNoSlot, kNoSlot);
-    double esc_x0 = 0.0;
+    // (two per thread: cfg3's tile 0 holds 1266 of them; a tile with more than 2048 walks the rest inside the phases)
+    const bool has_esc0 = threadIdx.x < n_esc, has_esc1 = threadIdx.x + kSweepBlock < n_esc;
+    uint32_t esc_tag0 = kSingle, esc_t0 = 0u, esc_tag1 = kSingle, esc_t1 = 0u;
+    uint2 esc_sl0 = make_uint2(kNoSlot, kNoSlot), esc_sl1 = esc_sl0;
+    double esc_x0 = 0.0, esc_x1 = 0.0;
     if (has_esc0) {
         esc_tag0 = a.esc_cls[e0 + threadIdx.x]; esc_t0 = a.esc_id[e0 + threadIdx.x];
         if (FUSED && upd) esc_sl0 = a.esc_slots[e0 + threadIdx.x];
     }
-    auto esc0_value = [&]() {                                            // (after the window's own requests have been issued)
-        if (!has_esc0 || (esc_tag0 & kSingle)) return;
+    if (has_esc1) {
+        esc_tag1 = a.esc_cls[e0 + threadIdx.x + kSweepBlock]; esc_t1 = a.esc_id[e0 + threadIdx.x + kSweepBlock];
+        if (FUSED && upd) esc_sl1 = a.esc_slots[e0 + threadIdx.x + kSweepBlock];
+    }
+    auto esc_value = [&](bool has, uint32_t tag, uint32_t t, uint2 sl) -> double {      // (called after the window's own requests have been issued)
+        if (!has || (tag & kSingle)) return 0.0;
         if (FUSED && upd) {
-            double ap = rd_aout[esc_t0];
-            const double len = a.lenc[esc_t0];
-            const double q0 = esc_sl0.x != kNoSlot ? rd_part[esc_sl0.x] : 0.0, q1 = esc_sl0.y != kNoSlot ? rd_part[esc_sl0.y] : 0.0;
-            if (esc_sl0.x != kNoSlot) ap += q0;
-            if (esc_sl0.y != kNoSlot) {
+            double ap = rd_aout[t];
+            const double len = a.lenc[t];
+            const double q0 = sl.x != kNoSlot ? rd_part[sl.x] : 0.0, q1 = sl.y != kNoSlot ? rd_part[sl.y] : 0.0;
+            if (sl.x != kNoSlot) ap += q0;
+            if (sl.y != kNoSlot) {
                 ap += q1;
-                for (uint32_t k = a.cov_ptr[esc_t0] + 2u, e = a.cov_ptr[esc_t0 + 1]; k < e; ++k) ap += rd_part[a.cov_pos[k]];
+                for (uint32_t k = a.cov_ptr[t] + 2u, e = a.cov_ptr[t + 1]; k < e; ++k) ap += rd_part[a.cov_pos[k]];
             }
             if (VB) ap += kPriorAlpha;
-            esc_x0 = x_of(ap, len);
-        } else esc_x0 = x[esc_t0];
+            return x_of(ap, len);
+        }
+        return x[t];
     };
+    auto esc_values = [&]() { esc_x0 = esc_value(has_esc0, esc_tag0, esc_t0, esc_sl0); esc_x1 = esc_value(has_esc1, esc_tag1, esc_t1, esc_sl1); };
     if constexpr (FUSED) {
         // ---- U + staging: descriptors (the tile's own and its NbTable), then ONE round trip of operands, the math, the stores.
         //      A thread holds at most one window slot (kWin <= kSweepBlock); fused plans have no order of their own (inv == null),
@@ -1032,7 +1040,7 @@ k_sweep_lds(SweepArgs a) {
                 if (VB) ap += kPriorAlpha;
             } else xv = x[pos];
         }
-        esc0_value();
+        esc_values();
         for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
         if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
         if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
@@ -1052,7 +1060,7 @@ k_sweep_lds(SweepArgs a) {
     else for (uint32_t i = threadIdx.x; i < span; i += kSweepBlock) { xs[i] = x[(uint64_t)lo + i]; acc[i] = 0.0; }
     }
     if constexpr (!FUSED) {
-    esc0_value();
+    esc_values();
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
     if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
     if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
@@ -1099,8 +1107,9 @@ k_sweep_lds(SweepArgs a) {
         }
         for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) den_chunk(words[g / 4], words[g / 4 + 1]);
         }
-        if (esc_x0 != 0.0) atomicAdd(&den[(esc_tag0 >> 16) & 0x1FFFu], esc_x0);       // far members: the first one from its register,
-        for (uint32_t i = threadIdx.x + kSweepBlock; i < n_esc; i += kSweepBlock) {      // the others by global gathers
+        if (esc_x0 != 0.0) atomicAdd(&den[(esc_tag0 >> 16) & 0x1FFFu], esc_x0);       // far members: the first two from their registers,
+        if (esc_x1 != 0.0) atomicAdd(&den[(esc_tag1 >> 16) & 0x1FFFu], esc_x1);
+        for (uint32_t i = threadIdx.x + 2u * kSweepBlock; i < n_esc; i += kSweepBlock) {      // the others by global gathers
             uint32_t tag = a.esc_cls[e0 + i];
             if (tag & kSingle) continue;
             double v = FUSED ? x_now(a.esc_id[e0 + i]) : x[a.esc_id[e0 + i]];
@@ -1183,11 +1192,9 @@ k_sweep_lds(SweepArgs a) {
         }
         for (uint32_t g = g0 + kRegChunks * kSweepBlock * kPerLane; g < n8; g += kSweepBlock * kPerLane) acc_chunk(words[g / 4], words[g / 4 + 1]);
         }
-        for (uint32_t i = threadIdx.x; i < n_esc; i += kSweepBlock) {   // escapes: global atomics
-            const bool first_esc = i == threadIdx.x;
-            uint32_t tag = first_esc ? esc_tag0 : a.esc_cls[e0 + i], t = first_esc ? esc_t0 : a.esc_id[e0 + i];
+        auto esc_add = [&](uint32_t tag, uint32_t t, double xval) {     // escapes: the tile's accumulator, global atomics beyond it
             double f = den[(tag >> 16) & 0x1FFFu];
-            double contrib = (tag & kSingle) ? f : (first_esc ? esc_x0 : (FUSED ? x_now(t) : x[t])) * f;
+            double contrib = (tag & kSingle) ? f : xval * f;
             if (contrib != 0.0) {
                 esc_sum += contrib;
                 uint32_t q = (t * 2654435761u) >> (32 - 7);                      // kEscSlots = 2^7
@@ -1199,6 +1206,12 @@ k_sweep_lds(SweepArgs a) {
                 }
                 if (!placed) atomicAdd(&wr_aout[t], contrib);                   // accumulator full around q: straight to memory
             }
+        };
+        if (has_esc0) esc_add(esc_tag0, esc_t0, esc_x0);
+        if (has_esc1) esc_add(esc_tag1, esc_t1, esc_x1);
+        for (uint32_t i = threadIdx.x + 2u * kSweepBlock; i < n_esc; i += kSweepBlock) {
+            const uint32_t tag = a.esc_cls[e0 + i], t = a.esc_id[e0 + i];
+            esc_add(tag, t, (tag & kSingle) ? 0.0 : (FUSED ? x_now(t) : x[t]));
         }
     }
     __syncthreads();
@@ -2240,9 +2253,12 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         std::vector<uint32_t> order;
         for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b * 16] && h[b * 16 + 10]) order.push_back(b);
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h[x * 16 + 10] - h[x * 16] > h[y * 16 + 10] - h[y * 16]; });
+        std::vector<TileDesc> htd(em->n_tiles);
+        (void)hipMemcpy(htd.data(), em->td, htd.size() * sizeof(TileDesc), hipMemcpyDeviceToHost);
         for (size_t q = 0; q < order.size() && q < 5; ++q) {
             const uint32_t b = order[q];
-            fprintf(stderr, "  slow tile %u (entry +%.2f):", b, (double)(h[b * 16] - t0min) * 0.01);
+            fprintf(stderr, "  slow tile %u (nc %u span %u n8 %u n_esc %u np %u nm %u nb %u; entry +%.2f):", b, htd[b].nc, htd[b].span, htd[b].n8, htd[b].n_esc, htd[b].np, htd[b].nm,
+                    htd[b].nb_n, (double)(h[b * 16] - t0min) * 0.01);
             for (int k = 1; k <= 10; ++k) fprintf(stderr, " %.2f", h[b * 16 + k] ? (double)(h[b * 16 + k] - h[b * 16]) * 0.01 : 0.0);
             fprintf(stderr, "\n");
         }
