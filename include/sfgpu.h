@@ -203,6 +203,8 @@ typedef struct {
     double alpha_sum;         /* after truncateCountVector (:875) */
     uint64_t n_active;        /* activeTranscriptIDs.size() (:774-782) */
     double loop_ms;           /* device time of the iteration loop (HIP events on `stream`) */
+    uint32_t fused;           /* 1: the loop ran as one kernel per iteration (update folded into the sweep), 0: sweep + update */
+    uint32_t reserved;
 } sfgpu_em_stats;
 
 SFGPU_API int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stream);

@@ -521,6 +521,7 @@ k_cover_pairs(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__
 // overlapping tiles somewhere, 2 = `lo` decreases somewhere (a caller-made class table out of canonical order): such plans keep the
 // two-kernel iteration.
 constexpr int kNbMax = 6;
+constexpr uint32_t kNbByList = 0xFFFFFFFFu;               // TileDesc::nb_n of a tile that more than kNbMax tiles overlap
 // everything a sweep block needs to know about its tile, in ONE 192-byte record: three scalar loads issued together instead of a
 // dozen words from nine arrays (each array a pointer from the kernel arguments first, then the word: the compiler serialises them
 // into a chain of dependent scalar round trips at the head of every launch)
@@ -573,11 +574,11 @@ __global__ void k_nb_table(uint32_t n_tiles, const uint32_t* __restrict__ tile_l
             if (U > T && ll < lo) { atomicOr(flags, 2u); break; }
             if (U > T && (uint64_t)ll >= (uint64_t)lo + span) break;
             if ((uint64_t)ll + sl > lo && (uint64_t)ll < (uint64_t)lo + span) {
-                if (n == (uint32_t)kNbMax) { atomicOr(flags, 1u); break; }
+                if (n == (uint32_t)kNbMax) { n = kNbByList; break; }       // too many for the record: this tile goes by the cover list
                 ent[n++] = make_uint4(ll, sl, (uint32_t)tile_off[U], U);
             }
         }
-        if (n_before > n) n_before = n;
+        if (n != kNbByList && n_before > n) n_before = n;
     }
     td[T].nb_n = n; td[T].nb_before = n_before;
     for (int j = 0; j < kNbMax; ++j) td[T].e[j] = ent[j];
@@ -1016,27 +1017,39 @@ k_sweep_lds(SweepArgs a) {
         const uint32_t nb_n = td.nb_n, nb_before = td.nb_before;
         const bool has = threadIdx.x < span;
         const uint32_t pos = lo + threadIdx.x;
-        bool in[kNbMax]; double pj[kNbMax];
         bool home = has;
-#pragma unroll
-        for (int j = 0; j < kNbMax; ++j) {
-            const uint4 e = td.e[j];                                     // {lo', span', off', tile'}
-            in[j] = has && (uint32_t)j < nb_n && (pos - e.x) < e.y;
-            pj[j] = (upd && in[j]) ? rd_part[(uint64_t)e.z + (pos - e.x)] : 0.0;
-            if (in[j] && (uint32_t)j < nb_before) home = false;
-        }
         double ap = 0.0, len = 1.0, av = 0.0, xv = 0.0;
-        if (has) {
+        if (nb_n != kNbByList) {
+            bool in[kNbMax]; double pj[kNbMax];
+#pragma unroll
+            for (int j = 0; j < kNbMax; ++j) {
+                const uint4 e = td.e[j];                                     // {lo', span', off', tile'}
+                in[j] = has && (uint32_t)j < nb_n && (pos - e.x) < e.y;
+                pj[j] = (upd && in[j]) ? rd_part[(uint64_t)e.z + (pos - e.x)] : 0.0;
+                if (in[j] && (uint32_t)j < nb_before) home = false;
+            }
+            if (has) {
+                if (upd) {
+                    ap = rd_aout[pos]; len = a.lenc[pos];
+                    const double own = rd_part[off + threadIdx.x];
+                    if (home) av = a.alpha[pos];
+                    // (the LDS accumulators are cleared below, while these words travel)
+#pragma unroll
+                    for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j < nb_before && in[j]) ap += pj[j];     // tile order, as the cover list
+                    ap += own;
+#pragma unroll
+                    for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j >= nb_before && in[j]) ap += pj[j];
+                    if (VB) ap += kPriorAlpha;
+                } else xv = x[pos];
+            }
+        } else if (has) {
+            // a tile in a crowd: the sums of transcript pos through its cover list (slots in tile order); home = the list's first slot
+            const uint32_t k0 = a.cov_ptr[pos], k1 = a.cov_ptr[pos + 1];
+            home = a.cov_pos[k0] == (uint32_t)off + threadIdx.x;
             if (upd) {
                 ap = rd_aout[pos]; len = a.lenc[pos];
-                const double own = rd_part[off + threadIdx.x];
                 if (home) av = a.alpha[pos];
-                // (the LDS accumulators are cleared below, while these words travel)
-#pragma unroll
-                for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j < nb_before && in[j]) ap += pj[j];     // tile order, as the cover list
-                ap += own;
-#pragma unroll
-                for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j >= nb_before && in[j]) ap += pj[j];
+                for (uint32_t k = k0; k < k1; ++k) ap += rd_part[a.cov_pos[k]];
                 if (VB) ap += kPriorAlpha;
             } else xv = x[pos];
         }
@@ -1586,6 +1599,7 @@ static void em_stats_from_state(sfgpu_em* em, sfgpu_em_stats* s) {
     const EmState* h = em->h_state;
     uint32_t it = h->it_a;
     s->iters = it;
+    s->fused = em->fused ? 1u : 0u; s->reserved = 0u;
     s->n_active = h->n_active;
     s->alpha_sum = h->alpha_sum;
     if (it == 0) { s->converged = 0; s->max_rel_diff = -DBL_MAX; return; }

@@ -643,6 +643,90 @@ def test_em_with_shuffled_transcript_ids_renumbers_its_plan(sf, gpu):
     assert r > 0.97, r                                     # (a class order mix-up would give ~0)
 
 
+def _far_member_problem(seed=31, M=60_000, C=120_000):
+    """the class table of test_em_far_members_shared_by_a_neighbourhood: local members + far transcripts of three kinds"""
+    rng = np.random.default_rng(seed)
+    first = np.sort(rng.integers(0, 40_000, C))
+    labels, counts = [], []
+    for c in range(C):
+        k = int(rng.integers(1, 5))
+        loc = first[c] + np.sort(rng.choice(200, k, replace=False))
+        kind = c % 4
+        if kind == 0: far = [M - 1 - first[c] // 1000]
+        elif kind == 1: far = [45_000 + (first[c] // 1000) * 7 + int(rng.integers(0, 600))]
+        elif kind == 2: far = []
+        else: far = [50_000 + int(rng.integers(0, 9_000)), 59_500 + int(rng.integers(0, 400))]
+        labels.append(np.unique(np.concatenate([loc, far]).astype(np.uint32))); counts.append(int(rng.integers(1, 50)))
+    key = sorted(range(len(labels)), key=lambda i: (int(labels[i][0]), len(labels[i]), labels[i].tobytes()))
+    seen, L2, C2 = set(), [], []
+    for i in key:
+        b = labels[i].tobytes()
+        if b in seen: continue
+        seen.add(b); L2.append(labels[i]); C2.append(counts[i])
+    rp = np.zeros(len(L2) + 1, np.uint64); rp[1:] = np.cumsum([len(l) for l in L2])
+    ii = np.concatenate(L2).astype(np.uint32); cc = np.asarray(C2, np.uint64)
+    eff = np.maximum(rng.lognormal(7.0, 0.7, M), 50.0)
+    return eff, rp, ii, cc, int(cc.sum())
+
+
+def _stacked_window_problem(M=3000, C=60_000, seed=5):
+    """60 000 classes of ~12 members inside ONE band of 900 transcripts: ~20 tiles share a window, more than a tile's overlap
+    table holds (6) -- such tiles find the other tiles' sums through the cover list"""
+    rng = np.random.default_rng(seed)
+    L, cnt, seen = [], [], set()
+    while len(L) < C:
+        lab = np.unique(rng.integers(100, 1000, int(rng.integers(8, 16)))).astype(np.uint32)
+        b = lab.tobytes()
+        if b in seen: continue
+        seen.add(b); L.append(lab); cnt.append(int(rng.integers(1, 30)))
+    key = sorted(range(len(L)), key=lambda i: (int(L[i][0]), len(L[i]), L[i].tobytes()))
+    L = [L[i] for i in key]; cnt = [cnt[i] for i in key]
+    rp = np.zeros(len(L) + 1, np.uint64); rp[1:] = np.cumsum([len(l) for l in L])
+    eff = np.maximum(rng.lognormal(7.0, 0.7, M), 50.0)
+    cc = np.asarray(cnt, np.uint64)
+    return eff, rp, np.concatenate(L).astype(np.uint32), cc, int(cc.sum())
+
+
+@pytest.mark.parametrize("vb", [False, True])
+@pytest.mark.parametrize("shape", ["midsize", "far_members", "stacked_windows"])
+def test_em_fused_iteration_equals_the_two_kernel_loop(sf, gpu, midsize, monkeypatch, vb, shape):
+    """round 4: inside optimize() an iteration is ONE kernel (the update of iteration it - 1 runs at the head of sweep it, the window
+    sums go from tile to tile through slot-major arrays and the tiles' overlap tables).  Same stop iteration, same statistics and
+    the same alpha (the additions are the same in the same order: 1e-12) as the sweep + k_update loop (SFGPU_EM_FUSED=0) and the
+    oracle, on: the midsize problem; a table with far members of every kind -- shared by a neighbourhood, more distinct ones than a
+    tile's accumulator holds, transcripts that are ONLY far members -- kept in the caller's order (SFGPU_EM_NO_RENUMBER: a plan with
+    an order of its own runs the two-kernel loop); and tables whose tiles overlap more than the tables hold (the midsize one too:
+    those tiles go by the cover list)."""
+    if shape == "midsize":
+        m = midsize; eff, rp, ii, cc, R = m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"]
+    elif shape == "far_members":
+        monkeypatch.setenv("SFGPU_EM_NO_RENUMBER", "1")
+        eff, rp, ii, cc, R = _far_member_problem()
+    else:
+        eff, rp, ii, cc, R = _stacked_window_problem()
+    runs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SFGPU_EM_FUSED", fused)
+        p = _gpu_em(sf, gpu, eff, rp, ii, cc, R)
+        out = []
+        for kw in (dict(tol=0.0, min_iter=0, max_iter=1), dict(tol=0.0, min_iter=0, max_iter=2), dict(tol=0.0, min_iter=0, max_iter=37),
+                   dict(), dict(iters_per_launch=5), dict(check_mode=1)):
+            grc, st = p.optimize(use_vbem=vb, **kw)
+            assert grc == 0
+            out.append((st, p.alpha.cpu().numpy().copy(), p.mass.cpu().numpy().copy()))
+        runs[fused] = out
+    expect_fused = True
+    for (sf_, af, mf), (s0, a0, m0) in zip(runs["1"], runs["0"]):
+        assert sf_["fused"] == expect_fused and not s0["fused"]
+        assert sf_["iters"] == s0["iters"] and sf_["converged"] == s0["converged"] and sf_["n_active"] == s0["n_active"]
+        assert _rel(af, a0) < 1e-12 and _rel(mf, m0) < 1e-12
+        assert abs(sf_["max_rel_diff"] - s0["max_rel_diff"]) <= 1e-9 * abs(s0["max_rel_diff"])
+        assert abs(sf_["alpha_sum"] - s0["alpha_sum"]) <= 1e-12 * s0["alpha_sum"]
+    rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, R, use_vbem=vb)
+    st, a, _ = runs["1"][3]
+    assert rc == 0 and st["iters"] == ost["iters"] and st["converged"] == ost["converged"] and _rel(a, oa) < TIGHT
+
+
 @pytest.mark.parametrize("vb", [False, True])
 def test_em_to_convergence_matches_stop_iteration(sf, gpu, midsize, vb):
     m = midsize
