@@ -692,7 +692,8 @@ def _stacked_window_problem(M=3000, C=60_000, seed=5):
 def test_em_fused_iteration_equals_the_two_kernel_loop(sf, gpu, midsize, monkeypatch, vb, shape):
     """round 4: inside optimize() an iteration is ONE kernel (the update of iteration it - 1 runs at the head of sweep it, the window
     sums go from tile to tile through slot-major arrays and the tiles' overlap tables).  Same stop iteration, same statistics and
-    the same alpha (the additions are the same in the same order: 1e-12) as the sweep + k_update loop (SFGPU_EM_FUSED=0) and the
+    the same alpha (the additions are the same in the same order; the far members' atomics and VBEM's leaner psi / exp differ in the
+    last bits: 1e-10) as the sweep + k_update loop (SFGPU_EM_FUSED=0) and the
     oracle, on: the midsize problem; a table with far members of every kind -- shared by a neighbourhood, more distinct ones than a
     tile's accumulator holds, transcripts that are ONLY far members -- kept in the caller's order (SFGPU_EM_NO_RENUMBER: a plan with
     an order of its own runs the two-kernel loop); and tables whose tiles overlap more than the tables hold (the midsize one too:
@@ -719,9 +720,9 @@ def test_em_fused_iteration_equals_the_two_kernel_loop(sf, gpu, midsize, monkeyp
     for (sf_, af, mf), (s0, a0, m0) in zip(runs["1"], runs["0"]):
         assert sf_["fused"] == expect_fused and not s0["fused"]
         assert sf_["iters"] == s0["iters"] and sf_["converged"] == s0["converged"] and sf_["n_active"] == s0["n_active"]
-        assert _rel(af, a0) < 1e-12 and _rel(mf, m0) < 1e-12
+        assert _rel(af, a0) < 1e-10 and _rel(mf, m0) < 1e-10
         assert abs(sf_["max_rel_diff"] - s0["max_rel_diff"]) <= 1e-9 * abs(s0["max_rel_diff"])
-        assert abs(sf_["alpha_sum"] - s0["alpha_sum"]) <= 1e-12 * s0["alpha_sum"]
+        assert abs(sf_["alpha_sum"] - s0["alpha_sum"]) <= 1e-10 * s0["alpha_sum"]
     rc, oa, om, ost = O.em_optimize(eff, rp, ii, cc, R, use_vbem=vb)
     st, a, _ = runs["1"][3]
     assert rc == 0 and st["iters"] == ost["iters"] and st["converged"] == ost["converged"] and _rel(a, oa) < TIGHT
