@@ -300,7 +300,7 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs of
     # this same command; FETCH_SIZE x2 for the wide streaming loads of the sweep, raw for the random
     # probes of the insert kernel -- see profiles/r1*_pmc_summary.md).  null when no profile matches.
-    traffic_em = traffic_ins = traffic_src = None
+    traffic_em = traffic_em_iter = traffic_ins = traffic_src = None
     try:
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{a.workload}.json")
         if not os.path.exists(pmc_path):
@@ -313,9 +313,14 @@ def main():
             #  most launches is the one the step ran)
             pick = lambda prefix: max((v for n, v in k.items() if n == prefix or (n.startswith(prefix) and n[len(prefix)] in "<,>")),
                                       key=lambda v: v.get("launches", 0), default=None)
-            e = pick("k_sweep_lds<true" if use_vbem else "k_sweep_lds<false")
-            if e:
-                traffic_em = bytes_of(e)
+            # k_sweep_lds<VB, GATHER, FUSED>: the plain sweep (what time_sweep launches) and the fused iteration are different instances
+            vbs = "true" if use_vbem else "false"
+            plain = [v for n, v in k.items() if n.startswith(f"k_sweep_lds<{vbs}") and (n.count(",") == 1 or n.endswith(", false>"))]
+            fusedk = [v for n, v in k.items() if n.startswith(f"k_sweep_lds<{vbs}") and n.count(",") == 2 and n.endswith(", true>")]
+            if plain:
+                traffic_em = bytes_of(max(plain, key=lambda v: v.get("launches", 0)))
+            if fusedk:
+                traffic_em_iter = bytes_of(max(fusedk, key=lambda v: v.get("launches", 0)))
             # class build = the partition kernels of one sub-batch (k_insert on the generic path)
             parts = [v for v in (pick("k_part_route"), pick("k_part_insert")) if v] or [v for v in (pick("k_insert"),) if v]
             if parts:
@@ -335,14 +340,17 @@ def main():
     #                           x vector it gathers from (8 M) + one partial sum per transcript it publishes (8 M); the other
     #                           32 M (+ 16 M VBEM) of B_iter' are the update's.
     b_sweep = 4 * L + 8 * C + 16 * M
-    roof_em = dict(bound="hbm", kernel="k_sweep_lds", achieved=b_sweep / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+    fused = bool(st.get("fused"))
+    roof_em = dict(bound="hbm", kernel="k_sweep_lds" + (" (the plain sweep, timed outside the loop: the loop itself runs it fused with the update)" if fused else ""), achieved=b_sweep / (sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
                    unit="GB/s", frac=b_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic_em, traffic_source=traffic_src,
                    bytes_per_launch=b_sweep, bytes_formula="4 L + 8 C + 16 M (sweep only: labels, rowptr + count, x gathered, partials published)",
                    avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
     it_s = em_loop_ms_per_iter * 1e-3
-    roof_em_iter = dict(bound="hbm", kernel="one EM iteration as the loop runs it (sweep + update + chunk boundaries)",
+    roof_em_iter = dict(bound="hbm", kernel=("one EM iteration as the loop runs it (ONE kernel: the update of the iteration before at the head of the sweep; + chunk boundaries)"
+                                            if fused else "one EM iteration as the loop runs it (sweep + update + chunk boundaries)"),
                         achieved=b_iter / it_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b_iter / it_s / 1e9 / HBM_PEAK_GBS,
-                        traffic=None, bytes_per_launch=b_iter, bytes_formula="B_iter' = 4 L + 8 C + 48 M (+ 16 M VBEM), SURVEY 8d aux-weight-free variant",
+                        traffic=(traffic_em_iter if fused else None), traffic_source=(traffic_src if fused else None),
+                        bytes_per_launch=b_iter, bytes_formula="B_iter' = 4 L + 8 C + 48 M (+ 16 M VBEM), SURVEY 8d aux-weight-free variant",
                         avg_launch_ms=em_loop_ms_per_iter, launches_per_step=st["iters"])
     # class build: SURVEY 8d's B_read (ids + offset + one 16-byte slot probe) and, next to it, the COMPULSORY bytes alone
     # (ids + offset: what any builder must read), so that the probe term cannot flatter the fraction
@@ -370,7 +378,7 @@ def main():
                    "reads_total": R_total, "reads_per_gpu": R_local, "transcripts": M, "hits": n_hits, "classes": C, "nnz": L,
                    "em_mode": info["em_mode"]},
         "em_iters": st["iters"], "em_iters_per_s": st["iters"] / (em_ms * 1e-3),
-        "em_us_per_iter_loop": em_loop_ms_per_iter * 1e3,
+        "em_us_per_iter_loop": em_loop_ms_per_iter * 1e3, "em_fused_iteration": fused,
         "phase_ms": {"class_build": build_ms, "insert_kernel": info["t_insert_ms"], "merge": info.get("t_merge_ms", 0.0),
                      "efflen": info["t_efflen_ms"], "em": em_ms, "tpm": info["t_tpm_ms"]},
         "class_build_reads_per_s": R_local / (build_ms * 1e-3),

@@ -1322,7 +1322,16 @@ k_update(uint64_t M, double* alpha, double* alpha_out, double* x, const double* 
         double ap = first ? ao_first : alpha_out[t];
         if (FOLD) {
             const uint32_t k0 = first ? k0_first : cov_ptr[t], k1 = first ? k1_first : cov_ptr[t + 1];
-            for (uint32_t k = k0; k < k1; ++k) ap += partial[k];       // transcript-major: contiguous, fixed order
+            // transcript-major: contiguous, fixed order.  (The first four entries are requested together: a loop over them is one
+            // round trip per entry, and some lane of a wavefront nearly always has three or four.)
+            const uint32_t nk = k1 - k0;
+            const double p0 = nk > 0u ? partial[k0] : 0.0, p1 = nk > 1u ? partial[k0 + 1u] : 0.0;
+            const double p2 = nk > 2u ? partial[k0 + 2u] : 0.0, p3 = nk > 3u ? partial[k0 + 3u] : 0.0;
+            if (nk > 0u) ap += p0;
+            if (nk > 1u) ap += p1;
+            if (nk > 2u) ap += p2;
+            if (nk > 3u) ap += p3;
+            for (uint32_t k = k0 + 4u; k < k1; ++k) ap += partial[k];
         }
         if (VB) ap += kPriorAlpha;                     // alphaOut starts at the prior (:318)
         double gate = check_mode ? a : ap;             // :852 vs :499

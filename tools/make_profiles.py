@@ -41,16 +41,48 @@ def short(name):
     return head.split("::")[-1] + lt + tail
 
 
+LOOP_KERNELS = ("k_sweep_lds", "k_update")       # enqueued in chunks: the launches past the stop iteration return at once
+
+
 def counters(d, counter):
-    per = defaultdict(lambda: [0, 0.0])
+    """-> {kernel: [launches, sum, no-op launches]}.  The EM loop's kernels are enqueued in chunks and turn into no-ops once the
+    loop has ended (em.hip): a launch whose counter is below 5 % of that kernel's largest is such a no-op and is left out of the
+    per-launch average (it would dilute it by the ~20 % of launches that do nothing)."""
+    vals = defaultdict(list)
     with open(find(d, "counter_collection.csv")) as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            k = short(row["Kernel_Name"])
-            per[k][0] += 1
-            per[k][1] += float(row["Counter_Value"])
+            vals[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    per = {}
+    for k, v in vals.items():
+        noop = 0
+        if k.startswith(LOOP_KERNELS) and v:
+            cut = 0.05 * max(v)
+            noop = sum(1 for x in v if x < cut)
+            v = [x for x in v if x >= cut]
+        per[k] = [len(v), sum(v), noop]
     return per
+
+
+def running_launch_us(stats_dir):
+    """average duration of the launches of the EM loop's kernels that did run (kernel trace; no-ops are < 30 % of the longest)"""
+    out = {}
+    try:
+        path = find(stats_dir, "kernel_trace.csv")
+    except SystemExit:
+        return out
+    durs = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            if k.startswith(LOOP_KERNELS):
+                durs[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    for k, v in durs.items():
+        cut = 0.3 * max(v)
+        run = [x for x in v if x >= cut]
+        out[k] = (len(run), sum(run) / len(run), len(v) - len(run))
+    return out
 
 
 def main():
@@ -68,7 +100,7 @@ def main():
         if not k.startswith("k_"):
             continue                        # torch ops of the input generator: not part of the path
         n = max(fe.get(k, [0, 0])[0], wr.get(k, [0, 0])[0], 1)
-        kernels[k] = {"launches": n,
+        kernels[k] = {"launches": n, "noop_launches_left_out": max(fe.get(k, [0, 0, 0])[2], wr.get(k, [0, 0, 0])[2]),
                       "fetch_kib_per_launch": fe.get(k, [0, 0.0])[1] / max(fe.get(k, [1, 0])[0], 1),
                       "write_kib_per_launch": wr.get(k, [0, 0.0])[1] / max(wr.get(k, [1, 0])[0], 1),
                       # MI355X_MICROARCH.md, HBM: gfx950 reports a wide (16 B per lane) coalesced streaming read at half its
@@ -92,6 +124,13 @@ def main():
             k = k if len(k) <= 72 else k[:69] + "..."
             f.write(f"| `{k}` | {calls} | {avg / 1e3:.2f} | {pct:.2f} | "
                     + (f"{e['fetch_kib_per_launch']:.1f} | {e['write_kib_per_launch']:.1f} | {'x2' if e['fetch_x2'] else 'x1'} |\n" if e else "- | - | |\n"))
+        run = running_launch_us(stats_dir)
+        if run:
+            f.write("\nThe EM loop's kernels are enqueued in chunks; launches past the stop iteration return at once.  The rows above average "
+                    "over ALL launches (rocprofv3's own statistics); the launches that did run, from the kernel trace (FETCH / WRITE per launch "
+                    "above already leave the no-ops out):\n\n| kernel | launches that ran | avg us | no-op launches |\n|---|---:|---:|---:|\n")
+            for k, (n, avg, noop) in sorted(run.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                f.write(f"| `{k}` | {n} | {avg:.2f} | {noop} |\n")
     print("wrote", tag, "with", len(stats), "kernels;", len(kernels), "with counters")
 
 
