@@ -55,6 +55,9 @@ while time.time() < t_end:
     vb = bool(rng.integers(0, 2)); iters = int(rng.choice([1, 3, 25]))
     rc, oa, om, ost = O.em_optimize(eff, rp.astype(np.uint64), ids, cnt, N, use_vbem=vb, tol=0.0, min_iter=iters, max_iter=iters)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+    # round 4: the fused iteration runs on plans in the caller's order -- keep that order for half of the cases that would be renumbered
+    if rng.random() < 0.5: os.environ["SFGPU_EM_NO_RENUMBER"] = "1"
+    else: os.environ.pop("SFGPU_EM_NO_RENUMBER", None)
     p = sf.EMProblem(torch.from_numpy(eff).to(dev), t(rp.astype(np.uint32), np.int32), t(ids, np.int32), t(cnt, np.int64), N)
     grc, st = p.optimize(use_vbem=vb, tol=0.0, min_iter=iters, max_iter=iters)
     ga = p.alpha.cpu().numpy()
@@ -64,7 +67,7 @@ while time.time() < t_end:
         assert np.array_equal(ga > 0, nz), "support differs"
         rel = float(np.max(np.abs(ga[nz] - oa[nz]) / oa[nz])) if nz.any() else 0.0
         worst = max(worst, rel)
-        print(f"M={M} C={C} nnz={rp[-1]} law={law} local={local} vb={vb} iters={iters}: rel {rel:.2e} iters {st['iters']}/{ost['iters']}", flush=True)
+        print(f"M={M} C={C} nnz={rp[-1]} law={law} local={local} vb={vb} iters={iters} fused={st['fused']}: rel {rel:.2e} iters {st['iters']}/{ost['iters']}", flush=True)
         assert rel < 1e-9 and st["iters"] == ost["iters"], "MISMATCH"
     p.close(); n += 1
 print("all ok:", n, "worst rel", worst)
