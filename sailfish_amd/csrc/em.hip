@@ -302,6 +302,11 @@ static_assert(kTileNnz < (1 << 13) && kWin < (1 << 16), "stream word: 13-bit cla
 static_assert(kTileNnz <= 8191, "class index field is 13 bits");
 static_assert(kEscSlots == 128, "the escape accumulator's hash takes 7 bits");
 
+__global__ void k_tile_most(uint32_t n_tiles, const uint32_t* __restrict__ tile_c0, unsigned int* most) {
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T < n_tiles) atomicMax(most, tile_c0[T + 1] - tile_c0[T]);
+}
+
 // tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*tile_nnz, (i+1)*tile_nnz)
 __global__ void k_tile_plan(uint64_t C, uint32_t n_tiles, uint32_t tile_nnz, const uint32_t* __restrict__ rowptr,
                             uint32_t* tile_c0) {
@@ -749,7 +754,7 @@ struct SweepArgs {
     const uint32_t* pub_pos;                                             // window slot -> index in `partial`
     double* alpha_out; double* partial;
     double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
-    const uint32_t* cov_ptr; const uint32_t* cov_pos; const uint32_t* unc; uint32_t n_unc; int check_mode;
+    const uint32_t* cov_ptr; const uint32_t* cov_pos; const uint32_t* unc; const uint32_t* unc_n; int check_mode;
     double* tmax;                                                        // [2][n_tiles][waves]: largest relative change a wavefront saw
     double tol; double log_norm; uint64_t M;
     unsigned long long* dbg;                                             // SFGPU_X_STAMP builds: [tile][16] phase time stamps (dev)
@@ -878,7 +883,8 @@ k_sweep_lds(SweepArgs a) {
     // the end of a FUSED launch: the transcripts no window holds, then what the wavefront saw of the convergence test
     auto fused_tail = [&]() {
 #ifndef SFGPU_X_NOUPD
-        for (uint32_t j = threadIdx.x * gridDim.x + blockIdx.x; j < a.n_unc; j += kSweepBlock * gridDim.x) {
+        const uint32_t n_unc = *a.unc_n;                        // (known on the device only: nothing waits for it at the head)
+        for (uint32_t j = threadIdx.x * gridDim.x + blockIdx.x; j < n_unc; j += kSweepBlock * gridDim.x) {
             const uint32_t t = a.unc[j];
             if (upd) { const double p = rd_aout[t] + (VB ? kPriorAlpha : 0.0); judge(a.alpha[t], p); a.alpha[t] = p; }
             zr_aout[t] = 0.0;
@@ -1399,7 +1405,7 @@ struct sfgpu_em {
     hipStream_t user_stream = nullptr;
     hipStream_t stream = nullptr;          // own stream: graph capture is illegal on the null stream
     hipStream_t cur = nullptr;             // where work goes: `stream` inside optimize(), the caller's stream for the piecewise API
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_join = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_join = nullptr, ev_plan = nullptr;
     hipEvent_t ev_poll[2] = {nullptr, nullptr};   // pipelined stop test of the loop (em_poll_start / em_poll_wait)
     unsigned long long* h_mirror = nullptr;       // pinned: what k_post_state wrote last
     sfgpu_problem prob{};
@@ -1431,7 +1437,6 @@ struct sfgpu_em {
     double* partial_a = nullptr;                            // (slot-major, like partial_b; `partial` stays the two-kernel loop's)
     uint2* esc_slots = nullptr; uint64_t E = 0;             // the far members' inline cover slots (k_esc_slots)
     uint32_t* unc = nullptr;                                // transcripts no window holds ([M] + count + the overlap tables' flags behind them)
-    uint32_t n_unc = 0;
     int fused_ok = -1;                                      // -1: not looked at yet; 0: this plan keeps the two-kernel iteration
     unsigned long long* dbg = nullptr;
     bool fused = false;                                     // this optimize() runs fused launches
@@ -1466,6 +1471,7 @@ static void em_free(sfgpu_em* em) {
     if (em->ev_a) (void)hipEventDestroy(em->ev_a);
     if (em->ev_b) (void)hipEventDestroy(em->ev_b);
     if (em->ev_join) (void)hipEventDestroy(em->ev_join);
+    if (em->ev_plan) (void)hipEventDestroy(em->ev_plan);
     for (hipEvent_t e : em->ev_poll) if (e) (void)hipEventDestroy(e);
     if (em->h_mirror) pinned_free(em->h_mirror);
     if (em->h_plan) pinned_free(em->h_plan);
@@ -1509,7 +1515,7 @@ static SweepArgs em_sweep_args(sfgpu_em* em) {
     a.part_a = em->partial_a; a.part_b = em->partial_b; a.aout_a = em->alpha_out; a.aout_b = em->aout_b; a.aout_c = em->aout_c;
     a.lenc = em->lenc; a.alpha = em->alpha; a.inv = em->inv; a.esc_id = em->esc_id; a.esc_cls = em->esc_cls; a.esc_slots = em->esc_slots;
     a.csc = em->csc; a.csc_slot0 = em->csc_slot0; a.pub_pos = em->pub_pos; a.alpha_out = em->alpha_out; a.partial = em->partial;
-    a.cov_ptr = em->cov_ptr; a.cov_pos = em->cov_pos; a.unc = em->unc; a.n_unc = em->n_unc; a.check_mode = em->opts.check_mode;
+    a.cov_ptr = em->cov_ptr; a.cov_pos = em->cov_pos; a.unc = em->unc; a.unc_n = em->unc ? em->unc + p.M : nullptr; a.check_mode = em->opts.check_mode;
     a.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm; a.M = p.M; a.dbg = em->dbg;
     return a;
 }
@@ -1702,6 +1708,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     em->cur = em->stream;
     EM_TRY(hipEventCreate(&em->ev_a)); EM_TRY(hipEventCreate(&em->ev_b));
     EM_TRY(hipEventCreateWithFlags(&em->ev_join, hipEventDisableTiming));
+    EM_TRY(hipEventCreateWithFlags(&em->ev_plan, hipEventDisableTiming));
     for (hipEvent_t& e : em->ev_poll) EM_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     EM_TRY(pinned_malloc(&em->h_mirror, 128));
     memset(em->h_mirror, 0, 128);
@@ -1786,40 +1793,37 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
       for (;;) {                             // (the plan; twice or three times when the transcripts are renumbered)
         rounds = rounds0; tile_nnz = tile_nnz0; nt = nt0; em->n_tiles = nt0;
         EM_TRY(pool_malloc(&t_len8, ((size_t)nt_cap + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt_cap + 1) * 4));
-        hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
-                           p_rowptr, em->tile_c0);
-        while (tile_nnz > (uint32_t)kTileNnz) {
-            uint32_t* c0 = nullptr;                         // (pinned: a copy into pageable memory is staged by the runtime)
-            EM_TRY(pinned_malloc(&c0, ((size_t)nt + 1) * 4));
-            hipError_t ce = hipMemcpyAsync(c0, em->tile_c0, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, em->cur);
-            if (ce == hipSuccess) ce = hipStreamSynchronize(em->cur);
-            uint32_t most = 0;
-            if (ce == hipSuccess) for (uint32_t i = 0; i < nt; ++i) most = std::max(most, c0[i + 1] - c0[i]);
-            pinned_free(c0);
-            EM_TRY(ce);
-            if (most <= (uint32_t)kTileNnz) break;
+        // (the check of the tiles' class counts rides on the read-back of the plan's sizes: the window pass and the scans below run on a
+        //  plan that may have to be redone with one more round -- rare, and harmless: they do not depend on the class counts)
+        unsigned int* d_most = reinterpret_cast<unsigned int*>(em->partials) + 4;
+        for (;;) {
+            hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
+                               p_rowptr, em->tile_c0);
+            EM_TRY(hipMemsetAsync(d_most, 0, 4, em->cur));
+            hipLaunchKernelGGL(k_tile_most, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, d_most);
+            hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
+                               em->tile_lo, em->tile_span, t_len8, t_nesc);
+            EM_TRY(hipGetLastError());
+            // (no host wait inside the scans: the totals are read back with one synchronisation below)
+            int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur, false);
+            if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur, false);
+            if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur, false);
+            if (sr) { pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur); em_free(em); return sr; }
+            EM_TRY(hipMemcpyAsync(em->h_plan + 1, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipMemcpyAsync(em->h_plan + 2, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipMemcpyAsync(em->h_plan + 3, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipMemcpyAsync(em->h_plan + 5, d_most, 4, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipStreamSynchronize(em->cur));
+            const uint32_t most = *reinterpret_cast<const uint32_t*>(em->h_plan + 5);
+            if (tile_nnz <= (uint32_t)kTileNnz || most <= (uint32_t)kTileNnz) break;
             ++rounds;
             tile_nnz = tile_for(rounds);
             if (tile_nnz < (uint32_t)kTileNnz) tile_nnz = kTileNnz;
             nt = (uint32_t)std::max<uint64_t>(1, ((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
             if (nt > nt_cap) { nt = nt_small; tile_nnz = kTileNnz; }
             em->n_tiles = nt;
-            hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
-                               p_rowptr, em->tile_c0);
         }
-        hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
-                           em->tile_lo, em->tile_span, t_len8, t_nesc);
-        EM_TRY(hipGetLastError());
-        // (no host wait inside the scans: the totals are read back with one synchronisation below)
-        int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur, false);
-        if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur, false);
-        if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur, false);
         pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur);
-        if (sr) { em_free(em); return sr; }
-        EM_TRY(hipMemcpyAsync(em->h_plan + 1, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
-        EM_TRY(hipMemcpyAsync(em->h_plan + 2, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-        EM_TRY(hipMemcpyAsync(em->h_plan + 3, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-        EM_TRY(hipStreamSynchronize(em->cur));
         P = em->h_plan[1]; S = em->h_plan[2]; E = em->h_plan[3];
         // Many members outside their tile's window (an index whose isoforms are not adjacent): let the plan order the transcripts
         // itself, and keep that order if it removes at least 40 % of the escapes.
@@ -1922,6 +1926,25 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         hipLaunchKernelGGL(k_tile_desc, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, em->tile_lo, em->tile_span,
                            em->tile_s0, em->tile_esc0, em->tile_off, em->gather ? em->tile_qb : nullptr, em->tile_np, em->tile_pr, em->td);
         EM_TRY(hipGetLastError());
+        if (em->gather && !em->inv) {
+            // what the FUSED iteration (k_sweep_lds<.., .., true>) needs besides: two slot-major arrays of window sums, two more escape
+            // accumulators, the wavefronts' maxima, the tiles' overlap tables, the list of transcripts no window holds and the far
+            // members' inline cover slots.  The tables' verdict (flags) is read back behind them without a wait; optimize() looks at it.
+            const uint64_t Pn = P ? P : 1;
+            EM_TRY(pool_malloc(&em->partial_a, Pn * 8)); EM_TRY(pool_malloc(&em->partial_b, Pn * 8));
+            EM_TRY(pool_malloc(&em->aout_b, M * 8)); EM_TRY(pool_malloc(&em->aout_c, M * 8));
+            EM_TRY(pool_malloc(&em->tmax, 2ull * nt * (kSweepBlock / kWave) * 8));
+            EM_TRY(pool_malloc(&em->unc, (M + 2) * 4));
+            EM_TRY(hipMemsetAsync(em->unc + M, 0, 8, em->cur));
+            hipLaunchKernelGGL(k_nb_table, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_lo, em->tile_span,
+                               em->tile_off, em->td, em->unc + M + 1);
+            hipLaunchKernelGGL(k_uncovered, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->cov_ptr, em->unc, em->unc + M);
+            EM_TRY(pool_malloc(&em->esc_slots, (E ? E : 1) * 8));
+            if (E) hipLaunchKernelGGL(k_esc_slots, dim3(blocks_for(E)), dim3(kEmBlock), 0, em->cur, E, em->esc_id, em->cov_ptr, em->cov_pos, em->esc_slots);
+            EM_TRY(hipGetLastError());
+            EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipEventRecord(em->ev_plan, em->cur));
+        }
     }
 #undef EM_TRY
     *out = em;
@@ -2180,46 +2203,25 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         const bool fused_off = fe && atoi(fe) == 0;
         em->fused = !fused_off && em->gather && !em->inv && em->fused_ok != 0 && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
     }
-    bool fresh_fused = false;
     if (em->fused && em->fused_ok < 0) {
-        // its arrays, once per handle: two slot-major arrays of window sums, two more escape accumulators, the wavefronts' maxima,
-        // the tiles' overlap tables and the list of transcripts no window holds (its length and the tables' flags come back with
-        // init's poll below)
-        const uint64_t M = em->prob.M, P = em->P ? em->P : 1;
-        SF_HIP(pool_malloc(&em->partial_a, P * 8)); SF_HIP(pool_malloc(&em->partial_b, P * 8));
-        SF_HIP(pool_malloc(&em->aout_b, M * 8)); SF_HIP(pool_malloc(&em->aout_c, M * 8));
-        SF_HIP(pool_malloc(&em->tmax, 2ull * em->n_tiles * (kSweepBlock / kWave) * 8));
-        SF_HIP(pool_malloc(&em->unc, (M + 2) * 4));
-        SF_HIP(hipMemsetAsync(em->unc + M, 0, 8, em->cur));
-        hipLaunchKernelGGL(k_nb_table, dim3((em->n_tiles + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, em->n_tiles, em->tile_lo, em->tile_span,
-                           em->tile_off, em->td, em->unc + M + 1);
-        SF_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_uncovered, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->cov_ptr, em->unc, em->unc + M);
-        SF_CHECK_LAUNCH();
-        SF_HIP(pool_malloc(&em->esc_slots, (em->E ? em->E : 1) * 8));
-        if (em->E) {
-            hipLaunchKernelGGL(k_esc_slots, dim3(blocks_for(em->E)), dim3(kEmBlock), 0, em->cur, em->E, em->esc_id, em->cov_ptr, em->cov_pos, em->esc_slots);
-            SF_CHECK_LAUNCH();
-        }
-        SF_HIP(hipMemcpyAsync(em->h_plan + 4, em->unc + M, 8, hipMemcpyDeviceToHost, em->cur));
-        fresh_fused = true;
+        // the plan's verdict on the fused kernel's tables (sfgpu_em_create queued its read-back behind them; long done by now)
+        SF_HIP(hipEventSynchronize(em->ev_plan));
+        em->fused_ok = (*reinterpret_cast<const uint32_t*>(em->h_plan + 4) == 0u && em->partial_a) ? 1 : 0;
+        if (!em->fused_ok) em->fused = false;                // (the classes are not in canonical order)
     }
     if ((rc = sfgpu_em_init_impl(em))) return rc;
     int done = 0;
     sfgpu_em_stats st{};
-    if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
-    if (fresh_fused) {
-        const uint32_t* hp = reinterpret_cast<const uint32_t*>(em->h_plan + 4);
-        em->n_unc = hp[0];
-        em->fused_ok = hp[1] == 0u ? 1 : 0;
-        if (!em->fused_ok) em->fused = false;                // (overlap tables too small, or the classes out of canonical order)
+    if (!em->fused) {
+        if ((rc = sfgpu_em_poll(em, &done, &st))) return rc;
+        if (st.n_active == 0) {                                                      // :794-798
+            set_error("It seems that no transcripts are expressed; something is likely wrong!");
+            if (stats) *stats = st;
+            return SFGPU_ERR_NO_ACTIVE;
+        }
     }
-    if (st.n_active == 0) {                                                      // :794-798
-        set_error("It seems that no transcripts are expressed; something is likely wrong!");
-        if (stats) *stats = st;
-        return SFGPU_ERR_NO_ACTIVE;
-    }
-    if (getenv("SFGPU_TIMING") && em->fused) fprintf(stderr, "em fused: %u transcripts outside every window\n", em->n_unc);
+    // (fused: no wait here -- the first launches go out behind init at once and the number of active transcripts is looked at when
+    //  the loop has ended: a job without any runs minIter iterations over zeros before it reports so)
     if (!quiet) log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
     const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
     uint32_t chunk = em->opts.iters_per_launch;
@@ -2259,6 +2261,11 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     }
     SF_HIP(hipEventRecord(em->ev_b, em->cur));
     rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
+    if (em->fused && st.n_active == 0) {                                             // :794-798 (see above)
+        set_error("It seems that no transcripts are expressed; something is likely wrong!");
+        if (stats) *stats = st;
+        return SFGPU_ERR_NO_ACTIVE;
+    }
 #ifdef SFGPU_X_STAMP
     if (em->dbg) {                                          // dev: phase stamps of the last launch that ran (100 MHz clock)
         std::vector<unsigned long long> h((size_t)em->n_tiles * 16);

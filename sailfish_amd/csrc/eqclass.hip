@@ -494,6 +494,7 @@ struct sfgpu_eq {
     hipStream_t ins_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_hot = nullptr, ev_join = nullptr;
     DevBuf<uint32_t> grid_dev; uint32_t* grid_host = nullptr; uint64_t grid_cap = 0;     // offsets at the sub-batch grid (pinned copy)
+    bool settled = false;       // the last partitioned sub-batch returned with the stream waited for and arena_used current
     bool use_pipe = false;      // SFGPU_EQ_PIPE=1: measured no faster than the serial form (profiles/r4_class_build_notes.md), so not the default
     uint64_t reads_seen = 0;                // reads added since start()
     uint64_t hot_cap = 0, hot_reads = 0;    // table size and reads_seen when the hot table was last rebuilt
@@ -848,6 +849,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
                           uint64_t n_words, const uint64_t* peek) {
     hipStream_t st = eq->stream;
     int rc;
+    eq->settled = false;
     // The table doubles when the classes seen so far would fill more than half of it (SFGPU_EQ_LOAD_DIV: 1/div).  A
     // region's LDS image overflows at 3/4 (kRegionLimit) -- 22 standard deviations above a half-full region of 4096
     // slots -- and an overflowing region only defers its reads to the generic kernel.  Half rather than a quarter
@@ -968,7 +970,9 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     const uint64_t n_def = eq->h_ctr[CTR_DEFER], n_long = eq->h_ctr[3];
     eq->stats.hot_reads += eq->h_ctr[CTR_HOT];
     if (n_def > saved_def && (rc = eq_deferred_save(eq, eq->part_words.p, eq->deferred_a.p + 2 * saved_def, n_def - saved_def))) return rc;
-    return eq_part_fixups(eq, d_ids, d_offsets, eq->part_long.p, n_long);
+    if ((rc = eq_part_fixups(eq, d_ids, d_offsets, eq->part_long.p, n_long))) return rc;
+    eq->settled = true;                  // the stream has been waited for and arena_used is the device's cursor
+    return SFGPU_OK;
 }
 
 constexpr uint32_t kScoutReads = 1u << 19;      // the first sub-batch of a builder: enough reads to see which classes are hot
@@ -1284,6 +1288,7 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     // new classes appear (the rate only falls as the table fills); the next sub-batch is made up to four
     // times larger (at most 2^26 reads) as long as, at that rate, the table would stay under half full:
     // fewer launches and longer region segments (400 M reads: 24 sub-batches -> 8).
+    bool settled = first0 == n_reads && first0 != 0;          // (the pipeline ends drained)
     for (uint32_t first = first0; first < n_reads; ) {
         uint32_t cnt = (n_reads - first < step) ? (n_reads - first) : step;
         const uint64_t classes_before = eq->n_classes;
@@ -1329,6 +1334,7 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
         }
         first += cnt;
         eq->reads_seen += cnt;
+        settled = done && eq->settled;   // (a partitioned sub-batch returns with the stream waited for and the arena cursor read)
         if (scout) { scout = false; step = usual_step; continue; }       // the scout sub-batch is extra: the usual sizes follow
         if (adaptive && done) {
             const double rate = (double)(eq->n_classes - classes_before + 1) / (double)cnt;
@@ -1338,11 +1344,13 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
             }
         }
     }
-    // the caller may reuse its buffers on return: wait for the last commit
-    SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long),
-                          hipMemcpyDeviceToHost, st));
-    SF_HIP(hipStreamSynchronize(st));
-    eq->arena_used = eq->h_ctr[CTR_ARENA];
+    // the caller may reuse its buffers on return: wait for the last commit (a batch that ended in a partitioned sub-batch has)
+    if (!settled) {
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_ARENA, eq->d_ctr + CTR_ARENA, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, st));
+        SF_HIP(hipStreamSynchronize(st));
+        eq->arena_used = eq->h_ctr[CTR_ARENA];
+    }
     return SFGPU_OK;
 }
 

@@ -23,7 +23,7 @@ class EMProblem:
                             (_lib.ptr(self._keep[3]).value if self._keep[3].numel() else None), int(num_mapped))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            torch.cuda.current_stream().synchronize()
+            # (no host wait: the handle orders its own stream behind everything already queued on the caller's, sfgpu_em_create)
             _lib.check(self._L.sfgpu_em_create(C.byref(h), C.byref(prob), _lib.current_stream_ptr()))
         self._h = h
         self.alpha = torch.zeros(self.M, dtype=torch.float64, device=self.device)
