@@ -598,10 +598,28 @@ __global__ void k_esc_slots(uint64_t E, const uint32_t* __restrict__ esc_id, con
     const uint32_t t = esc_id[i], k0 = cov_ptr[t], k1 = cov_ptr[t + 1];
     esc_slots[i] = make_uint2(k1 > k0 ? cov_pos[k0] : kNoSlot, k1 > k0 + 1u ? cov_pos[k0 + 1u] : kNoSlot);
 }
-// ... and the transcripts no window holds (inactive, or only ever a far member): the update reaches them through this list
-__global__ void k_uncovered(uint64_t M, const uint32_t* __restrict__ cov_ptr, uint32_t* list, uint32_t* n) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M && cov_ptr[t] == cov_ptr[t + 1]) list[atomicAdd(n, 1u)] = (uint32_t)t;
+// FUSED: the cover list of the transcript at POSITION pos of the plan's order ([k0, k1) of cov_pos), and the positions no window holds
+// (inactive, or only ever a far member): the update reaches those through the list
+__global__ void k_cov_by_pos(uint64_t M, const uint32_t* __restrict__ inv, const uint32_t* __restrict__ cov_ptr, uint2* cov2, uint32_t* list, uint32_t* n) {
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= M) return;
+    const uint32_t t = inv ? inv[pos] : (uint32_t)pos;
+    const uint2 r = make_uint2(cov_ptr[t], cov_ptr[t + 1]);
+    cov2[pos] = r;
+    if (r.x == r.y) list[atomicAdd(n, 1u)] = (uint32_t)pos;
+}
+// out[i] = map[in[i]] (the far members' transcripts as positions) ; out[pos] = in[inv[pos]] (a per-transcript vector in the plan's order)
+__global__ void k_map_u32(uint64_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ map, uint32_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = map[in[i]];
+}
+__global__ void k_gather_f64(uint64_t M, const double* __restrict__ in, const uint32_t* __restrict__ inv, double* out) {
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < M) out[pos] = in[inv[pos]];
+}
+__global__ void k_scatter_f64(uint64_t M, const double* __restrict__ in, const uint32_t* __restrict__ inv, double* out) {
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < M) out[inv[pos]] = in[pos];
 }
 
 // cov_pos[k] = window slot that sorts to position k  ->  pub_pos[slot] = k
@@ -754,7 +772,7 @@ struct SweepArgs {
     const uint32_t* pub_pos;                                             // window slot -> index in `partial`
     double* alpha_out; double* partial;
     double* tsum;                                                        // VBEM inside optimize(): what each tile added (else null)
-    const uint32_t* cov_ptr; const uint32_t* cov_pos; const uint32_t* unc; const uint32_t* unc_n; int check_mode;
+    const uint32_t* cov_ptr; const uint2* cov2; const uint32_t* cov_pos; const uint32_t* unc; const uint32_t* unc_n; int check_mode;
     double* tmax;                                                        // [2][n_tiles][waves]: largest relative change a wavefront saw
     double tol; double log_norm; uint64_t M;
     unsigned long long* dbg;                                             // SFGPU_X_STAMP builds: [tile][16] phase time stamps (dev)
@@ -858,10 +876,13 @@ k_sweep_lds(SweepArgs a) {
     // alpha' of a FAR transcript as k_update<.., FOLD> forms it (its sums through the cover list: cov_pos names the slots)
     auto new_alpha = [&](uint32_t t) -> double {
         double ap = rd_aout[t];
-        for (uint32_t k = a.cov_ptr[t], e = a.cov_ptr[t + 1]; k < e; ++k) ap += rd_part[a.cov_pos[k]];
+        const uint2 cr = a.cov2[t];
+        for (uint32_t k = cr.x; k < cr.y; ++k) ap += rd_part[a.cov_pos[k]];
         if (VB) ap += kPriorAlpha;
         return ap;
     };
+    // (FUSED kernels index per-transcript arrays by POSITION in the plan's order; the x vector init made is in the caller's)
+    auto x_first = [&](uint32_t pos_) -> double { return x[a.inv ? a.inv[pos_] : pos_]; };
     auto x_of = [&](double ap, double len) -> double {
 #ifdef SFGPU_X_CHEAPX
         return sweep_x<false>(ap / len);
@@ -869,7 +890,7 @@ k_sweep_lds(SweepArgs a) {
         if (VB) return (ap > kTiny) ? sweep_x<true>(vb_x_lean(ap, a.log_norm, len)) : 0.0;       // :300-320
         return sweep_x<false>(ap / len);
     };
-    auto x_now = [&](uint32_t t) -> double { return upd ? x_of(new_alpha(t), a.lenc[t]) : x[t]; };      // (far members)
+    auto x_now = [&](uint32_t t) -> double { return upd ? x_of(new_alpha(t), a.lenc[t]) : (FUSED ? x_first(t) : x[t]); };      // (far members)
     double local_max = -1.0; unsigned notconv = 0;
     auto judge = [&](double av_, double ap_) {
         const double gate = a.check_mode ? av_ : ap_;               // :852 vs :499
@@ -1007,18 +1028,19 @@ k_sweep_lds(SweepArgs a) {
             if (sl.x != kNoSlot) ap += q0;
             if (sl.y != kNoSlot) {
                 ap += q1;
-                for (uint32_t k = a.cov_ptr[t] + 2u, e = a.cov_ptr[t + 1]; k < e; ++k) ap += rd_part[a.cov_pos[k]];
+                const uint2 cr = a.cov2[t];
+                for (uint32_t k = cr.x + 2u; k < cr.y; ++k) ap += rd_part[a.cov_pos[k]];
             }
             if (VB) ap += kPriorAlpha;
             return x_of(ap, len);
         }
-        return x[t];
+        return FUSED ? x_first(t) : x[t];
     };
     auto esc_values = [&]() { esc_x0 = esc_value(has_esc0, esc_tag0, esc_t0, esc_sl0); esc_x1 = esc_value(has_esc1, esc_tag1, esc_t1, esc_sl1); };
     if constexpr (FUSED) {
         // ---- U + staging: descriptors (the tile's own and its NbTable), then ONE round trip of operands, the math, the stores.
-        //      A thread holds at most one window slot (kWin <= kSweepBlock); fused plans have no order of their own (inv == null),
-        //      so slot i is transcript lo + i.
+        //      A thread holds at most one window slot (kWin <= kSweepBlock); slot i is position lo + i of the plan's transcript order, and
+        //      the fused kernel's per-transcript arrays (alpha, effLen, the escape accumulators, cov2) are IN that order.
         static_assert(kWin <= kSweepBlock, "one window slot per thread");
         const uint32_t nb_n = td.nb_n, nb_before = td.nb_before;
         const bool has = threadIdx.x < span;
@@ -1046,18 +1068,19 @@ k_sweep_lds(SweepArgs a) {
 #pragma unroll
                     for (int j = 0; j < kNbMax; ++j) if ((uint32_t)j >= nb_before && in[j]) ap += pj[j];
                     if (VB) ap += kPriorAlpha;
-                } else xv = x[pos];
+                } else xv = x_first(pos);
             }
         } else if (has) {
             // a tile in a crowd: the sums of transcript pos through its cover list (slots in tile order); home = the list's first slot
-            const uint32_t k0 = a.cov_ptr[pos], k1 = a.cov_ptr[pos + 1];
+            const uint2 cr = a.cov2[pos];
+            const uint32_t k0 = cr.x, k1 = cr.y;
             home = a.cov_pos[k0] == (uint32_t)off + threadIdx.x;
             if (upd) {
                 ap = rd_aout[pos]; len = a.lenc[pos];
                 if (home) av = a.alpha[pos];
                 for (uint32_t k = k0; k < k1; ++k) ap += rd_part[a.cov_pos[k]];
                 if (VB) ap += kPriorAlpha;
-            } else xv = x[pos];
+            } else xv = x_first(pos);
         }
         esc_values();
         for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
@@ -1436,6 +1459,8 @@ struct sfgpu_em {
     double *partial_b = nullptr, *aout_b = nullptr, *aout_c = nullptr, *tmax = nullptr;
     double* partial_a = nullptr;                            // (slot-major, like partial_b; `partial` stays the two-kernel loop's)
     uint2* esc_slots = nullptr; uint64_t E = 0;             // the far members' inline cover slots (k_esc_slots)
+    uint2* cov2 = nullptr;                                  // cover list by position of the plan's order
+    uint32_t* esc_pos = nullptr; double *alphaP = nullptr, *lencP = nullptr;      // plans with an order of their own: far members as positions, alpha / effLen in that order
     uint32_t* unc = nullptr;                                // transcripts no window holds ([M] + count + the overlap tables' flags behind them)
     int fused_ok = -1;                                      // -1: not looked at yet; 0: this plan keeps the two-kernel iteration
     unsigned long long* dbg = nullptr;
@@ -1464,7 +1489,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -1515,7 +1540,7 @@ static SweepArgs em_sweep_args(sfgpu_em* em) {
     a.part_a = em->partial_a; a.part_b = em->partial_b; a.aout_a = em->alpha_out; a.aout_b = em->aout_b; a.aout_c = em->aout_c;
     a.lenc = em->lenc; a.alpha = em->alpha; a.inv = em->inv; a.esc_id = em->esc_id; a.esc_cls = em->esc_cls; a.esc_slots = em->esc_slots;
     a.csc = em->csc; a.csc_slot0 = em->csc_slot0; a.pub_pos = em->pub_pos; a.alpha_out = em->alpha_out; a.partial = em->partial;
-    a.cov_ptr = em->cov_ptr; a.cov_pos = em->cov_pos; a.unc = em->unc; a.unc_n = em->unc ? em->unc + p.M : nullptr; a.check_mode = em->opts.check_mode;
+    a.cov_ptr = em->cov_ptr; a.cov2 = em->cov2; a.cov_pos = em->cov_pos; a.unc = em->unc; a.unc_n = em->unc ? em->unc + p.M : nullptr; a.check_mode = em->opts.check_mode;
     a.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm; a.M = p.M; a.dbg = em->dbg;
     return a;
 }
@@ -1542,6 +1567,7 @@ static int em_enqueue_sweep(sfgpu_em* em) { Launcher L; L.stream = em->cur; retu
 static int em_enqueue_fused(sfgpu_em* em, Launcher& L, bool first) {
     SweepArgs a = em_sweep_args(em);
     a.par = em->par; a.first = first ? 1u : 0u;
+    if (em->inv) { a.alpha = em->alphaP; a.lenc = em->lencP; a.esc_id = em->esc_pos; }      // (per-transcript arrays in the plan's order)
     void* args[] = {&a};
     const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true, true>)
                                       : reinterpret_cast<const void*>(&k_sweep_lds<false, true, true>);
@@ -1926,21 +1952,31 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         hipLaunchKernelGGL(k_tile_desc, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, em->tile_lo, em->tile_span,
                            em->tile_s0, em->tile_esc0, em->tile_off, em->gather ? em->tile_qb : nullptr, em->tile_np, em->tile_pr, em->td);
         EM_TRY(hipGetLastError());
-        if (em->gather && !em->inv) {
+        if (em->gather) {
             // what the FUSED iteration (k_sweep_lds<.., .., true>) needs besides: two slot-major arrays of window sums, two more escape
-            // accumulators, the wavefronts' maxima, the tiles' overlap tables, the list of transcripts no window holds and the far
-            // members' inline cover slots.  The tables' verdict (flags) is read back behind them without a wait; optimize() looks at it.
+            // accumulators, the wavefronts' maxima, the tiles' overlap tables, the cover lists by position + the list of positions no
+            // window holds, the far members' inline cover slots; for a plan with an order of its own also the far members as positions
+            // and room for alpha / effLen in that order.  The tables' verdict (flags) is read back behind them without a wait;
+            // optimize() looks at it.
             const uint64_t Pn = P ? P : 1;
             EM_TRY(pool_malloc(&em->partial_a, Pn * 8)); EM_TRY(pool_malloc(&em->partial_b, Pn * 8));
             EM_TRY(pool_malloc(&em->aout_b, M * 8)); EM_TRY(pool_malloc(&em->aout_c, M * 8));
             EM_TRY(pool_malloc(&em->tmax, 2ull * nt * (kSweepBlock / kWave) * 8));
-            EM_TRY(pool_malloc(&em->unc, (M + 2) * 4));
+            EM_TRY(pool_malloc(&em->unc, (M + 2) * 4)); EM_TRY(pool_malloc(&em->cov2, M * 8));
             EM_TRY(hipMemsetAsync(em->unc + M, 0, 8, em->cur));
             hipLaunchKernelGGL(k_nb_table, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_lo, em->tile_span,
                                em->tile_off, em->td, em->unc + M + 1);
-            hipLaunchKernelGGL(k_uncovered, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->cov_ptr, em->unc, em->unc + M);
+            hipLaunchKernelGGL(k_cov_by_pos, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->inv, em->cov_ptr, em->cov2, em->unc, em->unc + M);
             EM_TRY(pool_malloc(&em->esc_slots, (E ? E : 1) * 8));
             if (E) hipLaunchKernelGGL(k_esc_slots, dim3(blocks_for(E)), dim3(kEmBlock), 0, em->cur, E, em->esc_id, em->cov_ptr, em->cov_pos, em->esc_slots);
+            if (em->inv) {
+                uint32_t* pos_of = nullptr;
+                EM_TRY(pool_malloc(&pos_of, M * 4)); EM_TRY(pool_malloc(&em->esc_pos, (E ? E : 1) * 4));
+                EM_TRY(pool_malloc(&em->alphaP, M * 8)); EM_TRY(pool_malloc(&em->lencP, M * 8));
+                hipLaunchKernelGGL(k_invert_perm, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->inv, pos_of);
+                if (E) hipLaunchKernelGGL(k_map_u32, dim3(blocks_for(E)), dim3(kEmBlock), 0, em->cur, E, em->esc_id, pos_of, em->esc_pos);
+                pool_free_on(pos_of, em->cur);
+            }
             EM_TRY(hipGetLastError());
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipEventRecord(em->ev_plan, em->cur));
@@ -2201,7 +2237,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     {
         const char* fe = getenv("SFGPU_EM_FUSED");              // (read per run: tests switch it)
         const bool fused_off = fe && atoi(fe) == 0;
-        em->fused = !fused_off && em->gather && !em->inv && em->fused_ok != 0 && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
+        em->fused = !fused_off && em->gather && em->fused_ok != 0 && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
     }
     if (em->fused && em->fused_ok < 0) {
         // the plan's verdict on the fused kernel's tables (sfgpu_em_create queued its read-back behind them; long done by now)
@@ -2210,6 +2246,12 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         if (!em->fused_ok) em->fused = false;                // (the classes are not in canonical order)
     }
     if ((rc = sfgpu_em_init_impl(em))) return rc;
+    if (em->fused && em->inv) {                               // alpha and effLen in the plan's order (the fused kernel's index space)
+        const uint64_t M = em->prob.M;
+        hipLaunchKernelGGL(k_gather_f64, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->alpha, em->inv, em->alphaP);
+        hipLaunchKernelGGL(k_gather_f64, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->lenc, em->inv, em->lencP);
+        SF_CHECK_LAUNCH();
+    }
     int done = 0;
     sfgpu_em_stats st{};
     if (!em->fused) {
@@ -2260,6 +2302,10 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         if (k > 0 && (rc = em_poll_wait(em, (int)((k - 1u) & 1u), use_graph, &done))) return rc;       // the chunk before this one
     }
     SF_HIP(hipEventRecord(em->ev_b, em->cur));
+    if (em->fused && em->inv) {                               // back to the caller's order
+        hipLaunchKernelGGL(k_scatter_f64, dim3(blocks_for(em->prob.M)), dim3(kEmBlock), 0, em->cur, em->prob.M, em->alphaP, em->inv, em->alpha);
+        SF_CHECK_LAUNCH();
+    }
     rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
     if (em->fused && st.n_active == 0) {                                             // :794-798 (see above)
         set_error("It seems that no transcripts are expressed; something is likely wrong!");

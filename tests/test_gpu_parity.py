@@ -688,21 +688,33 @@ def _stacked_window_problem(M=3000, C=60_000, seed=5):
 
 
 @pytest.mark.parametrize("vb", [False, True])
-@pytest.mark.parametrize("shape", ["midsize", "far_members", "stacked_windows"])
+@pytest.mark.parametrize("shape", ["midsize", "far_members", "far_members_renumbered", "shuffled_ids", "stacked_windows"])
 def test_em_fused_iteration_equals_the_two_kernel_loop(sf, gpu, midsize, monkeypatch, vb, shape):
     """round 4: inside optimize() an iteration is ONE kernel (the update of iteration it - 1 runs at the head of sweep it, the window
     sums go from tile to tile through slot-major arrays and the tiles' overlap tables).  Same stop iteration, same statistics and
     the same alpha (the additions are the same in the same order; the far members' atomics and VBEM's leaner psi / exp differ in the
     last bits: 1e-10) as the sweep + k_update loop (SFGPU_EM_FUSED=0) and the
     oracle, on: the midsize problem; a table with far members of every kind -- shared by a neighbourhood, more distinct ones than a
-    tile's accumulator holds, transcripts that are ONLY far members -- kept in the caller's order (SFGPU_EM_NO_RENUMBER: a plan with
-    an order of its own runs the two-kernel loop); and tables whose tiles overlap more than the tables hold (the midsize one too:
-    those tiles go by the cover list)."""
+    tile's accumulator holds, transcripts that are ONLY far members -- in the caller's order (SFGPU_EM_NO_RENUMBER) and as the plan
+    sees fit; the midsize table with its transcripts relabelled at random (the plan gives them an order of its own: the fused kernel's
+    per-transcript arrays live in that order); and tables whose tiles overlap more than the tables hold (the midsize one too: those
+    tiles go by the cover list)."""
     if shape == "midsize":
         m = midsize; eff, rp, ii, cc, R = m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"]
     elif shape == "far_members":
         monkeypatch.setenv("SFGPU_EM_NO_RENUMBER", "1")
         eff, rp, ii, cc, R = _far_member_problem()
+    elif shape == "far_members_renumbered":                  # the plan may give the transcripts an order of its own
+        eff, rp, ii, cc, R = _far_member_problem()
+    elif shape == "shuffled_ids":                            # ... and certainly does here: the midsize table under a random relabelling
+        m = midsize
+        rng = np.random.default_rng(12)
+        perm = rng.permutation(len(m["eff"])).astype(np.uint32)
+        labels = [np.sort(perm[m["ids"][int(a):int(b)]]) for a, b in zip(m["rowptr"][:-1], m["rowptr"][1:])]
+        key = sorted(range(len(labels)), key=lambda i: (int(labels[i][0]), len(labels[i]), labels[i].tobytes()))
+        rp = np.zeros(len(labels) + 1, np.uint64); rp[1:] = np.cumsum([len(labels[i]) for i in key])
+        ii = np.concatenate([labels[i] for i in key]).astype(np.uint32); cc = m["counts"][key]
+        eff = np.empty_like(m["eff"]); eff[perm] = m["eff"]; R = m["R"]
     else:
         eff, rp, ii, cc, R = _stacked_window_problem()
     runs = {}
