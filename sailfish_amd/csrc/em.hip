@@ -1508,7 +1508,10 @@ static int em_fill_opts(sfgpu_em* em, const sfgpu_em_opts* o) {
     SF_REQUIRE(o, SFGPU_ERR_INVALID, "null sfgpu_em_opts");
     SF_REQUIRE(o->tol >= 0.0, SFGPU_ERR_INVALID, "tol must be >= 0");
     em->opts = *o;
-    if (em->opts.iters_per_launch == 0) em->opts.iters_per_launch = 32;
+    if (em->opts.iters_per_launch == 0) {
+        static const uint32_t dflt = []() { const char* e = getenv("SFGPU_EM_CHUNK"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : 32); }();
+        em->opts.iters_per_launch = dflt;                     // (tuning: iterations per graph launch / poll)
+    }
     return SFGPU_OK;
 }
 
