@@ -2185,6 +2185,9 @@ int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_all
     }
     if (poll_every == 0) poll_every = 16;
     em->h_mirror[0] = em->h_mirror[8] = 0ull;
+    // (Iterations past the stop -- up to 2 poll_every of them -- still run their all-reduce.  What it sums then is all zeros: the last
+    //  update zeroed alphaOut, and past the stop the sweep, k_fold and the update return at once, so nothing can grow; finish() and
+    //  the statistics never read alphaOut.  The collective itself is the price of not having the host in the loop.)
     for (uint32_t k = 0; !done; ++k) {                                           // (stop test pipelined as in em_run: every rank sees
         for (uint32_t i = 0; i < poll_every; ++i) {                              //  the same state, iterations past the stop are no-ops)
             if ((rc = sfgpu_em_sweep(em)) || (rc = reduce()) || (rc = sfgpu_em_update(em))) return rc;
