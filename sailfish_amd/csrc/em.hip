@@ -777,6 +777,7 @@ struct SweepArgs {
     double tol; double log_norm; uint64_t M;
     unsigned long long* dbg;                                             // SFGPU_X_STAMP builds: [tile][16] phase time stamps (dev)
     unsigned long long* post;                                            // FUSED, streamed loop: pinned host word, "updates done | ended << 32" at the head of every launch
+    unsigned long long post_tag;                                         // ... | 1 << 33 | the run's number << 34 (the host ignores words of another run)
 };
 #ifdef SFGPU_X_STAMP
 #define SF_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
@@ -845,7 +846,7 @@ k_sweep_lds(SweepArgs a) {
             st->itv[a.par ^ 1u] = it_next; st->it_a = it_next;
             if (!stop) st->notconv3[it_next % 3u] = 0;                        // (the slot of the update the NEXT launch runs)
             // the streamed loop of em_run: the host follows the device through this word of pinned memory (no copy, no post kernel)
-            if (a.post) __hip_atomic_store(a.post, (unsigned long long)it | ((unsigned long long)(stop ? 1u : 0u) << 32) | (1ull << 33), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.post) __hip_atomic_store(a.post, (unsigned long long)it | ((unsigned long long)(stop ? 1u : 0u) << 32) | a.post_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             st->it_b = stop ? kDoneMark : it;
             if (!stop) { st->notconv[it & 1] = 0; st->gated[it & 1] = 0; }
@@ -1469,6 +1470,7 @@ struct sfgpu_em {
     unsigned long long* dbg = nullptr;
     bool fused = false;                                     // this optimize() runs fused launches
     bool streamed = false;                                  // ... one by one, the host a few launches ahead of the device (no graph)
+    uint32_t run_no = 0;                                    // tags the progress words of this optimize()
     uint32_t par = 0;                                       // parity of the next fused launch
     bool graph_fused = false;
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
@@ -1574,7 +1576,7 @@ static int em_enqueue_sweep(sfgpu_em* em) { Launcher L; L.stream = em->cur; retu
 static int em_enqueue_fused(sfgpu_em* em, Launcher& L, bool first) {
     SweepArgs a = em_sweep_args(em);
     a.par = em->par; a.first = first ? 1u : 0u;
-    a.post = em->streamed ? em->h_mirror : nullptr;
+    a.post = em->streamed ? em->h_mirror : nullptr; a.post_tag = (1ull << 33) | ((unsigned long long)(em->run_no & 0xFFFFFu) << 34);
     if (em->inv) { a.alpha = em->alphaP; a.lenc = em->lencP; a.esc_id = em->esc_pos; }      // (per-transcript arrays in the plan's order)
     void* args[] = {&a};
     const void* f = em->opts.use_vbem ? reinterpret_cast<const void*>(&k_sweep_lds<true, true, true>)
@@ -2304,16 +2306,18 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     if (em->streamed) {
         static const uint32_t kAhead = []() { const char* e = getenv("SFGPU_EM_AHEAD"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 256 ? v : 8); }();
         volatile unsigned long long* mir = em->h_mirror;
-        *mir = 0ull;                                          // (nothing of an earlier run is in flight: finish() waited for it)
+        *mir = 0ull;
+        ++em->run_no;                                         // (a word some launch of an earlier, failed run may still write is not this run's)
+        const unsigned long long tag = (1ull << 33) | ((unsigned long long)(em->run_no & 0xFFFFFu) << 34);
         uint32_t launched = 0;
         if ((rc = iteration(true))) return rc;
         ++launched;
         for (uint32_t spins = 0;;) {
             const unsigned long long v = *mir;
-            if ((v >> 32) & 1ull) break;                      // a launch found the loop ended: everything behind it is a no-op
+            const bool any = (v >> 33) == (tag >> 33);
+            if (any && ((v >> 32) & 1ull)) break;             // a launch found the loop ended: everything behind it is a no-op
             // launch n posts n - 1 updates done at its head; with `launched` enqueued, launched - 2 - posted wait behind the running one
-            const uint32_t posted = (v >> 33) ? (uint32_t)v : 0u;
-            const bool any = (v >> 33) != 0ull;
+            const uint32_t posted = any ? (uint32_t)v : 0u;
             const uint32_t queued = any ? (launched >= posted + 2u ? launched - posted - 2u : 0u) : launched;
             if (queued < kAhead) { if ((rc = iteration(false))) return rc; ++launched; spins = 0; }
             else if (++spins > 64u) { std::this_thread::yield(); spins = 0; }
