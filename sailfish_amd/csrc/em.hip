@@ -832,6 +832,8 @@ k_sweep_lds(SweepArgs a) {
                      "s"(td.e[4].x), "s"(td.e[4].y), "s"(td.e[4].z), "s"(td.e[5].x), "s"(td.e[5].y), "s"(td.e[5].z));
         static_assert(kNbMax == 6, "the pin above names six entries");
     }
+    uint32_t n_unc_v = 0;                                  // FUSED: length of the list of positions no window holds (needed at the END: requested here)
+    if constexpr (FUSED) { n_unc_v = *a.unc_n; asm volatile("" :: "s"(n_unc_v)); }
     asm volatile("" :: "s"(s_it_a), "s"(s_itv0), "s"(s_itv1), "s"(s_nc0), "s"(s_nc1), "s"(s_n30), "s"(s_n31), "s"(s_n32));
     const uint32_t it = FUSED ? (a.par ? s_itv1 : s_itv0) : s_it_a;
     bool stop;
@@ -908,7 +910,7 @@ k_sweep_lds(SweepArgs a) {
     // the end of a FUSED launch: the transcripts no window holds, then what the wavefront saw of the convergence test
     auto fused_tail = [&]() {
 #ifndef SFGPU_X_NOUPD
-        const uint32_t n_unc = *a.unc_n;                        // (known on the device only: nothing waits for it at the head)
+        const uint32_t n_unc = n_unc_v;                         // (known on the device only; requested with the descriptors)
         for (uint32_t j = threadIdx.x * gridDim.x + blockIdx.x; j < n_unc; j += kSweepBlock * gridDim.x) {
             const uint32_t t = a.unc[j];
             if (upd) { const double p = rd_aout[t] + (VB ? kPriorAlpha : 0.0); judge(a.alpha[t], p); a.alpha[t] = p; }
@@ -1443,6 +1445,7 @@ struct sfgpu_em {
     uint32_t* counts32 = nullptr;
     uint32_t* inv = nullptr; uint32_t* cperm = nullptr;      // the plan's own transcript / class order (em_renumber), or null
     uint32_t* tile_lo = nullptr; uint32_t* tile_c0 = nullptr; uint32_t* tile_span = nullptr; uint32_t n_tiles = 0;
+    uint32_t tile_nnz = 0;                                  // nonzeros per tile of the plan
     TileDesc* td = nullptr;                                 // the same, one record per tile (what the sweep reads)
     uint64_t* tile_off = nullptr; uint64_t P = 0;          // window slots over all tiles
     double* partial = nullptr;                              // [P] per-tile window sums of one sweep
@@ -1882,7 +1885,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         if (plan_state == 1) log_msg(0, "EM plan: transcripts renumbered by co-occurrence, %llu -> %llu of %u members outside their window",
                                      (unsigned long long)E_first, (unsigned long long)E, rp_end);
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
-        em->P = P; em->E = E;
+        em->P = P; em->E = E; em->tile_nnz = tile_nnz;
         if (getenv("SFGPU_TIMING")) fprintf(stderr, "em plan: %u tiles (%u nnz each), P = %llu window slots (%.2f per transcript), %llu escapes of %llu nonzeros\n",
                                             nt, tile_nnz, (unsigned long long)P, (double)P / (double)M, (unsigned long long)E, (unsigned long long)rp_end);
         EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
@@ -1990,6 +1993,15 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             EM_TRY(hipGetLastError());
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipEventRecord(em->ev_plan, em->cur));
+            if (getenv("SFGPU_TIMING")) {                     // dev: how many tiles go by the cover list, how many neighbours the others have
+                std::vector<TileDesc> h(nt);
+                (void)hipStreamSynchronize(em->cur);
+                (void)hipMemcpy(h.data(), em->td, (size_t)nt * sizeof(TileDesc), hipMemcpyDeviceToHost);
+                uint32_t by_list = 0; uint64_t nb_sum = 0, span_sum = 0;
+                for (const TileDesc& t : h) { if (t.nb_n == kNbByList) ++by_list; else nb_sum += t.nb_n; span_sum += t.span; }
+                fprintf(stderr, "em fused plan: %u of %u tiles by the cover list, %.2f overlapping tiles on average for the others, mean span %.0f\n", by_list, nt,
+                        nt > by_list ? (double)nb_sum / (nt - by_list) : 0.0, (double)span_sum / nt);
+            }
         }
     }
 #undef EM_TRY
@@ -2246,11 +2258,17 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     int rc;
     em->in_optimize = true;
     if ((rc = em_begin_on(em, opts, em->stream))) return rc;
-    // the fused iteration: GATHER plans, EM or VBEM with the constant normaliser (SFGPU_EM_FUSED=0: sweep + k_update as before)
+    // The fused iteration: GATHER plans, EM or VBEM with the constant normaliser.  It pays when the tiles are large: its head adds ~3 us
+    // of dependent round trips to every launch, which a co-resident block's phases hide when those are long, and saves k_update's
+    // launch + one kernel boundary.  Measured (profiles/r4_em_notes.md): 18 000-nonzero tiles (cfg3) - 2.3 us (EM) / - 3.0 (VBEM) per
+    // iteration, 12 900 - 3.1 / - 2.5, 5 300 (cfg2) + 1.25 / + 2.0.  So: fused from kFusedMinTileNnz nonzeros per tile up;
+    // SFGPU_EM_FUSED=1 forces it wherever it can run, =0 keeps sweep + k_update.
     {
+        constexpr uint32_t kFusedMinTileNnz = 9000;
         const char* fe = getenv("SFGPU_EM_FUSED");              // (read per run: tests switch it)
-        const bool fused_off = fe && atoi(fe) == 0;
-        em->fused = !fused_off && em->gather && em->fused_ok != 0 && em->prob.C != 0 && (!em->opts.use_vbem || em->const_norm);
+        const bool fused_off = fe && atoi(fe) == 0, fused_forced = fe && atoi(fe) != 0;
+        em->fused = !fused_off && (fused_forced || em->tile_nnz >= kFusedMinTileNnz) && em->gather && em->fused_ok != 0 && em->prob.C != 0 &&
+                    (!em->opts.use_vbem || em->const_norm);
     }
     if (em->fused && em->fused_ok < 0) {
         // the plan's verdict on the fused kernel's tables (sfgpu_em_create queued its read-back behind them; long done by now)

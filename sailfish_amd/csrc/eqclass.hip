@@ -169,6 +169,9 @@ __device__ __forceinline__ bool labels_equal(const uint32_t* a, const uint32_t* 
 }
 
 }  // namespace sfgpu
+#ifdef SFGPU_X_EQ_STAMP
+namespace sfgpu { __device__ unsigned long long g_eq_stamp[2][2][4096]; }      // dev: [route | insert][start | end][block], 100 MHz clock
+#endif
 #include "eqclass_part.h"
 namespace sfgpu {
 
@@ -709,7 +712,8 @@ static int eq_generic(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_off
 // the stream from above; a bin gets its share of that bound plus 25 % and a constant -- the share is a sum of ~mean / 1.6
 // independent labels, so this is > 6 standard deviations for hashed labels.  A region far above its share (one label holding a
 // large part of the reads) overflows into the generic kernel's list.  Rounded to whole 128-byte lines.
-struct PartGeom { uint32_t n_blocks, tile; uint64_t cap, n_bins; };
+struct PartGeom { uint32_t n_blocks, tile; uint64_t cap, n_bins;
+                  uint32_t tile_hi = 0, tile_lo = 0; };         // two tile sizes (tile_lo = 0: all blocks take `tile`)
 static PartGeom part_geometry(uint32_t cnt, uint64_t n_words, uint32_t n_regions, uint32_t mb) {
     PartGeom g;
     if (mb > 1024u) mb = 1024u;
@@ -718,6 +722,18 @@ static PartGeom part_geometry(uint32_t cnt, uint64_t n_words, uint32_t n_regions
     g.n_bins = (uint64_t)n_regions * g.n_blocks;
     const uint64_t stream_gr = (n_words + 4ull * cnt) / 4 + 1;
     g.cap = (stream_gr + g.n_bins - 1) / g.n_bins;
+    // two tile sizes for a full launch (see RouteArgs::half): the first half of the blocks takes (1000 + skew) / 1000 of the mean
+    g.tile_hi = g.tile; g.tile_lo = 0;
+    // (150: measured on cfg3 -- equal tiles: first half of the blocks done after 441 us, second after 510; 15 % skew: 486 / 491, the launch
+    //  3.4 % shorter, the step 16.59 -> 16.44 ms; cfg2 and the sorted / clustered / long-label probes: no worse.  SFGPU_EQ_SKEW=0: equal tiles)
+    static const uint32_t skew = []() { const char* e = getenv("SFGPU_EQ_SKEW"); long v = e ? atol(e) : 150; return (uint32_t)(v > 0 && v <= 300 ? v : 0); }();
+    if (skew && g.n_blocks == mb && (g.n_blocks & 1u) == 0u && g.n_blocks >= 64u && cnt >= (1u << 20)) {
+        const uint64_t half = g.n_blocks / 2;
+        const uint64_t hi = (((uint64_t)cnt * (1000u + skew) / 1000u + g.n_blocks - 1) / g.n_blocks + 63) & ~63ull;
+        const uint64_t rest = (uint64_t)cnt > half * hi ? (uint64_t)cnt - half * hi : 0;
+        const uint64_t lo = ((rest + half - 1) / half + 63) & ~63ull;
+        if (lo >= 64) { g.tile_hi = (uint32_t)hi; g.tile_lo = (uint32_t)lo; g.cap = g.cap * (1000u + skew) / 1000u + 1; }
+    }
     g.cap = g.cap + g.cap / 4 + 48;
     g.cap = (g.cap + 7) & ~7ull;
     return g;
@@ -923,7 +939,8 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     for (uint32_t g = 0; g < n_groups; ++g) {
         const uint32_t grp_lo = g * grp_n;
         RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
-                     eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode, grp_lo, grp_n};
+                     eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode, grp_lo, grp_n, 0u, 0u};
+        if (!ring && !quad && gm.tile_lo) { ra.tile = gm.tile_hi; ra.tile_lo = gm.tile_lo; ra.half = n_blocks / 2; }
         if (ring) {
             const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
                                      (size_t)kPartWaves * kRingFlushList * 4;
@@ -1184,7 +1201,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
         uint4* bins = reinterpret_cast<uint4*>(S.words.p);
         uint32_t* fill_f = S.hist.p, *fill_b = fill_f + gm.n_bins, *cutmarks = fill_b + gm.n_bins;
         RouteArgs ra{d_ids, d_offsets + first, first, cnt, gm.tile, n_regions - 1u, (uint32_t)gm.cap, bins, fill_f, fill_b, cutmarks,
-                     S.d_ctr + CTR_TMP, S.longl.p, eq->hot_bufs[eq->hot_cur].p, eq->arena.p, eq->table.p, S.d_ctr + CTR_HOT, eq->mix_mode, 0u, n_regions};
+                     S.d_ctr + CTR_TMP, S.longl.p, eq->hot_bufs[eq->hot_cur].p, eq->arena.p, eq->table.p, S.d_ctr + CTR_HOT, eq->mix_mode, 0u, n_regions, 0u, 0u};
         const size_t route_lds = (size_t)2 * n_regions * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
         hipLaunchKernelGGL(k_part_route<kFormDirect>, dim3(gm.n_blocks), dim3(kPartBlock), route_lds, sr, ra);
         SF_CHECK_LAUNCH();
@@ -1528,6 +1545,36 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
     std::lock_guard<std::mutex> lk(eq->mu);
     hipStream_t st = eq->stream;
     int rc;
+#ifdef SFGPU_X_EQ_STAMP
+    {   // dev: how the blocks of the LAST route / insert launch spread (us)
+        (void)hipStreamSynchronize(st);
+        static unsigned long long h[2][2][4096];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sfgpu::g_eq_stamp), sizeof(h)) == hipSuccess) {
+            for (int k = 0; k < 2; ++k) {
+                unsigned long long t0 = ~0ull, t1 = 0; double sum = 0, mx = 0; int n = 0; std::vector<double> d;
+                for (int b = 0; b < 4096; ++b) if (h[k][0][b] && h[k][1][b] > h[k][0][b]) { t0 = std::min(t0, h[k][0][b]); t1 = std::max(t1, h[k][1][b]); }
+                for (int b = 0; b < 4096; ++b) if (h[k][0][b] && h[k][1][b] > h[k][0][b]) { const double x = (double)(h[k][1][b] - h[k][0][b]) * 0.01; d.push_back(x); sum += x; mx = std::max(mx, x); ++n; }
+                if (!n) continue;
+                std::sort(d.begin(), d.end());
+                double late = 0; for (int b = 0; b < 4096; ++b) if (h[k][0][b] && h[k][1][b] > h[k][0][b]) late = std::max(late, (double)(h[k][0][b] - t0) * 0.01);
+                fprintf(stderr, "eq stamps %s: %d blocks, span %.1f us, block mean %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f, last start +%.1f\n", k ? "insert" : "route", n,
+                        (double)(t1 - t0) * 0.01, sum / n, d[n / 10], d[n / 2], d[n * 9 / 10], mx, late);
+                // by block index mod 8 (the XCD a block lands on), by index / 256, and first round (start within 5 us) vs later
+                double m8[8] = {0}, c8[8] = {0}, q[16] = {0}, cq[16] = {0}, r1 = 0, n1 = 0, r2 = 0, n2 = 0;
+                for (int b = 0; b < 4096; ++b) if (h[k][0][b] && h[k][1][b] > h[k][0][b]) {
+                    const double x = (double)(h[k][1][b] - h[k][0][b]) * 0.01;
+                    m8[b & 7] += x; c8[b & 7] += 1; q[b >> 8] += x; cq[b >> 8] += 1;
+                    if ((double)(h[k][0][b] - t0) * 0.01 < 5.0) { r1 += x; n1 += 1; } else { r2 += x; n2 += 1; }
+                }
+                fprintf(stderr, "   by index mod 8:");
+                for (int i = 0; i < 8; ++i) fprintf(stderr, " %.1f", c8[i] ? m8[i] / c8[i] : 0.0);
+                fprintf(stderr, " | by index / 256:");
+                for (int i = 0; i < 16; ++i) if (cq[i]) fprintf(stderr, " %.1f", q[i] / cq[i]);
+                fprintf(stderr, " | first round %.1f (%d blocks), later %.1f (%d)\n", n1 ? r1 / n1 : 0.0, (int)n1, n2 ? r2 / n2 : 0.0, (int)n2);
+            }
+        }
+    }
+#endif
     if ((rc = eq_flush_acc_locked(eq))) return rc;          // reads still waiting in the host accumulation buffer
     if ((rc = eq_flush_dacc_locked(eq))) return rc;         // ... and in the device one
     uint64_t n = eq->n_classes;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sailfish_amd as sf
 from sailfish_amd import synth
 dev = torch.device("cuda:0")
-M, P, R = 200_000, 4_000_000, 400_000_000
+M, P, R = (int(os.environ.get(k, d)) for k, d in (('EMP_M', 200_000), ('EMP_P', 4_000_000), ('EMP_R', 400_000_000)))      # (cfg2: 80000 / 1000000 / 50000000)
 ref_len = synth.transcript_lengths(M, device=dev)
 poff, pids = synth.label_pool(M, P, device=dev)
 ids, off = synth.reads_slice(poff, pids, 0, R, seed=7, device=dev)

@@ -58,6 +58,9 @@ while time.time() < t_end:
     # round 4: the fused iteration runs on plans in the caller's order -- keep that order for half of the cases that would be renumbered
     if rng.random() < 0.5: os.environ["SFGPU_EM_NO_RENUMBER"] = "1"
     else: os.environ.pop("SFGPU_EM_NO_RENUMBER", None)
+    # ... and it is chosen only for plans with large tiles: force it for two thirds of the cases
+    if rng.random() < 0.67: os.environ["SFGPU_EM_FUSED"] = "1"
+    else: os.environ.pop("SFGPU_EM_FUSED", None)
     p = sf.EMProblem(torch.from_numpy(eff).to(dev), t(rp.astype(np.uint32), np.int32), t(ids, np.int32), t(cnt, np.int64), N)
     grc, st = p.optimize(use_vbem=vb, tol=0.0, min_iter=iters, max_iter=iters)
     ga = p.alpha.cpu().numpy()
