@@ -732,6 +732,9 @@ k_part_insert(PartArgs a) {
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_eq_stamp[1][0][blockIdx.x] = wall_clock64();
     struct StampEnd { __device__ ~StampEnd() { if (threadIdx.x == 0 && blockIdx.x < 4096) g_eq_stamp[1][1][blockIdx.x] = wall_clock64(); } } stamp_end;
 #endif
+#ifdef SFGPU_X_INS_DELAY                 // experiment: the second block of every CU starts SFGPU_X_INS_DELAY us late (is the first round slow because both start in step?)
+    if (blockIdx.x >= 256u && blockIdx.x < 512u) { const unsigned long long t0d = wall_clock64(); while (wall_clock64() - t0d < (unsigned long long)(SFGPU_X_INS_DELAY) * 100ull) __builtin_amdgcn_s_sleep(8); }
+#endif
     __shared__ unsigned int slot32[kRegionSlots];
     __shared__ __attribute__((aligned(16))) uint4 chead[kMaxRegionClasses];
     __shared__ unsigned int ccnt[kMaxRegionClasses];
