@@ -23,6 +23,7 @@ inline hipStream_t as_stream(sfgpu_stream s) { return reinterpret_cast<hipStream
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p);
 void pool_free_on(void* p, hipStream_t s);     // back to the cache once the work enqueued on s so far is done (no host wait)
+void pool_free_on_many(void* const* ps, int n, hipStream_t s);      // ... several blocks behind ONE event (null entries are skipped)
 void pool_trim();
 void pool_set_large_limit(long long bytes);     // cached device blocks >= 1 GiB are kept up to this many bytes per device
 template <typename T>

@@ -70,14 +70,16 @@ size_t large_limit_locked() {
     return (size_t)g_large_limit;
 }
 
-struct Pending { void* p; hipEvent_t ev; };
+struct Pending { void* p; hipEvent_t ev; bool owns; };      // (blocks freed together share an event; the last one of them gives it back)
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_events;
 void reap_pending_locked(bool wait) {
     size_t keep = 0;
+    hipEvent_t seen = nullptr; hipError_t seen_q = hipSuccess;
     for (size_t i = 0; i < g_pending.size(); ++i) {
         Pending& x = g_pending[i];
-        hipError_t q = wait ? hipEventSynchronize(x.ev) : hipEventQuery(x.ev);
+        hipError_t q = (x.ev == seen) ? seen_q : (wait ? hipEventSynchronize(x.ev) : hipEventQuery(x.ev));
+        seen = x.ev; seen_q = q;
         if (q == hipErrorNotReady) { g_pending[keep++] = x; continue; }
         (void)hipGetLastError();
         auto it = g_pool_key.find(x.p);
@@ -88,7 +90,7 @@ void reap_pending_locked(bool wait) {
             if (it->second.kind == kDeviceMem && it->second.sz >= kLargeBlock) g_large_cached[it->second.dev] += it->second.sz;
             g_pool_free[it->second].push_back(x.p);
         }
-        g_events.push_back(x.ev);
+        if (x.owns) g_events.push_back(x.ev);
     }
     g_pending.resize(keep);
 }
@@ -97,12 +99,17 @@ hipError_t pool_get(void** p, size_t bytes, int kind) {
     const Key key{cur_device(), kind, round_up_pow2(bytes ? bytes : 1)};
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (!g_pending.empty()) reap_pending_locked(false);
-        auto it = g_pool_free.find(key);
-        if (it != g_pool_free.end() && !it->second.empty()) {
-            *p = it->second.back(); it->second.pop_back();
-            if (kind == kDeviceMem && key.sz >= kLargeBlock) g_large_cached[key.dev] -= key.sz;
-            return hipSuccess;
+        // (blocks freed stream-ordered are looked for only when the cache has none of this size, or when many are waiting: a query
+        //  per waiting block in front of EVERY allocation was hundreds of event queries per plan)
+        for (int pass = 0; pass < 2; ++pass) {
+            auto it = g_pool_free.find(key);
+            if (it != g_pool_free.end() && !it->second.empty()) {
+                *p = it->second.back(); it->second.pop_back();
+                if (kind == kDeviceMem && key.sz >= kLargeBlock) g_large_cached[key.dev] -= key.sz;
+                if (pass == 0 && g_pending.size() > 64) reap_pending_locked(false);
+                return hipSuccess;
+            }
+            if (pass == 0) { if (g_pending.empty()) break; reap_pending_locked(false); }
         }
     }
     void* q = nullptr;
@@ -135,18 +142,22 @@ void pool_put(void* p, int kind) {
 // Stream-ordered free: the block goes back to the cache once the work enqueued on `s` so far has completed (an event is
 // recorded now and polled when the allocator next runs) -- callers that would otherwise synchronise just to free a scratch
 // buffer (the rocPRIM wrappers: ~25 us of idle GPU each time) use this.
-void pool_free_on(void* p, hipStream_t s) {
-    if (!p) return;
+void pool_free_on_many(void* const* ps, int n, hipStream_t s) {
+    int live = 0;
+    for (int i = 0; i < n; ++i) if (ps[i]) ++live;
+    if (!live) return;
     hipEvent_t ev = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (!g_events.empty()) { ev = g_events.back(); g_events.pop_back(); }
     }
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamSynchronize(s); pool_free(p); return; }
-    if (hipEventRecord(ev, s) != hipSuccess) { (void)hipStreamSynchronize(s); pool_free(p); std::lock_guard<std::mutex> lk(g_pool_mu); g_events.push_back(ev); return; }
+    auto fallback = [&]() { (void)hipStreamSynchronize(s); for (int i = 0; i < n; ++i) if (ps[i]) pool_free(ps[i]); };
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { fallback(); return; }
+    if (hipEventRecord(ev, s) != hipSuccess) { fallback(); std::lock_guard<std::mutex> lk(g_pool_mu); g_events.push_back(ev); return; }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pending.push_back({p, ev});
+    for (int i = 0; i < n; ++i) if (ps[i]) g_pending.push_back({ps[i], ev, --live == 0});
 }
+void pool_free_on(void* p, hipStream_t s) { pool_free_on_many(&p, 1, s); }
 
 hipError_t pool_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kDeviceMem); }
 void pool_free(void* p) { pool_put(p, kDeviceMem); }

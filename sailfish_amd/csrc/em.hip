@@ -1862,7 +1862,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             if (nt > nt_cap) { nt = nt_small; tile_nnz = kTileNnz; }
             em->n_tiles = nt;
         }
-        pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur);
+        { void* ps[2] = {t_len8, t_nesc}; pool_free_on_many(ps, 2, em->cur); }
         P = em->h_plan[1]; S = em->h_plan[2]; E = em->h_plan[3];
         // Many members outside their tile's window (an index whose isoforms are not adjacent): let the plan order the transcripts
         // itself, and keep that order if it removes at least 40 % of the escapes.
@@ -1908,7 +1908,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             uint64_t *cb = nullptr, *ps = nullptr;
             struct Scratch {                                  // the plan's temporaries go back to the pool on every way out
                 void** slots[8]; hipStream_t st;
-                ~Scratch() { for (void** q : slots) if (*q) pool_free_on(*q, st); }
+                ~Scratch() { void* ps[8]; for (int i = 0; i < 8; ++i) ps[i] = *slots[i]; pool_free_on_many(ps, 8, st); }
             } scratch{{(void**)&tmp, (void**)&kv, (void**)&idx, (void**)&tin, (void**)&chunks, (void**)&pure, (void**)&cb, (void**)&ps}, em->cur};
             EM_TRY(pool_malloc(&em->chdr, (S / 8 + 1) * 4));
             // G: the number of chunks is only known on the device (cb[nt]); its bound -- every tile ends in a partial chunk --
@@ -1956,7 +1956,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, em->cov_ptr);
             }
             // (no host wait: the scratch goes back to the pool when the stream has passed this point)
-            pool_free_on(k_in, em->cur); pool_free_on(k_out, em->cur); pool_free_on(v_in, em->cur);
+            { void* ps[3] = {k_in, k_out, v_in}; pool_free_on_many(ps, 3, em->cur); }
             if (src) { em_free(em); return src; }
         } else {
             EM_TRY(hipMemsetAsync(em->cov_ptr, 0, ((size_t)M + 1) * 4, em->cur));
