@@ -326,20 +326,37 @@ __global__ void k_rehash(const uint64_t* __restrict__ old_table, uint64_t* table
 // radix passes instead of the eight of (first id << 32 | hash >> 32); classes that share a key (same first id, same 14 bits:
 // a few per thousand) are put into (hash, length, label) order by k_tie_fix.  max_first: the largest first id (sizes the sort).
 constexpr int kSortHashBits = 14;
+// The same pass adds up the classes' counts (total reads: one more scattered read per class next to the arena's, instead of a
+// pass of its own over the table later).
 __global__ void k_sort_keys(uint64_t n, const uint64_t* __restrict__ cls_hash, const uint64_t* __restrict__ cls_off,
-                            const uint32_t* __restrict__ arena, uint64_t* keys, uint32_t* vals, unsigned long long* max_first) {
+                            const uint32_t* __restrict__ arena, uint64_t* keys, uint32_t* vals, unsigned long long* max_first,
+                            const uint64_t* __restrict__ table, const uint32_t* __restrict__ cls_slot, unsigned long long* total) {
     // grid-stride over a capped grid: at most one atomic per wavefront of a few thousand blocks, not one per 64 classes (25 k atomics
     // on one address took 250 us)
     uint32_t mx = 0;
+    unsigned long long sum = 0;
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t first = arena[cls_off[c]];
+        const unsigned long long cnt = table[2 * (uint64_t)cls_slot[c] + 1];
         keys[c] = ((uint64_t)first << kSortHashBits) | (cls_hash[c] >> (64 - kSortHashBits));
         vals[c] = (uint32_t)c;
         mx = first > mx ? first : mx;
+        sum += cnt;
     }
-    for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t v = __shfl_down(mx, o, kWave); mx = v > mx ? v : mx; }
-    if ((threadIdx.x & (kWave - 1)) == 0 && (unsigned long long)mx > __hip_atomic_load(max_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(max_first, (unsigned long long)mx);       // (looks first: the running maximum is soon above most wavefronts')
+    for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t v = __shfl_down(mx, o, kWave); mx = v > mx ? v : mx; sum += __shfl_down(sum, o, kWave); }
+    // one atomic per BLOCK for the sum (every block has one to add: thousands of same-address atomics are served one after the other)
+    __shared__ unsigned long long wsum[kBlock / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if ((unsigned long long)mx > __hip_atomic_load(max_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(max_first, (unsigned long long)mx);   // (looks first: the running maximum is soon above most wavefronts')
+        wsum[threadIdx.x / kWave] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < kBlock / kWave; ++i) t += wsum[i];
+        if (t) atomicAdd(total, t);
+    }
 }
 
 __device__ bool class_less(uint32_t a, uint32_t b, const uint64_t* cls_hash, const uint64_t* cls_off,
@@ -1585,12 +1602,14 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
         DevBuf<uint64_t> keys_in, keys_out; DevBuf<uint32_t> vals_in, lens;
         if ((rc = keys_in.reserve(n, st, false)) || (rc = keys_out.reserve(n, st, false)) ||
             (rc = vals_in.reserve(n, st, false)) || (rc = lens.reserve(n + 1, st, false))) return rc;
-        SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n) < 4096 ? grid_for(n) : 4096), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
-                           eq->arena.p, keys_in.p, vals_in.p, eq->d_ctr + 3);
+        SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, 2 * sizeof(unsigned long long), st));           // (max first id, total reads: slots 3 and 4 = CTR_TMP + 1)
+        static_assert(CTR_N >= 5, "finish() uses counter slots 3 and 4");
+        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kBlock), 0, st, n, eq->cls_hash.p, eq->cls_off.p,
+                           eq->arena.p, keys_in.p, vals_in.p, eq->d_ctr + 3, eq->table.p, eq->cls_slot.p, eq->d_ctr + 4);
         SF_CHECK_LAUNCH();
-        SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));                       // (~15 us; each radix pass it saves costs ~35)
+        eq->total_reads = eq->h_ctr[4];
         int key_bits = kSortHashBits + 1;
         while (key_bits < 64 && (eq->h_ctr[3] >> (key_bits - kSortHashBits)) != 0) ++key_bits;
         // (no host wait inside the sort and the scan: everything they touch lives until the synchronisation below)
@@ -1601,14 +1620,8 @@ int sfgpu_eq_finish(sfgpu_eq* eq, uint64_t* n_classes, uint64_t* nnz, uint64_t* 
         hipLaunchKernelGGL(k_sorted_lens, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, n, eq->order.p, eq->cls_len.p, lens.p);
         SF_CHECK_LAUNCH();
         if ((rc = exclusive_scan_u32(lens.p, eq->rowptr64.p, n, st, false))) return rc;
-        SF_HIP(hipMemsetAsync(eq->d_ctr + 3, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(n) < 512 ? grid_for(n) : 512), dim3(kBlock), 0, st, n, eq->table.p, eq->cls_slot.p,
-                           eq->d_ctr + 3);
-        SF_CHECK_LAUNCH();
-        SF_HIP(hipMemcpyAsync(eq->h_ctr + 3, eq->d_ctr + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SF_HIP(hipMemcpyAsync(eq->h_ctr + CTR_NNZ, eq->rowptr64.p + n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));
-        eq->total_reads = eq->h_ctr[3];
         eq->nnz = eq->h_ctr[CTR_NNZ];
     }
     eq->finished = true;
