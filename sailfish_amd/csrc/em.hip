@@ -622,6 +622,46 @@ __global__ void k_scatter_f64(uint64_t M, const double* __restrict__ in, const u
     if (pos < M) out[inv[pos]] = in[pos];
 }
 
+// ---- the cover lists WITHOUT a sort (round 4).  A window is an interval of positions and, when the tiles' `lo` never decreases (the
+// canonical class order: checked by k_tile_mono, read back with the plan's sizes), the tiles that hold a position are found by walking
+// back from a tile until a window that starts kWin or more positions earlier: the rank of tile T in the list of position lo_T + d is
+// the number of earlier tiles whose window reaches it.  Counts per transcript by atomics, a scan, and every slot writes itself into
+// its place: the lists come out in tile order, exactly as the stable sort by transcript leaves them (5 small kernels against the
+// ~20 of a merge sort of 283 k pairs: ~0.1 ms of cfg3's plan).
+__global__ void k_tile_mono(uint32_t n_tiles, const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span, unsigned int* flag) {
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= n_tiles || T == 0 || !tile_span[T]) return;
+    for (uint32_t U = T; U-- > 0;) {
+        if (!tile_span[U]) continue;                          // (empty tiles carry no window)
+        if (tile_lo[U] > tile_lo[T]) atomicOr(flag, 1u);
+        break;
+    }
+}
+__global__ void __launch_bounds__(kEmBlock)
+k_cov_count(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span, const uint32_t* __restrict__ inv, uint32_t* cnt) {
+    const uint32_t lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
+    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) atomicAdd(&cnt[inv ? inv[lo + d] : lo + d], 1u);
+}
+__global__ void __launch_bounds__(kEmBlock)
+k_cov_fill(const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span, const uint64_t* __restrict__ tile_off,
+           const uint32_t* __restrict__ inv, const uint32_t* __restrict__ cov_ptr, uint32_t* cov_pos, uint32_t* pub_pos) {
+    const uint32_t T = blockIdx.x, lo = tile_lo[T], span = tile_span[T];
+    const uint64_t off = tile_off[T];
+    for (uint32_t d = threadIdx.x; d < span; d += kEmBlock) {
+        const uint32_t pos = lo + d;
+        uint32_t rank = 0;
+        for (uint32_t U = T; U-- > 0;) {                      // (the same walk for every thread of the tile: uniform loads)
+            const uint32_t sl = tile_span[U], ll = tile_lo[U];
+            if (!sl) continue;
+            if ((uint64_t)ll + kWin <= lo) break;             // no earlier window reaches this tile's
+            if ((uint64_t)ll + sl > pos) ++rank;
+        }
+        const uint32_t k = cov_ptr[inv ? inv[pos] : pos] + rank;
+        cov_pos[k] = (uint32_t)(off + d);
+        pub_pos[off + d] = k;
+    }
+}
+
 // cov_pos[k] = window slot that sorts to position k  ->  pub_pos[slot] = k
 __global__ void k_invert_perm(uint64_t P, const uint32_t* __restrict__ cov_pos, uint32_t* pub_pos) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1819,6 +1859,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         uint64_t E_first = 0;
         const uint64_t rounds0 = rounds; const uint32_t tile_nnz0 = tile_nnz, nt0 = nt;
         uint64_t P = 0, S = 0, E = 0;
+        bool lo_monotone = false;                            // the tiles' `lo` never decreases (k_tile_mono): the cover lists need no sort
         pool_free(em->tile_lo); em->tile_lo = nullptr;
         EM_TRY(pool_malloc(&em->tile_lo, (size_t)nt_cap * 4));
         EM_TRY(pool_malloc(&em->tile_span, ((size_t)nt_cap + 1) * 4));
@@ -1838,10 +1879,11 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         for (;;) {
             hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
                                p_rowptr, em->tile_c0);
-            EM_TRY(hipMemsetAsync(d_most, 0, 4, em->cur));
+            EM_TRY(hipMemsetAsync(d_most, 0, 8, em->cur));      // (the largest class count of a tile; 1 = some `lo` decreases)
             hipLaunchKernelGGL(k_tile_most, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, d_most);
             hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
                                em->tile_lo, em->tile_span, t_len8, t_nesc);
+            hipLaunchKernelGGL(k_tile_mono, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_lo, em->tile_span, d_most + 1);
             EM_TRY(hipGetLastError());
             // (no host wait inside the scans: the totals are read back with one synchronisation below)
             int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur, false);
@@ -1851,9 +1893,10 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             EM_TRY(hipMemcpyAsync(em->h_plan + 1, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipMemcpyAsync(em->h_plan + 2, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipMemcpyAsync(em->h_plan + 3, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-            EM_TRY(hipMemcpyAsync(em->h_plan + 5, d_most, 4, hipMemcpyDeviceToHost, em->cur));
+            EM_TRY(hipMemcpyAsync(em->h_plan + 5, d_most, 8, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipStreamSynchronize(em->cur));
             const uint32_t most = *reinterpret_cast<const uint32_t*>(em->h_plan + 5);
+            lo_monotone = reinterpret_cast<const uint32_t*>(em->h_plan + 5)[1] == 0u;
             if (tile_nnz <= (uint32_t)kTileNnz || most <= (uint32_t)kTileNnz) break;
             ++rounds;
             tile_nnz = tile_for(rounds);
@@ -1944,7 +1987,34 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&em->cov_pos, (P ? P : 1) * 4));
         EM_TRY(pool_malloc(&em->pub_pos, (P ? P : 1) * 4));
         EM_TRY(hipMemsetAsync(em->partial, 0, (P ? P : 1) * 8, em->cur));
-        if (P) {
+        const bool cover_by_sort = getenv("SFGPU_EM_COVER_SORT") != nullptr;             // (dev / tests: the sort form whatever the plan)
+        if (P && lo_monotone && !cover_by_sort) {
+            uint32_t* cnt = nullptr;
+            EM_TRY(pool_malloc(&cnt, ((size_t)M + 2) * 4));
+            EM_TRY(hipMemsetAsync(cnt, 0, ((size_t)M + 2) * 4, em->cur));
+            hipLaunchKernelGGL(k_cov_count, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->inv, cnt);
+            int cs = exclusive_scan_u32_u32(cnt, em->cov_ptr, M, em->cur);
+            if (!cs) hipLaunchKernelGGL(k_cov_fill, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off, em->inv, em->cov_ptr,
+                                        em->cov_pos, em->pub_pos);
+            pool_free_on(cnt, em->cur);
+            if (cs) { em_free(em); return cs; }
+            if (getenv("SFGPU_EM_COVER_CHECK")) {
+                // dev / tests: the sorted form next to it, compared word for word on the host
+                uint64_t *k_in = nullptr, *k_out = nullptr; uint32_t *v_in = nullptr, *pos2 = nullptr, *ptr2 = nullptr;
+                EM_TRY(pool_malloc(&k_in, P * 8)); EM_TRY(pool_malloc(&k_out, P * 8)); EM_TRY(pool_malloc(&v_in, P * 4));
+                EM_TRY(pool_malloc(&pos2, P * 4)); EM_TRY(pool_malloc(&ptr2, ((size_t)M + 1) * 4));
+                hipLaunchKernelGGL(k_cover_pairs, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off, k_in, v_in, em->inv);
+                int bits = 1; while (bits < 32 && (1ull << bits) <= M) ++bits;
+                int src = sort_pairs_u64_u32(k_in, k_out, v_in, pos2, P, em->cur, bits, true);
+                if (!src) hipLaunchKernelGGL(k_cover_ptr, dim3(blocks_for(M + 1)), dim3(kEmBlock), 0, em->cur, M, P, k_out, ptr2);
+                std::vector<uint32_t> a(P), b(P), c((size_t)M + 1), d((size_t)M + 1);
+                (void)hipStreamSynchronize(em->cur);
+                (void)hipMemcpy(a.data(), em->cov_pos, P * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), pos2, P * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(c.data(), em->cov_ptr, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(d.data(), ptr2, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost);
+                pool_free(k_in); pool_free(k_out); pool_free(v_in); pool_free(pos2); pool_free(ptr2);
+                if (src || a != b || c != d) { set_error("sfgpu_em_create: the cover lists built without a sort differ from the sorted ones"); em_free(em); return SFGPU_ERR_STATE; }
+            }
+        } else if (P) {
             uint64_t *k_in = nullptr, *k_out = nullptr; uint32_t* v_in = nullptr;
             EM_TRY(pool_malloc(&k_in, P * 8)); EM_TRY(pool_malloc(&k_out, P * 8)); EM_TRY(pool_malloc(&v_in, P * 4));
             hipLaunchKernelGGL(k_cover_pairs, dim3(nt), dim3(kEmBlock), 0, em->cur, em->tile_lo, em->tile_span, em->tile_off,

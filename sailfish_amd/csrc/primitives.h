@@ -16,4 +16,7 @@ int sort_pairs_u64_u32(const uint64_t* d_keys_in, uint64_t* d_keys_out, const ui
 // out[i] = sum_{j<i} in[j] for i in [0, n]; out has n+1 entries (out[n] = total).  sync as above.
 int exclusive_scan_u32(const uint32_t* d_in, uint64_t* d_out, uint64_t n, hipStream_t s, bool sync = true);
 
+// the same with 32-bit sums (the caller knows the total fits), nothing waited for
+int exclusive_scan_u32_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s);
+
 }  // namespace sfgpu

@@ -44,4 +44,15 @@ int exclusive_scan_u32(const uint32_t* d_in, uint64_t* d_out, uint64_t n, hipStr
     return SFGPU_OK;
 }
 
+int exclusive_scan_u32_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s) {
+    size_t tmp_bytes = 0;
+    SF_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, d_in, d_out, (uint32_t)0, (size_t)(n + 1), rocprim::plus<uint32_t>(), s));
+    void* tmp = nullptr;
+    SF_HIP(pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, d_in, d_out, (uint32_t)0, (size_t)(n + 1), rocprim::plus<uint32_t>(), s);
+    pool_free_on(tmp, s);
+    SF_HIP(e);
+    return SFGPU_OK;
+}
+
 }  // namespace sfgpu

@@ -740,6 +740,38 @@ def test_em_fused_iteration_equals_the_two_kernel_loop(sf, gpu, midsize, monkeyp
     assert rc == 0 and st["iters"] == ost["iters"] and st["converged"] == ost["converged"] and _rel(a, oa) < TIGHT
 
 
+def test_em_cover_lists_without_a_sort_equal_the_sorted_ones(sf, gpu, midsize, monkeypatch):
+    """round 4: when the tiles' first positions never decrease (every table in canonical order) the plan builds the cover lists --
+    which tiles hold a transcript, in tile order -- by counting and ranking instead of sorting (window slot, transcript) pairs.  The
+    lists are the same lists: SFGPU_EM_COVER_CHECK makes the plan build both and compare them word for word (sfgpu_em_create fails
+    if they differ); and the two-kernel loop, whose fold walks them, gives the same alpha either way.  Shapes: the midsize table, the
+    same with its transcripts relabelled at random (a plan with an order of its own), a table with far members of every kind, one
+    whose tiles crowd one window."""
+    m = midsize
+    rng = np.random.default_rng(12)
+    perm = rng.permutation(len(m["eff"])).astype(np.uint32)
+    labels = [np.sort(perm[m["ids"][int(a):int(b)]]) for a, b in zip(m["rowptr"][:-1], m["rowptr"][1:])]
+    key = sorted(range(len(labels)), key=lambda i: (int(labels[i][0]), len(labels[i]), labels[i].tobytes()))
+    rp2 = np.zeros(len(labels) + 1, np.uint64); rp2[1:] = np.cumsum([len(labels[i]) for i in key])
+    ii2 = np.concatenate([labels[i] for i in key]).astype(np.uint32); cc2 = m["counts"][key]
+    eff2 = np.empty_like(m["eff"]); eff2[perm] = m["eff"]
+    cases = [("midsize", (m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"]), True),
+             ("shuffled", (eff2, rp2, ii2, cc2, m["R"]), False),
+             ("far", _far_member_problem(), False), ("stacked", _stacked_window_problem(), False)]
+    monkeypatch.setenv("SFGPU_EM_FUSED", "0")
+    monkeypatch.setenv("SFGPU_EM_COVER_CHECK", "1")
+    for name, (eff, rp, ii, cc, R), exact in cases:
+        got = {}
+        for sort in (False, True):
+            if sort: monkeypatch.setenv("SFGPU_EM_COVER_SORT", "1")
+            else: monkeypatch.delenv("SFGPU_EM_COVER_SORT", raising=False)
+            p = _gpu_em(sf, gpu, eff, rp, ii, cc, R)
+            grc, st = p.optimize(use_vbem=False, tol=0.0, min_iter=0, max_iter=25)
+            assert grc == 0 and st["iters"] == 25
+            got[sort] = p.alpha.cpu().numpy().copy()
+        assert _rel(got[False], got[True]) < 1e-12, name
+
+
 @pytest.mark.parametrize("vb", [False, True])
 def test_em_to_convergence_matches_stop_iteration(sf, gpu, midsize, vb):
     m = midsize
