@@ -302,9 +302,62 @@ static_assert(kTileNnz < (1 << 13) && kWin < (1 << 16), "stream word: 13-bit cla
 static_assert(kTileNnz <= 8191, "class index field is 13 bits");
 static_assert(kEscSlots == 128, "the escape accumulator's hash takes 7 bits");
 
-__global__ void k_tile_most(uint32_t n_tiles, const uint32_t* __restrict__ tile_c0, unsigned int* most) {
-    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
-    if (T < n_tiles) atomicMax(most, tile_c0[T + 1] - tile_c0[T]);
+// what the host wants to know about a plan before it goes on: the largest class count of a tile (checks[0]) and whether some tile's
+// first position lies before that of the tile in front of it (checks[1] = 1: the cover lists then need a sort, see k_cov_fill); the
+// three scans over the tiles (window slots, stream words, escapes) by ONE block; and all of it posted into pinned host memory by
+// the same kernel (four copy commands and three device-wide scans of 513 numbers before: ~45 us of a plan)
+__global__ void __launch_bounds__(1024)
+k_tile_scans(uint32_t n_tiles, const uint32_t* __restrict__ tile_c0, const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ span,
+             const uint32_t* __restrict__ len8, const uint32_t* __restrict__ nesc, uint64_t* off, uint64_t* s0, uint64_t* esc0,
+             unsigned long long* host) {
+    __shared__ unsigned long long wsum[3][16];
+    __shared__ unsigned long long carry[3];
+    __shared__ unsigned int most_s, mono_s;
+    if (threadIdx.x < 3) carry[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) { most_s = 0u; mono_s = 0u; }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned int most = 0u, mono = 0u;
+    for (uint32_t base = 0; base <= n_tiles; base += 1024u) {           // (entry n_tiles holds the totals: the inputs' sentinels there are 0)
+        const uint32_t i = base + threadIdx.x;
+        const bool in = i < n_tiles;
+        unsigned long long v[3] = {in ? span[i] : 0u, in ? len8[i] : 0u, in ? nesc[i] : 0u};
+        if (in) {
+            const uint32_t nc = tile_c0[i + 1] - tile_c0[i];
+            most = nc > most ? nc : most;
+            if (i > 0 && span[i]) for (uint32_t U = i; U-- > 0;) { if (!span[U]) continue; if (tile_lo[U] > tile_lo[i]) mono = 1u; break; }
+        }
+        unsigned long long inc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned long long x = v[k];
+            for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(x, o, 64); if ((int)lane >= o) x += y; }
+            inc[k] = x;
+            if (lane == 63u) wsum[k][wave] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned long long pre = carry[k];
+            for (uint32_t w = 0; w < wave; ++w) pre += wsum[k][w];
+            const unsigned long long ex = pre + inc[k] - v[k];
+            uint64_t* out = k == 0 ? off : (k == 1 ? s0 : esc0);
+            if (i <= n_tiles) out[i] = ex;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023u) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { unsigned long long t = carry[k]; for (int w = 0; w < 16; ++w) t += wsum[k][w]; carry[k] = t; }
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned int m = __shfl_down(most, o, 64); most = m > most ? m : most; mono |= __shfl_down(mono, o, 64); }
+    if (lane == 0) { atomicMax(&most_s, most); if (mono) mono_s = 1u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host[1] = carry[0]; host[2] = carry[1]; host[3] = carry[2];   // P, S, E (window slots, stream words, escapes)
+        host[5] = (unsigned long long)most_s | ((unsigned long long)mono_s << 32);
+    }
 }
 
 // tile i = classes [tile_c0[i], tile_c0[i+1]) : those with rowptr[c] in [i*tile_nnz, (i+1)*tile_nnz)
@@ -1875,25 +1928,15 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         EM_TRY(pool_malloc(&t_len8, ((size_t)nt_cap + 1) * 4)); EM_TRY(pool_malloc(&t_nesc, ((size_t)nt_cap + 1) * 4));
         // (the check of the tiles' class counts rides on the read-back of the plan's sizes: the window pass and the scans below run on a
         //  plan that may have to be redone with one more round -- rare, and harmless: they do not depend on the class counts)
-        unsigned int* d_most = reinterpret_cast<unsigned int*>(em->partials) + 4;
         for (;;) {
             hipLaunchKernelGGL(k_tile_plan, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, C, nt, tile_nnz,
                                p_rowptr, em->tile_c0);
-            EM_TRY(hipMemsetAsync(d_most, 0, 8, em->cur));      // (the largest class count of a tile; 1 = some `lo` decreases)
-            hipLaunchKernelGGL(k_tile_most, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, d_most);
             hipLaunchKernelGGL(k_tile_window, dim3(nt), dim3(kEmBlock), 0, em->cur, p_rowptr, p_ids, em->tile_c0,
                                em->tile_lo, em->tile_span, t_len8, t_nesc);
-            hipLaunchKernelGGL(k_tile_mono, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_lo, em->tile_span, d_most + 1);
+            // (one block: the three scans over the tiles, the plan's checks, and everything the host reads posted into pinned memory)
+            hipLaunchKernelGGL(k_tile_scans, dim3(1), dim3(1024), 0, em->cur, nt, em->tile_c0, em->tile_lo, em->tile_span, t_len8, t_nesc,
+                               em->tile_off, em->tile_s0, em->tile_esc0, em->h_plan);
             EM_TRY(hipGetLastError());
-            // (no host wait inside the scans: the totals are read back with one synchronisation below)
-            int sr = exclusive_scan_u32(em->tile_span, em->tile_off, nt, em->cur, false);
-            if (!sr) sr = exclusive_scan_u32(t_len8, em->tile_s0, nt, em->cur, false);
-            if (!sr) sr = exclusive_scan_u32(t_nesc, em->tile_esc0, nt, em->cur, false);
-            if (sr) { pool_free_on(t_len8, em->cur); pool_free_on(t_nesc, em->cur); em_free(em); return sr; }
-            EM_TRY(hipMemcpyAsync(em->h_plan + 1, em->tile_off + nt, 8, hipMemcpyDeviceToHost, em->cur));
-            EM_TRY(hipMemcpyAsync(em->h_plan + 2, em->tile_s0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-            EM_TRY(hipMemcpyAsync(em->h_plan + 3, em->tile_esc0 + nt, 8, hipMemcpyDeviceToHost, em->cur));
-            EM_TRY(hipMemcpyAsync(em->h_plan + 5, d_most, 8, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipStreamSynchronize(em->cur));
             const uint32_t most = *reinterpret_cast<const uint32_t*>(em->h_plan + 5);
             lo_monotone = reinterpret_cast<const uint32_t*>(em->h_plan + 5)[1] == 0u;
