@@ -204,7 +204,7 @@ typedef struct {
     uint64_t n_active;        /* activeTranscriptIDs.size() (:774-782) */
     double loop_ms;           /* device time of the iteration loop (HIP events on `stream`) */
     uint32_t fused;           /* 1: the loop ran as one kernel per iteration (update folded into the sweep), 0: sweep + update */
-    uint32_t reserved;
+    uint32_t persistent;      /* 1: the whole loop ran as ONE launch (csrc/em_persist.h); implies fused */
 } sfgpu_em_stats;
 
 SFGPU_API int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stream);

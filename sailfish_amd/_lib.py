@@ -33,11 +33,11 @@ class EmOpts(C.Structure):
 class EmStats(C.Structure):
     _fields_ = [("iters", C.c_uint32), ("converged", C.c_uint32), ("max_rel_diff", C.c_double),
                 ("alpha_sum", C.c_double), ("n_active", C.c_uint64), ("loop_ms", C.c_double),
-                ("fused", C.c_uint32), ("reserved", C.c_uint32)]
+                ("fused", C.c_uint32), ("persistent", C.c_uint32)]
 
     def as_dict(self):
         return dict(iters=self.iters, converged=bool(self.converged), max_rel_diff=self.max_rel_diff,
-                    alpha_sum=self.alpha_sum, n_active=self.n_active, loop_ms=self.loop_ms, fused=bool(self.fused))
+                    alpha_sum=self.alpha_sum, n_active=self.n_active, loop_ms=self.loop_ms, fused=bool(self.fused), persistent=bool(self.persistent))
 
 
 class EqStats(C.Structure):

@@ -390,19 +390,28 @@ k_tile_window(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
     if (threadIdx.x == 0) esc_s = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kEmBlock / kWave; ++i) { mn = rmin[i] < mn ? rmin[i] : mn; mx = rmax[i] > mx ? rmax[i] : mx; }
-        uint32_t span = 0;
-        if (e == b) mn = 0; else { span = mx - mn + 1; span = span < (uint32_t)kWin ? span : (uint32_t)kWin; }
-        tile_lo[blockIdx.x] = mn; tile_span[blockIdx.x] = span; lo_s = mn;
-        tile_len8[blockIdx.x] = (e - b + kPerLane - 1) / kPerLane * kPerLane;
+        for (int i = 1; i < kEmBlock / kWave; ++i) mn = rmin[i] < mn ? rmin[i] : mn;
+        if (e == b) mn = 0;
+        lo_s = mn;
     }
     __syncthreads();
+    // the window ends at the largest member that lies within kWin of the smallest (round 5: a far member -- an escape -- used to
+    // stretch every window it touched to the full kWin slots: more slots to publish and fold, more overlapping tiles)
     const uint32_t lo = lo_s;
     unsigned int mine = 0;
-    for (uint32_t j = b + threadIdx.x; j < e; j += kEmBlock) mine += (ids[j] - lo >= (uint32_t)kWin) ? 1u : 0u;
+    uint32_t top = 0;
+    for (uint32_t j = b + threadIdx.x; j < e; j += kEmBlock) {
+        const uint32_t d = ids[j] - lo;
+        if (d >= (uint32_t)kWin) ++mine; else top = d > top ? d : top;
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) { const uint32_t w = __shfl_down(top, o, kWave); top = w > top ? w : top; }
+    if ((threadIdx.x & (kWave - 1)) == 0) rmax[threadIdx.x / kWave] = top;
     if (mine) atomicAdd(&esc_s, mine);
     __syncthreads();
     if (threadIdx.x == 0) {
+        for (int i = 1; i < kEmBlock / kWave; ++i) top = rmax[i] > top ? rmax[i] : top;
+        tile_lo[blockIdx.x] = lo; tile_span[blockIdx.x] = (e == b) ? 0u : top + 1u;
+        tile_len8[blockIdx.x] = (e - b + kPerLane - 1) / kPerLane * kPerLane;
         tile_nesc[blockIdx.x] = esc_s;
         if (blockIdx.x == gridDim.x - 1) { tile_span[gridDim.x] = 0; tile_len8[gridDim.x] = 0; tile_nesc[gridDim.x] = 0; }   // scan sentinels
     }
@@ -588,9 +597,9 @@ struct alignas(64) TileDesc {
     uint64_t s0; uint32_t n8, n_esc;
     uint64_t e0, off;
     uint64_t qb; uint32_t np, nm;                          // GATHER: the transcript-major copy (pure chunks, mixed chunks)
-    uint32_t pr, nb_n, nb_before, pad0;                    // nb_*: FUSED, the overlapping tiles below
+    uint32_t pr, nb_n, nb_before, f0;                      // nb_*: FUSED, the overlapping tiles below; f0: first far slot (em_persist.h)
     uint4 e[kNbMax];                                       // {lo', span', off', tile'}
-    uint4 pad1;
+    uint32_t nf, pad1[3];                                  // nf: distinct far transcripts of the tile = its far slots
 };
 static_assert(sizeof(TileDesc) == 192, "three 64-byte scalar loads");
 __global__ void k_tile_desc(uint32_t n_tiles, const uint32_t* __restrict__ tile_c0, const uint32_t* __restrict__ tile_lo,
@@ -632,7 +641,7 @@ __global__ void k_nb_table(uint32_t n_tiles, const uint32_t* __restrict__ tile_l
             if (U > T && ll < lo) { atomicOr(flags, 2u); break; }
             if (U > T && (uint64_t)ll >= (uint64_t)lo + span) break;
             if ((uint64_t)ll + sl > lo && (uint64_t)ll < (uint64_t)lo + span) {
-                if (n == (uint32_t)kNbMax) { n = kNbByList; break; }       // too many for the record: this tile goes by the cover list
+                if (n == (uint32_t)kNbMax) { n = kNbByList; atomicOr(flags, 1u); break; }       // too many for the record: this tile goes by the cover list
                 ent[n++] = make_uint4(ll, sl, (uint32_t)tile_off[U], U);
             }
         }
@@ -823,7 +832,7 @@ __global__ void k_csc_offsets(uint32_t n_tiles, const uint64_t* __restrict__ cb,
 __global__ void __launch_bounds__(kEmBlock)
 k_csc_write(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tile_in, const uint64_t* __restrict__ cb,
             const uint64_t* __restrict__ ps, const uint64_t* __restrict__ tile_qb, const uint32_t* __restrict__ tile_np,
-            unsigned char* csc, uint16_t* slot0) {
+            unsigned char* csc, uint16_t* slot0, uint32_t null_cls) {
     const uint32_t t = blockIdx.x, a = idx[t], e = a + tile_in[t];
     const uint64_t g0 = cb[t], p0 = ps[g0];
     const uint32_t n = (uint32_t)(cb[t + 1] - g0), np = tile_np[t];
@@ -835,7 +844,7 @@ k_csc_write(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, c
         for (uint32_t k = 0; k < 8u; ++k) {
             const uint32_t i = first + k;
             const uint32_t v = kv[i <= last ? i : last], key = v >> 16;
-            cl[k] = i <= last ? (v & 0xFFFFu) : (uint32_t)kTileNnz;           // padding: the null class (count / denom = 0)
+            cl[k] = i <= last ? (v & 0xFFFFu) : null_cls;                     // padding: the plan's null class (count / denom = 0)
             sl[k] = (key & 0x7FFu) | ((key & 0x800u) ? kCscSingleBit : 0u);
         }
         const uint64_t g = g0 + j, pr = ps[g];
@@ -854,6 +863,7 @@ k_csc_write(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, c
 struct SweepArgs {
     // (what the head of the kernel needs comes first: the kernel arguments are fetched 64 bytes at a time)
     const TileDesc* td; EmState* st; uint32_t min_iter, max_iter, par, first;
+    uint32_t null_cls;                                                   // GATHER: the class index of the transcript-major copy's padding (the plan's largest class count of a tile)
     const uint32_t* stream; const uint32_t* chdr;                        // GATHER: 16-bit window slots, 8 per chunk, + one header word per chunk
     const double* x; const uint32_t* counts;
     double* part_a; double* part_b;                                      // FUSED: the sweeps' window sums, by sweep parity
@@ -1183,7 +1193,7 @@ k_sweep_lds(SweepArgs a) {
         }
         esc_values();
         for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
-        if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
+        if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; den[a.null_cls] = 0.0; }
         if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
         SF_STAMP(3);
         if (has && upd) xv = x_of(ap, len);
@@ -1203,7 +1213,7 @@ k_sweep_lds(SweepArgs a) {
     if constexpr (!FUSED) {
     esc_values();
     for (uint32_t i = threadIdx.x; i < nc; i += kSweepBlock) den[i] = 0.0;
-    if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; }
+    if (threadIdx.x == 0) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[kTileNnz] = 0.0; den[a.null_cls] = 0.0; }
     if (threadIdx.x < kEscSlots) { esc_key[threadIdx.x] = 0u; esc_val[threadIdx.x] = 0.0; }
     }
     __syncthreads();
@@ -1382,6 +1392,8 @@ k_sweep_lds(SweepArgs a) {
         }
     }
 }
+
+#include "em_persist.h"
 
 // alphaOut[t] += sum of the tiles' window entries for t, in cover-list order (deterministic)
 __device__ __forceinline__ double fold_partials(uint64_t t, const uint32_t* __restrict__ cov_ptr,
@@ -1569,6 +1581,14 @@ struct sfgpu_em {
     uint32_t run_no = 0;                                    // tags the progress words of this optimize()
     uint32_t par = 0;                                       // parity of the next fused launch
     bool graph_fused = false;
+    uint32_t null_cls = kTileNnz;                           // GATHER: class index of the transcript-major copy's padding = the largest class count of a tile
+    // the PERSISTENT loop (em_persist.h): far-slot tables, the exchange buffer (control words + granule arrays), the plan's verdict
+    uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
+    unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
+    uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
+    int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
+    uint32_t far_cap = 0;
+    bool persist = false;                                   // this optimize() runs as one launch
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     EmState* d_state = nullptr;
@@ -1591,7 +1611,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->xbuf, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -1640,6 +1660,7 @@ struct Launcher {
 static SweepArgs em_sweep_args(sfgpu_em* em) {
     const sfgpu_problem& p = em->prob;
     SweepArgs a{};
+    a.null_cls = em->null_cls;
     a.td = em->td; a.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter;
     a.stream = em->lstream; a.chdr = em->chdr; a.x = em->x; a.counts = em->counts32;
     a.part_a = em->partial_a; a.part_b = em->partial_b; a.aout_a = em->alpha_out; a.aout_b = em->aout_b; a.aout_c = em->aout_c;
@@ -1746,7 +1767,7 @@ static void em_stats_from_state(sfgpu_em* em, sfgpu_em_stats* s) {
     const EmState* h = em->h_state;
     uint32_t it = h->it_a;
     s->iters = it;
-    s->fused = em->fused ? 1u : 0u; s->reserved = 0u;
+    s->fused = em->fused ? 1u : 0u; s->persistent = em->persist ? 1u : 0u;
     s->n_active = h->n_active;
     s->alpha_sum = h->alpha_sum;
     if (it == 0) { s->converged = 0; s->max_rel_diff = -DBL_MAX; return; }
@@ -1818,6 +1839,52 @@ static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint
     for (void* q : {(void*)key, (void*)perm, (void*)ckey, (void*)lens, (void*)vals, (void*)k_in, (void*)k_out, (void*)off64}) pool_free(q);
     em->inv = inv; em->cperm = cperm;
     *rowptr2_out = rowptr2; *vids_out = vids;
+    return SFGPU_OK;
+}
+
+// The persistent loop's part of the plan (em_persist.h): far slots per tile, the lists of far slots per target, the exchange buffer.
+// Leaves em->pflags on the device ([0] != 0: this plan does not run persistent; [1]: the most far slots a tile has); sfgpu_em_create
+// queues their read-back.  Nothing is waited for.
+static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P) {
+    static const bool off = []() { const char* e = getenv("SFGPU_EM_PERSIST"); return e && atoi(e) == 0; }();
+    if (off || 2 * P * 16ull + 3 * E * 16ull >= (1ull << 31)) return SFGPU_OK;                  // (granules are addressed with 32-bit byte offsets)
+    const uint64_t M = em->prob.M;
+    hipStream_t st = em->cur;
+    SF_HIP(pool_malloc(&em->pflags, 8));
+    SF_HIP(hipMemsetAsync(em->pflags, 0, 8, st));
+    const uint64_t En = E ? E : 1;
+    if (E) {
+        uint64_t *k_in = nullptr, *k_out = nullptr, *k2_in = nullptr, *k2_out = nullptr, *gsum = nullptr;
+        uint32_t *v_in = nullptr, *v_out = nullptr, *head = nullptr, *esc_g = nullptr;
+        struct Scratch {
+            void** slots[9]; hipStream_t st;
+            ~Scratch() { void* ps[9]; for (int i = 0; i < 9; ++i) ps[i] = *slots[i]; pool_free_on_many(ps, 9, st); }
+        } scratch{{(void**)&k_in, (void**)&k_out, (void**)&k2_in, (void**)&k2_out, (void**)&gsum, (void**)&v_in, (void**)&v_out, (void**)&head, (void**)&esc_g}, st};
+        SF_HIP(pool_malloc(&k_in, E * 8)); SF_HIP(pool_malloc(&k_out, E * 8)); SF_HIP(pool_malloc(&k2_in, E * 8)); SF_HIP(pool_malloc(&k2_out, E * 8));
+        SF_HIP(pool_malloc(&gsum, (E + 2) * 8)); SF_HIP(pool_malloc(&v_in, E * 4)); SF_HIP(pool_malloc(&v_out, E * 4));
+        SF_HIP(pool_malloc(&head, (E + 2) * 4)); SF_HIP(pool_malloc(&esc_g, E * 4));
+        SF_HIP(pool_malloc(&em->esc_far, E * 4)); SF_HIP(pool_malloc(&em->far_pos, E * 4)); SF_HIP(pool_malloc(&em->far_xi, E * 4));
+        SF_HIP(pool_malloc(&em->ft_list, E * 4)); SF_HIP(pool_malloc(&em->ftgt, M * 8));
+        SF_HIP(hipMemsetAsync(em->ftgt, 0, M * 8, st));
+        int tbits = 1; while (tbits < 31 && (1u << tbits) < nt) ++tbits;
+        int pbits = 1; while (pbits < 32 && (1ull << pbits) < M) ++pbits;
+        hipLaunchKernelGGL(k_far_keys, dim3(nt), dim3(kEmBlock), 0, st, em->td, em->inv ? em->esc_pos : em->esc_id, k_in, v_in);
+        int rc = sort_pairs_u64_u32(k_in, k_out, v_in, v_out, E, st, 32 + tbits, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_far_heads, dim3(blocks_for(E + 1)), dim3(kEmBlock), 0, st, E, k_out, head);
+        if ((rc = exclusive_scan_u32(head, gsum, E, st, false))) return rc;
+        hipLaunchKernelGGL(k_far_assign, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, k_out, v_out, head, gsum, esc_g, em->far_pos, k2_in);
+        hipLaunchKernelGGL(k_far_tiles, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, st, nt, E, k_out, gsum, em->td, em->pflags);
+        hipLaunchKernelGGL(k_far_local, dim3(nt), dim3(kEmBlock), 0, st, em->td, esc_g, em->esc_far);
+        if ((rc = sort_pairs_u64_u32(k2_in, k2_out, v_in, v_out, E, st, 32 + pbits, false))) return rc;     // (values unused)
+        hipLaunchKernelGGL(k_ft_ranges, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, k2_out, em->ftgt, em->ft_list);
+        hipLaunchKernelGGL(k_far_xi, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, em->far_pos, em->ftgt, em->cov2, em->far_xi, em->pflags);
+        SF_CHECK_LAUNCH();
+    }
+    // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    em->xbuf_bytes = up((size_t)kCtlWords * 8 + 64) + 2 * up((size_t)(P ? P : 1) * 16) + 3 * up((size_t)En * 16);
+    SF_HIP(pool_malloc(&em->xbuf, em->xbuf_bytes));
     return SFGPU_OK;
 }
 
@@ -1940,6 +2007,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             EM_TRY(hipStreamSynchronize(em->cur));
             const uint32_t most = *reinterpret_cast<const uint32_t*>(em->h_plan + 5);
             lo_monotone = reinterpret_cast<const uint32_t*>(em->h_plan + 5)[1] == 0u;
+            em->null_cls = most;                             // (<= kTileNnz when the loop ends: a tile holds no more classes than nonzeros)
             if (tile_nnz <= (uint32_t)kTileNnz || most <= (uint32_t)kTileNnz) break;
             ++rounds;
             tile_nnz = tile_for(rounds);
@@ -2020,7 +2088,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 hipLaunchKernelGGL(k_csc_offsets, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, cb, ps, em->tile_qb, em->tile_np, em->tile_pr);
                 EM_TRY(pool_malloc(&em->csc, 32 * (G ? G : 1) + 32));                  // (every chunk mixed: the upper bound)
                 EM_TRY(pool_malloc(&em->csc_slot0, (G + 1) * 2));
-                hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0);
+                hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0, em->null_cls);
                 EM_TRY(hipGetLastError());
             }
             if (cr) { em_free(em); return cr; }
@@ -2104,7 +2172,12 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 pool_free_on(pos_of, em->cur);
             }
             EM_TRY(hipGetLastError());
+            {   // the persistent loop's tables (em_persist.h); its verdict rides on the read-back below
+                const int pr = em_persist_plan(em, nt, E, P);
+                if (pr) { em_free(em); return pr; }
+            }
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
+            if (em->pflags) EM_TRY(hipMemcpyAsync(em->h_plan + 6, em->pflags, 8, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipEventRecord(em->ev_plan, em->cur));
             if (getenv("SFGPU_TIMING")) {                     // dev: how many tiles go by the cover list, how many neighbours the others have
                 std::vector<TileDesc> h(nt);
@@ -2365,6 +2438,64 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
     return SFGPU_OK;
 }
 
+// ---- the persistent loop (em_persist.h): eligibility, and the launch ----
+static std::mutex g_persist_mu[16];          // per device: two persistent launches of this process never share the chip (each needs ALL its blocks resident)
+static size_t em_persist_lds(const sfgpu_em* em) { return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32; }
+static const void* em_persist_func(bool vb) {
+    return vb ? reinterpret_cast<const void*>(&k_em_persist<true>) : reinterpret_cast<const void*>(&k_em_persist<false>);
+}
+// the plan's verdict (read back behind the tables), the LDS carve and the chip's residency: every block of the launch must be resident
+static void em_persist_check(sfgpu_em* em) {
+    em->persist_ok = 0;
+    const bool say = getenv("SFGPU_TIMING") != nullptr;
+    auto no = [&](const char* why) { if (say) fprintf(stderr, "em persistent: not eligible -- %s\n", why); };
+    if (!em->xbuf || !em->pflags || !em->partial_a) return no("no tables (SFGPU_EM_PERSIST=0 at create, or the exchange buffer would pass 2 GB)");
+    if (hipEventSynchronize(em->ev_plan) != hipSuccess) return no("plan event");
+    const uint32_t* pf = reinterpret_cast<const uint32_t*>(em->h_plan + 6);
+    if (pf[0] & 2u) return no("a far member's transcript lies in no window (no home thread)");
+    if (pf[0] & 4u) return no("a transcript is fed by more far slots than its home thread should walk");
+    if ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 1u) != 0u) return no("a tile that more than kNbMax tiles overlap (it goes by the cover list)");
+    em->far_cap = pf[1];
+    constexpr size_t kLdsPerBlock = 81920;                   // half a CU's LDS: two blocks per CU, like the sweep
+    const size_t lds = em_persist_lds(em);
+    if (lds > kLdsPerBlock) return no("the tile's classes + far slots do not fit the LDS");
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return no("device query");
+    for (int vb = 0; vb < 2; ++vb) {
+        int nb = 0;
+        if (hipFuncSetAttribute(em_persist_func(vb != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerBlock) != hipSuccess) { (void)hipGetLastError(); return no("hipFuncSetAttribute"); }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, em_persist_func(vb != 0), kSweepBlock, lds) != hipSuccess) { (void)hipGetLastError(); return no("occupancy query"); }
+        if ((uint64_t)nb * (uint64_t)n_cu < em->n_tiles) return no("more tiles than resident blocks (a multi-round plan)");
+    }
+    if (say) fprintf(stderr, "em persistent: eligible (%u tiles, %zu bytes of LDS, %u far slots at most per tile)\n", em->n_tiles, lds, em->far_cap);
+    em->persist_ok = 1;
+}
+static int em_launch_persist(sfgpu_em* em, int ablate) {
+    const uint64_t P = em->P ? em->P : 1, En = em->E ? em->E : 1;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    unsigned char* q = em->xbuf;
+    SF_HIP(hipMemsetAsync(q, 0, em->xbuf_bytes, em->cur));   // tags, counters, abort word, status: zeroed before EVERY launch
+    PersistArgs a{};
+    a.ctl = reinterpret_cast<unsigned long long*>(q); a.status = reinterpret_cast<uint32_t*>(q + (size_t)kCtlWords * 8);
+    a.xbuf = q; a.xbuf_bytes = (uint32_t)em->xbuf_bytes;
+    size_t o = up((size_t)kCtlWords * 8 + 64);
+    a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
+    a.far_off[0] = (uint32_t)o; o += up(En * 16); a.far_off[1] = (uint32_t)o; o += up(En * 16); a.xpub_off = (uint32_t)o;
+    a.td = em->td; a.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
+    a.stream = em->lstream; a.chdr = em->chdr; a.counts = em->counts32; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
+    a.x = em->x; a.inv = em->inv;
+    a.lenc = em->inv ? em->lencP : em->lenc; a.alpha = em->inv ? em->alphaP : em->alpha;
+    a.esc_cls = em->esc_cls; a.esc_far = em->esc_far; a.far_pos = em->far_pos; a.far_xi = em->far_xi; a.ftgt = em->ftgt; a.ft_list = em->ft_list;
+    a.unc = em->unc; a.unc_n = em->unc + em->prob.M;
+    a.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
+    a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.ablate = ablate;
+    void* args[] = {&a};
+    SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kSweepBlock), args, em_persist_lds(em), em->cur));
+    // (the launch's verdict, next to the plan's words in pinned memory; read behind finish()'s wait)
+    SF_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t*>(em->h_plan + 7), a.status, 4, hipMemcpyDeviceToHost, em->cur));
+    return SFGPU_OK;
+}
+
 // begin -> init -> iterate to the stop latch -> finish, on the handle's own stream
 static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, double* d_mass_out,
                   sfgpu_em_stats* stats, bool quiet) {
@@ -2383,12 +2514,34 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         em->fused = !fused_off && (fused_forced || em->tile_nnz >= kFusedMinTileNnz) && em->gather && em->fused_ok != 0 && em->prob.C != 0 &&
                     (!em->opts.use_vbem || em->const_norm);
     }
+    // The PERSISTENT loop (em_persist.h; round 5): the whole loop as one launch, wherever the fused iteration could run and the plan fits
+    // the chip in one round of blocks (whatever the tile size: it has no launch to amortise).  SFGPU_EM_PERSIST=0 keeps one kernel
+    // per iteration (read when the plan is made too: no tables then).
+    int persist_ablate = 0;
+    {
+        const char* fe = getenv("SFGPU_EM_FUSED"); const char* pe = getenv("SFGPU_EM_PERSIST");
+        const bool family = !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->fused_ok != 0 && em->prob.C != 0 &&
+                            (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 30) && em->persist_ok != 0 && em->xbuf;
+        em->persist = family;
+        if (family) em->fused = true;
+        if (pe && atoi(pe) == 2) persist_ablate = 1;         // dev: no tag checks (timing only)
+        if (pe && atoi(pe) == 3) persist_ablate = 3;         // tests: a tile gives up in step 2 (the run is repeated with one kernel per iteration)
+    }
     if (em->fused && em->fused_ok < 0) {
         // the plan's verdict on the fused kernel's tables (sfgpu_em_create queued its read-back behind them; long done by now)
         SF_HIP(hipEventSynchronize(em->ev_plan));
-        em->fused_ok = (*reinterpret_cast<const uint32_t*>(em->h_plan + 4) == 0u && em->partial_a) ? 1 : 0;
+        em->fused_ok = ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 2u) == 0u && em->partial_a) ? 1 : 0;
         if (!em->fused_ok) em->fused = false;                // (the classes are not in canonical order)
     }
+    if (em->persist && !em->fused) em->persist = false;
+    if (em->persist && em->persist_ok < 0) em_persist_check(em);
+    if (em->persist && em->persist_ok != 1) {
+        em->persist = false;
+        const char* fe = getenv("SFGPU_EM_FUSED");           // (back to the rule of the fused iteration)
+        em->fused = ((fe && atoi(fe) != 0) || em->tile_nnz >= 9000u);
+    }
+    std::unique_lock<std::mutex> persist_lock;
+    if (em->persist) { int dev = 0; (void)hipGetDevice(&dev); persist_lock = std::unique_lock<std::mutex>(g_persist_mu[dev & 15]); }
     if ((rc = sfgpu_em_init_impl(em))) return rc;
     if (em->fused && em->inv) {                               // alpha and effLen in the plan's order (the fused kernel's index space)
         const uint64_t M = em->prob.M;
@@ -2431,10 +2584,13 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     // run), ~8 no-op launches past the stop instead of ~48, no graph to build: cfg3 22.5 -> 21.3 us per iteration, EM phase 5.5 -> 5.2 ms.
     {
         const char* se = getenv("SFGPU_EM_STREAMED");
-        em->streamed = em->fused && !(se && atoi(se) == 0);
+        em->streamed = em->fused && !em->persist && !(se && atoi(se) == 0);
     }
     SF_HIP(hipEventRecord(em->ev_a, em->cur));
-    if (em->streamed) {
+    if (em->persist) {
+        if ((rc = em_launch_persist(em, persist_ablate))) return rc;
+        done = 1;
+    } else if (em->streamed) {
         static const uint32_t kAhead = []() { const char* e = getenv("SFGPU_EM_AHEAD"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 256 ? v : 8); }();
         volatile unsigned long long* mir = em->h_mirror;
         *mir = 0ull;
@@ -2482,6 +2638,14 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         SF_CHECK_LAUNCH();
     }
     rc = sfgpu_em_finish(em, d_alpha_out, d_mass_out, &st);
+    if (em->persist && *reinterpret_cast<const volatile uint32_t*>(em->h_plan + 7) != 0u) {
+        // a tile gave up waiting (its neighbours never became resident: the chip is shared with another process' kernels): this
+        // handle goes back to one kernel per iteration, and the run is repeated from its start
+        persist_lock.unlock();
+        em->persist_ok = 0;
+        log_msg(1, "EM: the persistent loop gave up waiting for a tile (is the device shared?); running one kernel per iteration");
+        return em_run(em, opts, d_alpha_out, d_mass_out, stats, quiet);
+    }
     if (em->fused && st.n_active == 0) {                                             // :794-798 (see above)
         set_error("It seems that no transcripts are expressed; something is likely wrong!");
         if (stats) *stats = st;

@@ -1,0 +1,463 @@
+// em_persist.h -- the whole EM / VBEM loop of optimize() as ONE launch (round 5).  Included by em.hip (inside namespace sfgpu,
+// behind k_sweep_lds: it uses TileDesc, sweep_x, vb_x_lean and the tile constants).
+//
+// Replaces the loop of src/CollapsedEMOptimizer.cpp:818-861 (while (itNum < minIter or (itNum < maxIter and !converged))
+// { EMUpdate_ / VBEMUpdate_; convergence test; swap; ++itNum }) for plans that fit the chip in one round of blocks.
+//
+// Why: with one kernel per iteration (k_sweep_lds<.., .., FUSED>) every iteration still pays a kernel boundary (~1.4 us), a cold L2
+// behind it (every dependent round trip at the head of a launch costs 1.2 - 2 us) and the wait for the launch's slowest tile.
+// Here a block keeps its tile for ALL iterations; what changes hands between iterations are the window sums of the <= 6 tiles whose
+// windows overlap a tile's own (TileDesc::e, k_nb_table) -- point to point, tile to tile, no grid barrier:
+//   * a sum travels as a 16-byte GRANULE {lo, tag, hi, tag} written by ONE write-through store (buffer_store_dwordx4 sc1) and read
+//     with sc1 loads (L1 bypassed; the per-XCD L2s are not coherent, the write-through store drops the line there): the data is its
+//     own flag.  tag = the sweep's number + 1 (never 0: the arrays are zeroed before every launch); each 8-byte half carries the
+//     tag, so a torn granule cannot pass.  Two arrays by tag parity: tile T overwrites the granules of sweep s - 1 with those of
+//     sweep s + 1 at the end of step s + 1, whose head needed its neighbours' sums of sweep s, which they publish after their
+//     step s has read T's sums of sweep s - 1 (the overlap relation is symmetric);
+//   * far members (escapes): tile V adds what it hands a far transcript t into a dense LDS accumulator (one FAR SLOT per distinct
+//     far transcript of the tile, numbered by the plan) and publishes the slots as granules like the window; t's home thread (in
+//     the lowest tile H whose window holds t) adds t's far slots in tile order in front of the window sums -- the sum k_update
+//     forms as alphaOut[t] + partials, without the atomics -- and publishes x_t as a granule of its own, which V's threads read
+//     in place of the x vector.  V -> H -> V: each hand-over names an EARLIER step or an earlier phase of the same step: no cycle;
+//   * the stop test needs every tile's verdict on update u: thread 0 of every block posts "update u done" on one of 8 counters
+//     (by block mod 8: the XCD) behind an atomicMax of u on "the last update some transcript of mine moved in"; wave 0 reads them
+//     at the head of step u + 1, one sweep later -- by then they are complete unless a tile trails by a whole sweep.  converged_u
+//     <=> all maxima < u (a tile only reaches update u + 1 if the loop did not stop at u).
+// alpha', the gate, the relative change and x are formed exactly as in the fused kernel (same additions, same order, vb_x_lean);
+// a transcript's alpha lives in a register of its home thread for the whole run and goes to memory when the loop ends.
+//
+// Every spin is bounded: a tile that waits ~1 s (a block that never became resident: another process holds the CUs) raises the
+// abort word, every other tile sees it in its own spins, the launch ends with status != 0 and em_run repeats the run with one
+// kernel per iteration.  Two persistent launches of one process never overlap (em_run holds a per-device mutex).
+
+typedef unsigned int gr4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kShards = 8;                      // arrival counters / convergence words, by block mod 8
+constexpr uint32_t kCtlStride = 16;                  // 64-bit words between two control words (128 bytes: a line of their own)
+constexpr uint32_t kCtlArrive = 0;                   // [4][kShards] arrivals of update u in slot u % 4 (monotonic over the run)
+constexpr uint32_t kCtlNotConv = 4 * kShards;        // [kShards] the last update in which some block of the shard saw a change > tol
+constexpr uint32_t kCtlAbort = 5 * kShards;          // != 0: some tile gave up waiting
+constexpr uint32_t kCtlWords = (5 * kShards + 1) * kCtlStride;
+constexpr uint32_t kSpinLimit = 1u << 20;            // slow-path polls of one wait (~1 us each) before a tile gives up
+constexpr uint32_t kFanInMax = 16;                   // far slots one transcript may collect (its home thread reads them one by one)
+
+// ---- the plan's far-slot tables (sfgpu_em_create -> em_persist_plan) ----------------------------------------------------------
+// An escape is (tile, class, far transcript).  The distinct far transcripts of a tile are its FAR SLOTS, numbered in position
+// order; global far slot g = TileDesc::f0 + f.  ft_list lists, per target position, the far slots that feed it in tile order
+// (ftgt[pos] = its range).  All of it from two sorts of E keys.
+__global__ void __launch_bounds__(kEmBlock)
+k_far_keys(const TileDesc* __restrict__ td, const uint32_t* __restrict__ esc_where, uint64_t* keys, uint32_t* vals) {
+    const uint32_t T = blockIdx.x, n = td[T].n_esc;
+    const uint64_t e0 = td[T].e0;
+    for (uint32_t i = threadIdx.x; i < n; i += kEmBlock) { keys[e0 + i] = ((uint64_t)T << 32) | esc_where[e0 + i]; vals[e0 + i] = (uint32_t)(e0 + i); }
+}
+__global__ void k_far_heads(uint64_t E, const uint64_t* __restrict__ ks, uint32_t* head) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) head[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u; else if (i == E) head[i] = 0u;
+}
+// sorted entry i belongs to far slot g = (heads before i) + head[i] - 1
+__global__ void k_far_assign(uint64_t E, const uint64_t* __restrict__ ks, const uint32_t* __restrict__ vs, const uint32_t* __restrict__ head,
+                             const uint64_t* __restrict__ gsum, uint32_t* esc_g, uint32_t* far_pos, uint64_t* keys2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const uint32_t g = (uint32_t)gsum[i] + head[i] - 1u;
+    esc_g[vs[i]] = g;
+    if (head[i]) { const uint32_t p = (uint32_t)ks[i]; far_pos[g] = p; keys2[g] = ((uint64_t)p << 32) | g; }
+    const uint64_t F = gsum[E];
+    if (i >= F) keys2[i] = ~0ull;                                        // (the second sort runs over E entries: the surplus goes last)
+}
+__global__ void k_far_tiles(uint32_t n_tiles, uint64_t E, const uint64_t* __restrict__ ks, const uint64_t* __restrict__ gsum, TileDesc* td, uint32_t* pflags) {
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= n_tiles) return;
+    auto first_of = [&](uint64_t tile) -> uint32_t {                     // far slots in front of `tile`'s
+        uint64_t lo = 0, hi = E;
+        const uint64_t key = tile << 32;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] >= key) hi = mid; else lo = mid + 1; }
+        return (uint32_t)gsum[lo];
+    };
+    const uint32_t a = first_of(T), b = first_of((uint64_t)T + 1u);
+    td[T].f0 = a; td[T].nf = b - a;
+    atomicMax(&pflags[1], b - a);
+}
+__global__ void __launch_bounds__(kEmBlock)
+k_far_local(const TileDesc* __restrict__ td, const uint32_t* __restrict__ esc_g, uint32_t* esc_far) {
+    const uint32_t T = blockIdx.x, n = td[T].n_esc, f0 = td[T].f0;
+    const uint64_t e0 = td[T].e0;
+    for (uint32_t i = threadIdx.x; i < n; i += kEmBlock) esc_far[e0 + i] = esc_g[e0 + i] - f0;
+}
+// the far slots sorted by (target position, slot): ranges per target
+__global__ void k_ft_ranges(uint64_t E, const uint64_t* __restrict__ gsum, const uint64_t* __restrict__ k2, uint2* ftgt, uint32_t* ft_list) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t F = gsum[E];
+    if (k >= F) return;
+    const uint32_t p = (uint32_t)(k2[k] >> 32);
+    ft_list[k] = (uint32_t)k2[k];
+    if (k == 0 || (uint32_t)(k2[k - 1] >> 32) != p) ftgt[p].x = (uint32_t)k;
+    if (k + 1 == F || (uint32_t)(k2[k + 1] >> 32) != p) ftgt[p].y = (uint32_t)k + 1u;
+}
+// where a far slot's x is published (the first list entry of its target), and the checks: a target that no window holds has no
+// home thread (flag 2), one that collects more than kFanInMax slots would stall its home thread (flag 4)
+__global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const uint32_t* __restrict__ far_pos, const uint2* __restrict__ ftgt,
+                         const uint2* __restrict__ cov2, uint32_t* far_xi, uint32_t* pflags) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gsum[E]) return;
+    const uint32_t p = far_pos[g];
+    const uint2 r = ftgt[p];
+    far_xi[g] = r.x;
+    if (cov2[p].x == cov2[p].y) atomicOr(&pflags[0], 2u);
+    if (r.y - r.x > kFanInMax) atomicOr(&pflags[0], 4u);
+}
+
+struct PersistArgs {
+    const TileDesc* td; EmState* st; uint32_t min_iter, max_iter, n_tiles; int check_mode;
+    const uint32_t* stream; const uint32_t* chdr; const uint32_t* counts;
+    const unsigned char* csc; const uint16_t* csc_slot0;
+    const double* x; const uint32_t* inv;                 // x of sweep 0 (init made it, in the caller's order); position -> transcript
+    const double* lenc; double* alpha;                    // by position of the plan's order
+    // the exchange buffer: ONE buffer descriptor, the pieces by byte offset -- granules of the window sums, slot-major
+    // (TileDesc::off + slot), by tag parity; granules of the far slots, by tag parity; granules of the far targets' x
+    void* xbuf; uint32_t xbuf_bytes, part_off[2], far_off[2], xpub_off;
+    const uint32_t* esc_cls; const uint32_t* esc_far;     // per escape: class << 16 | single ; far slot in the tile
+    const uint32_t* far_pos; const uint32_t* far_xi;      // per far slot (TileDesc::f0 + f): target position ; index of its x granule
+    const uint2* ftgt; const uint32_t* ft_list;           // per position: [k0, k1) of ft_list = the far slots that feed it, in tile order (null: no far members)
+    unsigned long long* ctl;                              // kCtlWords control words (zeroed before the launch)
+    const uint32_t* unc; const uint32_t* unc_n;           // positions no window holds (inactive transcripts)
+    double* tmax; double tol, log_norm;
+    uint32_t den_cap, far_cap;                            // LDS: den[den_cap + 1] (den_cap = the plan's null class), facc[far_cap]
+    uint32_t* status;                                     // 0: ran to the stop; 1: gave up (see above)
+    int ablate;                                           // dev: 1 = no tag checks (timing only: wrong results); 3 = tile 0 gives up in step 2 (tests)
+};
+
+__device__ __forceinline__ double gr_value(const gr4& g) { return __hiloint2double((int)g.z, (int)g.x); }
+__device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y == tag && g.w == tag; }
+
+template <bool VB>
+__global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_em_persist(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double plds[];
+    double* const xs = plds;                               // [kWin + 1]  (+ the slot of the null words: x = 0)
+    double* const acc = xs + (kWin + 2);                   // [kWin + 1]
+    double* const den = acc + (kWin + 2);                  // [den_cap + 1]  denominators, then count / denom (+ the null class at den_cap)
+    double* const facc = den + (a.den_cap + 2);            // [far_cap]
+    double* const wmax = facc + a.far_cap;                 // [2][waves]: the wavefronts' largest relative change, by update parity
+    uint32_t* const sctl = reinterpret_cast<uint32_t*>(wmax + 2 * (kSweepBlock / kWave));     // [0] stop, [1] abort (heads), [2..3] block saw a change > tol (by step parity), [4..5] abort (phases, by step parity)
+
+    const TileDesc td = a.td[blockIdx.x];
+    const uint32_t c0 = td.c0, nc = td.nc, lo = td.lo, span = td.span, n8 = td.n8, n_esc = td.n_esc;
+    const uint64_t s0 = td.s0, e0 = td.e0;
+    const uint32_t off = (uint32_t)td.off;
+    const uint32_t nb_n = td.nb_n, nb_before = td.nb_before, f0 = td.f0, nf = td.nf;
+    const uint32_t tid0 = threadIdx.x;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, a.xbuf_bytes, 0x00020000);
+    auto gr_load = [&](uint32_t piece_off, uint32_t idx) -> gr4 { return __builtin_amdgcn_raw_buffer_load_b128(rx, idx * 16u, piece_off, 16); };      // sc1
+    auto gr_store = [&](uint32_t piece_off, uint32_t idx, double v, uint32_t tag) {
+        gr4 w; w.x = (uint32_t)__double2loint(v); w.y = tag; w.z = (uint32_t)__double2hiint(v); w.w = tag;
+        __builtin_amdgcn_raw_buffer_store_b128(w, rx, idx * 16u, piece_off, 16);                                                                   // sc1: write-through
+    };
+    unsigned long long* const ctl = a.ctl;
+    // a wait that does not end: look at the abort word now and then, give up after ~1 s (returns true when the wait must be left)
+    // (`word`: the block's abort word this wait reports to -- sctl[1] for the waits of a head, sctl[4 + step parity] for those inside
+    //  the phases: every word is read by ALL threads behind ONE barrier that no writer of it can have passed, so the block leaves as one)
+    auto spin_check = [&](uint32_t& spins, uint32_t word) -> bool {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 63u) != 0u) return false;
+        if (__hip_atomic_load(&ctl[kCtlAbort * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { sctl[word] = 1u; return true; }
+        if (spins >= kSpinLimit) {
+            __hip_atomic_store(&ctl[kCtlAbort * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sctl[word] = 1u;
+            return true;
+        }
+        return false;
+    };
+
+    // ---- what a thread keeps for the whole run: its window slot (position lo + tid0), which of the overlapping tiles hold that
+    //      position (bits 0..5), whether it has a slot (bit 30) and whether this tile is the position's home (bit 31).  Everything else
+    //      it needs per step (effLen, alpha, its far members, the far slots that feed it) is read again every step: registers are
+    //      what this kernel is short of (64 per thread at two blocks per CU), and those words sit in the L2.
+    const uint32_t pos0 = lo + tid0;
+    uint32_t flags = tid0 < span ? 0x40000000u : 0u;
+    {
+        bool home = tid0 < span;
+#pragma unroll
+        for (int j = 0; j < kNbMax; ++j) {
+            const uint4 e = td.e[j];                                     // {lo', span', off', tile'}
+            const bool in = tid0 < span && (uint32_t)j < nb_n && (pos0 - e.x) < e.y;
+            if (in) { flags |= 1u << j; if ((uint32_t)j < nb_before) home = false; }
+        }
+        if (home) flags |= 0x80000000u;
+    }
+    if (tid0 < 8u) sctl[tid0] = 0u;
+    if (tid0 < kSweepBlock) acc[tid0] = 0.0;
+
+    const uint4* __restrict__ slots8 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.stream) + s0);
+    const uint32_t* __restrict__ hdrs = a.chdr + (s0 >> 3);
+    const uint4* __restrict__ pure = reinterpret_cast<const uint4*>(a.csc + td.qb);
+    const uint16_t* __restrict__ slot0_p = a.csc_slot0 + td.pr;
+    const uint32_t np = td.np, nm = td.nm;
+
+    auto x_of = [&](double ap, double l) -> double {
+        if (VB) return (ap > kTiny) ? sweep_x<true>(vb_x_lean(ap, a.log_norm, l)) : 0.0;       // :300-320
+        return sweep_x<false>(ap / l);
+    };
+    auto x_first = [&](uint32_t p) -> double { return a.x[a.inv ? a.inv[p] : p]; };
+    // x of the far member behind far slot f of this tile, for sweep s: sweep 0 reads the x vector, later sweeps the granule the
+    // transcript's home thread published at the head of its step s
+    auto far_x = [&](uint32_t f, uint32_t s, uint32_t word) -> double {
+        if (s == 0u) return x_first(a.far_pos[f0 + f]);
+        const uint32_t xi = a.far_xi[f0 + f];
+        gr4 g = gr_load(a.xpub_off, xi);
+        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, s);) { if (spin_check(spins, word)) break; g = gr_load(a.xpub_off, xi); }
+        return gr_value(g);
+    };
+    __syncthreads();
+
+    uint32_t k_done = 0;                                                 // updates done when the loop ends
+    bool conv_last = false;
+    for (uint32_t s = 0;; ++s) {
+        // (the thread's index, opaque to the compiler once per step: left alone it hoists every per-thread address of the loop body --
+        //  a dozen 64-bit pointers -- out of the loop and spills them)
+        uint32_t tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const uint32_t lane = tid & (kWave - 1), wave = tid / kWave, pos = lo + tid, g0 = tid * kPerLane;
+        const bool has_esc0 = tid < n_esc, has_esc1 = tid + kSweepBlock < n_esc;
+        // ================= head of step s: [the stop test of update s - 1] update s, x of sweep s =================
+        const bool has = (flags & 0x40000000u) != 0u, home = (flags & 0x80000000u) != 0u;
+        const uint32_t rd_off = a.part_off[s & 1u], frd_off = a.far_off[s & 1u];      // sums of sweep s - 1 carry tag s
+        double ap = 0.0, xv = 0.0, lm = -1.0, av = 0.0; unsigned ncv = 0u;
+        if (s > 0u) {
+            gr4 gq[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint4 e = td.e[j];
+                gq[j] = gr4{0u, s, 0u, s};
+                if (flags & (1u << j)) gq[j] = gr_load(rd_off, e.z + (pos - e.x));
+            }
+            double len = 1.0; uint2 ft = make_uint2(0u, 0u);
+            if (has) { len = a.lenc[pos]; if (a.ftgt) ft = a.ftgt[pos]; }
+            if (home) av = a.alpha[pos];
+            const double own = acc[tid];                                  // what this tile's last sweep handed the slot (cleared below)
+            // wave 0: has every tile finished update s - 1, and did the loop end there?  (:820)
+            if (wave == 0u && s >= 2u) {
+                const uint32_t u = s - 1u;
+                const uint32_t visits = (u & 3u) ? (u >> 2) + 1u : (u >> 2);
+                uint32_t ncu = 0u;
+                if (lane < kShards) {
+                    const unsigned long long want = (unsigned long long)visits * ((a.n_tiles + (kShards - 1u) - lane) / kShards);
+                    const unsigned long long* w = &ctl[(kCtlArrive + (u & 3u) * kShards + lane) * kCtlStride];
+                    unsigned long long got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.ablate != 1) for (uint32_t spins = 0; got < want;) { if (spin_check(spins, 1u)) break; got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    ncu = (uint32_t)__hip_atomic_load(&ctl[(kCtlNotConv + lane) * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const bool moved = __any(lane < kShards && ncu >= u);
+                if (lane == 0u) {
+                    const bool conv = !moved;
+                    const bool stop = u >= a.min_iter && (u >= a.max_iter || conv);
+                    sctl[0] = stop ? (conv ? 3u : 1u) : 0u;
+                }
+            } else if (wave == 0u && lane == 0u) {
+                const uint32_t u = s - 1u;                                    // (u = 0: nothing to wait for)
+                sctl[0] = (u >= a.min_iter && u >= a.max_iter) ? 1u : 0u;
+            }
+            if (has) {
+                // the far slots that feed this transcript, in tile order: what alphaOut held in the other loops
+                for (uint32_t k = ft.x; k < ft.y; ++k) {
+                    const uint32_t g = a.ft_list[k];
+                    gr4 q = gr_load(frd_off, g);
+                    if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(q, s);) { if (spin_check(spins, 1u)) break; q = gr_load(frd_off, g); }
+                    ap += gr_value(q);
+                }
+                // the overlapping tiles' sums, in tile order with this tile's own in its place (as the cover list); three at a time
+                auto wait3 = [&](int base) {
+                    if (a.ablate == 1) return;
+                    for (uint32_t spins = 0;;) {
+                        const bool ok = gr_ok(gq[0], s) && gr_ok(gq[1], s) && gr_ok(gq[2], s);
+                        if (ok || spin_check(spins, 1u)) break;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) if ((flags & (1u << (base + j))) && !gr_ok(gq[j], s)) { const uint4 e = td.e[base + j]; gq[j] = gr_load(rd_off, e.z + (pos - e.x)); }
+                    }
+                };
+                wait3(0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { if ((uint32_t)j == nb_before) ap += own; if (flags & (1u << j)) ap += gr_value(gq[j]); }
+                if (nb_n > 3u) {                                          // (block-uniform; most tiles overlap two or three others)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const uint4 e = td.e[3 + j];
+                        gq[j] = gr4{0u, s, 0u, s};
+                        if (flags & (8u << j)) gq[j] = gr_load(rd_off, e.z + (pos - e.x));
+                    }
+                    wait3(3);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { if ((uint32_t)(3 + j) == nb_before) ap += own; if (flags & (8u << j)) ap += gr_value(gq[j]); }
+                    if (nb_before >= 6u) ap += own;
+                } else if (nb_before >= 3u) ap += own;
+                if (VB) ap += kPriorAlpha;
+                xv = x_of(ap, len);
+                if (home) {
+                    const double gate = a.check_mode ? av : ap;           // :852 vs :499
+                    if (gate > kCheckCutoff) {
+                        const double rel = fabs(av - ap) / ap;
+                        if (rel > lm) lm = rel;                            // NaN never wins, as in the reference (:854)
+                        if (rel > a.tol) ncv = 1u;
+                        if (lm < 0.0) lm = 0.0;                            // gated at least once
+                    }
+                    if (ft.y > ft.x) gr_store(a.xpub_off, ft.x, xv, s);   // a far target: its x for the tiles that hold it as a far member
+                }
+            }
+            // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
+            for (int o = kWave / 2; o > 0; o >>= 1) { const double m = __shfl_down(lm, o, kWave); if (m > lm) lm = m; }
+            if (lane == 0u) wmax[(s & 1u) * (kSweepBlock / kWave) + wave] = lm;
+            if (__any(ncv != 0u) && lane == 0u) sctl[2u + (s & 1u)] = 1u;
+        } else if (has) xv = x_first(pos);
+        if (a.ablate == 3 && s == 2u && blockIdx.x == 0u && tid == 0u) {      // tests: tile 0 gives up here -- every tile must leave, the host repeats the run
+            __hip_atomic_store(&ctl[kCtlAbort * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sctl[1] = 1u;
+        }
+        // the thread's first two far members (few tiles have any): class, far slot, x
+        uint32_t esc_tag0 = kSingle, esc_f0 = 0u, esc_tag1 = kSingle, esc_f1 = 0u;
+        if (has_esc0) { esc_tag0 = a.esc_cls[e0 + tid]; esc_f0 = a.esc_far[e0 + tid]; }
+        if (has_esc1) { esc_tag1 = a.esc_cls[e0 + tid + kSweepBlock]; esc_f1 = a.esc_far[e0 + tid + kSweepBlock]; }
+        double esc_x0 = 0.0, esc_x1 = 0.0;
+        if (has_esc0 && !(esc_tag0 & kSingle)) esc_x0 = far_x(esc_f0, s, 1u);
+        if (has_esc1 && !(esc_tag1 & kSingle)) esc_x1 = far_x(esc_f1, s, 1u);
+        for (uint32_t i = tid; i < nc; i += kSweepBlock) den[i] = 0.0;
+        for (uint32_t i = tid; i < nf; i += kSweepBlock) facc[i] = 0.0;
+        if (tid == 0u) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[a.den_cap] = 0.0; }      // (den_cap: the plan's null class)
+        if (has) { xs[tid] = xv; acc[tid] = 0.0; }
+        __syncthreads();
+        if ((sctl[1] | sctl[4u + ((s + 1u) & 1u)]) != 0u) { k_done = 0xFFFFFFFFu; break; }      // some tile gave up (seen in this head, or in the phases of the step before): leave as one
+        if (s > 0u) {
+            const uint32_t sv = sctl[0];
+            if (sv != 0u) { k_done = s - 1u; conv_last = (sv & 2u) != 0u; break; }
+            // update s is final: alpha <- alpha' (home), and the block's word on it
+            if (home) a.alpha[pos] = ap;
+            if (tid == 0u) {
+                const uint32_t shard = blockIdx.x & (kShards - 1u);
+                if (sctl[2u + (s & 1u)] != 0u) {
+                    const unsigned long long old = atomicMax(&ctl[(kCtlNotConv + shard) * kCtlStride], (unsigned long long)s);
+                    asm volatile("" :: "v"(old) : "memory");              // (the maximum is in place before the arrival is counted)
+                    sctl[2u + (s & 1u)] = 0u;
+                }
+                __hip_atomic_fetch_add(&ctl[(kCtlArrive + (s & 3u) * kShards + shard) * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        uint4 sl_first = make_uint4(0u, 0u, 0u, 0u); uint32_t hdr_first = 0u;
+        if (g0 < n8) { sl_first = slots8[tid]; hdr_first = hdrs[tid]; }
+
+        // ================= A: denominators =================
+        {
+            auto den_slots = [&](const uint4& s4, uint32_t hdr) {
+                uint32_t cur = hdr & 0x1FFFu;
+                const uint32_t mask = hdr >> 16;
+                double run = xs[s4.x & 0xFFFFu];
+                auto step = [&](uint32_t k, uint32_t slot) {
+                    const double v = xs[slot];
+                    if (mask & (1u << k)) { atomicAdd(&den[cur], run); ++cur; run = v; } else run += v;
+                };
+                step(1, s4.x >> 16); step(2, s4.y & 0xFFFFu); step(3, s4.y >> 16); step(4, s4.z & 0xFFFFu);
+                step(5, s4.z >> 16); step(6, s4.w & 0xFFFFu); step(7, s4.w >> 16);
+                atomicAdd(&den[cur], run);
+            };
+            const uint32_t q1 = tid + kSweepBlock, q2 = tid + 2u * kSweepBlock;
+            const bool in1 = q1 * kPerLane < n8, in2 = q2 * kPerLane < n8;
+            uint4 sl1 = make_uint4(0u, 0u, 0u, 0u), sl2 = sl1; uint32_t hd1 = 0u, hd2 = 0u;
+            if (in1) { sl1 = slots8[q1]; hd1 = hdrs[q1]; }
+            if (in2) { sl2 = slots8[q2]; hd2 = hdrs[q2]; }
+            if (g0 < n8) den_slots(sl_first, hdr_first);
+            if (in1) den_slots(sl1, hd1);
+            if (in2) den_slots(sl2, hd2);
+            for (uint32_t q = tid + 3u * kSweepBlock; q * kPerLane < n8; q += kSweepBlock) den_slots(slots8[q], hdrs[q]);
+            if (esc_x0 != 0.0) atomicAdd(&den[(esc_tag0 >> 16) & 0x1FFFu], esc_x0);
+            if (esc_x1 != 0.0) atomicAdd(&den[(esc_tag1 >> 16) & 0x1FFFu], esc_x1);
+            for (uint32_t i = tid + 2u * kSweepBlock; i < n_esc; i += kSweepBlock) {
+                const uint32_t tag = a.esc_cls[e0 + i];
+                if (tag & kSingle) continue;
+                const double v = far_x(a.esc_far[e0 + i], s, 4u + (s & 1u));
+                if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
+            }
+        }
+        uint32_t cw[kCntAhead];                                             // bit 31: singleton class
+#pragma unroll
+        for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; cw[i] = (c < nc) ? a.counts[c0 + c] : 0u; }
+        __syncthreads();
+        // ================= B: count / denom per class (:260-264; singletons carry the full count :275 / :364) =================
+        auto invert = [&](uint32_t c, uint32_t cwc) {
+            const double cnt = (double)(cwc & 0x7FFFFFFFu);
+            const double d = den[c];
+            den[c] = (cwc >> 31) ? cnt : ((d > kTiny) ? cnt / d : 0.0);
+        };
+#pragma unroll
+        for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
+        for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, a.counts[c0 + c]);
+        uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u;
+        const bool pc_in0 = tid < np, pc_in1 = tid + kSweepBlock < np;
+        if (pc_in0) { pc_e0 = pure[tid]; pc_s0 = slot0_p[tid]; }
+        if (pc_in1) { pc_e1 = pure[tid + kSweepBlock]; pc_s1 = slot0_p[tid + kSweepBlock]; }
+        __syncthreads();
+        // ================= C: the window (a gather over the transcript-major copy) =================
+        {
+            auto pure_chunk = [&](const uint4& e4, uint32_t sf) {
+                const double q0 = den[e4.x & 0x1FFFu], q1 = den[(e4.x >> 16) & 0x1FFFu], q2 = den[e4.y & 0x1FFFu], q3 = den[(e4.y >> 16) & 0x1FFFu];
+                const double q4 = den[e4.z & 0x1FFFu], q5 = den[(e4.z >> 16) & 0x1FFFu], q6 = den[e4.w & 0x1FFFu], q7 = den[(e4.w >> 16) & 0x1FFFu];
+                const double sum = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
+                const uint32_t slot = sf & 0x7FFFu;
+                const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;
+                if (v != 0.0) atomicAdd(&acc[slot], v);
+            };
+            if (pc_in0) pure_chunk(pc_e0, pc_s0);
+            if (pc_in1) pure_chunk(pc_e1, pc_s1);
+            for (uint32_t ch = tid + 2u * kSweepBlock; ch < np; ch += kSweepBlock) pure_chunk(pure[ch], slot0_p[ch]);
+            const uint4* __restrict__ mixed = pure + np;
+            for (uint32_t ch = tid; ch < nm; ch += kSweepBlock) {
+                const uint4 e4 = mixed[2u * ch], s4 = mixed[2u * ch + 1u];
+                uint32_t cur = s4.x & 0xFFFFu;
+                double sum = 0.0;
+                auto flush_run = [&]() {
+                    const uint32_t slot = cur & 0x7FFFu;
+                    const double v = (cur & kCscSingleBit) ? sum : xs[slot] * sum;
+                    if (v != 0.0) atomicAdd(&acc[slot], v);
+                };
+                auto entry = [&](uint32_t cls, uint32_t sfk) {
+                    if (sfk != cur) { flush_run(); cur = sfk; sum = 0.0; }
+                    sum += den[cls & 0x1FFFu];
+                };
+                entry(e4.x & 0xFFFFu, s4.x & 0xFFFFu); entry(e4.x >> 16, s4.x >> 16); entry(e4.y & 0xFFFFu, s4.y & 0xFFFFu); entry(e4.y >> 16, s4.y >> 16);
+                entry(e4.z & 0xFFFFu, s4.z & 0xFFFFu); entry(e4.z >> 16, s4.z >> 16); entry(e4.w & 0xFFFFu, s4.w & 0xFFFFu); entry(e4.w >> 16, s4.w >> 16);
+                flush_run();
+            }
+            auto esc_add = [&](uint32_t tag, uint32_t f, double xval) {          // a far member: into the tile's far slot
+                const double q = den[(tag >> 16) & 0x1FFFu];
+                const double contrib = (tag & kSingle) ? q : xval * q;
+                if (contrib != 0.0) atomicAdd(&facc[f], contrib);
+            };
+            if (has_esc0) esc_add(esc_tag0, esc_f0, esc_x0);
+            if (has_esc1) esc_add(esc_tag1, esc_f1, esc_x1);
+            for (uint32_t i = tid + 2u * kSweepBlock; i < n_esc; i += kSweepBlock) {
+                const uint32_t tag = a.esc_cls[e0 + i], f = a.esc_far[e0 + i];
+                esc_add(tag, f, (tag & kSingle) ? 0.0 : far_x(f, s, 4u + (s & 1u)));
+            }
+        }
+        __syncthreads();
+        // ================= D: publish the window and the far slots: granules with tag s + 1 =================
+        if (has) gr_store(a.part_off[(s + 1u) & 1u], off + tid, acc[tid], s + 1u);
+        for (uint32_t f = tid; f < nf; f += kSweepBlock) gr_store(a.far_off[(s + 1u) & 1u], f0 + f, facc[f], s + 1u);
+        // (no barrier here: what the next head clears or writes before its own barrier -- xs[tid], acc[tid], den, facc[f] -- was last read
+        //  in phase C, behind the barrier above, or is this thread's own slot of phase D)
+    }
+
+    // ================= the loop has ended =================
+    const uint32_t tid = tid0, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (k_done == 0xFFFFFFFFu) { if (tid == 0u) *a.status = 1u; return; }
+    if (k_done > 0u) {
+        if (lane == 0u) a.tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + wave] = wmax[(k_done & 1u) * (kSweepBlock / kWave) + wave];
+        // positions no window holds are inactive transcripts here (a plan with far-only transcripts does not run persistent):
+        // every update leaves them at the prior (VBEM, :318) or at 0
+        const uint32_t n_unc = *a.unc_n;
+        for (uint32_t j = tid * gridDim.x + blockIdx.x; j < n_unc; j += kSweepBlock * gridDim.x) a.alpha[a.unc[j]] = VB ? kPriorAlpha : 0.0;
+    }
+    if (blockIdx.x == 0u && tid == 0u) {
+        EmState* st = a.st;
+        st->it_a = k_done; st->itv[0] = st->itv[1] = k_done;
+        if (k_done > 0u) st->notconv3[(k_done - 1u) % 3u] = conv_last ? 0u : 1u;
+    }
+}
