@@ -123,6 +123,48 @@ __device__ __forceinline__ double vb_x_lean(double a, double c, double len) {
     return y * exp(-q) / len;
 }
 
+// The same for the kernels that are short of registers AND of issue slots (the fused sweep, the persistent loop: every thread of a
+// window slot evaluates this once per iteration, ~9 wavefronts per tile on a dependent chain).  One division instead of three
+// (n / d, 1 / y and 1 / effLen share the reciprocal of d y effLen) and an exp of its own: k = rint(t log2 e), r = t - k ln 2 in two
+// pieces, the Taylor polynomial to r^13 (|r| <= ln 2 / 2: the remainder is below 4e-18), ldexp -- no special cases: the argument lies
+// in (-200, 0] (alpha >= the prior 0.01, c = psi(M prior + numMapped) < 50).  Its 15 constants sit in constant memory: as literals
+// the compiler keeps them in VGPR pairs across the persistent loop and spills them.  ~70 instructions against ~150; agrees with
+// exp(digamma_pos(a) - c) / len to a few ulp (tests/test_gpu_parity.py holds every loop to the oracle at 1e-9).
+struct VbConsts { double l2e, ln2_hi, ln2_lo, c[12]; double s[7]; };
+__device__ __constant__ VbConsts kVb = {
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0,
+     1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5},
+    {1.0 / 12.0, 691.0 / 32760.0, 1.0 / 132.0, 1.0 / 240.0, 1.0 / 252.0, 1.0 / 120.0, 1.0 / 12.0}};
+__device__ __forceinline__ double vb_x_fast(double a, double c, double len) {
+    double y = a, n = 0.0, d = 1.0;
+    if (a < 10.0) {
+        n = 1.0; d = a;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) { const double t = a + (double)k; n = fma(n, t, d); d = d * t; }
+        y = a + 10.0;
+    }
+    const double dy = d * y;
+    const double R = 1.0 / (dy * len);                                 // the one division
+    const double inv = (d * len) * R;                                  // 1 / y
+    const double rlen = dy * R;                                        // 1 / effLen
+    const double inv2 = inv * inv;
+    const VbConsts& K = kVb;
+    double s = fma(-inv2, K.s[0], K.s[1]);                              // inv2 (1/12 - inv2 (1/120 - inv2 (1/252 - inv2 (1/240 - inv2 (1/132 - inv2 (691/32760 - inv2 / 12))))))
+    s = fma(-inv2, s, K.s[2]); s = fma(-inv2, s, K.s[3]); s = fma(-inv2, s, K.s[4]); s = fma(-inv2, s, K.s[5]); s = fma(-inv2, s, K.s[6]);
+    s = s * inv2;
+    // t = -(c + n / d + 1 / (2 y) + s)   (n / d = n y effLen R)
+    const double t = -(c + fma(n * y, len * R, fma(0.5, inv, s)));
+    const double kf = rint(t * K.l2e);
+    double r = fma(-kf, K.ln2_hi, t);
+    r = fma(-kf, K.ln2_lo, r);
+    double p = K.c[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = fma(p, r, K.c[i]);
+    p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    return ldexp(p * y, (int)kf) * rlen;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     return v;
@@ -1589,6 +1631,7 @@ struct sfgpu_em {
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
     uint32_t far_cap = 0;
     bool persist = false;                                   // this optimize() runs as one launch
+    PersistCold h_pcold{};                                  // ... the part of its arguments it reads from device memory, staged for the copy
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     EmState* d_state = nullptr;
@@ -1883,7 +1926,7 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P) {
     }
     // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    em->xbuf_bytes = up((size_t)kCtlWords * 8 + 64) + 2 * up((size_t)(P ? P : 1) * 16) + 3 * up((size_t)En * 16);
+    em->xbuf_bytes = up((size_t)kCtlWords * 8 + 64 + sizeof(PersistCold)) + 2 * up((size_t)(P ? P : 1) * 16) + 3 * up((size_t)En * 16);
     SF_HIP(pool_malloc(&em->xbuf, em->xbuf_bytes));
     return SFGPU_OK;
 }
@@ -2440,7 +2483,7 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
 
 // ---- the persistent loop (em_persist.h): eligibility, and the launch ----
 static std::mutex g_persist_mu[16];          // per device: two persistent launches of this process never share the chip (each needs ALL its blocks resident)
-static size_t em_persist_lds(const sfgpu_em* em) { return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32; }
+static size_t em_persist_lds(const sfgpu_em* em) { return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + 2 * (size_t)em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32 + 64; }
 static const void* em_persist_func(bool vb) {
     return vb ? reinterpret_cast<const void*>(&k_em_persist<true>) : reinterpret_cast<const void*>(&k_em_persist<false>);
 }
@@ -2475,24 +2518,34 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     unsigned char* q = em->xbuf;
     SF_HIP(hipMemsetAsync(q, 0, em->xbuf_bytes, em->cur));   // tags, counters, abort word, status: zeroed before EVERY launch
-    PersistArgs a{};
-    a.ctl = reinterpret_cast<unsigned long long*>(q); a.status = reinterpret_cast<uint32_t*>(q + (size_t)kCtlWords * 8);
+    PersistArgs a{}; PersistCold c{};
+    a.ctl = reinterpret_cast<unsigned long long*>(q); c.status = reinterpret_cast<uint32_t*>(q + (size_t)kCtlWords * 8);
+    PersistCold* d_cold = reinterpret_cast<PersistCold*>(q + (size_t)kCtlWords * 8 + 64);
+    a.cold = d_cold;
     a.xbuf = q; a.xbuf_bytes = (uint32_t)em->xbuf_bytes;
-    size_t o = up((size_t)kCtlWords * 8 + 64);
+    size_t o = up((size_t)kCtlWords * 8 + 64 + sizeof(PersistCold));
     a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
-    a.far_off[0] = (uint32_t)o; o += up(En * 16); a.far_off[1] = (uint32_t)o; o += up(En * 16); a.xpub_off = (uint32_t)o;
-    a.td = em->td; a.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
+    c.far_off[0] = (uint32_t)o; o += up(En * 16); c.far_off[1] = (uint32_t)o; o += up(En * 16); c.xpub_off = (uint32_t)o;
+    a.tiles = em->td; c.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
     a.stream = em->lstream; a.chdr = em->chdr; a.counts = em->counts32; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
-    a.x = em->x; a.inv = em->inv;
+    c.x = em->x; c.inv = em->inv;
     a.lenc = em->inv ? em->lencP : em->lenc; a.alpha = em->inv ? em->alphaP : em->alpha;
-    a.esc_cls = em->esc_cls; a.esc_far = em->esc_far; a.far_pos = em->far_pos; a.far_xi = em->far_xi; a.ftgt = em->ftgt; a.ft_list = em->ft_list;
-    a.unc = em->unc; a.unc_n = em->unc + em->prob.M;
-    a.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
+    c.esc_cls = em->esc_cls; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;
+    c.unc = em->unc; c.unc_n = em->unc + em->prob.M;
+    c.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
     a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.ablate = ablate;
+#ifdef SFGPU_P_STAMP
+    if (!em->dbg) SF_HIP(pool_malloc(&em->dbg, (size_t)em->n_tiles * 16 * 8));
+    c.dbg = em->dbg;
+#endif
+    // (the cold block goes to device memory behind the control words; the copy's source is the handle's own staging block, which the stream
+    //  has read before the next optimize() can write it -- finish() waits)
+    em->h_pcold = c;
+    SF_HIP(hipMemcpyAsync(d_cold, &em->h_pcold, sizeof(PersistCold), hipMemcpyHostToDevice, em->cur));
     void* args[] = {&a};
     SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kSweepBlock), args, em_persist_lds(em), em->cur));
     // (the launch's verdict, next to the plan's words in pinned memory; read behind finish()'s wait)
-    SF_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t*>(em->h_plan + 7), a.status, 4, hipMemcpyDeviceToHost, em->cur));
+    SF_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t*>(em->h_plan + 7), c.status, 4, hipMemcpyDeviceToHost, em->cur));
     return SFGPU_OK;
 }
 
@@ -2651,6 +2704,21 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         if (stats) *stats = st;
         return SFGPU_ERR_NO_ACTIVE;
     }
+#ifdef SFGPU_P_STAMP
+    if (em->persist && em->dbg && st.iters > 2) {          // dev: where a persistent step goes, per tile (100 MHz clock)
+        std::vector<unsigned long long> h((size_t)em->n_tiles * 8);
+        (void)hipMemcpy(h.data(), em->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        static const char* nm[7] = {"operands", "x+update", "barrier", "A", "B", "C", "D"};
+        const double steps = (double)st.iters + 1.0;
+        fprintf(stderr, "persist stamps (%s, %u tiles, %u steps; us per step and tile, mean / min / max over the tiles):", em->opts.use_vbem ? "VBEM" : "EM", em->n_tiles, st.iters + 1);
+        for (int k = 0; k < 7; ++k) {
+            double sum = 0, mn = 1e30, mx = 0;
+            for (uint32_t b = 0; b < em->n_tiles; ++b) { const double v = (double)h[b * 8 + k] * 0.01 / steps; sum += v; mn = std::min(mn, v); mx = std::max(mx, v); }
+            fprintf(stderr, " %s %.2f/%.2f/%.2f", nm[k], sum / em->n_tiles, mn, mx);
+        }
+        fprintf(stderr, "\n");
+    }
+#endif
 #ifdef SFGPU_X_STAMP
     if (em->dbg) {                                          // dev: phase stamps of the last launch that ran (100 MHz clock)
         std::vector<unsigned long long> h((size_t)em->n_tiles * 16);

@@ -107,29 +107,48 @@ __global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const ui
     if (r.y - r.x > kFanInMax) atomicOr(&pflags[0], 4u);
 }
 
-struct PersistArgs {
-    const TileDesc* td; EmState* st; uint32_t min_iter, max_iter, n_tiles; int check_mode;
-    const uint32_t* stream; const uint32_t* chdr; const uint32_t* counts;
-    const unsigned char* csc; const uint16_t* csc_slot0;
-    const double* x; const uint32_t* inv;                 // x of sweep 0 (init made it, in the caller's order); position -> transcript
-    const double* lenc; double* alpha;                    // by position of the plan's order
-    // the exchange buffer: ONE buffer descriptor, the pieces by byte offset -- granules of the window sums, slot-major
-    // (TileDesc::off + slot), by tag parity; granules of the far slots, by tag parity; granules of the far targets' x
-    void* xbuf; uint32_t xbuf_bytes, part_off[2], far_off[2], xpub_off;
+// What the kernel reads in rare paths only (far members, the first sweep, the end of the loop) sits in DEVICE MEMORY and is fetched where
+// it is used: as by-value arguments these words would be loop invariants held in SGPRs for the whole run -- 80 are to be had at 8 waves
+// per SIMD, and what does not fit is spilled into VGPR lanes and fetched back with a v_readlane apiece all over the hot phases.
+// (Measured the other way round too, profiles/r5_em_notes.md: EVERYTHING read through memory at each phase's start costs a dependent scalar
+//  round trip per phase, 16 -> 21 us per step on cfg3.)
+struct PersistCold {
+    EmState* st; const double* x; const uint32_t* inv;    // x of sweep 0 (init made it, in the caller's order); position -> transcript
     const uint32_t* esc_cls; const uint32_t* esc_far;     // per escape: class << 16 | single ; far slot in the tile
     const uint32_t* far_pos; const uint32_t* far_xi;      // per far slot (TileDesc::f0 + f): target position ; index of its x granule
-    const uint2* ftgt; const uint32_t* ft_list;           // per position: [k0, k1) of ft_list = the far slots that feed it, in tile order (null: no far members)
-    unsigned long long* ctl;                              // kCtlWords control words (zeroed before the launch)
+    const uint32_t* ft_list;                              // the far slots that feed a position, in tile order (ranges: PersistArgs::ftgt)
+    uint32_t far_off[2], xpub_off;                        // exchange buffer: granules of the far slots (by tag parity), of the far targets' x
     const uint32_t* unc; const uint32_t* unc_n;           // positions no window holds (inactive transcripts)
-    double* tmax; double tol, log_norm;
+    double* tmax; uint32_t* status;                       // status: 0 = ran to the stop, 1 = gave up (see above)
+    unsigned long long* dbg;                              // SFGPU_P_STAMP builds: [tile][8] time spent per phase, summed over the steps (10 ns units)
+};
+struct PersistArgs {
+    const TileDesc* tiles; const PersistCold* cold;
+    uint32_t min_iter, max_iter, n_tiles; int check_mode;
+    const uint32_t* stream; const uint32_t* chdr; const uint32_t* counts;
+    const unsigned char* csc; const uint16_t* csc_slot0;
+    const double* lenc; double* alpha;                    // by position of the plan's order
+    const uint2* ftgt;                                    // per position: [k0, k1) of ft_list (null: the plan has no far members)
+    // the exchange buffer: ONE buffer descriptor, the pieces by byte offset; part_off: granules of the window sums, slot-major
+    // (TileDesc::off + slot), by tag parity
+    void* xbuf; uint32_t xbuf_bytes, part_off[2];
+    unsigned long long* ctl;                              // kCtlWords control words (zeroed before the launch)
+    double tol, log_norm;
     uint32_t den_cap, far_cap;                            // LDS: den[den_cap + 1] (den_cap = the plan's null class), facc[far_cap]
-    uint32_t* status;                                     // 0: ran to the stop; 1: gave up (see above)
     int ablate;                                           // dev: 1 = no tag checks (timing only: wrong results); 3 = tile 0 gives up in step 2 (tests)
 };
 
 __device__ __forceinline__ double gr_value(const gr4& g) { return __hiloint2double((int)g.z, (int)g.x); }
 __device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y == tag && g.w == tag; }
 
+#ifdef SFGPU_P_STAMP
+#define SFP_STAMP(k) do { if (tid == 0u) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = wall_clock64(); pst[k] += t_ - pst[7]; pst[7] = t_; } } while (0)
+#else
+#define SFP_STAMP(k) do { } while (0)
+#endif
+// the cold block / the tile's record, looked at from a rare path: the pointer is made opaque THERE, so no load of it is hoisted out
+#define SFP_COLD(name) const PersistCold* name = a.cold; asm volatile("" : "+s"(name))
+#define SFP_TILE(name) const TileDesc* name = a.tiles + blockIdx.x; asm volatile("" : "+s"(name))
 template <bool VB>
 __global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_em_persist(PersistArgs a) {
@@ -138,23 +157,50 @@ k_em_persist(PersistArgs a) {
     double* const acc = xs + (kWin + 2);                   // [kWin + 1]
     double* const den = acc + (kWin + 2);                  // [den_cap + 1]  denominators, then count / denom (+ the null class at den_cap)
     double* const facc = den + (a.den_cap + 2);            // [far_cap]
-    double* const wmax = facc + a.far_cap;                 // [2][waves]: the wavefronts' largest relative change, by update parity
+    double* const fxs = facc + a.far_cap;                  // [far_cap]  x of the far slots' transcripts, fetched once per step (head)
+    double* const wmax = fxs + a.far_cap;                  // [2][waves]: the wavefronts' largest relative change, by update parity
     uint32_t* const sctl = reinterpret_cast<uint32_t*>(wmax + 2 * (kSweepBlock / kWave));     // [0] stop, [1] abort (heads), [2..3] block saw a change > tol (by step parity), [4..5] abort (phases, by step parity)
-
-    const TileDesc td = a.td[blockIdx.x];
-    const uint32_t c0 = td.c0, nc = td.nc, lo = td.lo, span = td.span, n8 = td.n8, n_esc = td.n_esc;
-    const uint64_t s0 = td.s0, e0 = td.e0;
-    const uint32_t off = (uint32_t)td.off;
-    const uint32_t nb_n = td.nb_n, nb_before = td.nb_before, f0 = td.f0, nf = td.nf;
+#ifdef SFGPU_P_STAMP
+    unsigned long long* const pst = reinterpret_cast<unsigned long long*>(sctl + 8);       // [0..6] phase sums, [7] the last stamp
+    if (threadIdx.x == 0) { for (int k = 0; k < 7; ++k) pst[k] = 0ull; pst[7] = wall_clock64(); }
+#endif
     const uint32_t tid0 = threadIdx.x;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, a.xbuf_bytes, 0x00020000);
-    auto gr_load = [&](uint32_t piece_off, uint32_t idx) -> gr4 { return __builtin_amdgcn_raw_buffer_load_b128(rx, idx * 16u, piece_off, 16); };      // sc1
-    auto gr_store = [&](uint32_t piece_off, uint32_t idx, double v, uint32_t tag) {
-        gr4 w; w.x = (uint32_t)__double2loint(v); w.y = tag; w.z = (uint32_t)__double2hiint(v); w.w = tag;
-        __builtin_amdgcn_raw_buffer_store_b128(w, rx, idx * 16u, piece_off, 16);                                                                   // sc1: write-through
-    };
+    // ---- the tile: what the hot phases need, as scalars; the rest of the record (e0, f0) is read where a far member needs it
+    uint32_t lo, n8, nc, np, nm, n_esc, nf, off, nb_n, nb_before, delta[kNbMax];
+    const uint4* __restrict__ slots8; const uint32_t* __restrict__ hdrs; const uint32_t* __restrict__ cnt;
+    const uint4* __restrict__ pure; const uint16_t* __restrict__ slot0_p;
+    uint32_t flags;
+    // ---- what a thread keeps for the whole run: which of the overlapping tiles hold the position of its window slot (bits 0..5), whether
+    //      it has a slot (bit 30) and whether this tile is the position's home (bit 31).  Everything else it needs per step (effLen,
+    //      alpha, the far slots that feed it) is read again every step: registers are what this kernel is short of (64 per thread at
+    //      two blocks per CU), and those words sit in the L2.
+    {
+        const TileDesc t = a.tiles[blockIdx.x];
+        lo = t.lo; n8 = t.n8; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before;
+        slots8 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.stream) + t.s0);
+        hdrs = a.chdr + (t.s0 >> 3); cnt = a.counts + t.c0;
+        pure = reinterpret_cast<const uint4*>(a.csc + t.qb); slot0_p = a.csc_slot0 + t.pr;
+        const uint32_t span = t.span, pos0 = lo + tid0;
+        flags = tid0 < span ? 0x40000000u : 0u;
+        bool home = tid0 < span;
+#pragma unroll
+        for (int j = 0; j < kNbMax; ++j) {
+            const uint4 e = t.e[j];                                      // {lo', span', off', tile'}
+            delta[j] = e.z - e.x;                                        // the slot of position p in that tile's piece: p + delta
+            const bool in = tid0 < span && (uint32_t)j < nb_n && (pos0 - e.x) < e.y;
+            if (in) { flags |= 1u << j; if ((uint32_t)j < nb_before) home = false; }
+        }
+        if (home) flags |= 0x80000000u;
+    }
+    const double* __restrict__ lenc = a.lenc + lo; double* __restrict__ alpha = a.alpha + lo;
+    const uint2* __restrict__ ftgt = a.ftgt ? a.ftgt + lo : nullptr;
     unsigned long long* const ctl = a.ctl;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, a.xbuf_bytes, 0x00020000);
+    auto gr_load = [&](uint32_t piece_off, uint32_t idx) -> gr4 { return __builtin_amdgcn_raw_buffer_load_b128(rx, idx * 16u, piece_off, 16); };      // sc1: past the L1
+    auto gr_store = [&](uint32_t piece_off, uint32_t idx, double v, uint32_t tag) {                                                                    // sc1: write-through
+        gr4 w; w.x = (uint32_t)__double2loint(v); w.y = tag; w.z = (uint32_t)__double2hiint(v); w.w = tag;
+        __builtin_amdgcn_raw_buffer_store_b128(w, rx, idx * 16u, piece_off, 16);
+    };
     // a wait that does not end: look at the abort word now and then, give up after ~1 s (returns true when the wait must be left)
     // (`word`: the block's abort word this wait reports to -- sctl[1] for the waits of a head, sctl[4 + step parity] for those inside
     //  the phases: every word is read by ALL threads behind ONE barrier that no writer of it can have passed, so the block leaves as one)
@@ -169,44 +215,20 @@ k_em_persist(PersistArgs a) {
         }
         return false;
     };
-
-    // ---- what a thread keeps for the whole run: its window slot (position lo + tid0), which of the overlapping tiles hold that
-    //      position (bits 0..5), whether it has a slot (bit 30) and whether this tile is the position's home (bit 31).  Everything else
-    //      it needs per step (effLen, alpha, its far members, the far slots that feed it) is read again every step: registers are
-    //      what this kernel is short of (64 per thread at two blocks per CU), and those words sit in the L2.
-    const uint32_t pos0 = lo + tid0;
-    uint32_t flags = tid0 < span ? 0x40000000u : 0u;
-    {
-        bool home = tid0 < span;
-#pragma unroll
-        for (int j = 0; j < kNbMax; ++j) {
-            const uint4 e = td.e[j];                                     // {lo', span', off', tile'}
-            const bool in = tid0 < span && (uint32_t)j < nb_n && (pos0 - e.x) < e.y;
-            if (in) { flags |= 1u << j; if ((uint32_t)j < nb_before) home = false; }
-        }
-        if (home) flags |= 0x80000000u;
-    }
     if (tid0 < 8u) sctl[tid0] = 0u;
-    if (tid0 < kSweepBlock) acc[tid0] = 0.0;
+    acc[tid0] = 0.0;
 
-    const uint4* __restrict__ slots8 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.stream) + s0);
-    const uint32_t* __restrict__ hdrs = a.chdr + (s0 >> 3);
-    const uint4* __restrict__ pure = reinterpret_cast<const uint4*>(a.csc + td.qb);
-    const uint16_t* __restrict__ slot0_p = a.csc_slot0 + td.pr;
-    const uint32_t np = td.np, nm = td.nm;
-
-    auto x_of = [&](double ap, double l) -> double {
-        if (VB) return (ap > kTiny) ? sweep_x<true>(vb_x_lean(ap, a.log_norm, l)) : 0.0;       // :300-320
-        return sweep_x<false>(ap / l);
+    auto x_of = [&](double ap_, double l) -> double {
+        if (VB) return (ap_ > kTiny) ? sweep_x<true>(vb_x_fast(ap_, a.log_norm, l)) : 0.0;       // :300-320
+        return sweep_x<false>(ap_ / l);
     };
-    auto x_first = [&](uint32_t p) -> double { return a.x[a.inv ? a.inv[p] : p]; };
-    // x of the far member behind far slot f of this tile, for sweep s: sweep 0 reads the x vector, later sweeps the granule the
-    // transcript's home thread published at the head of its step s
-    auto far_x = [&](uint32_t f, uint32_t s, uint32_t word) -> double {
-        if (s == 0u) return x_first(a.far_pos[f0 + f]);
-        const uint32_t xi = a.far_xi[f0 + f];
-        gr4 g = gr_load(a.xpub_off, xi);
-        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, s);) { if (spin_check(spins, word)) break; g = gr_load(a.xpub_off, xi); }
+    // x of the far member behind far slot f of this tile (f0: the tile's first), for sweep s: sweep 0 reads the x vector, later sweeps
+    // the granule the transcript's home thread published at the head of its step s
+    auto far_x = [&](const PersistCold* cp, uint32_t f0, uint32_t f, uint32_t s, uint32_t word) -> double {
+        if (s == 0u) { const uint32_t p = cp->far_pos[f0 + f]; const uint32_t* inv = cp->inv; return cp->x[inv ? inv[p] : p]; }
+        const uint32_t xi = cp->far_xi[f0 + f], xo = cp->xpub_off;
+        gr4 g = gr_load(xo, xi);
+        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, s);) { if (spin_check(spins, word)) break; g = gr_load(xo, xi); }
         return gr_value(g);
     };
     __syncthreads();
@@ -218,23 +240,35 @@ k_em_persist(PersistArgs a) {
         //  a dozen 64-bit pointers -- out of the loop and spills them)
         uint32_t tid = tid0;
         asm volatile("" : "+v"(tid));
-        const uint32_t lane = tid & (kWave - 1), wave = tid / kWave, pos = lo + tid, g0 = tid * kPerLane;
-        const bool has_esc0 = tid < n_esc, has_esc1 = tid + kSweepBlock < n_esc;
+        const uint32_t lane = tid & (kWave - 1), wave = tid / kWave, g0 = tid * kPerLane;
         // ================= head of step s: [the stop test of update s - 1] update s, x of sweep s =================
         const bool has = (flags & 0x40000000u) != 0u, home = (flags & 0x80000000u) != 0u;
-        const uint32_t rd_off = a.part_off[s & 1u], frd_off = a.far_off[s & 1u];      // sums of sweep s - 1 carry tag s
-        double ap = 0.0, xv = 0.0, lm = -1.0, av = 0.0; unsigned ncv = 0u;
+        double ap_v = 0.0, xv = 0.0, lm = -1.0; unsigned ncv = 0u;
+        // phase A's stream chunks and phase B's class counts: requested in the head once the operands are in (they miss the L2 -- a tile's
+        // stream is read once per step and 64 tiles share 4 MB --, and the x arithmetic and the head's barrier hide the round trip);
+        // phase C's first chunk is requested at the start of phase A
+        const uint32_t q1 = tid + kSweepBlock, q2 = tid + 2u * kSweepBlock;
+        uint4 sl_first = make_uint4(0u, 0u, 0u, 0u), sl1 = sl_first, sl2 = sl_first; uint32_t hdr_first = 0u, hd1 = 0u, hd2 = 0u;
+        uint32_t cw[kCntAhead];                                             // bit 31: singleton class
+        auto request_stream = [&]() {
+            if (g0 < n8) { sl_first = slots8[tid]; hdr_first = hdrs[tid]; }
+            if (q1 * kPerLane < n8) { sl1 = slots8[q1]; hd1 = hdrs[q1]; }
+            if (q2 * kPerLane < n8) { sl2 = slots8[q2]; hd2 = hdrs[q2]; }
+#pragma unroll
+            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; cw[i] = (c < nc) ? cnt[c] : 0u; }
+        };
         if (s > 0u) {
+            const uint32_t rd_off = (s & 1u) ? a.part_off[1] : a.part_off[0];       // sums of sweep s - 1 carry tag s
+            const uint32_t pos = lo + tid;
             gr4 gq[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const uint4 e = td.e[j];
                 gq[j] = gr4{0u, s, 0u, s};
-                if (flags & (1u << j)) gq[j] = gr_load(rd_off, e.z + (pos - e.x));
+                if (flags & (1u << j)) gq[j] = gr_load(rd_off, pos + delta[j]);
             }
-            double len = 1.0; uint2 ft = make_uint2(0u, 0u);
-            if (has) { len = a.lenc[pos]; if (a.ftgt) ft = a.ftgt[pos]; }
-            if (home) av = a.alpha[pos];
+            double len = 1.0, av = 0.0; uint2 ft = make_uint2(0u, 0u);
+            if (has) { len = lenc[tid]; if (ftgt) ft = ftgt[tid]; }
+            if (home) av = alpha[tid];
             const double own = acc[tid];                                  // what this tile's last sweep handed the slot (cleared below)
             // wave 0: has every tile finished update s - 1, and did the loop end there?  (:820)
             if (wave == 0u && s >= 2u) {
@@ -260,77 +294,85 @@ k_em_persist(PersistArgs a) {
             }
             if (has) {
                 // the far slots that feed this transcript, in tile order: what alphaOut held in the other loops
-                for (uint32_t k = ft.x; k < ft.y; ++k) {
-                    const uint32_t g = a.ft_list[k];
-                    gr4 q = gr_load(frd_off, g);
-                    if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(q, s);) { if (spin_check(spins, 1u)) break; q = gr_load(frd_off, g); }
-                    ap += gr_value(q);
+                if (ft.y > ft.x) {
+                    SFP_COLD(cp);
+                    const uint32_t frd_off = (s & 1u) ? cp->far_off[1] : cp->far_off[0];
+                    for (uint32_t k = ft.x; k < ft.y; ++k) {
+                        const uint32_t g = cp->ft_list[k];
+                        gr4 q = gr_load(frd_off, g);
+                        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(q, s);) { if (spin_check(spins, 1u)) break; q = gr_load(frd_off, g); }
+                        ap_v += gr_value(q);
+                    }
                 }
                 // the overlapping tiles' sums, in tile order with this tile's own in its place (as the cover list); three at a time
-                auto wait3 = [&](int base) {
+                auto wait3 = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t fsh) {
                     if (a.ablate == 1) return;
                     for (uint32_t spins = 0;;) {
                         const bool ok = gr_ok(gq[0], s) && gr_ok(gq[1], s) && gr_ok(gq[2], s);
                         if (ok || spin_check(spins, 1u)) break;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) if ((flags & (1u << (base + j))) && !gr_ok(gq[j], s)) { const uint4 e = td.e[base + j]; gq[j] = gr_load(rd_off, e.z + (pos - e.x)); }
+                        if (((flags >> fsh) & 1u) && !gr_ok(gq[0], s)) gq[0] = gr_load(rd_off, pos + d0);
+                        if (((flags >> fsh) & 2u) && !gr_ok(gq[1], s)) gq[1] = gr_load(rd_off, pos + d1);
+                        if (((flags >> fsh) & 4u) && !gr_ok(gq[2], s)) gq[2] = gr_load(rd_off, pos + d2);
                     }
                 };
-                wait3(0);
+                wait3(delta[0], delta[1], delta[2], 0u);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { if ((uint32_t)j == nb_before) ap += own; if (flags & (1u << j)) ap += gr_value(gq[j]); }
+                for (int j = 0; j < 3; ++j) { if ((uint32_t)j == nb_before) ap_v += own; if (flags & (1u << j)) ap_v += gr_value(gq[j]); }
                 if (nb_n > 3u) {                                          // (block-uniform; most tiles overlap two or three others)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const uint4 e = td.e[3 + j];
                         gq[j] = gr4{0u, s, 0u, s};
-                        if (flags & (8u << j)) gq[j] = gr_load(rd_off, e.z + (pos - e.x));
+                        if (flags & (8u << j)) gq[j] = gr_load(rd_off, pos + delta[3 + j]);
                     }
-                    wait3(3);
+                    wait3(delta[3], delta[4], delta[5], 3u);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { if ((uint32_t)(3 + j) == nb_before) ap += own; if (flags & (8u << j)) ap += gr_value(gq[j]); }
-                    if (nb_before >= 6u) ap += own;
-                } else if (nb_before >= 3u) ap += own;
-                if (VB) ap += kPriorAlpha;
-                xv = x_of(ap, len);
+                    for (int j = 0; j < 3; ++j) { if ((uint32_t)(3 + j) == nb_before) ap_v += own; if (flags & (8u << j)) ap_v += gr_value(gq[j]); }
+                    if (nb_before >= 6u) ap_v += own;
+                } else if (nb_before >= 3u) ap_v += own;
+                SFP_STAMP(0);                                             // operands here
+                request_stream();
+                if (VB) ap_v += kPriorAlpha;
+                xv = x_of(ap_v, len);
                 if (home) {
-                    const double gate = a.check_mode ? av : ap;           // :852 vs :499
+                    const double gate = a.check_mode ? av : ap_v;         // :852 vs :499
                     if (gate > kCheckCutoff) {
-                        const double rel = fabs(av - ap) / ap;
+                        const double rel = fabs(av - ap_v) / ap_v;
                         if (rel > lm) lm = rel;                            // NaN never wins, as in the reference (:854)
                         if (rel > a.tol) ncv = 1u;
                         if (lm < 0.0) lm = 0.0;                            // gated at least once
                     }
-                    if (ft.y > ft.x) gr_store(a.xpub_off, ft.x, xv, s);   // a far target: its x for the tiles that hold it as a far member
+                    if (ft.y > ft.x) { SFP_COLD(cp); gr_store(cp->xpub_off, ft.x, xv, s); }      // a far target: its x for the tiles that hold it as a far member
                 }
-            }
+            } else request_stream();
             // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
             for (int o = kWave / 2; o > 0; o >>= 1) { const double m = __shfl_down(lm, o, kWave); if (m > lm) lm = m; }
             if (lane == 0u) wmax[(s & 1u) * (kSweepBlock / kWave) + wave] = lm;
             if (__any(ncv != 0u) && lane == 0u) sctl[2u + (s & 1u)] = 1u;
-        } else if (has) xv = x_first(pos);
+        } else {
+            request_stream();
+            if (has) { SFP_COLD(cp); const uint32_t* inv = cp->inv; const uint32_t p = lo + tid; xv = cp->x[inv ? inv[p] : p]; }
+        }
         if (a.ablate == 3 && s == 2u && blockIdx.x == 0u && tid == 0u) {      // tests: tile 0 gives up here -- every tile must leave, the host repeats the run
             __hip_atomic_store(&ctl[kCtlAbort * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sctl[1] = 1u;
         }
-        // the thread's first two far members (few tiles have any): class, far slot, x
-        uint32_t esc_tag0 = kSingle, esc_f0 = 0u, esc_tag1 = kSingle, esc_f1 = 0u;
-        if (has_esc0) { esc_tag0 = a.esc_cls[e0 + tid]; esc_f0 = a.esc_far[e0 + tid]; }
-        if (has_esc1) { esc_tag1 = a.esc_cls[e0 + tid + kSweepBlock]; esc_f1 = a.esc_far[e0 + tid + kSweepBlock]; }
-        double esc_x0 = 0.0, esc_x1 = 0.0;
-        if (has_esc0 && !(esc_tag0 & kSingle)) esc_x0 = far_x(esc_f0, s, 1u);
-        if (has_esc1 && !(esc_tag1 & kSingle)) esc_x1 = far_x(esc_f1, s, 1u);
         for (uint32_t i = tid; i < nc; i += kSweepBlock) den[i] = 0.0;
-        for (uint32_t i = tid; i < nf; i += kSweepBlock) facc[i] = 0.0;
+        if (nf) {                                                         // far members: the x of every far slot's transcript, once per step
+            SFP_COLD(cp); SFP_TILE(tp);
+            const uint32_t f0 = tp->f0;
+            for (uint32_t f = tid; f < nf; f += kSweepBlock) { fxs[f] = far_x(cp, f0, f, s, 1u); facc[f] = 0.0; }
+        }
         if (tid == 0u) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[a.den_cap] = 0.0; }      // (den_cap: the plan's null class)
         if (has) { xs[tid] = xv; acc[tid] = 0.0; }
+        SFP_STAMP(1);                                                     // x, the update, LDS cleared
         __syncthreads();
+        SFP_STAMP(2);                                                     // head barrier
         if ((sctl[1] | sctl[4u + ((s + 1u) & 1u)]) != 0u) { k_done = 0xFFFFFFFFu; break; }      // some tile gave up (seen in this head, or in the phases of the step before): leave as one
         if (s > 0u) {
             const uint32_t sv = sctl[0];
             if (sv != 0u) { k_done = s - 1u; conv_last = (sv & 2u) != 0u; break; }
             // update s is final: alpha <- alpha' (home), and the block's word on it
-            if (home) a.alpha[pos] = ap;
+            if (home) alpha[tid] = ap_v;
             if (tid == 0u) {
                 const uint32_t shard = blockIdx.x & (kShards - 1u);
                 if (sctl[2u + (s & 1u)] != 0u) {
@@ -341,11 +383,10 @@ k_em_persist(PersistArgs a) {
                 __hip_atomic_fetch_add(&ctl[(kCtlArrive + (s & 3u) * kShards + shard) * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        uint4 sl_first = make_uint4(0u, 0u, 0u, 0u); uint32_t hdr_first = 0u;
-        if (g0 < n8) { sl_first = slots8[tid]; hdr_first = hdrs[tid]; }
-
         // ================= A: denominators =================
+        uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u;
         {
+            if (tid < np) { pc_e0 = pure[tid]; pc_s0 = slot0_p[tid]; }
             auto den_slots = [&](const uint4& s4, uint32_t hdr) {
                 uint32_t cur = hdr & 0x1FFFu;
                 const uint32_t mask = hdr >> 16;
@@ -358,54 +399,49 @@ k_em_persist(PersistArgs a) {
                 step(5, s4.z >> 16); step(6, s4.w & 0xFFFFu); step(7, s4.w >> 16);
                 atomicAdd(&den[cur], run);
             };
-            const uint32_t q1 = tid + kSweepBlock, q2 = tid + 2u * kSweepBlock;
-            const bool in1 = q1 * kPerLane < n8, in2 = q2 * kPerLane < n8;
-            uint4 sl1 = make_uint4(0u, 0u, 0u, 0u), sl2 = sl1; uint32_t hd1 = 0u, hd2 = 0u;
-            if (in1) { sl1 = slots8[q1]; hd1 = hdrs[q1]; }
-            if (in2) { sl2 = slots8[q2]; hd2 = hdrs[q2]; }
             if (g0 < n8) den_slots(sl_first, hdr_first);
-            if (in1) den_slots(sl1, hd1);
-            if (in2) den_slots(sl2, hd2);
+            if (q1 * kPerLane < n8) den_slots(sl1, hd1);
+            if (q2 * kPerLane < n8) den_slots(sl2, hd2);
             for (uint32_t q = tid + 3u * kSweepBlock; q * kPerLane < n8; q += kSweepBlock) den_slots(slots8[q], hdrs[q]);
-            if (esc_x0 != 0.0) atomicAdd(&den[(esc_tag0 >> 16) & 0x1FFFu], esc_x0);
-            if (esc_x1 != 0.0) atomicAdd(&den[(esc_tag1 >> 16) & 0x1FFFu], esc_x1);
-            for (uint32_t i = tid + 2u * kSweepBlock; i < n_esc; i += kSweepBlock) {
-                const uint32_t tag = a.esc_cls[e0 + i];
-                if (tag & kSingle) continue;
-                const double v = far_x(a.esc_far[e0 + i], s, 4u + (s & 1u));
-                if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
+            // far members (few tiles have any): class and far slot from the plan, x from the LDS copy the head made
+            if (n_esc) {
+                SFP_COLD(cp); SFP_TILE(tp);
+                const uint64_t e0 = tp->e0;
+                for (uint32_t i = tid; i < n_esc; i += kSweepBlock) {
+                    const uint32_t tag = cp->esc_cls[e0 + i], f = cp->esc_far[e0 + i];
+                    const double v = (tag & kSingle) ? 0.0 : fxs[f];
+                    if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
+                }
             }
+            if (tid + kSweepBlock < np) { pc_e1 = pure[tid + kSweepBlock]; pc_s1 = slot0_p[tid + kSweepBlock]; }
         }
-        uint32_t cw[kCntAhead];                                             // bit 31: singleton class
-#pragma unroll
-        for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; cw[i] = (c < nc) ? a.counts[c0 + c] : 0u; }
         __syncthreads();
+        SFP_STAMP(3);                                                     // phase A + its barrier
         // ================= B: count / denom per class (:260-264; singletons carry the full count :275 / :364) =================
-        auto invert = [&](uint32_t c, uint32_t cwc) {
-            const double cnt = (double)(cwc & 0x7FFFFFFFu);
-            const double d = den[c];
-            den[c] = (cwc >> 31) ? cnt : ((d > kTiny) ? cnt / d : 0.0);
-        };
+        {
+            auto invert = [&](uint32_t c, uint32_t cwc) {
+                const double cn = (double)(cwc & 0x7FFFFFFFu);
+                const double d = den[c];
+                den[c] = (cwc >> 31) ? cn : ((d > kTiny) ? cn / d : 0.0);
+            };
 #pragma unroll
-        for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
-        for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, a.counts[c0 + c]);
-        uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u;
-        const bool pc_in0 = tid < np, pc_in1 = tid + kSweepBlock < np;
-        if (pc_in0) { pc_e0 = pure[tid]; pc_s0 = slot0_p[tid]; }
-        if (pc_in1) { pc_e1 = pure[tid + kSweepBlock]; pc_s1 = slot0_p[tid + kSweepBlock]; }
+            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
+            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, cnt[c]);
+        }
         __syncthreads();
+        SFP_STAMP(4);                                                     // phase B + its barrier
         // ================= C: the window (a gather over the transcript-major copy) =================
         {
             auto pure_chunk = [&](const uint4& e4, uint32_t sf) {
-                const double q0 = den[e4.x & 0x1FFFu], q1 = den[(e4.x >> 16) & 0x1FFFu], q2 = den[e4.y & 0x1FFFu], q3 = den[(e4.y >> 16) & 0x1FFFu];
+                const double q0 = den[e4.x & 0x1FFFu], q1_ = den[(e4.x >> 16) & 0x1FFFu], q2_ = den[e4.y & 0x1FFFu], q3 = den[(e4.y >> 16) & 0x1FFFu];
                 const double q4 = den[e4.z & 0x1FFFu], q5 = den[(e4.z >> 16) & 0x1FFFu], q6 = den[e4.w & 0x1FFFu], q7 = den[(e4.w >> 16) & 0x1FFFu];
-                const double sum = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
+                const double sum = ((q0 + q1_) + (q2_ + q3)) + ((q4 + q5) + (q6 + q7));
                 const uint32_t slot = sf & 0x7FFFu;
                 const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;
                 if (v != 0.0) atomicAdd(&acc[slot], v);
             };
-            if (pc_in0) pure_chunk(pc_e0, pc_s0);
-            if (pc_in1) pure_chunk(pc_e1, pc_s1);
+            if (tid < np) pure_chunk(pc_e0, pc_s0);
+            if (tid + kSweepBlock < np) pure_chunk(pc_e1, pc_s1);
             for (uint32_t ch = tid + 2u * kSweepBlock; ch < np; ch += kSweepBlock) pure_chunk(pure[ch], slot0_p[ch]);
             const uint4* __restrict__ mixed = pure + np;
             for (uint32_t ch = tid; ch < nm; ch += kSweepBlock) {
@@ -425,38 +461,47 @@ k_em_persist(PersistArgs a) {
                 entry(e4.z & 0xFFFFu, s4.z & 0xFFFFu); entry(e4.z >> 16, s4.z >> 16); entry(e4.w & 0xFFFFu, s4.w & 0xFFFFu); entry(e4.w >> 16, s4.w >> 16);
                 flush_run();
             }
-            auto esc_add = [&](uint32_t tag, uint32_t f, double xval) {          // a far member: into the tile's far slot
-                const double q = den[(tag >> 16) & 0x1FFFu];
-                const double contrib = (tag & kSingle) ? q : xval * q;
-                if (contrib != 0.0) atomicAdd(&facc[f], contrib);
-            };
-            if (has_esc0) esc_add(esc_tag0, esc_f0, esc_x0);
-            if (has_esc1) esc_add(esc_tag1, esc_f1, esc_x1);
-            for (uint32_t i = tid + 2u * kSweepBlock; i < n_esc; i += kSweepBlock) {
-                const uint32_t tag = a.esc_cls[e0 + i], f = a.esc_far[e0 + i];
-                esc_add(tag, f, (tag & kSingle) ? 0.0 : far_x(f, s, 4u + (s & 1u)));
+            if (n_esc) {                                                     // far members: into the tile's far slots
+                SFP_COLD(cp); SFP_TILE(tp);
+                const uint64_t e0 = tp->e0;
+                for (uint32_t i = tid; i < n_esc; i += kSweepBlock) {
+                    const uint32_t tag = cp->esc_cls[e0 + i], f = cp->esc_far[e0 + i];
+                    const double q = den[(tag >> 16) & 0x1FFFu];
+                    const double contrib = (tag & kSingle) ? q : fxs[f] * q;
+                    if (contrib != 0.0) atomicAdd(&facc[f], contrib);
+                }
             }
         }
         __syncthreads();
+        SFP_STAMP(5);                                                     // phase C + its barrier
         // ================= D: publish the window and the far slots: granules with tag s + 1 =================
-        if (has) gr_store(a.part_off[(s + 1u) & 1u], off + tid, acc[tid], s + 1u);
-        for (uint32_t f = tid; f < nf; f += kSweepBlock) gr_store(a.far_off[(s + 1u) & 1u], f0 + f, facc[f], s + 1u);
+        if (has) gr_store((s & 1u) ? a.part_off[0] : a.part_off[1], off + tid, acc[tid], s + 1u);
+        if (nf) {
+            SFP_COLD(cp); SFP_TILE(tp);
+            const uint32_t fo = (s & 1u) ? cp->far_off[0] : cp->far_off[1], f0 = tp->f0;
+            for (uint32_t f = tid; f < nf; f += kSweepBlock) gr_store(fo, f0 + f, facc[f], s + 1u);
+        }
+        SFP_STAMP(6);                                                     // phase D (stores drained)
         // (no barrier here: what the next head clears or writes before its own barrier -- xs[tid], acc[tid], den, facc[f] -- was last read
         //  in phase C, behind the barrier above, or is this thread's own slot of phase D)
     }
 
     // ================= the loop has ended =================
     const uint32_t tid = tid0, lane = tid & (kWave - 1), wave = tid / kWave;
-    if (k_done == 0xFFFFFFFFu) { if (tid == 0u) *a.status = 1u; return; }
+    SFP_COLD(cp);
+#ifdef SFGPU_P_STAMP
+    if (cp->dbg && tid == 0u) for (int k = 0; k < 7; ++k) cp->dbg[blockIdx.x * 8 + k] = pst[k];
+#endif
+    if (k_done == 0xFFFFFFFFu) { if (tid == 0u) *cp->status = 1u; return; }
     if (k_done > 0u) {
-        if (lane == 0u) a.tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + wave] = wmax[(k_done & 1u) * (kSweepBlock / kWave) + wave];
+        if (lane == 0u) cp->tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + wave] = wmax[(k_done & 1u) * (kSweepBlock / kWave) + wave];
         // positions no window holds are inactive transcripts here (a plan with far-only transcripts does not run persistent):
         // every update leaves them at the prior (VBEM, :318) or at 0
-        const uint32_t n_unc = *a.unc_n;
-        for (uint32_t j = tid * gridDim.x + blockIdx.x; j < n_unc; j += kSweepBlock * gridDim.x) a.alpha[a.unc[j]] = VB ? kPriorAlpha : 0.0;
+        const uint32_t n_unc = *cp->unc_n;
+        for (uint32_t j = tid * gridDim.x + blockIdx.x; j < n_unc; j += kSweepBlock * gridDim.x) a.alpha[cp->unc[j]] = VB ? kPriorAlpha : 0.0;
     }
     if (blockIdx.x == 0u && tid == 0u) {
-        EmState* st = a.st;
+        EmState* st = cp->st;
         st->it_a = k_done; st->itv[0] = st->itv[1] = k_done;
         if (k_done > 0u) st->notconv3[(k_done - 1u) % 3u] = conv_last ? 0u : 1u;
     }
