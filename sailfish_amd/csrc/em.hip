@@ -1631,7 +1631,7 @@ struct sfgpu_em {
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
     uint32_t far_cap = 0;
     bool persist = false;                                   // this optimize() runs as one launch
-    PersistCold h_pcold{};                                  // ... the part of its arguments it reads from device memory, staged for the copy
+    bool no_persist = false;                                // set while several bootstrap lanes run (see sfgpu_bootstrap)
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     EmState* d_state = nullptr;
@@ -2517,7 +2517,6 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     const uint64_t P = em->P ? em->P : 1, En = em->E ? em->E : 1;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     unsigned char* q = em->xbuf;
-    SF_HIP(hipMemsetAsync(q, 0, em->xbuf_bytes, em->cur));   // tags, counters, abort word, status: zeroed before EVERY launch
     PersistArgs a{}; PersistCold c{};
     a.ctl = reinterpret_cast<unsigned long long*>(q); c.status = reinterpret_cast<uint32_t*>(q + (size_t)kCtlWords * 8);
     PersistCold* d_cold = reinterpret_cast<PersistCold*>(q + (size_t)kCtlWords * 8 + 64);
@@ -2534,14 +2533,19 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     c.unc = em->unc; c.unc_n = em->unc + em->prob.M;
     c.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
     a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.ablate = ablate;
-#ifdef SFGPU_P_STAMP
+#if defined(SFGPU_P_STAMP) || defined(SFGPU_P_PROGRESS)
     if (!em->dbg) SF_HIP(pool_malloc(&em->dbg, (size_t)em->n_tiles * 16 * 8));
+    SF_HIP(hipMemsetAsync(em->dbg, 0, (size_t)em->n_tiles * 16 * 8, em->cur));
     c.dbg = em->dbg;
 #endif
-    // (the cold block goes to device memory behind the control words; the copy's source is the handle's own staging block, which the stream
-    //  has read before the next optimize() can write it -- finish() waits)
-    em->h_pcold = c;
-    SF_HIP(hipMemcpyAsync(d_cold, &em->h_pcold, sizeof(PersistCold), hipMemcpyHostToDevice, em->cur));
+    // tags, counters, abort word, status: zeroed before EVERY launch; the cold block written behind the control words
+    {
+        static_assert(((size_t)kCtlWords * 8 + 64) % 16 == 0, "the cold block starts on a 16-byte boundary");
+        const uint32_t c0 = (uint32_t)(((size_t)kCtlWords * 8 + 64) / 16), cn = (uint32_t)((sizeof(PersistCold) + 15) / 16);
+        const unsigned nb = (unsigned)std::min<uint64_t>((em->xbuf_bytes / 16 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_persist_init, dim3(nb), dim3(256), 0, em->cur, (void*)em->xbuf, (uint32_t)em->xbuf_bytes, c0, cn, d_cold, c);
+        SF_CHECK_LAUNCH();
+    }
     void* args[] = {&a};
     SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kSweepBlock), args, em_persist_lds(em), em->cur));
     // (the launch's verdict, next to the plan's words in pinned memory; read behind finish()'s wait)
@@ -2574,10 +2578,11 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     {
         const char* fe = getenv("SFGPU_EM_FUSED"); const char* pe = getenv("SFGPU_EM_PERSIST");
         const bool family = !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->fused_ok != 0 && em->prob.C != 0 &&
-                            (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 30) && em->persist_ok != 0 && em->xbuf;
+                            (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 30) && em->persist_ok != 0 && em->xbuf && !em->no_persist;
         em->persist = family;
         if (family) em->fused = true;
         if (pe && atoi(pe) == 2) persist_ablate = 1;         // dev: no tag checks (timing only)
+        if (pe && atoi(pe) == 4) persist_ablate = 4;         // tests: tile 0 starts late
         if (pe && atoi(pe) == 3) persist_ablate = 3;         // tests: a tile gives up in step 2 (the run is repeated with one kernel per iteration)
     }
     if (em->fused && em->fused_ok < 0) {
@@ -2696,7 +2701,44 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         // handle goes back to one kernel per iteration, and the run is repeated from its start
         persist_lock.unlock();
         em->persist_ok = 0;
-        log_msg(1, "EM: the persistent loop gave up waiting for a tile (is the device shared?); running one kernel per iteration");
+        {
+            unsigned long long who[4] = {0, 0, 0, 0};
+            (void)hipMemcpy(who, em->xbuf + (size_t)(kCtlAbort + 1) * kCtlStride * 8, sizeof(who), hipMemcpyDeviceToHost);
+#ifdef SFGPU_P_PROGRESS
+            {
+                std::vector<unsigned long long> h(em->n_tiles);
+                (void)hipMemcpy(h.data(), em->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+                std::string line;
+                for (uint32_t b = 0; b < em->n_tiles; ++b) { line += (char)('0' + (h[b] > 9 ? 9 : (int)h[b])); }
+                fprintf(stderr, "persist progress (step + 1 per tile, 0 = never ran): %s\n", line.c_str());
+                std::vector<unsigned long long> w(em->n_tiles);
+                (void)hipMemcpy(w.data(), em->dbg + em->n_tiles, w.size() * 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "persist waits at the give-up (tile: why * 1000 + step; tiles at steps < 2 only):");
+                for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b] < 3) fprintf(stderr, " %u:%llu", b, w[b]);
+                fprintf(stderr, "\n");
+                // the first stuck tile's view: what memory holds NOW where it polled (its neighbours' pieces, parity 1 = tags 1, 3, ...)
+                for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b] == 2 && w[b] / 1000 == 2) {
+                    TileDesc t; (void)hipMemcpy(&t, em->td + b, sizeof(t), hipMemcpyDeviceToHost);
+                    auto up2 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+                    const size_t o1 = up2((size_t)kCtlWords * 8 + 64 + sizeof(PersistCold)) + up2((size_t)(em->P ? em->P : 1) * 16);
+                    fprintf(stderr, "tile %u (lo %u span %u nb %u): tags in memory of its neighbours' first / last overlapping slots (parity 1):", b, t.lo, t.span, t.nb_n);
+                    for (uint32_t j2 = 0; j2 < t.nb_n && j2 < 6; ++j2) {
+                        const uint32_t lo2 = t.e[j2].x, sp2 = t.e[j2].y, off2 = t.e[j2].z;
+                        const uint32_t p0 = std::max(lo2, t.lo), p1 = std::min(lo2 + sp2, t.lo + t.span) - 1;
+                        uint32_t g0[4], g1[4];
+                        (void)hipMemcpy(g0, em->xbuf + o1 + (size_t)(off2 + (p0 - lo2)) * 16, 16, hipMemcpyDeviceToHost);
+                        (void)hipMemcpy(g1, em->xbuf + o1 + (size_t)(off2 + (p1 - lo2)) * 16, 16, hipMemcpyDeviceToHost);
+                        fprintf(stderr, " [tile %u: %u/%u .. %u/%u]", t.e[j2].w, g0[1], g0[3], g1[1], g1[3]);
+                    }
+                    fprintf(stderr, "\n");
+                    break;
+                }
+
+            }
+#endif
+            log_msg(1, "EM: the persistent loop gave up waiting for a tile (is the device shared?); running one kernel per iteration [tile %llu of %u, thread %llu, wait %llu, step %llu]",
+                    who[0] - 1ull, em->n_tiles, who[1], who[2], who[3]);
+        }
         return em_run(em, opts, d_alpha_out, d_mass_out, stats, quiet);
     }
     if (em->fused && st.n_active == 0) {                                             // :794-798 (see above)
@@ -2981,6 +3023,12 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
         if ((rc = em_join_user(c))) return rc;
         if ((rc = em_bootstrap_prepare(c))) return rc;
     }
+    // Several lanes keep one kernel per iteration.  The persistent loop needs the chip to itself: launched while another stream's kernels
+    // are in flight, tiles of one or two XCDs polled stale lines of the exchange buffer for 200 ms while memory held the tags their
+    // neighbours had published (profiles/r5_em_notes.md, section 6) -- the run then falls back, correct but late.  One lane runs persistent.
+    em->no_persist = n_lanes > 1;
+    for (sfgpu_em* c : em->bs_clones) c->no_persist = n_lanes > 1;
+    struct LaneGuard { sfgpu_em* e; ~LaneGuard() { e->no_persist = false; for (sfgpu_em* c : e->bs_clones) c->no_persist = false; } } lane_guard{em};
     BsOrder order;
     std::vector<int> lane_rc(n_lanes, SFGPU_OK);
     std::vector<std::string> lane_err(n_lanes);

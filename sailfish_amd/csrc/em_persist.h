@@ -36,8 +36,8 @@ constexpr uint32_t kCtlStride = 16;                  // 64-bit words between two
 constexpr uint32_t kCtlArrive = 0;                   // [4][kShards] arrivals of update u in slot u % 4 (monotonic over the run)
 constexpr uint32_t kCtlNotConv = 4 * kShards;        // [kShards] the last update in which some block of the shard saw a change > tol
 constexpr uint32_t kCtlAbort = 5 * kShards;          // != 0: some tile gave up waiting
-constexpr uint32_t kCtlWords = (5 * kShards + 1) * kCtlStride;
-constexpr uint32_t kSpinLimit = 1u << 20;            // slow-path polls of one wait (~1 us each) before a tile gives up
+constexpr uint32_t kCtlWords = (5 * kShards + 2) * kCtlStride;       // (+ a line for who gave up: tile + 1, thread, wait, step)
+constexpr uint32_t kSpinLimit = 1u << 18;            // polls of one wait (0.2 - 1 us each: 50 - 250 ms) before a tile gives up
 constexpr uint32_t kFanInMax = 16;                   // far slots one transcript may collect (its home thread reads them one by one)
 
 // ---- the plan's far-slot tables (sfgpu_em_create -> em_persist_plan) ----------------------------------------------------------
@@ -135,8 +135,23 @@ struct PersistArgs {
     unsigned long long* ctl;                              // kCtlWords control words (zeroed before the launch)
     double tol, log_norm;
     uint32_t den_cap, far_cap;                            // LDS: den[den_cap + 1] (den_cap = the plan's null class), facc[far_cap]
-    int ablate;                                           // dev: 1 = no tag checks (timing only: wrong results); 3 = tile 0 gives up in step 2 (tests)
+    int ablate;                                           // dev: 1 = no tag checks (timing only: wrong results); 3 = tile 0 gives up in step 2, 4 = tile 0 starts 100 us late (tests)
 };
+
+// before every launch: tags, counters, abort word and status zeroed, the cold block written -- ONE kernel, and its stores are
+// WRITE-THROUGH (sc1) like every later store to the exchange buffer: zeros written with plain stores stay behind as clean lines in the
+// L2 of the XCD that wrote them, a write-through store from another XCD does not reach those copies, and a tile that runs on that XCD
+// then polls (sc1 loads are L2-served) a line of zeros for ever.  Seen with three bootstrap lanes (other streams' kernels between the
+// launches: blocks land on other XCDs than b mod 8): tiles of one or two XCDs waited in step 1 for sums their neighbours had published.
+__global__ void __launch_bounds__(256)
+k_persist_init(void* xbuf, uint32_t bytes, uint32_t cold_first16, uint32_t cold_n16, PersistCold* d_cold, PersistCold cold) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, bytes, 0x00020000);
+    const uint32_t n16 = bytes / 16u;
+    const gr4 z = {0u, 0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x)
+        if (i - cold_first16 >= cold_n16) __builtin_amdgcn_raw_buffer_store_b128(z, rx, i * 16u, 0, 16);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_cold = cold;
+}
 
 __device__ __forceinline__ double gr_value(const gr4& g) { return __hiloint2double((int)g.z, (int)g.x); }
 __device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y == tag && g.w == tag; }
@@ -204,11 +219,29 @@ k_em_persist(PersistArgs a) {
     // a wait that does not end: look at the abort word now and then, give up after ~1 s (returns true when the wait must be left)
     // (`word`: the block's abort word this wait reports to -- sctl[1] for the waits of a head, sctl[4 + step parity] for those inside
     //  the phases: every word is read by ALL threads behind ONE barrier that no writer of it can have passed, so the block leaves as one)
+#ifdef SFGPU_P_PROGRESS
+    uint32_t why = 0u;                                                   // (dev builds: what the current wait is for -- 1 arrivals, 2 a window sum, 3 a far slot, 4 a far member's x)
+#define SFP_WHY(k) why = (k)
+#else
+    constexpr uint32_t why = 0u;
+#define SFP_WHY(k) do { } while (0)
+#endif
     auto spin_check = [&](uint32_t& spins, uint32_t word) -> bool {
-        __builtin_amdgcn_s_sleep(2);
+#ifndef SFGPU_P_SLEEP
+#define SFGPU_P_SLEEP 2
+#endif
+        if (SFGPU_P_SLEEP) __builtin_amdgcn_s_sleep(SFGPU_P_SLEEP);
         if ((++spins & 63u) != 0u) return false;
-        if (__hip_atomic_load(&ctl[kCtlAbort * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { sctl[word] = 1u; return true; }
+        if (__hip_atomic_load(&ctl[kCtlAbort * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+#ifdef SFGPU_P_PROGRESS
+            { SFP_COLD(cq); cq->dbg[gridDim.x + blockIdx.x] = (unsigned long long)why * 1000ull + sctl[6]; }
+#endif
+            sctl[word] = 1u; return true;
+        }
         if (spins >= kSpinLimit) {
+            // who gave up, for the log: [1] tile + 1, [2] thread, [3] what it waited for (the abort word of the wait: 1 = a head, 4 / 5 = a phase)
+            const unsigned long long first = atomicCAS(&ctl[(kCtlAbort + 1) * kCtlStride], 0ull, (unsigned long long)blockIdx.x + 1ull);
+            if (first == 0ull) { ctl[(kCtlAbort + 1) * kCtlStride + 1] = threadIdx.x; ctl[(kCtlAbort + 1) * kCtlStride + 2] = why ? why : word; ctl[(kCtlAbort + 1) * kCtlStride + 3] = sctl[6]; }
             __hip_atomic_store(&ctl[kCtlAbort * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sctl[word] = 1u;
             return true;
@@ -228,9 +261,11 @@ k_em_persist(PersistArgs a) {
         if (s == 0u) { const uint32_t p = cp->far_pos[f0 + f]; const uint32_t* inv = cp->inv; return cp->x[inv ? inv[p] : p]; }
         const uint32_t xi = cp->far_xi[f0 + f], xo = cp->xpub_off;
         gr4 g = gr_load(xo, xi);
+        SFP_WHY(4u);
         if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, s);) { if (spin_check(spins, word)) break; g = gr_load(xo, xi); }
         return gr_value(g);
     };
+    if (a.ablate == 4 && blockIdx.x == 0u) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(8); }      // tests: tile 0 starts 100 us late
     __syncthreads();
 
     uint32_t k_done = 0;                                                 // updates done when the loop ends
@@ -241,6 +276,10 @@ k_em_persist(PersistArgs a) {
         uint32_t tid = tid0;
         asm volatile("" : "+v"(tid));
         const uint32_t lane = tid & (kWave - 1), wave = tid / kWave, g0 = tid * kPerLane;
+        if (tid == 0u) sctl[6] = s;                                          // (for the log of a give-up)
+#ifdef SFGPU_P_PROGRESS
+        if (tid == 0u) { SFP_COLD(cq); __hip_atomic_store(&cq->dbg[blockIdx.x], (unsigned long long)s + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
         // ================= head of step s: [the stop test of update s - 1] update s, x of sweep s =================
         const bool has = (flags & 0x40000000u) != 0u, home = (flags & 0x80000000u) != 0u;
         double ap_v = 0.0, xv = 0.0, lm = -1.0; unsigned ncv = 0u;
@@ -257,6 +296,9 @@ k_em_persist(PersistArgs a) {
 #pragma unroll
             for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; cw[i] = (c < nc) ? cnt[c] : 0u; }
         };
+#ifdef SFGPU_P_EARLY
+        request_stream();
+#endif
         if (s > 0u) {
             const uint32_t rd_off = (s & 1u) ? a.part_off[1] : a.part_off[0];       // sums of sweep s - 1 carry tag s
             const uint32_t pos = lo + tid;
@@ -279,6 +321,7 @@ k_em_persist(PersistArgs a) {
                     const unsigned long long want = (unsigned long long)visits * ((a.n_tiles + (kShards - 1u) - lane) / kShards);
                     const unsigned long long* w = &ctl[(kCtlArrive + (u & 3u) * kShards + lane) * kCtlStride];
                     unsigned long long got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    SFP_WHY(1u);
                     if (a.ablate != 1) for (uint32_t spins = 0; got < want;) { if (spin_check(spins, 1u)) break; got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     ncu = (uint32_t)__hip_atomic_load(&ctl[(kCtlNotConv + lane) * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -300,6 +343,7 @@ k_em_persist(PersistArgs a) {
                     for (uint32_t k = ft.x; k < ft.y; ++k) {
                         const uint32_t g = cp->ft_list[k];
                         gr4 q = gr_load(frd_off, g);
+                        SFP_WHY(3u);
                         if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(q, s);) { if (spin_check(spins, 1u)) break; q = gr_load(frd_off, g); }
                         ap_v += gr_value(q);
                     }
@@ -307,6 +351,7 @@ k_em_persist(PersistArgs a) {
                 // the overlapping tiles' sums, in tile order with this tile's own in its place (as the cover list); three at a time
                 auto wait3 = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t fsh) {
                     if (a.ablate == 1) return;
+                    SFP_WHY(2u);
                     for (uint32_t spins = 0;;) {
                         const bool ok = gr_ok(gq[0], s) && gr_ok(gq[1], s) && gr_ok(gq[2], s);
                         if (ok || spin_check(spins, 1u)) break;
@@ -330,7 +375,9 @@ k_em_persist(PersistArgs a) {
                     if (nb_before >= 6u) ap_v += own;
                 } else if (nb_before >= 3u) ap_v += own;
                 SFP_STAMP(0);                                             // operands here
+#ifndef SFGPU_P_EARLY
                 request_stream();
+#endif
                 if (VB) ap_v += kPriorAlpha;
                 xv = x_of(ap_v, len);
                 if (home) {
@@ -343,13 +390,18 @@ k_em_persist(PersistArgs a) {
                     }
                     if (ft.y > ft.x) { SFP_COLD(cp); gr_store(cp->xpub_off, ft.x, xv, s); }      // a far target: its x for the tiles that hold it as a far member
                 }
-            } else request_stream();
+            }
+#ifndef SFGPU_P_EARLY
+            else request_stream();
+#endif
             // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
             for (int o = kWave / 2; o > 0; o >>= 1) { const double m = __shfl_down(lm, o, kWave); if (m > lm) lm = m; }
             if (lane == 0u) wmax[(s & 1u) * (kSweepBlock / kWave) + wave] = lm;
             if (__any(ncv != 0u) && lane == 0u) sctl[2u + (s & 1u)] = 1u;
         } else {
+#ifndef SFGPU_P_EARLY
             request_stream();
+#endif
             if (has) { SFP_COLD(cp); const uint32_t* inv = cp->inv; const uint32_t p = lo + tid; xv = cp->x[inv ? inv[p] : p]; }
         }
         if (a.ablate == 3 && s == 2u && blockIdx.x == 0u && tid == 0u) {      // tests: tile 0 gives up here -- every tile must leave, the host repeats the run
