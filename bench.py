@@ -83,8 +83,24 @@ def cpu_baseline_full(vec, ref_len_np, ids_t, off_t, n_total, use_vbem, fl_count
     assert b.n_classes == len(cc), "the sample's reads must all belong to known classes"
     eff = O.efflen_smoothed(ref_len_np, O.cf_counts(fl_counts) if fl_counts is not None else O.cf_gaussian())
     t0 = time.perf_counter()
-    O.em_optimize(eff, rp.astype(np.uint64), ii, cc, n_total, use_vbem=use_vbem, tol=0.0, min_iter=10, max_iter=10)
-    return n / t_look, (time.perf_counter() - t0) / 10
+    rc_o, alpha_o, _, _ = O.em_optimize(eff, rp.astype(np.uint64), ii, cc, n_total, use_vbem=use_vbem, tol=0.0, min_iter=10, max_iter=10)
+    em_s = (time.perf_counter() - t0) / 10
+    # ... and the alpha of those 10 iterations is the FULL problem's parity check: the HIP loop (the kernel configuration that was
+    # timed) over the same classes, 10 iterations, against it
+    full = None
+    try:
+        import sailfish_amd as sf
+        prob = sf.EMProblem(torch.from_numpy(eff).to(ids_t.device), vec.rowptr, vec.ids, vec.counts, n_total)
+        rc_g, st_g = prob.optimize(use_vbem=use_vbem, tol=0.0, min_iter=10, max_iter=10)
+        alpha_g = prob.alpha.cpu().numpy()
+        nz = alpha_o > 0
+        full = dict(iters=10, rc=[int(rc_o), int(rc_g)], support_identical=bool(np.array_equal(alpha_g > 0, nz)),
+                    max_rel_numreads=float(np.max(np.abs(alpha_g[nz] - alpha_o[nz]) / alpha_o[nz])) if nz.any() else 0.0,
+                    persistent=bool(st_g.get("persistent")), fused=bool(st_g.get("fused")))
+        prob.close()
+    except Exception as e:                        # never take the line down
+        full = dict(error=repr(e))
+    return n / t_look, em_s, full
 
 
 def cpu_baseline(ref_len_np, ids_t, off_t, target_s, use_vbem):
@@ -169,13 +185,30 @@ def info_total_reads(info, quant):
     return int(quant.last_vec.total_reads)
 
 
+def _relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (one process per GPU, the launch line
+    the driver uses: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch_under_torchrun(a)
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     if a.one_device:
         local = 0
+        if world > 1:
+            os.environ["SFGPU_EM_PERSIST"] = "0"     # several processes on ONE device: no kernel has the chip to itself (the persistent loop needs all its blocks resident)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -403,6 +436,15 @@ def main():
     # EM pays one all-reduce of M doubles per iteration; `auto` keeps the EM replicated while that costs more than a whole sweep)
     if dist:
         mg = {"em_mode_of_the_timed_steps": info["em_mode"]}
+        mg["em_mode"] = info["em_mode"]
+        # proof of what the line ran on: the ranks of libsfgpu's OWN RCCL communicator (ncclCommCount; null: the torch.distributed
+        # callback summed alphaOut -- gloo, or several ranks on one device), the devices, the backend
+        try:
+            ar = quant._allreduce() if hasattr(quant, "_allreduce") else None
+            mg["rccl_ranks"] = ar.count() if hasattr(ar, "count") else None
+        except Exception as e:
+            mg["rccl_ranks"] = None; mg["rccl_ranks_error"] = repr(e)
+        mg["backend"] = a.backend; mg["one_device"] = bool(a.one_device); mg["world"] = world
         try:
             buf = torch.zeros(M, dtype=torch.float64, device=dev)
             for _ in range(10):
@@ -518,7 +560,10 @@ def main():
             out["cpu_baseline_all_cores"] = mt
         out["parity_vs_cpu"] = cb["parity"]     # the metric's "TPM delta vs CPU ref", on the baseline's sample
         try:
-            look_rate, em_s = cpu_baseline_full(quant.last_vec, ref_len_np, ids, off, R, use_vbem, fl_counts)
+            look_rate, em_s, full_parity = cpu_baseline_full(quant.last_vec, ref_len_np, ids, off, R, use_vbem, fl_counts)
+            if isinstance(out.get("parity_vs_cpu"), dict) and full_parity:
+                out["parity_vs_cpu"]["full_problem"] = full_parity
+                out["parity_vs_cpu"]["full_problem_max_rel"] = full_parity.get("max_rel_numreads")
             full_s = R / look_rate + st["iters"] * em_s
             out["cpu_baseline"].update({
                 "value": R / full_s,

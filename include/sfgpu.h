@@ -272,6 +272,7 @@ typedef struct sfgpu_comm sfgpu_comm;
 SFGPU_API int sfgpu_comm_available(void);                                   /* 1 if librccl.so could be loaded */
 SFGPU_API int sfgpu_comm_unique_id(void* id_out /* SFGPU_COMM_ID_BYTES */);
 SFGPU_API int sfgpu_comm_create(sfgpu_comm** out, const void* id /* SFGPU_COMM_ID_BYTES */, int world, int rank);
+SFGPU_API int sfgpu_comm_count(sfgpu_comm* c, int* ranks);                     /* ncclCommCount: the ranks the communicator really spans */
 SFGPU_API int sfgpu_comm_destroy(sfgpu_comm* c);
 SFGPU_API int sfgpu_comm_allreduce_sum_f64(sfgpu_comm* c, double* d_buf, uint64_t n, sfgpu_stream stream);   /* in place, on `stream` */
 SFGPU_API sfgpu_allreduce_fn sfgpu_comm_allreduce_fn(void);

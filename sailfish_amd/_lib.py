@@ -143,6 +143,7 @@ _SIGS = {
     "sfgpu_comm_available": (C.c_int, []),
     "sfgpu_comm_unique_id": (C.c_int, [_P]),
     "sfgpu_comm_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),
+    "sfgpu_comm_count": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "sfgpu_comm_destroy": (C.c_int, [_P]),
     "sfgpu_comm_allreduce_sum_f64": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "sfgpu_comm_allreduce_fn": (_P, []),

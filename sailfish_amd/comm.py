@@ -58,6 +58,12 @@ class Comm:
             _lib.check(self._L.sfgpu_comm_time_allreduce(self._h, _lib.ptr(buf), int(n), int(reps), _lib.current_stream_ptr(), C.byref(us)))
         return us.value
 
+    def count(self):
+        """the ranks the communicator really spans (ncclCommCount)"""
+        n = C.c_int(0)
+        _lib.check(self._L.sfgpu_comm_count(self._h, C.byref(n)))
+        return n.value
+
     def callback(self):
         """(function pointer, user pointer) for sfgpu_em_optimize_sharded"""
         fn = C.cast(self._L.sfgpu_comm_allreduce_fn(), _lib.ALLREDUCE_CB)

@@ -27,6 +27,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 
@@ -44,6 +45,7 @@ static RcclApi& rccl() {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
     });
     return api;
@@ -96,6 +98,14 @@ int sfgpu_comm_create(sfgpu_comm** out, const void* id128, int world, int rank) 
         return SFGPU_ERR_HIP;
     }
     *out = c;
+    return SFGPU_OK;
+}
+
+// how many ranks the communicator REALLY spans (ncclCommCount): what a benchmark line quotes as proof of what it ran on
+int sfgpu_comm_count(sfgpu_comm* c, int* ranks) {
+    SF_REQUIRE(c && c->comm && ranks, SFGPU_ERR_INVALID, "sfgpu_comm_count: null pointer");
+    SF_REQUIRE(rccl().ok && rccl().CommCount, SFGPU_ERR_STATE, "sfgpu_comm: ncclCommCount is not available");
+    SF_RCCL(rccl().CommCount(c->comm, ranks));
     return SFGPU_OK;
 }
 

@@ -213,3 +213,23 @@ def test_rccl_comm_drives_the_sharded_loop(gpu):
             p.close()
     finally:
         c.close()
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` without a launcher around it starts its two ranks itself (torch.distributed.run, one process per
+    rank; here both on the one device, gloo) and prints ONE line that says what it ran on: n_gpus, the EM mode, both modes' times,
+    the ranks of the library's RCCL communicator (null on this dry run: gloo sums alphaOut)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--workload", "small",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-pinned", "--no-sampling"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["world"] == 2 and mg["em_mode"] in ("replicated", "sharded") and "rccl_ranks" in mg and mg["one_device"]
+    assert set(mg["em_ms"]) == {"replicated", "sharded"}
