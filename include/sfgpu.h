@@ -44,6 +44,20 @@ typedef struct sfgpu_eq sfgpu_eq;    /* EquivalenceClassBuilder on the device */
 typedef struct sfgpu_em sfgpu_em;    /* CollapsedEMOptimizer state on the device */
 
 SFGPU_API int sfgpu_version(void);
+/* 1 in builds made with -DSFGPU_VARIANTS (tools/em_variants.sh, tools/eq_variants.sh): they also hold the kernel forms that lost their
+ * measurements (the ring / quad / pipelined class build, the graph-replayed EM loops) and read the tuning switches; the product answers 0.
+ * Environment switches the PRODUCT library reads (everything else is a variants-only tuning knob):
+ *   SFGPU_EM_FUSED=0|1      0: sweep + update kernels per EM iteration; 1: one kernel per iteration wherever it can run
+ *   SFGPU_EM_PERSIST=0      never run the EM loop as one persistent launch (also read when a problem's plan is made)
+ *   SFGPU_EM_GATHER=0       phase C of the sweep scatters with LDS atomics (rounds 1 - 2) instead of the gather form
+ *   SFGPU_EM_EXACT_NORM=1   VBEM: psi(sum alpha) from the summed vector instead of the constant psi(M prior + numMapped)
+ *   SFGPU_EM_NO_RENUMBER=1  the EM plan keeps the caller's transcript order whatever the labels look like
+ *   SFGPU_EM_COVER_SORT=1 / SFGPU_EM_COVER_CHECK=1   tests: cover lists by sorting / both forms compared
+ *   SFGPU_EQ_SUBBATCH=n     reads per sub-batch of the class build; SFGPU_EQ_HOST_CHUNK=n reads per staged chunk of a host batch
+ *   SFGPU_BS_LANES=n        concurrent bootstrap replicates (1 .. 8, default 3)
+ *   SFGPU_POOL_LARGE_LIMIT_GB=g   cached device blocks >= 1 GiB kept per device
+ *   SFGPU_TIMING=1          plans described on stderr */
+SFGPU_API int sfgpu_has_variants(void);
 SFGPU_API const char* sfgpu_last_error(void);
 /* Forwarded to sopt.jointLog by the adaptor (level: 0 info, 1 warn, 2 error).  NULL = silent. */
 SFGPU_API void sfgpu_set_logger(void (*log)(int level, const char* msg));

@@ -94,6 +94,7 @@ class BiasStats(C.Structure):
 
 _SIGS = {
     "sfgpu_version": (C.c_int, []),
+    "sfgpu_has_variants": (C.c_int, []),
     "sfgpu_last_error": (C.c_char_p, []),
     "sfgpu_set_logger": (None, [_LOG_CB]),
     "sfgpu_pool_trim": (C.c_int, []),

@@ -707,7 +707,7 @@ int sfgpu_bias_update(sfgpu_bias* b, const double* d_eff_in, const double* d_alp
         return SFGPU_OK;
     }
     SF_REQUIRE(M < (1ull << 31), SFGPU_ERR_RANGE, "sfgpu_bias_update: more than 2^31 transcripts");
-    const bool timing = getenv("SFGPU_TIMING") != nullptr;                 // per-kernel times of this update
+    const bool timing = env_timing();                 // per-kernel times of this update
     hipEvent_t ev[5] = {};
     int n_ev = 0;
     auto mark = [&]() { if (timing && n_ev < 5) { (void)hipEventCreate(&ev[n_ev]); (void)hipEventRecord(ev[n_ev], st); ++n_ev; } };

@@ -75,6 +75,17 @@ struct DevBuf {
     }
 };
 
+// Tuning / experiment switches that lost their A/Bs (profiles/r*_notes.md name each) are read only by builds made with
+// -DSFGPU_VARIANTS (tools/*_variants.sh -> csrc/variants/libsfgpu_<name>.so): the product library neither reads them nor contains the
+// kernels they select.  The switches the product keeps are listed in include/sfgpu.h.
+#ifdef SFGPU_VARIANTS
+#define SF_DEV_ENV(name) getenv(name)
+#else
+#define SF_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+// SFGPU_TIMING=1: the library says on stderr what its plans look like (dev)
+inline bool env_timing() { static const bool on = getenv("SFGPU_TIMING") != nullptr; return on; }
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 }  // namespace sfgpu

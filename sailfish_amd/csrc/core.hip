@@ -57,17 +57,36 @@ int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 // SFGPU_POOL_LARGE_LIMIT_GB / sfgpu_pool_set_large_limit() change it (0: large blocks are never cached).
 constexpr size_t kLargeBlock = (size_t)1 << 30;
 std::unordered_map<int, size_t> g_large_cached;                      // device -> bytes of cached (free) large blocks
-long long g_large_limit = -1;                                        // bytes; -1: not decided yet
-size_t large_limit_locked() {
-    if (g_large_limit < 0) {
-        size_t fr = 0, tot = 0;
-        long long lim = 64ll << 30;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (long long)(tot / 4) < lim) lim = (long long)(tot / 4);
-        (void)hipGetLastError();
-        if (const char* e = getenv("SFGPU_POOL_LARGE_LIMIT_GB")) { const double g = atof(e); if (g >= 0) lim = (long long)(g * (double)(1ull << 30)); }
-        g_large_limit = lim;
-    }
-    return (size_t)g_large_limit;
+long long g_large_limit_user = -1;                                   // bytes, set by sfgpu_pool_set_large_limit / the environment for EVERY device; -1: per-device default
+std::unordered_map<int, long long> g_large_limit_dev;                // device -> its default (a quarter of ITS memory, at most 64 GiB)
+// (the limit of device `dev`: decided with that device current -- a node with unlike devices, or a first call made on the small one,
+//  gave every device the first device's quarter before)
+size_t large_limit_locked(int dev) {
+    static const long long env_lim = []() -> long long {
+        if (const char* e = getenv("SFGPU_POOL_LARGE_LIMIT_GB")) { const double g = atof(e); if (g >= 0) return (long long)(g * (double)(1ull << 30)); }
+        return -1;
+    }();
+    if (g_large_limit_user >= 0) return (size_t)g_large_limit_user;
+    if (env_lim >= 0) return (size_t)env_lim;
+    auto it = g_large_limit_dev.find(dev);
+    if (it != g_large_limit_dev.end()) return (size_t)it->second;
+    long long lim = 64ll << 30;
+    int cur = 0;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (long long)(tot / 4) < lim) lim = (long long)(tot / 4);
+    (void)hipGetLastError();
+    if (switched) (void)hipSetDevice(cur);
+    g_large_limit_dev[dev] = lim;
+    return (size_t)lim;
+}
+// a large block goes back to the driver because of the budget: said once (mapping it again costs ~15 ms per GB)
+void note_large_release(size_t sz, int dev) {
+    static bool said = false;
+    if (said) return;
+    said = true;
+    log_msg(0, "device block of %.1f GB released instead of cached (large-block budget of device %d: %.1f GB; SFGPU_POOL_LARGE_LIMIT_GB / sfgpu_pool_set_large_limit change it)",
+            (double)sz / (double)(1ull << 30), dev, (double)large_limit_locked(dev) / (double)(1ull << 30));
 }
 
 struct Pending { void* p; hipEvent_t ev; bool owns; };      // (blocks freed together share an event; the last one of them gives it back)
@@ -84,7 +103,8 @@ void reap_pending_locked(bool wait) {
         (void)hipGetLastError();
         auto it = g_pool_key.find(x.p);
         if (it == g_pool_key.end()) (void)hipFree(x.p);
-        else if (it->second.kind == kDeviceMem && it->second.sz >= kLargeBlock && g_large_cached[it->second.dev] + it->second.sz > large_limit_locked()) {
+        else if (it->second.kind == kDeviceMem && it->second.sz >= kLargeBlock && g_large_cached[it->second.dev] + it->second.sz > large_limit_locked(it->second.dev)) {
+            note_large_release(it->second.sz, it->second.dev);
             g_pool_key.erase(it); (void)hipFree(x.p);                        // over the large-block budget: back to the driver
         } else {
             if (it->second.kind == kDeviceMem && it->second.sz >= kLargeBlock) g_large_cached[it->second.dev] += it->second.sz;
@@ -132,7 +152,7 @@ void pool_put(void* p, int kind) {
     auto it = g_pool_key.find(p);
     if (it == g_pool_key.end()) { if (kind == kDeviceMem) (void)hipFree(p); else (void)hipHostFree(p); return; }
     if (kind == kDeviceMem && it->second.sz >= kLargeBlock) {
-        if (g_large_cached[it->second.dev] + it->second.sz > large_limit_locked()) { g_pool_key.erase(it); (void)hipFree(p); return; }
+        if (g_large_cached[it->second.dev] + it->second.sz > large_limit_locked(it->second.dev)) { note_large_release(it->second.sz, it->second.dev); g_pool_key.erase(it); (void)hipFree(p); return; }
         g_large_cached[it->second.dev] += it->second.sz;
     }
     g_pool_free[it->second].push_back(p);
@@ -193,7 +213,7 @@ void pool_trim() {
     g_large_cached.clear();
     for (auto& kv : g_streams) { for (hipStream_t s : kv.second) (void)hipStreamDestroy(s); kv.second.clear(); }
 }
-void pool_set_large_limit(long long bytes) { std::lock_guard<std::mutex> lk(g_pool_mu); g_large_limit = bytes; }
+void pool_set_large_limit(long long bytes) { std::lock_guard<std::mutex> lk(g_pool_mu); g_large_limit_user = bytes; }
 
 }  // namespace sfgpu
 
@@ -204,6 +224,15 @@ int sfgpu_pool_set_large_limit(long long bytes) { sfgpu::pool_set_large_limit(by
 
 
 int sfgpu_version(void) { return SFGPU_VERSION; }
+// 1: a build with -DSFGPU_VARIANTS (tools/*_variants.sh): the alternative kernel forms that lost their A/Bs and the tuning switches
+// are compiled in; the product library answers 0
+int sfgpu_has_variants(void) {
+#ifdef SFGPU_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char* sfgpu_last_error(void) { return sfgpu::g_err; }
 void sfgpu_set_logger(void (*log)(int level, const char* msg)) { sfgpu::g_logger = log; }
 

@@ -25,6 +25,7 @@
 #include "sampling.h"
 
 #include <cfloat>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -1622,7 +1623,7 @@ struct sfgpu_em {
     bool streamed = false;                                  // ... one by one, the host a few launches ahead of the device (no graph)
     uint32_t run_no = 0;                                    // tags the progress words of this optimize()
     uint32_t par = 0;                                       // parity of the next fused launch
-    bool graph_fused = false;
+    bool graph_fused = false; bool graph_const_norm = true; double graph_log_norm = 0.0;      // (what the cached graph was built for)
     uint32_t null_cls = kTileNnz;                           // GATHER: class index of the transcript-major copy's padding = the largest class count of a tile
     // the PERSISTENT loop (em_persist.h): far-slot tables, the exchange buffer (control words + granule arrays), the plan's verdict
     uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
@@ -1674,7 +1675,7 @@ static int em_fill_opts(sfgpu_em* em, const sfgpu_em_opts* o) {
     SF_REQUIRE(o->tol >= 0.0, SFGPU_ERR_INVALID, "tol must be >= 0");
     em->opts = *o;
     if (em->opts.iters_per_launch == 0) {
-        static const uint32_t dflt = []() { const char* e = getenv("SFGPU_EM_CHUNK"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : 32); }();
+        static const uint32_t dflt = []() { const char* e = SF_DEV_ENV("SFGPU_EM_CHUNK"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : 32); }();
         em->opts.iters_per_launch = dflt;                     // (tuning: iterations per graph launch / poll)
     }
     return SFGPU_OK;
@@ -1847,7 +1848,7 @@ static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint
     // key_t = smallest transcript id within a few class hops of t
     hipLaunchKernelGGL(k_renum_iota, dim3(blocks_for(M)), dim3(kEmBlock), 0, st, M, key);
     int hops = kRenumberHops;
-    if (const char* e = getenv("SFGPU_EM_RENUMBER_HOPS")) { int v = atoi(e); if (v >= 1 && v <= 64) hops = v; }      // tuning
+    if (const char* e = SF_DEV_ENV("SFGPU_EM_RENUMBER_HOPS")) { int v = atoi(e); if (v >= 1 && v <= 64) hops = v; }      // tuning
     {
         uint32_t *kin = key, *kout = perm;                  // (perm is filled further down: free until then)
         for (int hop = 0; hop < hops; ++hop) {
@@ -2009,7 +2010,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         uint64_t rounds = std::max<uint64_t>(1, ((uint64_t)rp_end + slots * kTileNnzMax - 1) / (slots * kTileNnzMax));
         rounds = std::max<uint64_t>(rounds, (C + slots * (kTileNnz * 3 / 4) - 1) / (slots * (kTileNnz * 3 / 4)));
         uint32_t tile_nnz = tile_for(rounds);
-        if (const char* e = getenv("SFGPU_EM_TILE")) { long v = atol(e); if (v >= 2048 && v <= kTileNnzMax) tile_nnz = (uint32_t)v; }   // tuning
+        if (const char* e = SF_DEV_ENV("SFGPU_EM_TILE")) { long v = atol(e); if (v >= 2048 && v <= kTileNnzMax) tile_nnz = (uint32_t)v; }   // tuning
         em->n_tiles = (uint32_t)std::max<uint64_t>(1, ((uint64_t)rp_end + tile_nnz - 1) / tile_nnz);
         const uint32_t nt_small = (uint32_t)std::max<uint64_t>(1, ((uint64_t)rp_end + kTileNnz - 1) / kTileNnz);
         const uint32_t nt_cap = std::max(em->n_tiles, nt_small);
@@ -2083,7 +2084,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                                      (unsigned long long)E_first, (unsigned long long)E, rp_end);
         if (P >= (1ull << 32)) { set_error("sfgpu_em_create: window slots exceed 2^32"); em_free(em); return SFGPU_ERR_RANGE; }
         em->P = P; em->E = E; em->tile_nnz = tile_nnz;
-        if (getenv("SFGPU_TIMING")) fprintf(stderr, "em plan: %u tiles (%u nnz each), P = %llu window slots (%.2f per transcript), %llu escapes of %llu nonzeros\n",
+        if (env_timing()) fprintf(stderr, "em plan: %u tiles (%u nnz each), P = %llu window slots (%.2f per transcript), %llu escapes of %llu nonzeros\n",
                                             nt, tile_nnz, (unsigned long long)P, (double)P / (double)M, (unsigned long long)E, (unsigned long long)rp_end);
         EM_TRY(pool_malloc(&em->lstream, (S ? S : 1) * 4 + 32));
         EM_TRY(pool_malloc(&em->esc_id, (E ? E : 1) * 4));
@@ -2222,7 +2223,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
             if (em->pflags) EM_TRY(hipMemcpyAsync(em->h_plan + 6, em->pflags, 8, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipEventRecord(em->ev_plan, em->cur));
-            if (getenv("SFGPU_TIMING")) {                     // dev: how many tiles go by the cover list, how many neighbours the others have
+            if (env_timing()) {                     // dev: how many tiles go by the cover list, how many neighbours the others have
                 std::vector<TileDesc> h(nt);
                 (void)hipStreamSynchronize(em->cur);
                 (void)hipMemcpy(h.data(), em->td, (size_t)nt * sizeof(TileDesc), hipMemcpyDeviceToHost);
@@ -2456,7 +2457,8 @@ constexpr uint32_t kPreLaunched = 8;      // iterations enqueued directly while 
 // `n` iterations as an executable graph (kernel arguments are baked, the iteration index and the stop
 // latch live in device memory)
 static bool em_graph_ready(const sfgpu_em* em, uint32_t n) {
-    return em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == n && em->graph_fused == em->fused;
+    return em->graph && same_opts(em->graph_opts, em->opts) && em->graph_iters == n && em->graph_fused == em->fused &&
+           em->graph_const_norm == em->const_norm && em->graph_log_norm == em->vb_log_norm;      // (baked kernel arguments, like the bounds)
 }
 static int em_build_graph(sfgpu_em* em, uint32_t n) {
     if (em_graph_ready(em, n)) return SFGPU_OK;
@@ -2478,6 +2480,7 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
     (void)hipGraphDestroy(L.graph);
     SF_HIP(ei);
     em->graph_opts = em->opts; em->graph_iters = n; em->graph_fused = em->fused;
+    em->graph_const_norm = em->const_norm; em->graph_log_norm = em->vb_log_norm;
     return SFGPU_OK;
 }
 
@@ -2490,7 +2493,7 @@ static const void* em_persist_func(bool vb) {
 // the plan's verdict (read back behind the tables), the LDS carve and the chip's residency: every block of the launch must be resident
 static void em_persist_check(sfgpu_em* em) {
     em->persist_ok = 0;
-    const bool say = getenv("SFGPU_TIMING") != nullptr;
+    const bool say = env_timing();
     auto no = [&](const char* why) { if (say) fprintf(stderr, "em persistent: not eligible -- %s\n", why); };
     if (!em->xbuf || !em->pflags || !em->partial_a) return no("no tables (SFGPU_EM_PERSIST=0 at create, or the exchange buffer would pass 2 GB)");
     if (hipEventSynchronize(em->ev_plan) != hipSuccess) return no("plan event");
@@ -2620,7 +2623,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     // (fused: no wait here -- the first launches go out behind init at once and the number of active transcripts is looked at when
     //  the loop has ended: a job without any runs minIter iterations over zeros before it reports so)
     if (!quiet) log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);   // :790
-    const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
+    const bool use_graph = SF_DEV_ENV("SFGPU_EM_NOGRAPH") == nullptr;
     uint32_t chunk = em->opts.iters_per_launch;
     if (em->fused) {
         chunk += chunk & 1u;                                  // (a graph bakes the launches' parities)
@@ -2641,7 +2644,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     // stops the moment the word says ended.  Against graph chunks of 32 iterations: no 14 us between graph launches (7 per cfg3
     // run), ~8 no-op launches past the stop instead of ~48, no graph to build: cfg3 22.5 -> 21.3 us per iteration, EM phase 5.5 -> 5.2 ms.
     {
-        const char* se = getenv("SFGPU_EM_STREAMED");
+        const char* se = SF_DEV_ENV("SFGPU_EM_STREAMED");
         em->streamed = em->fused && !em->persist && !(se && atoi(se) == 0);
     }
     SF_HIP(hipEventRecord(em->ev_a, em->cur));
@@ -2649,7 +2652,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         if ((rc = em_launch_persist(em, persist_ablate))) return rc;
         done = 1;
     } else if (em->streamed) {
-        static const uint32_t kAhead = []() { const char* e = getenv("SFGPU_EM_AHEAD"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 256 ? v : 8); }();
+        static const uint32_t kAhead = []() { const char* e = SF_DEV_ENV("SFGPU_EM_AHEAD"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 256 ? v : 8); }();
         volatile unsigned long long* mir = em->h_mirror;
         *mir = 0ull;
         ++em->run_no;                                         // (a word some launch of an earlier, failed run may still write is not this run's)
@@ -2657,14 +2660,31 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         uint32_t launched = 0;
         if ((rc = iteration(true))) return rc;
         ++launched;
-        for (uint32_t spins = 0;;) {
+        // (the host follows the device through a word of pinned memory: a device that has stopped answering must not spin it for ever --
+        //  every few thousand polls the stream is asked how it is, and two minutes without progress end the run)
+        auto give_up = [&](const char* why) -> int {
+            (void)hipStreamSynchronize(em->cur);              // nothing of this run stays queued behind the error
+            em->in_optimize = false;
+            set_error("sfgpu_em_optimize: %s", why);
+            return SFGPU_ERR_HIP;
+        };
+        const auto t_start = std::chrono::steady_clock::now();
+        unsigned long long last_v = ~0ull; auto t_progress = t_start;
+        for (uint32_t spins = 0, polls = 0;; ++polls) {
             const unsigned long long v = *mir;
+            if ((polls & 4095u) == 4095u) {
+                const hipError_t q = hipStreamQuery(em->cur);
+                if (q != hipSuccess && q != hipErrorNotReady) return give_up(hipGetErrorString(q));
+                const auto now = std::chrono::steady_clock::now();
+                if (v != last_v) { last_v = v; t_progress = now; }
+                else if (std::chrono::duration<double>(now - t_progress).count() > 120.0) return give_up("the EM loop made no progress for two minutes");
+            }
             const bool any = (v >> 33) == (tag >> 33);
             if (any && ((v >> 32) & 1ull)) break;             // a launch found the loop ended: everything behind it is a no-op
             // launch n posts n - 1 updates done at its head; with `launched` enqueued, launched - 2 - posted wait behind the running one
             const uint32_t posted = any ? (uint32_t)v : 0u;
             const uint32_t queued = any ? (launched >= posted + 2u ? launched - posted - 2u : 0u) : launched;
-            if (queued < kAhead) { if ((rc = iteration(false))) return rc; ++launched; spins = 0; }
+            if (queued < kAhead) { if ((rc = iteration(false))) { (void)hipStreamSynchronize(em->cur); em->in_optimize = false; return rc; } ++launched; spins = 0; }
             else if (++spins > 64u) { std::this_thread::yield(); spins = 0; }
         }
         done = 1;
@@ -2830,7 +2850,7 @@ static int em_run_bias(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_bias* bias
     }
     log_msg(0, "Optimizing over %llu equivalence classes", (unsigned long long)em->prob.C);
     const sfgpu_problem& p = em->prob;
-    const bool use_graph = getenv("SFGPU_EM_NOGRAPH") == nullptr;
+    const bool use_graph = SF_DEV_ENV("SFGPU_EM_NOGRAPH") == nullptr;
     const uint32_t chunk = user.iters_per_launch;
     uint32_t recomputes = 0;
     SF_HIP(hipEventRecord(em->ev_a, em->cur));

@@ -605,8 +605,8 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     eq->stream = as_stream(stream);
     eq->expected = expected_classes;
     if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) { eq->sub_batch = (uint32_t)v; eq->part_sub_batch = (uint32_t)v; } }
-    if (const char* e = getenv("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
-    if (const char* e = getenv("SFGPU_EQ_PIPE")) eq->use_pipe = atoi(e) != 0;
+    if (const char* e = SF_DEV_ENV("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
+    if (const char* e = SF_DEV_ENV("SFGPU_EQ_PIPE")) eq->use_pipe = atoi(e) != 0;
     hipError_t e1 = pool_malloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
     hipError_t e2 = pinned_malloc(&eq->h_ctr, (CTR_N + 4) * sizeof(unsigned long long));      // (+ 4: scratch for small readbacks)
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
@@ -743,7 +743,7 @@ static PartGeom part_geometry(uint32_t cnt, uint64_t n_words, uint32_t n_regions
     g.tile_hi = g.tile; g.tile_lo = 0;
     // (150: measured on cfg3 -- equal tiles: first half of the blocks done after 441 us, second after 510; 15 % skew: 486 / 491, the launch
     //  3.4 % shorter, the step 16.59 -> 16.44 ms; cfg2 and the sorted / clustered / long-label probes: no worse.  SFGPU_EQ_SKEW=0: equal tiles)
-    static const uint32_t skew = []() { const char* e = getenv("SFGPU_EQ_SKEW"); long v = e ? atol(e) : 150; return (uint32_t)(v > 0 && v <= 300 ? v : 0); }();
+    static const uint32_t skew = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_SKEW"); long v = e ? atol(e) : 150; return (uint32_t)(v > 0 && v <= 300 ? v : 0); }();
     if (skew && g.n_blocks == mb && (g.n_blocks & 1u) == 0u && g.n_blocks >= 64u && cnt >= (1u << 20)) {
         const uint64_t half = g.n_blocks / 2;
         const uint64_t hi = (((uint64_t)cnt * (1000u + skew) / 1000u + g.n_blocks - 1) / g.n_blocks + 63) & ~63ull;
@@ -756,11 +756,11 @@ static PartGeom part_geometry(uint32_t cnt, uint64_t n_words, uint32_t n_regions
     return g;
 }
 static uint32_t part_max_blocks() {
-    static const uint32_t v = []() { const char* e = getenv("SFGPU_EQ_BLOCKS"); long x = e ? atol(e) : 512; return (uint32_t)(x >= 1 && x <= 1024 ? x : 512); }();
+    static const uint32_t v = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_BLOCKS"); long x = e ? atol(e) : 512; return (uint32_t)(x >= 1 && x <= 1024 ? x : 512); }();
     return v;
 }
 static uint64_t part_load_div() {
-    static const uint64_t v = []() { const char* e = getenv("SFGPU_EQ_LOAD_DIV"); long x = e ? atol(e) : 2; return (uint64_t)(x >= 2 && x <= 8 ? x : 2); }();
+    static const uint64_t v = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_LOAD_DIV"); long x = e ? atol(e) : 2; return (uint64_t)(x >= 2 && x <= 8 ? x : 2); }();
     return v;
 }
 
@@ -919,8 +919,8 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     // OFF by default (SFGPU_EQ_RING=1 selects it): it writes whole 64-byte units -- no partial lines -- but one block per CU is
     // 4 wavefronts per SIMD and the pass is bound by instruction issue there: cfg3 9.4 ms per build against 9.7 under rocprofv3,
     // no difference in the bench step, and skewed / sorted streams and cfg2 are 10-80 % slower (profiles/r3_class_build_notes.md)
-    const int ring_mode = []() { const char* e = getenv("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();      // (read per sub-batch: tests switch it)
-    static const uint32_t ring_blocks = []() { const char* e = getenv("SFGPU_EQ_RING_BLOCKS"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 0); }();
+    const int ring_mode = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_RING"); return e ? atoi(e) : 0; }();      // (read per sub-batch: tests switch it)
+    static const uint32_t ring_blocks = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_RING_BLOCKS"); long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 0); }();
     bool ring = ring_mode != 0 && n_regions >= 2 && n_regions <= kRingMaxRegions;
     // (a bin's share of the stream is computed over ALL regions -- a group's launch fills the bins of its regions only)
     PartGeom gm = part_geometry(cnt, n_words, n_regions, ring ? (ring_blocks ? ring_blocks : (uint32_t)device_cus()) : part_max_blocks());
@@ -933,7 +933,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     // 64-byte units, but its per-region ticket couples the wavefronts of a block (a label waits for every label that reserved
     // before it in its region, wherever that wavefront is) -- route 8.75 ms per build against the direct form's 8.0 on one box
     // (profiles/r4_class_build_notes.md).
-    const int quad_mode = []() { const char* e = getenv("SFGPU_EQ_QUAD"); return e ? atoi(e) : 0; }();         // (read per sub-batch: tests switch it)
+    const int quad_mode = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_QUAD"); return e ? atoi(e) : 0; }();         // (read per sub-batch: tests switch it)
     const bool quad = !ring && quad_mode != 0 && n_groups == 1 && n_regions >= 2 && n_regions <= kRingMaxRegions && gm.cap <= kRingMaxCap;
     const uint32_t n_blocks = gm.n_blocks, tile = gm.tile;
     const uint64_t cap = gm.cap, n_bins = (uint64_t)grp_n * n_blocks;
@@ -958,6 +958,7 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
         RouteArgs ra{d_ids, d_offsets + first, first, cnt, tile, n_regions - 1u, (uint32_t)cap, bins, fill_f, fill_b, cutmarks,
                      eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode, grp_lo, grp_n, 0u, 0u};
         if (!ring && !quad && gm.tile_lo) { ra.tile = gm.tile_hi; ra.tile_lo = gm.tile_lo; ra.half = n_blocks / 2; }
+#ifdef SFGPU_VARIANTS
         if (ring) {
             const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
                                      (size_t)kPartWaves * kRingFlushList * 4;
@@ -973,14 +974,16 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
             }();
             (void)attr_ok;
             hipLaunchKernelGGL(k_part_route<kFormQuad>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
-        } else {
+        } else
+#endif
+        {
             const size_t route_lds = (size_t)2 * grp_n * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
             hipLaunchKernelGGL(k_part_route<kFormDirect>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
         }
         SF_CHECK_LAUNCH();
         PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
                     eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo, 0u, eq->probe.p};
-        static const bool route_only = getenv("SFGPU_X_ROUTE_ONLY") != nullptr;     // (dev: time pass 1 alone -- its experiment variants leave no valid bins)
+        static const bool route_only = SF_DEV_ENV("SFGPU_X_ROUTE_ONLY") != nullptr;     // (dev: time pass 1 alone -- its experiment variants leave no valid bins)
         if (!route_only) hipLaunchKernelGGL(k_part_insert, dim3(grp_n), dim3(kPartBlock), 0, st, pa);
         SF_CHECK_LAUNCH();
         if (g + 1 < n_groups) {
@@ -1037,6 +1040,7 @@ __global__ void k_gather_offsets(const uint32_t* __restrict__ off, uint32_t n_re
 __global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
 __global__ void k_zero_ctr(unsigned long long* ctr) { if (threadIdx.x < (unsigned)CTR_N) ctr[threadIdx.x] = 0ull; }
 
+#ifdef SFGPU_VARIANTS      // (the pipelined form of the partition passes: built, bit-exact, no faster -- profiles/r4_class_build_notes.md section 1)
 static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads, uint32_t* consumed) {
     *consumed = 0;
     hipStream_t sr = eq->stream;
@@ -1265,6 +1269,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
     *consumed = first;
     return SFGPU_OK;
 }
+#endif
 
 // caller holds eq->mu
 static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads,
@@ -1312,12 +1317,16 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
 
     if (!part && (rc = reserve_arena(batch_ids, n_reads))) return rc;
     uint32_t first0 = 0;
-    const bool ring_wanted = []() { const char* e = getenv("SFGPU_EQ_RING"); return e && atoi(e) != 0; }();
+    const bool ring_wanted = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_RING"); return e && atoi(e) != 0; }();
+#ifdef SFGPU_VARIANTS
     if (part && adaptive && eq->use_pipe && !ring_wanted && n_reads >= (1u << 22)) {
         // large batches: the sub-batches are pipelined (route(k + 1) next to insert(k), the host one sub-batch behind)
         if ((rc = eq_pipeline(eq, d_ids, d_offsets, n_reads, &first0))) return rc;
         if (first0) { scout = false; step = usual_step; }      // (whatever is left takes the serial loop at the usual size)
     }
+#else
+    (void)ring_wanted;
+#endif
     // Sub-batches bound the partition buffer and let the table grow between them.  Each one shows how fast
     // new classes appear (the rate only falls as the table fills); the next sub-batch is made up to four
     // times larger (at most 2^26 reads) as long as, at that rate, the table would stay under half full:

@@ -293,13 +293,13 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr; uint32_t* d_thin_off = nullptr;
     uint32_t *d_lens = nullptr, *d_off = nullptr, *d_rows = nullptr;          // plan scratch: the wide classes' labels
     int rc = SFGPU_OK;
-    const bool timing = getenv("SFGPU_TIMING") != nullptr;                 // where a call's time goes (stderr)
+    const bool timing = env_timing();                 // where a call's time goes (stderr)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     auto t_mark = now();
     auto lap = [&](const char* what) {
         if (!timing) return;
-        if (atoi(getenv("SFGPU_TIMING")) != 2) (void)hipStreamSynchronize(st);       // (2: host-side times only)
+        (void)hipStreamSynchronize(st);
         fprintf(stderr, "gibbs timing: %-12s %9.2f ms\n", what, ms_since(t_mark));
         t_mark = now();
     };

@@ -57,6 +57,15 @@ def sf(gpu):
     return sailfish_amd
 
 
+def _needs_variants():
+    """the kernel forms that lost their A/Bs (ring / quad / pipelined class build, graph-replayed EM loops) live in builds made with
+    -DSFGPU_VARIANTS only (tools/eq_variants.sh all:"" ; SFGPU_LIB_PATH=sailfish_amd/csrc/variants/libsfgpu_all.so): their tests
+    run against such a library and are skipped against the product"""
+    from sailfish_amd import _lib
+    if not _lib.lib().sfgpu_has_variants():
+        pytest.skip("the product library does not contain this variant (build one with tools/eq_variants.sh / tools/em_variants.sh)")
+
+
 # ---------------------------------------------------------------------------------------- a1
 def test_xxh64_kernel_golden_and_random(sf, gpu):
     g = json.load(open(os.path.join(GOLD, "xxh64_vectors.json")))["vectors"]
@@ -337,6 +346,7 @@ def test_builder_large_host_batch_is_streamed_in_chunks(sf, gpu, monkeypatch, ch
 
 @pytest.mark.parametrize("form", ["SFGPU_EQ_RING", "SFGPU_EQ_QUAD"])
 def test_builder_ring_form_of_the_route_pass(sf, gpu, monkeypatch, form):
+    _needs_variants()
     """SFGPU_EQ_RING=1: pass 1 writes its bins through LDS rings (whole 64-byte units from the front of a bin, long labels and
     labels that would have to wait for a ring slot directly at its back; eqclass_part.h) -- off by default, measured no faster;
     the classes must be the oracle's whichever form ran: the benchmark's law, a skewed stream with hot labels, runs of identical
@@ -426,6 +436,7 @@ def test_builder_beyond_partition_limit(sf, gpu, n, dup, min_slots):
 
 @pytest.mark.parametrize("shape", ["uniform", "hot", "sorted", "many_classes", "long_and_empty"])
 def test_builder_pipelined_partition_passes(sf, gpu, monkeypatch, shape):
+    _needs_variants()
     """Batches of >= 4 M reads take the PIPELINED partition passes (round 4: route(k + 1) next to insert(k) on a second stream,
     two sets of bins, class ids from a device-side counter, the host one sub-batch behind; eq_pipeline in eqclass.hip).  The
     classes must be the oracle's, and the serial form's (SFGPU_EQ_PIPE=0), on: the benchmark's law; a stream with hot labels

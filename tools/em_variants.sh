@@ -5,11 +5,12 @@ set -e
 cd "$(dirname "$0")/../sailfish_amd/csrc"
 mkdir -p variants
 make -s -j8 all
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-result -DSFGPU_VARIANTS"
 for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   hipcc $FLAGS $defs -c em.hip -o variants/em_$name.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libsfgpu_$name.so build/core.o build/eqclass.o variants/em_$name.o build/misc.o build/primitives.o \
+  hipcc $FLAGS -c core.hip -o variants/core_v.o           # (sfgpu_has_variants() answers 1)
+  hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libsfgpu_$name.so variants/core_v.o build/eqclass.o variants/em_$name.o build/misc.o build/primitives.o \
         build/sampling.o build/gibbs.o build/filter.o build/bias.o build/merge.o build/mapper.o build/comm.o -Wl,-rpath,/opt/rocm/lib
   echo built $name "($defs)"
 done

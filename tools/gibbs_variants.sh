@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../sailfish_amd/csrc"
 mkdir -p variants
 make -s -j8 all
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-result -DSFGPU_VARIANTS"
 for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   for f in gibbs sampling; do hipcc $FLAGS $defs -c $f.hip -o variants/${f}_$name.o; done
