@@ -270,6 +270,11 @@ typedef int (*sfgpu_allreduce_fn)(double* d_buf, uint64_t n, void* user, sfgpu_s
 SFGPU_API int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_allreduce_fn allreduce, void* user,
                                         uint32_t poll_every, double* d_alpha_out, double* d_mass_out, sfgpu_em_stats* stats);
 /* the stream the handle's kernels run on (what to pass to a collective that must be ordered with them) */
+/* The sharded loop with ONE sweep kernel per iteration (the update folded into the head of the next sweep, as in optimize()): sweep +
+ * fold + all-reduce per iteration instead of sweep + fold + all-reduce + update.  Every rank must run the same form: ask each rank
+ * (sfgpu_em_sharded_fused_ok: 1 if its plan allows it), agree on the minimum, tell each rank (sfgpu_em_set_sharded_fused). */
+SFGPU_API int sfgpu_em_sharded_fused_ok(sfgpu_em* em);
+SFGPU_API int sfgpu_em_set_sharded_fused(sfgpu_em* em, int on);
 SFGPU_API sfgpu_stream sfgpu_em_stream(sfgpu_em* em);
 
 /* ---------------------------------------------------------------------------------------------

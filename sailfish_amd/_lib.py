@@ -140,6 +140,8 @@ _SIGS = {
     "sfgpu_em_poll": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(EmStats)]),
     "sfgpu_em_finish": (C.c_int, [_P, _P, _P, C.POINTER(EmStats)]),
     "sfgpu_em_optimize_sharded": (C.c_int, [_P, C.POINTER(EmOpts), ALLREDUCE_CB, _P, C.c_uint32, _P, _P, C.POINTER(EmStats)]),
+    "sfgpu_em_sharded_fused_ok": (C.c_int, [_P]),
+    "sfgpu_em_set_sharded_fused": (C.c_int, [_P, C.c_int]),
     "sfgpu_em_stream": (_P, [_P]),
     "sfgpu_comm_available": (C.c_int, []),
     "sfgpu_comm_unique_id": (C.c_int, [_P]),

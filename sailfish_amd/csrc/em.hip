@@ -906,6 +906,7 @@ k_csc_write(const uint32_t* __restrict__ kv, const uint32_t* __restrict__ idx, c
 struct SweepArgs {
     // (what the head of the kernel needs comes first: the kernel arguments are fetched 64 bytes at a time)
     const TileDesc* td; EmState* st; uint32_t min_iter, max_iter, par, first;
+    uint32_t sharded;                                                    // FUSED inside the sharded loop: alpha' is the all-reduced vector alone (the fold ran before the all-reduce)
     uint32_t null_cls;                                                   // GATHER: the class index of the transcript-major copy's padding (the plan's largest class count of a tile)
     const uint32_t* stream; const uint32_t* chdr;                        // GATHER: 16-bit window slots, 8 per chunk, + one header word per chunk
     const double* x; const uint32_t* counts;
@@ -992,6 +993,7 @@ k_sweep_lds(SweepArgs a) {
         if constexpr (FUSED) {
             const uint32_t it_next = (stop || a.first) ? it : it + 1;       // updates done once this launch has ended
             st->itv[a.par ^ 1u] = it_next; st->it_a = it_next;
+            st->it_b = stop ? kDoneMark : (a.first ? it : it + 1u);        // the sweep this launch runs (k_fold_slots, sharded loop)
             if (!stop) st->notconv3[it_next % 3u] = 0;                        // (the slot of the update the NEXT launch runs)
             // the streamed loop of em_run: the host follows the device through this word of pinned memory (no copy, no post kernel)
             if (a.post) __hip_atomic_store(a.post, (unsigned long long)it | ((unsigned long long)(stop ? 1u : 0u) << 32) | a.post_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1029,7 +1031,7 @@ k_sweep_lds(SweepArgs a) {
     auto new_alpha = [&](uint32_t t) -> double {
         double ap = rd_aout[t];
         const uint2 cr = a.cov2[t];
-        for (uint32_t k = cr.x; k < cr.y; ++k) ap += rd_part[a.cov_pos[k]];
+        if (!a.sharded) for (uint32_t k = cr.x; k < cr.y; ++k) ap += rd_part[a.cov_pos[k]];
         if (VB) ap += kPriorAlpha;
         return ap;
     };
@@ -1176,6 +1178,7 @@ k_sweep_lds(SweepArgs a) {
         if (FUSED && upd) {
             double ap = rd_aout[t];
             const double len = a.lenc[t];
+            if (a.sharded) sl = make_uint2(kNoSlot, kNoSlot);             // (the reduced vector is complete)
             const double q0 = sl.x != kNoSlot ? rd_part[sl.x] : 0.0, q1 = sl.y != kNoSlot ? rd_part[sl.y] : 0.0;
             if (sl.x != kNoSlot) ap += q0;
             if (sl.y != kNoSlot) {
@@ -1205,13 +1208,13 @@ k_sweep_lds(SweepArgs a) {
             for (int j = 0; j < kNbMax; ++j) {
                 const uint4 e = td.e[j];                                     // {lo', span', off', tile'}
                 in[j] = has && (uint32_t)j < nb_n && (pos - e.x) < e.y;
-                pj[j] = (upd && in[j]) ? rd_part[(uint64_t)e.z + (pos - e.x)] : 0.0;
+                pj[j] = (upd && in[j] && !a.sharded) ? rd_part[(uint64_t)e.z + (pos - e.x)] : 0.0;
                 if (in[j] && (uint32_t)j < nb_before) home = false;
             }
             if (has) {
                 if (upd) {
                     ap = rd_aout[pos]; len = a.lenc[pos];
-                    const double own = rd_part[off + threadIdx.x];
+                    const double own = a.sharded ? 0.0 : rd_part[off + threadIdx.x];
                     if (home) av = a.alpha[pos];
                     // (the LDS accumulators are cleared below, while these words travel)
 #pragma unroll
@@ -1230,7 +1233,7 @@ k_sweep_lds(SweepArgs a) {
             if (upd) {
                 ap = rd_aout[pos]; len = a.lenc[pos];
                 if (home) av = a.alpha[pos];
-                for (uint32_t k = k0; k < k1; ++k) ap += rd_part[a.cov_pos[k]];
+                if (!a.sharded) for (uint32_t k = k0; k < k1; ++k) ap += rd_part[a.cov_pos[k]];
                 if (VB) ap += kPriorAlpha;
             } else xv = x_first(pos);
         }
@@ -1447,6 +1450,25 @@ __device__ __forceinline__ double fold_partials(uint64_t t, const uint32_t* __re
     return s;
 }
 
+// the sharded loop with ONE sweep kernel per iteration: the fused sweep published its window sums slot-major; this adds a transcript's
+// sums (cover list, tile order) to what the sweep's far members left in the accumulator of sweep `sw` -- the vector the all-reduce
+// then sums over the ranks.  sw comes from the state block (the sweep's head wrote it; kDoneMark: the loop has ended)
+__global__ void __launch_bounds__(kEmBlock)
+k_fold_slots(uint64_t M, const uint2* __restrict__ cov2, const uint32_t* __restrict__ cov_pos, const double* __restrict__ part_a,
+             const double* __restrict__ part_b, double* aout_a, double* aout_b, double* aout_c, const EmState* st) {
+    const uint32_t sw = st->it_b;
+    if (sw == kDoneMark) return;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    const double* __restrict__ part = (sw & 1u) ? part_b : part_a;
+    double* aout = (sw % 3u) == 0u ? aout_a : ((sw % 3u) == 1u ? aout_b : aout_c);
+    const uint2 r = cov2[t];
+    if (r.x == r.y) return;
+    double s2 = 0.0;
+    for (uint32_t k = r.x; k < r.y; ++k) s2 += part[cov_pos[k]];
+    aout[t] += s2;
+}
+
 // piecewise API: make alphaOut complete before the caller's all-reduce
 __global__ void k_fold(uint64_t M, double* alpha_out, const uint32_t* __restrict__ cov_ptr,
                        const uint32_t* __restrict__ cov_pos, const double* __restrict__ partial, const EmState* st) {
@@ -1633,6 +1655,7 @@ struct sfgpu_em {
     uint32_t far_cap = 0;
     bool persist = false;                                   // this optimize() runs as one launch
     bool no_persist = false;                                // set while several bootstrap lanes run (see sfgpu_bootstrap)
+    int sharded_fused = 0;                                  // sfgpu_em_set_sharded_fused: the sharded loop runs one sweep kernel per iteration (every rank agreed)
     uint64_t* bs_prefix = nullptr; uint32_t* bs_base = nullptr;   // bootstrap: prefix sums / copy of the observed counts
     uint32_t *bs_scratch_a = nullptr, *bs_scratch_b = nullptr; uint64_t bs_total = 0;
     EmState* d_state = nullptr;
@@ -1734,9 +1757,9 @@ static int em_enqueue_sweep(sfgpu_em* em) { Launcher L; L.stream = em->cur; retu
 // one FUSED launch: the update of the iteration before + the sweep of this one (k_sweep_lds<.., true, true>).  `first`: nothing to
 // update yet -- x comes from the x vector that init made.  The launch's parity is a kernel argument (a graph bakes it: chunks hold
 // an even number of launches).
-static int em_enqueue_fused(sfgpu_em* em, Launcher& L, bool first) {
+static int em_enqueue_fused(sfgpu_em* em, Launcher& L, bool first, bool sharded = false) {
     SweepArgs a = em_sweep_args(em);
-    a.par = em->par; a.first = first ? 1u : 0u;
+    a.par = em->par; a.first = first ? 1u : 0u; a.sharded = sharded ? 1u : 0u;
     a.post = em->streamed ? em->h_mirror : nullptr; a.post_tag = (1ull << 33) | ((unsigned long long)(em->run_no & 0xFFFFFu) << 34);
     if (em->inv) { a.alpha = em->alphaP; a.lenc = em->lencP; a.esc_id = em->esc_pos; }      // (per-transcript arrays in the plan's order)
     void* args[] = {&a};
@@ -2409,6 +2432,26 @@ int sfgpu_em_finish(sfgpu_em* em, double* d_alpha_out, double* d_mass_out, sfgpu
 
 sfgpu_stream sfgpu_em_stream(sfgpu_em* em) { return em ? reinterpret_cast<sfgpu_stream>(em->cur) : nullptr; }
 
+// Can this handle run the sharded loop with one sweep kernel per iteration?  (its plan has the fused kernel's tables, the caller's
+// transcript order -- a plan with an order of its own indexes its vectors by position, which the other ranks' plans do not share --
+// and VBEM's normaliser is the run's constant.)  A multi-rank host asks every rank, takes the minimum (a collective of its own) and
+// tells every rank the answer with sfgpu_em_set_sharded_fused: all ranks must run the same form.
+int sfgpu_em_sharded_fused_ok(sfgpu_em* em) {
+    if (!em || !em->gather || !em->partial_a || em->inv || em->prob.C == 0) return 0;
+    if (const char* fe = getenv("SFGPU_EM_FUSED")) if (atoi(fe) == 0) return 0;
+    if (getenv("SFGPU_EM_EXACT_NORM") != nullptr) return 0;
+    if (em->fused_ok < 0) {
+        if (hipEventSynchronize(em->ev_plan) != hipSuccess) return 0;
+        em->fused_ok = ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 2u) == 0u && em->partial_a) ? 1 : 0;
+    }
+    return em->fused_ok == 1 ? 1 : 0;
+}
+int sfgpu_em_set_sharded_fused(sfgpu_em* em, int on) {
+    SF_REQUIRE(em, SFGPU_ERR_INVALID, "sfgpu_em_set_sharded_fused: null handle");
+    em->sharded_fused = on ? 1 : 0;
+    return SFGPU_OK;
+}
+
 // classes partitioned over the ranks, alpha replicated, one SUM all-reduce of alphaOut per iteration; the
 // transport is the caller's (RCCL in a multi-GPU host), the loop is the piecewise one
 int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_allreduce_fn allreduce, void* user, uint32_t poll_every,
@@ -2434,6 +2477,31 @@ int sfgpu_em_optimize_sharded(sfgpu_em* em, const sfgpu_em_opts* opts, sfgpu_all
     }
     if (poll_every == 0) poll_every = 16;
     em->h_mirror[0] = em->h_mirror[8] = 0ull;
+    if (em->sharded_fused && sfgpu_em_sharded_fused_ok(em) == 1) {
+        // ONE sweep kernel per iteration (round 5): the update of iteration it - 1 runs at the head of sweep `it` from the all-reduced
+        // vector alone (k_sweep_lds<.., .., FUSED> with `sharded`: no neighbour sums to add -- the fold below ran before the
+        // all-reduce), so an iteration is sweep + fold + all-reduce instead of sweep + fold + all-reduce + update.  The accumulators
+        // rotate through three buffers as in the fused loop (read L - 1's sum, add into L's, zero L + 1's); the stop test lags one
+        // launch, and launches past the stop are no-ops whose all-reduce sums a vector nobody reads.  Every rank runs this form or
+        // none does (sfgpu_em_set_sharded_fused after a collective agreement): the two forms notice the stop one iteration apart.
+        em->fused = true; em->par = 0;
+        double* bufs[3] = {em->alpha_out, em->aout_b, em->aout_c};
+        uint32_t L = 0;
+        for (uint32_t k = 0; !done; ++k) {
+            for (uint32_t i = 0; i < poll_every; ++i, ++L) {
+                Launcher Ln; Ln.stream = em->cur;
+                if ((rc = em_enqueue_fused(em, Ln, L == 0, true))) return rc;
+                hipLaunchKernelGGL(k_fold_slots, dim3(blocks_for(M)), dim3(kEmBlock), 0, em->cur, M, em->cov2, em->cov_pos, em->partial_a, em->partial_b,
+                                   em->alpha_out, em->aout_b, em->aout_c, em->d_state);
+                SF_CHECK_LAUNCH();
+                const int cr = allreduce(bufs[L % 3u], M, user, reinterpret_cast<sfgpu_stream>(em->cur));
+                if (cr) { set_error("sfgpu_em_optimize_sharded: the all-reduce callback returned %d", cr); return SFGPU_ERR_STATE; }
+            }
+            if ((rc = em_poll_start(em, (int)(k & 1u), true))) return rc;
+            if (k > 0 && (rc = em_poll_wait(em, (int)((k - 1u) & 1u), false, &done))) return rc;
+        }
+        return sfgpu_em_finish(em, d_alpha_out, d_mass_out, stats);
+    }
     // (Iterations past the stop -- up to 2 poll_every of them -- still run their all-reduce.  What it sums then is all zeros: the last
     //  update zeroed alphaOut, and past the stop the sweep, k_fold and the update return at once, so nothing can grow; finish() and
     //  the statistics never read alphaOut.  The collective itself is the price of not having the host in the loop.)

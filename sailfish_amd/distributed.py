@@ -447,6 +447,12 @@ class DistributedQuant:
             if bias is None:
                 # the whole loop in C: begin -> all-reduce (union of the active sets) -> init -> { sweep, all-reduce,
                 # update } with the stop latch polled every poll_every iterations -> finish
+                # (one sweep kernel per iteration if EVERY rank's plan allows it: the two forms of the loop notice the stop one iteration
+                #  apart, so the ranks agree first -- a MIN all-reduce of one flag per problem)
+                if hasattr(p, "sharded_fused_ok"):
+                    flag = torch.tensor([int(p.sharded_fused_ok())], dtype=torch.int32, device=(self.engine.device if dist.get_backend(self.group) == "nccl" else "cpu"))
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                    p.set_sharded_fused(bool(int(flag.item())))
                 rc, st = p.optimize_sharded(self._allreduce(), poll_every=self.poll_every, **kw)
             else:
                 # doBiasCorrect: the loop runs in segments that end at the recompute iterations: the stop bounds are lowered

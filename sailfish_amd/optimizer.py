@@ -50,6 +50,14 @@ class EMProblem:
                                             _lib.ptr(eff), C.byref(nr), C.byref(st))
         return rc, st.as_dict(), eff, nr.value
 
+    def sharded_fused_ok(self):
+        """can this rank's slice run the sharded loop with one sweep kernel per iteration? (sfgpu_em_sharded_fused_ok)"""
+        return bool(self._L.sfgpu_em_sharded_fused_ok(self._h))
+
+    def set_sharded_fused(self, on):
+        """what the ranks agreed on (the minimum of sharded_fused_ok over the ranks): every rank runs the same form of the loop"""
+        _lib.check(self._L.sfgpu_em_set_sharded_fused(self._h, int(bool(on))))
+
     def optimize_sharded(self, allreduce, poll_every=16, **kw):
         """The sharded loop as ONE call (sfgpu_em_optimize_sharded): this handle holds one rank's slice of the classes,
         `allreduce` leaves the sum of alphaOut over the ranks on every rank -- a sailfish_amd.comm.Comm (ncclAllReduce on

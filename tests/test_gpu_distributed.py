@@ -206,6 +206,27 @@ def test_rccl_comm_drives_the_sharded_loop(gpu):
             nz = want > 0
             assert torch.equal(p.alpha > 0, nz)
             assert float(((p.alpha[nz] - want[nz]).abs() / want[nz]).max()) < 1e-9
+            # round 5: the same loop with ONE sweep kernel per iteration (the update at the head of the next sweep, from the
+            # all-reduced vector): this midsize table's tiles crowd one window (cover lists), a local table's do not -- both forms
+            # must stop where optimize() stops, with its alpha
+            for table in ("midsize", "local"):
+                if table == "local":
+                    rl2, ids2, off2 = synth.workload(60_000, 200_000, 2_000_000)
+                    eq2 = sf.EquivalenceClassBuilder(device=gpu); eq2.start(); eq2.add_batch(ids2.to(gpu), off2.to(gpu)); eq2.finish(); v2 = eq2.eqVec()
+                    pf = sf.EMProblem(rl2.to(gpu).to(torch.float64), v2.rowptr, v2.ids, v2.counts, eq2.total_reads)
+                    rcw, stw = pf.optimize(use_vbem=vb); want_f = pf.alpha.clone()
+                else:
+                    pf, stw, want_f = p, st, want
+                assert pf.sharded_fused_ok()
+                pf.set_sharded_fused(True)
+                rc4, st4 = pf.optimize_sharded(c, poll_every=7, use_vbem=vb)
+                pf.set_sharded_fused(False)
+                assert rc4 == 0 and st4["iters"] == stw["iters"] and st4["converged"] == stw["converged"] and st4["fused"]
+                nzf = want_f > 0
+                assert torch.equal(pf.alpha > 0, nzf)
+                assert float(((pf.alpha[nzf] - want_f[nzf]).abs() / want_f[nzf]).max()) < 1e-9
+                assert abs(st4["max_rel_diff"] - stw["max_rel_diff"]) <= 1e-9 * abs(stw["max_rel_diff"])
+                if pf is not p: pf.close()
             # and with a Python callable in the callback's place (what the gloo dry runs use)
             calls = []
             rc3, st3 = p.optimize_sharded(lambda buf: calls.append(buf.numel()), poll_every=7, use_vbem=vb)
