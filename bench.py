@@ -362,6 +362,11 @@ def main():
                 traffic_em = bytes_of(max(plain, key=lambda v: v.get("launches", 0)))
             if fusedk:
                 traffic_em_iter = bytes_of(max(fusedk, key=lambda v: v.get("launches", 0)))
+            # the persistent loop (round 5): ONE launch holds all iterations -- its counters divided by the steps it ran (the iterations
+            # + the one sweep that runs for nothing before the stop is known)
+            persk = [v for n, v in k.items() if n.startswith(f"k_em_persist<{vbs}")]
+            if persk and st.get("persistent"):
+                traffic_em_iter = bytes_of(max(persk, key=lambda v: v.get("launches", 0))) / (st["iters"] + 1)
             # class build = the partition kernels of one sub-batch (k_insert on the generic path)
             parts = [v for v in (pick("k_part_route"), pick("k_part_insert")) if v] or [v for v in (pick("k_insert"),) if v]
             if parts:
@@ -387,12 +392,15 @@ def main():
                    bytes_per_launch=b_sweep, bytes_formula="4 L + 8 C + 16 M (sweep only: labels, rowptr + count, x gathered, partials published)",
                    avg_launch_ms=sweep_ms, launches_per_step=st["iters"])
     it_s = em_loop_ms_per_iter * 1e-3
-    roof_em_iter = dict(bound="hbm", kernel=("one EM iteration as the loop runs it (ONE kernel: the update of the iteration before at the head of the sweep; + chunk boundaries)"
+    persistent = bool(st.get("persistent"))
+    roof_em_iter = dict(bound="hbm", kernel=("one EM iteration inside the persistent loop (k_em_persist: ONE launch per optimize(); the device time of the launch / its iterations)"
+                                            if persistent else
+                                            "one EM iteration as the loop runs it (ONE kernel: the update of the iteration before at the head of the sweep; + chunk boundaries)"
                                             if fused else "one EM iteration as the loop runs it (sweep + update + chunk boundaries)"),
                         achieved=b_iter / it_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b_iter / it_s / 1e9 / HBM_PEAK_GBS,
                         traffic=(traffic_em_iter if fused else None), traffic_source=(traffic_src if fused else None),
                         bytes_per_launch=b_iter, bytes_formula="B_iter' = 4 L + 8 C + 48 M (+ 16 M VBEM), SURVEY 8d aux-weight-free variant",
-                        avg_launch_ms=em_loop_ms_per_iter, launches_per_step=st["iters"])
+                        avg_launch_ms=em_loop_ms_per_iter, launches_per_step=(1 if persistent else st["iters"]), iterations_per_step=st["iters"], persistent=persistent)
     # class build: SURVEY 8d's B_read (ids + offset + one 16-byte slot probe) and, next to it, the COMPULSORY bytes alone
     # (ids + offset: what any builder must read), so that the probe term cannot flatter the fraction
     b_comp = 4.0 * n_hits / R_local + 4.0
@@ -489,7 +497,7 @@ def main():
         try:
             p = quant.problem
             nb = max(1, a.bootstrap_draws)
-            p.bootstrap(1, seed=3, use_vbem=use_vbem)                               # warm-up (the lanes' clones are planned once)
+            p.bootstrap(3, seed=3, use_vbem=use_vbem)                               # warm-up: three draws, so that all three lanes' clones are planned here, once
             torch.cuda.synchronize(); t1 = time.perf_counter()
             rc_b, outb, itb = p.bootstrap(nb, seed=1, use_vbem=use_vbem)
             torch.cuda.synchronize(); dtb = time.perf_counter() - t1

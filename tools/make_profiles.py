@@ -16,7 +16,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FETCH_X2 = ("k_sweep_lds", "k_part_route", "k_part_insert", "k_filter", "k_export")
+FETCH_X2 = ("k_sweep_lds", "k_em_persist", "k_part_route", "k_part_insert", "k_filter", "k_export")
 
 
 def find(d, suffix):
