@@ -642,7 +642,7 @@ struct alignas(64) TileDesc {
     uint64_t qb; uint32_t np, nm;                          // GATHER: the transcript-major copy (pure chunks, mixed chunks)
     uint32_t pr, nb_n, nb_before, f0;                      // nb_*: FUSED, the overlapping tiles below; f0: first far slot (em_persist.h)
     uint4 e[kNbMax];                                       // {lo', span', off', tile'}
-    uint32_t nf, pad1[3];                                  // nf: distinct far transcripts of the tile = its far slots
+    uint32_t nf, ov0, n_ov, pad1;                          // nf: distinct far transcripts of the tile = its far slots; ov0 / n_ov: overflow chunks of its long classes (em_persist.h)
 };
 static_assert(sizeof(TileDesc) == 192, "three 64-byte scalar loads");
 __global__ void k_tile_desc(uint32_t n_tiles, const uint32_t* __restrict__ tile_c0, const uint32_t* __restrict__ tile_lo,
@@ -1649,6 +1649,7 @@ struct sfgpu_em {
     uint32_t null_cls = kTileNnz;                           // GATHER: class index of the transcript-major copy's padding = the largest class count of a tile
     // the PERSISTENT loop (em_persist.h): far-slot tables, the exchange buffer (control words + granule arrays), the plan's verdict
     uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
+    uint4 *cls8 = nullptr, *ov8 = nullptr; uint32_t* ovc = nullptr;        // phase A's chunk-per-class stream and the long classes' overflow
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
@@ -1678,7 +1679,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->xbuf, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->cls8, em->ov8, em->ovc, em->xbuf, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -1912,7 +1913,7 @@ static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint
 // The persistent loop's part of the plan (em_persist.h): far slots per tile, the lists of far slots per target, the exchange buffer.
 // Leaves em->pflags on the device ([0] != 0: this plan does not run persistent; [1]: the most far slots a tile has); sfgpu_em_create
 // queues their read-back.  Nothing is waited for.
-static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P) {
+static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, const uint32_t* p_rowptr) {
     static const bool off = []() { const char* e = getenv("SFGPU_EM_PERSIST"); return e && atoi(e) == 0; }();
     if (off || 2 * P * 16ull + 3 * E * 16ull >= (1ull << 31)) return SFGPU_OK;                  // (granules are addressed with 32-bit byte offsets)
     const uint64_t M = em->prob.M;
@@ -1946,6 +1947,19 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P) {
         if ((rc = sort_pairs_u64_u32(k2_in, k2_out, v_in, v_out, E, st, 32 + pbits, false))) return rc;     // (values unused)
         hipLaunchKernelGGL(k_ft_ranges, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, k2_out, em->ftgt, em->ft_list);
         hipLaunchKernelGGL(k_far_xi, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, em->far_pos, em->ftgt, em->cov2, em->far_xi, em->pflags);
+        SF_CHECK_LAUNCH();
+    }
+    {   // phase A's chunk-per-class stream (k_cls8_build): from the compact stream's 16-bit slots, the plan's rowptr and tile table
+        const uint64_t C = em->prob.C, Lnz = em->L;
+        uint32_t* extra = nullptr; uint64_t* ov_start = nullptr;
+        SF_HIP(pool_malloc(&extra, (C + 2) * 4)); SF_HIP(pool_malloc(&ov_start, (C + 3) * 8));
+        SF_HIP(pool_malloc(&em->cls8, (C ? C : 1) * 16)); SF_HIP(pool_malloc(&em->ovc, (Lnz / 8 + 2) * 4)); SF_HIP(pool_malloc(&em->ov8, (Lnz / 8 + 2) * 16));
+        hipLaunchKernelGGL(k_cls8_count, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, st, C, p_rowptr, extra);
+        int rc = exclusive_scan_u32(extra, ov_start, C, st, false);
+        if (!rc) hipLaunchKernelGGL(k_cls8_build, dim3(nt), dim3(kEmBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
+                                    ov_start, em->cls8, em->ovc, em->ov8, em->td);
+        { void* ps[2] = {extra, ov_start}; pool_free_on_many(ps, 2, st); }
+        if (rc) return rc;
         SF_CHECK_LAUNCH();
     }
     // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned
@@ -2160,7 +2174,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             }
             if (cr) { em_free(em); return cr; }
         }
-        if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }
+        // (rowptr2 / vids, a renumbered plan's class table, are freed at the end: the persistent loop's plan reads the plan's rowptr)
         EM_TRY(pool_malloc(&em->partial, (P ? P : 1) * 8));
         EM_TRY(pool_malloc(&em->cov_pos, (P ? P : 1) * 4));
         EM_TRY(pool_malloc(&em->pub_pos, (P ? P : 1) * 4));
@@ -2240,7 +2254,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             }
             EM_TRY(hipGetLastError());
             {   // the persistent loop's tables (em_persist.h); its verdict rides on the read-back below
-                const int pr = em_persist_plan(em, nt, E, P);
+                const int pr = em_persist_plan(em, nt, E, P, p_rowptr);
                 if (pr) { em_free(em); return pr; }
             }
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
@@ -2256,6 +2270,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                         nt > by_list ? (double)nb_sum / (nt - by_list) : 0.0, (double)span_sum / nt);
             }
         }
+        if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }
     }
 #undef EM_TRY
     *out = em;
@@ -2597,7 +2612,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
     c.far_off[0] = (uint32_t)o; o += up(En * 16); c.far_off[1] = (uint32_t)o; o += up(En * 16); c.xpub_off = (uint32_t)o;
     a.tiles = em->td; c.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
-    a.stream = em->lstream; a.chdr = em->chdr; a.counts = em->counts32; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
+    a.cls8 = em->cls8; a.ovc = em->ovc; a.ov8 = em->ov8; a.counts = em->counts32; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
     c.x = em->x; c.inv = em->inv;
     a.lenc = em->inv ? em->lencP : em->lenc; a.alpha = em->inv ? em->alphaP : em->alpha;
     c.esc_cls = em->esc_cls; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;

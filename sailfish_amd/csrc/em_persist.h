@@ -112,6 +112,45 @@ __global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const ui
 // per SIMD, and what does not fit is spilled into VGPR lanes and fetched back with a v_readlane apiece all over the hot phases.
 // (Measured the other way round too, profiles/r5_em_notes.md: EVERYTHING read through memory at each phase's start costs a dependent scalar
 //  round trip per phase, 16 -> 21 us per step on cfg3.)
+// ---- phase A's stream for the persistent loop: ONE 16-byte chunk per class (round 5) ------------------------------------------------
+// The compact class-major stream of k_sweep_lds packs the nonzeros eight to a chunk regardless of class boundaries: a lane walks its
+// chunk, detects where a class ends and hands every run to den[] with an LDS atomic -- ~100 instructions per chunk, half of them the
+// branches around the atomics, and ~2.4 atomics.  Classes average 5.8 members, so here a class IS a chunk: its first eight window slots
+// (16 bits each; kWin = the null slot, whose x is 0: padding, a far member), lane per class: eight LDS reads, a tree of adds, one plain
+// store -- no run detection, no atomic.  A class with more than eight members, or with a far member (whose x arrives by atomic), is
+// flagged LONG (bit 15 of slot 0): its chunks add with atomics, the ones behind the first come from an overflow list (class, 8 slots).
+constexpr uint32_t kCls8Long = 0x8000u;
+__global__ void k_cls8_count(uint64_t C, const uint32_t* __restrict__ rowptr, uint32_t* extra) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { const uint32_t k = rowptr[c + 1] - rowptr[c]; extra[c] = k > 8u ? (k - 8u + 7u) / 8u : 0u; } else if (c == C) extra[c] = 0u;
+}
+__global__ void __launch_bounds__(kEmBlock)
+k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
+             const uint16_t* __restrict__ slot16, const uint64_t* __restrict__ ov_start, uint4* cls8, uint32_t* ovc, uint4* ov8, TileDesc* td) {
+    const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1];
+    const uint64_t s0 = tile_s0[T];
+    const uint32_t j0 = rowptr[c0];
+    if (threadIdx.x == 0) { td[T].ov0 = (uint32_t)ov_start[c0]; td[T].n_ov = (uint32_t)(ov_start[c1] - ov_start[c0]); }
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
+        const uint16_t* sl = slot16 + s0 + (b - j0);
+        uint32_t w[8]; bool far = false;
+        for (uint32_t m = 0; m < 8u; ++m) { w[m] = m < k ? sl[m] : (uint32_t)kWin; if (m < k && w[m] == (uint32_t)kWin) far = true; }
+        for (uint32_t m = 8u; m < k; ++m) if (sl[m] == (uint16_t)kWin) far = true;
+        const bool single = k == 1u;                              // (a singleton's denominator is never used: nothing to read)
+        if (single) w[0] = kWin;
+        if (k > 8u || far) w[0] |= kCls8Long;
+        cls8[c] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
+        uint64_t at = ov_start[c];
+        for (uint32_t m0 = 8u; m0 < k; m0 += 8u, ++at) {
+            uint32_t v[8];
+            for (uint32_t m = 0; m < 8u; ++m) v[m] = m0 + m < k ? sl[m0 + m] : (uint32_t)kWin;
+            ovc[at] = c - c0;
+            ov8[at] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        }
+    }
+}
+
 struct PersistCold {
     EmState* st; const double* x; const uint32_t* inv;    // x of sweep 0 (init made it, in the caller's order); position -> transcript
     const uint32_t* esc_cls; const uint32_t* esc_far;     // per escape: class << 16 | single ; far slot in the tile
@@ -125,7 +164,8 @@ struct PersistCold {
 struct PersistArgs {
     const TileDesc* tiles; const PersistCold* cold;
     uint32_t min_iter, max_iter, n_tiles; int check_mode;
-    const uint32_t* stream; const uint32_t* chdr; const uint32_t* counts;
+    const uint4* cls8; const uint32_t* ovc; const uint4* ov8;      // phase A: a chunk per class, the overflow of long classes (class in the tile, 8 slots)
+    const uint32_t* counts;
     const unsigned char* csc; const uint16_t* csc_slot0;
     const double* lenc; double* alpha;                    // by position of the plan's order
     const uint2* ftgt;                                    // per position: [k0, k1) of ft_list (null: the plan has no far members)
@@ -181,8 +221,8 @@ k_em_persist(PersistArgs a) {
 #endif
     const uint32_t tid0 = threadIdx.x;
     // ---- the tile: what the hot phases need, as scalars; the rest of the record (e0, f0) is read where a far member needs it
-    uint32_t lo, n8, nc, np, nm, n_esc, nf, off, nb_n, nb_before, delta[kNbMax];
-    const uint4* __restrict__ slots8; const uint32_t* __restrict__ hdrs; const uint32_t* __restrict__ cnt;
+    uint32_t lo, nc, np, nm, n_esc, nf, off, nb_n, nb_before, n_ov, delta[kNbMax];
+    const uint4* __restrict__ c8p; const uint32_t* __restrict__ ovcp; const uint4* __restrict__ ov8p; const uint32_t* __restrict__ cnt;
     const uint4* __restrict__ pure; const uint16_t* __restrict__ slot0_p;
     uint32_t flags;
     // ---- what a thread keeps for the whole run: which of the overlapping tiles hold the position of its window slot (bits 0..5), whether
@@ -191,9 +231,8 @@ k_em_persist(PersistArgs a) {
     //      two blocks per CU), and those words sit in the L2.
     {
         const TileDesc t = a.tiles[blockIdx.x];
-        lo = t.lo; n8 = t.n8; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before;
-        slots8 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.stream) + t.s0);
-        hdrs = a.chdr + (t.s0 >> 3); cnt = a.counts + t.c0;
+        lo = t.lo; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before; n_ov = t.n_ov;
+        c8p = a.cls8 + t.c0; ovcp = a.ovc + t.ov0; ov8p = a.ov8 + t.ov0; cnt = a.counts + t.c0;
         pure = reinterpret_cast<const uint4*>(a.csc + t.qb); slot0_p = a.csc_slot0 + t.pr;
         const uint32_t span = t.span, pos0 = lo + tid0;
         flags = tid0 < span ? 0x40000000u : 0u;
@@ -275,7 +314,7 @@ k_em_persist(PersistArgs a) {
         //  a dozen 64-bit pointers -- out of the loop and spills them)
         uint32_t tid = tid0;
         asm volatile("" : "+v"(tid));
-        const uint32_t lane = tid & (kWave - 1), wave = tid / kWave, g0 = tid * kPerLane;
+        const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
         if (tid == 0u) sctl[6] = s;                                          // (for the log of a give-up)
 #ifdef SFGPU_P_PROGRESS
         if (tid == 0u) { SFP_COLD(cq); __hip_atomic_store(&cq->dbg[blockIdx.x], (unsigned long long)s + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -286,19 +325,16 @@ k_em_persist(PersistArgs a) {
         // phase A's stream chunks and phase B's class counts: requested in the head once the operands are in (they miss the L2 -- a tile's
         // stream is read once per step and 64 tiles share 4 MB --, and the x arithmetic and the head's barrier hide the round trip);
         // phase C's first chunk is requested at the start of phase A
-        const uint32_t q1 = tid + kSweepBlock, q2 = tid + 2u * kSweepBlock;
-        uint4 sl_first = make_uint4(0u, 0u, 0u, 0u), sl1 = sl_first, sl2 = sl_first; uint32_t hdr_first = 0u, hd1 = 0u, hd2 = 0u;
-        uint32_t cw[kCntAhead];                                             // bit 31: singleton class
+        uint4 c8[kCntAhead];                                               // the thread's first class chunks (a chunk per class: see k_cls8_build)
+        uint32_t cw[kCntAhead];                                             // ... and their counts; bit 31: singleton class
         auto request_stream = [&]() {
-            if (g0 < n8) { sl_first = slots8[tid]; hdr_first = hdrs[tid]; }
-            if (q1 * kPerLane < n8) { sl1 = slots8[q1]; hd1 = hdrs[q1]; }
-            if (q2 * kPerLane < n8) { sl2 = slots8[q2]; hd2 = hdrs[q2]; }
 #pragma unroll
-            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; cw[i] = (c < nc) ? cnt[c] : 0u; }
+            for (int i = 0; i < kCntAhead; ++i) {
+                const uint32_t c = tid + i * kSweepBlock;
+                c8[i] = make_uint4(0u, 0u, 0u, 0u); cw[i] = 0u;
+                if (c < nc) { c8[i] = c8p[c]; cw[i] = cnt[c]; }
+            }
         };
-#ifdef SFGPU_P_EARLY
-        request_stream();
-#endif
         if (s > 0u) {
             const uint32_t rd_off = (s & 1u) ? a.part_off[1] : a.part_off[0];       // sums of sweep s - 1 carry tag s
             const uint32_t pos = lo + tid;
@@ -439,22 +475,19 @@ k_em_persist(PersistArgs a) {
         uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u;
         {
             if (tid < np) { pc_e0 = pure[tid]; pc_s0 = slot0_p[tid]; }
-            auto den_slots = [&](const uint4& s4, uint32_t hdr) {
-                uint32_t cur = hdr & 0x1FFFu;
-                const uint32_t mask = hdr >> 16;
-                double run = xs[s4.x & 0xFFFFu];
-                auto step = [&](uint32_t k, uint32_t slot) {
-                    const double v = xs[slot];
-                    if (mask & (1u << k)) { atomicAdd(&den[cur], run); ++cur; run = v; } else run += v;
-                };
-                step(1, s4.x >> 16); step(2, s4.y & 0xFFFFu); step(3, s4.y >> 16); step(4, s4.z & 0xFFFFu);
-                step(5, s4.z >> 16); step(6, s4.w & 0xFFFFu); step(7, s4.w >> 16);
-                atomicAdd(&den[cur], run);
+            auto chunk_sum = [&](const uint4& s4) -> double {                   // eight window slots (bit 15 of the first: the long flag)
+                const double v0 = xs[s4.x & 0x7FFFu], v1 = xs[s4.x >> 16], v2 = xs[s4.y & 0xFFFFu], v3 = xs[s4.y >> 16];
+                const double v4 = xs[s4.z & 0xFFFFu], v5 = xs[s4.z >> 16], v6 = xs[s4.w & 0xFFFFu], v7 = xs[s4.w >> 16];
+                return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
             };
-            if (g0 < n8) den_slots(sl_first, hdr_first);
-            if (q1 * kPerLane < n8) den_slots(sl1, hd1);
-            if (q2 * kPerLane < n8) den_slots(sl2, hd2);
-            for (uint32_t q = tid + 3u * kSweepBlock; q * kPerLane < n8; q += kSweepBlock) den_slots(slots8[q], hdrs[q]);
+            auto class_chunk = [&](uint32_t c, const uint4& s4) {
+                const double sum = chunk_sum(s4);
+                if (s4.x & kCls8Long) atomicAdd(&den[c], sum); else den[c] = sum;      // (long: overflow chunks and far members add to it as well)
+            };
+#pragma unroll
+            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) class_chunk(c, c8[i]); }
+            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) class_chunk(c, c8p[c]);
+            for (uint32_t j = tid; j < n_ov; j += kSweepBlock) atomicAdd(&den[ovcp[j]], chunk_sum(ov8p[j]));
             // far members (few tiles have any): class and far slot from the plan, x from the LDS copy the head made
             if (n_esc) {
                 SFP_COLD(cp); SFP_TILE(tp);
