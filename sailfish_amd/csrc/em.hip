@@ -1649,7 +1649,7 @@ struct sfgpu_em {
     uint32_t null_cls = kTileNnz;                           // GATHER: class index of the transcript-major copy's padding = the largest class count of a tile
     // the PERSISTENT loop (em_persist.h): far-slot tables, the exchange buffer (control words + granule arrays), the plan's verdict
     uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
-    uint4 *cls8 = nullptr, *ov8 = nullptr; uint32_t* ovc = nullptr;        // phase A's chunk-per-class stream and the long classes' overflow
+    uint4 *cls8 = nullptr, *ov8 = nullptr; uint32_t *ovc = nullptr, *cnt8 = nullptr;        // phase A's chunk-per-class stream and the long classes' overflow
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
@@ -1679,7 +1679,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->cls8, em->ov8, em->ovc, em->xbuf, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->cls8, em->ov8, em->ovc, em->cnt8, em->xbuf, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
@@ -1953,11 +1953,11 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
         const uint64_t C = em->prob.C, Lnz = em->L;
         uint32_t* extra = nullptr; uint64_t* ov_start = nullptr;
         SF_HIP(pool_malloc(&extra, (C + 2) * 4)); SF_HIP(pool_malloc(&ov_start, (C + 3) * 8));
-        SF_HIP(pool_malloc(&em->cls8, (C ? C : 1) * 16)); SF_HIP(pool_malloc(&em->ovc, (Lnz / 8 + 2) * 4)); SF_HIP(pool_malloc(&em->ov8, (Lnz / 8 + 2) * 16));
+        SF_HIP(pool_malloc(&em->cls8, (C ? C : 1) * 16)); SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->ovc, (Lnz / 8 + 2) * 4)); SF_HIP(pool_malloc(&em->ov8, (Lnz / 8 + 2) * 16));
         hipLaunchKernelGGL(k_cls8_count, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, st, C, p_rowptr, extra);
         int rc = exclusive_scan_u32(extra, ov_start, C, st, false);
         if (!rc) hipLaunchKernelGGL(k_cls8_build, dim3(nt), dim3(kEmBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
-                                    ov_start, em->cls8, em->ovc, em->ov8, em->td);
+                                    ov_start, em->counts32, em->cls8, em->cnt8, em->ovc, em->ov8, em->td, em->pflags);
         { void* ps[2] = {extra, ov_start}; pool_free_on_many(ps, 2, st); }
         if (rc) return rc;
         SF_CHECK_LAUNCH();
@@ -2569,7 +2569,7 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
 
 // ---- the persistent loop (em_persist.h): eligibility, and the launch ----
 static std::mutex g_persist_mu[16];          // per device: two persistent launches of this process never share the chip (each needs ALL its blocks resident)
-static size_t em_persist_lds(const sfgpu_em* em) { return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + 2 * (size_t)em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32 + 64; }
+static size_t em_persist_lds(const sfgpu_em* em) { return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + 2 * (size_t)em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32 + 4 * kShards * 4 + 64; }
 static const void* em_persist_func(bool vb) {
     return vb ? reinterpret_cast<const void*>(&k_em_persist<true>) : reinterpret_cast<const void*>(&k_em_persist<false>);
 }
@@ -2612,7 +2612,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
     c.far_off[0] = (uint32_t)o; o += up(En * 16); c.far_off[1] = (uint32_t)o; o += up(En * 16); c.xpub_off = (uint32_t)o;
     a.tiles = em->td; c.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
-    a.cls8 = em->cls8; a.ovc = em->ovc; a.ov8 = em->ov8; a.counts = em->counts32; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
+    a.cls8 = em->cls8; a.ovc = em->ovc; a.ov8 = em->ov8; a.counts = em->cnt8; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
     c.x = em->x; c.inv = em->inv;
     a.lenc = em->inv ? em->lencP : em->lenc; a.alpha = em->inv ? em->alphaP : em->alpha;
     c.esc_cls = em->esc_cls; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;

@@ -33,8 +33,7 @@
 typedef unsigned int gr4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kShards = 8;                      // arrival counters / convergence words, by block mod 8
 constexpr uint32_t kCtlStride = 16;                  // 64-bit words between two control words (128 bytes: a line of their own)
-constexpr uint32_t kCtlArrive = 0;                   // [4][kShards] arrivals of update u in slot u % 4 (monotonic over the run)
-constexpr uint32_t kCtlNotConv = 4 * kShards;        // [kShards] the last update in which some block of the shard saw a change > tol
+constexpr uint32_t kCtlArrive = 0;                   // [4][kShards] update u, slot u % 4, monotonic over the run: low word arrivals, high word those that saw a change > tol
 constexpr uint32_t kCtlAbort = 5 * kShards;          // != 0: some tile gave up waiting
 constexpr uint32_t kCtlWords = (5 * kShards + 2) * kCtlStride;       // (+ a line for who gave up: tile + 1, thread, wait, step)
 constexpr uint32_t kSpinLimit = 1u << 18;            // polls of one wait (0.2 - 1 us each: 50 - 250 ms) before a tile gives up
@@ -119,14 +118,18 @@ __global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const ui
 // (16 bits each; kWin = the null slot, whose x is 0: padding, a far member), lane per class: eight LDS reads, a tree of adds, one plain
 // store -- no run detection, no atomic.  A class with more than eight members, or with a far member (whose x arrives by atomic), is
 // flagged LONG (bit 15 of slot 0): its chunks add with atomics, the ones behind the first come from an overflow list (class, 8 slots).
+// A class that is not long is FINISHED by the lane that summed it: count / denominator goes to den[] right away, phase B is left with
+// the long classes (the flag is bit 30 of the count word: cnt8, a copy of the plan's counts).
 constexpr uint32_t kCls8Long = 0x8000u;
+constexpr uint32_t kCnt8Long = 0x40000000u;        // the same flag in the class's count word (bit 31: singleton)
 __global__ void k_cls8_count(uint64_t C, const uint32_t* __restrict__ rowptr, uint32_t* extra) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) { const uint32_t k = rowptr[c + 1] - rowptr[c]; extra[c] = k > 8u ? (k - 8u + 7u) / 8u : 0u; } else if (c == C) extra[c] = 0u;
 }
 __global__ void __launch_bounds__(kEmBlock)
 k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
-             const uint16_t* __restrict__ slot16, const uint64_t* __restrict__ ov_start, uint4* cls8, uint32_t* ovc, uint4* ov8, TileDesc* td) {
+             const uint16_t* __restrict__ slot16, const uint64_t* __restrict__ ov_start, const uint32_t* __restrict__ counts,
+             uint4* cls8, uint32_t* cnt8, uint32_t* ovc, uint4* ov8, TileDesc* td, uint32_t* pflags) {
     const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1];
     const uint64_t s0 = tile_s0[T];
     const uint32_t j0 = rowptr[c0];
@@ -139,7 +142,11 @@ k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ t
         for (uint32_t m = 8u; m < k; ++m) if (sl[m] == (uint16_t)kWin) far = true;
         const bool single = k == 1u;                              // (a singleton's denominator is never used: nothing to read)
         if (single) w[0] = kWin;
-        if (k > 8u || far) w[0] |= kCls8Long;
+        const bool lng = k > 8u || far;
+        if (lng) w[0] |= kCls8Long;
+        const uint32_t cw = counts[c];                               // count, bit 31: singleton (k_narrow_counts)
+        if (cw & kCnt8Long) atomicOr(&pflags[0], 8u);                // (a class of >= 2^30 reads: the bit is taken -- such a plan keeps one kernel per iteration)
+        cnt8[c] = cw | (lng ? kCnt8Long : 0u);
         cls8[c] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
         uint64_t at = ov_start[c];
         for (uint32_t m0 = 8u; m0 < k; m0 += 8u, ++at) {
@@ -165,7 +172,7 @@ struct PersistArgs {
     const TileDesc* tiles; const PersistCold* cold;
     uint32_t min_iter, max_iter, n_tiles; int check_mode;
     const uint4* cls8; const uint32_t* ovc; const uint4* ov8;      // phase A: a chunk per class, the overflow of long classes (class in the tile, 8 slots)
-    const uint32_t* counts;
+    const uint32_t* counts;                               // cnt8: count | long << 30 | singleton << 31
     const unsigned char* csc; const uint16_t* csc_slot0;
     const double* lenc; double* alpha;                    // by position of the plan's order
     const uint2* ftgt;                                    // per position: [k0, k1) of ft_list (null: the plan has no far members)
@@ -197,11 +204,21 @@ __device__ __forceinline__ double gr_value(const gr4& g) { return __hiloint2doub
 __device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y == tag && g.w == tag; }
 
 #ifdef SFGPU_P_STAMP
-#define SFP_STAMP(k) do { if (tid == 0u) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = wall_clock64(); pst[k] += t_ - pst[7]; pst[7] = t_; } } while (0)
+#if SFGPU_P_STAMP == 2                                                     // (2: no drain of the memory queue in front of a stamp -- issue times; the stamps behind barriers are exact)
+#define SFP_DRAIN() do { } while (0)
+#else
+#define SFP_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
+#define SFP_STAMP(k) do { if (tid == 0u) { SFP_DRAIN(); const unsigned long long t_ = wall_clock64(); pst[k] += t_ - pst[7]; pst[7] = t_; } } while (0)
 #else
 #define SFP_STAMP(k) do { } while (0)
 #endif
 // the cold block / the tile's record, looked at from a rare path: the pointer is made opaque THERE, so no load of it is hoisted out
+#ifdef SFGPU_P_L2HIT                                                       // dev, timing only: every stream load of a tile falls into its first 1024 entries (all L2 hits)
+#define SFP_IX(i) ((i) & 1023u)
+#else
+#define SFP_IX(i) (i)
+#endif
 #define SFP_COLD(name) const PersistCold* name = a.cold; asm volatile("" : "+s"(name))
 #define SFP_TILE(name) const TileDesc* name = a.tiles + blockIdx.x; asm volatile("" : "+s"(name))
 template <bool VB>
@@ -215,8 +232,9 @@ k_em_persist(PersistArgs a) {
     double* const fxs = facc + a.far_cap;                  // [far_cap]  x of the far slots' transcripts, fetched once per step (head)
     double* const wmax = fxs + a.far_cap;                  // [2][waves]: the wavefronts' largest relative change, by update parity
     uint32_t* const sctl = reinterpret_cast<uint32_t*>(wmax + 2 * (kSweepBlock / kWave));     // [0] stop, [1] abort (heads), [2..3] block saw a change > tol (by step parity), [4..5] abort (phases, by step parity)
+    uint32_t* const hprev = sctl + 8;                      // [4][kShards] the counters' high words at wave 0's last visit
 #ifdef SFGPU_P_STAMP
-    unsigned long long* const pst = reinterpret_cast<unsigned long long*>(sctl + 8);       // [0..6] phase sums, [7] the last stamp
+    unsigned long long* const pst = reinterpret_cast<unsigned long long*>(sctl + 8 + 4 * kShards);       // [0..6] phase sums, [7] the last stamp
     if (threadIdx.x == 0) { for (int k = 0; k < 7; ++k) pst[k] = 0ull; pst[7] = wall_clock64(); }
 #endif
     const uint32_t tid0 = threadIdx.x;
@@ -287,7 +305,7 @@ k_em_persist(PersistArgs a) {
         }
         return false;
     };
-    if (tid0 < 8u) sctl[tid0] = 0u;
+    if (tid0 < 8u + 4u * kShards) sctl[tid0] = 0u;                       // (and hprev)
     acc[tid0] = 0.0;
 
     auto x_of = [&](double ap_, double l) -> double {
@@ -332,7 +350,7 @@ k_em_persist(PersistArgs a) {
             for (int i = 0; i < kCntAhead; ++i) {
                 const uint32_t c = tid + i * kSweepBlock;
                 c8[i] = make_uint4(0u, 0u, 0u, 0u); cw[i] = 0u;
-                if (c < nc) { c8[i] = c8p[c]; cw[i] = cnt[c]; }
+                if (c < nc) { c8[i] = c8p[SFP_IX(c)]; cw[i] = cnt[SFP_IX(c)]; }
             }
         };
         if (s > 0u) {
@@ -352,16 +370,18 @@ k_em_persist(PersistArgs a) {
             if (wave == 0u && s >= 2u) {
                 const uint32_t u = s - 1u;
                 const uint32_t visits = (u & 3u) ? (u >> 2) + 1u : (u >> 2);
-                uint32_t ncu = 0u;
+                bool mv = false;
                 if (lane < kShards) {
                     const unsigned long long want = (unsigned long long)visits * ((a.n_tiles + (kShards - 1u) - lane) / kShards);
                     const unsigned long long* w = &ctl[(kCtlArrive + (u & 3u) * kShards + lane) * kCtlStride];
                     unsigned long long got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     SFP_WHY(1u);
-                    if (a.ablate != 1) for (uint32_t spins = 0; got < want;) { if (spin_check(spins, 1u)) break; got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    ncu = (uint32_t)__hip_atomic_load(&ctl[(kCtlNotConv + lane) * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.ablate != 1) for (uint32_t spins = 0; (got & 0xFFFFFFFFull) < want;) { if (spin_check(spins, 1u)) break; got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    // (ONE word says both: every arrival of a visit is in, and how many of them moved -- against the count of the visit before)
+                    const uint32_t hi = (uint32_t)(got >> 32), k = (u & 3u) * kShards + lane;
+                    mv = hi != hprev[k]; hprev[k] = hi;
                 }
-                const bool moved = __any(lane < kShards && ncu >= u);
+                const bool moved = __any(mv);
                 if (lane == 0u) {
                     const bool conv = !moved;
                     const bool stop = u >= a.min_iter && (u >= a.max_iter || conv);
@@ -463,30 +483,31 @@ k_em_persist(PersistArgs a) {
             if (home) alpha[tid] = ap_v;
             if (tid == 0u) {
                 const uint32_t shard = blockIdx.x & (kShards - 1u);
-                if (sctl[2u + (s & 1u)] != 0u) {
-                    const unsigned long long old = atomicMax(&ctl[(kCtlNotConv + shard) * kCtlStride], (unsigned long long)s);
-                    asm volatile("" :: "v"(old) : "memory");              // (the maximum is in place before the arrival is counted)
-                    sctl[2u + (s & 1u)] = 0u;
-                }
-                __hip_atomic_fetch_add(&ctl[(kCtlArrive + (s & 3u) * kShards + shard) * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long inc = 1ull;
+                if (sctl[2u + (s & 1u)] != 0u) { inc |= 1ull << 32; sctl[2u + (s & 1u)] = 0u; }
+                __hip_atomic_fetch_add(&ctl[(kCtlArrive + (s & 3u) * kShards + shard) * kCtlStride], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // ================= A: denominators =================
         uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u;
         {
-            if (tid < np) { pc_e0 = pure[tid]; pc_s0 = slot0_p[tid]; }
+            if (tid < np) { pc_e0 = pure[SFP_IX(tid)]; pc_s0 = slot0_p[SFP_IX(tid)]; }
             auto chunk_sum = [&](const uint4& s4) -> double {                   // eight window slots (bit 15 of the first: the long flag)
                 const double v0 = xs[s4.x & 0x7FFFu], v1 = xs[s4.x >> 16], v2 = xs[s4.y & 0xFFFFu], v3 = xs[s4.y >> 16];
                 const double v4 = xs[s4.z & 0xFFFFu], v5 = xs[s4.z >> 16], v6 = xs[s4.w & 0xFFFFu], v7 = xs[s4.w >> 16];
                 return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
             };
-            auto class_chunk = [&](uint32_t c, const uint4& s4) {
+            auto class_chunk = [&](uint32_t c, const uint4& s4, uint32_t cwc) {
                 const double sum = chunk_sum(s4);
-                if (s4.x & kCls8Long) atomicAdd(&den[c], sum); else den[c] = sum;      // (long: overflow chunks and far members add to it as well)
+                if (cwc & kCnt8Long) atomicAdd(&den[c], sum);              // (long: overflow chunks and far members add to it as well; phase B divides)
+                else {
+                    const double cn = (double)(cwc & 0x3FFFFFFFu);
+                    den[c] = (cwc >> 31) ? cn : ((sum > kTiny) ? cn / sum : 0.0);      // :260-264; singletons carry the full count :275 / :364
+                }
             };
 #pragma unroll
-            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) class_chunk(c, c8[i]); }
-            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) class_chunk(c, c8p[c]);
+            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) class_chunk(c, c8[i], cw[i]); }
+            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) class_chunk(c, c8p[SFP_IX(c)], cnt[SFP_IX(c)]);
             for (uint32_t j = tid; j < n_ov; j += kSweepBlock) atomicAdd(&den[ovcp[j]], chunk_sum(ov8p[j]));
             // far members (few tiles have any): class and far slot from the plan, x from the LDS copy the head made
             if (n_esc) {
@@ -498,20 +519,21 @@ k_em_persist(PersistArgs a) {
                     if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
                 }
             }
-            if (tid + kSweepBlock < np) { pc_e1 = pure[tid + kSweepBlock]; pc_s1 = slot0_p[tid + kSweepBlock]; }
+            if (tid + kSweepBlock < np) { pc_e1 = pure[SFP_IX(tid + kSweepBlock)]; pc_s1 = slot0_p[SFP_IX(tid + kSweepBlock)]; }
         }
         __syncthreads();
         SFP_STAMP(3);                                                     // phase A + its barrier
         // ================= B: count / denom per class (:260-264; singletons carry the full count :275 / :364) =================
         {
-            auto invert = [&](uint32_t c, uint32_t cwc) {
-                const double cn = (double)(cwc & 0x7FFFFFFFu);
+            auto invert = [&](uint32_t c, uint32_t cwc) {                        // the long classes (a singleton among them: its one member is a far one)
+                if (!(cwc & kCnt8Long)) return;
+                const double cn = (double)(cwc & 0x3FFFFFFFu);
                 const double d = den[c];
                 den[c] = (cwc >> 31) ? cn : ((d > kTiny) ? cn / d : 0.0);
             };
 #pragma unroll
             for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
-            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, cnt[c]);
+            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, cnt[SFP_IX(c)]);
         }
         __syncthreads();
         SFP_STAMP(4);                                                     // phase B + its barrier
@@ -527,7 +549,7 @@ k_em_persist(PersistArgs a) {
             };
             if (tid < np) pure_chunk(pc_e0, pc_s0);
             if (tid + kSweepBlock < np) pure_chunk(pc_e1, pc_s1);
-            for (uint32_t ch = tid + 2u * kSweepBlock; ch < np; ch += kSweepBlock) pure_chunk(pure[ch], slot0_p[ch]);
+            for (uint32_t ch = tid + 2u * kSweepBlock; ch < np; ch += kSweepBlock) pure_chunk(pure[SFP_IX(ch)], slot0_p[SFP_IX(ch)]);
             const uint4* __restrict__ mixed = pure + np;
             for (uint32_t ch = tid; ch < nm; ch += kSweepBlock) {
                 const uint4 e4 = mixed[2u * ch], s4 = mixed[2u * ch + 1u];
