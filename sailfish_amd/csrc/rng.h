@@ -53,7 +53,12 @@ struct Philox {
         ++ctr[0];                                   // 2^32 blocks per sequence; the sequence id lives in the other words
         have = 4;
     }
-    SF_HD uint32_t next32() { if (have == 0) block(); return out[--have]; }
+    // (selects, not out[--have]: a dynamically indexed array of a device thread lives in LDS or scratch -- a dependent round trip per word)
+    SF_HD uint32_t next32() {
+        if (have == 0) block();
+        --have;
+        return have == 3 ? out[3] : (have == 2 ? out[2] : (have == 1 ? out[1] : out[0]));
+    }
     // uniform in the open interval (0, 1), 53 random bits
     SF_HD double uniform() {
         uint64_t hi = next32(), lo = next32();
@@ -73,6 +78,7 @@ constexpr double kBinvMaxMean = 60.0;
 #define SFGPU_BINV_SWITCH 128          // (tests/test_sampling_cpu.py builds the header with 8 as well, to walk through the switch)
 #endif
 constexpr uint32_t kBinvSwitch = SFGPU_BINV_SWITCH;
+constexpr uint32_t kBinvPowMax = 1024;
 constexpr double binv_unscale(uint32_t n) { double f = 1.0; for (uint32_t i = 2; i <= n; ++i) f *= (double)i; return 1.0 / f; }
 constexpr double kBinvUnscale = binv_unscale(kBinvSwitch - 1u);      // ~ 1 / 127! = 3.3e-214 (U and F get the same factor: its last bits do not matter)
 
@@ -89,21 +95,35 @@ SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
     if (dn * r < kBinvMaxMean) {
         // ---- BINV: walk the CDF from 0
         const double s = r / q, a = (dn + 1.0) * s;
-        const double f0 = exp(dn * log1p(-r));   // q^n >= e^(-2 ln 2 * 60): no underflow
+        // f_0 = q^n: by squaring for n <= kBinvPowMax (<= 2 log2 n multiplications against ~110 instructions of log1p + exp; the error
+        // grows like n ulp / 2 -- 1e-13 at the bound), exp(n log1p(-r)) beyond.  q^n >= e^(-1.39 * 60): no underflow of the result.
+        double f0;
+        if (n <= kBinvPowMax) {
+            f0 = 1.0;
+            double b = q;
+            for (uint32_t e = n; e != 0u; e >>= 1) { if (e & 1u) f0 *= b; b *= b; }
+        } else f0 = exp(dn * log1p(-r));
+        // (the walk is the sampler's hot loop: ONE exit test per step, a wavefront-uniform bound -- with the end-of-range and the switch
+        //  tests inside it the compiler spent 25 scalar instructions per step on lane masks next to 10 vector ones.  A lane whose walk
+        //  runs past n -- rounding: F is 0 or noise from there on -- walks on to the switch and redraws.)
         for (;;) {
             double F = f0, U = g.uniform();                  // x! f_x and x! u_x
             uint32_t x = 0;
-            bool ok = true;
             while (U > F && x < kBinvSwitch - 1u) {           // scaled by x!: no division
                 ++x;
-                if (x > n) { ok = false; break; }              // rounding ran off the end: redraw
                 const double dx = (double)x;
-                U = dx * (U - F); F *= (a - s * dx);
+                U = dx * (U - F); F *= fma(-s, dx, a);
             }
-            if (ok && x == kBinvSwitch - 1u && U > F) {        // (probability < 1e-40 for the means BINV is used for)
-                U *= kBinvUnscale; F *= kBinvUnscale;
-                while (U > F) { U -= F; ++x; if (x > n) { ok = false; break; } F *= (a / (double)x - s); }
-            }
+            if (x > n) continue;                              // rounding ran off the end: redraw
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(U), "+v"(F));              // (the exit state is compared HERE, once -- not tracked in a lane mask through every step)
+#endif
+            if (!(U > F)) { y = (double)x; break; }
+            if (x == n) continue;                             // rounding ran off the end: redraw
+            // x = kBinvSwitch - 1 < n (probability < 1e-40 for the means BINV is used for): on unscaled
+            bool ok = true;
+            U *= kBinvUnscale; F *= kBinvUnscale;
+            while (U > F) { U -= F; ++x; if (x > n) { ok = false; break; } F *= (a / (double)x - s); }
             if (ok) { y = (double)x; break; }
         }
     } else {
