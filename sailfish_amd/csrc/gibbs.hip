@@ -51,6 +51,10 @@ constexpr uint32_t kMaxPhases = 1024;      // more phases than this: fall back t
 constexpr uint32_t kWideSerial = 64;       // up to this many wide classes are visited one after another by one launch
 constexpr uint32_t kMaxColours = 1u << 16; // more colours than this: visit the wide classes one after another after all
 constexpr uint32_t kThinWidth = 12;        // a component of wide classes with fewer classes per colour than this is visited serially
+#if !defined(SFGPU_GIBBS_LIGHT_MAX)
+#define SFGPU_GIBBS_LIGHT_MAX 1500
+#endif
+constexpr uint64_t kGibbsLightMax = SFGPU_GIBBS_LIGHT_MAX;   // classes of more reads than this are HEAVY: visited by the phase kernel that carries BTPE (see k_gibbs_phase)
 constexpr double kGibbsPrior = 1e-8;       // priorAlpha (:215)
 constexpr double kGibbsTiny = 4.9406564584124654e-324;
 
@@ -64,26 +68,29 @@ struct GibbsArgs {
     uint64_t seed; uint32_t round;
 };
 
-// multinomial(n; p_0..p_{k-1}) as conditional binomials; calls put(i, r_i) for every member
-template <typename ProbFn, typename PutFn>
-__device__ __forceinline__ void multinomial_chain(Philox& g, uint32_t n, uint32_t k, double p_total, ProbFn prob, PutFn put) {
+// multinomial(n; p_0..p_{k-1}) as conditional binomials; calls put(i, r_i) for every member.  Member `last` gets what the others
+// leave: a BINV walk costs its mean, so the chain costs n (1 - p_last) steps in all -- least when the LARGEST member is not sampled
+// at all.  `last` is the same for every chain of the wavefront (the member with the largest EM weight: the chains live around the EM
+// solution), so no lane idles; any order gives the same distribution.
+template <bool LIGHT, typename ProbFn, typename PutFn>
+__device__ __forceinline__ void multinomial_chain(Philox& g, uint32_t n, uint32_t k, double p_total, uint32_t last, ProbFn prob, PutFn put) {
     double p_rem = p_total;
     uint32_t n_rem = n;
     for (uint32_t i = 0; i < k; ++i) {
-        uint32_t r;
-        if (i + 1 == k) r = n_rem;
-        else {
-            double p = prob(i);
-            double ratio = (p_rem > 0.0) ? p / p_rem : 0.0;
-            r = (n_rem == 0) ? 0u : binomial(g, n_rem, ratio < 1.0 ? ratio : 1.0);
-            p_rem -= p; if (p_rem < 0.0) p_rem = 0.0;
-        }
+        if (i == last) continue;
+        const double p = prob(i);
+        const double ratio = (p_rem > 0.0) ? p / p_rem : 0.0;
+        const double pr = ratio < 1.0 ? ratio : 1.0;
+        const uint32_t r = (n_rem == 0) ? 0u : (LIGHT ? binomial_by_inversion(g, n_rem, pr) : binomial(g, n_rem, pr));
+        p_rem -= p; if (p_rem < 0.0) p_rem = 0.0;
         put(i, r);
         n_rem -= r;
     }
+    put(last, n_rem);
 }
 
 // initCountMap_ (:45-92) for one class and one chain
+template <bool LIGHT = false>
 __device__ __forceinline__ void gibbs_init_class(const GibbsArgs& a, uint64_t c, uint32_t ch) {
     const uint32_t b = a.rowptr[c], k = a.rowptr[c + 1] - b;
     const uint32_t n = (uint32_t)a.counts[c];            // uint32 n in MultinomialSampler (:15)
@@ -94,14 +101,14 @@ __device__ __forceinline__ void gibbs_init_class(const GibbsArgs& a, uint64_t c,
         a.txp_count[(uint64_t)a.ids[b] * nch + ch] += (int32_t)n;
         return;
     }
-    double denom = 0.0;
-    for (uint32_t i = 0; i < k; ++i) denom += a.w_mass[a.ids[b + i]];                 // :58-63
+    double denom = 0.0, w_top = -1.0; uint32_t last = 0;
+    for (uint32_t i = 0; i < k; ++i) { const double w = a.w_mass[a.ids[b + i]]; denom += w; if (w > w_top) { w_top = w; last = i; } }      // :58-63
     if (!(denom > kGibbsTiny)) {                                                      // :65 -- nothing assigned
         for (uint32_t i = 0; i < k; ++i) a.count_map[(uint64_t)(b + i) * nch + ch] = 0;
         return;
     }
     Philox g; g.init(a.seed, ch, c);
-    multinomial_chain(g, n, k, denom,
+    multinomial_chain<LIGHT>(g, n, k, denom, last,
         [&](uint32_t i) { return a.w_mass[a.ids[b + i]]; },
         [&](uint32_t i, uint32_t r) {
             a.count_map[(uint64_t)(b + i) * nch + ch] = r;                            // :76-79
@@ -110,6 +117,7 @@ __device__ __forceinline__ void gibbs_init_class(const GibbsArgs& a, uint64_t c,
 }
 
 // sampleRound_ (:113-184) for one class and one chain
+template <bool LIGHT = false>
 __device__ __forceinline__ void gibbs_round_class(const GibbsArgs& a, uint64_t c, uint32_t ch) {
     const uint32_t b = a.rowptr[c], k = a.rowptr[c + 1] - b;
     if (k <= 1) return;                                     // singletons keep their full count (:128)
@@ -117,10 +125,11 @@ __device__ __forceinline__ void gibbs_round_class(const GibbsArgs& a, uint64_t c
     Philox g; g.init(a.seed, ((uint64_t)(a.round + 1) << 32) | ch, c);
     const double frac = 0.25 + 0.5 * g.uniform();           // U(0.25, 0.75) per class (:106, :115)
     // pass 1: take round(frac * current) reads away from every member (:138-148)
-    uint32_t n_res = 0; double denom = 0.0;
+    uint32_t n_res = 0, last = 0; double denom = 0.0, w_top = -1.0;
     for (uint32_t i = 0; i < k; ++i) {
         const uint64_t at = (uint64_t)(b + i) * nch + ch;
         const uint32_t t = a.ids[b + i];
+        { const double w = a.w_mass[t]; if (w > w_top) { w_top = w; last = i; } }        // (wavefront-uniform: the member the chain does not sample)
         const uint32_t cur = a.count_map[at];
         const uint32_t r = (uint32_t)(frac * (double)cur + 0.5);                       // std::round, values >= 0 (:142)
         n_res += r;
@@ -131,7 +140,7 @@ __device__ __forceinline__ void gibbs_round_class(const GibbsArgs& a, uint64_t c
     }
     // pass 2: re-draw them from p_i ~ (prior + txpCount_i) * aux_i (:150-170).  denom >= k*1e-8/len > 0,
     // so the reference's "did not sample" branch (:172-179) cannot trigger for finite inputs.
-    multinomial_chain(g, n_res, k, denom,
+    multinomial_chain<LIGHT>(g, n_res, k, denom, last,
         [&](uint32_t i) { const uint32_t t = a.ids[b + i]; return (kGibbsPrior + (double)a.txp_count[(uint64_t)t * nch + ch]) * a.inv_len[t]; },
         [&](uint32_t i, uint32_t r) {
             if (r) { a.count_map[(uint64_t)(b + i) * nch + ch] += r; a.txp_count[(uint64_t)a.ids[b + i] * nch + ch] += (int32_t)r; }
@@ -139,10 +148,16 @@ __device__ __forceinline__ void gibbs_round_class(const GibbsArgs& a, uint64_t c
 }
 
 // one phase: blockIdx.x -> tile (phase + K * x), blockIdx.y -> group of 64 chains
-// (4 wavefronts per SIMD, 128 VGPRs: the compiler's own choice is 142 registers and 3 wavefronts -- the sampler is long chains of
-//  dependent f64 operations, a fourth wavefront to switch to is worth 9 %; at 5 it spills)
-template <bool INIT>
-__global__ void __launch_bounds__(kGibbsBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// Two forms (round 5).  The sampler is long chains of dependent f64 operations: what a SIMD needs is wavefronts to switch between, and
+// what limits them is BTPE's registers -- the kernel with it needs 128 VGPRs for 4 wavefronts per SIMD (the compiler's own choice is
+// 142 and 3; at 5 it spills), without it 76: 6 wavefronts.  A class of <= kGibbsLightMax reads does without BTPE: a binomial of a
+// larger mean than one BINV walk takes is drawn as a sum of equal parts (binomial_by_inversion: the sum of binomials over a split
+// of n IS the binomial) -- rarely more than two at that size.  So the LIGHT form visits those classes at 6 wavefronts per SIMD, the
+// other form the HEAVY classes of the same tiles in a launch of its own behind it (when the phase has any): still one systematic
+// scan -- the light classes of a phase's tiles, then their heavy ones.  cfg3 (classes of 250 reads on average, 21 tiles with a heavy
+// one): init 136 -> 109 ms, a round 173 -> 141; with the bound at 440 (every tile has heavy classes: two launches per phase) 117 / 150.
+template <bool INIT, bool LIGHT>
+__global__ void __launch_bounds__(kGibbsBlock) __attribute__((amdgpu_waves_per_eu(LIGHT ? 6 : 4, LIGHT ? 6 : 4)))
 k_gibbs_phase(GibbsArgs a, uint32_t phase, uint32_t K, uint32_t n_tiles) {
     const uint32_t tile = phase + K * blockIdx.x;
     const uint32_t ch = blockIdx.y * kGibbsBlock + threadIdx.x;
@@ -150,8 +165,8 @@ k_gibbs_phase(GibbsArgs a, uint32_t phase, uint32_t K, uint32_t n_tiles) {
     const uint64_t c0 = (uint64_t)tile * kGibbsTile;
     const uint64_t c1 = (c0 + kGibbsTile < a.C) ? c0 + kGibbsTile : a.C;
     for (uint64_t c = c0; c < c1; ++c) {
-        if (a.wide[c]) continue;
-        if (INIT) gibbs_init_class(a, c, ch); else gibbs_round_class(a, c, ch);
+        if (a.wide[c] != (LIGHT ? 0 : 2)) continue;                  // 0 light, 1 wide (not here), 2 heavy
+        if (INIT) gibbs_init_class<LIGHT>(a, c, ch); else gibbs_round_class<LIGHT>(a, c, ch);
     }
 }
 
@@ -199,22 +214,25 @@ k_gibbs_components(GibbsArgs a, const uint32_t* __restrict__ list, const uint32_
 
 // plan: per class wide flag; per tile the band [lo, hi] of its non-wide classes
 __global__ void k_gibbs_plan(uint64_t C, uint32_t n_tiles, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
-                             uint8_t* wide, uint32_t* tile_lo, uint32_t* tile_hi, uint32_t* wide_list, unsigned int* n_wide) {
+                             const uint64_t* __restrict__ counts, uint8_t* wide, uint32_t* tile_lo, uint32_t* tile_hi, uint8_t* tile_kind,
+                             uint32_t* wide_list, unsigned int* n_wide) {
     uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
     const uint64_t c0 = (uint64_t)tile * kGibbsTile;
     const uint64_t c1 = (c0 + kGibbsTile < C) ? c0 + kGibbsTile : C;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0, kind = 0;                 // kind: bit 0 the tile has light classes, bit 1 heavy ones
     for (uint64_t c = c0; c < c1; ++c) {
         uint32_t b = rowptr[c], e = rowptr[c + 1];
         uint32_t mn = 0xFFFFFFFFu, mx = 0;
         for (uint32_t j = b; j < e; ++j) { uint32_t t = ids[j]; mn = t < mn ? t : mn; mx = t > mx ? t : mx; }
         bool w = (e > b) && (mx - mn > kWideSpan);
-        wide[c] = w ? 1 : 0;
+        const bool heavy = !w && e - b > 1u && counts[c] > kGibbsLightMax;       // (a singleton is never sampled)
+        wide[c] = w ? 1 : (heavy ? 2 : 0);
         if (w) wide_list[atomicAdd(n_wide, 1u)] = (uint32_t)c;
-        else if (e > b) { lo = mn < lo ? mn : lo; hi = mx > hi ? mx : hi; }
+        else if (e > b) { lo = mn < lo ? mn : lo; hi = mx > hi ? mx : hi; kind |= heavy ? 2u : 1u; }
     }
     tile_lo[tile] = lo; tile_hi[tile] = hi;                  // lo > hi: the tile has no banded class
+    tile_kind[tile] = (uint8_t)kind;
 }
 
 // the labels of the listed classes as a compact CSR (the host colours the wide classes: it needs their labels, not all 9 M nonzeros)
@@ -289,7 +307,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     if (C) { SF_HIP(hipMemcpyAsync(&L, prob->d_rowptr + C, 4, hipMemcpyDeviceToHost, st)); SF_HIP(hipStreamSynchronize(st)); }
     const uint32_t n_tiles = (uint32_t)((C + kGibbsTile - 1) / kGibbsTile);
     uint32_t* count_map = nullptr; int32_t* txp_count = nullptr; double *inv_len = nullptr, *w_mass = nullptr;
-    uint8_t* wide = nullptr; uint32_t *tile_lo = nullptr, *tile_hi = nullptr, *wide_list = nullptr; unsigned int* d_nwide = nullptr;
+    uint8_t *wide = nullptr, *tile_kind = nullptr; uint32_t *tile_lo = nullptr, *tile_hi = nullptr, *wide_list = nullptr; unsigned int* d_nwide = nullptr;
     int32_t* d_tmp = nullptr; int32_t* h_tmp = nullptr; uint32_t* d_thin_off = nullptr;
     uint32_t *d_lens = nullptr, *d_off = nullptr, *d_rows = nullptr;          // plan scratch: the wide classes' labels
     int rc = SFGPU_OK;
@@ -308,6 +326,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
     G_TRY(pool_malloc(&txp_count, (uint64_t)M * n_chains * 4));
     G_TRY(pool_malloc(&inv_len, M * 8)); G_TRY(pool_malloc(&w_mass, M * 8));
     G_TRY(pool_malloc(&wide, C ? C : 1)); G_TRY(pool_malloc(&wide_list, (C ? C : 1) * 4)); G_TRY(pool_malloc(&d_nwide, 4));
+    G_TRY(pool_malloc(&tile_kind, (size_t)(n_tiles ? n_tiles : 1)));
     G_TRY(pool_malloc(&tile_lo, (size_t)(n_tiles ? n_tiles : 1) * 4)); G_TRY(pool_malloc(&tile_hi, (size_t)(n_tiles ? n_tiles : 1) * 4));
     if (!d_out) G_TRY(pool_malloc(&d_tmp, (uint64_t)n_chains * M * 4));
     if (cb) G_TRY(pinned_malloc(&h_tmp, (uint64_t)n_chains * M * 4));
@@ -322,17 +341,23 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
         std::vector<uint32_t> colour_off;                  // wide classes by colour (empty: visited one after another)
         std::vector<uint32_t> thin_off, thin_list;         // ... and those of thin components, by component
         unsigned int n_rest = 0;                           // wide classes outside the thin components: wide_list[0, n_rest)
+        std::vector<uint8_t> phase_kind;                   // per phase: bit 0 some tile has light classes, bit 1 heavy ones
+        uint64_t n_heavy_tiles = 0;
         if (n_tiles) {
             hipLaunchKernelGGL(k_gibbs_plan, dim3((n_tiles + 255) / 256), dim3(256), 0, st, C, n_tiles, prob->d_rowptr, prob->d_ids,
-                               wide, tile_lo, tile_hi, wide_list, d_nwide);
+                               prob->d_counts, wide, tile_lo, tile_hi, tile_kind, wide_list, d_nwide);
             G_TRY(hipGetLastError());
             std::vector<uint32_t> lo(n_tiles), hi(n_tiles);
+            std::vector<uint8_t> kind(n_tiles);
+            G_TRY(hipMemcpyAsync(kind.data(), tile_kind, (size_t)n_tiles, hipMemcpyDeviceToHost, st));
             G_TRY(hipMemcpyAsync(lo.data(), tile_lo, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, st));
             G_TRY(hipMemcpyAsync(hi.data(), tile_hi, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, st));
             G_TRY(hipMemcpyAsync(&n_wide, d_nwide, 4, hipMemcpyDeviceToHost, st));
             G_TRY(hipStreamSynchronize(st));
             K = gibbs_phase_count(lo, hi);
             if (K > kMaxPhases) K = n_tiles;             // no locality to exploit: one tile per launch == a sequential scan
+            phase_kind.assign(K, 0);
+            for (uint32_t t = 0; t < n_tiles; ++t) { phase_kind[t % K] |= kind[t]; n_heavy_tiles += (kind[t] >> 1) & 1u; }
             n_rest = n_wide;
             if (n_wide > 1) {
                 // the plan appends wide classes with an atomic cursor: put them into class order, so that the wide
@@ -412,7 +437,7 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
                 G_TRY(hipStreamSynchronize(st));
             }
         }
-        log_msg(0, "gibbs: %u chains, %u tiles in %u phases, %u wide classes%s%s", n_chains, n_tiles, K, n_wide,
+        log_msg(0, "gibbs: %u chains, %llu heavy tiles, %u tiles in %u phases, %u wide classes%s%s", n_chains, (unsigned long long)n_heavy_tiles, n_tiles, K, n_wide,
                 colour_off.empty() ? "" : (": " + std::to_string(n_rest) + " in " + std::to_string(colour_off.size() - 1) + " colours").c_str(),
                 thin_off.empty() ? "" : (", " + std::to_string(thin_list.size()) + " in " + std::to_string(thin_off.size() - 1) + " thin components").c_str());
         GibbsArgs a{n_chains, C, prob->d_rowptr, prob->d_ids, prob->d_counts, inv_len, w_mass, count_map, txp_count,
@@ -421,8 +446,14 @@ int sfgpu_gibbs_sample(const sfgpu_problem* prob, const double* d_mass, uint32_t
         auto sweep = [&](bool init) -> hipError_t {
             for (uint32_t p = 0; p < K && p < n_tiles; ++p) {
                 dim3 g((n_tiles - p + K - 1) / K, groups);
-                if (init) hipLaunchKernelGGL(k_gibbs_phase<true>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
-                else hipLaunchKernelGGL(k_gibbs_phase<false>, g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+                if (phase_kind[p] & 1u) {
+                    if (init) hipLaunchKernelGGL((k_gibbs_phase<true, true>), g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+                    else hipLaunchKernelGGL((k_gibbs_phase<false, true>), g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+                }
+                if (phase_kind[p] & 2u) {
+                    if (init) hipLaunchKernelGGL((k_gibbs_phase<true, false>), g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+                    else hipLaunchKernelGGL((k_gibbs_phase<false, false>), g, dim3(kGibbsBlock), 0, st, a, p, K, n_tiles);
+                }
             }
             if (!thin_off.empty()) {
                 dim3 g((unsigned)(thin_off.size() - 1), groups);
@@ -472,7 +503,7 @@ done:
     (void)hipStreamSynchronize(st);
     lap("drain");
     for (void* p : {(void*)count_map, (void*)txp_count, (void*)inv_len, (void*)w_mass, (void*)wide, (void*)wide_list,
-                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)d_tmp, (void*)d_thin_off, (void*)d_lens, (void*)d_off, (void*)d_rows})
+                    (void*)d_nwide, (void*)tile_lo, (void*)tile_hi, (void*)tile_kind, (void*)d_tmp, (void*)d_thin_off, (void*)d_lens, (void*)d_off, (void*)d_rows})
         if (p) pool_free(p);
     if (h_tmp) pinned_free(h_tmp);
     // The chain state (4 * nnz * n_chains bytes, 38 GB for cfg3's classes and 1024 chains) stays in the allocator's cache: giving

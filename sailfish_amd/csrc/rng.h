@@ -20,6 +20,13 @@
 
 namespace sfgpu {
 
+#if !defined(SFGPU_X_PHILOX_ROUNDS)        // (dev, timing only: tools/gibbs_variants.sh builds the samplers with fewer rounds / a cut walk to see what each part costs)
+#define SFGPU_X_PHILOX_ROUNDS 10
+#endif
+#if !defined(SFGPU_X_WALK_MAX)
+#define SFGPU_X_WALK_MAX (kBinvSwitch - 1u)
+#endif
+
 struct Philox {
     uint32_t key[2];
     uint32_t ctr[4];
@@ -41,7 +48,7 @@ struct Philox {
     }
     SF_HD void block() {
         uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-        for (int r = 0; r < 10; ++r) {
+        for (int r = 0; r < SFGPU_X_PHILOX_ROUNDS; ++r) {
             uint32_t hi0, lo0, hi1, lo1;
             mulhilo(0xD2511F53u, c0, hi0, lo0);
             mulhilo(0xCD9E8D57u, c2, hi1, lo1);
@@ -60,8 +67,12 @@ struct Philox {
         return have == 3 ? out[3] : (have == 2 ? out[2] : (have == 1 ? out[1] : out[0]));
     }
     // uniform in the open interval (0, 1), 53 random bits
+    // (a PAIR of words per draw, one refill test: uniform() is the only consumer in the samplers, `have` is 0, 2 or 4 there; the words
+    //  come in next32()'s order)
     SF_HD double uniform() {
-        uint64_t hi = next32(), lo = next32();
+        if (have < 2) block();
+        have -= 2;
+        const uint64_t hi = have == 2 ? out[3] : out[1], lo = have == 2 ? out[2] : out[0];
         uint64_t x = ((hi << 32) | lo) >> 11;
         return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
     }
@@ -69,18 +80,71 @@ struct Philox {
 
 // The BINV walk below, f_x = f_(x-1) * (a / x - s) against u_x = u_(x-1) - f_(x-1), costs an f64 division per step.  Both
 // sides scaled by x! need none:  F_x = x! f_x = F_(x-1) * (a - s x),  U_x = x! u_x = x * (U_(x-1) - F_(x-1)),  and
-// u_x > f_x  <=>  U_x > F_x.  127! is the last factorial a double holds comfortably: from step kBinvSwitch on the walk
-// continues unscaled.  BINV is used up to a mean of kBinvMaxMean = 60 (the customary 30 dates from scalar machines: in a
-// wavefront of 64 chains BTPE costs every lane the slowest lane's rejection path, the walk costs mean + ~3 sd cheap steps;
-// measured on the Gibbs sampler over cfg3's classes: 30 -> 60 is -14 %, beyond 60 nothing).
-constexpr double kBinvMaxMean = 60.0;
+// u_x > f_x  <=>  U_x > F_x.  170! is the last factorial a double holds: from step kBinvSwitch - 4 ... - 1 on the walk continues
+// unscaled.  BINV is used up to a mean of kBinvMaxMean = 110 (the customary 30 dates from scalar machines: in a wavefront of 64
+// chains BTPE costs every lane the slowest lane's rejection path, the walk costs mean + ~3 sd cheap steps -- 7 vector instructions
+// each since round 5; measured on the Gibbs sampler over cfg3's classes: 30 -> 60 was -14 % in round 3, 60 -> 100 is -4 % with the
+// round-5 walk, 120 no better).  At the bound the walk passes step 164 with probability < 1e-6 (5 sd), and then only gets slower.
+#if !defined(SFGPU_BINV_MAX_MEAN)
+#define SFGPU_BINV_MAX_MEAN 110.0
+#endif
+constexpr double kBinvMaxMean = SFGPU_BINV_MAX_MEAN;
 #if !defined(SFGPU_BINV_SWITCH)
-#define SFGPU_BINV_SWITCH 128          // (tests/test_sampling_cpu.py builds the header with 8 as well, to walk through the switch)
+#define SFGPU_BINV_SWITCH 168          // (tests/test_sampling_cpu.py builds the header with 8 as well, to walk through the switch)
 #endif
 constexpr uint32_t kBinvSwitch = SFGPU_BINV_SWITCH;
 constexpr uint32_t kBinvPowMax = 1024;
 constexpr double binv_unscale(uint32_t n) { double f = 1.0; for (uint32_t i = 2; i <= n; ++i) f *= (double)i; return 1.0 / f; }
-constexpr double kBinvUnscale = binv_unscale(kBinvSwitch - 1u);      // ~ 1 / 127! = 3.3e-214 (U and F get the same factor: its last bits do not matter)
+constexpr double kBinvUnscale = binv_unscale(kBinvSwitch - 1u);      // ~ 1 / 167! (U and F get the same factor: its value does not matter, only that neither leaves the range)
+
+// BINV: Binomial(n, r) for r <= 1/2 and a mean n r < kBinvMaxMean, by walking the CDF from 0 (q = 1 - r)
+SF_HD uint32_t binv(Philox& g, uint32_t n, double r, double q) {
+    const double dn = (double)n;
+    uint32_t y;
+    {
+        const double s = r / q, a = (dn + 1.0) * s;
+        // f_0 = q^n: by squaring for n <= kBinvPowMax (<= 2 log2 n multiplications against ~110 instructions of log1p + exp; the error
+        // grows like n ulp / 2 -- 1e-13 at the bound), exp(n log1p(-r)) beyond.  q^n >= e^(-1.39 * 110): no underflow of the result.
+        double f0;
+        if (n <= kBinvPowMax) {
+            f0 = 1.0;
+            double b = q;
+            for (uint32_t e = n; e != 0u; e >>= 1) { if (e & 1u) f0 *= b; b *= b; }
+        } else f0 = exp(dn * log1p(-r));
+        // (the walk is the sampler's hot loop.  Four steps per trip, each behind its own test and nested in the one before: a lane
+        //  that is done drops out of the rest of the trip with one mask instruction, and the trip's bookkeeping -- the bound, the
+        //  branch -- is paid once per four steps.  With the end-of-range and the switch tests inside every step the compiler spent 25
+        //  scalar instructions per step on lane masks next to 10 vector ones; this form has 7 vector and ~3 scalar.  A lane whose
+        //  walk runs past n -- rounding: F is 0 or noise from there on -- walks on to the switch and redraws.)
+        for (;;) {
+            double F = f0, U = g.uniform();                  // x! f_x and x! u_x
+            uint32_t x = 0;
+            double dx = 0.0;
+#define SFGPU_BINV_STEP ++x; dx += 1.0; U = dx * (U - F); F *= fma(-s, dx, a);      /* scaled by x!: no division */
+            while (U > F && x < SFGPU_X_WALK_MAX - 3u) {
+                SFGPU_BINV_STEP
+                if (U > F) { SFGPU_BINV_STEP
+                    if (U > F) { SFGPU_BINV_STEP
+                        if (U > F) { SFGPU_BINV_STEP } } }
+            }
+#undef SFGPU_BINV_STEP
+#if defined(SFGPU_X_WALK_CUT)
+            y = x; break;
+#endif
+            if (x > n) continue;                              // rounding ran off the end: redraw
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(U), "+v"(F));              // (the exit state is compared HERE, once -- not tracked in a lane mask through every step)
+#endif
+            if (!(U > F)) { y = x; break; }
+            // kBinvSwitch - 4 <= x <= n, x < kBinvSwitch (probability < 1e-40 for the means BINV is used for): on unscaled
+            bool ok = true;
+            U *= kBinvUnscale; F *= kBinvUnscale;
+            while (U > F) { U -= F; ++x; if (x > n) { ok = false; break; } F *= (a / (double)x - s); }
+            if (ok) { y = x; break; }
+        }
+    }
+    return y;
+}
 
 // Binomial(n, p), exact: inversion (BINV) for small means, BTPE (Kachitvichyanukul & Schmeiser, 1988)
 // otherwise.  n < 2^32.
@@ -93,40 +157,11 @@ SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
     const double dn = (double)n;
     double y;
     if (dn * r < kBinvMaxMean) {
-        // ---- BINV: walk the CDF from 0
-        const double s = r / q, a = (dn + 1.0) * s;
-        // f_0 = q^n: by squaring for n <= kBinvPowMax (<= 2 log2 n multiplications against ~110 instructions of log1p + exp; the error
-        // grows like n ulp / 2 -- 1e-13 at the bound), exp(n log1p(-r)) beyond.  q^n >= e^(-1.39 * 60): no underflow of the result.
-        double f0;
-        if (n <= kBinvPowMax) {
-            f0 = 1.0;
-            double b = q;
-            for (uint32_t e = n; e != 0u; e >>= 1) { if (e & 1u) f0 *= b; b *= b; }
-        } else f0 = exp(dn * log1p(-r));
-        // (the walk is the sampler's hot loop: ONE exit test per step, a wavefront-uniform bound -- with the end-of-range and the switch
-        //  tests inside it the compiler spent 25 scalar instructions per step on lane masks next to 10 vector ones.  A lane whose walk
-        //  runs past n -- rounding: F is 0 or noise from there on -- walks on to the switch and redraws.)
-        for (;;) {
-            double F = f0, U = g.uniform();                  // x! f_x and x! u_x
-            uint32_t x = 0;
-            while (U > F && x < kBinvSwitch - 1u) {           // scaled by x!: no division
-                ++x;
-                const double dx = (double)x;
-                U = dx * (U - F); F *= fma(-s, dx, a);
-            }
-            if (x > n) continue;                              // rounding ran off the end: redraw
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(U), "+v"(F));              // (the exit state is compared HERE, once -- not tracked in a lane mask through every step)
-#endif
-            if (!(U > F)) { y = (double)x; break; }
-            if (x == n) continue;                             // rounding ran off the end: redraw
-            // x = kBinvSwitch - 1 < n (probability < 1e-40 for the means BINV is used for): on unscaled
-            bool ok = true;
-            U *= kBinvUnscale; F *= kBinvUnscale;
-            while (U > F) { U -= F; ++x; if (x > n) { ok = false; break; } F *= (a / (double)x - s); }
-            if (ok) { y = (double)x; break; }
-        }
+        y = (double)binv(g, n, r, q);
     } else {
+#if defined(SFGPU_X_NO_BTPE)
+        y = 0.0;
+#else
         // ---- BTPE
         const double fm = dn * r + r;
         const double m = floor(fm);
@@ -193,10 +228,32 @@ SF_HD uint32_t binomial(Philox& g, uint32_t n, double p) {
             if (A > bound) continue;
             break;
         }
+#endif
     }
     if (y < 0.0) y = 0.0;
     if (y > dn) y = dn;
     uint32_t k = (uint32_t)y;
+    return flip ? n - k : k;
+}
+
+// The same distribution from BINV alone: a sum of independent Binomial(n_i, r) with sum n_i = n IS Binomial(n, r), so a large mean is
+// drawn as equal parts of mean < kBinvMaxMean each.  For kernels that cannot afford BTPE's registers (52 VGPRs more in the Gibbs phase
+// kernel: four wavefronts per SIMD instead of six) and know their n to be moderate -- the cost is ~ n r walk steps.
+SF_HD uint32_t binomial_by_inversion(Philox& g, uint32_t n, double p) {
+    if (n == 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double r = flip ? 1.0 - p : p;       // r <= 0.5
+    const double q = 1.0 - r;
+    const double mean = (double)n * r;
+    uint32_t k;
+    if (mean < kBinvMaxMean) k = binv(g, n, r, q);
+    else {
+        const uint32_t parts = (uint32_t)(mean / kBinvMaxMean) + 1u;             // <= n / 220 + 1
+        const uint32_t base = n / parts, extra = n % parts;                      // `extra` parts of base + 1, the others of base
+        k = 0;
+        for (uint32_t i = 0; i < parts; ++i) k += binv(g, base + (i < extra ? 1u : 0u), r, q);
+    }
     return flip ? n - k : k;
 }
 

@@ -8,6 +8,12 @@ void draw_binomial(uint64_t seed, uint32_t n, double p, uint32_t count, uint32_t
         out[i] = sfgpu::binomial(g, n, p);
     }
 }
+void draw_binomial_by_inversion(uint64_t seed, uint32_t n, double p, uint32_t count, uint32_t* out) {
+    for (uint32_t i = 0; i < count; ++i) {
+        sfgpu::Philox g; g.init(seed, i, 0);
+        out[i] = sfgpu::binomial_by_inversion(g, n, p);
+    }
+}
 void draw_uniform(uint64_t seed, uint64_t stream, uint32_t count, double* out) {
     sfgpu::Philox g; g.init(seed, stream, 0);
     for (uint32_t i = 0; i < count; ++i) out[i] = g.uniform();

@@ -275,14 +275,16 @@ def test_cfg5_thousand_draws_over_cfg3_classes(gpu):
         p.close()
 
 
-@pytest.mark.parametrize("n_wide_labels", [3, 150, 600])
-def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labels):
+@pytest.mark.parametrize("n_wide_labels,heavy", [(3, False), (150, False), (600, False), (3, True)])
+def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labels, heavy):
     """per-transcript mean and spread of the phase-parallel sampler vs the oracle's sequential sampleRound_
     (src/CollapsedGibbsSampler.cpp:113-184) on a problem with thousands of classes, a multi-phase round and wide classes.
     3 wide labels: visited one after another by one launch; 150 wide labels in groups of 30 that share a far transcript (the
     pseudogene every read of a gene also hits) and overlap otherwise: five THIN components (30 classes need 30 colours), each
     walked by one wavefront per 64 chains; 600 wide labels linked into one long chain (label i shares a transcript with label
-    i + 1, and a far one with two others): one component, a few colours of ~200 classes, one launch per colour."""
+    i + 1, and a far one with two others): one component, a few colours of ~200 classes, one launch per colour.
+    heavy: the first 100 reads 2000 times more -- up to 100 classes of > 1500 reads among the light ones: the phase kernel's two forms
+    (BINV only at six wavefronts per SIMD; with BTPE at four) share the tiles."""
     import sailfish_amd as sf
     from sailfish_amd import _lib, synth
     M, P, R = 3000, 6000, 120_000
@@ -301,6 +303,11 @@ def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labe
     else:
         wide = [np.array([i, i + 1, 2800 + i % 190], np.int32) for i in range(n_wide_labels)]       # (span > 2048: wide)
         reps = 20
+    if heavy:
+        n0 = int(off[100])
+        ids = torch.cat([ids, ids[:n0].repeat(2000)])
+        off = torch.cat([off, int(off[-1]) + (off[1:101].repeat(2000) + n0 * torch.arange(2000, dtype=off.dtype).repeat_interleave(100))])
+        R += 200_000
     extra_ids = np.concatenate([np.tile(w, reps) for w in wide])
     extra_len = np.concatenate([np.full(reps, len(w)) for w in wide])
     extra_off = int(off[-1]) + np.cumsum(extra_len)
@@ -325,6 +332,7 @@ def test_gibbs_multi_phase_round_matches_the_sequential_sampler(gpu, n_wide_labe
     plan = [m for m in logs if "gibbs:" in m][-1]
     K = int(plan.split(" tiles in ")[1].split()[0]); n_wide = int(plan.split(" phases, ")[1].split()[0])
     assert K >= 2 and n_wide >= 3, plan
+    assert (int(plan.split(" chains, ")[1].split()[0]) > 0) == heavy, plan          # "... chains, H heavy tiles, T tiles in K phases, ..."
     # "... W wide classes: A in B colours, C in D thin components"
     assert ("colours" in plan) == (n_wide_labels > 64), plan
     if n_wide_labels > 64:

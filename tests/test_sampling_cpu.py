@@ -17,6 +17,7 @@ def _harness(tmp_path_factory, *defs):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", *defs, "-o", str(so), os.path.join(HERE, "sampling_harness.cpp")])
     L = C.CDLL(str(so))
     L.draw_binomial.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p]
+    L.draw_binomial_by_inversion.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p]
     L.draw_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
     L.philox_block.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
     return L
@@ -29,7 +30,7 @@ def H(tmp_path_factory):
 
 @pytest.fixture(scope="module")
 def H8(tmp_path_factory):
-    """the same header with the BINV walk leaving its factorial-scaled form after 7 steps instead of 127"""
+    """the same header with the BINV walk leaving its factorial-scaled form after 4 - 7 steps instead of 164 - 167"""
     return _harness(tmp_path_factory, "-DSFGPU_BINV_SWITCH=8")
 
 
@@ -58,7 +59,7 @@ def test_binv_switch_point_is_invisible(H, H8):
     the same draws wherever the switch lies -- up to the last bits of the running products, which move a draw that falls
     on a boundary of the CDF by one (rare)"""
     N = 20000
-    for n, p in ((100, 0.2), (1000, 0.05), (59, 0.5), (130, 0.45), (100000, 0.0004)):
+    for n, p in ((100, 0.2), (1000, 0.05), (59, 0.5), (130, 0.45), (100000, 0.0004), (215, 0.5), (1000, 0.105)):
         a = np.zeros(N, np.uint32); b = np.zeros(N, np.uint32)
         H.draw_binomial(99, n, p, N, a.ctypes.data); H8.draw_binomial(99, n, p, N, b.ctypes.data)
         assert b.max() > 8                                      # the walk did pass the switch
@@ -69,12 +70,24 @@ def test_binv_switch_point_is_invisible(H, H8):
 @pytest.mark.parametrize("n,p", [(1, 0.3), (10, 0.5), (100, 0.01), (1000, 0.02), (50, 0.9), (200, 0.16), (1000, 0.5),
                                  (100000, 0.001), (100000, 0.3), (3000000, 0.7), (4000000000, 1e-9), (4000000000, 0.25),
                                  (59, 0.5), (61, 0.5), (400, 0.075),
-                                 # around the BINV / BTPE boundary (mean 60) and BTPE's explicit-product path
-                                 (119, 0.5), (121, 0.5), (1000, 0.055), (600000, 0.0001), (130, 0.45), (250, 0.45), (700, 0.1)])
+                                 # around the BINV / BTPE boundary (mean 110; 60 until round 5) and BTPE's explicit-product path
+                                 (119, 0.5), (121, 0.5), (1000, 0.055), (600000, 0.0001), (130, 0.45), (250, 0.45), (700, 0.1),
+                                 (219, 0.5), (221, 0.5), (1000, 0.109), (1000, 0.111), (1100000, 0.0001), (260, 0.45), (1200, 0.1)])
 def test_binomial_matches_scipy(H, n, p):
+    _check_against_scipy(H.draw_binomial, n, p)
+
+
+@pytest.mark.parametrize("n,p", [(1, 0.3), (100, 0.01), (200, 0.16), (219, 0.5), (221, 0.5), (440, 0.5), (441, 0.5), (300, 0.45), (1000, 0.3),
+                                 (1000, 0.7), (5000, 0.5), (100000, 0.001), (100000, 0.0025), (333, 0.34)])
+def test_binomial_by_inversion_matches_scipy(H, n, p):
+    """the BINV-only sampler of the Gibbs kernel's light form: one walk below a mean of 110, a sum of equal parts above"""
+    _check_against_scipy(H.draw_binomial_by_inversion, n, p)
+
+
+def _check_against_scipy(draw, n, p):
     N = 60000
     x = np.zeros(N, np.uint32)
-    H.draw_binomial(12345 + n, n, p, N, x.ctypes.data)
+    draw(12345 + n, n, p, N, x.ctypes.data)
     x = x.astype(np.float64)
     mean, var = n * p, n * p * (1 - p)
     assert x.min() >= 0 and x.max() <= n
