@@ -2266,8 +2266,10 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 (void)hipMemcpy(h.data(), em->td, (size_t)nt * sizeof(TileDesc), hipMemcpyDeviceToHost);
                 uint32_t by_list = 0; uint64_t nb_sum = 0, span_sum = 0;
                 for (const TileDesc& t : h) { if (t.nb_n == kNbByList) ++by_list; else nb_sum += t.nb_n; span_sum += t.span; }
-                fprintf(stderr, "em fused plan: %u of %u tiles by the cover list, %.2f overlapping tiles on average for the others, mean span %.0f\n", by_list, nt,
-                        nt > by_list ? (double)nb_sum / (nt - by_list) : 0.0, (double)span_sum / nt);
+                uint32_t hist[kNbMax + 1] = {};
+                for (const TileDesc& t : h) if (t.nb_n <= (uint32_t)kNbMax) ++hist[t.nb_n];
+                fprintf(stderr, "em fused plan: %u of %u tiles by the cover list, %.2f overlapping tiles on average for the others (0..6: %u %u %u %u %u %u %u), mean span %.0f\n", by_list, nt,
+                        nt > by_list ? (double)nb_sum / (nt - by_list) : 0.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], (double)span_sum / nt);
             }
         }
         if (rowptr2) { pool_free_on(rowptr2, em->cur); pool_free_on(vids, em->cur); rowptr2 = vids = nullptr; }

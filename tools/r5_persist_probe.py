@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sailfish_amd as sf
 from sailfish_amd import synth
 dev = torch.device("cuda:0")
-SHAPES = dict(cfg3=(200_000, 4_000_000, 400_000_000), cfg2=(80_000, 1_000_000, 50_000_000), mid=(400_000, 3_000_000, 100_000_000))
+SHAPES = dict(cfg3=(200_000, 4_000_000, 400_000_000), cfg2=(80_000, 1_000_000, 50_000_000), mid=(400_000, 3_000_000, 100_000_000), tiny=(100_000, 150_000, 3_000_000))
 MODES = dict(two=dict(SFGPU_EM_FUSED="0"), fused=dict(SFGPU_EM_FUSED="1", SFGPU_EM_PERSIST="0"), persist=dict(SFGPU_EM_FUSED="1", SFGPU_EM_PERSIST="1"),
              ablate=dict(SFGPU_EM_FUSED="1", SFGPU_EM_PERSIST="2"))
 for shape in os.environ.get("EMP_SHAPES", "cfg3,cfg2").split(","):
