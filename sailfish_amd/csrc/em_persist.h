@@ -214,6 +214,11 @@ __device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y =
 #define SFP_STAMP(k) do { } while (0)
 #endif
 // the cold block / the tile's record, looked at from a rare path: the pointer is made opaque THERE, so no load of it is hoisted out
+#ifdef SFGPU_P_NOCONF                                                      // dev, timing only: every LDS gather of phases A and C without bank conflicts (wrong addresses)
+#define SFP_BANK(v, m) (((v) & ~31u) | ((lane + (m)) & 31u))
+#else
+#define SFP_BANK(v, m) (v)
+#endif
 #ifdef SFGPU_P_L2HIT                                                       // dev, timing only: every stream load of a tile falls into its first 1024 entries (all L2 hits)
 #define SFP_IX(i) ((i) & 1023u)
 #else
@@ -493,8 +498,8 @@ k_em_persist(PersistArgs a) {
         {
             if (tid < np) { pc_e0 = pure[SFP_IX(tid)]; pc_s0 = slot0_p[SFP_IX(tid)]; }
             auto chunk_sum = [&](const uint4& s4) -> double {                   // eight window slots (bit 15 of the first: the long flag)
-                const double v0 = xs[s4.x & 0x7FFFu], v1 = xs[s4.x >> 16], v2 = xs[s4.y & 0xFFFFu], v3 = xs[s4.y >> 16];
-                const double v4 = xs[s4.z & 0xFFFFu], v5 = xs[s4.z >> 16], v6 = xs[s4.w & 0xFFFFu], v7 = xs[s4.w >> 16];
+                const double v0 = xs[SFP_BANK(s4.x & 0x7FFFu, 0)], v1 = xs[SFP_BANK(s4.x >> 16, 1)], v2 = xs[SFP_BANK(s4.y & 0xFFFFu, 2)], v3 = xs[SFP_BANK(s4.y >> 16, 3)];
+                const double v4 = xs[SFP_BANK(s4.z & 0xFFFFu, 4)], v5 = xs[SFP_BANK(s4.z >> 16, 5)], v6 = xs[SFP_BANK(s4.w & 0xFFFFu, 6)], v7 = xs[SFP_BANK(s4.w >> 16, 7)];
                 return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
             };
             auto class_chunk = [&](uint32_t c, const uint4& s4, uint32_t cwc) {
@@ -540,8 +545,8 @@ k_em_persist(PersistArgs a) {
         // ================= C: the window (a gather over the transcript-major copy) =================
         {
             auto pure_chunk = [&](const uint4& e4, uint32_t sf) {
-                const double q0 = den[e4.x & 0x1FFFu], q1_ = den[(e4.x >> 16) & 0x1FFFu], q2_ = den[e4.y & 0x1FFFu], q3 = den[(e4.y >> 16) & 0x1FFFu];
-                const double q4 = den[e4.z & 0x1FFFu], q5 = den[(e4.z >> 16) & 0x1FFFu], q6 = den[e4.w & 0x1FFFu], q7 = den[(e4.w >> 16) & 0x1FFFu];
+                const double q0 = den[SFP_BANK(e4.x & 0x1FFFu, 0)], q1_ = den[SFP_BANK((e4.x >> 16) & 0x1FFFu, 1)], q2_ = den[SFP_BANK(e4.y & 0x1FFFu, 2)], q3 = den[SFP_BANK((e4.y >> 16) & 0x1FFFu, 3)];
+                const double q4 = den[SFP_BANK(e4.z & 0x1FFFu, 4)], q5 = den[SFP_BANK((e4.z >> 16) & 0x1FFFu, 5)], q6 = den[SFP_BANK(e4.w & 0x1FFFu, 6)], q7 = den[SFP_BANK((e4.w >> 16) & 0x1FFFu, 7)];
                 const double sum = ((q0 + q1_) + (q2_ + q3)) + ((q4 + q5) + (q6 + q7));
                 const uint32_t slot = sf & 0x7FFFu;
                 const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;
