@@ -1957,7 +1957,7 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
         hipLaunchKernelGGL(k_cls8_count, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, st, C, p_rowptr, extra);
         int rc = exclusive_scan_u32(extra, ov_start, C, st, false);
         if (!rc) hipLaunchKernelGGL(k_cls8_build, dim3(nt), dim3(kEmBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
-                                    ov_start, em->counts32, em->cls8, em->cnt8, em->ovc, em->ov8, em->td, em->pflags);
+                                    ov_start, em->counts32, em->cls8, em->ovc, em->ov8, em->td, em->pflags);
         { void* ps[2] = {extra, ov_start}; pool_free_on_many(ps, 2, st); }
         if (rc) return rc;
         SF_CHECK_LAUNCH();
@@ -2585,6 +2585,7 @@ static void em_persist_check(sfgpu_em* em) {
     const uint32_t* pf = reinterpret_cast<const uint32_t*>(em->h_plan + 6);
     if (pf[0] & 2u) return no("a far member's transcript lies in no window (no home thread)");
     if (pf[0] & 4u) return no("a transcript is fed by more far slots than its home thread should walk");
+    if (pf[0] & 8u) return no("a class of 2^30 reads or more (bit 30 of the loop's count words is a flag)");
     if ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 1u) != 0u) return no("a tile that more than kNbMax tiles overlap (it goes by the cover list)");
     em->far_cap = pf[1];
     constexpr size_t kLdsPerBlock = 81920;                   // half a CU's LDS: two blocks per CU, like the sweep
@@ -2631,7 +2632,8 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
         static_assert(((size_t)kCtlWords * 8 + 64) % 16 == 0, "the cold block starts on a 16-byte boundary");
         const uint32_t c0 = (uint32_t)(((size_t)kCtlWords * 8 + 64) / 16), cn = (uint32_t)((sizeof(PersistCold) + 15) / 16);
         const unsigned nb = (unsigned)std::min<uint64_t>((em->xbuf_bytes / 16 + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_persist_init, dim3(nb), dim3(256), 0, em->cur, (void*)em->xbuf, (uint32_t)em->xbuf_bytes, c0, cn, d_cold, c);
+        hipLaunchKernelGGL(k_persist_init, dim3(nb), dim3(256), 0, em->cur, (void*)em->xbuf, (uint32_t)em->xbuf_bytes, c0, cn, d_cold, c,
+                           (uint64_t)em->prob.C, (const uint32_t*)em->counts32, (const uint4*)em->cls8, em->cnt8);
         SF_CHECK_LAUNCH();
     }
     void* args[] = {&a};

@@ -129,7 +129,7 @@ __global__ void k_cls8_count(uint64_t C, const uint32_t* __restrict__ rowptr, ui
 __global__ void __launch_bounds__(kEmBlock)
 k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
              const uint16_t* __restrict__ slot16, const uint64_t* __restrict__ ov_start, const uint32_t* __restrict__ counts,
-             uint4* cls8, uint32_t* cnt8, uint32_t* ovc, uint4* ov8, TileDesc* td, uint32_t* pflags) {
+             uint4* cls8, uint32_t* ovc, uint4* ov8, TileDesc* td, uint32_t* pflags) {
     const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1];
     const uint64_t s0 = tile_s0[T];
     const uint32_t j0 = rowptr[c0];
@@ -144,9 +144,9 @@ k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ t
         if (single) w[0] = kWin;
         const bool lng = k > 8u || far;
         if (lng) w[0] |= kCls8Long;
-        const uint32_t cw = counts[c];                               // count, bit 31: singleton (k_narrow_counts)
-        if (cw & kCnt8Long) atomicOr(&pflags[0], 8u);                // (a class of >= 2^30 reads: the bit is taken -- such a plan keeps one kernel per iteration)
-        cnt8[c] = cw | (lng ? kCnt8Long : 0u);
+        // (a class of ~2^30 reads: bit 30 of the count word is taken -- such a plan keeps one kernel per iteration.  The margin is for the
+        //  bootstrap's resampled counts: a class of c reads draws c +- sqrt(c), 2^20 is 30 of those)
+        if ((counts[c] & 0x7FFFFFFFu) >= kCnt8Long - (1u << 20)) atomicOr(&pflags[0], 8u);
         cls8[c] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
         uint64_t at = ov_start[c];
         for (uint32_t m0 = 8u; m0 < k; m0 += 8u, ++at) {
@@ -190,8 +190,13 @@ struct PersistArgs {
 // L2 of the XCD that wrote them, a write-through store from another XCD does not reach those copies, and a tile that runs on that XCD
 // then polls (sc1 loads are L2-served) a line of zeros for ever.  Seen with three bootstrap lanes (other streams' kernels between the
 // launches: blocks land on other XCDs than b mod 8): tiles of one or two XCDs waited in step 1 for sums their neighbours had published.
+// ... and cnt8, the count words the loop reads: the handle's CURRENT counts (the bootstrap resamples them before every run) with the
+// long flag of the class's chunk in bit 30.
 __global__ void __launch_bounds__(256)
-k_persist_init(void* xbuf, uint32_t bytes, uint32_t cold_first16, uint32_t cold_n16, PersistCold* d_cold, PersistCold cold) {
+k_persist_init(void* xbuf, uint32_t bytes, uint32_t cold_first16, uint32_t cold_n16, PersistCold* d_cold, PersistCold cold,
+               uint64_t C, const uint32_t* __restrict__ counts, const uint4* __restrict__ cls8, uint32_t* __restrict__ cnt8) {
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (uint64_t)gridDim.x * blockDim.x)
+        cnt8[c] = (counts[c] & ~kCnt8Long) | ((cls8[c].x & kCls8Long) ? kCnt8Long : 0u);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, bytes, 0x00020000);
     const uint32_t n16 = bytes / 16u;
     const gr4 z = {0u, 0u, 0u, 0u};

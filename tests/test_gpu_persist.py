@@ -128,3 +128,37 @@ def test_persistent_loop_gives_up_and_the_run_is_repeated(sf, gpu, local_table, 
     monkeypatch.setenv("SFGPU_EM_PERSIST", "1")
     grc, st = p.optimize(use_vbem=True)                    # (the handle does not try again)
     assert grc == 0 and not st["persistent"] and st["iters"] == ost["iters"]
+
+
+def test_bootstrap_on_one_lane_runs_the_persistent_loop_on_the_resampled_counts(sf, gpu, local_table, monkeypatch):
+    """a replicate = the class counts resampled + the EM loop over them.  Several lanes keep one kernel per iteration (notes 5);
+    ONE lane runs the persistent loop, whose count words are a copy with a flag bit: made again before every launch
+    (k_persist_init), or the replicates would all be the observed counts'.  Draw b is the same whichever lane makes it."""
+    m = local_table
+    p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    monkeypatch.setenv("SFGPU_BS_LANES", "1")
+    rc1, out1, it1 = p.bootstrap(3, seed=5)
+    monkeypatch.setenv("SFGPU_BS_LANES", "3")
+    rc3, out3, it3 = p.bootstrap(3, seed=5)
+    assert rc1 == 0 and rc3 == 0 and np.array_equal(it1, it3)
+    a1, a3 = out1.cpu().numpy(), out3.cpu().numpy()
+    for b in range(3):
+        assert _rel(a1[b], a3[b]) < TIGHT
+    assert float(np.abs(a1[0] - a1[1]).max()) > 1.0          # (the replicates differ: the counts were resampled)
+    grc, st = p.optimize()                                    # the observed counts are back, and the loop reads them
+    rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], m["counts"], m["R"])
+    assert grc == 0 and st["persistent"] and st["iters"] == ost["iters"] and _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+    p.close()
+
+
+def test_a_class_of_2_to_the_30_reads_keeps_one_kernel_per_iteration(sf, gpu, local_table):
+    """bit 30 of the persistent loop's count words is its long-class flag: a plan with a class that large is not eligible"""
+    m = local_table
+    cc = m["counts"].copy(); cc[len(cc) // 2] = (1 << 30) + 12345
+    R = int(cc.sum())
+    rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], cc, R, max_iter=20, min_iter=20, tol=0.0)
+    p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], cc, R)
+    grc, st = p.optimize(max_iter=20, min_iter=20, tol=0.0)
+    assert grc == 0 and rc == 0 and not st["persistent"] and st["iters"] == ost["iters"]
+    assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+    p.close()
