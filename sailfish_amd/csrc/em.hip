@@ -1951,15 +1951,10 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
     }
     {   // phase A's chunk-per-class stream (k_cls8_build): from the compact stream's 16-bit slots, the plan's rowptr and tile table
         const uint64_t C = em->prob.C, Lnz = em->L;
-        uint32_t* extra = nullptr; uint64_t* ov_start = nullptr;
-        SF_HIP(pool_malloc(&extra, (C + 2) * 4)); SF_HIP(pool_malloc(&ov_start, (C + 3) * 8));
-        SF_HIP(pool_malloc(&em->cls8, (C ? C : 1) * 16)); SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->ovc, (Lnz / 8 + 2) * 4)); SF_HIP(pool_malloc(&em->ov8, (Lnz / 8 + 2) * 16));
-        hipLaunchKernelGGL(k_cls8_count, dim3(blocks_for(C + 1)), dim3(kEmBlock), 0, st, C, p_rowptr, extra);
-        int rc = exclusive_scan_u32(extra, ov_start, C, st, false);
-        if (!rc) hipLaunchKernelGGL(k_cls8_build, dim3(nt), dim3(kEmBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
-                                    ov_start, em->counts32, em->cls8, em->ovc, em->ov8, em->td, em->pflags);
-        { void* ps[2] = {extra, ov_start}; pool_free_on_many(ps, 2, st); }
-        if (rc) return rc;
+        SF_HIP(pool_malloc(&em->cls8, (C ? C : 1) * 16)); SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4));
+        SF_HIP(pool_malloc(&em->ovc, (Lnz / 8 + 2 * (uint64_t)nt + 2) * 4)); SF_HIP(pool_malloc(&em->ov8, (Lnz / 8 + 2 * (uint64_t)nt + 2) * 16));      // (a tile's stream is padded to whole chunks)
+        hipLaunchKernelGGL(k_cls8_build, dim3(nt), dim3(kSweepBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
+                           em->counts32, em->cls8, em->ovc, em->ov8, em->td, em->pflags);
         SF_CHECK_LAUNCH();
     }
     // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned

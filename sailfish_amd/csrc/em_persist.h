@@ -122,19 +122,33 @@ __global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const ui
 // the long classes (the flag is bit 30 of the count word: cnt8, a copy of the plan's counts).
 constexpr uint32_t kCls8Long = 0x8000u;
 constexpr uint32_t kCnt8Long = 0x40000000u;        // the same flag in the class's count word (bit 31: singleton)
-__global__ void k_cls8_count(uint64_t C, const uint32_t* __restrict__ rowptr, uint32_t* extra) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) { const uint32_t k = rowptr[c + 1] - rowptr[c]; extra[c] = k > 8u ? (k - 8u + 7u) / 8u : 0u; } else if (c == C) extra[c] = 0u;
-}
-__global__ void __launch_bounds__(kEmBlock)
+// One block per tile.  A tile's overflow chunks start at tile_s0 / 8 + tile (a tile of n nonzeros has at most n / 8 of them: the
+// regions cannot meet), a class's at the block-wide prefix sum of the chunks its predecessors need: no global scan, one launch.
+__global__ void __launch_bounds__(kSweepBlock)
 k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
-             const uint16_t* __restrict__ slot16, const uint64_t* __restrict__ ov_start, const uint32_t* __restrict__ counts,
+             const uint16_t* __restrict__ slot16, const uint32_t* __restrict__ counts,
              uint4* cls8, uint32_t* ovc, uint4* ov8, TileDesc* td, uint32_t* pflags) {
-    const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1];
+    __shared__ uint32_t ext[8192];                                   // overflow chunks in front of a class's (class field: 13 bits)
+    __shared__ uint32_t wsum[kSweepBlock / kWave];
+    const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1], nc = c1 - c0, tid = threadIdx.x;
     const uint64_t s0 = tile_s0[T];
     const uint32_t j0 = rowptr[c0];
-    if (threadIdx.x == 0) { td[T].ov0 = (uint32_t)ov_start[c0]; td[T].n_ov = (uint32_t)(ov_start[c1] - ov_start[c0]); }
-    for (uint32_t c = c0 + threadIdx.x; c < c1; c += kEmBlock) {
+    const uint32_t ov0 = (uint32_t)(s0 / 8u) + T;
+    // a thread's run of classes [q0, q1), its chunks, then the block's exclusive prefix over the threads
+    const uint32_t per = (nc + kSweepBlock - 1u) / kSweepBlock, q0 = tid * per < nc ? tid * per : nc, q1 = q0 + per < nc ? q0 + per : nc;
+    uint32_t mine = 0;
+    for (uint32_t c = q0; c < q1; ++c) { const uint32_t k = rowptr[c0 + c + 1] - rowptr[c0 + c]; ext[c] = mine; mine += k > 8u ? (k - 8u + 7u) / 8u : 0u; }
+    uint32_t incl = mine;
+    for (int o = 1; o < kWave; o <<= 1) { const uint32_t v = __shfl_up(incl, o, kWave); if ((tid & (kWave - 1)) >= (uint32_t)o) incl += v; }
+    if ((tid & (kWave - 1)) == kWave - 1) wsum[tid / kWave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < tid / kWave; ++w) base += wsum[w];
+    base += incl - mine;
+    for (uint32_t c = q0; c < q1; ++c) ext[c] += base;
+    if (tid == kSweepBlock - 1u) { td[T].ov0 = ov0; td[T].n_ov = base + mine; }
+    __syncthreads();
+    for (uint32_t c = c0 + tid; c < c1; c += kSweepBlock) {
         const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
         const uint16_t* sl = slot16 + s0 + (b - j0);
         uint32_t w[8]; bool far = false;
@@ -148,7 +162,7 @@ k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ t
         //  bootstrap's resampled counts: a class of c reads draws c +- sqrt(c), 2^20 is 30 of those)
         if ((counts[c] & 0x7FFFFFFFu) >= kCnt8Long - (1u << 20)) atomicOr(&pflags[0], 8u);
         cls8[c] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
-        uint64_t at = ov_start[c];
+        uint32_t at = ov0 + ext[c - c0];
         for (uint32_t m0 = 8u; m0 < k; m0 += 8u, ++at) {
             uint32_t v[8];
             for (uint32_t m = 0; m < 8u; ++m) v[m] = m0 + m < k ? sl[m0 + m] : (uint32_t)kWin;
