@@ -1118,12 +1118,17 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
             float ms = 0.f; if (hipEventElapsedTime(&ms, eq->ev0, eq->ev1) == hipSuccess) eq->stats.insert_ms += ms;
             timing = false;
         } else SF_HIP(hipStreamSynchronize(sr));
+        // (the deferred labels of BOTH sets first, then the fix-ups: eq_part_fixups doubles the table when it has deferred labels to
+        //  replay -- set by set it doubled twice per drain and began its stuck-cluster detection anew)
         bool fixed = false;
+        for (int j = 0; j < 2; ++j) {
+            sfgpu_eq::PartSet& S = eq->pset[(k + j) & 1];
+            if (S.fix && (r = eq_deferred_save(eq, S.words.p, S.deferred.p, S.n_def))) return r;
+        }
         for (int j = 0; j < 2; ++j) {
             sfgpu_eq::PartSet& S = eq->pset[(k + j) & 1];
             if (!S.fix) continue;
             S.fix = false; fixed = true;
-            if ((r = eq_deferred_save(eq, S.words.p, S.deferred.p, S.n_def))) return r;
             if ((r = eq_part_fixups(eq, d_ids, d_offsets, S.longl.p, S.n_long))) return r;
         }
         if (fixed) {                                  // the generic kernel committed classes the device-side counter has not seen
