@@ -2591,7 +2591,7 @@ static void em_persist_check(sfgpu_em* em) {
     for (int vb = 0; vb < 2; ++vb) {
         int nb = 0;
         if (hipFuncSetAttribute(em_persist_func(vb != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerBlock) != hipSuccess) { (void)hipGetLastError(); return no("hipFuncSetAttribute"); }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, em_persist_func(vb != 0), kSweepBlock, lds) != hipSuccess) { (void)hipGetLastError(); return no("occupancy query"); }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, em_persist_func(vb != 0), kPB, lds) != hipSuccess) { (void)hipGetLastError(); return no("occupancy query"); }
         if ((uint64_t)nb * (uint64_t)n_cu < em->n_tiles) return no("more tiles than resident blocks (a multi-round plan)");
     }
     if (say) fprintf(stderr, "em persistent: eligible (%u tiles, %zu bytes of LDS, %u far slots at most per tile)\n", em->n_tiles, lds, em->far_cap);
@@ -2632,7 +2632,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
         SF_CHECK_LAUNCH();
     }
     void* args[] = {&a};
-    SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kSweepBlock), args, em_persist_lds(em), em->cur));
+    SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kPB), args, em_persist_lds(em), em->cur));
     // (the launch's verdict, next to the plan's words in pinned memory; read behind finish()'s wait)
     SF_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t*>(em->h_plan + 7), c.status, 4, hipMemcpyDeviceToHost, em->cur));
     return SFGPU_OK;

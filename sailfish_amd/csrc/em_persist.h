@@ -38,6 +38,20 @@ constexpr uint32_t kCtlAbort = 5 * kShards;          // != 0: some tile gave up 
 constexpr uint32_t kCtlWords = (5 * kShards + 2) * kCtlStride;       // (+ a line for who gave up: tile + 1, thread, wait, step)
 constexpr uint32_t kSpinLimit = 1u << 18;            // polls of one wait (0.2 - 1 us each: 50 - 250 ms) before a tile gives up
 constexpr uint32_t kFanInMax = 16;                   // far slots one transcript may collect (its home thread reads them one by one)
+// The block: 1024 threads, one window slot per thread, two blocks per CU.  The kernel is written for kPS window slots per thread
+// (`-DSFGPU_PERSIST_BLOCK=512`: two slots, four wavefronts per SIMD, 128 VGPRs / 102 SGPRs instead of 64 / 80) because a step costs a
+// wavefront ~570 instructions whatever its tile holds and half the wavefronts looked like half of that cost -- measured, it is the
+// other way round: cfg3 15.9 -> 20.2 us per step, cfg2 8.7 -> 10.6, a 2 k-nonzero problem 7.4 -> 8.5.  A step is chains of dependent
+// instructions (granule -> sum -> division -> LDS -> barrier ...), and what hides them is other wavefronts (profiles/r5_em_notes.md 4b).
+#if !defined(SFGPU_PERSIST_BLOCK)
+#define SFGPU_PERSIST_BLOCK 1024
+#endif
+constexpr int kPB = SFGPU_PERSIST_BLOCK;                // threads of a block of the persistent loop
+constexpr int kPS = (kWin + kPB - 1) / kPB;             // window slots per thread: slot j of thread t is t + j * kPB
+constexpr int kPWaves = kPB / kWave;
+constexpr int kPAhead = kCntAhead * (kSweepBlock / kPB);      // class chunks (and counts) a thread requests ahead of phase A
+constexpr int kPCAhead = 2 * (kSweepBlock / kPB);       // transcript-major chunks a thread requests ahead of phase C
+static_assert(kPB % kWave == 0 && kPB <= kSweepBlock && kSweepBlock % kPB == 0, "block of the persistent loop");
 
 // ---- the plan's far-slot tables (sfgpu_em_create -> em_persist_plan) ----------------------------------------------------------
 // An escape is (tile, class, far transcript).  The distinct far transcripts of a tile are its FAR SLOTS, numbered in position
@@ -246,7 +260,7 @@ __device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y =
 #define SFP_COLD(name) const PersistCold* name = a.cold; asm volatile("" : "+s"(name))
 #define SFP_TILE(name) const TileDesc* name = a.tiles + blockIdx.x; asm volatile("" : "+s"(name))
 template <bool VB>
-__global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(kPB) __attribute__((amdgpu_waves_per_eu(kPB / 128, kPB / 128)))
 k_em_persist(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plds[];
     double* const xs = plds;                               // [kWin + 1]  (+ the slot of the null words: x = 0)
@@ -255,7 +269,7 @@ k_em_persist(PersistArgs a) {
     double* const facc = den + (a.den_cap + 2);            // [far_cap]
     double* const fxs = facc + a.far_cap;                  // [far_cap]  x of the far slots' transcripts, fetched once per step (head)
     double* const wmax = fxs + a.far_cap;                  // [2][waves]: the wavefronts' largest relative change, by update parity
-    uint32_t* const sctl = reinterpret_cast<uint32_t*>(wmax + 2 * (kSweepBlock / kWave));     // [0] stop, [1] abort (heads), [2..3] block saw a change > tol (by step parity), [4..5] abort (phases, by step parity)
+    uint32_t* const sctl = reinterpret_cast<uint32_t*>(wmax + 2 * kPWaves);     // [0] stop, [1] abort (heads), [2..3] block saw a change > tol (by step parity), [4..5] abort (phases, by step parity)
     uint32_t* const hprev = sctl + 8;                      // [4][kShards] the counters' high words at wave 0's last visit
 #ifdef SFGPU_P_STAMP
     unsigned long long* const pst = reinterpret_cast<unsigned long long*>(sctl + 8 + 4 * kShards);       // [0..6] phase sums, [7] the last stamp
@@ -266,7 +280,7 @@ k_em_persist(PersistArgs a) {
     uint32_t lo, nc, np, nm, n_esc, nf, off, nb_n, nb_before, n_ov, delta[kNbMax];
     const uint4* __restrict__ c8p; const uint32_t* __restrict__ ovcp; const uint4* __restrict__ ov8p; const uint32_t* __restrict__ cnt;
     const uint4* __restrict__ pure; const uint16_t* __restrict__ slot0_p;
-    uint32_t flags;
+    uint32_t flags[kPS];
     // ---- what a thread keeps for the whole run: which of the overlapping tiles hold the position of its window slot (bits 0..5), whether
     //      it has a slot (bit 30) and whether this tile is the position's home (bit 31).  Everything else it needs per step (effLen,
     //      alpha, the far slots that feed it) is read again every step: registers are what this kernel is short of (64 per thread at
@@ -276,17 +290,23 @@ k_em_persist(PersistArgs a) {
         lo = t.lo; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before; n_ov = t.n_ov;
         c8p = a.cls8 + t.c0; ovcp = a.ovc + t.ov0; ov8p = a.ov8 + t.ov0; cnt = a.counts + t.c0;
         pure = reinterpret_cast<const uint4*>(a.csc + t.qb); slot0_p = a.csc_slot0 + t.pr;
-        const uint32_t span = t.span, pos0 = lo + tid0;
-        flags = tid0 < span ? 0x40000000u : 0u;
-        bool home = tid0 < span;
+        const uint32_t span = t.span;
+        bool home[kPS];
+#pragma unroll
+        for (int q = 0; q < kPS; ++q) { home[q] = tid0 + q * kPB < span; flags[q] = home[q] ? 0x40000000u : 0u; }
 #pragma unroll
         for (int j = 0; j < kNbMax; ++j) {
             const uint4 e = t.e[j];                                      // {lo', span', off', tile'}
             delta[j] = e.z - e.x;                                        // the slot of position p in that tile's piece: p + delta
-            const bool in = tid0 < span && (uint32_t)j < nb_n && (pos0 - e.x) < e.y;
-            if (in) { flags |= 1u << j; if ((uint32_t)j < nb_before) home = false; }
+#pragma unroll
+            for (int q = 0; q < kPS; ++q) {
+                const uint32_t sidx = tid0 + q * kPB;
+                const bool in = sidx < span && (uint32_t)j < nb_n && (lo + sidx - e.x) < e.y;
+                if (in) { flags[q] |= 1u << j; if ((uint32_t)j < nb_before) home[q] = false; }
+            }
         }
-        if (home) flags |= 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < kPS; ++q) if (home[q]) flags[q] |= 0x80000000u;
     }
     const double* __restrict__ lenc = a.lenc + lo; double* __restrict__ alpha = a.alpha + lo;
     const uint2* __restrict__ ftgt = a.ftgt ? a.ftgt + lo : nullptr;
@@ -330,7 +350,8 @@ k_em_persist(PersistArgs a) {
         return false;
     };
     if (tid0 < 8u + 4u * kShards) sctl[tid0] = 0u;                       // (and hprev)
-    acc[tid0] = 0.0;
+#pragma unroll
+    for (int q = 0; q < kPS; ++q) acc[tid0 + q * kPB] = 0.0;
 
     auto x_of = [&](double ap_, double l) -> double {
         if (VB) return (ap_ > kTiny) ? sweep_x<true>(vb_x_fast(ap_, a.log_norm, l)) : 0.0;       // :300-320
@@ -362,34 +383,45 @@ k_em_persist(PersistArgs a) {
         if (tid == 0u) { SFP_COLD(cq); __hip_atomic_store(&cq->dbg[blockIdx.x], (unsigned long long)s + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
         // ================= head of step s: [the stop test of update s - 1] update s, x of sweep s =================
-        const bool has = (flags & 0x40000000u) != 0u, home = (flags & 0x80000000u) != 0u;
-        double ap_v = 0.0, xv = 0.0, lm = -1.0; unsigned ncv = 0u;
+        bool has[kPS], home[kPS];
+#pragma unroll
+        for (int q = 0; q < kPS; ++q) { has[q] = (flags[q] & 0x40000000u) != 0u; home[q] = (flags[q] & 0x80000000u) != 0u; }
+        double ap_v[kPS], xv[kPS];
+#pragma unroll
+        for (int q = 0; q < kPS; ++q) { ap_v[q] = 0.0; xv[q] = 0.0; }
+        double lm = -1.0; unsigned ncv = 0u;
         // phase A's stream chunks and phase B's class counts: requested in the head once the operands are in (they miss the L2 -- a tile's
         // stream is read once per step and 64 tiles share 4 MB --, and the x arithmetic and the head's barrier hide the round trip);
-        // phase C's first chunk is requested at the start of phase A
-        uint4 c8[kCntAhead];                                               // the thread's first class chunks (a chunk per class: see k_cls8_build)
-        uint32_t cw[kCntAhead];                                             // ... and their counts; bit 31: singleton class
+        // phase C's first chunks are requested at the start of phase A
+        uint4 c8[kPAhead];                                                 // the thread's first class chunks (a chunk per class: see k_cls8_build)
+        uint32_t cw[kPAhead];                                               // ... and their counts; bit 31: singleton class, bit 30: long
         auto request_stream = [&]() {
 #pragma unroll
-            for (int i = 0; i < kCntAhead; ++i) {
-                const uint32_t c = tid + i * kSweepBlock;
+            for (int i = 0; i < kPAhead; ++i) {
+                const uint32_t c = tid + i * kPB;
                 c8[i] = make_uint4(0u, 0u, 0u, 0u); cw[i] = 0u;
                 if (c < nc) { c8[i] = c8p[SFP_IX(c)]; cw[i] = cnt[SFP_IX(c)]; }
             }
         };
         if (s > 0u) {
             const uint32_t rd_off = (s & 1u) ? a.part_off[1] : a.part_off[0];       // sums of sweep s - 1 carry tag s
-            const uint32_t pos = lo + tid;
-            gr4 gq[3];
+            const uint32_t pos = lo + tid;                                   // (slot q of the thread: position pos + q * kPB)
+            gr4 gq[kPS][3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                gq[j] = gr4{0u, s, 0u, s};
-                if (flags & (1u << j)) gq[j] = gr_load(rd_off, pos + delta[j]);
+            for (int q = 0; q < kPS; ++q)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    gq[q][j] = gr4{0u, s, 0u, s};
+                    if (flags[q] & (1u << j)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[j]);
+                }
+            double len[kPS], av[kPS], own[kPS]; uint2 ft[kPS];
+#pragma unroll
+            for (int q = 0; q < kPS; ++q) {
+                len[q] = 1.0; av[q] = 0.0; ft[q] = make_uint2(0u, 0u);
+                if (has[q]) { len[q] = lenc[tid + q * kPB]; if (ftgt) ft[q] = ftgt[tid + q * kPB]; }
+                if (home[q]) av[q] = alpha[tid + q * kPB];
+                own[q] = acc[tid + q * kPB];                               // what this tile's last sweep handed the slot (cleared below)
             }
-            double len = 1.0, av = 0.0; uint2 ft = make_uint2(0u, 0u);
-            if (has) { len = lenc[tid]; if (ftgt) ft = ftgt[tid]; }
-            if (home) av = alpha[tid];
-            const double own = acc[tid];                                  // what this tile's last sweep handed the slot (cleared below)
             // wave 0: has every tile finished update s - 1, and did the loop end there?  (:820)
             if (wave == 0u && s >= 2u) {
                 const uint32_t u = s - 1u;
@@ -415,87 +447,107 @@ k_em_persist(PersistArgs a) {
                 const uint32_t u = s - 1u;                                    // (u = 0: nothing to wait for)
                 sctl[0] = (u >= a.min_iter && u >= a.max_iter) ? 1u : 0u;
             }
-            if (has) {
-                // the far slots that feed this transcript, in tile order: what alphaOut held in the other loops
-                if (ft.y > ft.x) {
+            // the far slots that feed a transcript, in tile order: what alphaOut held in the other loops
+#pragma unroll
+            for (int q = 0; q < kPS; ++q) {
+                if (has[q] && ft[q].y > ft[q].x) {
                     SFP_COLD(cp);
                     const uint32_t frd_off = (s & 1u) ? cp->far_off[1] : cp->far_off[0];
-                    for (uint32_t k = ft.x; k < ft.y; ++k) {
+                    for (uint32_t k = ft[q].x; k < ft[q].y; ++k) {
                         const uint32_t g = cp->ft_list[k];
-                        gr4 q = gr_load(frd_off, g);
+                        gr4 w = gr_load(frd_off, g);
                         SFP_WHY(3u);
-                        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(q, s);) { if (spin_check(spins, 1u)) break; q = gr_load(frd_off, g); }
-                        ap_v += gr_value(q);
+                        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(w, s);) { if (spin_check(spins, 1u)) break; w = gr_load(frd_off, g); }
+                        ap_v[q] += gr_value(w);
                     }
                 }
-                // the overlapping tiles' sums, in tile order with this tile's own in its place (as the cover list); three at a time
-                auto wait3 = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t fsh) {
-                    if (a.ablate == 1) return;
-                    SFP_WHY(2u);
-                    for (uint32_t spins = 0;;) {
-                        const bool ok = gr_ok(gq[0], s) && gr_ok(gq[1], s) && gr_ok(gq[2], s);
-                        if (ok || spin_check(spins, 1u)) break;
-                        if (((flags >> fsh) & 1u) && !gr_ok(gq[0], s)) gq[0] = gr_load(rd_off, pos + d0);
-                        if (((flags >> fsh) & 2u) && !gr_ok(gq[1], s)) gq[1] = gr_load(rd_off, pos + d1);
-                        if (((flags >> fsh) & 4u) && !gr_ok(gq[2], s)) gq[2] = gr_load(rd_off, pos + d2);
-                    }
-                };
-                wait3(delta[0], delta[1], delta[2], 0u);
+            }
+            // the overlapping tiles' sums, in tile order with this tile's own in its place (as the cover list); three at a time
+            // (a slot the thread does not have, or a tile that does not hold it, keeps the preset granule: its tag is right)
+            auto wait3 = [&](uint32_t first) {
+                if (a.ablate == 1) return;
+                SFP_WHY(2u);
+                for (uint32_t spins = 0;;) {
+                    bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { if ((uint32_t)j == nb_before) ap_v += own; if (flags & (1u << j)) ap_v += gr_value(gq[j]); }
-                if (nb_n > 3u) {                                          // (block-uniform; most tiles overlap two or three others)
+                    for (int q = 0; q < kPS; ++q) ok = ok && gr_ok(gq[q][0], s) && gr_ok(gq[q][1], s) && gr_ok(gq[q][2], s);
+                    if (ok || spin_check(spins, 1u)) break;
+#pragma unroll
+                    for (int q = 0; q < kPS; ++q)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            if (((flags[q] >> (first + j)) & 1u) && !gr_ok(gq[q][j], s)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[first + j]);
+                }
+            };
+            wait3(0u);
+#pragma unroll
+            for (int q = 0; q < kPS; ++q)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { if ((uint32_t)j == nb_before) ap_v[q] += own[q]; if (flags[q] & (1u << j)) ap_v[q] += gr_value(gq[q][j]); }
+            if (nb_n > 3u) {                                              // (block-uniform; most tiles overlap two or three others)
+#pragma unroll
+                for (int q = 0; q < kPS; ++q)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        gq[j] = gr4{0u, s, 0u, s};
-                        if (flags & (8u << j)) gq[j] = gr_load(rd_off, pos + delta[3 + j]);
+                        gq[q][j] = gr4{0u, s, 0u, s};
+                        if (flags[q] & (8u << j)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[3 + j]);
                     }
-                    wait3(delta[3], delta[4], delta[5], 3u);
+                wait3(3u);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { if ((uint32_t)(3 + j) == nb_before) ap_v += own; if (flags & (8u << j)) ap_v += gr_value(gq[j]); }
-                    if (nb_before >= 6u) ap_v += own;
-                } else if (nb_before >= 3u) ap_v += own;
-                SFP_STAMP(0);                                             // operands here
+                for (int q = 0; q < kPS; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { if ((uint32_t)(3 + j) == nb_before) ap_v[q] += own[q]; if (flags[q] & (8u << j)) ap_v[q] += gr_value(gq[q][j]); }
+                    if (nb_before >= 6u) ap_v[q] += own[q];
+                }
+            } else if (nb_before >= 3u) {
+#pragma unroll
+                for (int q = 0; q < kPS; ++q) ap_v[q] += own[q];
+            }
+            SFP_STAMP(0);                                                 // operands here
 #ifndef SFGPU_P_EARLY
-                request_stream();
+            request_stream();
 #endif
-                if (VB) ap_v += kPriorAlpha;
-                xv = x_of(ap_v, len);
-                if (home) {
-                    const double gate = a.check_mode ? av : ap_v;         // :852 vs :499
+#pragma unroll
+            for (int q = 0; q < kPS; ++q) {
+                if (!has[q]) continue;
+                if (VB) ap_v[q] += kPriorAlpha;
+                xv[q] = x_of(ap_v[q], len[q]);
+                if (home[q]) {
+                    const double gate = a.check_mode ? av[q] : ap_v[q];   // :852 vs :499
                     if (gate > kCheckCutoff) {
-                        const double rel = fabs(av - ap_v) / ap_v;
+                        const double rel = fabs(av[q] - ap_v[q]) / ap_v[q];
                         if (rel > lm) lm = rel;                            // NaN never wins, as in the reference (:854)
                         if (rel > a.tol) ncv = 1u;
                         if (lm < 0.0) lm = 0.0;                            // gated at least once
                     }
-                    if (ft.y > ft.x) { SFP_COLD(cp); gr_store(cp->xpub_off, ft.x, xv, s); }      // a far target: its x for the tiles that hold it as a far member
+                    if (ft[q].y > ft[q].x) { SFP_COLD(cp); gr_store(cp->xpub_off, ft[q].x, xv[q], s); }      // a far target: its x for the tiles that hold it as a far member
                 }
             }
-#ifndef SFGPU_P_EARLY
-            else request_stream();
-#endif
             // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
             for (int o = kWave / 2; o > 0; o >>= 1) { const double m = __shfl_down(lm, o, kWave); if (m > lm) lm = m; }
-            if (lane == 0u) wmax[(s & 1u) * (kSweepBlock / kWave) + wave] = lm;
+            if (lane == 0u) wmax[(s & 1u) * kPWaves + wave] = lm;
             if (__any(ncv != 0u) && lane == 0u) sctl[2u + (s & 1u)] = 1u;
         } else {
 #ifndef SFGPU_P_EARLY
             request_stream();
 #endif
-            if (has) { SFP_COLD(cp); const uint32_t* inv = cp->inv; const uint32_t p = lo + tid; xv = cp->x[inv ? inv[p] : p]; }
+#pragma unroll
+            for (int q = 0; q < kPS; ++q)
+                if (has[q]) { SFP_COLD(cp); const uint32_t* inv = cp->inv; const uint32_t p = lo + tid + q * kPB; xv[q] = cp->x[inv ? inv[p] : p]; }
         }
         if (a.ablate == 3 && s == 2u && blockIdx.x == 0u && tid == 0u) {      // tests: tile 0 gives up here -- every tile must leave, the host repeats the run
             __hip_atomic_store(&ctl[kCtlAbort * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sctl[1] = 1u;
         }
-        for (uint32_t i = tid; i < nc; i += kSweepBlock) den[i] = 0.0;
+        for (uint32_t i = tid; i < nc; i += kPB) den[i] = 0.0;
         if (nf) {                                                         // far members: the x of every far slot's transcript, once per step
             SFP_COLD(cp); SFP_TILE(tp);
             const uint32_t f0 = tp->f0;
-            for (uint32_t f = tid; f < nf; f += kSweepBlock) { fxs[f] = far_x(cp, f0, f, s, 1u); facc[f] = 0.0; }
+            for (uint32_t f = tid; f < nf; f += kPB) { fxs[f] = far_x(cp, f0, f, s, 1u); facc[f] = 0.0; }
         }
         if (tid == 0u) { xs[kWin] = 0.0; acc[kWin] = 0.0; den[a.den_cap] = 0.0; }      // (den_cap: the plan's null class)
-        if (has) { xs[tid] = xv; acc[tid] = 0.0; }
+#pragma unroll
+        for (int q = 0; q < kPS; ++q) if (has[q]) { xs[tid + q * kPB] = xv[q]; acc[tid + q * kPB] = 0.0; }
         SFP_STAMP(1);                                                     // x, the update, LDS cleared
         __syncthreads();
         SFP_STAMP(2);                                                     // head barrier
@@ -504,7 +556,8 @@ k_em_persist(PersistArgs a) {
             const uint32_t sv = sctl[0];
             if (sv != 0u) { k_done = s - 1u; conv_last = (sv & 2u) != 0u; break; }
             // update s is final: alpha <- alpha' (home), and the block's word on it
-            if (home) alpha[tid] = ap_v;
+#pragma unroll
+            for (int q = 0; q < kPS; ++q) if (home[q]) alpha[tid + q * kPB] = ap_v[q];
             if (tid == 0u) {
                 const uint32_t shard = blockIdx.x & (kShards - 1u);
                 unsigned long long inc = 1ull;
@@ -513,9 +566,12 @@ k_em_persist(PersistArgs a) {
             }
         }
         // ================= A: denominators =================
-        uint4 pc_e0 = make_uint4(0u, 0u, 0u, 0u), pc_e1 = pc_e0; uint32_t pc_s0 = 0u, pc_s1 = 0u;
+        uint4 pc_e[kPCAhead]; uint32_t pc_s[kPCAhead];                   // phase C's first chunks: half of them requested here, half at the end of A
         {
-            if (tid < np) { pc_e0 = pure[SFP_IX(tid)]; pc_s0 = slot0_p[SFP_IX(tid)]; }
+#pragma unroll
+            for (int i = 0; i < kPCAhead; ++i) { pc_e[i] = make_uint4(0u, 0u, 0u, 0u); pc_s[i] = 0u; }
+#pragma unroll
+            for (int i = 0; i < kPCAhead / 2; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) { pc_e[i] = pure[SFP_IX(ch)]; pc_s[i] = slot0_p[SFP_IX(ch)]; } }
             auto chunk_sum = [&](const uint4& s4) -> double {                   // eight window slots (bit 15 of the first: the long flag)
                 const double v0 = xs[SFP_BANK(s4.x & 0x7FFFu, 0)], v1 = xs[SFP_BANK(s4.x >> 16, 1)], v2 = xs[SFP_BANK(s4.y & 0xFFFFu, 2)], v3 = xs[SFP_BANK(s4.y >> 16, 3)];
                 const double v4 = xs[SFP_BANK(s4.z & 0xFFFFu, 4)], v5 = xs[SFP_BANK(s4.z >> 16, 5)], v6 = xs[SFP_BANK(s4.w & 0xFFFFu, 6)], v7 = xs[SFP_BANK(s4.w >> 16, 7)];
@@ -530,20 +586,21 @@ k_em_persist(PersistArgs a) {
                 }
             };
 #pragma unroll
-            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) class_chunk(c, c8[i], cw[i]); }
-            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) class_chunk(c, c8p[SFP_IX(c)], cnt[SFP_IX(c)]);
-            for (uint32_t j = tid; j < n_ov; j += kSweepBlock) atomicAdd(&den[ovcp[j]], chunk_sum(ov8p[j]));
+            for (int i = 0; i < kPAhead; ++i) { const uint32_t c = tid + i * kPB; if (c < nc) class_chunk(c, c8[i], cw[i]); }
+            for (uint32_t c = tid + kPAhead * kPB; c < nc; c += kPB) class_chunk(c, c8p[SFP_IX(c)], cnt[SFP_IX(c)]);
+            for (uint32_t j = tid; j < n_ov; j += kPB) atomicAdd(&den[ovcp[j]], chunk_sum(ov8p[j]));
             // far members (few tiles have any): class and far slot from the plan, x from the LDS copy the head made
             if (n_esc) {
                 SFP_COLD(cp); SFP_TILE(tp);
                 const uint64_t e0 = tp->e0;
-                for (uint32_t i = tid; i < n_esc; i += kSweepBlock) {
+                for (uint32_t i = tid; i < n_esc; i += kPB) {
                     const uint32_t tag = cp->esc_cls[e0 + i], f = cp->esc_far[e0 + i];
                     const double v = (tag & kSingle) ? 0.0 : fxs[f];
                     if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
                 }
             }
-            if (tid + kSweepBlock < np) { pc_e1 = pure[SFP_IX(tid + kSweepBlock)]; pc_s1 = slot0_p[SFP_IX(tid + kSweepBlock)]; }
+#pragma unroll
+            for (int i = kPCAhead / 2; i < kPCAhead; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) { pc_e[i] = pure[SFP_IX(ch)]; pc_s[i] = slot0_p[SFP_IX(ch)]; } }
         }
         __syncthreads();
         SFP_STAMP(3);                                                     // phase A + its barrier
@@ -556,8 +613,8 @@ k_em_persist(PersistArgs a) {
                 den[c] = (cwc >> 31) ? cn : ((d > kTiny) ? cn / d : 0.0);
             };
 #pragma unroll
-            for (int i = 0; i < kCntAhead; ++i) { const uint32_t c = tid + i * kSweepBlock; if (c < nc) invert(c, cw[i]); }
-            for (uint32_t c = tid + kCntAhead * kSweepBlock; c < nc; c += kSweepBlock) invert(c, cnt[SFP_IX(c)]);
+            for (int i = 0; i < kPAhead; ++i) { const uint32_t c = tid + i * kPB; if (c < nc) invert(c, cw[i]); }
+            for (uint32_t c = tid + kPAhead * kPB; c < nc; c += kPB) invert(c, cnt[SFP_IX(c)]);
         }
         __syncthreads();
         SFP_STAMP(4);                                                     // phase B + its barrier
@@ -571,11 +628,11 @@ k_em_persist(PersistArgs a) {
                 const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;
                 if (v != 0.0) atomicAdd(&acc[slot], v);
             };
-            if (tid < np) pure_chunk(pc_e0, pc_s0);
-            if (tid + kSweepBlock < np) pure_chunk(pc_e1, pc_s1);
-            for (uint32_t ch = tid + 2u * kSweepBlock; ch < np; ch += kSweepBlock) pure_chunk(pure[SFP_IX(ch)], slot0_p[SFP_IX(ch)]);
+#pragma unroll
+            for (int i = 0; i < kPCAhead; ++i) if (tid + i * kPB < np) pure_chunk(pc_e[i], pc_s[i]);
+            for (uint32_t ch = tid + kPCAhead * kPB; ch < np; ch += kPB) pure_chunk(pure[SFP_IX(ch)], slot0_p[SFP_IX(ch)]);
             const uint4* __restrict__ mixed = pure + np;
-            for (uint32_t ch = tid; ch < nm; ch += kSweepBlock) {
+            for (uint32_t ch = tid; ch < nm; ch += kPB) {
                 const uint4 e4 = mixed[2u * ch], s4 = mixed[2u * ch + 1u];
                 uint32_t cur = s4.x & 0xFFFFu;
                 double sum = 0.0;
@@ -595,7 +652,7 @@ k_em_persist(PersistArgs a) {
             if (n_esc) {                                                     // far members: into the tile's far slots
                 SFP_COLD(cp); SFP_TILE(tp);
                 const uint64_t e0 = tp->e0;
-                for (uint32_t i = tid; i < n_esc; i += kSweepBlock) {
+                for (uint32_t i = tid; i < n_esc; i += kPB) {
                     const uint32_t tag = cp->esc_cls[e0 + i], f = cp->esc_far[e0 + i];
                     const double q = den[(tag >> 16) & 0x1FFFu];
                     const double contrib = (tag & kSingle) ? q : fxs[f] * q;
@@ -606,11 +663,12 @@ k_em_persist(PersistArgs a) {
         __syncthreads();
         SFP_STAMP(5);                                                     // phase C + its barrier
         // ================= D: publish the window and the far slots: granules with tag s + 1 =================
-        if (has) gr_store((s & 1u) ? a.part_off[0] : a.part_off[1], off + tid, acc[tid], s + 1u);
+#pragma unroll
+        for (int q = 0; q < kPS; ++q) if (has[q]) gr_store((s & 1u) ? a.part_off[0] : a.part_off[1], off + tid + q * kPB, acc[tid + q * kPB], s + 1u);
         if (nf) {
             SFP_COLD(cp); SFP_TILE(tp);
             const uint32_t fo = (s & 1u) ? cp->far_off[0] : cp->far_off[1], f0 = tp->f0;
-            for (uint32_t f = tid; f < nf; f += kSweepBlock) gr_store(fo, f0 + f, facc[f], s + 1u);
+            for (uint32_t f = tid; f < nf; f += kPB) gr_store(fo, f0 + f, facc[f], s + 1u);
         }
         SFP_STAMP(6);                                                     // phase D (stores drained)
         // (no barrier here: what the next head clears or writes before its own barrier -- xs[tid], acc[tid], den, facc[f] -- was last read
@@ -625,11 +683,14 @@ k_em_persist(PersistArgs a) {
 #endif
     if (k_done == 0xFFFFFFFFu) { if (tid == 0u) *cp->status = 1u; return; }
     if (k_done > 0u) {
-        if (lane == 0u) cp->tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + wave] = wmax[(k_done & 1u) * (kSweepBlock / kWave) + wave];
+        // (the table has a row of kSweepBlock / kWave entries per tile, as the other loops fill it: a wavefront writes its maximum into every
+        //  kPWaves-th of them)
+        if (lane == 0u) for (uint32_t w2 = wave; w2 < (uint32_t)(kSweepBlock / kWave); w2 += kPWaves)
+            cp->tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + w2] = wmax[(k_done & 1u) * kPWaves + wave];
         // positions no window holds are inactive transcripts here (a plan with far-only transcripts does not run persistent):
         // every update leaves them at the prior (VBEM, :318) or at 0
         const uint32_t n_unc = *cp->unc_n;
-        for (uint32_t j = tid * gridDim.x + blockIdx.x; j < n_unc; j += kSweepBlock * gridDim.x) a.alpha[cp->unc[j]] = VB ? kPriorAlpha : 0.0;
+        for (uint32_t j = tid * gridDim.x + blockIdx.x; j < n_unc; j += kPB * gridDim.x) a.alpha[cp->unc[j]] = VB ? kPriorAlpha : 0.0;
     }
     if (blockIdx.x == 0u && tid == 0u) {
         EmState* st = cp->st;
