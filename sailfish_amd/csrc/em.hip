@@ -1653,7 +1653,7 @@ struct sfgpu_em {
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
-    uint32_t far_cap = 0;
+    uint32_t far_cap = 0, esc_ln = 0;                       // LDS of the persistent loop: far slots of a tile at most; far members of a tile kept on chip
     bool persist = false;                                   // this optimize() runs as one launch
     bool no_persist = false;                                // set while several bootstrap lanes run (see sfgpu_bootstrap)
     int sharded_fused = 0;                                  // sfgpu_em_set_sharded_fused: the sharded loop runs one sweep kernel per iteration (every rank agreed)
@@ -1918,8 +1918,8 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
     if (off || 2 * P * 16ull + 3 * E * 16ull >= (1ull << 31)) return SFGPU_OK;                  // (granules are addressed with 32-bit byte offsets)
     const uint64_t M = em->prob.M;
     hipStream_t st = em->cur;
-    SF_HIP(pool_malloc(&em->pflags, 8));
-    SF_HIP(hipMemsetAsync(em->pflags, 0, 8, st));
+    SF_HIP(pool_malloc(&em->pflags, 16));
+    SF_HIP(hipMemsetAsync(em->pflags, 0, 16, st));
     const uint64_t En = E ? E : 1;
     if (E) {
         uint64_t *k_in = nullptr, *k_out = nullptr, *k2_in = nullptr, *k2_out = nullptr, *gsum = nullptr;
@@ -1987,8 +1987,8 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
     for (hipEvent_t& e : em->ev_poll) EM_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     EM_TRY(pinned_malloc(&em->h_mirror, 128));
     memset(em->h_mirror, 0, 128);
-    EM_TRY(pinned_malloc(&em->h_plan, 64));
-    memset(em->h_plan, 0, 64);
+    EM_TRY(pinned_malloc(&em->h_plan, 128));
+    memset(em->h_plan, 0, 128);
     EM_TRY(pool_malloc(&em->alpha, M * 8)); EM_TRY(pool_malloc(&em->alpha_out, M * 8));
     EM_TRY(pool_malloc(&em->x, M * 8)); EM_TRY(pool_malloc(&em->lenc, M * 8)); EM_TRY(pool_malloc(&em->scratch, M * 8));
     EM_TRY(pool_malloc(&em->partials, kMaxPartials * 8)); EM_TRY(pool_malloc(&em->sum_partials, kMaxPartials * 8));
@@ -2253,7 +2253,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
                 if (pr) { em_free(em); return pr; }
             }
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
-            if (em->pflags) EM_TRY(hipMemcpyAsync(em->h_plan + 6, em->pflags, 8, hipMemcpyDeviceToHost, em->cur));
+            if (em->pflags) EM_TRY(hipMemcpyAsync(em->h_plan + 8, em->pflags, 16, hipMemcpyDeviceToHost, em->cur));
             EM_TRY(hipEventRecord(em->ev_plan, em->cur));
             if (env_timing()) {                     // dev: how many tiles go by the cover list, how many neighbours the others have
                 std::vector<TileDesc> h(nt);
@@ -2566,7 +2566,12 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
 
 // ---- the persistent loop (em_persist.h): eligibility, and the launch ----
 static std::mutex g_persist_mu[16];          // per device: two persistent launches of this process never share the chip (each needs ALL its blocks resident)
-static size_t em_persist_lds(const sfgpu_em* em) { return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + 2 * (size_t)em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32 + 4 * kShards * 4 + 64; }
+// xs | acc | den | facc | fxs | wmax | sctl, hprev | far_xi_l | ftg_l | esc_l | (dev stamps)
+static size_t em_persist_lds_base(const sfgpu_em* em) {
+    return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + 2 * (size_t)em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32 + 4 * kShards * 4
+           + ((size_t)em->far_cap + (em->ftgt ? (size_t)kWin : 0) + 1) * 4;
+}
+static size_t em_persist_lds(const sfgpu_em* em) { return em_persist_lds_base(em) + (size_t)em->esc_ln * 8 + 64; }
 static const void* em_persist_func(bool vb) {
     return vb ? reinterpret_cast<const void*>(&k_em_persist<true>) : reinterpret_cast<const void*>(&k_em_persist<false>);
 }
@@ -2577,13 +2582,18 @@ static void em_persist_check(sfgpu_em* em) {
     auto no = [&](const char* why) { if (say) fprintf(stderr, "em persistent: not eligible -- %s\n", why); };
     if (!em->xbuf || !em->pflags || !em->partial_a) return no("no tables (SFGPU_EM_PERSIST=0 at create, or the exchange buffer would pass 2 GB)");
     if (hipEventSynchronize(em->ev_plan) != hipSuccess) return no("plan event");
-    const uint32_t* pf = reinterpret_cast<const uint32_t*>(em->h_plan + 6);
+    const uint32_t* pf = reinterpret_cast<const uint32_t*>(em->h_plan + 8);
     if (pf[0] & 2u) return no("a far member's transcript lies in no window (no home thread)");
     if (pf[0] & 4u) return no("a transcript is fed by more far slots than its home thread should walk");
     if (pf[0] & 8u) return no("a class of 2^30 reads or more (bit 30 of the loop's count words is a flag)");
     if ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 1u) != 0u) return no("a tile that more than kNbMax tiles overlap (it goes by the cover list)");
     em->far_cap = pf[1];
     constexpr size_t kLdsPerBlock = 81920;                   // half a CU's LDS: two blocks per CU, like the sweep
+    {   // the tiles' far members on chip: all of the plan's largest list, or what is left of the block's LDS
+        const size_t base = em_persist_lds_base(em) + 64;
+        const size_t room = base < kLdsPerBlock ? (kLdsPerBlock - base) / 8 : 0;
+        em->esc_ln = (uint32_t)std::min<size_t>(pf[2], room);
+    }
     const size_t lds = em_persist_lds(em);
     if (lds > kLdsPerBlock) return no("the tile's classes + far slots do not fit the LDS");
     int dev = 0, n_cu = 0;
@@ -2608,7 +2618,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     a.xbuf = q; a.xbuf_bytes = (uint32_t)em->xbuf_bytes;
     size_t o = up((size_t)kCtlWords * 8 + 64 + sizeof(PersistCold));
     a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
-    c.far_off[0] = (uint32_t)o; o += up(En * 16); c.far_off[1] = (uint32_t)o; o += up(En * 16); c.xpub_off = (uint32_t)o;
+    a.far_off0 = (uint32_t)o; a.far_stride = (uint32_t)up(En * 16);         // (far slots by parity, then the far targets' x)
     a.tiles = em->td; c.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
     a.cls8 = em->cls8; a.ovc = em->ovc; a.ov8 = em->ov8; a.counts = em->cnt8; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
     c.x = em->x; c.inv = em->inv;
@@ -2616,7 +2626,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     c.esc_cls = em->esc_cls; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;
     c.unc = em->unc; c.unc_n = em->unc + em->prob.M;
     c.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
-    a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.ablate = ablate;
+    a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.esc_ln = em->esc_ln; a.ablate = ablate;
 #if defined(SFGPU_P_STAMP) || defined(SFGPU_P_PROGRESS)
     if (!em->dbg) SF_HIP(pool_malloc(&em->dbg, (size_t)em->n_tiles * 16 * 8));
     SF_HIP(hipMemsetAsync(em->dbg, 0, (size_t)em->n_tiles * 16 * 8, em->cur));
@@ -2861,6 +2871,21 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
             fprintf(stderr, " %s %.2f/%.2f/%.2f", nm[k], sum / em->n_tiles, mn, mx);
         }
         fprintf(stderr, "\n");
+        // the tiles that wait least for their operands set the pace: what are they made of?
+        std::vector<TileDesc> htd(em->n_tiles);
+        (void)hipMemcpy(htd.data(), em->td, htd.size() * sizeof(TileDesc), hipMemcpyDeviceToHost);
+        std::vector<uint32_t> order(em->n_tiles);
+        for (uint32_t b = 0; b < em->n_tiles; ++b) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h[x * 8] < h[y * 8]; });
+        double mean_nc = 0, mean_np = 0, mean_nm = 0, mean_ov = 0;
+        for (const TileDesc& t : htd) { mean_nc += t.nc; mean_np += t.np; mean_nm += t.nm; mean_ov += t.n_ov; }
+        fprintf(stderr, "  tile means: classes %.0f, pure chunks %.0f, mixed chunks %.0f, overflow chunks %.0f\n", mean_nc / em->n_tiles, mean_np / em->n_tiles, mean_nm / em->n_tiles, mean_ov / em->n_tiles);
+        for (uint32_t i = 0; i < 6 && i < em->n_tiles; ++i) {
+            const uint32_t b = order[i]; const TileDesc& t = htd[b];
+            fprintf(stderr, "  tile %4u:", b);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.2f", nm[k], (double)h[b * 8 + k] * 0.01 / steps);
+            fprintf(stderr, " | span %u classes %u pure %u mixed %u overflow %u far members %u far slots %u neighbours %u\n", t.span, t.nc, t.np, t.nm, t.n_ov, t.n_esc, t.nf, t.nb_n);
+        }
     }
 #endif
 #ifdef SFGPU_X_STAMP

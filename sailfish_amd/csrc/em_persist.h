@@ -90,6 +90,7 @@ __global__ void k_far_tiles(uint32_t n_tiles, uint64_t E, const uint64_t* __rest
     const uint32_t a = first_of(T), b = first_of((uint64_t)T + 1u);
     td[T].f0 = a; td[T].nf = b - a;
     atomicMax(&pflags[1], b - a);
+    atomicMax(&pflags[2], td[T].n_esc);                                  // (sizes the LDS copy of the tiles' far members)
 }
 __global__ void __launch_bounds__(kEmBlock)
 k_far_local(const TileDesc* __restrict__ td, const uint32_t* __restrict__ esc_g, uint32_t* esc_far) {
@@ -191,7 +192,6 @@ struct PersistCold {
     const uint32_t* esc_cls; const uint32_t* esc_far;     // per escape: class << 16 | single ; far slot in the tile
     const uint32_t* far_pos; const uint32_t* far_xi;      // per far slot (TileDesc::f0 + f): target position ; index of its x granule
     const uint32_t* ft_list;                              // the far slots that feed a position, in tile order (ranges: PersistArgs::ftgt)
-    uint32_t far_off[2], xpub_off;                        // exchange buffer: granules of the far slots (by tag parity), of the far targets' x
     const uint32_t* unc; const uint32_t* unc_n;           // positions no window holds (inactive transcripts)
     double* tmax; uint32_t* status;                       // status: 0 = ran to the stop, 1 = gave up (see above)
     unsigned long long* dbg;                              // SFGPU_P_STAMP builds: [tile][8] time spent per phase, summed over the steps (10 ns units)
@@ -210,6 +210,8 @@ struct PersistArgs {
     unsigned long long* ctl;                              // kCtlWords control words (zeroed before the launch)
     double tol, log_norm;
     uint32_t den_cap, far_cap;                            // LDS: den[den_cap + 1] (den_cap = the plan's null class), facc[far_cap]
+    uint32_t esc_ln;                                      // LDS: far members of the tile kept on chip (the plan's most, or what fits)
+    uint32_t far_off0, far_stride;                        // exchange buffer: far slots' granules at far_off0 + parity * far_stride, the far targets' x at + 2 * far_stride
     int ablate;                                           // dev: 1 = no tag checks (timing only: wrong results); 3 = tile 0 gives up in step 2, 4 = tile 0 starts 100 us late (tests)
 };
 
@@ -271,8 +273,14 @@ k_em_persist(PersistArgs a) {
     double* const wmax = fxs + a.far_cap;                  // [2][waves]: the wavefronts' largest relative change, by update parity
     uint32_t* const sctl = reinterpret_cast<uint32_t*>(wmax + 2 * kPWaves);     // [0] stop, [1] abort (heads), [2..3] block saw a change > tol (by step parity), [4..5] abort (phases, by step parity)
     uint32_t* const hprev = sctl + 8;                      // [4][kShards] the counters' high words at wave 0's last visit
+    // What the far paths need of the plan, on chip (round 5, second pass): read through the cold block these were two or three DEPENDENT
+    // round trips to memory in the head, in phase A and again in phase C of every step -- in the tiles that have far members, and those
+    // set the pace of all (cfg2's tile 0: x + update 2.8 us against 1.45, C 3.1 against 2.3, tools/r5_pstamp.sh).
+    uint32_t* const far_xi_l = hprev + 4 * kShards;        // [far_cap] per far slot of the tile: index of its transcript's x granule
+    uint32_t* const ftg_l = far_xi_l + a.far_cap;          // [kWin] per window slot: the first far slot that feeds it (plans with far members)
+    uint2* const esc_l = reinterpret_cast<uint2*>(ftg_l + (a.ftgt ? kWin : 0) + ((a.far_cap + (a.ftgt ? kWin : 0)) & 1u));      // [esc_ln] far members: {class << 16 | single, far slot}
 #ifdef SFGPU_P_STAMP
-    unsigned long long* const pst = reinterpret_cast<unsigned long long*>(sctl + 8 + 4 * kShards);       // [0..6] phase sums, [7] the last stamp
+    unsigned long long* const pst = reinterpret_cast<unsigned long long*>(esc_l + a.esc_ln);       // [0..6] phase sums, [7] the last stamp
     if (threadIdx.x == 0) { for (int k = 0; k < 7; ++k) pst[k] = 0ull; pst[7] = wall_clock64(); }
 #endif
     const uint32_t tid0 = threadIdx.x;
@@ -361,12 +369,28 @@ k_em_persist(PersistArgs a) {
     // the granule the transcript's home thread published at the head of its step s
     auto far_x = [&](const PersistCold* cp, uint32_t f0, uint32_t f, uint32_t s, uint32_t word) -> double {
         if (s == 0u) { const uint32_t p = cp->far_pos[f0 + f]; const uint32_t* inv = cp->inv; return cp->x[inv ? inv[p] : p]; }
-        const uint32_t xi = cp->far_xi[f0 + f], xo = cp->xpub_off;
+        const uint32_t xi = far_xi_l[f], xo = a.far_off0 + 2u * a.far_stride;
         gr4 g = gr_load(xo, xi);
         SFP_WHY(4u);
         if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, s);) { if (spin_check(spins, word)) break; g = gr_load(xo, xi); }
         return gr_value(g);
     };
+    {   // the far paths' tables into the LDS, once
+        SFP_COLD(cp); SFP_TILE(tp);
+        if (nf) { const uint32_t f0 = tp->f0; for (uint32_t f = tid0; f < nf; f += kPB) far_xi_l[f] = cp->far_xi[f0 + f]; }
+        if (ftgt) {
+#pragma unroll
+            for (int q = 0; q < kPS; ++q) {
+                const uint32_t sidx = tid0 + q * kPB;
+                if (flags[q] & 0x40000000u) { const uint2 r = ftgt[sidx]; ftg_l[sidx] = r.y > r.x ? cp->ft_list[r.x] : 0u; }
+            }
+        }
+        if (n_esc) {
+            const uint64_t e0 = tp->e0;
+            const uint32_t n = n_esc < a.esc_ln ? n_esc : a.esc_ln;
+            for (uint32_t i = tid0; i < n; i += kPB) esc_l[i] = make_uint2(cp->esc_cls[e0 + i], cp->esc_far[e0 + i]);
+        }
+    }
     if (a.ablate == 4 && blockIdx.x == 0u) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(8); }      // tests: tile 0 starts 100 us late
     __syncthreads();
 
@@ -451,10 +475,10 @@ k_em_persist(PersistArgs a) {
 #pragma unroll
             for (int q = 0; q < kPS; ++q) {
                 if (has[q] && ft[q].y > ft[q].x) {
-                    SFP_COLD(cp);
-                    const uint32_t frd_off = (s & 1u) ? cp->far_off[1] : cp->far_off[0];
+                    const uint32_t frd_off = a.far_off0 + ((s & 1u) ? a.far_stride : 0u);
                     for (uint32_t k = ft[q].x; k < ft[q].y; ++k) {
-                        const uint32_t g = cp->ft_list[k];
+                        uint32_t g = ftg_l[tid + q * kPB];                 // (the first from the LDS: most targets have one)
+                        if (k != ft[q].x) { SFP_COLD(cp); g = cp->ft_list[k]; }
                         gr4 w = gr_load(frd_off, g);
                         SFP_WHY(3u);
                         if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(w, s);) { if (spin_check(spins, 1u)) break; w = gr_load(frd_off, g); }
@@ -520,7 +544,7 @@ k_em_persist(PersistArgs a) {
                         if (rel > a.tol) ncv = 1u;
                         if (lm < 0.0) lm = 0.0;                            // gated at least once
                     }
-                    if (ft[q].y > ft[q].x) { SFP_COLD(cp); gr_store(cp->xpub_off, ft[q].x, xv[q], s); }      // a far target: its x for the tiles that hold it as a far member
+                    if (ft[q].y > ft[q].x) gr_store(a.far_off0 + 2u * a.far_stride, ft[q].x, xv[q], s);      // a far target: its x for the tiles that hold it as a far member
                 }
             }
             // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
@@ -591,10 +615,10 @@ k_em_persist(PersistArgs a) {
             for (uint32_t j = tid; j < n_ov; j += kPB) atomicAdd(&den[ovcp[j]], chunk_sum(ov8p[j]));
             // far members (few tiles have any): class and far slot from the plan, x from the LDS copy the head made
             if (n_esc) {
-                SFP_COLD(cp); SFP_TILE(tp);
-                const uint64_t e0 = tp->e0;
                 for (uint32_t i = tid; i < n_esc; i += kPB) {
-                    const uint32_t tag = cp->esc_cls[e0 + i], f = cp->esc_far[e0 + i];
+                    uint2 e;
+                    if (i < a.esc_ln) e = esc_l[i]; else { SFP_COLD(cp); SFP_TILE(tp); const uint64_t e0 = tp->e0; e = make_uint2(cp->esc_cls[e0 + i], cp->esc_far[e0 + i]); }
+                    const uint32_t tag = e.x, f = e.y;
                     const double v = (tag & kSingle) ? 0.0 : fxs[f];
                     if (v != 0.0) atomicAdd(&den[(tag >> 16) & 0x1FFFu], v);
                 }
@@ -650,10 +674,10 @@ k_em_persist(PersistArgs a) {
                 flush_run();
             }
             if (n_esc) {                                                     // far members: into the tile's far slots
-                SFP_COLD(cp); SFP_TILE(tp);
-                const uint64_t e0 = tp->e0;
                 for (uint32_t i = tid; i < n_esc; i += kPB) {
-                    const uint32_t tag = cp->esc_cls[e0 + i], f = cp->esc_far[e0 + i];
+                    uint2 e;
+                    if (i < a.esc_ln) e = esc_l[i]; else { SFP_COLD(cp); SFP_TILE(tp); const uint64_t e0 = tp->e0; e = make_uint2(cp->esc_cls[e0 + i], cp->esc_far[e0 + i]); }
+                    const uint32_t tag = e.x, f = e.y;
                     const double q = den[(tag >> 16) & 0x1FFFu];
                     const double contrib = (tag & kSingle) ? q : fxs[f] * q;
                     if (contrib != 0.0) atomicAdd(&facc[f], contrib);
@@ -666,8 +690,8 @@ k_em_persist(PersistArgs a) {
 #pragma unroll
         for (int q = 0; q < kPS; ++q) if (has[q]) gr_store((s & 1u) ? a.part_off[0] : a.part_off[1], off + tid + q * kPB, acc[tid + q * kPB], s + 1u);
         if (nf) {
-            SFP_COLD(cp); SFP_TILE(tp);
-            const uint32_t fo = (s & 1u) ? cp->far_off[0] : cp->far_off[1], f0 = tp->f0;
+            SFP_TILE(tp);
+            const uint32_t fo = a.far_off0 + ((s & 1u) ? 0u : a.far_stride), f0 = tp->f0;
             for (uint32_t f = tid; f < nf; f += kPB) gr_store(fo, f0 + f, facc[f], s + 1u);
         }
         SFP_STAMP(6);                                                     // phase D (stores drained)
