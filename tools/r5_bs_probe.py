@@ -20,9 +20,9 @@ for shape in os.environ.get("EMP_SHAPES", "cfg3").split(","):
             p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads)
             p.optimize(use_vbem=True)
             ts = []
-            for n in (1, 6, 6, 12):
+            for n in (1, 6, 6, 12, 24, 48):
                 torch.cuda.synchronize(); t = time.perf_counter()
                 rc, out, it = p.bootstrap(n, seed=1, use_vbem=True)
                 torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3 / n)
-            print(f"{shape} persist {persist} lanes {lanes}: ms per replicate for n = 1, 6, 6, 12: " + " ".join(f"{x:.2f}" for x in ts) + f" | iters {it.mean():.0f}", flush=True)
+            print(f"{shape} persist {persist} lanes {lanes}: ms per replicate for n = 1, 6, 6, 12, 24, 48: " + " ".join(f"{x:.2f}" for x in ts) + f" | iters {it.mean():.0f}", flush=True)
             p.close()
