@@ -93,6 +93,7 @@ constexpr double kBinvMaxMean = SFGPU_BINV_MAX_MEAN;
 #define SFGPU_BINV_SWITCH 168          // (tests/test_sampling_cpu.py builds the header with 8 as well, to walk through the switch)
 #endif
 constexpr uint32_t kBinvSwitch = SFGPU_BINV_SWITCH;
+static_assert(kBinvSwitch >= 8u && kBinvSwitch <= 170u, "the scaled walk holds x! in a double and leaves it four steps before the switch");
 constexpr uint32_t kBinvPowMax = 1024;
 constexpr double binv_unscale(uint32_t n) { double f = 1.0; for (uint32_t i = 2; i <= n; ++i) f *= (double)i; return 1.0 / f; }
 constexpr double kBinvUnscale = binv_unscale(kBinvSwitch - 1u);      // ~ 1 / 167! (U and F get the same factor: its value does not matter, only that neither leaves the range)
