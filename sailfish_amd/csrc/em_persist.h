@@ -362,6 +362,9 @@ k_em_persist(PersistArgs a) {
     for (int q = 0; q < kPS; ++q) acc[tid0 + q * kPB] = 0.0;
 
     auto x_of = [&](double ap_, double l) -> double {
+#ifdef SFGPU_P_VBCHEAP                                                     // dev, timing only: VBEM with EM's x (what the digamma / exp chain of the head costs)
+        if (VB) return (ap_ > kTiny) ? sweep_x<true>(ap_ / (l * a.log_norm)) : 0.0;
+#endif
         if (VB) return (ap_ > kTiny) ? sweep_x<true>(vb_x_fast(ap_, a.log_norm, l)) : 0.0;       // :300-320
         return sweep_x<false>(ap_ / l);
     };
