@@ -135,7 +135,7 @@ int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h
     hipLaunchKernelGGL(k_efflen, dim3((unsigned)((M + kMiscBlock - 1) / kMiscBlock)), dim3(kMiscBlock), 0, st, M,
                        d_ref_len, d_cf, max_frag_len, d_eff_len);
     hipError_t le = hipGetLastError();
-    if (d_cf) { (void)hipStreamSynchronize(st); pool_free(d_cf); }
+    if (d_cf) pool_free_on(d_cf, st);                   // (stream-ordered: no host wait between the class build and the EM's plan; h_cf was consumed by the copy above -- pageable memory is staged before hipMemcpyAsync returns)
     SF_HIP(le);
     return SFGPU_OK;
 }
