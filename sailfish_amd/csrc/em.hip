@@ -501,7 +501,7 @@ k_fill_stream(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ 
 // sums of phase C are formed in the same order on every rank and in every plan.  A nonzero finds its class without a walk
 // per class: a step's 64 consecutive positions meet at most 64 class starts, which the lanes load side by side and search with
 // shuffles.  One pass of ~30 us on cfg3 in place of a key pass, a 3-pass radix sort of all nonzeros and a search per tile (0.4 ms).
-constexpr int kBuildBlock = 512, kBuildWaves = kBuildBlock / kWave, kBuildPerThread = 7;
+constexpr int kBuildBlock = 256, kBuildWaves = kBuildBlock / kWave, kBuildPerThread = 13;      // (round 5: 4 rows of bins = 49 KB, three blocks per CU -- 512 threads and 8 rows were one block per CU, two rounds of tiles at two wavefronts per SIMD)
 constexpr uint32_t kEscBin = 0xC00u, kBuildBins = kEscBin + 1u;          // keys 0..0x3FF, 0x800..0xBFF and the escape bin
 static_assert(kBuildBlock * kBuildPerThread >= (int)kBuildBins, "bins per thread in the column scan");
 static_assert(kWin <= 0x400, "key: 10 bits of window slot under the singleton bit");
