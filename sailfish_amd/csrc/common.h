@@ -33,6 +33,13 @@ hipError_t pinned_malloc(void** p, size_t bytes);
 void pinned_free(void* p);
 template <typename T>
 inline hipError_t pinned_malloc(T** p, size_t bytes) { return pinned_malloc(reinterpret_cast<void**>(p), bytes); }
+// device memory with the UNCACHED memory type (hipExtMallocWithFlags(.., hipDeviceMallocUncached)): no XCD's L2 ever holds a line of
+// it, so what one workgroup stores is what every other workgroup's next load returns -- the exchange buffer of the persistent EM loop
+// (em_persist.h).  Recycled like the other kinds (hipFree synchronises the device).
+hipError_t uncached_malloc(void** p, size_t bytes);
+void uncached_free(void* p);
+template <typename T>
+inline hipError_t uncached_malloc(T** p, size_t bytes) { return uncached_malloc(reinterpret_cast<void**>(p), bytes); }
 hipError_t stream_acquire(hipStream_t* s);
 void stream_release(hipStream_t s);
 

@@ -38,7 +38,7 @@ struct KeyHash { size_t operator()(const Key& k) const { return std::hash<size_t
 std::unordered_map<Key, std::vector<void*>, KeyHash> g_pool_free;   // (device, kind, rounded size) -> free blocks
 std::unordered_map<void*, Key> g_pool_key;                           // live or cached block -> its key
 std::unordered_map<int, std::vector<hipStream_t>> g_streams;         // device -> idle non-blocking streams
-enum { kDeviceMem = 0, kPinnedMem = 1 };
+enum { kDeviceMem = 0, kPinnedMem = 1, kUncachedMem = 2 };      // (uncached: device memory no L2 may hold a line of -- the persistent EM loop's exchange buffer)
 // size classes: powers of two up to 1 GiB; above that eight steps per octave (a 38 GB block is 40 GB, not 64: mapping a block
 // for the first time costs ~15 ms per GB) -- still few distinct keys, so freed blocks keep finding takers
 size_t round_up_pow2(size_t n) {
@@ -80,13 +80,20 @@ size_t large_limit_locked(int dev) {
     g_large_limit_dev[dev] = lim;
     return (size_t)lim;
 }
-// a large block goes back to the driver because of the budget: said once (mapping it again costs ~15 ms per GB)
+// a large block goes back to the driver because of the budget: said once (mapping it again costs ~15 ms per GB).  The note is only
+// RECORDED under g_pool_mu; the logger callback runs after the lock is released (flush_large_note): a logger that allocates or frees
+// through the pool, or calls sfgpu_pool_*, would deadlock otherwise.
+struct LargeNote { bool pending = false, said = false; size_t sz = 0; int dev = 0; size_t limit = 0; } g_large_note;
 void note_large_release(size_t sz, int dev) {
-    static bool said = false;
-    if (said) return;
-    said = true;
+    if (g_large_note.said) return;
+    g_large_note.said = true; g_large_note.pending = true;
+    g_large_note.sz = sz; g_large_note.dev = dev; g_large_note.limit = large_limit_locked(dev);
+}
+void flush_large_note() {                                      // (called WITHOUT g_pool_mu)
+    LargeNote n;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); if (!g_large_note.pending) return; n = g_large_note; g_large_note.pending = false; }
     log_msg(0, "device block of %.1f GB released instead of cached (large-block budget of device %d: %.1f GB; SFGPU_POOL_LARGE_LIMIT_GB / sfgpu_pool_set_large_limit change it)",
-            (double)sz / (double)(1ull << 30), dev, (double)large_limit_locked(dev) / (double)(1ull << 30));
+            (double)n.sz / (double)(1ull << 30), n.dev, (double)n.limit / (double)(1ull << 30));
 }
 
 struct Pending { void* p; hipEvent_t ev; bool owns; };      // (blocks freed together share an event; the last one of them gives it back)
@@ -132,8 +139,13 @@ hipError_t pool_get(void** p, size_t bytes, int kind) {
             if (pass == 0) { if (g_pending.empty()) break; reap_pending_locked(false); }
         }
     }
+    flush_large_note();
     void* q = nullptr;
-    auto alloc = [&] { return kind == kDeviceMem ? hipMalloc(&q, key.sz) : hipHostMalloc(&q, key.sz, hipHostMallocDefault); };
+    auto alloc = [&] {
+        if (kind == kDeviceMem) return hipMalloc(&q, key.sz);
+        if (kind == kUncachedMem) return hipExtMallocWithFlags(&q, key.sz, hipDeviceMallocUncached);
+        return hipHostMalloc(&q, key.sz, hipHostMallocDefault);
+    };
     hipError_t e = alloc();
     if (e != hipSuccess) {              // out of memory: give the cache back and retry once
         (void)hipGetLastError();
@@ -146,16 +158,19 @@ hipError_t pool_get(void** p, size_t bytes, int kind) {
     *p = q;
     return hipSuccess;
 }
-void pool_put(void* p, int kind) {
-    if (!p) return;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
+void pool_put_locked(void* p, int kind) {
     auto it = g_pool_key.find(p);
-    if (it == g_pool_key.end()) { if (kind == kDeviceMem) (void)hipFree(p); else (void)hipHostFree(p); return; }
+    if (it == g_pool_key.end()) { if (kind != kPinnedMem) (void)hipFree(p); else (void)hipHostFree(p); return; }
     if (kind == kDeviceMem && it->second.sz >= kLargeBlock) {
         if (g_large_cached[it->second.dev] + it->second.sz > large_limit_locked(it->second.dev)) { note_large_release(it->second.sz, it->second.dev); g_pool_key.erase(it); (void)hipFree(p); return; }
         g_large_cached[it->second.dev] += it->second.sz;
     }
     g_pool_free[it->second].push_back(p);
+}
+void pool_put(void* p, int kind) {
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); pool_put_locked(p, kind); }
+    flush_large_note();
 }
 }  // namespace
 
@@ -183,6 +198,8 @@ hipError_t pool_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kDevi
 void pool_free(void* p) { pool_put(p, kDeviceMem); }
 hipError_t pinned_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kPinnedMem); }
 void pinned_free(void* p) { pool_put(p, kPinnedMem); }
+hipError_t uncached_malloc(void** p, size_t bytes) { return pool_get(p, bytes, kUncachedMem); }
+void uncached_free(void* p) { pool_put(p, kUncachedMem); }
 
 hipError_t stream_acquire(hipStream_t* s) {
     {
@@ -199,6 +216,7 @@ void stream_release(hipStream_t s) {          // the caller has synchronised it
 }
 
 void pool_trim() {
+    struct Flush { ~Flush() { flush_large_note(); } } flush_after_unlock;      // (destroyed after the lock below)
     std::lock_guard<std::mutex> lk(g_pool_mu);
     reap_pending_locked(true);
     for (hipEvent_t ev : g_events) (void)hipEventDestroy(ev);
@@ -206,7 +224,7 @@ void pool_trim() {
     for (auto& kv : g_pool_free) {
         for (void* q : kv.second) {
             g_pool_key.erase(q);
-            if (kv.first.kind == kDeviceMem) (void)hipFree(q); else (void)hipHostFree(q);
+            if (kv.first.kind != kPinnedMem) (void)hipFree(q); else (void)hipHostFree(q);
         }
         kv.second.clear();
     }

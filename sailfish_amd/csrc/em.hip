@@ -24,6 +24,7 @@
 #include "primitives.h"
 #include "sampling.h"
 
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <condition_variable>
@@ -1651,6 +1652,7 @@ struct sfgpu_em {
     uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
     uint4 *cls8 = nullptr, *ov8 = nullptr; uint32_t *ovc = nullptr, *cnt8 = nullptr;        // phase A's chunk-per-class stream and the long classes' overflow
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
+    bool xbuf_uncached = false;                             // ... in UNCACHED device memory (the default; SFGPU_EM_XBUF=pool: an ordinary pool block)
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
     uint32_t far_cap = 0, esc_ln = 0;                       // LDS of the persistent loop: far slots of a tile at most; far members of a tile kept on chip
@@ -1679,8 +1681,9 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->cls8, em->ov8, em->ovc, em->cnt8, em->xbuf, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->cls8, em->ov8, em->ovc, em->cnt8, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
+    if (em->xbuf) { if (em->xbuf_uncached) uncached_free(em->xbuf); else pool_free(em->xbuf); }
     if (em->h_state) pinned_free(em->h_state);
     if (em->h_blkmax) pinned_free(em->h_blkmax);
     if (em->ev_a) (void)hipEventDestroy(em->ev_a);
@@ -1960,7 +1963,14 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
     // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     em->xbuf_bytes = up((size_t)kCtlWords * 8 + 64 + sizeof(PersistCold)) + 2 * up((size_t)(P ? P : 1) * 16) + 3 * up((size_t)En * 16);
-    SF_HIP(pool_malloc(&em->xbuf, em->xbuf_bytes));
+    // The exchange buffer lives in UNCACHED device memory (round 6): what the tiles hand each other must never be served from an XCD's L2.
+    // In ordinary (coarse-grained) pool memory that was a property of the sc1 forms observed on one stream -- and with other streams'
+    // kernels in flight tiles did poll stale lines (profiles/r5_em_notes.md 5).  The sc1 forms stay (they also skip the L1).
+    {
+        const bool in_pool = []() { const char* e = getenv("SFGPU_EM_XBUF"); return e && strcmp(e, "pool") == 0; }();
+        if (!in_pool && uncached_malloc(&em->xbuf, em->xbuf_bytes) == hipSuccess) em->xbuf_uncached = true;
+        else { (void)hipGetLastError(); em->xbuf = nullptr; SF_HIP(pool_malloc(&em->xbuf, em->xbuf_bytes)); }
+    }
     return SFGPU_OK;
 }
 
@@ -2627,6 +2637,10 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     c.unc = em->unc; c.unc_n = em->unc + em->prob.M;
     c.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
     a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.esc_ln = em->esc_ln; a.ablate = ablate;
+    {   // the launch's epoch: 1..255 in rotation over all persistent launches of the process (exchange buffers are recycled between handles)
+        static std::atomic<uint32_t> g_epoch{0};
+        a.tag0 = (g_epoch.fetch_add(1u, std::memory_order_relaxed) % 255u + 1u) << 24;
+    }
 #if defined(SFGPU_P_STAMP) || defined(SFGPU_P_PROGRESS)
     if (!em->dbg) SF_HIP(pool_malloc(&em->dbg, (size_t)em->n_tiles * 16 * 8));
     SF_HIP(hipMemsetAsync(em->dbg, 0, (size_t)em->n_tiles * 16 * 8, em->cur));
@@ -2642,7 +2656,13 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
         SF_CHECK_LAUNCH();
     }
     void* args[] = {&a};
-    SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kPB), args, em_persist_lds(em), em->cur));
+    {
+        // (SFGPU_EM_COOP=1: a cooperative launch -- the runtime checks the grid against the occupancy query at launch time; residency on
+        //  the chip is the same as a plain launch's, see profiles/r6_em_notes.md)
+        const bool coop = []() { const char* e = getenv("SFGPU_EM_COOP"); return e && atoi(e) != 0; }();
+        if (coop) SF_HIP(hipLaunchCooperativeKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kPB), args, (unsigned int)em_persist_lds(em), em->cur));
+        else SF_HIP(hipLaunchKernel(em_persist_func(em->opts.use_vbem != 0), dim3(em->n_tiles), dim3(kPB), args, em_persist_lds(em), em->cur));
+    }
     // (the launch's verdict, next to the plan's words in pinned memory; read behind finish()'s wait)
     SF_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t*>(em->h_plan + 7), c.status, 4, hipMemcpyDeviceToHost, em->cur));
     return SFGPU_OK;
@@ -2673,7 +2693,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     {
         const char* fe = getenv("SFGPU_EM_FUSED"); const char* pe = getenv("SFGPU_EM_PERSIST");
         const bool family = !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->fused_ok != 0 && em->prob.C != 0 &&
-                            (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 30) && em->persist_ok != 0 && em->xbuf && !em->no_persist;
+                            (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 24) - 2u && em->persist_ok != 0 && em->xbuf && !em->no_persist;
         em->persist = family;
         if (family) em->fused = true;
         if (pe && atoi(pe) == 2) persist_ablate = 1;         // dev: no tag checks (timing only)
@@ -3153,8 +3173,9 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     // Several lanes keep one kernel per iteration.  The persistent loop needs the chip to itself: launched while another stream's kernels
     // are in flight, tiles of one or two XCDs polled stale lines of the exchange buffer for 200 ms while memory held the tags their
     // neighbours had published (profiles/r5_em_notes.md, section 6) -- the run then falls back, correct but late.  One lane runs persistent.
-    em->no_persist = n_lanes > 1;
-    for (sfgpu_em* c : em->bs_clones) c->no_persist = n_lanes > 1;
+    const bool lanes_persist = []() { const char* e = getenv("SFGPU_BS_PERSIST"); return e && atoi(e) != 0; }();
+    em->no_persist = n_lanes > 1 && !lanes_persist;
+    for (sfgpu_em* c : em->bs_clones) c->no_persist = n_lanes > 1 && !lanes_persist;
     struct LaneGuard { sfgpu_em* e; ~LaneGuard() { e->no_persist = false; for (sfgpu_em* c : e->bs_clones) c->no_persist = false; } } lane_guard{em};
     BsOrder order;
     std::vector<int> lane_rc(n_lanes, SFGPU_OK);

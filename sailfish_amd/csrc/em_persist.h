@@ -10,8 +10,10 @@
 // windows overlap a tile's own (TileDesc::e, k_nb_table) -- point to point, tile to tile, no grid barrier:
 //   * a sum travels as a 16-byte GRANULE {lo, tag, hi, tag} written by ONE write-through store (buffer_store_dwordx4 sc1) and read
 //     with sc1 loads (L1 bypassed; the per-XCD L2s are not coherent, the write-through store drops the line there): the data is its
-//     own flag.  tag = the sweep's number + 1 (never 0: the arrays are zeroed before every launch); each 8-byte half carries the
-//     tag, so a torn granule cannot pass.  Two arrays by tag parity: tile T overwrites the granules of sweep s - 1 with those of
+//     own flag.  tag = EPOCH << 24 | the sweep's number + 1 (never 0: the arrays are zeroed before every launch; the epoch is a
+//     process-wide launch counter, 1..255 in rotation -- round 6 -- so that a granule some EARLIER launch left behind with the
+//     same sweep number can never validate, wherever a copy of it may have survived); each 8-byte half carries the tag, so a
+//     torn granule cannot pass.  Two arrays by tag parity: tile T overwrites the granules of sweep s - 1 with those of
 //     sweep s + 1 at the end of step s + 1, whose head needed its neighbours' sums of sweep s, which they publish after their
 //     step s has read T's sums of sweep s - 1 (the overlap relation is symmetric);
 //   * far members (escapes): tile V adds what it hands a far transcript t into a dense LDS accumulator (one FAR SLOT per distinct
@@ -212,6 +214,7 @@ struct PersistArgs {
     uint32_t den_cap, far_cap;                            // LDS: den[den_cap + 1] (den_cap = the plan's null class), facc[far_cap]
     uint32_t esc_ln;                                      // LDS: far members of the tile kept on chip (the plan's most, or what fits)
     uint32_t far_off0, far_stride;                        // exchange buffer: far slots' granules at far_off0 + parity * far_stride, the far targets' x at + 2 * far_stride
+    uint32_t tag0;                                        // the launch's EPOCH in the top byte of every tag (see the tags below)
     int ablate;                                           // dev: 1 = no tag checks (timing only: wrong results); 3 = tile 0 gives up in step 2, 4 = tile 0 starts 100 us late (tests)
 };
 
@@ -341,6 +344,7 @@ k_em_persist(PersistArgs a) {
 #endif
         if (SFGPU_P_SLEEP) __builtin_amdgcn_s_sleep(SFGPU_P_SLEEP);
         if ((++spins & 63u) != 0u) return false;
+        asm volatile("buffer_inv sc1" ::: "memory");                         // (agent-scope invalidate now and then: nothing this CU caches may stand between a poll and memory)
         if (__hip_atomic_load(&ctl[kCtlAbort * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
 #ifdef SFGPU_P_PROGRESS
             { SFP_COLD(cq); cq->dbg[gridDim.x + blockIdx.x] = (unsigned long long)why * 1000ull + sctl[6]; }
@@ -375,7 +379,7 @@ k_em_persist(PersistArgs a) {
         const uint32_t xi = far_xi_l[f], xo = a.far_off0 + 2u * a.far_stride;
         gr4 g = gr_load(xo, xi);
         SFP_WHY(4u);
-        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, s);) { if (spin_check(spins, word)) break; g = gr_load(xo, xi); }
+        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(g, a.tag0 + s);) { if (spin_check(spins, word)) break; g = gr_load(xo, xi); }
         return gr_value(g);
     };
     {   // the far paths' tables into the LDS, once
@@ -430,6 +434,7 @@ k_em_persist(PersistArgs a) {
                 if (c < nc) { c8[i] = c8p[SFP_IX(c)]; cw[i] = cnt[SFP_IX(c)]; }
             }
         };
+        const uint32_t tg = a.tag0 + s;                                      // the tag of what sweep s - 1 published: epoch | s
         if (s > 0u) {
             const uint32_t rd_off = (s & 1u) ? a.part_off[1] : a.part_off[0];       // sums of sweep s - 1 carry tag s
             const uint32_t pos = lo + tid;                                   // (slot q of the thread: position pos + q * kPB)
@@ -438,7 +443,7 @@ k_em_persist(PersistArgs a) {
             for (int q = 0; q < kPS; ++q)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    gq[q][j] = gr4{0u, s, 0u, s};
+                    gq[q][j] = gr4{0u, tg, 0u, tg};
                     if (flags[q] & (1u << j)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[j]);
                 }
             double len[kPS], av[kPS], own[kPS]; uint2 ft[kPS];
@@ -484,7 +489,7 @@ k_em_persist(PersistArgs a) {
                         if (k != ft[q].x) { SFP_COLD(cp); g = cp->ft_list[k]; }
                         gr4 w = gr_load(frd_off, g);
                         SFP_WHY(3u);
-                        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(w, s);) { if (spin_check(spins, 1u)) break; w = gr_load(frd_off, g); }
+                        if (a.ablate != 1) for (uint32_t spins = 0; !gr_ok(w, tg);) { if (spin_check(spins, 1u)) break; w = gr_load(frd_off, g); }
                         ap_v[q] += gr_value(w);
                     }
                 }
@@ -497,13 +502,13 @@ k_em_persist(PersistArgs a) {
                 for (uint32_t spins = 0;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int q = 0; q < kPS; ++q) ok = ok && gr_ok(gq[q][0], s) && gr_ok(gq[q][1], s) && gr_ok(gq[q][2], s);
+                    for (int q = 0; q < kPS; ++q) ok = ok && gr_ok(gq[q][0], tg) && gr_ok(gq[q][1], tg) && gr_ok(gq[q][2], tg);
                     if (ok || spin_check(spins, 1u)) break;
 #pragma unroll
                     for (int q = 0; q < kPS; ++q)
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
-                            if (((flags[q] >> (first + j)) & 1u) && !gr_ok(gq[q][j], s)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[first + j]);
+                            if (((flags[q] >> (first + j)) & 1u) && !gr_ok(gq[q][j], tg)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[first + j]);
                 }
             };
             wait3(0u);
@@ -516,7 +521,7 @@ k_em_persist(PersistArgs a) {
                 for (int q = 0; q < kPS; ++q)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        gq[q][j] = gr4{0u, s, 0u, s};
+                        gq[q][j] = gr4{0u, tg, 0u, tg};
                         if (flags[q] & (8u << j)) gq[q][j] = gr_load(rd_off, pos + q * kPB + delta[3 + j]);
                     }
                 wait3(3u);
@@ -547,7 +552,7 @@ k_em_persist(PersistArgs a) {
                         if (rel > a.tol) ncv = 1u;
                         if (lm < 0.0) lm = 0.0;                            // gated at least once
                     }
-                    if (ft[q].y > ft[q].x) gr_store(a.far_off0 + 2u * a.far_stride, ft[q].x, xv[q], s);      // a far target: its x for the tiles that hold it as a far member
+                    if (ft[q].y > ft[q].x) gr_store(a.far_off0 + 2u * a.far_stride, ft[q].x, xv[q], tg);     // a far target: its x for the tiles that hold it as a far member
                 }
             }
             // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
@@ -691,11 +696,11 @@ k_em_persist(PersistArgs a) {
         SFP_STAMP(5);                                                     // phase C + its barrier
         // ================= D: publish the window and the far slots: granules with tag s + 1 =================
 #pragma unroll
-        for (int q = 0; q < kPS; ++q) if (has[q]) gr_store((s & 1u) ? a.part_off[0] : a.part_off[1], off + tid + q * kPB, acc[tid + q * kPB], s + 1u);
+        for (int q = 0; q < kPS; ++q) if (has[q]) gr_store((s & 1u) ? a.part_off[0] : a.part_off[1], off + tid + q * kPB, acc[tid + q * kPB], tg + 1u);
         if (nf) {
             SFP_TILE(tp);
             const uint32_t fo = a.far_off0 + ((s & 1u) ? 0u : a.far_stride), f0 = tp->f0;
-            for (uint32_t f = tid; f < nf; f += kPB) gr_store(fo, f0 + f, facc[f], s + 1u);
+            for (uint32_t f = tid; f < nf; f += kPB) gr_store(fo, f0 + f, facc[f], tg + 1u);
         }
         SFP_STAMP(6);                                                     // phase D (stores drained)
         // (no barrier here: what the next head clears or writes before its own barrier -- xs[tid], acc[tid], den, facc[f] -- was last read

@@ -155,3 +155,57 @@ def test_cfg3_properties(gpu):
     del ids, off
     res = _em_vs_oracle_at_full_size(sf, gpu, v, eff.cpu().numpy(), R, True)
     assert res["convergence"][0]["iters"] == it1
+
+
+def _class_table_vs_oracle(sf, gpu, ids, off, n_reads):
+    """the class TABLE itself under the oracle at BASELINE's sizes (round 6): the exported (label -> count, XXH64) table, class for
+    class in canonical order, against the oracle's threaded builder on the same reads (contract:
+    include/EquivalenceClassBuilder.hpp:64-108 -- addGroup's upsert and finish's snapshot --, src/TranscriptGroup.cpp:9-12, 53-55 --
+    XXH64 of the label bytes, vector equality).  Integer work: bit-exact."""
+    import os
+    import torch
+    eq = sf.EquivalenceClassBuilder(device=gpu)
+    eq.start(); eq.add_batch(ids, off); eq.finish()
+    rp, ii, cc, hh = eq.eqVec().to_numpy()
+    h_ids = ids.cpu().numpy().view(np.uint32)
+    h_off = (off.to(torch.int64) & 0xFFFFFFFF).cpu().numpy().astype(np.uint64)
+    assert len(h_off) == n_reads + 1 and int(h_off[-1]) == len(h_ids)
+    ob = O.EqBuilder()
+    ob.add_batch_mt(h_ids, h_off, max(1, min(32, os.cpu_count() or 1)))
+    orp, oids, ocnt, ohash = ob.finish()
+    assert ob.total_reads == n_reads == eq.total_reads and ob.n_classes == eq.n_classes and ob.nnz == eq.nnz
+    assert np.array_equal(rp, orp.astype(np.uint32))
+    assert np.array_equal(ii, oids)
+    assert np.array_equal(cc, ocnt) and int(cc.sum()) == n_reads
+    assert np.array_equal(hh, ohash)
+    eq.close()
+    return ob.n_classes
+
+
+def test_cfg2_class_table_equals_the_oracles(gpu):
+    """config 2 in full: 50 M reads over an 80 k-transcript index"""
+    import torch
+    import sailfish_amd as sf
+    from sailfish_amd import synth
+    M, P, R = 80_000, 1_000_000, 50_000_000
+    poff, pids = synth.label_pool(M, P, device=gpu)
+    ids, off = synth.reads_from_pool(poff, pids, R, device=gpu)
+    torch.cuda.synchronize()
+    n = _class_table_vs_oracle(sf, gpu, ids, off, R)
+    assert 0 < n <= P
+
+
+def test_cfg3_prefix_class_table_equals_the_oracles(gpu):
+    """the first 100 M fragments of config 3's read stream (200 k transcripts, 4 M pool labels): more reads than any sub-batch of the
+    partitioned build holds (2^26), so table growth, the scout sub-batch and several route / insert launch pairs are all under the
+    oracle"""
+    import torch
+    import sailfish_amd as sf
+    from sailfish_amd import synth
+    M, P, R = 200_000, 4_000_000, 100_000_000
+    poff, pids = synth.label_pool(M, P, device=gpu)
+    ids, off = synth.reads_slice(poff, pids, 0, R, seed=7, device=gpu)
+    del poff, pids
+    torch.cuda.synchronize()
+    n = _class_table_vs_oracle(sf, gpu, ids, off, R)
+    assert 0 < n <= P
