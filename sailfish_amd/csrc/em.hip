@@ -25,6 +25,7 @@
 #include "sampling.h"
 
 #include <atomic>
+#include <map>
 #include <cfloat>
 #include <chrono>
 #include <condition_variable>
@@ -2848,6 +2849,32 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
                 fprintf(stderr, "persist waits at the give-up (tile: why * 1000 + step; tiles at steps < 2 only):");
                 for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b] < 3) fprintf(stderr, " %u:%llu", b, w[b]);
                 fprintf(stderr, "\n");
+                {   // when and where every block started (100 MHz clock): the late ones, and a histogram of the waits' reasons
+                    std::vector<unsigned long long> t0(em->n_tiles), hw(em->n_tiles);
+                    (void)hipMemcpy(t0.data(), em->dbg + 2 * em->n_tiles, t0.size() * 8, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(hw.data(), em->dbg + 3 * em->n_tiles, hw.size() * 8, hipMemcpyDeviceToHost);
+                    unsigned long long tmin = ~0ull; uint32_t never = 0;
+                    for (uint32_t b = 0; b < em->n_tiles; ++b) { if (!t0[b]) ++never; else tmin = std::min(tmin, t0[b]); }
+                    std::vector<uint32_t> ord(em->n_tiles);
+                    for (uint32_t b = 0; b < em->n_tiles; ++b) ord[b] = b;
+                    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return t0[x] > t0[y]; });
+                    fprintf(stderr, "persist starts: %u blocks never started; the latest (tile: us after the first, xcc, hw_id):", never);
+                    for (uint32_t i = 0; i < 12 && i < em->n_tiles; ++i) { const uint32_t b = ord[i]; fprintf(stderr, " %u:%.1f,x%llu,%05llx", b, t0[b] ? (double)(t0[b] - tmin) * 0.01 : -1.0, hw[b] >> 32, hw[b] & 0xFFFFFull); }
+                    fprintf(stderr, "\n  why histogram (why * 1000 + step -> tiles):");
+                    std::map<unsigned long long, uint32_t> hist;
+                    for (uint32_t b = 0; b < em->n_tiles; ++b) ++hist[w[b]];
+                    for (auto& kv : hist) fprintf(stderr, " %llu->%u", kv.first, kv.second);
+                    fprintf(stderr, "\n  steps histogram (step + 1 -> tiles):");
+                    std::map<unsigned long long, uint32_t> hs;
+                    for (uint32_t b = 0; b < em->n_tiles; ++b) ++hs[h[b]];
+                    for (auto& kv : hs) fprintf(stderr, " %llu->%u", kv.first, kv.second);
+                    // the arrival counters as memory holds them now
+                    unsigned long long ctlw[4 * kShards];
+                    for (uint32_t k = 0; k < 4 * kShards; ++k) (void)hipMemcpy(&ctlw[k], em->xbuf + (size_t)(kCtlArrive + k) * kCtlStride * 8, 8, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "\n  arrival counters [slot][shard] (low word):");
+                    for (uint32_t k = 0; k < 4 * kShards; ++k) fprintf(stderr, "%s%llu", (k % kShards) ? " " : " | ", ctlw[k] & 0xFFFFFFFFull);
+                    fprintf(stderr, "\n");
+                }
                 // the first stuck tile's view: what memory holds NOW where it polled (its neighbours' pieces, parity 1 = tags 1, 3, ...)
                 for (uint32_t b = 0; b < em->n_tiles; ++b) if (h[b] == 2 && w[b] / 1000 == 2) {
                     TileDesc t; (void)hipMemcpy(&t, em->td + b, sizeof(t), hipMemcpyDeviceToHost);

@@ -352,6 +352,9 @@ k_em_persist(PersistArgs a) {
             sctl[word] = 1u; return true;
         }
         if (spins >= kSpinLimit) {
+#ifdef SFGPU_P_PROGRESS
+            { SFP_COLD(cq); cq->dbg[gridDim.x + blockIdx.x] = 900000ull + (unsigned long long)why * 1000ull + sctl[6]; }      // (9xxxxx: the tile that gave up)
+#endif
             // who gave up, for the log: [1] tile + 1, [2] thread, [3] what it waited for (the abort word of the wait: 1 = a head, 4 / 5 = a phase)
             const unsigned long long first = atomicCAS(&ctl[(kCtlAbort + 1) * kCtlStride], 0ull, (unsigned long long)blockIdx.x + 1ull);
             if (first == 0ull) { ctl[(kCtlAbort + 1) * kCtlStride + 1] = threadIdx.x; ctl[(kCtlAbort + 1) * kCtlStride + 2] = why ? why : word; ctl[(kCtlAbort + 1) * kCtlStride + 3] = sctl[6]; }
@@ -411,7 +414,14 @@ k_em_persist(PersistArgs a) {
         const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
         if (tid == 0u) sctl[6] = s;                                          // (for the log of a give-up)
 #ifdef SFGPU_P_PROGRESS
-        if (tid == 0u) { SFP_COLD(cq); __hip_atomic_store(&cq->dbg[blockIdx.x], (unsigned long long)s + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (tid == 0u) {
+            SFP_COLD(cq); __hip_atomic_store(&cq->dbg[blockIdx.x], (unsigned long long)s + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s == 0u) {                                                   // when and where the block started (its first step)
+                __hip_atomic_store(&cq->dbg[2 * gridDim.x + blockIdx.x], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20), hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_XCC_ID, HW_REG_HW_ID
+                __hip_atomic_store(&cq->dbg[3 * gridDim.x + blockIdx.x], ((unsigned long long)xcc << 32) | hwid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
 #endif
         // ================= head of step s: [the stop test of update s - 1] update s, x of sweep s =================
         bool has[kPS], home[kPS];

@@ -22,7 +22,8 @@ length = ref_len.to(torch.float64)
 ref = None
 for xbuf in os.environ.get("BSP_XBUF", "uncached,pool").split(","):
     for coop in os.environ.get("BSP_COOP", "0").split(","):
-        for lanes, bsp in ((1, 1), (2, 1), (3, 1), (3, 0)):
+        LS = [tuple(map(int, x.split(':'))) if ':' in x else (int(x), 1) for x in os.environ['BSP_LANESETS'].split(',')] if 'BSP_LANESETS' in os.environ else ((1, 1), (2, 1), (3, 1), (3, 0))
+        for lanes, bsp in LS:
             os.environ["SFGPU_EM_XBUF"] = xbuf; os.environ["SFGPU_EM_COOP"] = coop
             os.environ["SFGPU_BS_LANES"] = str(lanes); os.environ["SFGPU_BS_PERSIST"] = str(bsp)
             p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads)
