@@ -322,7 +322,8 @@ constexpr int kTileNnz = SFGPU_TILE_NNZ;     // largest CSR bucket that defines 
 constexpr uint64_t kRenumberMinClasses = 4096;   // smaller problems are not worth a second plan
 constexpr int kRenumberHops = 5;           // class hops of the label propagation behind the plan's own transcript order (em_renumber)
 constexpr int kEscSlots = 128;              // LDS accumulator for escaped members (per tile)
-constexpr int kWin = 1024;                   // LDS window (transcripts): 2 x 8 KB
+constexpr int kWin = 1023;                   // LDS window (transcripts): 2 x 8 KB.  1023, not 1024 (round 6): a window slot is a 10-bit field in the
+                                             // persistent loop's class records (em_persist.h) and 1023 is the null slot, whose x is 0
 #ifndef SFGPU_SWEEP_BLOCK
 #define SFGPU_SWEEP_BLOCK 1024
 #endif
@@ -1651,7 +1652,8 @@ struct sfgpu_em {
     uint32_t null_cls = kTileNnz;                           // GATHER: class index of the transcript-major copy's padding = the largest class count of a tile
     // the PERSISTENT loop (em_persist.h): far-slot tables, the exchange buffer (control words + granule arrays), the plan's verdict
     uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
-    uint4 *cls8 = nullptr, *ov8 = nullptr; uint32_t *ovc = nullptr, *cnt8 = nullptr;        // phase A's chunk-per-class stream and the long classes' overflow
+    uint4* recs = nullptr; uint16_t* ovc = nullptr; TilePack* tp = nullptr; uint32_t *cnt8 = nullptr, *cpos = nullptr, *esc_cls_p = nullptr;      // phase A's class records (k_pack_build)
+    unsigned char* csc_p = nullptr;                         // ... and the transcript-major copy with the permuted class positions (k_csc_remap)
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
     bool xbuf_uncached = false;                             // ... in UNCACHED device memory (the default; SFGPU_EM_XBUF=pool: an ordinary pool block)
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
@@ -1682,7 +1684,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->cls8, em->ov8, em->ovc, em->cnt8, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->recs, em->ovc, em->tp, em->cnt8, em->cpos, em->esc_cls_p, em->csc_p, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->xbuf) { if (em->xbuf_uncached) uncached_free(em->xbuf); else pool_free(em->xbuf); }
     if (em->h_state) pinned_free(em->h_state);
@@ -1953,12 +1955,17 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
         hipLaunchKernelGGL(k_far_xi, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, em->far_pos, em->ftgt, em->cov2, em->far_xi, em->pflags);
         SF_CHECK_LAUNCH();
     }
-    {   // phase A's chunk-per-class stream (k_cls8_build): from the compact stream's 16-bit slots, the plan's rowptr and tile table
-        const uint64_t C = em->prob.C, Lnz = em->L;
-        SF_HIP(pool_malloc(&em->cls8, (C ? C : 1) * 16)); SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4));
-        SF_HIP(pool_malloc(&em->ovc, (Lnz / 8 + 2 * (uint64_t)nt + 2) * 4)); SF_HIP(pool_malloc(&em->ov8, (Lnz / 8 + 2 * (uint64_t)nt + 2) * 16));      // (a tile's stream is padded to whole chunks)
-        hipLaunchKernelGGL(k_cls8_build, dim3(nt), dim3(kSweepBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
-                           em->counts32, em->cls8, em->ovc, em->ov8, em->td, em->pflags);
+    {   // phase A's class records (k_pack_build: from the compact stream's 16-bit slots, the plan's rowptr and tile table) and phase C's
+        // transcript-major copy with the classes' permuted positions (k_csc_remap)
+        const uint64_t C = em->prob.C, Lnz = em->L, S8 = Lnz / 8 + 2 * (uint64_t)nt + 2;      // (a tile's stream is padded to whole chunks of 8)
+        SF_HIP(pool_malloc(&em->recs, (C + S8 + 4 * (uint64_t)nt + 4) * 16)); SF_HIP(pool_malloc(&em->ovc, S8 * 2));
+        SF_HIP(pool_malloc(&em->tp, (size_t)nt * sizeof(TilePack)));
+        SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->cpos, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->esc_cls_p, En * 4));
+        hipLaunchKernelGGL(k_pack_build, dim3(nt), dim3(kSweepBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
+                           em->td, em->esc_cls, em->recs, em->ovc, em->tp, em->cpos, em->esc_cls_p);
+        const uint64_t csc_bytes = 32 * (Lnz / 8 + nt + 1) + 32;                           // (as em->csc was sized)
+        SF_HIP(pool_malloc(&em->csc_p, csc_bytes));
+        hipLaunchKernelGGL(k_csc_remap, dim3(nt), dim3(kEmBlock), 0, st, em->td, em->cpos, em->csc, em->csc_p, em->null_cls);
         SF_CHECK_LAUNCH();
     }
     // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned
@@ -2577,10 +2584,10 @@ static int em_build_graph(sfgpu_em* em, uint32_t n) {
 
 // ---- the persistent loop (em_persist.h): eligibility, and the launch ----
 static std::mutex g_persist_mu[16];          // per device: two persistent launches of this process never share the chip (each needs ALL its blocks resident)
-// xs | acc | den | facc | fxs | wmax | sctl, hprev | far_xi_l | ftg_l | esc_l | (dev stamps)
+// xs | acc | den | facc | fxs | wmax | sctl, hprev | cntl | far_xi_l | ftg_l | esc_l | (dev stamps)
 static size_t em_persist_lds_base(const sfgpu_em* em) {
     return ((size_t)2 * (kWin + 2) + (em->null_cls + 2) + 2 * (size_t)em->far_cap + 2 * (kSweepBlock / kWave)) * 8 + 32 + 4 * kShards * 4
-           + ((size_t)em->far_cap + (em->ftgt ? (size_t)kWin : 0) + 1) * 4;
+           + ((size_t)(em->null_cls + 2) + (size_t)em->far_cap + (em->ftgt ? (size_t)kWin : 0) + 1) * 4;
 }
 static size_t em_persist_lds(const sfgpu_em* em) { return em_persist_lds_base(em) + (size_t)em->esc_ln * 8 + 64; }
 static const void* em_persist_func(bool vb) {
@@ -2596,7 +2603,6 @@ static void em_persist_check(sfgpu_em* em) {
     const uint32_t* pf = reinterpret_cast<const uint32_t*>(em->h_plan + 8);
     if (pf[0] & 2u) return no("a far member's transcript lies in no window (no home thread)");
     if (pf[0] & 4u) return no("a transcript is fed by more far slots than its home thread should walk");
-    if (pf[0] & 8u) return no("a class of 2^30 reads or more (bit 30 of the loop's count words is a flag)");
     if ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 1u) != 0u) return no("a tile that more than kNbMax tiles overlap (it goes by the cover list)");
     em->far_cap = pf[1];
     constexpr size_t kLdsPerBlock = 81920;                   // half a CU's LDS: two blocks per CU, like the sweep
@@ -2631,10 +2637,10 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
     a.far_off0 = (uint32_t)o; a.far_stride = (uint32_t)up(En * 16);         // (far slots by parity, then the far targets' x)
     a.tiles = em->td; c.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
-    a.cls8 = em->cls8; a.ovc = em->ovc; a.ov8 = em->ov8; a.counts = em->cnt8; a.csc = em->csc; a.csc_slot0 = em->csc_slot0;
+    a.tp = em->tp; a.recs = em->recs; a.ovc = em->ovc; a.counts = em->cnt8; a.csc = em->csc_p; a.csc_slot0 = em->csc_slot0;
     c.x = em->x; c.inv = em->inv;
     a.lenc = em->inv ? em->lencP : em->lenc; a.alpha = em->inv ? em->alphaP : em->alpha;
-    c.esc_cls = em->esc_cls; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;
+    c.esc_cls = em->esc_cls_p; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;
     c.unc = em->unc; c.unc_n = em->unc + em->prob.M;
     c.tmax = em->tmax; a.tol = em->opts.tol; a.log_norm = em->vb_log_norm;
     a.den_cap = em->null_cls; a.far_cap = em->far_cap; a.esc_ln = em->esc_ln; a.ablate = ablate;
@@ -2653,7 +2659,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
         const uint32_t c0 = (uint32_t)(((size_t)kCtlWords * 8 + 64) / 16), cn = (uint32_t)((sizeof(PersistCold) + 15) / 16);
         const unsigned nb = (unsigned)std::min<uint64_t>((em->xbuf_bytes / 16 + 255) / 256, 2048);
         hipLaunchKernelGGL(k_persist_init, dim3(nb), dim3(256), 0, em->cur, (void*)em->xbuf, (uint32_t)em->xbuf_bytes, c0, cn, d_cold, c,
-                           (uint64_t)em->prob.C, (const uint32_t*)em->counts32, (const uint4*)em->cls8, em->cnt8);
+                           (uint64_t)em->prob.C, (const uint32_t*)em->counts32, (const uint32_t*)em->cpos, em->cnt8);
         SF_CHECK_LAUNCH();
     }
     void* args[] = {&a};
@@ -2924,14 +2930,18 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
         std::vector<uint32_t> order(em->n_tiles);
         for (uint32_t b = 0; b < em->n_tiles; ++b) order[b] = b;
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h[x * 8] < h[y * 8]; });
-        double mean_nc = 0, mean_np = 0, mean_nm = 0, mean_ov = 0;
-        for (const TileDesc& t : htd) { mean_nc += t.nc; mean_np += t.np; mean_nm += t.nm; mean_ov += t.n_ov; }
-        fprintf(stderr, "  tile means: classes %.0f, pure chunks %.0f, mixed chunks %.0f, overflow chunks %.0f\n", mean_nc / em->n_tiles, mean_np / em->n_tiles, mean_nm / em->n_tiles, mean_ov / em->n_tiles);
+        std::vector<TilePack> htp(em->n_tiles);
+        (void)hipMemcpy(htp.data(), em->tp, htp.size() * sizeof(TilePack), hipMemcpyDeviceToHost);
+        double mean_nc = 0, mean_np = 0, mean_nm = 0, mean_ov = 0, mean_n[4] = {0, 0, 0, 0};
+        for (const TileDesc& t : htd) { mean_nc += t.nc; mean_np += t.np; mean_nm += t.nm; }
+        for (const TilePack& t : htp) { mean_ov += t.n_ov; mean_n[0] += t.n1; mean_n[1] += t.n2; mean_n[2] += t.n3; mean_n[3] += t.n4; }
+        fprintf(stderr, "  tile means: classes %.0f (records of 4 / 8 / 16 bytes / long: %.0f %.0f %.0f %.0f), pure chunks %.0f, mixed chunks %.0f, overflow chunks %.0f\n", mean_nc / em->n_tiles,
+                mean_n[0] / em->n_tiles, mean_n[1] / em->n_tiles, mean_n[2] / em->n_tiles, mean_n[3] / em->n_tiles, mean_np / em->n_tiles, mean_nm / em->n_tiles, mean_ov / em->n_tiles);
         for (uint32_t i = 0; i < 6 && i < em->n_tiles; ++i) {
             const uint32_t b = order[i]; const TileDesc& t = htd[b];
             fprintf(stderr, "  tile %4u:", b);
             for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.2f", nm[k], (double)h[b * 8 + k] * 0.01 / steps);
-            fprintf(stderr, " | span %u classes %u pure %u mixed %u overflow %u far members %u far slots %u neighbours %u\n", t.span, t.nc, t.np, t.nm, t.n_ov, t.n_esc, t.nf, t.nb_n);
+            fprintf(stderr, " | span %u classes %u pure %u mixed %u overflow %u far members %u far slots %u neighbours %u\n", t.span, t.nc, t.np, t.nm, htp[b].n_ov, t.n_esc, t.nf, t.nb_n);
         }
     }
 #endif

@@ -128,64 +128,131 @@ __global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const ui
 // per SIMD, and what does not fit is spilled into VGPR lanes and fetched back with a v_readlane apiece all over the hot phases.
 // (Measured the other way round too, profiles/r5_em_notes.md: EVERYTHING read through memory at each phase's start costs a dependent scalar
 //  round trip per phase, 16 -> 21 us per step on cfg3.)
-// ---- phase A's stream for the persistent loop: ONE 16-byte chunk per class (round 5) ------------------------------------------------
-// The compact class-major stream of k_sweep_lds packs the nonzeros eight to a chunk regardless of class boundaries: a lane walks its
-// chunk, detects where a class ends and hands every run to den[] with an LDS atomic -- ~100 instructions per chunk, half of them the
-// branches around the atomics, and ~2.4 atomics.  Classes average 5.8 members, so here a class IS a chunk: its first eight window slots
-// (16 bits each; kWin = the null slot, whose x is 0: padding, a far member), lane per class: eight LDS reads, a tree of adds, one plain
-// store -- no run detection, no atomic.  A class with more than eight members, or with a far member (whose x arrives by atomic), is
-// flagged LONG (bit 15 of slot 0): its chunks add with atomics, the ones behind the first come from an overflow list (class, 8 slots).
-// A class that is not long is FINISHED by the lane that summed it: count / denominator goes to den[] right away, phase B is left with
-// the long classes (the flag is bit 30 of the count word: cnt8, a copy of the plan's counts).
-constexpr uint32_t kCls8Long = 0x8000u;
-constexpr uint32_t kCnt8Long = 0x40000000u;        // the same flag in the class's count word (bit 31: singleton)
-// One block per tile.  A tile's overflow chunks start at tile_s0 / 8 + tile (a tile of n nonzeros has at most n / 8 of them: the
-// regions cannot meet), a class's at the block-wide prefix sum of the chunks its predecessors need: no global scan, one launch.
+// ---- phase A's stream for the persistent loop (round 6): one RECORD per class, in four sizes ---------------------------------------
+// Round 5 gave every class one 16-byte chunk (its first eight window slots, 16 bits each) and sent the members behind the eighth through
+// an overflow list with atomics.  cfg3's class sizes are not the pool's geometric law (small labels collide in the pool and merge): of
+// its 1.62 M classes 36 % hold <= 3 members, 29 % 4 - 6, 27 % 7 - 12 and 8 % more -- 22 % were "long" under the eight-slot chunk, 45 % of
+// the nonzeros went through overflow chunks, and a tile streamed 51 KB of chunks + 13 KB of counts + ~10 KB of overflow per step.
+// Now a window slot is a 10-bit field (kWin = 1023: slots 0 .. 1022, 1023 = the null slot whose x is 0) and a class is a record of
+//   4 bytes (<= 3 in-window members), 8 bytes (<= 6), 16 bytes (<= 12), or 16 bytes + overflow chunks of 12 (more, or a far member),
+// three slots to a dword.  The classes of a tile are PERMUTED so that the records of one size are contiguous (B1 | B2 | B3 | B4):
+// lane per record, fixed-size loads, no run detection, and only B4 -- classes of more than 12 in-window members or with a far member,
+// whose x arrives by atomic -- adds with atomics and needs phase B.  den[] is indexed by the permuted position; the transcript-major
+// copy of phase C is remapped once at plan time (k_csc_remap), the count words are scattered into permuted order before every launch
+// (k_persist_init) and live in the block's LDS for the whole run.  cfg3: 25 KB of records + 3 KB of overflow per tile and step.
+struct TilePack { uint32_t a16, n1, n2, n3, n4, n_ov, ov0, pad; };        // a16: the tile's first 16-byte unit in `recs`: [B3 | B4 | overflow | B2 | B1]
+static_assert(sizeof(TilePack) == 32, "two to a 64-byte line");
+constexpr uint32_t kRecSlots3 = 12;                                   // slots of a 16-byte record / overflow chunk
+__device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { return a | (b << 10) | (c << 20); }
+// One block per tile.  recs: the tile's records start at unit a16 = c0 + s0 / 8 + 4 T (16 bytes per class bound the records, 2 bytes per
+// nonzero the overflow chunks: no scan over the tiles); ovc: class (permuted, in the tile) of every overflow chunk, at s0 / 8 + T.
 __global__ void __launch_bounds__(kSweepBlock)
-k_cls8_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
-             const uint16_t* __restrict__ slot16, const uint32_t* __restrict__ counts,
-             uint4* cls8, uint32_t* ovc, uint4* ov8, TileDesc* td, uint32_t* pflags) {
-    __shared__ uint32_t ext[8192];                                   // overflow chunks in front of a class's (class field: 13 bits)
-    __shared__ uint32_t wsum[kSweepBlock / kWave];
-    const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1], nc = c1 - c0, tid = threadIdx.x;
+k_pack_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
+             const uint16_t* __restrict__ slot16, const TileDesc* __restrict__ td, const uint32_t* __restrict__ esc_cls,
+             uint4* recs, uint16_t* ovc, TilePack* tp, uint32_t* cpos, uint32_t* esc_cls_p) {
+    __shared__ uint16_t perm_l[8192];                                 // class in the tile -> its permuted position (pass 1: its rank in the thread's run)
+    __shared__ uint32_t ext_l[8192];                                  // bucket << 30 | overflow chunks in front of the class's
+    __shared__ unsigned long long wsum[kSweepBlock / kWave];
+    __shared__ uint32_t wsum2[kSweepBlock / kWave];
+    __shared__ uint32_t tot_s[5];
+    const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1], nc = c1 - c0, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint64_t s0 = tile_s0[T];
     const uint32_t j0 = rowptr[c0];
-    const uint32_t ov0 = (uint32_t)(s0 / 8u) + T;
-    // a thread's run of classes [q0, q1), its chunks, then the block's exclusive prefix over the threads
-    const uint32_t per = (nc + kSweepBlock - 1u) / kSweepBlock, q0 = tid * per < nc ? tid * per : nc, q1 = q0 + per < nc ? q0 + per : nc;
-    uint32_t mine = 0;
-    for (uint32_t c = q0; c < q1; ++c) { const uint32_t k = rowptr[c0 + c + 1] - rowptr[c0 + c]; ext[c] = mine; mine += k > 8u ? (k - 8u + 7u) / 8u : 0u; }
-    uint32_t incl = mine;
-    for (int o = 1; o < kWave; o <<= 1) { const uint32_t v = __shfl_up(incl, o, kWave); if ((tid & (kWave - 1)) >= (uint32_t)o) incl += v; }
-    if ((tid & (kWave - 1)) == kWave - 1) wsum[tid / kWave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < tid / kWave; ++w) base += wsum[w];
-    base += incl - mine;
-    for (uint32_t c = q0; c < q1; ++c) ext[c] += base;
-    if (tid == kSweepBlock - 1u) { td[T].ov0 = ov0; td[T].n_ov = base + mine; }
-    __syncthreads();
-    for (uint32_t c = c0 + tid; c < c1; c += kSweepBlock) {
-        const uint32_t b = rowptr[c], k = rowptr[c + 1] - b;
+    auto bucket_of = [&](uint32_t c, uint32_t& n_in) -> uint32_t {
+        const uint32_t b = rowptr[c0 + c], k = rowptr[c0 + c + 1] - b;
         const uint16_t* sl = slot16 + s0 + (b - j0);
-        uint32_t w[8]; bool far = false;
-        for (uint32_t m = 0; m < 8u; ++m) { w[m] = m < k ? sl[m] : (uint32_t)kWin; if (m < k && w[m] == (uint32_t)kWin) far = true; }
-        for (uint32_t m = 8u; m < k; ++m) if (sl[m] == (uint16_t)kWin) far = true;
-        const bool single = k == 1u;                              // (a singleton's denominator is never used: nothing to read)
-        if (single) w[0] = kWin;
-        const bool lng = k > 8u || far;
-        if (lng) w[0] |= kCls8Long;
-        // (a class of ~2^30 reads: bit 30 of the count word is taken -- such a plan keeps one kernel per iteration.  The margin is for the
-        //  bootstrap's resampled counts: a class of c reads draws c +- sqrt(c), 2^20 is 30 of those)
-        if ((counts[c] & 0x7FFFFFFFu) >= kCnt8Long - (1u << 20)) atomicOr(&pflags[0], 8u);
-        cls8[c] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
-        uint32_t at = ov0 + ext[c - c0];
-        for (uint32_t m0 = 8u; m0 < k; m0 += 8u, ++at) {
-            uint32_t v[8];
-            for (uint32_t m = 0; m < 8u; ++m) v[m] = m0 + m < k ? sl[m0 + m] : (uint32_t)kWin;
-            ovc[at] = c - c0;
-            ov8[at] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        n_in = 0; bool far = false;
+        for (uint32_t m = 0; m < k; ++m) { if (sl[m] == (uint16_t)kWin) far = true; else ++n_in; }
+        return (far || n_in > kRecSlots3) ? 3u : (n_in <= 3u ? 0u : (n_in <= 6u ? 1u : 2u));
+    };
+    // pass 1: a thread's run of classes [q0, q1): bucket, rank inside the run, overflow chunks in front
+    const uint32_t per = (nc + kSweepBlock - 1u) / kSweepBlock, q0 = tid * per < nc ? tid * per : nc, q1 = q0 + per < nc ? q0 + per : nc;
+    unsigned long long mine = 0ull; uint32_t mine_ov = 0u;             // four 16-bit counters (a tile holds < 8192 classes)
+    for (uint32_t c = q0; c < q1; ++c) {
+        uint32_t n_in; const uint32_t bk = bucket_of(c, n_in);
+        perm_l[c] = (uint16_t)((mine >> (16u * bk)) & 0xFFFFull);
+        ext_l[c] = (bk << 30) | mine_ov;
+        mine += 1ull << (16u * bk);
+        if (bk == 3u && n_in > kRecSlots3) mine_ov += (n_in - 1u) / kRecSlots3;
+    }
+    unsigned long long incl = mine; uint32_t incl_ov = mine_ov;
+    for (int o = 1; o < kWave; o <<= 1) {
+        const unsigned long long v = __shfl_up(incl, o, kWave); const uint32_t v2 = __shfl_up(incl_ov, o, kWave);
+        if ((int)lane >= o) { incl += v; incl_ov += v2; }
+    }
+    if (lane == kWave - 1) { wsum[wave] = incl; wsum2[wave] = incl_ov; }
+    __syncthreads();
+    unsigned long long base = incl - mine; uint32_t base_ov = incl_ov - mine_ov;
+    for (uint32_t w = 0; w < wave; ++w) { base += wsum[w]; base_ov += wsum2[w]; }
+    if (tid == kSweepBlock - 1u) {
+        const unsigned long long t = base + mine;
+        tot_s[0] = (uint32_t)(t & 0xFFFFull); tot_s[1] = (uint32_t)((t >> 16) & 0xFFFFull); tot_s[2] = (uint32_t)((t >> 32) & 0xFFFFull); tot_s[3] = (uint32_t)((t >> 48) & 0xFFFFull);
+        tot_s[4] = base_ov + mine_ov;
+    }
+    __syncthreads();
+    const uint32_t n1 = tot_s[0], n2 = tot_s[1], n3 = tot_s[2], n4 = tot_s[3], n_ov = tot_s[4];
+    const uint32_t first[4] = {0u, n1, n1 + n2, n1 + n2 + n3};
+    const uint32_t a16 = c0 + (uint32_t)(s0 / 8u) + 4u * T, ov0 = (uint32_t)(s0 / 8u) + T;
+    if (tid == 0u) { TilePack r; r.a16 = a16; r.n1 = n1; r.n2 = n2; r.n3 = n3; r.n4 = n4; r.n_ov = n_ov; r.ov0 = ov0; r.pad = 0u; tp[T] = r; }
+    // pass 2: the permuted position
+    for (uint32_t c = q0; c < q1; ++c) {
+        const uint32_t bk = ext_l[c] >> 30;
+        const uint32_t pos = first[bk] + (uint32_t)((base >> (16u * bk)) & 0xFFFFull) + perm_l[c];
+        perm_l[c] = (uint16_t)pos;
+        ext_l[c] = (bk << 30) | (base_ov + (ext_l[c] & 0x3FFFFFFFu));
+        cpos[c0 + c] = c0 + pos;
+    }
+    __syncthreads();
+    // pass 3: the records
+    uint4* const r3 = recs + a16; uint4* const r4 = r3 + n3; uint4* const rov = r4 + n4;
+    uint2* const r2 = reinterpret_cast<uint2*>(rov + n_ov); uint32_t* const r1 = reinterpret_cast<uint32_t*>(r2 + n2);
+    for (uint32_t c = tid; c < nc; c += kSweepBlock) {
+        const uint32_t b = rowptr[c0 + c], k = rowptr[c0 + c + 1] - b;
+        const uint16_t* sl = slot16 + s0 + (b - j0);
+        const uint32_t bk = ext_l[c] >> 30, pos = perm_l[c];
+        uint32_t w[kRecSlots3], n = 0;
+        uint32_t at = ov0 + (ext_l[c] & 0x3FFFFFFFu);
+        bool head = true;
+        auto flush = [&]() {
+            for (uint32_t m = n; m < kRecSlots3; ++m) w[m] = (uint32_t)kWin;
+            const uint4 v = make_uint4(pack3(w[0], w[1], w[2]), pack3(w[3], w[4], w[5]), pack3(w[6], w[7], w[8]), pack3(w[9], w[10], w[11]));
+            if (head) {
+                if (bk == 0u) r1[pos] = v.x;
+                else if (bk == 1u) r2[pos - first[1]] = make_uint2(v.x, v.y);
+                else if (bk == 2u) r3[pos - first[2]] = v;
+                else r4[pos - first[3]] = v;
+                head = false;
+            } else { ovc[at] = (uint16_t)pos; rov[at - ov0] = v; ++at; }
+            n = 0;
+        };
+        const bool single = k == 1u;                                  // (a singleton's denominator is never used: nothing to read)
+        for (uint32_t m = 0; m < k; ++m) {
+            const uint32_t s = sl[m];
+            if (s == (uint32_t)kWin || single) continue;              // a far member: its x arrives through the tile's far slots
+            if (n == kRecSlots3) flush();
+            w[n++] = s;
         }
+        flush();                                                      // (the head record always exists; a full last chunk is written here)
+    }
+    // pass 4: the far members' classes as permuted positions
+    const uint32_t n_esc = td[T].n_esc; const uint64_t e0 = td[T].e0;
+    for (uint32_t i = tid; i < n_esc; i += kSweepBlock) { const uint32_t t = esc_cls[e0 + i]; esc_cls_p[e0 + i] = ((uint32_t)perm_l[(t >> 16) & 0x1FFFu] << 16) | (t & kSingle); }
+}
+// the transcript-major copy with the classes' permuted positions (the padding's null class stays)
+__global__ void __launch_bounds__(kEmBlock)
+k_csc_remap(const TileDesc* __restrict__ td, const uint32_t* __restrict__ cpos, const unsigned char* __restrict__ csc, unsigned char* csc_p, uint32_t null_cls) {
+    const TileDesc& t = td[blockIdx.x];
+    const uint32_t c0 = t.c0, nc = t.nc, np = t.np, nm = t.nm;
+    const uint4* src = reinterpret_cast<const uint4*>(csc + t.qb); uint4* dst = reinterpret_cast<uint4*>(csc_p + t.qb);
+    auto remap = [&](uint32_t v) -> uint32_t {
+        const uint32_t a = v & 0xFFFFu, b = v >> 16;
+        const uint32_t a2 = a < nc ? cpos[c0 + a] - c0 : null_cls, b2 = b < nc ? cpos[c0 + b] - c0 : null_cls;
+        return a2 | (b2 << 16);
+    };
+    for (uint32_t j = threadIdx.x; j < np + 2u * nm; j += kEmBlock) {
+        uint4 v = src[j];
+        if (j < np || ((j - np) & 1u) == 0u) v = make_uint4(remap(v.x), remap(v.y), remap(v.z), remap(v.w));      // (a mixed chunk's second half holds slots)
+        dst[j] = v;
     }
 }
 
@@ -201,9 +268,9 @@ struct PersistCold {
 struct PersistArgs {
     const TileDesc* tiles; const PersistCold* cold;
     uint32_t min_iter, max_iter, n_tiles; int check_mode;
-    const uint4* cls8; const uint32_t* ovc; const uint4* ov8;      // phase A: a chunk per class, the overflow of long classes (class in the tile, 8 slots)
-    const uint32_t* counts;                               // cnt8: count | long << 30 | singleton << 31
-    const unsigned char* csc; const uint16_t* csc_slot0;
+    const TilePack* tp; const uint4* recs; const uint16_t* ovc;    // phase A: a record per class in four sizes, the overflow chunks' classes (k_pack_build)
+    const uint32_t* counts;                               // cnt8: count | singleton << 31, in the tiles' permuted class order
+    const unsigned char* csc; const uint16_t* csc_slot0;  // phase C: the transcript-major copy with permuted class positions (k_csc_remap)
     const double* lenc; double* alpha;                    // by position of the plan's order
     const uint2* ftgt;                                    // per position: [k0, k1) of ft_list (null: the plan has no far members)
     // the exchange buffer: ONE buffer descriptor, the pieces by byte offset; part_off: granules of the window sums, slot-major
@@ -223,13 +290,13 @@ struct PersistArgs {
 // L2 of the XCD that wrote them, a write-through store from another XCD does not reach those copies, and a tile that runs on that XCD
 // then polls (sc1 loads are L2-served) a line of zeros for ever.  Seen with three bootstrap lanes (other streams' kernels between the
 // launches: blocks land on other XCDs than b mod 8): tiles of one or two XCDs waited in step 1 for sums their neighbours had published.
-// ... and cnt8, the count words the loop reads: the handle's CURRENT counts (the bootstrap resamples them before every run) with the
-// long flag of the class's chunk in bit 30.
+// ... and cnt8, the count words the loop reads: the handle's CURRENT counts (the bootstrap resamples them before every run) in the
+// tiles' permuted class order (cpos: class of the plan -> its position).
 __global__ void __launch_bounds__(256)
 k_persist_init(void* xbuf, uint32_t bytes, uint32_t cold_first16, uint32_t cold_n16, PersistCold* d_cold, PersistCold cold,
-               uint64_t C, const uint32_t* __restrict__ counts, const uint4* __restrict__ cls8, uint32_t* __restrict__ cnt8) {
+               uint64_t C, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ cpos, uint32_t* __restrict__ cnt8) {
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (uint64_t)gridDim.x * blockDim.x)
-        cnt8[c] = (counts[c] & ~kCnt8Long) | ((cls8[c].x & kCls8Long) ? kCnt8Long : 0u);
+        cnt8[cpos[c]] = counts[c];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, bytes, 0x00020000);
     const uint32_t n16 = bytes / 16u;
     const gr4 z = {0u, 0u, 0u, 0u};
@@ -279,7 +346,8 @@ k_em_persist(PersistArgs a) {
     // What the far paths need of the plan, on chip (round 5, second pass): read through the cold block these were two or three DEPENDENT
     // round trips to memory in the head, in phase A and again in phase C of every step -- in the tiles that have far members, and those
     // set the pace of all (cfg2's tile 0: x + update 2.8 us against 1.45, C 3.1 against 2.3, tools/r5_pstamp.sh).
-    uint32_t* const far_xi_l = hprev + 4 * kShards;        // [far_cap] per far slot of the tile: index of its transcript's x granule
+    uint32_t* const cntl = hprev + 4 * kShards;            // [den_cap + 2] the tile's count words (bit 31: singleton), permuted order: read from memory ONCE per launch (round 6)
+    uint32_t* const far_xi_l = cntl + (a.den_cap + 2);     // [far_cap] per far slot of the tile: index of its transcript's x granule
     uint32_t* const ftg_l = far_xi_l + a.far_cap;          // [kWin] per window slot: the first far slot that feeds it (plans with far members)
     uint2* const esc_l = reinterpret_cast<uint2*>(ftg_l + (a.ftgt ? kWin : 0) + ((a.far_cap + (a.ftgt ? kWin : 0)) & 1u));      // [esc_ln] far members: {class << 16 | single, far slot}
 #ifdef SFGPU_P_STAMP
@@ -288,8 +356,9 @@ k_em_persist(PersistArgs a) {
 #endif
     const uint32_t tid0 = threadIdx.x;
     // ---- the tile: what the hot phases need, as scalars; the rest of the record (e0, f0) is read where a far member needs it
-    uint32_t lo, nc, np, nm, n_esc, nf, off, nb_n, nb_before, n_ov, delta[kNbMax];
-    const uint4* __restrict__ c8p; const uint32_t* __restrict__ ovcp; const uint4* __restrict__ ov8p; const uint32_t* __restrict__ cnt;
+    uint32_t lo, nc, np, nm, n_esc, nf, off, nb_n, nb_before, delta[kNbMax];
+    uint32_t n1, n2, n3, n4, n_ov;                                       // the tile's records by size (k_pack_build): B1 | B2 | B3 | B4 in den[]'s order
+    const uint4* __restrict__ recs; const uint16_t* __restrict__ ovcp;   // recs: [B3 | B4 | overflow | B2 | B1]
     const uint4* __restrict__ pure; const uint16_t* __restrict__ slot0_p;
     uint32_t flags[kPS];
     // ---- what a thread keeps for the whole run: which of the overlapping tiles hold the position of its window slot (bits 0..5), whether
@@ -298,8 +367,16 @@ k_em_persist(PersistArgs a) {
     //      two blocks per CU), and those words sit in the L2.
     {
         const TileDesc t = a.tiles[blockIdx.x];
-        lo = t.lo; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before; n_ov = t.n_ov;
-        c8p = a.cls8 + t.c0; ovcp = a.ovc + t.ov0; ov8p = a.ov8 + t.ov0; cnt = a.counts + t.c0;
+        lo = t.lo; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before;
+        {
+            const TilePack pk = a.tp[blockIdx.x];
+            n1 = pk.n1; n2 = pk.n2; n3 = pk.n3; n4 = pk.n4; n_ov = pk.n_ov;
+            recs = a.recs + pk.a16; ovcp = a.ovc + pk.ov0;
+        }
+        {   // the count words: on chip for the whole run
+            const uint32_t* __restrict__ cnt = a.counts + t.c0;
+            for (uint32_t c = threadIdx.x; c < nc; c += kPB) cntl[c] = cnt[c];
+        }
         pure = reinterpret_cast<const uint4*>(a.csc + t.qb); slot0_p = a.csc_slot0 + t.pr;
         const uint32_t span = t.span;
         bool home[kPS];
@@ -434,15 +511,20 @@ k_em_persist(PersistArgs a) {
         // phase A's stream chunks and phase B's class counts: requested in the head once the operands are in (they miss the L2 -- a tile's
         // stream is read once per step and 64 tiles share 4 MB --, and the x arithmetic and the head's barrier hide the round trip);
         // phase C's first chunks are requested at the start of phase A
-        uint4 c8[kPAhead];                                                 // the thread's first class chunks (a chunk per class: see k_cls8_build)
-        uint32_t cw[kPAhead];                                               // ... and their counts; bit 31: singleton class, bit 30: long
+        // the thread's records (see k_pack_build): two of B1, one each of B2, B3, B4 -- the lanes are dealt differently per size so that
+        // the wavefronts' work evens out (B3 starts at the block's middle, B4 at its end)
+        uint32_t ra[2]; uint2 rb; uint4 rc, rd;
+#define SFP_I3 ((tid + kPB / 2) & (kPB - 1u))
+#define SFP_I4 (kPB - 1u - tid)
+        const uint2* __restrict__ r2p = reinterpret_cast<const uint2*>(recs + (n3 + n4 + n_ov));
+        const uint32_t* __restrict__ r1p = reinterpret_cast<const uint32_t*>(r2p + n2);
         auto request_stream = [&]() {
-#pragma unroll
-            for (int i = 0; i < kPAhead; ++i) {
-                const uint32_t c = tid + i * kPB;
-                c8[i] = make_uint4(0u, 0u, 0u, 0u); cw[i] = 0u;
-                if (c < nc) { c8[i] = c8p[SFP_IX(c)]; cw[i] = cnt[SFP_IX(c)]; }
-            }
+            ra[0] = ra[1] = 0u; rb = make_uint2(0u, 0u); rc = rd = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < n1) ra[0] = r1p[SFP_IX(tid)];
+            if (tid + kPB < n1) ra[1] = r1p[SFP_IX(tid + kPB)];
+            if (tid < n2) rb = r2p[SFP_IX(tid)];
+            if (SFP_I3 < n3) rc = recs[SFP_IX(SFP_I3)];
+            if (SFP_I4 < n4) rd = recs[n3 + SFP_IX(SFP_I4)];
         };
         const uint32_t tg = a.tag0 + s;                                      // the tag of what sweep s - 1 published: epoch | s
         if (s > 0u) {
@@ -581,7 +663,7 @@ k_em_persist(PersistArgs a) {
             __hip_atomic_store(&ctl[kCtlAbort * kCtlStride], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sctl[1] = 1u;
         }
-        for (uint32_t i = tid; i < nc; i += kPB) den[i] = 0.0;
+        for (uint32_t i = n1 + n2 + n3 + tid; i < nc; i += kPB) den[i] = 0.0;      // (B4 adds with atomics; every other class's word is written whole in phase A)
         if (nf) {                                                         // far members: the x of every far slot's transcript, once per step
             SFP_COLD(cp); SFP_TILE(tp);
             const uint32_t f0 = tp->f0;
@@ -614,23 +696,26 @@ k_em_persist(PersistArgs a) {
             for (int i = 0; i < kPCAhead; ++i) { pc_e[i] = make_uint4(0u, 0u, 0u, 0u); pc_s[i] = 0u; }
 #pragma unroll
             for (int i = 0; i < kPCAhead / 2; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) { pc_e[i] = pure[SFP_IX(ch)]; pc_s[i] = slot0_p[SFP_IX(ch)]; } }
-            auto chunk_sum = [&](const uint4& s4) -> double {                   // eight window slots (bit 15 of the first: the long flag)
-                const double v0 = xs[SFP_BANK(s4.x & 0x7FFFu, 0)], v1 = xs[SFP_BANK(s4.x >> 16, 1)], v2 = xs[SFP_BANK(s4.y & 0xFFFFu, 2)], v3 = xs[SFP_BANK(s4.y >> 16, 3)];
-                const double v4 = xs[SFP_BANK(s4.z & 0xFFFFu, 4)], v5 = xs[SFP_BANK(s4.z >> 16, 5)], v6 = xs[SFP_BANK(s4.w & 0xFFFFu, 6)], v7 = xs[SFP_BANK(s4.w >> 16, 7)];
-                return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+            // (x of three window slots of a dword; the null slot kWin reads 0)
+            auto sum3 = [&](uint32_t w) -> double { return (xs[SFP_BANK(w & 1023u, 0)] + xs[SFP_BANK((w >> 10) & 1023u, 1)]) + xs[SFP_BANK((w >> 20) & 1023u, 2)]; };
+            auto finish = [&](uint32_t c, double sum) {                          // :260-264; singletons carry the full count :275 / :364
+                const uint32_t cwc = cntl[c];
+                const double cn = (double)(cwc & 0x7FFFFFFFu);
+                den[c] = (cwc >> 31) ? cn : ((sum > kTiny) ? cn / sum : 0.0);
             };
-            auto class_chunk = [&](uint32_t c, const uint4& s4, uint32_t cwc) {
-                const double sum = chunk_sum(s4);
-                if (cwc & kCnt8Long) atomicAdd(&den[c], sum);              // (long: overflow chunks and far members add to it as well; phase B divides)
-                else {
-                    const double cn = (double)(cwc & 0x3FFFFFFFu);
-                    den[c] = (cwc >> 31) ? cn : ((sum > kTiny) ? cn / sum : 0.0);      // :260-264; singletons carry the full count :275 / :364
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < kPAhead; ++i) { const uint32_t c = tid + i * kPB; if (c < nc) class_chunk(c, c8[i], cw[i]); }
-            for (uint32_t c = tid + kPAhead * kPB; c < nc; c += kPB) class_chunk(c, c8p[SFP_IX(c)], cnt[SFP_IX(c)]);
-            for (uint32_t j = tid; j < n_ov; j += kPB) atomicAdd(&den[ovcp[j]], chunk_sum(ov8p[j]));
+            if (tid < n1) finish(tid, sum3(ra[0]));
+            if (tid + kPB < n1) finish(tid + kPB, sum3(ra[1]));
+            for (uint32_t c = tid + 2u * kPB; c < n1; c += kPB) finish(c, sum3(r1p[SFP_IX(c)]));
+            if (tid < n2) finish(n1 + tid, sum3(rb.x) + sum3(rb.y));
+            for (uint32_t c = tid + kPB; c < n2; c += kPB) { const uint2 w = r2p[SFP_IX(c)]; finish(n1 + c, sum3(w.x) + sum3(w.y)); }
+            auto sum12 = [&](const uint4& w) -> double { return (sum3(w.x) + sum3(w.y)) + (sum3(w.z) + sum3(w.w)); };
+            if (SFP_I3 < n3) finish(n1 + n2 + SFP_I3, sum12(rc));
+            for (uint32_t c = SFP_I3 + kPB; c < n3; c += kPB) finish(n1 + n2 + c, sum12(recs[SFP_IX(c)]));
+            // B4: more than twelve in-window members (overflow chunks), or a far member: everything adds with atomics, phase B divides
+            const uint32_t b4 = n1 + n2 + n3;
+            if (SFP_I4 < n4) atomicAdd(&den[b4 + SFP_I4], sum12(rd));
+            for (uint32_t c = SFP_I4 + kPB; c < n4; c += kPB) atomicAdd(&den[b4 + c], sum12(recs[n3 + SFP_IX(c)]));
+            for (uint32_t j = tid; j < n_ov; j += kPB) atomicAdd(&den[ovcp[j]], sum12(recs[n3 + n4 + SFP_IX(j)]));
             // far members (few tiles have any): class and far slot from the plan, x from the LDS copy the head made
             if (n_esc) {
                 for (uint32_t i = tid; i < n_esc; i += kPB) {
@@ -648,15 +733,13 @@ k_em_persist(PersistArgs a) {
         SFP_STAMP(3);                                                     // phase A + its barrier
         // ================= B: count / denom per class (:260-264; singletons carry the full count :275 / :364) =================
         {
-            auto invert = [&](uint32_t c, uint32_t cwc) {                        // the long classes (a singleton among them: its one member is a far one)
-                if (!(cwc & kCnt8Long)) return;
-                const double cn = (double)(cwc & 0x3FFFFFFFu);
+            // B4 only (a singleton among them: its one member is a far one)
+            for (uint32_t c = n1 + n2 + n3 + tid; c < nc; c += kPB) {
+                const uint32_t cwc = cntl[c];
+                const double cn = (double)(cwc & 0x7FFFFFFFu);
                 const double d = den[c];
                 den[c] = (cwc >> 31) ? cn : ((d > kTiny) ? cn / d : 0.0);
-            };
-#pragma unroll
-            for (int i = 0; i < kPAhead; ++i) { const uint32_t c = tid + i * kPB; if (c < nc) invert(c, cw[i]); }
-            for (uint32_t c = tid + kPAhead * kPB; c < nc; c += kPB) invert(c, cnt[SFP_IX(c)]);
+            }
         }
         __syncthreads();
         SFP_STAMP(4);                                                     // phase B + its barrier

@@ -151,14 +151,15 @@ def test_bootstrap_on_one_lane_runs_the_persistent_loop_on_the_resampled_counts(
     p.close()
 
 
-def test_a_class_of_2_to_the_30_reads_keeps_one_kernel_per_iteration(sf, gpu, local_table):
-    """bit 30 of the persistent loop's count words is its long-class flag: a plan with a class that large is not eligible"""
+def test_a_class_of_2_to_the_30_reads_runs_persistent(sf, gpu, local_table):
+    """the persistent loop's count words hold 31 bits of count (round 5 kept a flag in bit 30 and sent such a plan to one kernel per
+    iteration; the records of round 6 need no flag)"""
     m = local_table
     cc = m["counts"].copy(); cc[len(cc) // 2] = (1 << 30) + 12345
     R = int(cc.sum())
     rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], cc, R, max_iter=20, min_iter=20, tol=0.0)
     p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], cc, R)
     grc, st = p.optimize(max_iter=20, min_iter=20, tol=0.0)
-    assert grc == 0 and rc == 0 and not st["persistent"] and st["iters"] == ost["iters"]
+    assert grc == 0 and rc == 0 and st["persistent"] and st["iters"] == ost["iters"]
     assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT
     p.close()
