@@ -168,6 +168,54 @@ __device__ __forceinline__ double vb_x_fast(double a, double c, double len) {
     return ldexp(p * y, (int)kf) * rlen;
 }
 
+// The same arithmetic for the PERSISTENT loop's head (round 6).  There every tile is in the same phase at the same time (a tile needs its
+// neighbours' sums of the step before: lockstep), so the head's instructions are not hidden under another block's LDS phases and every
+// one of them is on the step's critical path -- and the constants of vb_x_fast arrived through 58 v_readlane per evaluation (22 doubles
+// loaded once, far more than the kernel's SGPRs hold: spilled into VGPR lanes).  Here a constant is two s_mov_b32 with literals right where
+// it is used (scalar ALU, no memory, no spill, never hoisted: the asm is volatile), and the two divisions are v_rcp_f64 + two Newton steps
+// (the operands are far from the denormals: a >= the prior, effLen >= 1) instead of the IEEE sequence.
+template <uint64_t B> __device__ __forceinline__ double kd_bits() {
+    uint32_t lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((uint32_t)B));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((uint32_t)(B >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define SF_KD(x) kd_bits<__builtin_bit_cast(uint64_t, (double)(x))>()
+__device__ __forceinline__ double fast_rcp(double x) {                 // 1 / x to ~1 ulp for normal x
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double vb_x_head(double a, double c, double len) {
+    double y = a, n = 0.0, d = 1.0;
+    if (a < 10.0) {
+        n = 1.0; d = a;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) { const double t = a + (double)k; n = fma(n, t, d); d = d * t; }
+        y = a + 10.0;
+    }
+    const double dy = d * y;
+    const double R = fast_rcp(dy * len);                               // the one reciprocal
+    const double inv = (d * len) * R;                                  // 1 / y
+    const double rlen = dy * R;                                        // 1 / effLen
+    const double inv2 = inv * inv;
+    double s = fma(-inv2, SF_KD(1.0 / 12.0), SF_KD(691.0 / 32760.0));   // inv2 (1/12 - inv2 (1/120 - inv2 (1/252 - inv2 (1/240 - inv2 (1/132 - inv2 (691/32760 - inv2 / 12))))))
+    s = fma(-inv2, s, SF_KD(1.0 / 132.0)); s = fma(-inv2, s, SF_KD(1.0 / 240.0)); s = fma(-inv2, s, SF_KD(1.0 / 252.0));
+    s = fma(-inv2, s, SF_KD(1.0 / 120.0)); s = fma(-inv2, s, SF_KD(1.0 / 12.0));
+    s = s * inv2;
+    const double t = -(c + fma(n * y, len * R, fma(0.5, inv, s)));      // -(c + n / d + 1 / (2 y) + s)   (n / d = n y effLen R)
+    const double kf = rint(t * SF_KD(1.4426950408889634074));
+    double r = fma(-kf, SF_KD(6.93147180369123816490e-01), t);
+    r = fma(-kf, SF_KD(1.90821492927058770002e-10), r);
+    double p = SF_KD(1.0 / 6227020800.0);
+    p = fma(p, r, SF_KD(1.0 / 479001600.0)); p = fma(p, r, SF_KD(1.0 / 39916800.0)); p = fma(p, r, SF_KD(1.0 / 3628800.0));
+    p = fma(p, r, SF_KD(1.0 / 362880.0)); p = fma(p, r, SF_KD(1.0 / 40320.0)); p = fma(p, r, SF_KD(1.0 / 5040.0)); p = fma(p, r, SF_KD(1.0 / 720.0));
+    p = fma(p, r, SF_KD(1.0 / 120.0)); p = fma(p, r, SF_KD(1.0 / 24.0)); p = fma(p, r, SF_KD(1.0 / 6.0)); p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    return ldexp(p * y, (int)kf) * rlen;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     return v;

@@ -449,8 +449,12 @@ k_em_persist(PersistArgs a) {
 #ifdef SFGPU_P_VBCHEAP                                                     // dev, timing only: VBEM with EM's x (what the digamma / exp chain of the head costs)
         if (VB) return (ap_ > kTiny) ? sweep_x<true>(ap_ / (l * a.log_norm)) : 0.0;
 #endif
-        if (VB) return (ap_ > kTiny) ? sweep_x<true>(vb_x_fast(ap_, a.log_norm, l)) : 0.0;       // :300-320
+#ifdef SFGPU_P_OLDHEAD                                                     // dev: the head's arithmetic of round 5 (vb_x_fast from constant memory, IEEE divisions)
+        if (VB) return (ap_ > kTiny) ? sweep_x<true>(vb_x_fast(ap_, a.log_norm, l)) : 0.0;
         return sweep_x<false>(ap_ / l);
+#endif
+        if (VB) return (ap_ > kTiny) ? sweep_x<true>(vb_x_head(ap_, a.log_norm, l)) : 0.0;       // :300-320
+        return sweep_x<false>(ap_ * fast_rcp(l));
     };
     // x of the far member behind far slot f of this tile (f0: the tile's first), for sweep s: sweep 0 reads the x vector, later sweeps
     // the granule the transcript's home thread published at the head of its step s
@@ -483,6 +487,7 @@ k_em_persist(PersistArgs a) {
 
     uint32_t k_done = 0;                                                 // updates done when the loop ends
     bool conv_last = false;
+    double lm_keep = -1.0;                                               // the thread's largest relative change in the last FINAL update
     for (uint32_t s = 0;; ++s) {
         // (the thread's index, opaque to the compiler once per step: left alone it hoists every per-thread address of the loop body --
         //  a dozen 64-bit pointers -- out of the loop and spills them)
@@ -639,7 +644,13 @@ k_em_persist(PersistArgs a) {
                 if (home[q]) {
                     const double gate = a.check_mode ? av[q] : ap_v[q];   // :852 vs :499
                     if (gate > kCheckCutoff) {
+#ifdef SFGPU_P_OLDHEAD
                         const double rel = fabs(av[q] - ap_v[q]) / ap_v[q];
+#else
+                        // (:852's gate makes ap > 1e-2: a reciprocal + Newton will do; :499's gate -- the bootstrap's -- is on the OLD alpha and
+                        //  leaves ap anything >= 0, 0 included: the IEEE division, whose infinity counts as "moved" like the reference's)
+                        const double rel = a.check_mode ? fabs(av[q] - ap_v[q]) / ap_v[q] : fabs(av[q] - ap_v[q]) * fast_rcp(ap_v[q]);
+#endif
                         if (rel > lm) lm = rel;                            // NaN never wins, as in the reference (:854)
                         if (rel > a.tol) ncv = 1u;
                         if (lm < 0.0) lm = 0.0;                            // gated at least once
@@ -647,9 +658,13 @@ k_em_persist(PersistArgs a) {
                     if (ft[q].y > ft[q].x) gr_store(a.far_off0 + 2u * a.far_stride, ft[q].x, xv[q], tg);     // a far target: its x for the tiles that hold it as a far member
                 }
             }
-            // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier)
+            // what the wavefront saw of update s (tentative until the stop test of update s - 1 is known, behind the barrier); the largest
+            // relative change stays in the thread's register and is reduced ONCE, when the loop has ended (round 6: six shuffle steps of a
+            // double in every wavefront of every step before)
+#ifdef SFGPU_P_OLDHEAD
             for (int o = kWave / 2; o > 0; o >>= 1) { const double m = __shfl_down(lm, o, kWave); if (m > lm) lm = m; }
             if (lane == 0u) wmax[(s & 1u) * kPWaves + wave] = lm;
+#endif
             if (__any(ncv != 0u) && lane == 0u) sctl[2u + (s & 1u)] = 1u;
         } else {
 #ifndef SFGPU_P_EARLY
@@ -682,6 +697,7 @@ k_em_persist(PersistArgs a) {
             // update s is final: alpha <- alpha' (home), and the block's word on it
 #pragma unroll
             for (int q = 0; q < kPS; ++q) if (home[q]) alpha[tid + q * kPB] = ap_v[q];
+            lm_keep = lm;
             if (tid == 0u) {
                 const uint32_t shard = blockIdx.x & (kShards - 1u);
                 unsigned long long inc = 1ull;
@@ -808,10 +824,16 @@ k_em_persist(PersistArgs a) {
 #endif
     if (k_done == 0xFFFFFFFFu) { if (tid == 0u) *cp->status = 1u; return; }
     if (k_done > 0u) {
+#ifdef SFGPU_P_OLDHEAD
+        const double wm = wmax[(k_done & 1u) * kPWaves + wave];
+#else
+        double wm = lm_keep;                                             // (update k_done was the last one declared final: its values are what the threads kept)
+        for (int o = kWave / 2; o > 0; o >>= 1) { const double m = __shfl_down(wm, o, kWave); if (m > wm) wm = m; }
+#endif
         // (the table has a row of kSweepBlock / kWave entries per tile, as the other loops fill it: a wavefront writes its maximum into every
         //  kPWaves-th of them)
         if (lane == 0u) for (uint32_t w2 = wave; w2 < (uint32_t)(kSweepBlock / kWave); w2 += kPWaves)
-            cp->tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + w2] = wmax[(k_done & 1u) * kPWaves + wave];
+            cp->tmax[((uint64_t)((k_done - 1u) & 1u) * gridDim.x + blockIdx.x) * (kSweepBlock / kWave) + w2] = wm;
         // positions no window holds are inactive transcripts here (a plan with far-only transcripts does not run persistent):
         // every update leaves them at the prior (VBEM, :318) or at 0
         const uint32_t n_unc = *cp->unc_n;
