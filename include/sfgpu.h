@@ -54,7 +54,11 @@ SFGPU_API int sfgpu_version(void);
  *   SFGPU_EM_NO_RENUMBER=1  the EM plan keeps the caller's transcript order whatever the labels look like
  *   SFGPU_EM_COVER_SORT=1 / SFGPU_EM_COVER_CHECK=1   tests: cover lists by sorting / both forms compared
  *   SFGPU_EQ_SUBBATCH=n     reads per sub-batch of the class build; SFGPU_EQ_HOST_CHUNK=n reads per staged chunk of a host batch
- *   SFGPU_BS_LANES=n        concurrent bootstrap replicates (1 .. 8, default 3)
+ *   SFGPU_BS_LANES=n        concurrent bootstrap replicates (1 .. 8; default: 1 where a replicate's EM loop runs as one persistent launch, else 3)
+ *   SFGPU_BS_PERSIST=1      several lanes keep the persistent loop (dev: they disturb each other's launches, profiles/r6_em_notes.md 4)
+ *   SFGPU_EM_XBUF=pool      the persistent loop's exchange buffer in ordinary pool memory instead of uncached device memory
+ *   SFGPU_EM_COOP=1         the persistent loop is launched with hipLaunchCooperativeKernel (a launch-time check of the grid's residency)
+ *   SFGPU_MN_TREE=levels    the bootstrap's multinomial tree with one launch per level (tests: the two-launch form gives the same counts)
  *   SFGPU_POOL_LARGE_LIMIT_GB=g   cached device blocks >= 1 GiB kept per device
  *   SFGPU_TIMING=1          plans described on stderr */
 SFGPU_API int sfgpu_has_variants(void);
@@ -315,8 +319,9 @@ SFGPU_API int sfgpu_em_time_sweep(sfgpu_em* em, const sfgpu_em_opts* opts, uint3
  *             draw with a host copy of alpha; return 0 to abort.  May be NULL.
  *   h_iters : per-draw iteration counts (host), may be NULL
  * opts->use_vbem / tol / max_iter are honoured; min_iter and check_mode are forced to doBootstrap's.
- * Up to three draws run concurrently (the handle plus internal clones of it, each on its own stream
- * and host thread; SFGPU_BS_LANES=1..8 overrides); draw b is the same whichever lane computes it and
+ * Where a replicate's EM loop runs as one persistent launch the draws run one after the other; elsewhere up to three
+ * run concurrently (the handle plus internal clones of it, each on its own stream and host thread);
+ * SFGPU_BS_LANES=1..8 overrides; draw b is the same whichever lane computes it and
  * `cb` is still called one draw at a time, in draw order.
  * Synchronous.  The handle's counts are restored afterwards.
  * ------------------------------------------------------------------------------------------- */

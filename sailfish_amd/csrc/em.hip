@@ -3242,7 +3242,19 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     sfgpu_em_opts o = *opts;
     o.min_iter = 0;            // doBootstrap has no 50-iteration floor (:486)
     o.check_mode = 1;          // and gates on alphas > 1e-2 (:499)
+    // Lanes.  Where the plan runs as ONE persistent launch per replicate, one lane is the fastest form (cfg3: 4.15 ms per replicate against
+    // 4.98 with three lanes of one kernel per iteration -- the persistent loop needs the chip to itself, see below); everywhere else
+    // three lanes fill each other's kernel boundaries.  SFGPU_BS_LANES overrides.
     uint32_t n_lanes = 3;
+    {
+        const char* fe = getenv("SFGPU_EM_FUSED"); const char* pe = getenv("SFGPU_EM_PERSIST");
+        bool may = !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->prob.C != 0 && em->xbuf && getenv("SFGPU_EM_EXACT_NORM") == nullptr &&
+                   o.max_iter >= 1u && o.max_iter < (1u << 24) - 2u && em->persist_ok != 0 && em->fused_ok != 0;
+        if (may && em->fused_ok < 0 && hipEventSynchronize(em->ev_plan) == hipSuccess)
+            em->fused_ok = ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 2u) == 0u && em->partial_a) ? 1 : 0;
+        if (may && em->fused_ok == 1 && em->persist_ok < 0) em_persist_check(em);
+        if (may && em->fused_ok == 1 && em->persist_ok == 1) n_lanes = 1;
+    }
     if (const char* e = getenv("SFGPU_BS_LANES")) { long v = atol(e); if (v >= 1 && v <= 8) n_lanes = (uint32_t)v; }
     if (n_lanes > n_bootstraps) n_lanes = n_bootstraps ? n_bootstraps : 1;
     while (em->bs_clones.size() + 1 < n_lanes) {        // clones are kept with the handle for the next call
@@ -3256,8 +3268,10 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
         if ((rc = em_bootstrap_prepare(c))) return rc;
     }
     // Several lanes keep one kernel per iteration.  The persistent loop needs the chip to itself: launched while another stream's kernels
-    // are in flight, tiles of one or two XCDs polled stale lines of the exchange buffer for 200 ms while memory held the tags their
-    // neighbours had published (profiles/r5_em_notes.md, section 6) -- the run then falls back, correct but late.  One lane runs persistent.
+    // are in flight, the last blocks of one or two XCDs never become resident -- blocks of the other kernel that came and went while a CU's
+    // first persistent block was placed leave its registers / LDS allocated in pieces, and the second 1024-thread block does not fit while
+    // the first one lives (profiles/r6_em_notes.md 4: start times of every block, kernel trace) -- the run then gives up after ~50 ms
+    // and falls back, correct but late.  One lane runs persistent.
     const bool lanes_persist = []() { const char* e = getenv("SFGPU_BS_PERSIST"); return e && atoi(e) != 0; }();
     em->no_persist = n_lanes > 1 && !lanes_persist;
     for (sfgpu_em* c : em->bs_clones) c->no_persist = n_lanes > 1 && !lanes_persist;

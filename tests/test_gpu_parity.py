@@ -915,6 +915,28 @@ def test_efflen_and_end_to_end_driver(sf, gpu, midsize, tmp_path):
 
 
 # -------------------------------------------------------------------------------- a15 / a17
+@pytest.mark.parametrize("n_classes", [1, 2, 700, 2048, 2049, 40_000, 300_000])
+def test_multinomial_tree_in_two_launches_equals_a_launch_per_level(sf, gpu, monkeypatch, n_classes):
+    """the resample (include/MultinomialSampler.hpp:13-64 as doBootstrap uses it, :468) as one block for the tree's top levels + one
+    block per subtree (round 6) against the form with a launch per level: same nodes, same Philox streams -- the same counts, bit for
+    bit, for trees of one block, of exactly one subtree, and of many"""
+    import torch
+    rng = np.random.default_rng(n_classes)
+    M = max(4, min(5000, n_classes + 3))
+    ids = rng.integers(0, M, n_classes).astype(np.uint32)
+    rowptr = np.arange(n_classes + 1, dtype=np.uint64)
+    counts = rng.integers(1, 2000, n_classes).astype(np.uint64)
+    counts[rng.integers(0, n_classes)] += 3_000_000                                  # one heavy class: BTPE in the upper levels
+    p = _gpu_em(sf, gpu, np.full(M, 1000.0), rowptr, ids, counts, int(counts.sum()))
+    for seed, draw in ((1, 0), (1, 1), (77, 5)):
+        monkeypatch.setenv("SFGPU_MN_TREE", "levels")
+        a = p.bootstrap_counts(seed, draw).cpu().numpy()
+        monkeypatch.delenv("SFGPU_MN_TREE")
+        b = p.bootstrap_counts(seed, draw).cpu().numpy()
+        assert int(a.sum()) == int(counts.sum()) and np.array_equal(a, b)
+    p.close()
+
+
 def test_multinomial_resample_is_exact_in_distribution(sf, gpu, midsize):
     """sampCounts of doBootstrap (:468): every draw sums to N; per-class counts are Binomial(N, p_c)"""
     m = midsize
