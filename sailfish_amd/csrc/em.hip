@@ -1703,6 +1703,7 @@ struct sfgpu_em {
     uint4* recs = nullptr; uint16_t* ovc = nullptr; TilePack* tp = nullptr; uint32_t *cnt8 = nullptr, *cpos = nullptr, *esc_cls_p = nullptr;      // phase A's class records (k_pack_build)
     unsigned char* csc_p = nullptr;                         // ... and the transcript-major copy with the permuted class positions (k_csc_remap)
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_side = nullptr;      // the plan's side stream (em_persist_plan)
     bool xbuf_uncached = false;                             // ... in UNCACHED device memory (the default; SFGPU_EM_XBUF=pool: an ordinary pool block)
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
@@ -1728,6 +1729,9 @@ static void em_free(sfgpu_em* em) {
     for (sfgpu_em* c : em->bs_clones) em_free(c);
     em->bs_clones.clear();
     if (em->stream) (void)hipStreamSynchronize(em->stream);
+    if (em->side) { (void)hipStreamSynchronize(em->side); stream_release(em->side); }
+    if (em->ev_fork) (void)hipEventDestroy(em->ev_fork);
+    if (em->ev_side) (void)hipEventDestroy(em->ev_side);
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
@@ -1975,6 +1979,39 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
     SF_HIP(pool_malloc(&em->pflags, 16));
     SF_HIP(hipMemsetAsync(em->pflags, 0, 16, st));
     const uint64_t En = E ? E : 1;
+    // The class records / the remapped transcript-major copy and the far-slot tables do not depend on each other (k_far_tiles writes f0 / nf
+    // of the tiles' records, k_pack_build reads e0 / n_esc): the first pair runs on a side stream next to the far tables' ~17 small kernels
+    hipStream_t s2 = st;
+    if (E) {
+        bool ok = em->side || stream_acquire(&em->side) == hipSuccess;
+        ok = ok && (em->ev_fork || hipEventCreateWithFlags(&em->ev_fork, hipEventDisableTiming) == hipSuccess);
+        ok = ok && (em->ev_side || hipEventCreateWithFlags(&em->ev_side, hipEventDisableTiming) == hipSuccess);
+        ok = ok && hipEventRecord(em->ev_fork, st) == hipSuccess && hipStreamWaitEvent(em->side, em->ev_fork, 0) == hipSuccess;
+        if (ok) s2 = em->side; else (void)hipGetLastError();
+    }
+    struct Join {                                             // (the side stream joins the plan's stream on every way out)
+        sfgpu_em* em; hipStream_t s2, st;
+        ~Join() { if (s2 != st) { (void)hipEventRecord(em->ev_side, s2); (void)hipStreamWaitEvent(st, em->ev_side, 0); } }
+    } join{em, s2, st};
+    {   // phase A's class records (k_pack_build: from the compact stream's 16-bit slots, the plan's rowptr and tile table) and phase C's
+        // transcript-major copy with the classes' permuted positions (k_csc_remap)
+        const uint64_t C = em->prob.C, Lnz = em->L, S8 = Lnz / 8 + 2 * (uint64_t)nt + 2;      // (a tile's stream is padded to whole chunks of 8)
+        SF_HIP(pool_malloc(&em->recs, (C + S8 + 4 * (uint64_t)nt + 4) * 16)); SF_HIP(pool_malloc(&em->ovc, S8 * 2));
+        SF_HIP(pool_malloc(&em->tp, (size_t)nt * sizeof(TilePack)));
+        SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->cpos, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->esc_cls_p, En * 4));
+        {
+            // (the tile's slots staged in LDS when they fit next to the kernel's 48 KB of tables: one block per CU then, which is what 512 tiles get anyway)
+            const uint32_t want = (em->tile_nnz + 7u) & ~7u, cap_slots = (160u * 1024u - 50u * 1024u) / 2u;
+            const uint32_t lds_slots = want <= cap_slots ? want : 0u;
+            if (lds_slots) SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pack_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_slots * 2u + 16u)));
+            hipLaunchKernelGGL(k_pack_build, dim3(nt), dim3(kSweepBlock), lds_slots ? lds_slots * 2u + 16u : 0u, s2, p_rowptr, em->tile_c0, em->tile_s0,
+                               reinterpret_cast<const uint16_t*>(em->lstream), em->td, em->esc_cls, em->recs, em->ovc, em->tp, em->cpos, em->esc_cls_p, lds_slots);
+        }
+        const uint64_t csc_bytes = 32 * (Lnz / 8 + nt + 1) + 32;                           // (as em->csc was sized)
+        SF_HIP(pool_malloc(&em->csc_p, csc_bytes));
+        hipLaunchKernelGGL(k_csc_remap, dim3(nt), dim3(kEmBlock), 0, s2, em->td, em->cpos, em->csc, em->csc_p, em->null_cls);
+        SF_CHECK_LAUNCH();
+    }
     if (E) {
         uint64_t *k_in = nullptr, *k_out = nullptr, *k2_in = nullptr, *k2_out = nullptr, *gsum = nullptr;
         uint32_t *v_in = nullptr, *v_out = nullptr, *head = nullptr, *esc_g = nullptr;
@@ -2001,19 +2038,6 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
         if ((rc = sort_pairs_u64_u32(k2_in, k2_out, v_in, v_out, E, st, 32 + pbits, false))) return rc;     // (values unused)
         hipLaunchKernelGGL(k_ft_ranges, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, k2_out, em->ftgt, em->ft_list);
         hipLaunchKernelGGL(k_far_xi, dim3(blocks_for(E)), dim3(kEmBlock), 0, st, E, gsum, em->far_pos, em->ftgt, em->cov2, em->far_xi, em->pflags);
-        SF_CHECK_LAUNCH();
-    }
-    {   // phase A's class records (k_pack_build: from the compact stream's 16-bit slots, the plan's rowptr and tile table) and phase C's
-        // transcript-major copy with the classes' permuted positions (k_csc_remap)
-        const uint64_t C = em->prob.C, Lnz = em->L, S8 = Lnz / 8 + 2 * (uint64_t)nt + 2;      // (a tile's stream is padded to whole chunks of 8)
-        SF_HIP(pool_malloc(&em->recs, (C + S8 + 4 * (uint64_t)nt + 4) * 16)); SF_HIP(pool_malloc(&em->ovc, S8 * 2));
-        SF_HIP(pool_malloc(&em->tp, (size_t)nt * sizeof(TilePack)));
-        SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->cpos, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->esc_cls_p, En * 4));
-        hipLaunchKernelGGL(k_pack_build, dim3(nt), dim3(kSweepBlock), 0, st, p_rowptr, em->tile_c0, em->tile_s0, reinterpret_cast<const uint16_t*>(em->lstream),
-                           em->td, em->esc_cls, em->recs, em->ovc, em->tp, em->cpos, em->esc_cls_p);
-        const uint64_t csc_bytes = 32 * (Lnz / 8 + nt + 1) + 32;                           // (as em->csc was sized)
-        SF_HIP(pool_malloc(&em->csc_p, csc_bytes));
-        hipLaunchKernelGGL(k_csc_remap, dim3(nt), dim3(kEmBlock), 0, st, em->td, em->cpos, em->csc, em->csc_p, em->null_cls);
         SF_CHECK_LAUNCH();
     }
     // [control words + status | part0 | part1 | far0 | far1 | xpub], every piece 256-byte aligned

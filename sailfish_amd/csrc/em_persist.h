@@ -149,18 +149,27 @@ __device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { 
 __global__ void __launch_bounds__(kSweepBlock)
 k_pack_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ tile_c0, const uint64_t* __restrict__ tile_s0,
              const uint16_t* __restrict__ slot16, const TileDesc* __restrict__ td, const uint32_t* __restrict__ esc_cls,
-             uint4* recs, uint16_t* ovc, TilePack* tp, uint32_t* cpos, uint32_t* esc_cls_p) {
+             uint4* recs, uint16_t* ovc, TilePack* tp, uint32_t* cpos, uint32_t* esc_cls_p, uint32_t lds_slots) {
     __shared__ uint16_t perm_l[8192];                                 // class in the tile -> its permuted position (pass 1: its rank in the thread's run)
     __shared__ uint32_t ext_l[8192];                                  // bucket << 30 | overflow chunks in front of the class's
+    extern __shared__ uint16_t slots_l[];                             // the tile's 16-bit slots, when they fit (lds_slots entries): the passes below read every
+                                                                      // slot twice, a lane walking its class -- from memory that was 82 us of cfg3's plan
     __shared__ unsigned long long wsum[kSweepBlock / kWave];
     __shared__ uint32_t wsum2[kSweepBlock / kWave];
     __shared__ uint32_t tot_s[5];
     const uint32_t T = blockIdx.x, c0 = tile_c0[T], c1 = tile_c0[T + 1], nc = c1 - c0, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint64_t s0 = tile_s0[T];
-    const uint32_t j0 = rowptr[c0];
+    const uint32_t j0 = rowptr[c0], nnz = rowptr[c1] - j0;
+    const bool in_lds = nnz <= lds_slots;
+    if (in_lds) {                                                     // coalesced: 16 bytes per lane (s0 is a multiple of 8 slots)
+        const uint4* src = reinterpret_cast<const uint4*>(slot16 + s0); uint4* dst = reinterpret_cast<uint4*>(slots_l);
+        for (uint32_t i = tid; i < (nnz + 7u) / 8u; i += kSweepBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint16_t* const slots_base = in_lds ? slots_l : slot16 + s0;
     auto bucket_of = [&](uint32_t c, uint32_t& n_in) -> uint32_t {
         const uint32_t b = rowptr[c0 + c], k = rowptr[c0 + c + 1] - b;
-        const uint16_t* sl = slot16 + s0 + (b - j0);
+        const uint16_t* sl = slots_base + (b - j0);
         n_in = 0; bool far = false;
         for (uint32_t m = 0; m < k; ++m) { if (sl[m] == (uint16_t)kWin) far = true; else ++n_in; }
         return (far || n_in > kRecSlots3) ? 3u : (n_in <= 3u ? 0u : (n_in <= 6u ? 1u : 2u));
@@ -208,7 +217,7 @@ k_pack_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ t
     uint2* const r2 = reinterpret_cast<uint2*>(rov + n_ov); uint32_t* const r1 = reinterpret_cast<uint32_t*>(r2 + n2);
     for (uint32_t c = tid; c < nc; c += kSweepBlock) {
         const uint32_t b = rowptr[c0 + c], k = rowptr[c0 + c + 1] - b;
-        const uint16_t* sl = slot16 + s0 + (b - j0);
+        const uint16_t* sl = slots_base + (b - j0);
         const uint32_t bk = ext_l[c] >> 30, pos = perm_l[c];
         uint32_t w[kRecSlots3], n = 0;
         uint32_t at = ov0 + (ext_l[c] & 0x3FFFFFFFu);
