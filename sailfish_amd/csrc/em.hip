@@ -2000,9 +2000,11 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
         SF_HIP(pool_malloc(&em->tp, (size_t)nt * sizeof(TilePack)));
         SF_HIP(pool_malloc(&em->cnt8, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->cpos, (C ? C : 1) * 4)); SF_HIP(pool_malloc(&em->esc_cls_p, En * 4));
         {
-            // (the tile's slots staged in LDS when they fit next to the kernel's 48 KB of tables: one block per CU then, which is what 512 tiles get anyway)
+            // (staging the tile's slots in LDS was measured: 82 -> 98 us on cfg3 -- the 36 KB leave one block per CU where three ran; lds_slots = 0
+            //  keeps the reads in memory, the kernel still takes the staged form for a build that asks for it)
             const uint32_t want = (em->tile_nnz + 7u) & ~7u, cap_slots = (160u * 1024u - 50u * 1024u) / 2u;
-            const uint32_t lds_slots = want <= cap_slots ? want : 0u;
+            const bool stage = []() { const char* e = SF_DEV_ENV("SFGPU_EM_PACK_LDS"); return e && atoi(e) != 0; }();
+            const uint32_t lds_slots = (stage && want <= cap_slots) ? want : 0u;
             if (lds_slots) SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pack_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_slots * 2u + 16u)));
             hipLaunchKernelGGL(k_pack_build, dim3(nt), dim3(kSweepBlock), lds_slots ? lds_slots * 2u + 16u : 0u, s2, p_rowptr, em->tile_c0, em->tile_s0,
                                reinterpret_cast<const uint16_t*>(em->lstream), em->td, em->esc_cls, em->recs, em->ovc, em->tp, em->cpos, em->esc_cls_p, lds_slots);
