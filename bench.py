@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline ...).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -208,7 +209,8 @@ def main():
     if a.one_device:
         local = 0
         if world > 1:
-            os.environ["SFGPU_EM_PERSIST"] = "0"     # several processes on ONE device: no kernel has the chip to itself (the persistent loop needs all its blocks resident)
+            from sailfish_amd import _lib as _sflib
+            _sflib.lib().sfgpu_em_allow_persistent(0)     # several processes on ONE device: no kernel has the chip to itself (the persistent loop needs all its blocks resident)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -434,6 +436,32 @@ def main():
         "class_build_reads_per_s": R_local / (build_ms * 1e-3),
         "roofline": dominant, "roofline_em_iteration": roof_em_iter, "roofline_em_sweep": roof_em, "roofline_class_build": roof_build,
     }
+    if world == 1:
+        # ---- what this N = 1 run implies for N = 2 / 4 / 8: a BUDGET made of this run's measured pieces plus
+        #      stated constants, so that the first SCALE record of an 8-GPU node can be read against it.  Nothing here was run on > 1 GPU.
+        #      build(N)  = insert kernels / N (reads shard with no exchange) + finish / export of the rank's own classes (unchanged)
+        #      merge(N)  = the owner all-to-all + disjoint all-gather of the (label, count, hash) table over xGMI, (N - 1) / N of it per rank,
+        #                  7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md) at half of peak, + 0.4 ms of launches and packing (cfg4 on one device)
+        #      EM        = replicated: this run's EM phase on every rank (no scaling);  sharded: iterations x (the sweep's fixed ~7 us + its
+        #                  per-nonzero part / N + one all-reduce of M doubles: 10 us measured with a one-rank RCCL communicator
+        #                  (profiles/r5_em_notes.md 6) + ~5 us per doubling of the ranks assumed for xGMI hops) -- `auto` takes the smaller
+        tbl_bytes = C * 20 + L * 4
+        link_GBs = 7 * 153.0 * 0.5
+        sweep_us = em_loop_ms_per_iter * 1e3
+        fixed_us = 6.9
+        pred = {}
+        for n in (2, 4, 8):
+            build = info["t_insert_ms"] / n + (build_ms - info["t_insert_ms"])
+            merge = 0.4 + tbl_bytes * (n - 1) / n / (link_GBs * 1e9) * 1e3 * 2
+            em_rep = em_ms
+            ar_us = 10.0 + 5.0 * math.log2(n)
+            em_sh = (em_ms - st["iters"] * sweep_us * 1e-3) + st["iters"] * (fixed_us + max(0.0, sweep_us - fixed_us) / n + 10.0 + ar_us) * 1e-3
+            step = build + merge + min(em_rep, em_sh) + info["t_efflen_ms"] + info["t_tpm_ms"]
+            pred[str(n)] = {"ms_per_step": step, "class_build": build, "merge": merge, "em_replicated": em_rep, "em_sharded": em_sh,
+                            "speedup_vs_this_run": (dt / a.steps * 1e3) / step}
+        out["multi_gpu"] = {"predicted_ms": pred,
+                            "predicted_from": "this N = 1 run's phase_ms + constants stated in bench.py / DESIGN.md 5 (xGMI 7 x 153 GB/s at half of peak, all-reduce of M "
+                                              "doubles 10 us with one rank + 5 us per doubling, sharded iteration = one sweep kernel + fold + all-reduce); NOT measured on > 1 GPU"}
     if host_leg is not None:
         # BASELINE.md 3 / SURVEY 8d time the step from host-pinned hit lists: this is the figure that answers them
         out["value_host_pinned"] = host_leg.get("value")

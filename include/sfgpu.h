@@ -180,7 +180,9 @@ SFGPU_API int sfgpu_eq_export_host(sfgpu_eq* eq, uint32_t* h_rowptr, uint32_t* h
 SFGPU_API int sfgpu_cf_gaussian(uint32_t max_frag_len, uint64_t mean, uint64_t sd, double* h_cf);
 /* correctionFactorsFromCounts :769-807 */
 SFGPU_API int sfgpu_cf_counts(const uint32_t* h_fl_counts, uint32_t max_frag_len, double* h_cf);
-/* computeSmoothedEffectiveLengths :809-838 ; setEffectiveLengthsDirect :706-715 when h_cf == NULL */
+/* computeSmoothedEffectiveLengths :809-838 ; setEffectiveLengthsDirect :706-715 when h_cf == NULL.
+ * Asynchronous on `stream`: the table h_cf is copied to the device by a stream-ordered copy, so a PINNED h_cf must stay valid and
+ * unchanged until the stream has passed this call (pageable memory is staged by the runtime before the call returns). */
 SFGPU_API int sfgpu_efflen_smoothed(const uint32_t* d_ref_len, uint64_t M, const double* h_cf, uint32_t max_frag_len,
                           double* d_eff_len, sfgpu_stream stream);
 /* --unsmoothedFLD: computeEmpiricalEffectiveLengths :717-767 over EmpiricalDistribution
@@ -261,6 +263,11 @@ SFGPU_API double* sfgpu_em_alpha_out(sfgpu_em* em);
 SFGPU_API double* sfgpu_em_alpha(sfgpu_em* em);
 SFGPU_API double* sfgpu_em_lengths(sfgpu_em* em);
 SFGPU_API int sfgpu_em_set_bounds(sfgpu_em* em, uint32_t min_iter, uint32_t max_iter);
+/* Process-wide: may optimize() / the bootstrap run the EM loop as ONE persistent launch (csrc/em_persist.h; the loop of
+ * src/CollapsedEMOptimizer.cpp:818-861)?  Default 1.  The launch needs every one of its blocks resident, i.e. the device to itself while
+ * it starts: processes or ranks that share a device call this with 0 (one kernel per iteration then; the same results).  Takes effect
+ * for runs that begin afterwards; handles planned while it was 0 have no tables for the loop and keep one kernel per iteration. */
+SFGPU_API int sfgpu_em_allow_persistent(int on);
 SFGPU_API int sfgpu_em_rebase(sfgpu_em* em, const double* d_len);
 /* The sharded loop as ONE call (classes partitioned over the GPUs, alpha replicated, one SUM all-reduce of
  * alphaOut per iteration): `em` holds THIS rank's slice of the classes; `allreduce` must leave the element-wise sum over

@@ -160,6 +160,7 @@ _SIGS = {
     "sfgpu_em_alpha": (_P, [_P]),
     "sfgpu_em_lengths": (_P, [_P]),
     "sfgpu_em_set_bounds": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "sfgpu_em_allow_persistent": (C.c_int, [C.c_int]),
     "sfgpu_em_rebase": (C.c_int, [_P, _P]),
     "sfgpu_em_time_sweep": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.POINTER(C.c_double)]),
     "sfgpu_bootstrap": (C.c_int, [_P, C.POINTER(EmOpts), C.c_uint32, C.c_uint64, _P, SAMPLE_CB, _P, _P]),

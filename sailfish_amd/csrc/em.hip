@@ -1651,6 +1651,8 @@ static inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kEmBlock 
 
 using namespace sfgpu;
 
+static std::atomic<bool> g_allow_persist{true};      // sfgpu_em_allow_persistent: the process-wide switch (ranks that share a device turn the loop off)
+
 struct sfgpu_em {
     hipStream_t user_stream = nullptr;
     hipStream_t stream = nullptr;          // own stream: graph capture is illegal on the null stream
@@ -1972,7 +1974,7 @@ static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint
 // Leaves em->pflags on the device ([0] != 0: this plan does not run persistent; [1]: the most far slots a tile has); sfgpu_em_create
 // queues their read-back.  Nothing is waited for.
 static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, const uint32_t* p_rowptr) {
-    static const bool off = []() { const char* e = getenv("SFGPU_EM_PERSIST"); return e && atoi(e) == 0; }();
+    const bool off = []() { const char* e = getenv("SFGPU_EM_PERSIST"); return e && atoi(e) == 0; }() || !g_allow_persist.load(std::memory_order_relaxed);
     if (off || 2 * P * 16ull + 3 * E * 16ull >= (1ull << 31)) return SFGPU_OK;                  // (granules are addressed with 32-bit byte offsets)
     const uint64_t M = em->prob.M;
     hipStream_t st = em->cur;
@@ -2426,6 +2428,8 @@ int sfgpu_em_init(sfgpu_em* em) { return sfgpu_em_init_impl(em); }
 double* sfgpu_em_alpha(sfgpu_em* em) { return em ? em->alpha : nullptr; }
 double* sfgpu_em_lengths(sfgpu_em* em) { return em ? em->lenc : nullptr; }
 
+int sfgpu_em_allow_persistent(int on) { g_allow_persist.store(on != 0, std::memory_order_relaxed); return SFGPU_OK; }
+
 int sfgpu_em_set_bounds(sfgpu_em* em, uint32_t min_iter, uint32_t max_iter) {
     SF_REQUIRE(em && em->begun && !em->in_optimize, SFGPU_ERR_STATE, "sfgpu_em_set_bounds: piecewise API only, after begin");
     em->opts.min_iter = min_iter; em->opts.max_iter = max_iter;
@@ -2774,7 +2778,7 @@ static int em_run(sfgpu_em* em, const sfgpu_em_opts* opts, double* d_alpha_out, 
     {
         const char* fe = getenv("SFGPU_EM_FUSED"); const char* pe = getenv("SFGPU_EM_PERSIST");
         const bool family = !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->fused_ok != 0 && em->prob.C != 0 &&
-                            (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 24) - 2u && em->persist_ok != 0 && em->xbuf && !em->no_persist;
+                            g_allow_persist.load(std::memory_order_relaxed) && (!em->opts.use_vbem || em->const_norm) && em->opts.max_iter >= 1u && em->opts.max_iter < (1u << 24) - 2u && em->persist_ok != 0 && em->xbuf && !em->no_persist;
         em->persist = family;
         if (family) em->fused = true;
         if (pe && atoi(pe) == 2) persist_ablate = 1;         // dev: no tag checks (timing only)
@@ -3274,7 +3278,7 @@ int sfgpu_bootstrap(sfgpu_em* em, const sfgpu_em_opts* opts, uint32_t n_bootstra
     uint32_t n_lanes = 3;
     {
         const char* fe = getenv("SFGPU_EM_FUSED"); const char* pe = getenv("SFGPU_EM_PERSIST");
-        bool may = !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->prob.C != 0 && em->xbuf && getenv("SFGPU_EM_EXACT_NORM") == nullptr &&
+        bool may = g_allow_persist.load(std::memory_order_relaxed) && !(fe && atoi(fe) == 0) && !(pe && atoi(pe) == 0) && em->gather && em->prob.C != 0 && em->xbuf && getenv("SFGPU_EM_EXACT_NORM") == nullptr &&
                    o.max_iter >= 1u && o.max_iter < (1u << 24) - 2u && em->persist_ok != 0 && em->fused_ok != 0;
         if (may && em->fused_ok < 0 && hipEventSynchronize(em->ev_plan) == hipSuccess)
             em->fused_ok = ((*reinterpret_cast<const uint32_t*>(em->h_plan + 4) & 2u) == 0u && em->partial_a) ? 1 : 0;

@@ -1,5 +1,5 @@
 // em_persist.h -- the whole EM / VBEM loop of optimize() as ONE launch (round 5).  Included by em.hip (inside namespace sfgpu,
-// behind k_sweep_lds: it uses TileDesc, sweep_x, vb_x_lean and the tile constants).
+// behind k_sweep_lds: it uses TileDesc, sweep_x, vb_x_head and the tile constants).
 //
 // Replaces the loop of src/CollapsedEMOptimizer.cpp:818-861 (while (itNum < minIter or (itNum < maxIter and !converged))
 // { EMUpdate_ / VBEMUpdate_; convergence test; swap; ++itNum }) for plans that fit the chip in one round of blocks.
@@ -25,8 +25,11 @@
 //     (by block mod 8: the XCD) behind an atomicMax of u on "the last update some transcript of mine moved in"; wave 0 reads them
 //     at the head of step u + 1, one sweep later -- by then they are complete unless a tile trails by a whole sweep.  converged_u
 //     <=> all maxima < u (a tile only reaches update u + 1 if the loop did not stop at u).
-// alpha', the gate, the relative change and x are formed exactly as in the fused kernel (same additions, same order, vb_x_lean);
-// a transcript's alpha lives in a register of its home thread for the whole run and goes to memory when the loop ends.
+// alpha', the gate and the relative change are formed as in the fused kernel (same additions, same order); x by vb_x_head / a
+// reciprocal (em.hip): the same recurrence, series and exp as the other loops' vb_x_lean / vb_x_fast with the divisions as a reciprocal
+// + two Newton steps -- agreement ~1e-13 relative, not bit identity: a run that falls back to one kernel per iteration (a give-up,
+// several bootstrap lanes) differs from the persistent one at that level, both within 1e-9 of the oracle (tests).  A transcript's alpha
+// is read and written by its home thread only and goes to memory at every final update.
 //
 // Every spin is bounded: a tile that waits ~1 s (a block that never became resident: another process holds the CUs) raises the
 // abort word, every other tile sees it in its own spins, the launch ends with status != 0 and em_run repeats the run with one

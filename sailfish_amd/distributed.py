@@ -180,7 +180,7 @@ class DistributedQuant:
         if self.world > 1 and isinstance(self.engine, HipEngine):
             # several ranks on ONE device (dry runs, the tests on a one-GPU box): no kernel of any rank has the chip to itself, and
             # the persistent EM loop (csrc/em_persist.h) needs all its blocks resident -- such ranks keep one kernel per iteration
-            import os, socket
+            import socket
             import torch
             import torch.distributed as dist
             dv = torch.device(self.engine.device)
@@ -188,7 +188,8 @@ class DistributedQuant:
             everyone = [None] * self.world
             dist.all_gather_object(everyone, me, group=group)
             if len(set(everyone)) < self.world:
-                os.environ["SFGPU_EM_PERSIST"] = "0"
+                from . import _lib
+                _lib.lib().sfgpu_em_allow_persistent(0)      # (a switch of the library, not of the process environment)
         self.em_mode = em_mode
         self.tol, self.max_iter, self.poll_every = tol, max_iter, poll_every
         self.min_iter = min_iter            # optimize()'s minIter is 50 (src/CollapsedEMOptimizer.cpp:716); tests shorten the loop

@@ -130,6 +130,28 @@ def test_persistent_loop_gives_up_and_the_run_is_repeated(sf, gpu, local_table, 
     assert grc == 0 and not st["persistent"] and st["iters"] == ost["iters"]
 
 
+def test_back_to_back_persistent_runs_with_other_counts_share_nothing(sf, gpu, local_table):
+    """two persistent launches behind each other on handles that recycle one exchange buffer, with DIFFERENT counts and the same
+    iteration counts (fixed 7 / 7, then to convergence): a granule of the earlier launch with the same step number must never
+    validate in the later one -- the tags carry a per-launch epoch (round 6), the buffer is zeroed before every launch and lives in
+    uncached memory.  Each run against the oracle on its own counts."""
+    m = local_table
+    rng = np.random.default_rng(5)
+    counts2 = (m["counts"].astype(np.int64) * rng.integers(1, 9, len(m["counts"]))).astype(np.uint64)
+    R2 = int(counts2.sum())
+    for kw in (dict(tol=0.0, min_iter=7, max_iter=7), dict()):
+        for vb in (False, True):
+            for cc, R in ((m["counts"], m["R"]), (counts2, R2), (m["counts"], m["R"])):
+                p = _gpu_em(sf, gpu, m["eff"], m["rowptr"], m["ids"], cc, R)           # (a new handle: the pool hands it the buffer the last one returned)
+                grc, st = p.optimize(use_vbem=vb, **kw)
+                rc, oa, om, ost = O.em_optimize(m["eff"], m["rowptr"], m["ids"], cc, R, use_vbem=vb, **kw)
+                assert grc == 0 and rc == 0 and st["persistent"] and st["iters"] == ost["iters"], (kw, vb, st, ost)
+                assert _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+                grc, st2 = p.optimize(use_vbem=vb, **kw)                                # ... and the same handle again
+                assert grc == 0 and st2["iters"] == ost["iters"] and _rel(p.alpha.cpu().numpy(), oa) < TIGHT
+                p.close()
+
+
 def test_bootstrap_on_one_lane_runs_the_persistent_loop_on_the_resampled_counts(sf, gpu, local_table, monkeypatch):
     """a replicate = the class counts resampled + the EM loop over them.  Several lanes keep one kernel per iteration (notes 5);
     ONE lane runs the persistent loop, whose count words are a copy with a flag bit: made again before every launch
