@@ -1703,7 +1703,8 @@ struct sfgpu_em {
     // the PERSISTENT loop (em_persist.h): far-slot tables, the exchange buffer (control words + granule arrays), the plan's verdict
     uint32_t *esc_far = nullptr, *far_pos = nullptr, *far_xi = nullptr, *ft_list = nullptr; uint2* ftgt = nullptr;
     uint4* recs = nullptr; uint16_t* ovc = nullptr; TilePack* tp = nullptr; uint32_t *cnt8 = nullptr, *cpos = nullptr, *esc_cls_p = nullptr;      // phase A's class records (k_pack_build)
-    unsigned char* csc_p = nullptr;                         // ... and the transcript-major copy with the permuted class positions (k_csc_remap)
+    uint4* cscp = nullptr;                                  // ... and the transcript-major copy with every chunk one slot's (k_cscp_build)
+    uint32_t *kv_tmp = nullptr, *idx_tmp = nullptr, *tin_tmp = nullptr;      // the plan's sorted nonzeros, kept until the persistent loop's tables are made
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_side = nullptr;      // the plan's side stream (em_persist_plan)
     bool xbuf_uncached = false;                             // ... in UNCACHED device memory (the default; SFGPU_EM_XBUF=pool: an ordinary pool block)
@@ -1738,7 +1739,7 @@ static void em_free(sfgpu_em* em) {
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
                     em->cov_ptr, em->cov_pos, em->pub_pos, em->bs_prefix, em->bs_base, em->bs_scratch_a, em->bs_scratch_b, em->lstream, em->esc_id, em->esc_cls, em->tile_s0, em->tile_esc0, em->chdr, em->csc, em->csc_slot0, em->tile_qb, em->tile_np, em->tile_pr,
-                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->recs, em->ovc, em->tp, em->cnt8, em->cpos, em->esc_cls_p, em->csc_p, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
+                    em->blkmax, em->tsum, em->inv, em->cperm, em->esc_far, em->far_pos, em->far_xi, em->ft_list, em->ftgt, em->recs, em->ovc, em->tp, em->cnt8, em->cpos, em->esc_cls_p, em->cscp, em->kv_tmp, em->idx_tmp, em->tin_tmp, em->pflags, em->partial_b, em->aout_b, em->aout_c, em->tmax, em->td, em->unc, em->partial_a, em->esc_slots, em->cov2, em->esc_pos, em->alphaP, em->lencP};
     for (void* b : bufs) if (b) pool_free(b);
     if (em->xbuf) { if (em->xbuf_uncached) uncached_free(em->xbuf); else pool_free(em->xbuf); }
     if (em->h_state) pinned_free(em->h_state);
@@ -1976,6 +1977,7 @@ static int em_renumber(sfgpu_em* em, const sfgpu_problem* prob, uint32_t L, uint
 static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, const uint32_t* p_rowptr) {
     const bool off = []() { const char* e = getenv("SFGPU_EM_PERSIST"); return e && atoi(e) == 0; }() || !g_allow_persist.load(std::memory_order_relaxed);
     if (off || 2 * P * 16ull + 3 * E * 16ull >= (1ull << 31)) return SFGPU_OK;                  // (granules are addressed with 32-bit byte offsets)
+    if (nt > 4096u) return SFGPU_OK;                            // (a plan of several rounds of tiles never runs persistent: no tables -- phase C's chunk array alone reserves 32 KB per tile)
     const uint64_t M = em->prob.M;
     hipStream_t st = em->cur;
     SF_HIP(pool_malloc(&em->pflags, 16));
@@ -2011,9 +2013,8 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
             hipLaunchKernelGGL(k_pack_build, dim3(nt), dim3(kSweepBlock), lds_slots ? lds_slots * 2u + 16u : 0u, s2, p_rowptr, em->tile_c0, em->tile_s0,
                                reinterpret_cast<const uint16_t*>(em->lstream), em->td, em->esc_cls, em->recs, em->ovc, em->tp, em->cpos, em->esc_cls_p, lds_slots);
         }
-        const uint64_t csc_bytes = 32 * (Lnz / 8 + nt + 1) + 32;                           // (as em->csc was sized)
-        SF_HIP(pool_malloc(&em->csc_p, csc_bytes));
-        hipLaunchKernelGGL(k_csc_remap, dim3(nt), dim3(kEmBlock), 0, s2, em->td, em->cpos, em->csc, em->csc_p, em->null_cls);
+        SF_HIP(pool_malloc(&em->cscp, (Lnz / 8 + 2048ull * nt + (uint64_t)nt + 8) * 16));      // (a tile: at most n8 / 8 + 2046 chunks, one partial chunk per key)
+        hipLaunchKernelGGL(k_cscp_build, dim3(nt), dim3(kSweepBlock), 0, s2, em->td, em->tp, em->cpos, em->kv_tmp, em->idx_tmp, em->tin_tmp, em->tile_s0, em->cscp, em->null_cls);
         SF_CHECK_LAUNCH();
     }
     if (E) {
@@ -2231,15 +2232,17 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             uint32_t *tmp = nullptr, *kv = nullptr, *idx = nullptr, *tin = nullptr, *chunks = nullptr, *pure = nullptr;
             uint64_t *cb = nullptr, *ps = nullptr;
             struct Scratch {                                  // the plan's temporaries go back to the pool on every way out
-                void** slots[8]; hipStream_t st;
-                ~Scratch() { void* ps[8]; for (int i = 0; i < 8; ++i) ps[i] = *slots[i]; pool_free_on_many(ps, 8, st); }
-            } scratch{{(void**)&tmp, (void**)&kv, (void**)&idx, (void**)&tin, (void**)&chunks, (void**)&pure, (void**)&cb, (void**)&ps}, em->cur};
+                void** slots[5]; hipStream_t st;
+                ~Scratch() { void* ps[5]; for (int i = 0; i < 5; ++i) ps[i] = *slots[i]; pool_free_on_many(ps, 5, st); }
+            } scratch{{(void**)&tmp, (void**)&chunks, (void**)&pure, (void**)&cb, (void**)&ps}, em->cur};
+            // (kv / idx / tin -- the tiles' nonzeros sorted by window slot -- live until em_persist_plan has made phase C's chunks from them)
             EM_TRY(pool_malloc(&em->chdr, (S / 8 + 1) * 4));
             // G: the number of chunks is only known on the device (cb[nt]); its bound -- every tile ends in a partial chunk --
             // sizes the arrays, and the flags behind the last real chunk stay 0, so no readback holds the plan up
             const uint64_t G = Lnz / 8 + nt + 1;
-            EM_TRY(pool_malloc(&tmp, Lnz * 4)); EM_TRY(pool_malloc(&kv, Lnz * 4));
-            EM_TRY(pool_malloc(&idx, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&tin, ((size_t)nt + 2) * 4));
+            EM_TRY(pool_malloc(&tmp, Lnz * 4)); EM_TRY(pool_malloc(&em->kv_tmp, Lnz * 4));
+            EM_TRY(pool_malloc(&em->idx_tmp, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&em->tin_tmp, ((size_t)nt + 2) * 4));
+            kv = em->kv_tmp; idx = em->idx_tmp; tin = em->tin_tmp;
             EM_TRY(pool_malloc(&chunks, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&cb, ((size_t)nt + 3) * 8));
             EM_TRY(pool_malloc(&em->tile_qb, ((size_t)nt + 2) * 8)); EM_TRY(pool_malloc(&em->tile_np, ((size_t)nt + 2) * 4)); EM_TRY(pool_malloc(&em->tile_pr, ((size_t)nt + 2) * 4));
             constexpr size_t kBuildLds = (size_t)kBuildWaves * kBuildBins * 4;
@@ -2345,6 +2348,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             {   // the persistent loop's tables (em_persist.h); its verdict rides on the read-back below
                 const int pr = em_persist_plan(em, nt, E, P, p_rowptr);
                 if (pr) { em_free(em); return pr; }
+                { void* ps3[3] = {em->kv_tmp, em->idx_tmp, em->tin_tmp}; pool_free_on_many(ps3, 3, em->cur); em->kv_tmp = em->idx_tmp = em->tin_tmp = nullptr; }
             }
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
             if (em->pflags) EM_TRY(hipMemcpyAsync(em->h_plan + 8, em->pflags, 16, hipMemcpyDeviceToHost, em->cur));
@@ -2715,7 +2719,7 @@ static int em_launch_persist(sfgpu_em* em, int ablate) {
     a.part_off[0] = (uint32_t)o; o += up(P * 16); a.part_off[1] = (uint32_t)o; o += up(P * 16);
     a.far_off0 = (uint32_t)o; a.far_stride = (uint32_t)up(En * 16);         // (far slots by parity, then the far targets' x)
     a.tiles = em->td; c.st = em->d_state; a.min_iter = em->opts.min_iter; a.max_iter = em->opts.max_iter; a.n_tiles = em->n_tiles; a.check_mode = em->opts.check_mode;
-    a.tp = em->tp; a.recs = em->recs; a.ovc = em->ovc; a.counts = em->cnt8; a.csc = em->csc_p; a.csc_slot0 = em->csc_slot0;
+    a.tp = em->tp; a.recs = em->recs; a.ovc = em->ovc; a.counts = em->cnt8; a.cscp = em->cscp;
     c.x = em->x; c.inv = em->inv;
     a.lenc = em->inv ? em->lencP : em->lenc; a.alpha = em->inv ? em->alphaP : em->alpha;
     c.esc_cls = em->esc_cls_p; c.esc_far = em->esc_far; c.far_pos = em->far_pos; c.far_xi = em->far_xi; a.ftgt = em->ftgt; c.ft_list = em->ft_list;

@@ -55,7 +55,10 @@ constexpr int kPB = SFGPU_PERSIST_BLOCK;                // threads of a block of
 constexpr int kPS = (kWin + kPB - 1) / kPB;             // window slots per thread: slot j of thread t is t + j * kPB
 constexpr int kPWaves = kPB / kWave;
 constexpr int kPAhead = kCntAhead * (kSweepBlock / kPB);      // class chunks (and counts) a thread requests ahead of phase A
-constexpr int kPCAhead = 2 * (kSweepBlock / kPB);       // transcript-major chunks a thread requests ahead of phase C
+#ifndef SFGPU_P_CAHEAD
+#define SFGPU_P_CAHEAD 2
+#endif
+constexpr int kPCAhead = SFGPU_P_CAHEAD * (kSweepBlock / kPB);       // transcript-major chunks a thread requests ahead of phase C
 static_assert(kPB % kWave == 0 && kPB <= kSweepBlock && kSweepBlock % kPB == 0, "block of the persistent loop");
 
 // ---- the plan's far-slot tables (sfgpu_em_create -> em_persist_plan) ----------------------------------------------------------
@@ -143,8 +146,12 @@ __global__ void k_far_xi(uint64_t E, const uint64_t* __restrict__ gsum, const ui
 // whose x arrives by atomic -- adds with atomics and needs phase B.  den[] is indexed by the permuted position; the transcript-major
 // copy of phase C is remapped once at plan time (k_csc_remap), the count words are scattered into permuted order before every launch
 // (k_persist_init) and live in the block's LDS for the whole run.  cfg3: 25 KB of records + 3 KB of overflow per tile and step.
-struct TilePack { uint32_t a16, n1, n2, n3, n4, n_ov, ov0, pad; };        // a16: the tile's first 16-byte unit in `recs`: [B3 | B4 | overflow | B2 | B1]
-static_assert(sizeof(TilePack) == 32, "two to a 64-byte line");
+struct TilePack {
+    uint32_t a16, n1, n2, n3, n4, n_ov, ov0;              // a16: the tile's first 16-byte unit in `recs`: [B3 | B4 | overflow | B2 | B1]
+    uint32_t nq;                                          // phase C: the tile's chunks in `cscp` (k_cscp_build), from unit q16
+    uint32_t q16, pad[7];
+};
+static_assert(sizeof(TilePack) == 64, "one 64-byte line");
 constexpr uint32_t kRecSlots3 = 12;                                   // slots of a 16-byte record / overflow chunk
 __device__ __forceinline__ uint32_t pack3(uint32_t a, uint32_t b, uint32_t c) { return a | (b << 10) | (c << 20); }
 // One block per tile.  recs: the tile's records start at unit a16 = c0 + s0 / 8 + 4 T (16 bytes per class bound the records, 2 bytes per
@@ -205,7 +212,7 @@ k_pack_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ t
     const uint32_t n1 = tot_s[0], n2 = tot_s[1], n3 = tot_s[2], n4 = tot_s[3], n_ov = tot_s[4];
     const uint32_t first[4] = {0u, n1, n1 + n2, n1 + n2 + n3};
     const uint32_t a16 = c0 + (uint32_t)(s0 / 8u) + 4u * T, ov0 = (uint32_t)(s0 / 8u) + T;
-    if (tid == 0u) { TilePack r; r.a16 = a16; r.n1 = n1; r.n2 = n2; r.n3 = n3; r.n4 = n4; r.n_ov = n_ov; r.ov0 = ov0; r.pad = 0u; tp[T] = r; }
+    if (tid == 0u) { tp[T].a16 = a16; tp[T].n1 = n1; tp[T].n2 = n2; tp[T].n3 = n3; tp[T].n4 = n4; tp[T].n_ov = n_ov; tp[T].ov0 = ov0; }      // (nq / q16: k_cscp_build)
     // pass 2: the permuted position
     for (uint32_t c = q0; c < q1; ++c) {
         const uint32_t bk = ext_l[c] >> 30;
@@ -250,21 +257,58 @@ k_pack_build(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ t
     const uint32_t n_esc = td[T].n_esc; const uint64_t e0 = td[T].e0;
     for (uint32_t i = tid; i < n_esc; i += kSweepBlock) { const uint32_t t = esc_cls[e0 + i]; esc_cls_p[e0 + i] = ((uint32_t)perm_l[(t >> 16) & 0x1FFFu] << 16) | (t & kSingle); }
 }
-// the transcript-major copy with the classes' permuted positions (the padding's null class stays)
-__global__ void __launch_bounds__(kEmBlock)
-k_csc_remap(const TileDesc* __restrict__ td, const uint32_t* __restrict__ cpos, const unsigned char* __restrict__ csc, unsigned char* csc_p, uint32_t null_cls) {
-    const TileDesc& t = td[blockIdx.x];
-    const uint32_t c0 = t.c0, nc = t.nc, np = t.np, nm = t.nm;
-    const uint4* src = reinterpret_cast<const uint4*>(csc + t.qb); uint4* dst = reinterpret_cast<uint4*>(csc_p + t.qb);
-    auto remap = [&](uint32_t v) -> uint32_t {
-        const uint32_t a = v & 0xFFFFu, b = v >> 16;
-        const uint32_t a2 = a < nc ? cpos[c0 + a] - c0 : null_cls, b2 = b < nc ? cpos[c0 + b] - c0 : null_cls;
-        return a2 | (b2 << 16);
-    };
-    for (uint32_t j = threadIdx.x; j < np + 2u * nm; j += kEmBlock) {
-        uint4 v = src[j];
-        if (j < np || ((j - np) & 1u) == 0u) v = make_uint4(remap(v.x), remap(v.y), remap(v.z), remap(v.w));      // (a mixed chunk's second half holds slots)
-        dst[j] = v;
+// ---- phase C's stream for the persistent loop (round 6): every chunk PURE -------------------------------------------------------------
+// The transcript-major copy of k_sweep_lds keeps a tile's nonzeros sorted by window slot in chunks of 8 whatever the slots' runs look
+// like: a chunk that straddles two slots is MIXED (8 classes + 8 slots, 32 bytes, walked run by run: ~100 instructions, two loads, up
+// to 8 atomics) -- a fifth of cfg3's chunks, and they cost the persistent loop 1.0 - 2.2 us of a step (`-DSFGPU_P_NOMIXED`: cfg3 VBEM
+// 12.9 -> 10.6 us without them, which also drops their 20 % of the work).  Here a slot's run is padded to whole chunks with the null class
+// (count / denominator 0), so every chunk is one slot: eight 13-bit class positions (permuted: k_pack_build) and the slot + singleton
+// bit in the dwords' spare bits -- 16 bytes, one load, eight LDS reads, one atomic; ~10 % more chunks than pure + mixed before, no second
+// loop, no slot array.  Built from the tile's sorted nonzeros (kv: key << 16 | class in the tile, key = singleton << 11 | slot, stable: the
+// order of k_tile_build), so the sums are formed in the same order in every plan.
+//   chunk = { c0 | c1 << 13 | slot[5:0] << 26,  c2 | c3 << 13 | slot[9:6] << 26 | single << 31,  c4 | c5 << 13,  c6 | c7 << 13 }
+__global__ void __launch_bounds__(kSweepBlock)
+k_cscp_build(const TileDesc* __restrict__ td, TilePack* tp, const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ kv,
+             const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tile_in, const uint64_t* __restrict__ tile_s0, uint4* cscp, uint32_t null_cls) {
+    __shared__ uint32_t start[kEscBin + 1];                              // first entry of key b among the tile's sorted nonzeros
+    __shared__ uint32_t coff[kEscBin + 1];                               // first chunk of key b
+    __shared__ uint32_t wsum[kSweepBlock / kWave];
+    const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t c0 = td[T].c0, j0 = idx[T], n = tile_in[T];
+    const uint32_t* __restrict__ e = kv + j0;
+    for (uint32_t b = tid; b <= kEscBin; b += kSweepBlock) {              // lower bound of key b (the escape bin's start = n)
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((e[mid] >> 16) >= b) hi = mid; else lo = mid + 1u; }
+        start[b] = lo;
+    }
+    __syncthreads();
+    constexpr uint32_t kPer = (kEscBin + kSweepBlock - 1) / kSweepBlock;  // bins per thread in the scan (3)
+    uint32_t mine[kPer], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) { const uint32_t b = tid * kPer + k; mine[k] = b < kEscBin ? (start[b + 1] - start[b] + 7u) >> 3 : 0u; sum += mine[k]; }
+    uint32_t incl = sum;
+    for (int o = 1; o < kWave; o <<= 1) { const uint32_t v = __shfl_up(incl, o, kWave); if ((int)lane >= o) incl += v; }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) { const uint32_t b = tid * kPer + k; if (b < kEscBin) coff[b] = base; base += mine[k]; }
+    if (tid == kSweepBlock - 1u) coff[kEscBin] = base;
+    __syncthreads();
+    const uint32_t nq = coff[kEscBin];
+    const uint32_t q16 = (uint32_t)(tile_s0[T] / 8u) + 2048u * T;          // (a tile of n8 padded nonzeros has at most n8 / 8 + 2046 chunks: one partial chunk per key)
+    if (tid == 0u) { tp[T].nq = nq; tp[T].q16 = q16; }
+    for (uint32_t j = tid; j < nq; j += kSweepBlock) {
+        uint32_t lo = 0, hi = kEscBin;                                   // the last key whose first chunk is <= j (keys without entries share their successor's offset)
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= j) lo = mid; else hi = mid; }
+        while (coff[lo + 1u] <= j) ++lo;                                  // (cannot run past kEscBin - 1: j < nq = coff[kEscBin])
+        const uint32_t b = lo, first = start[b] + 8u * (j - coff[b]), end = start[b + 1];
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) c[k] = first + k < end ? cpos[c0 + (e[first + k] & 0xFFFFu)] - c0 : null_cls;
+        const uint32_t slot = b & 0x3FFu, single = (b & 0x800u) ? 1u : 0u;
+        cscp[q16 + j] = make_uint4(c[0] | (c[1] << 13) | ((slot & 63u) << 26), c[2] | (c[3] << 13) | ((slot >> 6) << 26) | (single << 31), c[4] | (c[5] << 13), c[6] | (c[7] << 13));
     }
 }
 
@@ -282,7 +326,7 @@ struct PersistArgs {
     uint32_t min_iter, max_iter, n_tiles; int check_mode;
     const TilePack* tp; const uint4* recs; const uint16_t* ovc;    // phase A: a record per class in four sizes, the overflow chunks' classes (k_pack_build)
     const uint32_t* counts;                               // cnt8: count | singleton << 31, in the tiles' permuted class order
-    const unsigned char* csc; const uint16_t* csc_slot0;  // phase C: the transcript-major copy with permuted class positions (k_csc_remap)
+    const uint4* cscp;                                    // phase C: the transcript-major copy, every chunk one slot's (k_cscp_build)
     const double* lenc; double* alpha;                    // by position of the plan's order
     const uint2* ftgt;                                    // per position: [k0, k1) of ft_list (null: the plan has no far members)
     // the exchange buffer: ONE buffer descriptor, the pieces by byte offset; part_off: granules of the window sums, slot-major
@@ -368,10 +412,10 @@ k_em_persist(PersistArgs a) {
 #endif
     const uint32_t tid0 = threadIdx.x;
     // ---- the tile: what the hot phases need, as scalars; the rest of the record (e0, f0) is read where a far member needs it
-    uint32_t lo, nc, np, nm, n_esc, nf, off, nb_n, nb_before, delta[kNbMax];
+    uint32_t lo, nc, np, n_esc, nf, off, nb_n, nb_before, delta[kNbMax];
     uint32_t n1, n2, n3, n4, n_ov;                                       // the tile's records by size (k_pack_build): B1 | B2 | B3 | B4 in den[]'s order
     const uint4* __restrict__ recs; const uint16_t* __restrict__ ovcp;   // recs: [B3 | B4 | overflow | B2 | B1]
-    const uint4* __restrict__ pure; const uint16_t* __restrict__ slot0_p;
+    const uint4* __restrict__ pure;                                      // the tile's chunks of phase C (all of one slot each: k_cscp_build)
     uint32_t flags[kPS];
     // ---- what a thread keeps for the whole run: which of the overlapping tiles hold the position of its window slot (bits 0..5), whether
     //      it has a slot (bit 30) and whether this tile is the position's home (bit 31).  Everything else it needs per step (effLen,
@@ -379,17 +423,17 @@ k_em_persist(PersistArgs a) {
     //      two blocks per CU), and those words sit in the L2.
     {
         const TileDesc t = a.tiles[blockIdx.x];
-        lo = t.lo; nc = t.nc; np = t.np; nm = t.nm; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before;
+        lo = t.lo; nc = t.nc; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before;
         {
             const TilePack pk = a.tp[blockIdx.x];
             n1 = pk.n1; n2 = pk.n2; n3 = pk.n3; n4 = pk.n4; n_ov = pk.n_ov;
             recs = a.recs + pk.a16; ovcp = a.ovc + pk.ov0;
+            np = pk.nq; pure = a.cscp + pk.q16;
         }
         {   // the count words: on chip for the whole run
             const uint32_t* __restrict__ cnt = a.counts + t.c0;
             for (uint32_t c = threadIdx.x; c < nc; c += kPB) cntl[c] = cnt[c];
         }
-        pure = reinterpret_cast<const uint4*>(a.csc + t.qb); slot0_p = a.csc_slot0 + t.pr;
         const uint32_t span = t.span;
         bool home[kPS];
 #pragma unroll
@@ -718,12 +762,12 @@ k_em_persist(PersistArgs a) {
             }
         }
         // ================= A: denominators =================
-        uint4 pc_e[kPCAhead]; uint32_t pc_s[kPCAhead];                   // phase C's first chunks: half of them requested here, half at the end of A
+        uint4 pc_e[kPCAhead];                                            // phase C's first chunks: half of them requested here, half at the end of A
         {
 #pragma unroll
-            for (int i = 0; i < kPCAhead; ++i) { pc_e[i] = make_uint4(0u, 0u, 0u, 0u); pc_s[i] = 0u; }
+            for (int i = 0; i < kPCAhead; ++i) pc_e[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-            for (int i = 0; i < kPCAhead / 2; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) { pc_e[i] = pure[SFP_IX(ch)]; pc_s[i] = slot0_p[SFP_IX(ch)]; } }
+            for (int i = 0; i < kPCAhead / 2; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) pc_e[i] = pure[SFP_IX(ch)]; }
             // (x of three window slots of a dword; the null slot kWin reads 0)
             auto sum3 = [&](uint32_t w) -> double { return (xs[SFP_BANK(w & 1023u, 0)] + xs[SFP_BANK((w >> 10) & 1023u, 1)]) + xs[SFP_BANK((w >> 20) & 1023u, 2)]; };
             auto finish = [&](uint32_t c, double sum) {                          // :260-264; singletons carry the full count :275 / :364
@@ -755,7 +799,7 @@ k_em_persist(PersistArgs a) {
                 }
             }
 #pragma unroll
-            for (int i = kPCAhead / 2; i < kPCAhead; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) { pc_e[i] = pure[SFP_IX(ch)]; pc_s[i] = slot0_p[SFP_IX(ch)]; } }
+            for (int i = kPCAhead / 2; i < kPCAhead; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) pc_e[i] = pure[SFP_IX(ch)]; }
         }
         __syncthreads();
         SFP_STAMP(3);                                                     // phase A + its barrier
@@ -773,35 +817,17 @@ k_em_persist(PersistArgs a) {
         SFP_STAMP(4);                                                     // phase B + its barrier
         // ================= C: the window (a gather over the transcript-major copy) =================
         {
-            auto pure_chunk = [&](const uint4& e4, uint32_t sf) {
-                const double q0 = den[SFP_BANK(e4.x & 0x1FFFu, 0)], q1_ = den[SFP_BANK((e4.x >> 16) & 0x1FFFu, 1)], q2_ = den[SFP_BANK(e4.y & 0x1FFFu, 2)], q3 = den[SFP_BANK((e4.y >> 16) & 0x1FFFu, 3)];
-                const double q4 = den[SFP_BANK(e4.z & 0x1FFFu, 4)], q5 = den[SFP_BANK((e4.z >> 16) & 0x1FFFu, 5)], q6 = den[SFP_BANK(e4.w & 0x1FFFu, 6)], q7 = den[SFP_BANK((e4.w >> 16) & 0x1FFFu, 7)];
+            auto pure_chunk = [&](const uint4& e4) {                              // eight classes of ONE slot (k_cscp_build): slot and singleton bit in the spare bits
+                const double q0 = den[SFP_BANK(e4.x & 0x1FFFu, 0)], q1_ = den[SFP_BANK((e4.x >> 13) & 0x1FFFu, 1)], q2_ = den[SFP_BANK(e4.y & 0x1FFFu, 2)], q3 = den[SFP_BANK((e4.y >> 13) & 0x1FFFu, 3)];
+                const double q4 = den[SFP_BANK(e4.z & 0x1FFFu, 4)], q5 = den[SFP_BANK((e4.z >> 13) & 0x1FFFu, 5)], q6 = den[SFP_BANK(e4.w & 0x1FFFu, 6)], q7 = den[SFP_BANK((e4.w >> 13) & 0x1FFFu, 7)];
                 const double sum = ((q0 + q1_) + (q2_ + q3)) + ((q4 + q5) + (q6 + q7));
-                const uint32_t slot = sf & 0x7FFFu;
-                const double v = (sf & kCscSingleBit) ? sum : xs[slot] * sum;
+                const uint32_t slot = (e4.x >> 26) | (((e4.y >> 26) & 15u) << 6);
+                const double v = (e4.y >> 31) ? sum : xs[slot] * sum;
                 if (v != 0.0) atomicAdd(&acc[slot], v);
             };
 #pragma unroll
-            for (int i = 0; i < kPCAhead; ++i) if (tid + i * kPB < np) pure_chunk(pc_e[i], pc_s[i]);
-            for (uint32_t ch = tid + kPCAhead * kPB; ch < np; ch += kPB) pure_chunk(pure[SFP_IX(ch)], slot0_p[SFP_IX(ch)]);
-            const uint4* __restrict__ mixed = pure + np;
-            for (uint32_t ch = tid; ch < nm; ch += kPB) {
-                const uint4 e4 = mixed[2u * ch], s4 = mixed[2u * ch + 1u];
-                uint32_t cur = s4.x & 0xFFFFu;
-                double sum = 0.0;
-                auto flush_run = [&]() {
-                    const uint32_t slot = cur & 0x7FFFu;
-                    const double v = (cur & kCscSingleBit) ? sum : xs[slot] * sum;
-                    if (v != 0.0) atomicAdd(&acc[slot], v);
-                };
-                auto entry = [&](uint32_t cls, uint32_t sfk) {
-                    if (sfk != cur) { flush_run(); cur = sfk; sum = 0.0; }
-                    sum += den[cls & 0x1FFFu];
-                };
-                entry(e4.x & 0xFFFFu, s4.x & 0xFFFFu); entry(e4.x >> 16, s4.x >> 16); entry(e4.y & 0xFFFFu, s4.y & 0xFFFFu); entry(e4.y >> 16, s4.y >> 16);
-                entry(e4.z & 0xFFFFu, s4.z & 0xFFFFu); entry(e4.z >> 16, s4.z >> 16); entry(e4.w & 0xFFFFu, s4.w & 0xFFFFu); entry(e4.w >> 16, s4.w >> 16);
-                flush_run();
-            }
+            for (int i = 0; i < kPCAhead; ++i) if (tid + i * kPB < np) pure_chunk(pc_e[i]);
+            for (uint32_t ch = tid + kPCAhead * kPB; ch < np; ch += kPB) pure_chunk(pure[SFP_IX(ch)]);
             if (n_esc) {                                                     // far members: into the tile's far slots
                 for (uint32_t i = tid; i < n_esc; i += kPB) {
                     uint2 e;

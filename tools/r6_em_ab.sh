@@ -4,9 +4,9 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 {
-echo "=== tests"; timeout 1500 python -m pytest tests/test_gpu_persist.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "em or EM or persist or vbem or optimize or cfg or bootstrap or far or shuffled or fused or tpm" 2>&1 | tail -8
+echo "=== tests"; timeout 1500 python -m pytest tests/test_gpu_persist.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -5
 echo "--- product"; EMP_MODES=persist timeout 300 python tools/r5_persist_probe.py 2>&1 | grep -E "==|us/iter" | cut -c1-150
-for name in base "$@"; do echo "--- $name"
+for name in "$@"; do echo "--- $name"
   SFGPU_LIB_PATH=$PWD/sailfish_amd/csrc/variants/libsfgpu_$name.so EMP_MODES=persist timeout 300 python tools/r5_persist_probe.py 2>&1 | grep -E "us/iter" | cut -c1-150
 done
 } > gpurun_out/r6_em_ab.log 2>&1
