@@ -710,6 +710,14 @@ __global__ void k_tile_desc(uint32_t n_tiles, const uint32_t* __restrict__ tile_
     if (tile_qb) { r.qb = tile_qb[T]; r.np = tile_np[T]; r.nm = (uint32_t)((tile_qb[T + 1] - r.qb - 16ull * r.np) >> 5); r.pr = tile_pr[T]; }
     td[T] = r;
 }
+// the transcript-major copy's fields of the tile records, written when that copy's offsets are known (it is laid out on the plan's side
+// stream, next to the cover lists: sfgpu_em_create)
+__global__ void k_tile_desc_csc(uint32_t n_tiles, const uint64_t* __restrict__ tile_qb, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_pr, TileDesc* td) {
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= n_tiles) return;
+    const uint64_t qb = tile_qb[T]; const uint32_t np = tile_np[T];
+    td[T].qb = qb; td[T].np = np; td[T].nm = (uint32_t)((tile_qb[T + 1] - qb - 16ull * np) >> 5); td[T].pr = tile_pr[T];
+}
 __global__ void k_nb_table(uint32_t n_tiles, const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_span,
                            const uint64_t* __restrict__ tile_off, TileDesc* td, unsigned int* flags) {
     const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1706,7 +1714,8 @@ struct sfgpu_em {
     uint4* cscp = nullptr;                                  // ... and the transcript-major copy with every chunk one slot's (k_cscp_build)
     uint32_t *kv_tmp = nullptr, *idx_tmp = nullptr, *tin_tmp = nullptr;      // the plan's sorted nonzeros, kept until the persistent loop's tables are made
     unsigned char* xbuf = nullptr; size_t xbuf_bytes = 0;   // [control words | status | part0 | part1 | far0 | far1 | xpub]
-    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_side = nullptr;      // the plan's side stream (em_persist_plan)
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_td = nullptr;      // the plan's side stream (sfgpu_em_create)
+    bool side_live = false;                                 // ... forked and not yet joined
     bool xbuf_uncached = false;                             // ... in UNCACHED device memory (the default; SFGPU_EM_XBUF=pool: an ordinary pool block)
     uint32_t* pflags = nullptr;                             // device: [0] plan flags (!= 0: not eligible), [1] most far slots of a tile
     int persist_ok = -1;                                    // -1: not looked at yet; 0: this plan (or this device) does not run persistent
@@ -1735,6 +1744,7 @@ static void em_free(sfgpu_em* em) {
     if (em->side) { (void)hipStreamSynchronize(em->side); stream_release(em->side); }
     if (em->ev_fork) (void)hipEventDestroy(em->ev_fork);
     if (em->ev_side) (void)hipEventDestroy(em->ev_side);
+    if (em->ev_td) (void)hipEventDestroy(em->ev_td);
     if (em->graph) (void)hipGraphExecDestroy(em->graph);
     void* bufs[] = {em->alpha, em->alpha_out, em->x, em->lenc, em->partials, em->sum_partials, em->scratch,
                     em->counts32, em->d_state, em->tile_lo, em->tile_c0, em->tile_span, em->tile_off, em->partial,
@@ -1985,18 +1995,7 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
     const uint64_t En = E ? E : 1;
     // The class records / the remapped transcript-major copy and the far-slot tables do not depend on each other (k_far_tiles writes f0 / nf
     // of the tiles' records, k_pack_build reads e0 / n_esc): the first pair runs on a side stream next to the far tables' ~17 small kernels
-    hipStream_t s2 = st;
-    if (E) {
-        bool ok = em->side || stream_acquire(&em->side) == hipSuccess;
-        ok = ok && (em->ev_fork || hipEventCreateWithFlags(&em->ev_fork, hipEventDisableTiming) == hipSuccess);
-        ok = ok && (em->ev_side || hipEventCreateWithFlags(&em->ev_side, hipEventDisableTiming) == hipSuccess);
-        ok = ok && hipEventRecord(em->ev_fork, st) == hipSuccess && hipStreamWaitEvent(em->side, em->ev_fork, 0) == hipSuccess;
-        if (ok) s2 = em->side; else (void)hipGetLastError();
-    }
-    struct Join {                                             // (the side stream joins the plan's stream on every way out)
-        sfgpu_em* em; hipStream_t s2, st;
-        ~Join() { if (s2 != st) { (void)hipEventRecord(em->ev_side, s2); (void)hipStreamWaitEvent(st, em->ev_side, 0); } }
-    } join{em, s2, st};
+    hipStream_t s2 = em->side_live ? em->side : st;      // (sfgpu_em_create forked it behind k_tile_build and joins it when the plan is complete)
     {   // phase A's class records (k_pack_build: from the compact stream's 16-bit slots, the plan's rowptr and tile table) and phase C's
         // transcript-major copy with the classes' permuted positions (k_csc_remap)
         const uint64_t C = em->prob.C, Lnz = em->L, S8 = Lnz / 8 + 2 * (uint64_t)nt + 2;      // (a tile's stream is padded to whole chunks of 8)
@@ -2250,18 +2249,31 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             hipLaunchKernelGGL(k_tile_build, dim3(nt), dim3(kBuildBlock), kBuildLds, em->cur, p_rowptr, p_ids, em->tile_c0, em->tile_lo, em->tile_s0, em->tile_esc0,
                                reinterpret_cast<uint16_t*>(em->lstream), em->chdr, em->esc_id, em->esc_cls, em->inv, tmp, kv, idx, tin, chunks);
             EM_TRY(hipGetLastError());
-            int cr = exclusive_scan_u32(chunks, cb, nt, em->cur, false);
+            // From here on the plan runs on TWO streams (round 6): the transcript-major copy of the sweep kernels (two scans, three kernels) and,
+            // in em_persist_plan, the persistent loop's records and chunks go to a side stream; the cover lists, the tile records, the
+            // overlap tables and the far tables stay on this one.  The two join when the plan is complete (below).
+            hipStream_t cs = em->cur;
+            {
+                bool ok = em->side || stream_acquire(&em->side) == hipSuccess;
+                ok = ok && (em->ev_fork || hipEventCreateWithFlags(&em->ev_fork, hipEventDisableTiming) == hipSuccess);
+                ok = ok && (em->ev_side || hipEventCreateWithFlags(&em->ev_side, hipEventDisableTiming) == hipSuccess);
+                ok = ok && (em->ev_td || hipEventCreateWithFlags(&em->ev_td, hipEventDisableTiming) == hipSuccess);
+                ok = ok && hipEventRecord(em->ev_fork, em->cur) == hipSuccess && hipStreamWaitEvent(em->side, em->ev_fork, 0) == hipSuccess;
+                if (ok) { cs = em->side; em->side_live = true; } else (void)hipGetLastError();
+            }
+            scratch.st = cs;
+            int cr = exclusive_scan_u32(chunks, cb, nt, cs, false);
             if (!cr) {
                 EM_TRY(pool_malloc(&pure, (G + 2) * 4)); EM_TRY(pool_malloc(&ps, (G + 3) * 8));
-                EM_TRY(hipMemsetAsync(pure, 0, (G + 2) * 4, em->cur));
-                hipLaunchKernelGGL(k_csc_pure, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, pure);
-                cr = exclusive_scan_u32(pure, ps, G, em->cur, false);
+                EM_TRY(hipMemsetAsync(pure, 0, (G + 2) * 4, cs));
+                hipLaunchKernelGGL(k_csc_pure, dim3(nt), dim3(kEmBlock), 0, cs, kv, idx, tin, cb, pure);
+                cr = exclusive_scan_u32(pure, ps, G, cs, false);
             }
             if (!cr) {
-                hipLaunchKernelGGL(k_csc_offsets, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, cb, ps, em->tile_qb, em->tile_np, em->tile_pr);
+                hipLaunchKernelGGL(k_csc_offsets, dim3((nt + 1 + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, cs, nt, cb, ps, em->tile_qb, em->tile_np, em->tile_pr);
                 EM_TRY(pool_malloc(&em->csc, 32 * (G ? G : 1) + 32));                  // (every chunk mixed: the upper bound)
                 EM_TRY(pool_malloc(&em->csc_slot0, (G + 1) * 2));
-                hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, em->cur, kv, idx, tin, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0, em->null_cls);
+                hipLaunchKernelGGL(k_csc_write, dim3(nt), dim3(kEmBlock), 0, cs, kv, idx, tin, cb, ps, em->tile_qb, em->tile_np, em->csc, em->csc_slot0, em->null_cls);
                 EM_TRY(hipGetLastError());
             }
             if (cr) { em_free(em); return cr; }
@@ -2317,7 +2329,12 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
         }
         EM_TRY(pool_malloc(&em->td, (size_t)nt * sizeof(TileDesc)));
         hipLaunchKernelGGL(k_tile_desc, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, em->cur, nt, em->tile_c0, em->tile_lo, em->tile_span,
-                           em->tile_s0, em->tile_esc0, em->tile_off, em->gather ? em->tile_qb : nullptr, em->tile_np, em->tile_pr, em->td);
+                           em->tile_s0, em->tile_esc0, em->tile_off, (const uint64_t*)nullptr, em->tile_np, em->tile_pr, em->td);
+        if (em->gather) {      // (the copy's fields: behind the records on this stream, behind the copy's offsets on the side stream)
+            hipStream_t cs = em->cur;
+            if (em->side_live) { EM_TRY(hipEventRecord(em->ev_td, em->cur)); EM_TRY(hipStreamWaitEvent(em->side, em->ev_td, 0)); cs = em->side; }
+            hipLaunchKernelGGL(k_tile_desc_csc, dim3((nt + kEmBlock - 1) / kEmBlock), dim3(kEmBlock), 0, cs, nt, em->tile_qb, em->tile_np, em->tile_pr, em->td);
+        }
         EM_TRY(hipGetLastError());
         if (em->gather) {
             // what the FUSED iteration (k_sweep_lds<.., .., true>) needs besides: two slot-major arrays of window sums, two more escape
@@ -2348,6 +2365,7 @@ int sfgpu_em_create(sfgpu_em** out, const sfgpu_problem* prob, sfgpu_stream stre
             {   // the persistent loop's tables (em_persist.h); its verdict rides on the read-back below
                 const int pr = em_persist_plan(em, nt, E, P, p_rowptr);
                 if (pr) { em_free(em); return pr; }
+                if (em->side_live) { EM_TRY(hipEventRecord(em->ev_side, em->side)); EM_TRY(hipStreamWaitEvent(em->cur, em->ev_side, 0)); em->side_live = false; }
                 { void* ps3[3] = {em->kv_tmp, em->idx_tmp, em->tin_tmp}; pool_free_on_many(ps3, 3, em->cur); em->kv_tmp = em->idx_tmp = em->tin_tmp = nullptr; }
             }
             EM_TRY(hipMemcpyAsync(em->h_plan + 4, em->unc + M + 1, 4, hipMemcpyDeviceToHost, em->cur));
