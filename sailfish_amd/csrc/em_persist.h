@@ -28,7 +28,7 @@
 // alpha', the gate and the relative change are formed as in the fused kernel (same additions, same order); x by vb_x_head / a
 // reciprocal (em.hip): the same recurrence, series and exp as the other loops' vb_x_lean / vb_x_fast with the divisions as a reciprocal
 // + two Newton steps -- agreement ~1e-13 relative, not bit identity: a run that falls back to one kernel per iteration (a give-up,
-// several bootstrap lanes) differs from the persistent one at that level, both within 1e-9 of the oracle (tests).  A transcript's alpha
+// several bootstrap lanes) differs from the persistent one at that level, both within 1e-9 of the CPU restatement the tests check against.  A transcript's alpha
 // is read and written by its home thread only and goes to memory at every final update.
 //
 // Every spin is bounded: a tile that waits ~1 s (a block that never became resident: another process holds the CUs) raises the
