@@ -2012,7 +2012,7 @@ static int em_persist_plan(sfgpu_em* em, uint32_t nt, uint64_t E, uint64_t P, co
             hipLaunchKernelGGL(k_pack_build, dim3(nt), dim3(kSweepBlock), lds_slots ? lds_slots * 2u + 16u : 0u, s2, p_rowptr, em->tile_c0, em->tile_s0,
                                reinterpret_cast<const uint16_t*>(em->lstream), em->td, em->esc_cls, em->recs, em->ovc, em->tp, em->cpos, em->esc_cls_p, lds_slots);
         }
-        SF_HIP(pool_malloc(&em->cscp, (Lnz / 8 + 2048ull * nt + (uint64_t)nt + 8) * 16));      // (a tile: at most n8 / 8 + 2046 chunks, one partial chunk per key)
+        SF_HIP(pool_malloc(&em->cscp, (Lnz / 8 + 2112ull * nt + (uint64_t)nt + 8) * 16));      // (a tile: at most n8 / 8 + 2046 chunks, one partial chunk per key)
         hipLaunchKernelGGL(k_cscp_build, dim3(nt), dim3(kSweepBlock), 0, s2, em->td, em->tp, em->cpos, em->kv_tmp, em->idx_tmp, em->tin_tmp, em->tile_s0, em->cscp, em->null_cls);
         SF_CHECK_LAUNCH();
     }

@@ -297,8 +297,17 @@ k_cscp_build(const TileDesc* __restrict__ td, TilePack* tp, const uint32_t* __re
     if (tid == kSweepBlock - 1u) coff[kEscBin] = base;
     __syncthreads();
     const uint32_t nq = coff[kEscBin];
-    const uint32_t q16 = (uint32_t)(tile_s0[T] / 8u) + 2048u * T;          // (a tile of n8 padded nonzeros has at most n8 / 8 + 2046 chunks: one partial chunk per key)
-    if (tid == 0u) { tp[T].nq = nq; tp[T].q16 = q16; }
+    const uint32_t q16 = (uint32_t)(tile_s0[T] / 8u) + 2112u * T;          // (a tile of n8 padded nonzeros has at most n8 / 8 + 2046 chunks: one partial chunk per key; + 63 of the transposition below)
+    // The chunks of a slot follow each other, and thread t of the loop takes chunk t: the lanes of a wavefront would add to ONE accumulator,
+    // and same-address LDS atomics of one instruction serialise (an ablation with plain stores in their place: cfg3 - 1.9 us of a step).  So
+    // the chunks are stored TRANSPOSED: position row * 64 + col holds chunk col * rows + row (rows = ceil(nq / 64)) -- the 64 lanes of a load
+    // get chunks `rows` apart, i.e. of different slots, and the loads stay contiguous.  Positions without a chunk hold null chunks.
+    const uint32_t rows = (nq + 63u) / 64u, nq_pad = rows * 64u;
+    if (tid == 0u) { tp[T].nq = nq_pad; tp[T].q16 = q16; }
+    for (uint32_t j = nq + tid; j < nq_pad; j += kSweepBlock) {
+        const uint32_t n2 = null_cls | (null_cls << 13);
+        cscp[q16 + (j % rows) * 64u + j / rows] = make_uint4(n2, n2 | (1u << 31), n2, n2);      // (singleton bit: adds the sum of its zeros, whatever x is)
+    }
     for (uint32_t j = tid; j < nq; j += kSweepBlock) {
         uint32_t lo = 0, hi = kEscBin;                                   // the last key whose first chunk is <= j (keys without entries share their successor's offset)
         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= j) lo = mid; else hi = mid; }
@@ -308,7 +317,7 @@ k_cscp_build(const TileDesc* __restrict__ td, TilePack* tp, const uint32_t* __re
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k) c[k] = first + k < end ? cpos[c0 + (e[first + k] & 0xFFFFu)] - c0 : null_cls;
         const uint32_t slot = b & 0x3FFu, single = (b & 0x800u) ? 1u : 0u;
-        cscp[q16 + j] = make_uint4(c[0] | (c[1] << 13) | ((slot & 63u) << 26), c[2] | (c[3] << 13) | ((slot >> 6) << 26) | (single << 31), c[4] | (c[5] << 13), c[6] | (c[7] << 13));
+        cscp[q16 + (j % rows) * 64u + j / rows] = make_uint4(c[0] | (c[1] << 13) | ((slot & 63u) << 26), c[2] | (c[3] << 13) | ((slot >> 6) << 26) | (single << 31), c[4] | (c[5] << 13), c[6] | (c[7] << 13));
     }
 }
 
@@ -427,8 +436,17 @@ k_em_persist(PersistArgs a) {
         {
             const TilePack pk = a.tp[blockIdx.x];
             n1 = pk.n1; n2 = pk.n2; n3 = pk.n3; n4 = pk.n4; n_ov = pk.n_ov;
+#ifdef SFGPU_P_NOB4                                                        // dev, timing only: no long classes
+            n4 = 0u; n_ov = 0u;
+#endif
+#ifdef SFGPU_P_NOA                                                         // dev, timing only: phase A without any record
+            n1 = n2 = n3 = n4 = n_ov = 0u;
+#endif
             recs = a.recs + pk.a16; ovcp = a.ovc + pk.ov0;
             np = pk.nq; pure = a.cscp + pk.q16;
+#ifdef SFGPU_P_NOC                                                         // dev, timing only: phase C without any chunk
+            np = 0u;
+#endif
         }
         {   // the count words: on chip for the whole run
             const uint32_t* __restrict__ cnt = a.counts + t.c0;
@@ -773,7 +791,11 @@ k_em_persist(PersistArgs a) {
             auto finish = [&](uint32_t c, double sum) {                          // :260-264; singletons carry the full count :275 / :364
                 const uint32_t cwc = cntl[c];
                 const double cn = (double)(cwc & 0x7FFFFFFFu);
+#ifdef SFGPU_P_NOFIN                                                       // dev, timing only: no division per class
+                den[c] = (cwc >> 31) ? cn : sum;
+#else
                 den[c] = (cwc >> 31) ? cn : ((sum > kTiny) ? cn / sum : 0.0);
+#endif
             };
             if (tid < n1) finish(tid, sum3(ra[0]));
             if (tid + kPB < n1) finish(tid + kPB, sum3(ra[1]));
@@ -823,7 +845,11 @@ k_em_persist(PersistArgs a) {
                 const double sum = ((q0 + q1_) + (q2_ + q3)) + ((q4 + q5) + (q6 + q7));
                 const uint32_t slot = (e4.x >> 26) | (((e4.y >> 26) & 15u) << 6);
                 const double v = (e4.y >> 31) ? sum : xs[slot] * sum;
+#ifdef SFGPU_P_NOATOMC                                                     // dev, timing only: a plain store where phase C adds
+                if (v != 0.0) acc[slot] = v;
+#else
                 if (v != 0.0) atomicAdd(&acc[slot], v);
+#endif
             };
 #pragma unroll
             for (int i = 0; i < kPCAhead; ++i) if (tid + i * kPB < np) pure_chunk(pc_e[i]);

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 {
-echo "=== tests"; timeout 1500 python -m pytest tests/test_gpu_persist.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -5
+echo "=== tests skipped"
 echo "--- product"; EMP_MODES=persist timeout 300 python tools/r5_persist_probe.py 2>&1 | grep -E "==|us/iter" | cut -c1-150
 for name in "$@"; do echo "--- $name"
   SFGPU_LIB_PATH=$PWD/sailfish_amd/csrc/variants/libsfgpu_$name.so EMP_MODES=persist timeout 300 python tools/r5_persist_probe.py 2>&1 | grep -E "us/iter" | cut -c1-150
