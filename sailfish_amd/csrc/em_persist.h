@@ -402,6 +402,11 @@ __device__ __forceinline__ bool gr_ok(const gr4& g, uint32_t tag) { return g.y =
 #else
 #define SFP_IX(i) (i)
 #endif
+#if defined(SFGPU_P_NT_C)                                                  // dev: phase C's chunks with non-temporal loads (do the records then stay in the L2?)
+#define SFP_LDC(p) ([&]() { typedef uint32_t u32x4_ __attribute__((ext_vector_type(4))); const u32x4_ v_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(p)); return make_uint4(v_.x, v_.y, v_.z, v_.w); }())
+#else
+#define SFP_LDC(p) (*(p))
+#endif
 #define SFP_COLD(name) const PersistCold* name = a.cold; asm volatile("" : "+s"(name))
 #define SFP_TILE(name) const TileDesc* name = a.tiles + blockIdx.x; asm volatile("" : "+s"(name))
 template <bool VB>
@@ -441,6 +446,9 @@ k_em_persist(PersistArgs a) {
     {
         const TileDesc t = a.tiles[blockIdx.x];
         lo = t.lo; nc = t.nc; n_esc = t.n_esc; nf = t.nf; off = (uint32_t)t.off; nb_n = t.nb_n; nb_before = t.nb_before;
+#ifdef SFGPU_P_NOFAR                                                       // dev, timing only: no far members (is the tile that has them the one everybody waits for?)
+        n_esc = 0u; nf = 0u;
+#endif
         {
             const TilePack pk = a.tp[blockIdx.x];
             n1 = pk.n1; n2 = pk.n2; n3 = pk.n3; n4 = pk.n4; n_ov = pk.n_ov;
@@ -796,7 +804,7 @@ k_em_persist(PersistArgs a) {
 #pragma unroll
             for (int i = 0; i < kPCAhead; ++i) pc_e[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-            for (int i = 0; i < kPCAhead / 2; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) pc_e[i] = pure[SFP_IX(ch)]; }
+            for (int i = 0; i < kPCAhead / 2; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) pc_e[i] = SFP_LDC(pure + SFP_IX(ch)); }
             // (x of three window slots of a dword; the null slot kWin reads 0)
             auto sum3 = [&](uint32_t w) -> double { return (lds_f64(kLdsXs + ((w << 3) & 0x1FF8u)) + lds_f64(kLdsXs + ((w >> 7) & 0x1FF8u))) + lds_f64(kLdsXs + ((w >> 17) & 0x1FF8u)); };
             auto finish = [&](uint32_t c, double sum) {                          // :260-264; singletons carry the full count :275 / :364
@@ -832,7 +840,7 @@ k_em_persist(PersistArgs a) {
                 }
             }
 #pragma unroll
-            for (int i = kPCAhead / 2; i < kPCAhead; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) pc_e[i] = pure[SFP_IX(ch)]; }
+            for (int i = kPCAhead / 2; i < kPCAhead; ++i) { const uint32_t ch = tid + i * kPB; if (ch < np) pc_e[i] = SFP_LDC(pure + SFP_IX(ch)); }
         }
         __syncthreads();
         SFP_STAMP(3);                                                     // phase A + its barrier
@@ -864,7 +872,7 @@ k_em_persist(PersistArgs a) {
             };
 #pragma unroll
             for (int i = 0; i < kPCAhead; ++i) if (tid + i * kPB < np) pure_chunk(pc_e[i]);
-            for (uint32_t ch = tid + kPCAhead * kPB; ch < np; ch += kPB) pure_chunk(pure[SFP_IX(ch)]);
+            for (uint32_t ch = tid + kPCAhead * kPB; ch < np; ch += kPB) pure_chunk(SFP_LDC(pure + SFP_IX(ch)));
             if (n_esc) {                                                     // far members: into the tile's far slots
                 for (uint32_t i = tid; i < n_esc; i += kPB) {
                     uint2 e;
