@@ -935,12 +935,18 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
     // (profiles/r4_class_build_notes.md).
     const int quad_mode = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_QUAD"); return e ? atoi(e) : 0; }();         // (read per sub-batch: tests switch it)
     const bool quad = !ring && quad_mode != 0 && n_groups == 1 && n_regions >= 2 && n_regions <= kRingMaxRegions && gm.cap <= kRingMaxCap;
+    // the SHARED form of pass 1 (round 6, eqclass_part.h): the blocks of an XCD share one bin per region and reserve a step's granules of a
+    // region with one atomic.  SFGPU_EQ_SHARED=1 selects it (dev builds).
+    const int shared_mode = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_SHARED"); return e ? atoi(e) : 0; }();
+    const bool shared = !ring && !quad && shared_mode != 0 && n_groups == 1 && n_regions >= 2 && n_regions <= (uint32_t)kPartBlock && gm.n_blocks >= 64u;
     const uint32_t n_blocks = gm.n_blocks, tile = gm.tile;
-    const uint64_t cap = gm.cap, n_bins = (uint64_t)grp_n * n_blocks;
+    // (shared: a bin is an XCD's share of the region -- n_blocks / 8 block bins and their slack in one; + 1/8 for XCDs that got more blocks)
+    const uint32_t n_pass2_bins = shared ? kSharedBins : n_blocks;
+    const uint64_t cap = shared ? (((gm.cap * n_blocks / kSharedBins) * 9 / 8 + 7) & ~7ull) : gm.cap, n_bins = (uint64_t)grp_n * n_pass2_bins;
     // positions inside the bins are 31-bit granule indices (bit 31 of a slot's rep marks arena entries)
     SF_REQUIRE(n_bins * cap < (1ull << 31), SFGPU_ERR_RANGE, "partition buffer would exceed 2^31 granules");
     if ((rc = eq->part_words.reserve(n_bins * cap * 4 + 8, st, false))) return rc;
-    if ((rc = eq->part_hist.reserve(4 * n_bins + 1, st, false))) return rc;      // fill of every bin (front, back) + the ring form's cut marks
+    if ((rc = eq->part_hist.reserve(4 * n_bins + 1, st, false))) return rc;      // fill of every bin (front, back) + the ring form's cut marks (shared form: the XCDs' cursors)
     if ((rc = eq->part_long.reserve(cnt, st, false))) return rc;
     if ((rc = eq->deferred_a.reserve(2ull * cnt, st, false))) return rc;
     hipLaunchKernelGGL(k_sub_batch_begin, dim3(1), dim3(64), 0, st, eq->d_ctr, d_offsets, peek[0], peek[1], peek[2], (unsigned long long)eq->n_classes);   // CTR_NEW, CTR_DEFER, long-label counter
@@ -959,7 +965,13 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
                      eq->d_ctr + 3, eq->part_long.p, hot_h, eq->arena.p, eq->table.p, eq->d_ctr + CTR_HOT, eq->mix_mode, grp_lo, grp_n, 0u, 0u};
         if (!ring && !quad && gm.tile_lo) { ra.tile = gm.tile_hi; ra.tile_lo = gm.tile_lo; ra.half = n_blocks / 2; }
 #ifdef SFGPU_VARIANTS
-        if (ring) {
+        if (shared) {
+            ra.gcur = cutmarks; ra.gcut = cutmarks + n_bins;
+            hipLaunchKernelGGL(k_shared_begin, dim3(grid_for(n_bins)), dim3(kBlock), 0, st, ra.gcur, ra.gcut, (uint32_t)n_bins);
+            const size_t route_lds = (size_t)2 * grp_n * 4 + (size_t)kPartWaves * (kStageWords / 4 + 4) * 16 + (size_t)kHotSlots * 12;
+            hipLaunchKernelGGL(k_part_route<kFormShared>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
+            hipLaunchKernelGGL(k_shared_fill, dim3(grid_for(n_bins)), dim3(kBlock), 0, st, ra.gcur, ra.gcut, grp_n, fill_f, fill_b);
+        } else if (ring) {
             const size_t route_lds = (size_t)n_regions * 128 + (size_t)n_regions * 8 + (size_t)kPartWaves * (kRingStageWords / 4 + 4) * 16 + (size_t)kRingHotSlots * 8 +
                                      (size_t)kPartWaves * kRingFlushList * 4;
             static const bool attr_ok = []() {
@@ -981,8 +993,8 @@ static int eq_partitioned(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d
             hipLaunchKernelGGL(k_part_route<kFormDirect>, dim3(n_blocks), dim3(kPartBlock), route_lds, st, ra);
         }
         SF_CHECK_LAUNCH();
-        PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_blocks, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
-                    eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo, 0u, eq->probe.p};
+        PartArgs pa{eq->table.p, bins, fill_f, fill_b, n_pass2_bins, (uint32_t)cap, eq->cls_hash.p, eq->cls_off.p, eq->cls_len.p, eq->cls_slot.p,
+                    eq->arena.p, eq->d_ctr, eq->d_ctr + CTR_ARENA, eq->d_ctr + CTR_GCLS, eq->deferred_a.p, eq->mix_mode, grp_lo, 0u, eq->probe.p, shared ? 1u : 0u};
         static const bool route_only = SF_DEV_ENV("SFGPU_X_ROUTE_ONLY") != nullptr;     // (dev: time pass 1 alone -- its experiment variants leave no valid bins)
         if (!route_only) hipLaunchKernelGGL(k_part_insert, dim3(grp_n), dim3(kPartBlock), 0, st, pa);
         SF_CHECK_LAUNCH();

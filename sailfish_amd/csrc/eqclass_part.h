@@ -122,6 +122,9 @@ struct RouteArgs {
     // take `tile`).  The block dispatched to a CU FIRST runs ~15 % faster than the one that joins it (its wavefronts are the older
     // ones at every issue slot), so equal tiles leave the second half of the launch running alone at the end.
     uint32_t half, tile_lo;
+    // SHARED form (round 6): the blocks of one XCD share ONE bin per region -- bin (xcc, r) of `cap` granules at granule (xcc * grp_n + r) * cap,
+    // front cursor gcur[xcc * grp_n + r] (a block reserves the granules of a whole step with one atomic), first granule that did not fit gcut[..]
+    uint32_t* gcur; uint32_t* gcut;
 };
 
 constexpr uint32_t kCountedBit = 0x80000000u;          // in H: the label is followed by a granule [count, 0, 0, 0]
@@ -169,7 +172,8 @@ __global__ void k_hot_select(const uint64_t* __restrict__ table, uint64_t n_slot
 //   MEASURED SLOWER than the direct form (8.75 vs 8.0 ms per build): the ticket makes a label wait for every earlier label of its
 //   region, in whatever wavefront that is -- the wavefronts of a block no longer run independently.  Off by default, kept with its
 //   parity tests (builder_stress.py switches it) as the record of the attempt.
-constexpr int kFormDirect = 0, kFormRing = 1, kFormQuad = 2;
+constexpr int kFormDirect = 0, kFormRing = 1, kFormQuad = 2, kFormShared = 3;
+constexpr uint32_t kSharedBins = 8;                          // XCDs of the device: bins per region in the shared form
 template <int FORM>
 __global__ void __launch_bounds__(kPartBlock) __attribute__((amdgpu_waves_per_eu(FORM == kFormRing ? 4 : 8, FORM == kFormRing ? 4 : 8)))
 k_part_route(RouteArgs a) {
@@ -177,14 +181,14 @@ k_part_route(RouteArgs a) {
 #ifdef SFGPU_X_EQ_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_eq_stamp[0][0][blockIdx.x] = wall_clock64();
 #endif
-    constexpr bool RING = FORM == kFormRing, QUAD = FORM == kFormQuad, SMALL = FORM != kFormDirect;
+    constexpr bool RING = FORM == kFormRing, QUAD = FORM == kFormQuad, SHARED = FORM == kFormShared, SMALL = RING || QUAD;
     constexpr int SW = SMALL ? kRingStageWords : kStageWords;
     constexpr uint32_t HS = SMALL ? kRingHotSlots : kHotSlots;
     const uint32_t NR = a.grp_n;                   // regions of this launch (= the whole table unless it is built in groups)
     // LDS: [ring: NR x 8 granules] | per region 2 words (RING: {cursors, unit state}; else {cursor, cut}) | staging | hot table
     uint4* ring4 = reinterpret_cast<uint4*>(smem);
     unsigned int* cur = reinterpret_cast<unsigned int*>(smem + (RING ? (size_t)NR * 128u : (QUAD ? (size_t)NR * 48u : 0u)));      // direct: NR: granules taken from my bin of region r
-    unsigned int* cut = cur + NR;                                                     // !RING: NR: first granule of a label that did not fit
+    unsigned int* cut = cur + NR;                                                     // !RING: NR: first granule of a label that did not fit (SHARED: the step's bases)
     uint2* cbst = reinterpret_cast<uint2*>(cur);                                      // RING: NR x {cursors, unit state}; QUAD: NR x {cursors, ticket}
     uint4* mail = reinterpret_cast<uint4*>(smem);                                     // QUAD: NR x 3 granules
     const uint32_t B1 = gridDim.x, blk = blockIdx.x, cap = a.cap, tid = threadIdx.x;
@@ -243,7 +247,9 @@ k_part_route(RouteArgs a) {
         if (RING && r0 + 64u * kPartWaves < t1) offsets(r0 + 64u * kPartWaves, no, noe);
         fetch(__shfl(o, 0, kWave), oe, x0, x1);
     }
-    for (; r0 < t1; r0 += 64u * kPartWaves) {
+    // (SHARED: block barriers inside -- every wavefront takes the same number of steps; one past the tile's end finds no reads)
+    const uint32_t xcc = SHARED ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kSharedBins - 1u)) : 0u;
+    for (uint32_t rb = t0; SHARED ? (rb < t1) : (r0 < t1); r0 += 64u * kPartWaves, rb += 64u * kPartWaves) {
         const uint32_t nr0 = r0 + 64u * kPartWaves;
         // the next step's offsets travel now (ring form, one block per CU: the offsets of the step after it -- the ids of the
         // next step are then requested with offsets that arrived a whole step ago)
@@ -446,8 +452,56 @@ k_part_route(RouteArgs a) {
                     pend = false;
                 }
             }
-        } else if constexpr (!RING) {
+        } else if constexpr (SHARED) {
+            // ---- one reservation per (step of the block, region): the lanes rank their labels with the LDS atomic of the direct form,
+            //      thread r then takes the step's granules of region r out of the XCD's bin with ONE returning atomic, and the labels
+            //      are stored at base + rank.  Neighbouring granules of a bin come from the blocks of one XCD within microseconds of
+            //      each other: the L2 hands whole 64-byte units on (TCC_EA0_WRREQ 0.91 -> 0.33 per read, all of them 64-byte ones).
+            //      Measured (profiles/r6_class_build_notes.md): the pass is no faster for it -- 7.45 against 7.1 ms -- the two barriers
+            //      and the exposed atomic cost 0.65 ms, the stores 2.9 instead of 3.15: what the stores cost is their REQUESTS into the
+            //      L2 (one per label either way), not what leaves it.  A form with one barrier per step (answers used a step later,
+            //      the first granules parked in LDS meanwhile) was slower still: 8.85 ms.
+            uint32_t rank = 0;
+            if (place) rank = atomicAdd(&cur[rg], ngx);
+            __syncthreads();
+            if (tid < NR) {
+                const uint32_t c = cur[tid];
+                if (c) { cut[tid] = atomicAdd(&a.gcur[xcc * NR + tid], c); cur[tid] = 0u; }
+            }
+            __syncthreads();
             if (place) {
+                const uint32_t at = cut[rg] + rank;
+                if (at + ngx <= cap) {
+                    uint4* dst = a.out + (size_t)(xcc * NR + rg) * cap + at;
+#if !defined(SFGPU_X_NOSTORE)
+                    dst[0] = head_granule();
+                    if (mult > 1u) dst[ng] = count_granule();
+                    if (ng > 1u) dst[1] = make_uint4(w[3], w[4], w[5], w[6]);
+                    for (uint32_t g = 2; g < ng; ++g) dst[g] = granule(g);
+#else
+                    if (at == 0xFFFFFFF0u) dst[0] = head_granule();
+#endif
+                } else {
+                    atomicMin(&a.gcut[xcc * NR + rg], at);                                  // the bin ends before this label
+                    generic = true;
+                }
+            }
+        } else if constexpr (!RING) {
+#if defined(SFGPU_X_PAIR)            // experiment (WRONG bins, timing only): the lanes of a group of SFGPU_X_PAIR store their first granules behind the
+                                     // group's first lane's -- runs of that many granules at the alignment a bin's cursor happens to have: what a
+                                     // block-local multisplit could at best make of the stores (requests into the L2 per label: 1 / SFGPU_X_PAIR)
+            unsigned long long d64 = 0ull;
+            if (place) {
+                const uint32_t at = atomicAdd(&cur[rg], ngx);
+                if (at + ngx <= cap) d64 = reinterpret_cast<unsigned long long>(a.out + (size_t)(blk * NR + rg) * cap + at);
+                else { atomicMin(&cut[rg], at); generic = true; }
+            }
+            const unsigned long long l64 = __shfl(d64, (int)(lane & ~(uint32_t)(SFGPU_X_PAIR - 1)), kWave);
+            if (d64 && l64) reinterpret_cast<uint4*>(l64)[lane & (uint32_t)(SFGPU_X_PAIR - 1)] = head_granule();
+            if (false) {
+#else
+            if (place) {
+#endif
                 const uint32_t at = atomicAdd(&cur[rg], ngx);                               // my granules in the bin (rg, blk)
                 if (at + ngx <= cap) {
 #if defined(SFGPU_X_FOLD)            // experiment: every store lands in 1 MB (L2-resident): what do the stores cost WITHOUT the memory behind the L2?
@@ -658,6 +712,8 @@ k_part_route(RouteArgs a) {
             for (uint32_t j = 0; j < (f & 3u); ++j) a.out[(size_t)(blk * NR + r) * cap + (f & ~3u) + j] = mail[r * 3u + j];
             a.fill[r * B1 + blk] = f; a.fill_back[r * B1 + blk] = bk;
         }
+    } else if constexpr (SHARED) {
+        // (the bins' fills are the XCDs' cursors: k_shared_fill, after the launch)
     } else if constexpr (!RING) {
         for (uint32_t r = tid; r < NR; r += kPartBlock) { const unsigned int c = cur[r], x = cut[r]; a.fill[r * B1 + blk] = c < x ? c : x; a.fill_back[r * B1 + blk] = 0u; }
     } else {
@@ -687,6 +743,19 @@ k_part_route(RouteArgs a) {
 #endif
 }
 
+// shared form: cursors of the XCDs' bins before a launch, fills after it (pass 2 sees kSharedBins "blocks")
+__global__ void k_shared_begin(uint32_t* gcur, uint32_t* gcut, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { gcur[i] = 0u; gcut[i] = 0xFFFFFFFFu; }
+}
+__global__ void k_shared_fill(const uint32_t* __restrict__ gcur, const uint32_t* __restrict__ gcut, uint32_t n_regions, uint32_t* fill, uint32_t* fill_back) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;                // = x * n_regions + r
+    if (i >= n_regions * kSharedBins) return;
+    const uint32_t x = i / n_regions, r = i - x * n_regions;
+    const uint32_t c = gcur[i], m = gcut[i];
+    fill[r * kSharedBins + x] = c < m ? c : m; fill_back[r * kSharedBins + x] = 0u;
+}
+
 struct PartArgs {
     uint64_t* table;                       // {word, count} pairs
     const uint4* bins;                     // granules
@@ -704,6 +773,8 @@ struct PartArgs {
                                            // what it counted for hot classes to the same words); 0: plain read-modify-write (nothing else runs)
     uint32_t* probe;                       // slot-indexed copies of the classes' probe granules (4 words per table slot): a region's probes are
                                            // one coalesced 64 KB read (the copies in the arena, found through rep, were 1.6 M scattered reads per launch)
+    uint32_t shared;                       // 1: the bins are the XCDs' (shared form of pass 1): n_blocks = kSharedBins long segments per region, which
+                                           // the wavefronts of the block take in 16 equal slices (a label belongs to the slice that holds its first granule)
 };
 
 // ---- pass 2: one block per region
@@ -751,7 +822,8 @@ k_part_insert(PartArgs a) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // this wavefront's bins: lane t holds the fills of bin wave + 16 t.  A bin is two SEGMENTS of whole labels: [0, fill) and
     // [cap - fill_back, cap); segment t < 64 is the front of bin t, segment 64 + t its back
-    const uint32_t my_bin = wave + kPartWaves * lane;
+    const bool sh = a.shared != 0u;
+    const uint32_t my_bin = sh ? lane : wave + kPartWaves * lane;
     const uint32_t my_fill = (my_bin < a.n_blocks) ? a.fill[region * a.n_blocks + my_bin] : 0u;
     const uint32_t my_back = (my_bin < a.n_blocks) ? a.fill_back[region * a.n_blocks + my_bin] : 0u;
 
@@ -812,7 +884,7 @@ k_part_insert(PartArgs a) {
             if ((back ? vb : vf) <= qq) t = c;
         }
         const uint32_t p0f = __shfl(pf, (int)t, kWave), p0b = __shfl(pb, (int)t, kWave), fb = __shfl(my_back, (int)t, kWave);
-        const uint32_t bin0 = ((wave + kPartWaves * t) * gridDim.x + region) * a.cap;
+        const uint32_t bin0 = ((sh ? t : wave + kPartWaves * t) * gridDim.x + region) * a.cap;
         return back ? bin0 + a.cap - fb + (qq - p0b) : bin0 + (qq - p0f);
     };
     // One label through the region's LDS image.  s = its home slot, key = tag | length, (w0, w1, w2) = the payload of its first
@@ -905,13 +977,15 @@ k_part_insert(PartArgs a) {
         __builtin_amdgcn_wave_barrier();
         qn = 0;
     };
-    uint32_t gpos = 0;                                     // flat index of the step's first granule (wavefront-uniform)
-    uint32_t here = locate(lane < T ? lane : (T ? T - 1u : 0u));      // where this lane's granule sits in the bins (granule index)
+    // (shared bins: this wavefront's slice [lo, hi) of the region's stream -- the labels whose FIRST granule lies in it; a step may read on past hi)
+    const uint32_t lo = sh ? (uint32_t)((uint64_t)T * wave / kPartWaves) : 0u, hi = sh ? (uint32_t)((uint64_t)T * (wave + 1u) / kPartWaves) : T;
+    uint32_t gpos = lo;                                    // flat index of the step's first granule (wavefront-uniform)
+    uint32_t here = locate(lo + lane < T ? lo + lane : (T ? T - 1u : 0u));      // where this lane's granule sits in the bins (granule index)
     uint4 g = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < T) g = a.bins[here];
-    while (gpos < T) {
+    if (lo + lane < T) g = a.bins[here];
+    while (gpos < hi) {
         const uint32_t cnt = (T - gpos < 64u) ? (T - gpos) : 64u;
-        const bool is_head = lane < cnt && (g.x & kHeadBit);
+        const bool is_head = lane < cnt && (g.x & kHeadBit) && gpos + lane < hi;
         const uint32_t H = g.y;
         const uint32_t len = (H >> 24) & 0x7Fu;
         const bool compact = (g.x & kCompactBit) != 0u;       // the whole label is in this granule (first id + 8- or 4-bit steps)

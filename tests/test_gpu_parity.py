@@ -344,7 +344,7 @@ def test_builder_large_host_batch_is_streamed_in_chunks(sf, gpu, monkeypatch, ch
     _assert_same_classes(eq, ob, *oc)
 
 
-@pytest.mark.parametrize("form", ["SFGPU_EQ_RING", "SFGPU_EQ_QUAD"])
+@pytest.mark.parametrize("form", ["SFGPU_EQ_RING", "SFGPU_EQ_QUAD", "SFGPU_EQ_SHARED"])
 def test_builder_ring_form_of_the_route_pass(sf, gpu, monkeypatch, form):
     _needs_variants()
     """SFGPU_EQ_RING=1: pass 1 writes its bins through LDS rings (whole 64-byte units from the front of a bin, long labels and
@@ -354,7 +354,8 @@ def test_builder_ring_form_of_the_route_pass(sf, gpu, monkeypatch, form):
     import torch
     from sailfish_amd import synth
     # (round 4: the same streams through the QUAD form -- single-granule labels written four to a 64-byte unit through per-region
-    #  mailboxes and a ticket; measured slower than the direct form, off by default)
+    #  mailboxes and a ticket; measured slower than the direct form, off by default; round 6: the SHARED form -- the blocks of an XCD
+    #  share one bin per region and reserve a step's granules with one atomic: whole units leave the L2, the pass is no faster)
     monkeypatch.setenv(form, "1")
     rng = np.random.default_rng(12)
     ref_len, ids, off = synth.workload(20000, 150_000, 2_500_000)

@@ -51,8 +51,11 @@ while time.time() < t_end:
     else: os.environ.pop("SFGPU_EQ_SUBBATCH", None)
     pipe = rng.choice(["1", "1", "0"])                             # batches of >= 4 M reads: pipelined partition passes (round 4) or the serial form
     os.environ["SFGPU_EQ_PIPE"] = pipe
-    quad = rng.choice(["1", "1", "0"])                             # tables of <= 1024 regions: the quad form of pass 1 (round 4) or the direct form
+    # tables of <= 1024 regions: the quad form of pass 1 (round 4), the shared form (round 6: XCD-shared bins) or the direct form (STRESS_FORM fixes it)
+    form = os.environ.get("STRESS_FORM") or rng.choice(["quad", "shared", "direct"])
+    quad = "1" if form == "quad" else "0"
     os.environ["SFGPU_EQ_QUAD"] = quad
+    os.environ["SFGPU_EQ_SHARED"] = "1" if form == "shared" else "0"
     eq = sf.EquivalenceClassBuilder(device=dev, expected_classes=int(rng.choice([0, 1000, 5_000_000])))
     eq.start()
     ncut = int(rng.integers(0, 4)); cuts = sorted(set([0, R] + rng.integers(0, R, ncut).tolist()))
@@ -65,7 +68,7 @@ while time.time() < t_end:
     rp, ii, cc, hh = eq.eqVec().to_numpy()
     ok = (eq.n_classes == ob.n_classes and np.array_equal(rp, orp.astype(np.uint32)) and np.array_equal(ii, oi)
           and np.array_equal(cc, oc) and np.array_equal(hh, oh))
-    print(f"M={M} P={P} R={R} kind={kind} shape={shape} sb={sb} pipe={pipe} quad={quad} host={host} cuts={len(cuts)-1}: classes {eq.n_classes} {'ok' if ok else 'MISMATCH'} {eq.stats()}", flush=True)
+    print(f"M={M} P={P} R={R} kind={kind} shape={shape} sb={sb} pipe={pipe} form={form} host={host} cuts={len(cuts)-1}: classes {eq.n_classes} {'ok' if ok else 'MISMATCH'} {eq.stats()}", flush=True)
     if not ok: sys.exit(1)
     n_ok += 1
 print("all ok:", n_ok)
