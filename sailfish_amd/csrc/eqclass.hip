@@ -515,7 +515,12 @@ struct sfgpu_eq {
     hipEvent_t ev_fork = nullptr, ev_hot = nullptr, ev_join = nullptr;
     DevBuf<uint32_t> grid_dev; uint32_t* grid_host = nullptr; uint64_t grid_cap = 0;     // offsets at the sub-batch grid (pinned copy)
     bool settled = false;       // the last partitioned sub-batch returned with the stream waited for and arena_used current
-    bool use_pipe = false;      // SFGPU_EQ_PIPE=1: measured no faster than the serial form (profiles/r4_class_build_notes.md), so not the default
+    // dev builds (SFGPU_EQ_PIPE): how the sub-batches of a large batch are queued (eq_pipeline).  0 (the product): one sub-batch, one host round
+    // trip.  1: route(k + 1) on a second stream NEXT TO insert(k), the host one sub-batch behind (round 4: bit-exact, no faster -- the two
+    // kernels take each other's block slots, profiles/r4_class_build_notes.md).  2: the same queueing on ONE stream -- no kernel overlap, no
+    // idle device between sub-batches (round 6: the 8 round trips of cfg3 are 0.24 ms, and the form is 0.2 ms SLOWER: deciding the
+    // sub-batch sizes one sub-batch late makes one launch pair more, profiles/r6_class_build_notes.md section 4)
+    int pipe_mode = 0;
     uint64_t reads_seen = 0;                // reads added since start()
     uint64_t hot_cap = 0, hot_reads = 0;    // table size and reads_seen when the hot table was last rebuilt
     uint32_t hot_slots = 0;                 // ... and the number of slots it was laid out for
@@ -606,7 +611,7 @@ int sfgpu_eq_create(sfgpu_eq** out, uint64_t expected_classes, sfgpu_stream stre
     eq->expected = expected_classes;
     if (const char* e = getenv("SFGPU_EQ_SUBBATCH")) { long v = atol(e); if (v >= 1024) { eq->sub_batch = (uint32_t)v; eq->part_sub_batch = (uint32_t)v; } }
     if (const char* e = SF_DEV_ENV("SFGPU_EQ_PARTITION")) eq->use_part = atoi(e) != 0;
-    if (const char* e = SF_DEV_ENV("SFGPU_EQ_PIPE")) eq->use_pipe = atoi(e) != 0;
+    if (const char* e = SF_DEV_ENV("SFGPU_EQ_PIPE")) { const int v = atoi(e); eq->pipe_mode = (v >= 0 && v <= 2) ? v : 0; }
     hipError_t e1 = pool_malloc(&eq->d_ctr, CTR_N * sizeof(unsigned long long));
     hipError_t e2 = pinned_malloc(&eq->h_ctr, (CTR_N + 4) * sizeof(unsigned long long));      // (+ 4: scratch for small readbacks)
     if (e1 == hipSuccess) e1 = hipEventCreate(&eq->ev0);
@@ -1052,7 +1057,7 @@ __global__ void k_gather_offsets(const uint32_t* __restrict__ off, uint32_t n_re
 __global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
 __global__ void k_zero_ctr(unsigned long long* ctr) { if (threadIdx.x < (unsigned)CTR_N) ctr[threadIdx.x] = 0ull; }
 
-#ifdef SFGPU_VARIANTS      // (the pipelined form of the partition passes: built, bit-exact, no faster -- profiles/r4_class_build_notes.md section 1)
+#ifdef SFGPU_VARIANTS      // (the pipelined forms of the partition passes: built, bit-exact, no faster -- profiles/r4_class_build_notes.md section 1, r6 section 4)
 static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_offsets, uint32_t n_reads, uint32_t* consumed) {
     *consumed = 0;
     hipStream_t sr = eq->stream;
@@ -1070,7 +1075,7 @@ static int eq_pipeline(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_of
             SF_HIP(hipEventCreateWithFlags(&S.ev_ins, hipEventDisableTiming));
         }
     }
-    hipStream_t si = eq->ins_stream;
+    hipStream_t si = eq->pipe_mode == 2 ? sr : eq->ins_stream;       // (mode 2: everything in the builder's stream, in the order it is queued here)
     // ---- offsets at the grid of possible sub-batch boundaries: one round trip for the whole batch
     const uint32_t g = kScoutReads;
     const uint32_t n_grid = n_reads / g + 2;
@@ -1336,8 +1341,8 @@ static int eq_add_locked(sfgpu_eq* eq, const uint32_t* d_ids, const uint32_t* d_
     uint32_t first0 = 0;
     const bool ring_wanted = []() { const char* e = SF_DEV_ENV("SFGPU_EQ_RING"); return e && atoi(e) != 0; }();
 #ifdef SFGPU_VARIANTS
-    if (part && adaptive && eq->use_pipe && !ring_wanted && n_reads >= (1u << 22)) {
-        // large batches: the sub-batches are pipelined (route(k + 1) next to insert(k), the host one sub-batch behind)
+    if (part && adaptive && eq->pipe_mode != 0 && !ring_wanted && n_reads >= (1u << 22)) {
+        // large batches: the sub-batches are queued ahead of the host (mode 1: route(k + 1) next to insert(k))
         if ((rc = eq_pipeline(eq, d_ids, d_offsets, n_reads, &first0))) return rc;
         if (first0) { scout = false; step = usual_step; }      // (whatever is left takes the serial loop at the usual size)
     }
