@@ -79,7 +79,7 @@ __device__ __forceinline__ void multinomial_chain(Philox& g, uint32_t n, uint32_
     for (uint32_t i = 0; i < k; ++i) {
         if (i == last) continue;
         const double p = prob(i);
-        const double ratio = (p_rem > 0.0) ? p / p_rem : 0.0;
+        const double ratio = (p_rem > 0.0) ? ratio_of(p, p_rem) : 0.0;
         const double pr = ratio < 1.0 ? ratio : 1.0;
         const uint32_t r = (n_rem == 0) ? 0u : (LIGHT ? binomial_by_inversion(g, n_rem, pr) : binomial(g, n_rem, pr));
         p_rem -= p; if (p_rem < 0.0) p_rem = 0.0;

@@ -98,15 +98,31 @@ constexpr uint32_t kBinvPowMax = 1024;
 constexpr double binv_unscale(uint32_t n) { double f = 1.0; for (uint32_t i = 2; i <= n; ++i) f *= (double)i; return 1.0 / f; }
 constexpr double kBinvUnscale = binv_unscale(kBinvSwitch - 1u);      // ~ 1 / 167! (U and F get the same factor: its value does not matter, only that neither leaves the range)
 
+// a / b for the samplers' ratios (b > 0, finite): on the device the reciprocal instruction and two Newton steps instead of the IEEE
+// division sequence (~6 instead of ~15 instructions; the last bit may differ -- the ratio of two weights that are sums of products)
+SF_HD double ratio_of(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SFGPU_X_IEEE_DIV)
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(fma(-b, y, 1.0), y, y);
+    y = fma(fma(-b, y, 1.0), y, y);
+    return a * y;
+#else
+    return a / b;
+#endif
+}
+
 // BINV: Binomial(n, r) for r <= 1/2 and a mean n r < kBinvMaxMean, by walking the CDF from 0 (q = 1 - r)
 SF_HD uint32_t binv(Philox& g, uint32_t n, double r, double q) {
     const double dn = (double)n;
     uint32_t y;
     {
-        const double s = r / q, a = (dn + 1.0) * s;
+        const double s = ratio_of(r, q), a = (dn + 1.0) * s;
         // f_0 = q^n: by squaring for n <= kBinvPowMax (<= 2 log2 n multiplications against ~110 instructions of log1p + exp; the error
         // grows like n ulp / 2 -- 1e-13 at the bound), exp(n log1p(-r)) beyond.  q^n >= e^(-1.39 * 110): no underflow of the result.
         double f0;
+#if defined(SFGPU_X_NOPOW)              // (dev, timing only: what does q^n cost?)
+        if (n != 0xFFFFFFFFu) f0 = q; else
+#endif
         if (n <= kBinvPowMax) {
             f0 = 1.0;
             double b = q;
