@@ -19,8 +19,9 @@ for shape in os.environ.get("EMP_SHAPES", "cfg3,cfg2").split(","):
     for rep in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         p = sf.EMProblem(length, v.rowptr, v.ids, v.counts, eq.total_reads)
+        th = time.perf_counter()                                   # (the host is back: the plan's last kernels are still queued)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         rc, st = p.optimize(use_vbem=True)
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        print(f"  create {1e3 * (t1 - t0):.3f} ms | optimize {1e3 * (t2 - t1):.3f} ms ({st['iters']} iterations, loop {st['loop_ms']:.3f} ms, persistent {int(st.get('persistent', 0))})", flush=True)
+        print(f"  create {1e3 * (t1 - t0):.3f} ms (host back after {1e3 * (th - t0):.3f}) | optimize {1e3 * (t2 - t1):.3f} ms ({st['iters']} iterations, loop {st['loop_ms']:.3f} ms, persistent {int(st.get('persistent', 0))})", flush=True)
         p.close()
